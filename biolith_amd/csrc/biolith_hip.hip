@@ -1,0 +1,658 @@
+// biolith_hip.hip -- host side of the C-ABI in include/biolith_hip.h (+ the small non-templated kernels).
+//
+// Everything numpyro did behind `mcmc.run` (biolith/utils/fit.py:128-130) for the occu model is
+// reached through these entry points.  No CPU fallback exists: without a HIP device every compute
+// entry point returns BL_ERR_NO_DEVICE.
+#include "../../include/biolith_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "logp_kernel.hpp"
+#include "nuts_kernel.hpp"
+
+// ------------------------------------------------------------------ errors ----
+static thread_local std::string g_err;
+static int bl_fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define BL_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return bl_fail(BL_ERR_NO_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),   \
+                           __FILE__, __LINE__);                                                        \
+    } while (0)
+
+// ------------------------------------------- kernel instantiation dispatch ----
+#define BL_K_LIST(X, a) X(a, 1) X(a, 2) X(a, 3) X(a, 4) X(a, 8) X(a, 16)
+#define BL_KK_LIST(X) BL_K_LIST(X, 1) BL_K_LIST(X, 2) BL_K_LIST(X, 3) BL_K_LIST(X, 4) BL_K_LIST(X, 8) BL_K_LIST(X, 16)
+#define BL_DECL(ks, ko)                                                                                        \
+    extern "C" int bl_launch_nuts_##ks##_##ko(const BlNutsParams *, int, int, int, hipStream_t);               \
+    extern "C" int bl_launch_logp_##ks##_##ko(const BlLogpParams *, int, int, int, hipStream_t);
+BL_KK_LIST(BL_DECL)
+
+typedef int (*nuts_launch_fn)(const BlNutsParams *, int, int, int, hipStream_t);
+typedef int (*logp_launch_fn)(const BlLogpParams *, int, int, int, hipStream_t);
+struct KernelEntry {
+    int ks, ko;
+    nuts_launch_fn nuts;
+    logp_launch_fn logp;
+};
+#define BL_ENTRY(ks, ko) {ks, ko, bl_launch_nuts_##ks##_##ko, bl_launch_logp_##ks##_##ko},
+static const KernelEntry g_kernels[] = {BL_KK_LIST(BL_ENTRY)};
+
+static int pad_covs(int k)
+{
+    if (k <= 1) return 1;
+    if (k <= 4) return k;
+    if (k <= 8) return 8;
+    return 16;
+}
+static const KernelEntry *find_kernels(int KS, int KO)
+{
+    for (const auto &e : g_kernels)
+        if (e.ks == KS && e.ko == KO) return &e;
+    return nullptr;
+}
+
+// ------------------------------------------------------------- host RNG ----
+// xoshiro128++ 1.0 with jump(); stream (chain, s) = base advanced by chain*64+s jumps.
+static inline uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+static uint32_t xo_next(uint32_t s[4])
+{
+    const uint32_t result = rotl32(s[0] + s[3], 7) + s[0];
+    const uint32_t t = s[1] << 9;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl32(s[3], 11);
+    return result;
+}
+static void xo_jump(uint32_t s[4])
+{
+    static const uint32_t JUMP[4] = {0x8764000bu, 0xf542d2d3u, 0x6fa035c3u, 0x77f2db5bu};
+    uint32_t t[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; i++)
+        for (int b = 0; b < 32; b++) {
+            if (JUMP[i] & (1u << b)) { t[0] ^= s[0]; t[1] ^= s[1]; t[2] ^= s[2]; t[3] ^= s[3]; }
+            xo_next(s);
+        }
+    memcpy(s, t, sizeof t);
+}
+static uint64_t splitmix64(uint64_t &x)
+{
+    uint64_t z = (x += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+static void rng_streams(uint64_t seed, int chain, int nstreams, uint32_t *out)
+{
+    uint64_t sm = seed;
+    const uint64_t a = splitmix64(sm), b = splitmix64(sm);
+    uint32_t s[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+    if (!(s[0] | s[1] | s[2] | s[3])) s[0] = 1;
+    for (long k = 0; k < (long)chain * BL_RNG_STREAMS_PER_CHAIN; k++) xo_jump(s);
+    for (int k = 0; k < nstreams; k++) {
+        memcpy(out + 4 * k, s, sizeof s);
+        xo_jump(s);
+    }
+}
+
+static int adaptation_schedule(int num_steps, int32_t *starts, int32_t *ends, int cap)
+{
+    // numpyro.infer.hmc_util.build_adaptation_schedule
+    int n = 0;
+    auto push = [&](int s, int e) { if (n < cap) { starts[n] = s; ends[n] = e; } n++; };
+    if (num_steps <= 0) return 0;
+    if (num_steps < 20) { push(0, num_steps - 1); return n; }
+    int start_buffer = 75, end_buffer = 50, init_window = 25;
+    if (start_buffer + end_buffer + init_window > num_steps) {
+        start_buffer = (int)(0.15 * num_steps);
+        end_buffer = (int)(0.1 * num_steps);
+        init_window = num_steps - start_buffer - end_buffer;
+    }
+    push(0, start_buffer - 1);
+    const int end_window_start = num_steps - end_buffer;
+    int next_size = init_window, next_start = start_buffer;
+    while (next_start < end_window_start) {
+        int cur_start = next_start, cur_size = next_size;
+        if (3 * cur_size <= end_window_start - cur_start) next_size = 2 * cur_size;
+        else cur_size = end_window_start - cur_start;
+        next_start = cur_start + cur_size;
+        push(cur_start, next_start - 1);
+    }
+    push(end_window_start, num_steps - 1);
+    return n;
+}
+
+// ----------------------------------------------------------------- handle ----
+struct bl_dataset {
+    int device = 0;
+    bl_dims dims{};
+    int Ks = 0, Ko = 0, KS = 0, KO = 0, D = 0;
+    int n_stride = 0, n_rows = 0;
+    float *d_rows = nullptr;
+    BlDevData dd{};
+    const KernelEntry *kern = nullptr;
+    bl_normal_prior pb{}, pa{};
+    // raw nan_to_num'd obs covariates, site-fastest [V][Ko][n_stride], for prob_detection (lazy upload)
+    std::vector<float> h_wraw;
+    float *d_wraw = nullptr;
+    // ---- last NUTS launch ----
+    bool in_flight = false, have_run = false;
+    int C = 0, S = 0, W = 0, k = 0, nloc = 0, lds_ld = 0, lds_bytes = 0, staged = 0, nvp = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void *d_run = nullptr;  // one slab for all run buffers
+    size_t run_bytes = 0;
+    float *d_draws = nullptr, *d_acc = nullptr, *d_pot = nullptr, *d_eps = nullptr, *d_minv = nullptr, *d_init = nullptr;
+    unsigned char *d_div = nullptr;
+    int *d_steps = nullptr, *d_status = nullptr;
+    long long *d_nleap = nullptr;
+    uint32_t *d_rng = nullptr;
+    unsigned long long *d_xchg = nullptr;
+    size_t xchg_bytes = 0;
+    int *h_abort = nullptr, *d_abort = nullptr;
+};
+
+static int set_device(const bl_dataset *ds)
+{
+    BL_HIP(hipSetDevice(ds->device));
+    return BL_OK;
+}
+
+extern "C" int bl_abi_version(void) { return BL_ABI_VERSION; }
+extern "C" const char *bl_last_error(void) { return g_err.c_str(); }
+
+extern "C" int bl_device_count(int *count)
+{
+    if (!count) return bl_fail(BL_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return bl_fail(BL_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return BL_OK;
+}
+
+extern "C" int bl_rng_streams(uint64_t seed, int chain, int nstreams, uint32_t *out)
+{
+    if (!out || chain < 0 || nstreams < 0) return bl_fail(BL_ERR_INVALID, "bl_rng_streams: bad argument");
+    rng_streams(seed, chain, nstreams, out);
+    return BL_OK;
+}
+
+extern "C" int bl_adaptation_schedule(int num_warmup, int32_t *starts, int32_t *ends, int capacity)
+{
+    if (!starts || !ends || capacity <= 0) return -1;
+    return adaptation_schedule(num_warmup, starts, ends, capacity);
+}
+
+extern "C" int bl_dataset_create(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
+                                 const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha, int device,
+                                 bl_dataset **out)
+{
+    if (!dims || !out) return bl_fail(BL_ERR_INVALID, "dims/out is NULL");
+    *out = nullptr;
+    const int S = dims->n_species, N = dims->n_sites, T = dims->n_periods, J = dims->n_replicates;
+    const int Ks = dims->n_site_covs, Ko = dims->n_obs_covs;
+    // shape checks mirror the asserts at biolith/models/occu.py:103-133
+    if (N <= 0 || T <= 0 || J <= 0 || Ks < 0 || Ko < 0) return bl_fail(BL_ERR_INVALID, "non-positive dimension");
+    if (S != 1)
+        return bl_fail(BL_ERR_UNSUPPORTED, "n_species=%d: this build samples one species per dataset (occu.py:182)", S);
+    if (Ks > BL_MAX_COVS || Ko > BL_MAX_COVS)
+        return bl_fail(BL_ERR_UNSUPPORTED, "more than %d covariates per side (Ks=%d, Ko=%d)", BL_MAX_COVS, Ks, Ko);
+    if ((Ks > 0 && !site_covs) || (Ko > 0 && !obs_covs) || !obs) return bl_fail(BL_ERR_INVALID, "NULL data pointer");
+    const bl_normal_prior pb = prior_beta ? *prior_beta : bl_normal_prior{0.0, 1.0};
+    const bl_normal_prior pa = prior_alpha ? *prior_alpha : bl_normal_prior{0.0, 1.0};
+    if (!(pb.scale > 0.0) || !(pa.scale > 0.0) || !std::isfinite(pb.loc) || !std::isfinite(pa.loc))
+        return bl_fail(BL_ERR_INVALID, "Normal prior needs finite loc and scale > 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return bl_fail(BL_ERR_NO_DEVICE, "no HIP device visible: the occupancy engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return bl_fail(BL_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+
+    bl_dataset *ds = new bl_dataset();
+    ds->device = device; ds->dims = *dims; ds->Ks = Ks; ds->Ko = Ko; ds->D = Ks + Ko + 2;
+    ds->KS = pad_covs(Ks); ds->KO = pad_covs(Ko);
+    ds->kern = find_kernels(ds->KS, ds->KO);
+    ds->pb = pb; ds->pa = pa;
+    if (!ds->kern) { delete ds; return bl_fail(BL_ERR_UNSUPPORTED, "no kernel for capacity (%d,%d)", pad_covs(Ks), pad_covs(Ko)); }
+    const int V = T * J, KS = ds->KS, KO = ds->KO;
+    const int n_stride = (N + 63) / 64 * 64;
+    const int n_rows = KS + V * (KO + 1) + 2 * T;
+    ds->n_stride = n_stride; ds->n_rows = n_rows;
+
+    // ---- pack: mask (occu.py:136-142, modeling.py:15-17), NaN->0, sign folding, site-fastest rows ----
+    std::vector<float> rows((size_t)n_rows * n_stride, 0.0f);
+    ds->h_wraw.assign((size_t)V * (Ko > 0 ? Ko : 1) * n_stride, 0.0f);
+    const double LN2 = 0.69314718055994530942, LOG_TINY = -87.33654475055310898657;
+    const int row_wc = KS, row_ka = KS + V * (KO + 1), row_kb = row_ka + T;
+    for (int i = 0; i < N; i++) {
+        bool site_nan = false;
+        for (int k = 0; k < Ks; k++) {
+            float x = site_covs[(size_t)i * Ks + k];
+            if (std::isnan(x)) { site_nan = true; x = 0.0f; }
+            rows[(size_t)k * n_stride + i] = x;
+        }
+        for (int t = 0; t < T; t++) {
+            int n_masked = 0, n_det = 0;
+            for (int j = 0; j < J; j++) {
+                const int v = t * J + j;
+                const size_t o = ((size_t)i * T + t) * J + j;
+                bool cov_nan = site_nan;
+                float w[BL_MAX_COVS];
+                for (int k = 0; k < Ko; k++) {
+                    float x = obs_covs[o * Ko + k];
+                    if (std::isnan(x)) { cov_nan = true; x = 0.0f; }
+                    w[k] = x;
+                    ds->h_wraw[((size_t)v * Ko + k) * n_stride + i] = x;
+                }
+                const float y = obs[o];
+                float c = 0.0f;
+                if (cov_nan || !std::isfinite(y)) n_masked++;
+                else if (y != 0.0f) { c = 1.0f; n_det++; }
+                else c = -1.0f;
+                const size_t r0 = (size_t)(row_wc + v * (KO + 1));
+                rows[r0 * n_stride + i] = c;
+                for (int k = 0; k < Ko; k++) rows[(r0 + 1 + k) * n_stride + i] = c * w[k];
+            }
+            rows[(size_t)(row_ka + t) * n_stride + i] = (float)(n_masked * LN2);
+            rows[(size_t)(row_kb + t) * n_stride + i] = (float)(n_det * LOG_TINY);
+        }
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc((void **)&ds->d_rows, rows.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(ds->d_rows, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&ds->h_abort, 64, hipHostMallocMapped);
+    if (e == hipSuccess) { *ds->h_abort = 0; e = hipHostGetDevicePointer((void **)&ds->d_abort, ds->h_abort, 0); }
+    if (e == hipSuccess) e = hipEventCreate(&ds->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ds->ev1);
+    if (e != hipSuccess) {
+        const int rc = bl_fail(BL_ERR_NO_DEVICE, "dataset upload failed: %s", hipGetErrorString(e));
+        bl_dataset_destroy(ds);
+        return rc;
+    }
+    BlDevData &dd = ds->dd;
+    dd.rows = ds->d_rows; dd.n_sites = N; dd.n_stride = n_stride; dd.T = T; dd.J = J;
+    dd.Ks = Ks; dd.Ko = Ko; dd.KS = KS; dd.KO = KO;
+    dd.loc_b = (float)pb.loc; dd.isc2_b = (float)(1.0 / (pb.scale * pb.scale));
+    dd.loc_a = (float)pa.loc; dd.isc2_a = (float)(1.0 / (pa.scale * pa.scale));
+    dd.prior_const = (Ks + 1) * std::log(pb.scale) + (Ko + 1) * std::log(pa.scale) + ds->D * 0.91893853320467274178;
+    *out = ds;
+    return BL_OK;
+}
+
+extern "C" int bl_dataset_destroy(bl_dataset *ds)
+{
+    if (!ds) return BL_OK;
+    hipSetDevice(ds->device);
+    if (ds->in_flight) { *ds->h_abort = 1; hipStreamSynchronize(ds->stream); }
+    if (ds->d_rows) hipFree(ds->d_rows);
+    if (ds->d_wraw) hipFree(ds->d_wraw);
+    if (ds->d_run) hipFree(ds->d_run);
+    if (ds->d_xchg) hipFree(ds->d_xchg);
+    if (ds->h_abort) hipHostFree(ds->h_abort);
+    if (ds->ev0) hipEventDestroy(ds->ev0);
+    if (ds->ev1) hipEventDestroy(ds->ev1);
+    delete ds;
+    return BL_OK;
+}
+
+extern "C" int bl_dataset_param_dim(const bl_dataset *ds, int *D)
+{
+    if (!ds || !D) return bl_fail(BL_ERR_INVALID, "NULL argument");
+    *D = ds->D;
+    return BL_OK;
+}
+
+// Workgroups per chain / LDS staging decision.  One site per thread is the latency optimum
+// (DESIGN.md "geometry"); fall back to several sites per thread, then to un-staged HBM rows.
+static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k_out, int *nloc_out, int *ld_out,
+                            int *lds_bytes_out, int *staged_out)
+{
+    const int N = ds->dims.n_sites;
+    int kmax = 256 / (chains > 0 ? chains : 1);
+    if (kmax < 1) kmax = 1;
+    if (kmax > 64) kmax = 64;
+    int k = want_k > 0 ? want_k : (N + BL_THREADS - 1) / BL_THREADS;
+    if (k > kmax) k = kmax;
+    if (k < 1) k = 1;
+    const int lds_cap = BL_LDS_TOTAL - BL_OFF_DATA;
+    auto fits = [&](int kk, int *nloc, int *ld) {
+        *nloc = (N + kk - 1) / kk;
+        *ld = (*nloc + 31) / 32 * 32;
+        return (long long)ds->n_rows * *ld * 4 <= lds_cap;
+    };
+    int nloc, ld;
+    bool ok = fits(k, &nloc, &ld);
+    if (!ok && want_k <= 0)
+        for (int kk = k + 1; kk <= kmax && !ok; kk++) { ok = fits(kk, &nloc, &ld); if (ok) k = kk; }
+    if (!ok) fits(k, &nloc, &ld);
+    *k_out = k; *nloc_out = nloc; *ld_out = ld; *staged_out = ok ? 1 : 0;
+    *lds_bytes_out = ok ? BL_OFF_DATA + ds->n_rows * ld * 4 : BL_OFF_DATA;
+}
+
+// ------------------------------------------------------------- K1 logp ----
+__global__ void bl_logp_final_kernel(BlDevData dd, int k, const double *theta, const double *partial, double *U, double *grad)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int D = dd.Ks + dd.Ko + 2;
+    double acc = 0.0;
+    if (lane <= D)
+        for (int m = 0; m < k; m++) acc += partial[((size_t)b * k + m) * 64 + lane];
+    double pr = 0.0;
+    if (lane < D) {
+        const bool is_b = lane <= dd.Ks;
+        const double loc = is_b ? dd.loc_b : dd.loc_a, isc2 = is_b ? dd.isc2_b : dd.isc2_a;
+        const double dth = theta[(size_t)b * D + lane] - loc;
+        pr = 0.5 * dth * dth * isc2;
+        grad[(size_t)b * D + lane] = -acc + dth * isc2;
+    }
+    const double prior = bl_wave_sum_d(pr);
+    if (lane == D) U[b] = -acc + prior + dd.prior_const;
+}
+
+extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *U, double *grad, int staged)
+{
+    if (!ds || !theta || !U || !grad || B <= 0) return bl_fail(BL_ERR_INVALID, "bl_logp_grad: bad argument");
+    if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
+    int rc = set_device(ds);
+    if (rc) return rc;
+    const int D = ds->D;
+    int k, nloc, ld, lds_bytes, can_stage;
+    choose_geometry(ds, 1, 0, &k, &nloc, &ld, &lds_bytes, &can_stage);
+    const int use_staged = staged && can_stage;
+    if (!use_staged) lds_bytes = BL_OFF_DATA;
+    std::vector<float> th32((size_t)B * D);
+    for (size_t i = 0; i < th32.size(); i++) th32[i] = (float)theta[i];
+    float *d_th32 = nullptr;
+    double *d_th = nullptr, *d_partial = nullptr, *d_U = nullptr, *d_grad = nullptr;
+    BL_HIP(hipMalloc((void **)&d_th32, th32.size() * 4));
+    BL_HIP(hipMalloc((void **)&d_th, (size_t)B * D * 8));
+    BL_HIP(hipMalloc((void **)&d_partial, (size_t)B * k * 64 * 8));
+    BL_HIP(hipMalloc((void **)&d_U, (size_t)B * 8));
+    BL_HIP(hipMalloc((void **)&d_grad, (size_t)B * D * 8));
+    BL_HIP(hipMemcpy(d_th32, th32.data(), th32.size() * 4, hipMemcpyHostToDevice));
+    BL_HIP(hipMemcpy(d_th, theta, (size_t)B * D * 8, hipMemcpyHostToDevice));
+    BL_HIP(hipMemset(d_partial, 0, (size_t)B * k * 64 * 8));
+    BlLogpParams p{};
+    p.dd = ds->dd; p.k = k; p.nloc = nloc; p.lds_ld = ld; p.n_rows = ds->n_rows; p.B = B; p.theta = d_th32; p.partial = d_partial;
+    const int lrc = ds->kern->logp(&p, k, lds_bytes, use_staged, nullptr);
+    if (lrc != 0) return bl_fail(BL_ERR_NO_DEVICE, "logp kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    hipLaunchKernelGGL(bl_logp_final_kernel, dim3(B), dim3(64), 0, nullptr, ds->dd, k, d_th, d_partial, d_U, d_grad);
+    BL_HIP(hipGetLastError());
+    BL_HIP(hipMemcpy(U, d_U, (size_t)B * 8, hipMemcpyDeviceToHost));
+    BL_HIP(hipMemcpy(grad, d_grad, (size_t)B * D * 8, hipMemcpyDeviceToHost));
+    hipFree(d_th32); hipFree(d_th); hipFree(d_partial); hipFree(d_U); hipFree(d_grad);
+    return BL_OK;
+}
+
+// ------------------------------------------------------------------- NUTS ----
+static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *stream)
+{
+    if (!ds || !cfg) return bl_fail(BL_ERR_INVALID, "NULL argument");
+    if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is already in flight on this handle");
+    const int C = cfg->num_chains, S = cfg->num_samples, W = cfg->num_warmup, D = ds->D;
+    if (C <= 0 || S < 0 || W < 0 || S + W <= 0) return bl_fail(BL_ERR_INVALID, "num_chains/num_samples/num_warmup out of range");
+    if (C > 256) return bl_fail(BL_ERR_UNSUPPORTED, "num_chains=%d > 256 per device launch", C);
+    const int max_depth = cfg->max_tree_depth > 0 ? cfg->max_tree_depth : 10;
+    if (max_depth > BL_MAX_DEPTH) return bl_fail(BL_ERR_INVALID, "max_tree_depth > %d", BL_MAX_DEPTH);
+    if (cfg->chain_offset < 0) return bl_fail(BL_ERR_INVALID, "chain_offset < 0");
+    int rc = set_device(ds);
+    if (rc) return rc;
+
+    int k, nloc, ld, lds_bytes, staged;
+    choose_geometry(ds, C, cfg->wgs_per_chain, &k, &nloc, &ld, &lds_bytes, &staged);
+    const int nvp = (D + 3 <= 16) ? 16 : (D + 3 <= 32 ? 32 : 64);
+
+    // ---- (re)allocate run slab ----
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
+    const size_t Sa = S > 0 ? S : 1;
+    const size_t o_draws = carve((size_t)C * Sa * D * 4), o_div = carve((size_t)C * Sa), o_steps = carve((size_t)C * Sa * 4),
+                 o_acc = carve((size_t)C * Sa * 4), o_pot = carve((size_t)C * Sa * 4), o_eps = carve((size_t)C * 4),
+                 o_minv = carve((size_t)C * D * 4), o_nleap = carve((size_t)C * 16), o_status = carve(16),
+                 o_rng = carve((size_t)C * BL_RNG_STREAMS_PER_CHAIN * 16), o_init = carve((size_t)C * D * 4);
+    if (off > ds->run_bytes) {
+        if (ds->d_run) hipFree(ds->d_run);
+        ds->d_run = nullptr; ds->run_bytes = 0;
+        BL_HIP(hipMalloc(&ds->d_run, off));
+        ds->run_bytes = off;
+    }
+    char *base = (char *)ds->d_run;
+    ds->d_draws = (float *)(base + o_draws); ds->d_div = (unsigned char *)(base + o_div); ds->d_steps = (int *)(base + o_steps);
+    ds->d_acc = (float *)(base + o_acc); ds->d_pot = (float *)(base + o_pot); ds->d_eps = (float *)(base + o_eps);
+    ds->d_minv = (float *)(base + o_minv); ds->d_nleap = (long long *)(base + o_nleap); ds->d_status = (int *)(base + o_status);
+    ds->d_rng = (uint32_t *)(base + o_rng); ds->d_init = (float *)(base + o_init);
+    const size_t xb = align256((size_t)C * 2 * k * nvp * 8);
+    if (xb > ds->xchg_bytes) {
+        if (ds->d_xchg) hipFree(ds->d_xchg);
+        ds->d_xchg = nullptr; ds->xchg_bytes = 0;
+        BL_HIP(hipMalloc((void **)&ds->d_xchg, xb));
+        ds->xchg_bytes = xb;
+    }
+
+    hipStream_t st = (hipStream_t)stream;
+    // ---- inputs: RNG streams (host-jumped), optional init ----
+    std::vector<uint32_t> rs((size_t)C * BL_RNG_STREAMS_PER_CHAIN * 4);
+    for (int c = 0; c < C; c++)
+        rng_streams(cfg->seed, cfg->chain_offset + c, BL_RNG_STREAMS_PER_CHAIN, rs.data() + (size_t)c * BL_RNG_STREAMS_PER_CHAIN * 4);
+    BL_HIP(hipMemcpyAsync(ds->d_rng, rs.data(), rs.size() * 4, hipMemcpyHostToDevice, st));
+    if (cfg->init_theta) {
+        std::vector<float> it32((size_t)C * D);
+        for (size_t i = 0; i < it32.size(); i++) it32[i] = (float)cfg->init_theta[i];
+        BL_HIP(hipMemcpyAsync(ds->d_init, it32.data(), it32.size() * 4, hipMemcpyHostToDevice, st));
+    }
+    BL_HIP(hipStreamSynchronize(st)); // staging vectors die with this scope
+    *ds->h_abort = 0;
+
+    BlNutsParams p{};
+    p.dd = ds->dd;
+    p.num_warmup = W; p.num_samples = S; p.num_chains = C;
+    p.k = k; p.nloc = nloc; p.lds_ld = ld; p.n_rows = ds->n_rows; p.nvp = nvp;
+    p.max_depth = max_depth;
+    p.target_accept = (float)(cfg->target_accept > 0.0 ? cfg->target_accept : 0.8);
+    int32_t ws[32], we[32];
+    p.nwin = adaptation_schedule(W, ws, we, 32);
+    if (p.nwin > 32) return bl_fail(BL_ERR_INVALID, "adaptation schedule too long");
+    for (int i = 0; i < 32; i++) p.win_end[i] = i < p.nwin ? we[i] : 0x7fffffff;
+    p.rng = ds->d_rng;
+    p.init_theta = cfg->init_theta ? ds->d_init : nullptr;
+    p.xchg = ds->d_xchg;
+    p.abort_flag = ds->d_abort;
+    p.spin_limit = 1u << 18;
+    p.draws = ds->d_draws; p.diverging = ds->d_div; p.num_steps = ds->d_steps; p.accept_prob = ds->d_acc;
+    p.potential = ds->d_pot; p.step_size = ds->d_eps; p.inv_mass = ds->d_minv; p.nleap = ds->d_nleap; p.status = ds->d_status;
+
+    // timed region: state re-init (guide G16 "re-initialise every call") + the persistent kernel
+    BL_HIP(hipEventRecord(ds->ev0, st));
+    BL_HIP(hipMemsetAsync(ds->d_xchg, 0, xb, st));
+    BL_HIP(hipMemsetAsync(ds->d_status, 0, 16, st));
+    const int lrc = ds->kern->nuts(&p, C * k, lds_bytes, staged, st);
+    if (lrc != 0) return bl_fail(BL_ERR_NO_DEVICE, "NUTS kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    BL_HIP(hipEventRecord(ds->ev1, st));
+    ds->stream = st; ds->in_flight = true; ds->have_run = true;
+    ds->C = C; ds->S = S; ds->W = W; ds->k = k; ds->nloc = nloc; ds->lds_ld = ld; ds->lds_bytes = lds_bytes; ds->staged = staged; ds->nvp = nvp;
+    return BL_OK;
+}
+
+extern "C" int bl_nuts_poll(bl_dataset *ds, int *done)
+{
+    if (!ds || !done) return bl_fail(BL_ERR_INVALID, "NULL argument");
+    if (!ds->in_flight) { *done = 1; return BL_OK; }
+    hipSetDevice(ds->device);
+    hipError_t e = hipEventQuery(ds->ev1);
+    if (e == hipSuccess) { *done = 1; return BL_OK; }
+    if (e == hipErrorNotReady) { *done = 0; return BL_OK; }
+    return bl_fail(BL_ERR_NO_DEVICE, "hipEventQuery: %s", hipGetErrorString(e));
+}
+
+extern "C" int bl_nuts_abort(bl_dataset *ds)
+{
+    if (!ds) return bl_fail(BL_ERR_INVALID, "NULL argument");
+    if (ds->h_abort) __atomic_store_n(ds->h_abort, 1, __ATOMIC_SEQ_CST);
+    return BL_OK;
+}
+
+extern "C" int bl_nuts_wait(bl_dataset *ds)
+{
+    if (!ds) return bl_fail(BL_ERR_INVALID, "NULL argument");
+    if (!ds->have_run) return bl_fail(BL_ERR_INVALID, "no NUTS launch on this handle");
+    int rc = set_device(ds);
+    if (rc) return rc;
+    if (ds->in_flight) {
+        BL_HIP(hipEventSynchronize(ds->ev1));
+        ds->in_flight = false;
+    }
+    int status = 0;
+    BL_HIP(hipMemcpy(&status, ds->d_status, 4, hipMemcpyDeviceToHost));
+    if (status == BL_ERR_TIMEOUT) return bl_fail(BL_ERR_TIMEOUT, "in-kernel exchange spin bound hit (a workgroup was not resident?)");
+    if (status == BL_ERR_ABORTED) return bl_fail(BL_ERR_ABORTED, "sampling aborted on request");
+    if (status != 0) return bl_fail(BL_ERR_NO_DEVICE, "kernel reported status %d", status);
+    return BL_OK;
+}
+
+extern "C" int bl_nuts_fetch(bl_dataset *ds, bl_nuts_output *out)
+{
+    if (!ds || !out) return bl_fail(BL_ERR_INVALID, "NULL argument");
+    if (!ds->have_run || ds->in_flight) return bl_fail(BL_ERR_BUSY, "no finished NUTS launch to fetch");
+    int rc = set_device(ds);
+    if (rc) return rc;
+    const size_t C = ds->C, S = ds->S, D = ds->D;
+    if (out->draws && S) BL_HIP(hipMemcpy(out->draws, ds->d_draws, C * S * D * 4, hipMemcpyDeviceToHost));
+    if (out->diverging && S) BL_HIP(hipMemcpy(out->diverging, ds->d_div, C * S, hipMemcpyDeviceToHost));
+    if (out->num_steps && S) BL_HIP(hipMemcpy(out->num_steps, ds->d_steps, C * S * 4, hipMemcpyDeviceToHost));
+    if (out->accept_prob && S) BL_HIP(hipMemcpy(out->accept_prob, ds->d_acc, C * S * 4, hipMemcpyDeviceToHost));
+    if (out->potential_energy && S) BL_HIP(hipMemcpy(out->potential_energy, ds->d_pot, C * S * 4, hipMemcpyDeviceToHost));
+    if (out->step_size) BL_HIP(hipMemcpy(out->step_size, ds->d_eps, C * 4, hipMemcpyDeviceToHost));
+    if (out->inv_mass) BL_HIP(hipMemcpy(out->inv_mass, ds->d_minv, C * D * 4, hipMemcpyDeviceToHost));
+    if (out->n_leapfrog) BL_HIP(hipMemcpy(out->n_leapfrog, ds->d_nleap, C * 16, hipMemcpyDeviceToHost));
+    return BL_OK;
+}
+
+extern "C" int bl_nuts_run(bl_dataset *ds, const bl_nuts_config *cfg, bl_nuts_output *out)
+{
+    int rc = bl_nuts_launch(ds, cfg, nullptr);
+    if (rc) return rc;
+    rc = bl_nuts_wait(ds);
+    if (rc) return rc;
+    return out ? bl_nuts_fetch(ds, out) : BL_OK;
+}
+
+extern "C" int bl_nuts_elapsed_ms(bl_dataset *ds, float *ms)
+{
+    if (!ds || !ms) return bl_fail(BL_ERR_INVALID, "NULL argument");
+    if (!ds->have_run || ds->in_flight) return bl_fail(BL_ERR_BUSY, "no finished NUTS launch");
+    BL_HIP(hipEventElapsedTime(ms, ds->ev0, ds->ev1));
+    return BL_OK;
+}
+
+extern "C" int bl_nuts_device_draws(bl_dataset *ds, void **dev_ptr, size_t *bytes)
+{
+    if (!ds || !dev_ptr || !bytes) return bl_fail(BL_ERR_INVALID, "NULL argument");
+    if (!ds->have_run) return bl_fail(BL_ERR_INVALID, "no NUTS launch on this handle");
+    *dev_ptr = ds->d_draws;
+    *bytes = (size_t)ds->C * ds->S * ds->D * 4;
+    return BL_OK;
+}
+
+extern "C" int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads_per_wg, int *lds_bytes, int *lds_staged)
+{
+    if (!ds) return bl_fail(BL_ERR_INVALID, "NULL argument");
+    if (!ds->have_run) return bl_fail(BL_ERR_INVALID, "no NUTS launch on this handle");
+    if (wgs_per_chain) *wgs_per_chain = ds->k;
+    if (threads_per_wg) *threads_per_wg = BL_THREADS;
+    if (lds_bytes) *lds_bytes = ds->lds_bytes;
+    if (lds_staged) *lds_staged = ds->staged;
+    return BL_OK;
+}
+
+// ------------------------------------------------- deterministic sites ----
+// psi[n][t][i] = sigmoid(beta0 + x_i . beta)      (occu.py:198-207; constant over t)
+__global__ void bl_psi_kernel(const float *__restrict__ rows, int n_stride, int N, int T, int Ks, int D,
+                              const float *__restrict__ draws, int n0, int n1, float *__restrict__ psi)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float x[BL_MAX_COVS];
+    for (int k = 0; k < Ks; k++) x[k] = rows[(size_t)k * n_stride + i];
+    for (int n = n0 + blockIdx.y; n < n1; n += gridDim.y) {
+        const float *th = draws + (size_t)n * D;
+        float eta = th[0];
+        for (int k = 0; k < Ks; k++) eta = fmaf(x[k], th[k + 1], eta);
+        const float v = 1.0f / (1.0f + __expf(-eta));
+        for (int t = 0; t < T; t++) psi[((size_t)(n - n0) * T + t) * N + i] = v;
+    }
+}
+// prob_detection[n][j][t][i] = sigmoid(alpha0 + w_itj . alpha)   (occu.py:221-228)
+__global__ void bl_pdet_kernel(const float *__restrict__ wraw, int n_stride, int N, int T, int J, int Ks, int Ko, int D,
+                               const float *__restrict__ draws, int n0, int n1, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    for (int n = n0 + blockIdx.y; n < n1; n += gridDim.y) {
+        const float *al = draws + (size_t)n * D + Ks + 1;
+        for (int t = 0; t < T; t++)
+            for (int j = 0; j < J; j++) {
+                const int v = t * J + j;
+                float nu = al[0];
+                for (int k = 0; k < Ko; k++) nu = fmaf(wraw[((size_t)v * Ko + k) * n_stride + i], al[k + 1], nu);
+                out[(((size_t)(n - n0) * J + j) * T + t) * N + i] = 1.0f / (1.0f + __expf(-nu));
+            }
+    }
+}
+
+extern "C" int bl_deterministic(bl_dataset *ds, int n_draws, const float *draws, float *psi, float *prob_detection)
+{
+    if (!ds || !draws || n_draws <= 0) return bl_fail(BL_ERR_INVALID, "bl_deterministic: bad argument");
+    if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
+    int rc = set_device(ds);
+    if (rc) return rc;
+    const int N = ds->dims.n_sites, T = ds->dims.n_periods, J = ds->dims.n_replicates, D = ds->D;
+    float *d_draws = nullptr, *d_out = nullptr;
+    BL_HIP(hipMalloc((void **)&d_draws, (size_t)n_draws * D * 4));
+    BL_HIP(hipMemcpy(d_draws, draws, (size_t)n_draws * D * 4, hipMemcpyHostToDevice));
+    // chunk the draws so the device staging buffer stays <= 256 MiB
+    const size_t per_draw = (size_t)T * N * 4 * (prob_detection ? (size_t)J : 1);
+    int chunk = (int)((256u << 20) / (per_draw ? per_draw : 1));
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_draws) chunk = n_draws;
+    BL_HIP(hipMalloc((void **)&d_out, (size_t)chunk * per_draw));
+    if (prob_detection && !ds->d_wraw) {
+        BL_HIP(hipMalloc((void **)&ds->d_wraw, ds->h_wraw.size() * 4));
+        BL_HIP(hipMemcpy(ds->d_wraw, ds->h_wraw.data(), ds->h_wraw.size() * 4, hipMemcpyHostToDevice));
+    }
+    const dim3 block(256);
+    for (int n0 = 0; n0 < n_draws; n0 += chunk) {
+        const int n1 = (n0 + chunk < n_draws) ? n0 + chunk : n_draws;
+        const dim3 grid((N + 255) / 256, (n1 - n0) < 1024 ? (n1 - n0) : 1024);
+        if (psi) {
+            hipLaunchKernelGGL(bl_psi_kernel, grid, block, 0, nullptr, ds->d_rows, ds->n_stride, N, T, ds->Ks, D, d_draws, n0, n1, d_out);
+            BL_HIP(hipGetLastError());
+            BL_HIP(hipMemcpy(psi + (size_t)n0 * T * N, d_out, (size_t)(n1 - n0) * T * N * 4, hipMemcpyDeviceToHost));
+        }
+        if (prob_detection) {
+            hipLaunchKernelGGL(bl_pdet_kernel, grid, block, 0, nullptr, ds->d_wraw, ds->n_stride, N, T, J, ds->Ks, ds->Ko, D, d_draws, n0, n1, d_out);
+            BL_HIP(hipGetLastError());
+            BL_HIP(hipMemcpy(prob_detection + (size_t)n0 * J * T * N, d_out, (size_t)(n1 - n0) * J * T * N * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    hipFree(d_draws); hipFree(d_out);
+    return BL_OK;
+}

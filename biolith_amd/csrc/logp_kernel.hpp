@@ -1,0 +1,64 @@
+// logp_kernel.hpp -- K1: batched occupancy log-density + gradient (parity hook behind bl_logp_grad).
+// Uses exactly the device functions the persistent NUTS kernel uses (same LDS staging, same
+// per-site arithmetic, same wave/workgroup reduction order), one launch per batch.
+#pragma once
+#include "occu_device.hpp"
+
+struct BlLogpParams {
+    BlDevData dd;
+    int k, nloc, lds_ld, n_rows;
+    int B;
+    const float *theta;  // [B][D] float32 view of the caller's double theta
+    double *partial;     // [B][k][64]: c < D grad of log-lik, c == D log-lik
+};
+
+template <int KS, int KO, bool LDS>
+__global__ void __launch_bounds__(BL_THREADS) bl_logp_kernel(const BlLogpParams p)
+{
+    const int member = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int Ks = p.dd.Ks, Ko = p.dd.Ko, D = Ks + Ko + 2;
+    const int s0 = member * p.nloc;
+    int cnt = p.dd.n_sites - s0;
+    cnt = cnt < 0 ? 0 : (cnt > p.nloc ? p.nloc : cnt);
+    const float *grows;
+    int ld;
+    if constexpr (LDS) {
+        bl_stage_rows(p.dd.rows, p.n_rows, p.dd.n_stride, s0, cnt, p.lds_ld);
+        grows = nullptr;
+        ld = p.lds_ld;
+    } else {
+        grows = p.dd.rows + s0;
+        ld = p.dd.n_stride;
+    }
+    float *sh_theta = bl_lds_f(BL_OFF_THETA);
+    for (int b = 0; b < p.B; b++) {
+        if (wave == 0) sh_theta[lane] = lane < D ? p.theta[(size_t)b * D + lane] : 0.0f;
+        __syncthreads();
+        float beta[KS + 1], alpha[KO + 1];
+        bl_load_coefs<KS, KO>(sh_theta, Ks, Ko, beta, alpha);
+        float ll = 0.0f, gb[KS + 1], ga[KO + 1];
+#pragma unroll
+        for (int k = 0; k <= KS; k++) gb[k] = 0.0f;
+#pragma unroll
+        for (int k = 0; k <= KO; k++) ga[k] = 0.0f;
+        bl_eval_sites<KS, KO, LDS>(grows, ld, cnt, p.dd.T, p.dd.J, beta, alpha, ll, gb, ga);
+        bl_wave_partials_to_lds<KS, KO>(Ks, Ko, ll, gb, ga);
+        __syncthreads();
+        if (wave == 0) {
+            const float *part = bl_lds_f(BL_OFF_PART);
+            const double *pll = bl_lds_d(BL_OFF_LL);
+            float g = 0.0f;
+            double llwg = 0.0;
+#pragma unroll
+            for (int w = 0; w < BL_WAVES; w++) {
+                g += lane < D ? part[w * 64 + lane] : 0.0f;
+                llwg += pll[w];
+            }
+            double *out = p.partial + ((size_t)b * p.k + member) * 64;
+            if (lane < D) out[lane] = (double)g;
+            if (lane == D) out[lane] = llwg;
+        }
+        __syncthreads();
+    }
+}

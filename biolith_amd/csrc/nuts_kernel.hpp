@@ -1,0 +1,369 @@
+// nuts_kernel.hpp -- persistent multi-CU NUTS kernel (one launch = all chains, warmup + sampling).
+//
+// Replaces numpyro.infer.MCMC(NUTS(occu)).run(...) as biolith/utils/fit.py:92-130 invokes it.
+// The sampler follows NumPyro's algorithm: iterative tree doubling with
+// checkpointed generalised U-turn checks, multinomial proposals (uniform inside a subtree, biased
+// between subtrees), dual-averaging step size, windowed Welford diagonal mass matrix.
+//
+// Mapping to the chip
+//   * one chain = k cooperating workgroups (512 threads each, ~1 per CU); a workgroup owns a
+//     contiguous slice of sites, staged ONCE into LDS (site-fastest rows; see occu_device.hpp);
+//   * every leapfrog ("tick"): all 8 waves evaluate their sites' log-lik + gradient from LDS ->
+//     DPP wave reduction -> LDS -> workgroup partial (D grads f32, log-lik as hi+lo f32 pair);
+//   * the k partials are all-gathered through 8-byte {epoch, value} granules written with ONE
+//     sc1 store each and polled with relaxed agent-scope loads (guide G16, form R2: the data is
+//     the flag; placement independent).  Every workgroup sums the k partials in the same fixed
+//     order in f64, so all k copies of the chain state stay bit-identical without any broadcast;
+//   * wave 0 of every workgroup then advances the (replicated) NUTS state machine by one leaf,
+//     lane d holding dimension d, and publishes the next position to its workgroup through LDS.
+// No host round trip, no kernel boundary and no HBM traffic inside the sampling loop.
+#pragma once
+#include "occu_device.hpp"
+
+struct BlNutsParams {
+    BlDevData dd;
+    int num_warmup, num_samples, num_chains;
+    int k;        // workgroups per chain
+    int nloc;     // sites per workgroup
+    int lds_ld;   // LDS row stride (floats) when staged
+    int n_rows;   // rows of the data matrix
+    int nvp;      // granules per workgroup record: 16, 32 or 64 (>= D+3)
+    int max_depth;
+    float target_accept;
+    int nwin;
+    int win_end[32];               // numpyro adaptation windows (inclusive ends)
+    const uint32_t *rng;           // [C][64][4] xoshiro states (host-jumped)
+    const float *init_theta;       // [C][D] or null -> Uniform(-2,2)
+    unsigned long long *xchg;      // [C][2][k][nvp] granules, zeroed before every launch
+    const int *abort_flag;         // host-mapped
+    unsigned spin_limit;
+    float *draws;                  // [C][S][D]
+    unsigned char *diverging;      // [C][S]
+    int *num_steps;                // [C][S]
+    float *accept_prob;            // [C][S]
+    float *potential;              // [C][S]
+    float *step_size;              // [C]
+    float *inv_mass;               // [C][D]
+    long long *nleap;              // [C][2]
+    int *status;                   // [1]
+};
+
+__device__ __forceinline__ float bl_logaddexp(float a, float b)
+{
+    const float m = fmaxf(a, b);
+    if (m == -INFINITY) return m;
+    return m + __logf(1.0f + __expf(-fabsf(a - b)));
+}
+
+// numpyro hmc_util._is_turning (diagonal mass); lane d = dim d, lanes >= D hold zeros.
+__device__ __forceinline__ bool bl_is_turning(float minv, float rl, float rr, float rsum)
+{
+    const float rho = rsum - 0.5f * (rl + rr);
+    const float dl = bl_wave_sum(minv * rl * rho);
+    const float dr = bl_wave_sum(minv * rr * rho);
+    return (dl <= 0.0f) || (dr <= 0.0f);
+}
+
+template <int KS, int KO, bool LDS>
+__global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams p)
+{
+    const int chain = blockIdx.x / p.k, member = blockIdx.x - chain * p.k;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int Ks = p.dd.Ks, Ko = p.dd.Ko, D = Ks + Ko + 2;
+    const int T = p.dd.T, J = p.dd.J;
+    const int s0 = member * p.nloc;
+    int cnt = p.dd.n_sites - s0;
+    cnt = cnt < 0 ? 0 : (cnt > p.nloc ? p.nloc : cnt);
+    const float *grows;
+    int ld;
+    if constexpr (LDS) {
+        bl_stage_rows(p.dd.rows, p.n_rows, p.dd.n_stride, s0, cnt, p.lds_ld);
+        grows = nullptr;
+        ld = p.lds_ld;
+    } else {
+        grows = p.dd.rows + s0;
+        ld = p.dd.n_stride;
+    }
+    float *sh_theta = bl_lds_f(BL_OFF_THETA);
+    int *sh_flag = bl_lds_i(BL_OFF_FLAG);
+    float *sh_ckr = bl_lds_f(BL_OFF_CKR), *sh_ckrs = bl_lds_f(BL_OFF_CKRS);
+
+    // ------------------------------------------------ replicated chain state (wave 0) ----
+    const bool act = lane < D;
+    const int S = p.num_samples, W = p.num_warmup, total = W + S;
+    BlRng rng_d, rng_s; // per-dimension stream, shared scalar stream
+    float th = 0.f, gr = 0.f;           // current position / gradient of U
+    double U = 0.0;                     // current potential
+    float minv = act ? 1.0f : 0.0f;     // diagonal inverse mass (0 in idle lanes keeps sums clean)
+    float eps = 1.0f;
+    // dual averaging + Welford
+    float da_xt = 0.f, da_xavg = 0.f, da_gavg = 0.f, da_prox = __logf(10.0f);
+    int da_t = 0, wf_n = 0, win_idx = 0;
+    float wf_mean = 0.f, wf_m2 = 0.f;
+    // tree
+    double E0 = 0.0, Up = 0.0;
+    float zl = 0, rl = 0, gl = 0, zr = 0, rr = 0, gR = 0, zp = 0, gp = 0, rsum = 0, wt = 0, sumacc = 0;
+    int depth = 0, nprop = 0;
+    bool diverged = false;
+    // subtree under construction
+    double sUp = 0.0;
+    float szp = 0, sgp = 0, srsum = 0, swt = 0, ssumacc = 0;
+    int snprop = 0;
+    bool sdiv = false, sturn = false, going_right = false;
+    float epsdir = 0.f;
+    // leaf in flight
+    float cz = 0, rh = 0;
+    int it = -1; // -1: evaluating the initial position
+    long long nleap_w = 0, nleap_s = 0;
+    const float prior_loc = (lane <= Ks) ? p.dd.loc_b : p.dd.loc_a;
+    const float prior_isc2 = act ? ((lane <= Ks) ? p.dd.isc2_b : p.dd.isc2_a) : 0.0f;
+
+    if (wave == 0) {
+        const uint32_t *rs = p.rng + ((size_t)chain * BL_NSTREAM + lane) * 4;
+        rng_d.s0 = rs[0]; rng_d.s1 = rs[1]; rng_d.s2 = rs[2]; rng_d.s3 = rs[3];
+        const uint32_t *rc = p.rng + ((size_t)chain * BL_NSTREAM + BL_SCALAR_STREAM) * 4;
+        rng_s.s0 = rc[0]; rng_s.s1 = rc[1]; rng_s.s2 = rc[2]; rng_s.s3 = rc[3];
+        const float u0 = bl_rng_uniform(rng_d); // init_to_uniform(radius=2), fit.py:93
+        cz = act ? (p.init_theta ? p.init_theta[chain * D + lane] : 4.0f * u0 - 2.0f) : 0.0f;
+        sh_theta[lane] = cz;
+        if (lane == 0) sh_flag[0] = 0;
+    }
+    __syncthreads();
+
+    unsigned epoch = 0;
+    while (true) {
+        // ------------------------------------------- phase A: all waves, site log-lik ----
+        float beta[KS + 1], alpha[KO + 1];
+        bl_load_coefs<KS, KO>(sh_theta, Ks, Ko, beta, alpha);
+        float ll = 0.0f, gb[KS + 1], ga[KO + 1];
+#pragma unroll
+        for (int k = 0; k <= KS; k++) gb[k] = 0.0f;
+#pragma unroll
+        for (int k = 0; k <= KO; k++) ga[k] = 0.0f;
+        bl_eval_sites<KS, KO, LDS>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga);
+        bl_wave_partials_to_lds<KS, KO>(Ks, Ko, ll, gb, ga);
+        __syncthreads();
+
+        if (wave == 0) {
+            epoch++;
+            // ---------------------------------- workgroup partial (fixed wave order) ----
+            const float *part = bl_lds_f(BL_OFF_PART);
+            const double *pll = bl_lds_d(BL_OFF_LL);
+            float gpart = 0.0f;
+            double llwg = 0.0;
+#pragma unroll
+            for (int w = 0; w < BL_WAVES; w++) {
+                gpart += act ? part[w * 64 + lane] : 0.0f;
+                llwg += pll[w];
+            }
+            const float ll_hi = (float)llwg, ll_lo = (float)(llwg - (double)ll_hi);
+            float comp = act ? gpart : 0.0f;
+            if (lane == D) comp = ll_hi;
+            if (lane == D + 1) comp = ll_lo;
+            if (lane == D + 2 && member == 0 && (epoch & 255u) == 0u)
+                comp = (__hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1.0f : 0.0f;
+
+            // ------------------------------ all-gather of the k partials (G16 / R2) ----
+            const int nvp = p.nvp, G = 64 / nvp;
+            unsigned long long *rec = p.xchg + ((size_t)(chain * 2 + (epoch & 1u)) * p.k) * nvp;
+            if (lane < nvp)
+                __hip_atomic_store(rec + (size_t)member * nvp + lane,
+                                   ((unsigned long long)epoch << 32) | __float_as_uint(comp),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int c_idx = lane & (nvp - 1), sub = lane / nvp;
+            double acc = 0.0;
+            bool timed_out = false;
+            for (int p0 = 0; p0 < p.k; p0 += 8 * G) {
+                unsigned long long v[8];
+                unsigned spins = 0;
+                while (true) {
+                    bool ok = true;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const int w = p0 + q * G + sub;
+                        v[q] = 0ull;
+                        if (w < p.k) {
+                            v[q] = __hip_atomic_load(rec + (size_t)w * nvp + c_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = ok && ((unsigned)(v[q] >> 32) == epoch);
+                        }
+                    }
+                    if (__all(ok)) break;
+                    if (++spins > p.spin_limit) { timed_out = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (timed_out) break;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int w = p0 + q * G + sub;
+                    if (w < p.k) acc += (double)__uint_as_float((unsigned)v[q]);
+                }
+            }
+            for (int off = nvp; off < 64; off <<= 1) {
+                const unsigned long long b = (unsigned long long)__double_as_longlong(acc);
+                const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)b, off);
+                const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(b >> 32), off);
+                acc += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+            }
+            const double ll_tot = bl_readlane_d(acc, D) + bl_readlane_d(acc, D + 1);
+            const bool abort_req = bl_readlane_d(acc, D + 2) != 0.0;
+            int flag = 0;
+            if (timed_out) flag = 4;       // BL_ERR_TIMEOUT
+            else if (abort_req) flag = 5;  // BL_ERR_ABORTED
+
+            // ------------------------------------------------ potential at cz (lane d) ----
+            const float dth = cz - prior_loc;
+            const double Un = -ll_tot + (double)(0.5f * bl_wave_sum(act ? dth * dth * prior_isc2 : 0.0f)) + p.dd.prior_const;
+            const float cg = act ? (-(float)acc + dth * prior_isc2) : 0.0f;
+
+            bool new_transition = false;
+            if (flag == 0) {
+                if (it < 0) {
+                    // initial evaluation done
+                    th = cz; gr = cg; U = Un;
+                    it = 0;
+                    new_transition = true;
+                } else {
+                    if (it < W) nleap_w++; else nleap_s++;
+                    // ---------------- finish the leaf (_build_basetree) ----------------
+                    const float cr = rh - 0.5f * epsdir * cg;
+                    const double Kn = (double)(0.5f * bl_wave_sum(minv * cr * cr));
+                    double dE = (Un + Kn) - E0;
+                    if (dE != dE) dE = (double)INFINITY;
+                    const float dEf = (float)dE;
+                    const float lw = -dEf;
+                    const bool ldiv = dE > 1000.0;
+                    const float lacc = dEf <= 0.0f ? 1.0f : __expf(-dEf);
+                    const int leaf_idx = snprop;
+                    if (leaf_idx == 0) {
+                        szp = cz; sgp = cg; sUp = Un; swt = lw; srsum = cr;
+                        sdiv = ldiv; ssumacc = lacc; snprop = 1;
+                    } else {
+                        // _combine_tree(..., biased=False): uniform transition kernel
+                        const float pr = 1.0f / (1.0f + __expf(-(lw - swt)));
+                        const float u = bl_rng_uniform(rng_s);
+                        if (u < pr) { szp = cz; sgp = cg; sUp = Un; }
+                        swt = bl_logaddexp(swt, lw);
+                        sdiv = ldiv;
+                        ssumacc += lacc;
+                        srsum += cr;
+                        snprop++;
+                    }
+                    // checkpointed U-turn (_leaf_idx_to_ckpt_idxs / _is_iterative_turning)
+                    const int idx_max = __popc((unsigned)leaf_idx >> 1);
+                    const int idx_min = idx_max - (int)__builtin_ctz(~(unsigned)leaf_idx) + 1;
+                    if ((leaf_idx & 1) == 0) {
+                        sh_ckr[idx_max * 64 + lane] = cr;
+                        sh_ckrs[idx_max * 64 + lane] = srsum;
+                    } else {
+                        for (int i = idx_max; i >= idx_min && !sturn; i--) {
+                            const float ck = sh_ckr[i * 64 + lane];
+                            const float srs = srsum - sh_ckrs[i * 64 + lane] + ck;
+                            sturn = bl_is_turning(minv, ck, cr, srs);
+                        }
+                    }
+                    if (snprop < (1 << depth) && !sturn && !sdiv) {
+                        // next leaf continues from this one
+                        rh = cr - 0.5f * epsdir * cg;
+                        cz = cz + epsdir * minv * rh;
+                    } else {
+                        // ---------- _combine_tree(tree, subtree, biased=True) ----------
+                        if (going_right) { zr = cz; rr = cr; gR = cg; }
+                        else { zl = cz; rl = cr; gl = cg; }
+                        rsum += srsum;
+                        float pr = fminf(1.0f, __expf(swt - wt));
+                        if (sturn || sdiv) pr = 0.0f;
+                        const bool turning = bl_is_turning(minv, rl, rr, rsum);
+                        const float u = bl_rng_uniform(rng_s);
+                        if (u < pr) { zp = szp; gp = sgp; Up = sUp; }
+                        depth++;
+                        wt = bl_logaddexp(wt, swt);
+                        diverged = sdiv;
+                        sumacc += ssumacc;
+                        nprop += snprop;
+                        if (depth < p.max_depth && !turning && !diverged) {
+                            // next doubling
+                            going_right = (bl_rng_next(rng_s) >> 31) != 0u;
+                            epsdir = going_right ? eps : -eps;
+                            snprop = 0; sturn = false; sdiv = false;
+                            const float ez = going_right ? zr : zl, er = going_right ? rr : rl, eg = going_right ? gR : gl;
+                            rh = er - 0.5f * epsdir * eg;
+                            cz = ez + epsdir * minv * rh;
+                        } else {
+                            // ---------------- transition complete ----------------
+                            const float accp = sumacc / (float)nprop;
+                            th = zp; gr = gp; U = Up;
+                            if (it < W) {
+                                // warmup_adapter.update_fn: dual averaging (t0=10, kappa=.75, gamma=.05)
+                                const float g = p.target_accept - accp;
+                                da_t += 1;
+                                const float tt = (float)da_t;
+                                da_gavg = (1.0f - 1.0f / (tt + 10.0f)) * da_gavg + g / (tt + 10.0f);
+                                da_xt = da_prox - sqrtf(tt) / 0.05f * da_gavg;
+                                const float wgt = __powf(tt, -0.75f);
+                                da_xavg = (1.0f - wgt) * da_xavg + wgt * da_xt;
+                                eps = (it == W - 1) ? __expf(da_xavg) : __expf(da_xt);
+                                eps = fminf(fmaxf(eps, 1.1754944e-38f), 3.4028235e+38f);
+                                const bool middle = win_idx > 0 && win_idx < p.nwin - 1;
+                                if (middle) {
+                                    wf_n += 1;
+                                    const float dpre = th - wf_mean;
+                                    wf_mean += dpre / (float)wf_n;
+                                    wf_m2 += dpre * (th - wf_mean);
+                                }
+                                const bool at_end = it == p.win_end[win_idx];
+                                if (at_end) win_idx++;
+                                if (at_end && middle) {
+                                    const float n = (float)wf_n;
+                                    const float var = wf_m2 / (n - 1.0f);
+                                    minv = act ? ((n / (n + 5.0f)) * var + 1e-3f * (5.0f / (n + 5.0f))) : 0.0f;
+                                    wf_mean = 0.f; wf_m2 = 0.f; wf_n = 0;
+                                    da_xt = 0.f; da_xavg = 0.f; da_gavg = 0.f; da_t = 0;
+                                    da_prox = __logf(10.0f * eps);
+                                }
+                            } else if (member == 0) {
+                                const size_t s = (size_t)chain * S + (it - W);
+                                if (act) p.draws[s * D + lane] = th;
+                                if (lane == 0) {
+                                    p.num_steps[s] = nprop;
+                                    p.accept_prob[s] = accp;
+                                    p.diverging[s] = diverged ? 1 : 0;
+                                    p.potential[s] = (float)U;
+                                }
+                            }
+                            it++;
+                            if (it >= total) flag = 1; // done
+                            else new_transition = true;
+                        }
+                    }
+                }
+                if (new_transition) {
+                    // sample momentum r = N(0,1)/sqrt(M^-1); start a fresh tree and its first doubling
+                    const float z01 = bl_rng_normal(rng_d);
+                    const float r0 = act ? z01 * rsqrtf(minv) : 0.0f;
+                    E0 = U + (double)(0.5f * bl_wave_sum(minv * r0 * r0));
+                    zl = th; rl = r0; gl = gr; zr = th; rr = r0; gR = gr;
+                    zp = th; gp = gr; Up = U;
+                    wt = 0.f; rsum = r0; sumacc = 0.f; nprop = 0; depth = 0; diverged = false;
+                    going_right = (bl_rng_next(rng_s) >> 31) != 0u;
+                    epsdir = going_right ? eps : -eps;
+                    snprop = 0; sturn = false; sdiv = false;
+                    rh = r0 - 0.5f * epsdir * gr;
+                    cz = th + epsdir * minv * rh;
+                }
+            }
+            sh_theta[lane] = act ? cz : 0.0f;
+            if (lane == 0) sh_flag[0] = flag;
+            if (flag != 0 && member == 0) {
+                if (flag > 1 && lane == 0) atomicMax(p.status, flag);
+                if (act) p.inv_mass[chain * D + lane] = minv;
+                if (lane == 0) {
+                    p.step_size[chain] = eps;
+                    p.nleap[chain * 2 + 0] = nleap_w;
+                    p.nleap[chain * 2 + 1] = nleap_s;
+                }
+            }
+        }
+        __syncthreads();
+        if (sh_flag[0] != 0) break;
+    }
+}

@@ -1,0 +1,43 @@
+"""Minimal prior objects standing in for ``numpyro.distributions`` in model signatures.
+
+Only what ``occu``'s signature names (biolith/models/occu.py:28-39).  The HIP engine samples
+coefficients under ``Normal(loc, scale)`` priors (``prior.expand([K+1]).to_event(1)``,
+biolith/regression/linear.py:28); the other classes exist so that reference-style calls that pass
+the defaults keep working and non-default ones can be rejected with a clear message.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class Normal:
+    loc: float = 0.0
+    scale: float = 1.0
+
+
+@dataclass(frozen=True)
+class HalfNormal:
+    scale: float = 1.0
+
+
+@dataclass(frozen=True)
+class Beta:
+    concentration1: float = 1.0
+    concentration0: float = 1.0
+
+
+def as_normal(prior, name: str = "prior") -> tuple:
+    """(loc, scale) of a Normal prior; duck-types numpyro's ``dist.Normal`` (has .loc/.scale)."""
+    cls = type(prior).__name__
+    if cls != "Normal" or not hasattr(prior, "loc") or not hasattr(prior, "scale"):
+        raise NotImplementedError(f"{name}: the HIP engine supports Normal(loc, scale) priors, got {prior!r}")
+    import numpy as np
+
+    loc, scale = np.asarray(prior.loc, dtype=float), np.asarray(prior.scale, dtype=float)
+    if loc.size != 1 or scale.size != 1:
+        raise NotImplementedError(f"{name}: scalar loc/scale only (the reference expands one prior over all coefficients)")
+    loc, scale = float(loc.reshape(())), float(scale.reshape(()))
+    if not scale > 0:
+        raise ValueError(f"{name}: scale must be positive")
+    return loc, scale

@@ -1,0 +1,215 @@
+"""Python handle over the HIP engine's C-ABI: dataset upload, log-density hook, NUTS driver.
+
+This is the host-side counterpart of what ``mcmc.run`` did in the reference
+(biolith/utils/fit.py:105-130).  It only marshals NumPy buffers through ``ctypes``; all arithmetic
+of the hot path runs in the gfx950 kernels under ``csrc/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+@dataclass
+class NutsResult:
+    draws: np.ndarray             # (C, S, D) float32
+    diverging: np.ndarray         # (C, S) bool
+    num_steps: np.ndarray         # (C, S) int32
+    accept_prob: np.ndarray       # (C, S) float32
+    potential_energy: np.ndarray  # (C, S) float32
+    step_size: np.ndarray         # (C,)
+    inv_mass: np.ndarray          # (C, D)
+    n_leapfrog: np.ndarray        # (C, 2) int64: warmup, sampling gradient evaluations
+    kernel_ms: float              # HIP-event time of the persistent kernel
+    wgs_per_chain: int
+    lds_bytes: int
+    lds_staged: bool
+
+
+class OccuDataset:
+    """Device-resident occupancy dataset (one species).
+
+    Parameters mirror ``occu``'s data arguments (biolith/models/occu.py:19-40):
+    ``site_covs (N, Ks)``, ``obs_covs (N, T, J, Ko)``, ``obs (S=1, N, T, J)``; NaN = missing.
+    """
+
+    def __init__(self, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0), device: int = 0):
+        lib = _ffi.load()
+        X = np.ascontiguousarray(site_covs, dtype=np.float32)
+        W = np.ascontiguousarray(obs_covs, dtype=np.float32)
+        Y = np.ascontiguousarray(obs, dtype=np.float32)
+        if X.ndim != 2:
+            raise ValueError("site_covs must be of shape (n_sites, n_site_covs)")
+        if W.ndim != 4:
+            raise ValueError("obs_covs must be of shape (n_sites, n_periods, n_replicates, n_obs_covs)")
+        if Y.ndim != 4:
+            raise ValueError("obs must be of shape (n_species, n_sites, n_periods, n_replicates)")
+        N, Ks = X.shape
+        _, T, J, Ko = W.shape
+        if W.shape[0] != N:
+            raise ValueError("site_covs and obs_covs must have the same number of sites")
+        if Y.shape[1:] != (N, T, J):
+            raise ValueError("obs must have shape (n_species, n_sites, n_periods, n_replicates) matching obs_covs")
+        self.dims = _ffi.bl_dims(Y.shape[0], N, T, J, Ks, Ko)
+        self.N, self.T, self.J, self.Ks, self.Ko, self.S = N, T, J, Ks, Ko, Y.shape[0]
+        self.D = Ks + Ko + 2
+        self.device = device
+        pb = _ffi.bl_normal_prior(float(prior_beta[0]), float(prior_beta[1]))
+        pa = _ffi.bl_normal_prior(float(prior_alpha[0]), float(prior_alpha[1]))
+        h = C.c_void_p()
+        _ffi.check(lib.bl_dataset_create(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), C.byref(pb), C.byref(pa),
+                                         device, C.byref(h)))
+        self._h = h
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bl_dataset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ K1 parity hook ----
+    def logp_grad(self, theta, staged: bool = True):
+        """U(theta) = -log p(theta, y) and dU/dtheta; theta (D,) or (B, D)."""
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        single = th.ndim == 1
+        th2 = th.reshape(1, -1) if single else th
+        if th2.shape[1] != self.D:
+            raise ValueError(f"theta must have {self.D} columns")
+        B = th2.shape[0]
+        U = np.empty(B)
+        G = np.empty((B, self.D))
+        _ffi.check(self._lib.bl_logp_grad(self._h, B, _dp(th2), _dp(U), _dp(G), int(staged)))
+        return (U[0], G[0]) if single else (U, G)
+
+    # --------------------------------------------------------------------------- NUTS ----
+    def _config(self, num_warmup, num_samples, num_chains, seed, chain_offset, max_tree_depth, target_accept,
+                wgs_per_chain, init_theta):
+        cfg = _ffi.bl_nuts_config()
+        cfg.num_warmup, cfg.num_samples, cfg.num_chains = int(num_warmup), int(num_samples), int(num_chains)
+        cfg.chain_offset, cfg.seed = int(chain_offset), int(seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.max_tree_depth, cfg.wgs_per_chain = int(max_tree_depth), int(wgs_per_chain)
+        cfg.target_accept = float(target_accept)
+        keep = None
+        if init_theta is not None:
+            keep = np.ascontiguousarray(init_theta, dtype=np.float64)
+            if keep.shape != (num_chains, self.D):
+                raise ValueError("init_theta must have shape (num_chains, D)")
+            cfg.init_theta = _dp(keep)
+        return cfg, keep
+
+    def launch(self, num_warmup=1000, num_samples=1000, num_chains=1, seed=0, chain_offset=0, max_tree_depth=10,
+               target_accept=0.8, wgs_per_chain=0, init_theta=None, stream: Optional[int] = None):
+        """Asynchronous launch of the persistent kernel (returns immediately)."""
+        cfg, keep = self._config(num_warmup, num_samples, num_chains, seed, chain_offset, max_tree_depth,
+                                 target_accept, wgs_per_chain, init_theta)
+        _ffi.check(self._lib.bl_nuts_launch(self._h, C.byref(cfg), C.c_void_p(stream or 0)))
+        self._shape = (int(num_chains), int(num_samples))
+
+    def done(self) -> bool:
+        d = C.c_int(0)
+        _ffi.check(self._lib.bl_nuts_poll(self._h, C.byref(d)))
+        return bool(d.value)
+
+    def abort(self):
+        self._lib.bl_nuts_abort(self._h)
+
+    def wait(self):
+        _ffi.check(self._lib.bl_nuts_wait(self._h))
+
+    def elapsed_ms(self) -> float:
+        ms = C.c_float(0)
+        _ffi.check(self._lib.bl_nuts_elapsed_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def device_draws(self):
+        """(device pointer, bytes) of the last launch's draws [C][S][D] float32."""
+        p, n = C.c_void_p(), C.c_size_t()
+        _ffi.check(self._lib.bl_nuts_device_draws(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def fetch(self) -> NutsResult:
+        Cn, S = self._shape
+        D = self.D
+        draws = np.empty((Cn, S, D), dtype=np.float32)
+        div = np.empty((Cn, S), dtype=np.uint8)
+        steps = np.empty((Cn, S), dtype=np.int32)
+        acc = np.empty((Cn, S), dtype=np.float32)
+        pot = np.empty((Cn, S), dtype=np.float32)
+        eps = np.empty(Cn, dtype=np.float32)
+        minv = np.empty((Cn, D), dtype=np.float32)
+        nleap = np.empty((Cn, 2), dtype=np.int64)
+        out = _ffi.bl_nuts_output(
+            _fp(draws), div.ctypes.data_as(C.POINTER(C.c_uint8)), steps.ctypes.data_as(C.POINTER(C.c_int32)),
+            _fp(acc), _fp(pot), _fp(eps), _fp(minv), nleap.ctypes.data_as(C.POINTER(C.c_int64)),
+        )
+        _ffi.check(self._lib.bl_nuts_fetch(self._h, C.byref(out)))
+        k, thr, lds, staged = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _ffi.check(self._lib.bl_nuts_geometry(self._h, C.byref(k), C.byref(thr), C.byref(lds), C.byref(staged)))
+        return NutsResult(draws, div.astype(bool), steps, acc, pot, eps, minv, nleap, self.elapsed_ms(),
+                          k.value, lds.value, bool(staged.value))
+
+    def nuts(self, timeout: Optional[float] = None, **kw) -> NutsResult:
+        """launch + wait + fetch.  With ``timeout`` (seconds) the kernel is aborted through its
+        host-mapped flag and ``TimeoutError`` raised (fit(timeout=...), biolith/utils/fit.py:124-128)."""
+        self.launch(**kw)
+        if timeout is not None:
+            t_end = time.monotonic() + float(timeout)
+            try:
+                while not self.done():
+                    if time.monotonic() > t_end:
+                        raise TimeoutError("Timed out")
+                    time.sleep(0.0005)
+            except BaseException:
+                # also reached for the reference-style SIGALRM TimeoutException or Ctrl-C
+                self.abort()
+                try:
+                    self.wait()
+                except Exception:
+                    pass
+                raise
+        self.wait()
+        return self.fetch()
+
+    # ------------------------------------------------------------ deterministic sites ----
+    def deterministic(self, draws, psi: bool = True, prob_detection: bool = False):
+        """psi (n, T, N) and/or prob_detection (n, J, T, N) for draws (n, D) (occu.py:207,221-228)."""
+        d = np.ascontiguousarray(draws, dtype=np.float32).reshape(-1, self.D)
+        n = d.shape[0]
+        out_psi = np.empty((n, self.T, self.N), dtype=np.float32) if psi else None
+        out_pd = np.empty((n, self.J, self.T, self.N), dtype=np.float32) if prob_detection else None
+        _ffi.check(self._lib.bl_deterministic(self._h, n, _fp(d), _fp(out_psi), _fp(out_pd)))
+        return out_psi, out_pd
+
+
+def rng_streams(seed: int, chain: int, nstreams: int = _ffi.RNG_STREAMS_PER_CHAIN) -> np.ndarray:
+    out = np.zeros((nstreams, 4), dtype=np.uint32)
+    _ffi.check(_ffi.load().bl_rng_streams(int(seed), int(chain), int(nstreams),
+                                          out.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return out
+
+
+def adaptation_schedule(num_warmup: int):
+    s = (C.c_int32 * 40)()
+    e = (C.c_int32 * 40)()
+    n = _ffi.load().bl_adaptation_schedule(int(num_warmup), s, e, 40)
+    return [(s[i], e[i]) for i in range(n)]

@@ -1,0 +1,143 @@
+/*
+ * biolith_hip.h -- C-ABI of the MI355X-native occupancy-model NUTS engine.
+ *
+ * This is the drop-in boundary for ONE path of timmh/biolith:
+ *     biolith.utils.fit(biolith.models.occu, ...)          (biolith/utils/fit.py:16-135)
+ * Everything numpyro/jax did behind `mcmc.run(...)` (fit.py:128-130) happens behind these
+ * entry points in hand-written HIP for gfx950.  Plain pointers and sizes only; no torch / C++
+ * types cross the boundary; no exception crosses it (int status + bl_last_error()).
+ *
+ * Ownership: the caller allocates every output.  bl_dataset_create copies its inputs; the
+ * library keeps nothing of the caller's after any call returns, except its own opaque handle.
+ * A handle is not thread-safe; use one host thread (or process) per handle.
+ */
+#ifndef BIOLITH_HIP_H
+#define BIOLITH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BL_ABI_VERSION 1
+
+enum {
+    BL_OK = 0,
+    BL_ERR_INVALID = 1,      /* bad argument / unsupported shape (message says which)       */
+    BL_ERR_NO_DEVICE = 2,    /* no HIP device / HIP runtime error                            */
+    BL_ERR_UNSUPPORTED = 3,  /* model option outside the built path                          */
+    BL_ERR_TIMEOUT = 4,      /* in-kernel spin bound hit (a cooperating workgroup vanished)  */
+    BL_ERR_ABORTED = 5,      /* bl_nuts_abort() was honoured                                 */
+    BL_ERR_BUSY = 6          /* a launch is still in flight on this handle                   */
+};
+
+#define BL_RNG_STREAMS_PER_CHAIN 64
+#define BL_MAX_COVS 16 /* per side (site / observation) */
+
+/* Shapes as the reference names them (biolith/models/occu.py:116-133). */
+typedef struct bl_dims {
+    int32_t n_species;    /* S : must be 1 in this build (occu.py:182 plate "species")      */
+    int32_t n_sites;      /* N                                                               */
+    int32_t n_periods;    /* T : stacked periods sharing psi (occu.py:198-210)               */
+    int32_t n_replicates; /* J : visits per period                                           */
+    int32_t n_site_covs;  /* Ks                                                              */
+    int32_t n_obs_covs;   /* Ko                                                              */
+} bl_dims;
+
+/* prior.expand([K+1]).to_event(1) with prior = Normal(loc, scale)
+ * (biolith/regression/linear.py:28, defaults occu.py:28-29). */
+typedef struct bl_normal_prior {
+    double loc;
+    double scale;
+} bl_normal_prior;
+
+typedef struct bl_dataset bl_dataset;
+
+int bl_abi_version(void);
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char *bl_last_error(void);
+int bl_device_count(int *count);
+
+/*
+ * Replaces what numpyro traces out of occu() on first call (fit.py:128 -> occu.py:102-242):
+ * validates shapes (occu.py:103-133), builds the missing-data mask (occu.py:136-142,
+ * utils/modeling.py:15-17), NaN->0 on covariates, and lays the data out site-fastest in HBM.
+ *   site_covs [N][Ks]  obs_covs [N][T][J][Ko]  obs [S][N][T][J]   (row-major float32, NaN = missing)
+ * exactly the arrays prepare_data() produces (utils/data.py:135-140).
+ */
+int bl_dataset_create(const bl_dims *dims, const float *site_covs, const float *obs_covs,
+                      const float *obs, const bl_normal_prior *prior_beta,
+                      const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
+int bl_dataset_destroy(bl_dataset *ds);
+/* D = Ks+1 + Ko+1; theta = [beta_0..beta_Ks, alpha_0..alpha_Ko] */
+int bl_dataset_param_dim(const bl_dataset *ds, int *D);
+
+/*
+ * Parity hook for the likelihood kernel: U = -log p(theta, y) (z marginalised, Normal prior
+ * normaliser included) and dU/dtheta for B parameter vectors.  Replaces
+ * jax.value_and_grad(potential_fn) over occu.py:136-242 + funsor enumeration (occu.py:208-210).
+ * `staged` != 0 evaluates through the same LDS-staged code path the NUTS kernel uses.
+ */
+int bl_logp_grad(bl_dataset *ds, int B, const double *theta /*[B][D]*/, double *U /*[B]*/,
+                 double *grad /*[B][D]*/, int staged);
+
+/* MCMC(NUTS(model), num_samples, num_warmup, num_chains).run(PRNGKey(seed))  (fit.py:92-130) */
+typedef struct bl_nuts_config {
+    int32_t num_warmup;     /* fit.py:23 default 1000 */
+    int32_t num_samples;    /* fit.py:22 default 1000 */
+    int32_t num_chains;     /* chains run by THIS call (fit.py:25 default 5)                 */
+    int32_t chain_offset;   /* global id of this call's first chain: selects its RNG streams */
+    uint64_t seed;          /* fit.py:24 / fit.py:122                                       */
+    int32_t max_tree_depth; /* numpyro NUTS default 10                                       */
+    int32_t wgs_per_chain;  /* 0 = auto; workgroups (CUs) cooperating on one chain           */
+    double target_accept;   /* numpyro NUTS default 0.8                                      */
+    const double *init_theta; /* NULL = init_to_uniform(radius 2) (fit.py:93); else [C][D]  */
+} bl_nuts_config;
+
+/* Host pointers, caller-allocated; NULL = not wanted.  C = num_chains, S = num_samples. */
+typedef struct bl_nuts_output {
+    float *draws;            /* [C][S][D] post-warmup positions (mcmc.get_samples, fit.py:132) */
+    uint8_t *diverging;      /* [C][S]   extra field "diverging" (diagnostics.py:34-38)        */
+    int32_t *num_steps;      /* [C][S]   leapfrogs of each transition                          */
+    float *accept_prob;      /* [C][S]                                                          */
+    float *potential_energy; /* [C][S]                                                          */
+    float *step_size;        /* [C]      adapted step size                                      */
+    float *inv_mass;         /* [C][D]   adapted diagonal inverse mass                          */
+    int64_t *n_leapfrog;     /* [C][2]   gradient evaluations: warmup, sampling                 */
+} bl_nuts_output;
+
+/* Blocking convenience: launch + wait + fetch. */
+int bl_nuts_run(bl_dataset *ds, const bl_nuts_config *cfg, bl_nuts_output *out);
+
+/* Asynchronous form (timeouts, overlap, timing).  `stream` is a hipStream_t or NULL. */
+int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *stream);
+int bl_nuts_poll(bl_dataset *ds, int *done);
+int bl_nuts_abort(bl_dataset *ds); /* fit(timeout=...) (fit.py:124-128): kernel exits at its next leapfrog */
+int bl_nuts_wait(bl_dataset *ds);  /* returns BL_ERR_TIMEOUT / BL_ERR_ABORTED if the kernel reported it */
+int bl_nuts_fetch(bl_dataset *ds, bl_nuts_output *out);
+/* HIP-event time of the last launch (kernel + its memset), on the launch stream. */
+int bl_nuts_elapsed_ms(bl_dataset *ds, float *ms);
+/* Device address of the last launch's draws [C][S][D] float32 (for an RCCL gather). */
+int bl_nuts_device_draws(bl_dataset *ds, void **dev_ptr, size_t *bytes);
+/* Geometry the last launch used. */
+int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads_per_wg, int *lds_bytes, int *lds_staged);
+
+/*
+ * Deterministic sites (occu.py:207, 221-228), recomputed from draws on the device:
+ *   psi            [n_draws][T][N]      = sigmoid(beta_0 + X beta)       (constant over T)
+ *   prob_detection [n_draws][J][T][N]   = sigmoid(alpha_0 + W alpha)
+ * draws is [n_draws][D] float32 on the host; outputs are host float32 (NULL = skip).
+ */
+int bl_deterministic(bl_dataset *ds, int n_draws, const float *draws, float *psi, float *prob_detection);
+
+/* The engine's xoshiro128++ streams (host-side; no GPU needed): out[nstreams][4]. */
+int bl_rng_streams(uint64_t seed, int chain, int nstreams, uint32_t *out);
+/* numpyro build_adaptation_schedule restatement used by the kernel: returns window count. */
+int bl_adaptation_schedule(int num_warmup, int32_t *starts, int32_t *ends, int capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIOLITH_HIP_H */

@@ -1,0 +1,298 @@
+"""ctypes front-end of ``occu_oracle.c`` + two pure-NumPy restatements (TEST INFRASTRUCTURE).
+
+* ``OracleData`` / ``nuts_run``: the C restatement (float64) of the marginalised occupancy
+  log-density (biolith/models/occu.py:136-242) and of NumPyro's NUTS.
+* ``literal_log_joint``: a line-by-line NumPy statement of the *generative* model with the
+  latent z summed by brute force -- used to cross-check the closed form in the C file.
+* ``effective_sample_size`` / ``split_gelman_rubin``: restatement of numpyro.diagnostics
+  (what biolith/evaluation/diagnostics.py:23 calls).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_LOCK = threading.Lock()
+
+TINY_F32 = float(np.finfo(np.float32).tiny)
+EPS_F32 = float(np.finfo(np.float32).eps)
+
+
+def build(force: bool = False) -> str:
+    """Compile ``liboccu_oracle.so`` with gcc (a few hundred ms)."""
+    so = os.path.join(_HERE, "liboccu_oracle.so")
+    src = os.path.join(_HERE, "occu_oracle.c")
+    if force or not os.path.exists(so) or (
+        os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)
+    ):
+        subprocess.run(["make", "-C", _HERE, "-s", "-B", "liboccu_oracle.so"], check=True)
+    return so
+
+
+def lib():
+    global _LIB
+    with _LOCK:
+        if _LIB is None:
+            L = C.CDLL(build())
+            dp = C.POINTER(C.c_double)
+            L.orc_data_create.restype = C.c_void_p
+            L.orc_data_create.argtypes = [C.c_int] * 5 + [dp, dp, dp] + [C.c_double] * 4
+            L.orc_data_destroy.argtypes = [C.c_void_p]
+            L.orc_data_dim.argtypes = [C.c_void_p]
+            L.orc_potential_grad.restype = C.c_double
+            L.orc_potential_grad.argtypes = [C.c_void_p, dp, dp]
+            L.orc_rng_streams.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
+            L.orc_rng_next.restype = C.c_uint32
+            L.orc_rng_next.argtypes = [C.POINTER(C.c_uint32)]
+            L.orc_rng_jump.argtypes = [C.POINTER(C.c_uint32)]
+            L.orc_rng_uniform.restype = C.c_double
+            L.orc_rng_uniform.argtypes = [C.POINTER(C.c_uint32)]
+            L.orc_rng_normal.restype = C.c_double
+            L.orc_rng_normal.argtypes = [C.POINTER(C.c_uint32)]
+            L.orc_adaptation_schedule.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+            L.orc_nuts_run.restype = C.c_int
+            L.orc_nuts_run.argtypes = [
+                C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_double,
+                dp, dp, C.POINTER(C.c_int), dp, C.POINTER(C.c_ubyte), dp, dp, dp,
+                C.POINTER(C.c_longlong), dp, C.POINTER(C.c_int), dp,
+            ]
+            _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _as_f32_f64(a):
+    """The reference feeds float32 arrays (utils/data.py:135-140); keep those exact values."""
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32).astype(np.float64))
+
+
+class OracleData:
+    """Prepared dataset for ONE species: site_covs (N,Ks), obs_covs (N,T,J,Ko), obs (N,T,J)."""
+
+    def __init__(self, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):
+        X = _as_f32_f64(site_covs)
+        W = _as_f32_f64(obs_covs)
+        Y = _as_f32_f64(obs)
+        if Y.ndim == 4:
+            assert Y.shape[0] == 1, "oracle handles one species"
+            Y = np.ascontiguousarray(Y[0])
+        assert X.ndim == 2 and W.ndim == 4 and Y.ndim == 3
+        N, Ks = X.shape
+        _, T, J, Ko = W.shape
+        assert W.shape[0] == N and Y.shape == (N, T, J)
+        self.N, self.T, self.J, self.Ks, self.Ko = N, T, J, Ks, Ko
+        self.D = Ks + Ko + 2
+        self._h = lib().orc_data_create(
+            N, T, J, Ks, Ko, _dp(X), _dp(W), _dp(Y),
+            float(prior_beta[0]), float(prior_beta[1]), float(prior_alpha[0]), float(prior_alpha[1]),
+        )
+        self.X, self.W, self.Y = X, W, Y
+        self.prior_beta, self.prior_alpha = tuple(prior_beta), tuple(prior_alpha)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().orc_data_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def potential_grad(self, theta):
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        if th.ndim == 1:
+            g = np.empty(self.D)
+            u = lib().orc_potential_grad(self._h, _dp(th), _dp(g))
+            return u, g
+        U = np.empty(th.shape[0])
+        G = np.empty_like(th)
+        for b in range(th.shape[0]):
+            U[b] = lib().orc_potential_grad(self._h, _dp(th[b]), _dp(G[b]))
+        return U, G
+
+
+def rng_streams(seed: int, chain: int, nstreams: int = 64) -> np.ndarray:
+    out = np.zeros((nstreams, 4), dtype=np.uint32)
+    lib().orc_rng_streams(seed, chain, nstreams, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out
+
+
+def adaptation_schedule(num_warmup: int):
+    s = (C.c_int * 40)()
+    e = (C.c_int * 40)()
+    n = lib().orc_adaptation_schedule(num_warmup, s, e)
+    return [(s[i], e[i]) for i in range(n)]
+
+
+def _run_chain(data, num_warmup, num_samples, seed, chain, max_tree_depth, target_accept, init, trace):
+    D = data.D
+    draws = np.empty((num_samples, D))
+    steps = np.empty(num_samples, dtype=np.int32)
+    acc = np.empty(num_samples)
+    div = np.empty(num_samples, dtype=np.uint8)
+    pot = np.empty(num_samples)
+    eps = C.c_double()
+    minv = np.empty(D)
+    nleap = (C.c_longlong * 2)()
+    tot = num_warmup + num_samples
+    tr_t = np.empty((tot, D)) if trace else None
+    tr_s = np.empty(tot, dtype=np.int32) if trace else None
+    tr_e = np.empty(tot) if trace else None
+    init_a = np.ascontiguousarray(init, dtype=np.float64) if init is not None else None
+    rc = lib().orc_nuts_run(
+        data._h, num_warmup, num_samples, seed, chain, max_tree_depth, target_accept,
+        _dp(init_a), _dp(draws), steps.ctypes.data_as(C.POINTER(C.c_int)), _dp(acc),
+        div.ctypes.data_as(C.POINTER(C.c_ubyte)), _dp(pot), C.byref(eps), _dp(minv), nleap,
+        _dp(tr_t), tr_s.ctypes.data_as(C.POINTER(C.c_int)) if trace else None, _dp(tr_e),
+    )
+    if rc != 0:
+        raise RuntimeError(f"orc_nuts_run failed rc={rc}")
+    out = dict(draws=draws, num_steps=steps, accept_prob=acc, diverging=div, potential=pot,
+               step_size=eps.value, inv_mass=minv, n_leapfrog=(nleap[0], nleap[1]))
+    if trace:
+        out.update(trace_theta=tr_t, trace_steps=tr_s, trace_eps=tr_e)
+    return out
+
+
+def nuts_run(data: OracleData, num_warmup=1000, num_samples=1000, num_chains=1, seed=0,
+             chain_offset=0, max_tree_depth=10, target_accept=0.8, init=None, trace=False,
+             threads=None):
+    """Run ``num_chains`` oracle chains (one OS thread each; ctypes drops the GIL)."""
+    threads = threads or min(num_chains, os.cpu_count() or 1)
+    lib()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        futs = [
+            ex.submit(_run_chain, data, num_warmup, num_samples, seed, chain_offset + c,
+                      max_tree_depth, target_accept, None if init is None else init[c], trace)
+            for c in range(num_chains)
+        ]
+        res = [f.result() for f in futs]
+    out = {k: np.stack([r[k] for r in res]) for k in res[0] if k != "n_leapfrog"}
+    out["n_leapfrog"] = np.array([r["n_leapfrog"] for r in res])
+    out["threads"] = threads
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# Literal NumPy statement of the generative model (biolith/models/occu.py:136-242), z summed by
+# brute force.  Independent of the closed form in occu_oracle.c.
+# --------------------------------------------------------------------------------------------
+def _bernoulli_logpmf_clamped(p, y):
+    """numpyro BernoulliProbs.log_prob with clamp_probs (float32 tiny / eps) [UPSTREAM]."""
+    pc = np.clip(p, TINY_F32, 1.0 - EPS_F32)
+    return y * np.log(pc) + (1.0 - y) * np.log1p(-pc)
+
+
+def literal_log_joint(theta, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0),
+                      clamp_z1=False):
+    """log p(theta, y) for one species; obs (N,T,J).  ``clamp_z1`` applies numpyro's prob clamp
+    in the z=1 branch too (the C oracle does not; they differ only for |nu| > ~15.9)."""
+    X = _as_f32_f64(site_covs)
+    W = _as_f32_f64(obs_covs)
+    Y = _as_f32_f64(obs)
+    if Y.ndim == 4:
+        Y = Y[0]
+    N, Ks = X.shape
+    Ko = W.shape[-1]
+    theta = np.asarray(theta, dtype=np.float64)
+    beta, alpha = theta[: Ks + 1], theta[Ks + 1:]
+    # occu.py:136-142
+    obs_mask = np.isnan(W).any(-1) | np.isnan(X).any(-1)[:, None, None]
+    Y = np.where(obs_mask, np.nan, Y)
+    W = np.nan_to_num(W)
+    X = np.nan_to_num(X)
+    occ_linear = beta[0] + X @ beta[1:]                        # occu.py:198-202, linear.py:59-66
+    psi = 1.0 / (1.0 + np.exp(-occ_linear))                    # occu.py:207
+    det_linear = alpha[0] + np.tensordot(W, alpha[1:], axes=([3], [0]))
+    p = 1.0 / (1.0 + np.exp(-det_linear))                      # occu.py:221-228
+    finite = np.isfinite(Y)                                    # modeling.py:15-17
+    y0 = np.where(finite, Y, 0.0)
+    per_z = []
+    for z in (0.0, 1.0):
+        p_fp = 1.0 - (1.0 - z * p) * (1.0 - 0.0) * (1.0 - (1.0 - z) * 0.0)   # occu.py:229-235
+        if z == 1.0 and not clamp_z1:
+            ly = y0 * (-np.logaddexp(0.0, -det_linear)) + (1.0 - y0) * (-np.logaddexp(0.0, det_linear))
+        else:
+            ly = _bernoulli_logpmf_clamped(p_fp, y0)
+        ly = np.where(finite, ly, 0.0).sum(axis=2)             # over replicates -> (N,T)
+        lz = _bernoulli_logpmf_clamped(psi, z)[:, None]        # z ~ Bernoulli(psi) per period
+        per_z.append(lz + ly)
+    ll = np.logaddexp(per_z[0], per_z[1]).sum()
+
+    def normal_logpdf(v, loc, scale):
+        return (-0.5 * ((v - loc) / scale) ** 2 - np.log(scale) - 0.5 * np.log(2 * np.pi)).sum()
+
+    return ll + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
+
+
+# --------------------------------------------------------------------------------------------
+# numpyro.diagnostics restatement [UPSTREAM] -- SURVEY.md Appendix B.6
+# --------------------------------------------------------------------------------------------
+def _next_fast_len(n: int) -> int:
+    try:
+        from scipy.fft import next_fast_len
+        return int(next_fast_len(n))
+    except Exception:  # pragma: no cover
+        m = 1
+        while m < n:
+            m *= 2
+        return m
+
+
+def _autocovariance(x, axis):
+    x = np.swapaxes(x, axis, -1)
+    n = x.shape[-1]
+    m2 = 2 * _next_fast_len(n)
+    xc = x - x.mean(axis=-1, keepdims=True)
+    f = np.fft.rfft(xc, n=m2, axis=-1)
+    ac = np.fft.irfft(f * np.conjugate(f), n=m2, axis=-1)[..., :n]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ac = ac / ac[..., :1]
+    ac = ac * x.var(axis=-1, keepdims=True)
+    return np.swapaxes(ac, axis, -1)
+
+
+def _chain_variance_stats(x):
+    n = x.shape[1]
+    var_within = x.var(axis=1, ddof=1).mean(axis=0)
+    var_estimator = var_within * (n - 1) / n
+    if x.shape[0] > 1:
+        var_estimator = var_estimator + x.mean(axis=1).var(axis=0, ddof=1)
+    else:
+        var_within = var_estimator
+    return var_within, var_estimator
+
+
+def effective_sample_size(x):
+    """x: (chains, draws, ...) -> n_eff of shape x.shape[2:]."""
+    x = np.asarray(x, dtype=np.float64)
+    assert x.ndim >= 2 and x.shape[1] >= 2
+    gamma = _autocovariance(x, axis=1)
+    var_within, var_estimator = _chain_variance_stats(x)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rho = (var_estimator - var_within + gamma.mean(axis=0)) / var_estimator
+    rho[0] = 1.0
+    if rho.shape[0] % 2:
+        rho = rho[:-1]
+    P = rho.reshape((-1, 2) + rho.shape[1:]).sum(axis=1)
+    P = np.concatenate([P[:1], np.minimum.accumulate(P[1:].clip(min=0), axis=0)], axis=0)
+    tau = -1.0 + 2.0 * P.sum(axis=0)
+    return x.shape[0] * x.shape[1] / tau
+
+
+def split_gelman_rubin(x):
+    x = np.asarray(x, dtype=np.float64)
+    h = x.shape[1] // 2
+    y = np.concatenate([x[:, :h], x[:, -h:]], axis=0)
+    var_within, var_estimator = _chain_variance_stats(y)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return np.sqrt(var_estimator / var_within)

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz|json by IMPORTING the reference (build container only).
+
+The reference's model/inference half needs jax/numpyro/funsor, which are not installed and cannot
+be.  Its simulators are pure NumPy, so this script serves MagicMock modules
+for those three roots at import time, imports ``biolith.models`` from /root/reference and records
+the outputs of ``simulate()`` (biolith/models/occu.py:245-430).  Only DATA is written: inputs
+(kwargs) and outputs (arrays or their SHA-256).  Nothing of the reference's source travels.
+
+Run:  python tests/golden/make_golden.py        (needs /root/reference; not run on the GPU box)
+"""
+import contextlib
+import hashlib
+import importlib.abc
+import importlib.machinery
+import io
+import json
+import os
+import sys
+from unittest import mock
+
+import numpy as np
+
+REFERENCE = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    roots = ("jax", "numpyro", "funsor")
+
+    def find_spec(self, name, path, target=None):
+        if name.split(".")[0] in self.roots:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = mock.MagicMock(name=spec.name)
+        m.__path__ = []
+        m.__spec__ = spec
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def load_reference_simulate():
+    sys.meta_path.insert(0, _StubFinder())
+    sys.path.insert(0, REFERENCE)
+    import biolith.models  # noqa: F401
+    return sys.modules["biolith.models.occu"].simulate
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
+
+
+# name -> kwargs; "store" = keep full arrays (small), else hashes + moments only
+CASES = {
+    "default": dict(store=True, kw=dict()),
+    "missing": dict(store=True, kw=dict(simulate_missing=True)),
+    "missing_3periods": dict(store=True, kw=dict(simulate_missing=True, n_periods=3)),
+    "small_3x3": dict(store=True, kw=dict(n_sites=300, n_site_covs=3, n_obs_covs=3,
+                                          deployment_days_per_site=35, session_duration=7)),
+    "seed7_2x1": dict(store=True, kw=dict(n_sites=64, n_site_covs=2, n_obs_covs=1, random_seed=7,
+                                          deployment_days_per_site=56)),
+    "cfg2": dict(store=False, kw=dict(n_sites=10000, n_site_covs=3, n_obs_covs=3,
+                                      deployment_days_per_site=35, session_duration=7)),
+    "stacked": dict(store=False, kw=dict(n_sites=2000, n_periods=8, n_site_covs=3, n_obs_covs=3,
+                                         deployment_days_per_site=28, session_duration=7)),
+    "bench_i3": dict(store=False, kw=dict(n_sites=800, n_site_covs=2, n_obs_covs=1, random_seed=45,
+                                          deployment_days_per_site=23 * 7, session_duration=7)),
+}
+
+
+def main():
+    simulate = load_reference_simulate()
+    index = {}
+    for name, case in CASES.items():
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            data, truth = simulate(**case["kw"])
+        entry = dict(
+            kwargs=case["kw"],
+            stdout=buf.getvalue(),
+            shapes={k: list(np.shape(data[k])) for k in ("site_covs", "obs_covs", "obs")},
+            sha256={k: sha(data[k]) for k in ("site_covs", "obs_covs", "obs")},
+            coords=data["coords"],
+            ell=float(data["ell"]),
+            beta=np.asarray(truth["beta"]).tolist(),
+            alpha=np.asarray(truth["alpha"]).tolist(),
+            mean_z=float(np.mean(truth["z"])),
+            sha256_z=sha(truth["z"]),
+            mean_obs=float(np.nanmean(data["obs"])),
+            nan_frac_obs=float(np.isnan(data["obs"]).mean()),
+            stored=bool(case["store"]),
+        )
+        if case["store"]:
+            np.savez_compressed(
+                os.path.join(HERE, f"simulate_{name}.npz"),
+                site_covs=data["site_covs"], obs_covs=data["obs_covs"], obs=data["obs"],
+                z=truth["z"], beta=truth["beta"], alpha=truth["alpha"],
+            )
+        index[name] = entry
+        print(name, entry["shapes"], entry["sha256"]["obs"][:24])
+    with open(os.path.join(HERE, "simulate_index.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
