@@ -1,0 +1,55 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol include/biolith_hip.h
+declares; host-only entry points agree with the oracle; compute entry points fail loudly here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from biolith_amd import _ffi
+from biolith_amd.engine import OccuDataset, adaptation_schedule
+from conftest import ROOT, load_golden
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "biolith_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bl_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _ffi.load()
+    declared = _declared()
+    assert declared == sorted(_ffi.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.bl_abi_version() == 1
+
+
+def test_adaptation_schedule_through_abi():
+    for w in (0, 5, 19, 20, 100, 150, 151, 300, 1000, 2000):
+        assert adaptation_schedule(w) == (oracle.adaptation_schedule(w) if w > 0 else [])
+
+
+@pytest.mark.skipif(_ffi.device_count() > 0, reason="only meaningful on a box without a GPU")
+def test_no_gpu_means_loud_failure_not_fallback():
+    g = load_golden("seed7_2x1")
+    with pytest.raises(_ffi.EngineError, match="no HIP device"):
+        OccuDataset(g["site_covs"], g["obs_covs"], g["obs"])
+    from biolith_amd.models import occu
+    from biolith_amd.utils import fit
+
+    with pytest.raises(_ffi.EngineError, match="no CPU fallback"):
+        fit(occu, site_covs=g["site_covs"], obs_covs=g["obs_covs"], obs=g["obs"], num_chains=1,
+            num_samples=10, num_warmup=10)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "biolith_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
+                assert "liboccu_oracle" not in src, f

@@ -1,0 +1,73 @@
+"""fit(occu, ...) end to end on the MI355X, written like the reference's own inline tests
+(biolith/models/occu.py:433-492) with the reference's tolerances."""
+import time
+
+import numpy as np
+import pytest
+
+from biolith_amd.evaluation import diagnostics
+from biolith_amd.models import occu, simulate
+from biolith_amd.utils import fit
+from biolith_amd.utils.misc import TimeoutException
+from biolith_amd import _ffi
+
+pytestmark = pytest.mark.gpu
+
+
+def test_engine_is_the_native_library():
+    assert _ffi.device_count() >= 1
+    assert _ffi.load().bl_abi_version() == 1
+
+
+def test_occu():  # occu.py:433-456
+    data, true_params = simulate(simulate_missing=True)
+    results = fit(occu, **data, timeout=600)
+    assert np.allclose(results.samples["psi"].mean(), true_params["z"].mean(), atol=0.1)
+    assert np.allclose(
+        [results.samples[k].mean() for k in [f"cov_state_{i}" for i in range(true_params["beta"].shape[1])]],
+        true_params["beta"].mean(axis=0), atol=0.5)
+    assert np.allclose(
+        [results.samples[k].mean() for k in [f"cov_det_{i}" for i in range(true_params["alpha"].shape[1])]],
+        true_params["alpha"].mean(axis=0), atol=0.5)
+    # sample-dict contract: defaults are 5 chains x 1000 draws
+    s = results.samples
+    assert s["cov_state_0"].shape == (5000, 1) and s["cov_det_1"].shape == (5000, 1)
+    assert s["psi"].shape == (5000, 1, 100, 1)
+    assert s["prob_detection"].shape == (5000, 52, 1, 100, 1)
+    assert "beta" not in s and "alpha" not in s
+    d = diagnostics(results.mcmc)
+    assert d["mean_r_hat"] < 1.01 and d["mean_frac_eff"] > 0.3 and d["frac_diverging"] < 0.01
+    assert results.mcmc.num_chains == 5 and results.mcmc.num_samples == 1000
+    assert results.mcmc.get_samples(group_by_chain=True)["beta"].shape == (5, 1000, 1, 2)
+
+
+def test_occu_multi_season():  # occu.py:459-475
+    data, true_params = simulate(simulate_missing=True, n_periods=3)
+    results = fit(occu, **data, num_chains=1, num_samples=300, num_warmup=300, timeout=600)
+    assert results.samples["psi"].shape == (300, 3, 100, 1)
+    assert np.allclose(results.samples["psi"].mean(), true_params["z"].mean(), atol=0.15)
+
+
+def test_fit_is_seeded():
+    data, _ = simulate(n_sites=50, random_seed=3)
+    a = fit(occu, **data, num_chains=2, num_samples=50, num_warmup=50, random_seed=1)
+    b = fit(occu, **data, num_chains=2, num_samples=50, num_warmup=50, random_seed=1)
+    c = fit(occu, **data, num_chains=2, num_samples=50, num_warmup=50, random_seed=2)
+    assert np.array_equal(a.samples["cov_state_0"], b.samples["cov_state_0"])
+    assert not np.array_equal(a.samples["cov_state_0"], c.samples["cov_state_0"])
+
+
+def test_dataframe_inputs_name_the_coefficients():
+    import pandas as pd
+    data, _ = simulate(n_sites=40, n_site_covs=2, n_obs_covs=1, deployment_days_per_site=35, random_seed=5)
+    site_df = pd.DataFrame(data["site_covs"], columns=["elev", "forest"])
+    r = fit(occu, site_covs=site_df, obs_covs=data["obs_covs"], obs=data["obs"], num_chains=1, num_samples=40, num_warmup=40)
+    assert {"cov_state_intercept", "cov_state_elev", "cov_state_forest", "cov_det_0", "cov_det_1"} <= set(r.samples)
+
+
+def test_timeout_raises_like_reference():  # fit.py:124-128 -> misc.py:11-21
+    data, _ = simulate(n_sites=5000, n_site_covs=2, n_obs_covs=2, deployment_days_per_site=70, random_seed=1)
+    t0 = time.time()
+    with pytest.raises((TimeoutException, TimeoutError)):
+        fit(occu, **data, num_chains=4, num_samples=500000, num_warmup=500000, timeout=1)
+    assert time.time() - t0 < 10

@@ -1,0 +1,152 @@
+"""Host-side mirror of the reference interface: prepare_data / rename_samples
+(biolith/utils/data.py), occu()'s validation (biolith/models/occu.py:103-133), fit()'s argument
+handling (biolith/utils/fit.py:85-104), diagnostics (biolith/evaluation/diagnostics.py)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+import oracle
+from biolith_amd.distributions import Normal
+from biolith_amd.evaluation import diagnostics, effective_sample_size, split_gelman_rubin, summary
+from biolith_amd.models import occu
+from biolith_amd.regression import AbstractRegression, LinearRegression
+from biolith_amd.utils import fit
+from biolith_amd.utils.data import prepare_data, rename_samples
+from biolith_amd.utils.mcmc import HipMCMC, LazySamples
+from conftest import load_golden
+
+
+def test_prepare_data_ndarray_shapes_and_names():
+    g = load_golden("default")
+    sc, oc, ob, sd, sn, on = prepare_data(g["site_covs"], g["obs_covs"], g["obs"])
+    assert sc.dtype == oc.dtype == ob.dtype == np.float32 and sd is None
+    assert sc.shape == (100, 1) and oc.shape == (100, 1, 52, 1) and ob.shape == (1, 100, 1, 52)
+    assert sn == ["0", "1"] and on == ["0", "1"]  # data.py:130-133
+    # season-less inputs get the period axis (data.py:113-128)
+    _, oc2, ob2, sd2, _, _ = prepare_data(None, np.zeros((5, 3)), np.zeros((5, 3)), np.ones((5, 3)))
+    assert oc2.shape == (5, 1, 3, 1) and ob2.shape == (5, 1, 3) and sd2.shape == (5, 1, 3)
+    _, oc3, _, _, _, on3 = prepare_data(None, np.zeros((5, 3, 2)))
+    assert oc3.shape == (5, 1, 3, 2) and on3 == ["0", "1", "2"]
+
+
+def test_prepare_data_dataframes_align_and_name():
+    sites = [f"s{i}" for i in range(4)]
+    site_df = pd.DataFrame({"elev": [1.0, 2, 3, 4], "forest": [0.1, 0.2, 0.3, 0.4]}, index=sites)
+    cols = pd.MultiIndex.from_product([["effort", "temp"], [0, 1, 2]])
+    obs_cov_df = pd.DataFrame(np.arange(24.0).reshape(4, 6), index=sites, columns=cols)
+    obs_df = pd.DataFrame(np.eye(4, 3), index=sites[::-1])  # reversed order: must not win
+    sc, oc, ob, _, sn, on = prepare_data(site_df, obs_cov_df, obs_df)
+    assert sn == ["intercept", "elev", "forest"] and on == ["intercept", "effort", "temp"]
+    assert oc.shape == (4, 1, 3, 2) and ob.shape == (4, 1, 3)
+    # obs is the reference frame (first DataFrame among obs, site_covs, obs_covs): others follow ITS order
+    assert np.array_equal(sc[:, 0], [4, 3, 2, 1])
+    assert np.array_equal(oc[0, 0, :, 0], obs_cov_df.loc["s3"].to_numpy()[:3])
+    assert np.array_equal(oc[0, 0, :, 1], obs_cov_df.loc["s3"].to_numpy()[3:])
+    cols3 = pd.MultiIndex.from_product([["effort"], [0, 1], [0, 1, 2]])
+    oc3 = prepare_data(None, pd.DataFrame(np.arange(24.0).reshape(4, 6), columns=cols3))[1]
+    assert oc3.shape == (4, 2, 3, 1) and oc3[1, 1, 2, 0] == 11.0
+    with pytest.raises(ValueError, match="MultiIndex"):
+        prepare_data(None, pd.DataFrame(np.zeros((4, 6))))
+
+
+def test_rename_samples():
+    s = dict(beta=np.arange(12.0).reshape(6, 1, 2), alpha=np.arange(18.0).reshape(6, 1, 3), psi=np.zeros(3))
+    r = rename_samples(s, ["0", "1"], ["intercept", "a", "b"])
+    assert set(r) == {"cov_state_0", "cov_state_1", "cov_det_intercept", "cov_det_a", "cov_det_b", "psi"}
+    assert r["cov_state_1"].shape == (6, 1) and np.array_equal(r["cov_det_b"][:, 0], s["alpha"][:, 0, 2])
+    assert "beta" in s  # input not mutated
+
+
+def test_occu_validates_like_reference():
+    g = load_golden("seed7_2x1")
+    spec = occu(g["site_covs"], g["obs_covs"], obs=g["obs"], coords=None, ell=0.0)
+    assert spec.shape == dict(S=1, N=64, T=1, J=8, Ks=2, Ko=1)
+    assert spec.prior_beta == (0.0, 1.0)
+    with pytest.raises(AssertionError, match="obs must be None or of shape"):
+        occu(g["site_covs"], g["obs_covs"], obs=g["obs"][0])
+    with pytest.raises(AssertionError, match="same number of sites"):
+        occu(g["site_covs"][:10], g["obs_covs"], obs=g["obs"])
+    with pytest.raises(AssertionError, match="cannot both be True"):
+        occu(g["site_covs"], g["obs_covs"], obs=g["obs"], false_positives_constant=True, false_positives_unoccupied=True)
+    for kw in (dict(coords=np.zeros((64, 2))), dict(false_positives_constant=True), dict(site_random_effects=True),
+               dict(obs_random_effects=True), dict(regressor_occ=AbstractRegression)):
+        with pytest.raises(NotImplementedError):
+            occu(g["site_covs"], g["obs_covs"], obs=g["obs"], **kw)
+    with pytest.raises(NotImplementedError):
+        occu(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]))
+    assert occu(g["site_covs"], g["obs_covs"], obs=g["obs"], prior_beta=Normal(0.5, 2.0)).prior_beta == (0.5, 2.0)
+
+    class Laplace:
+        loc, scale = 0.0, 1.0
+
+    with pytest.raises(NotImplementedError, match="Normal"):
+        occu(g["site_covs"], g["obs_covs"], obs=g["obs"], prior_alpha=Laplace())
+    assert LinearRegression("beta", 2).n_covs == 2
+
+
+def test_fit_argument_errors():
+    g = load_golden("seed7_2x1")
+    kw = dict(site_covs=g["site_covs"], obs_covs=g["obs_covs"], obs=g["obs"])
+    with pytest.raises(TypeError, match="biolith_amd model"):
+        fit(lambda **k: None, **kw)
+    for k in ("hmc", "mixed_hmc", "discrete_hmc_gibbs", "hmcecs"):
+        with pytest.raises(NotImplementedError):
+            fit(occu, kernel=k, **kw)
+    with pytest.raises(KeyError):
+        fit(occu, kernel="bogus", **kw)  # the reference's dict lookup raises KeyError too (fit.py:92-104)
+    with pytest.raises(NotImplementedError, match="init_strategy"):
+        fit(occu, init_strategy=lambda: None, **kw)
+
+
+def test_lazy_samples():
+    calls = []
+    s = LazySamples(a=1)
+    s.set_lazy("big", lambda: calls.append(1) or np.ones(3))
+    assert "big" in s and list(s.keys()) == ["a", "big"] and not calls
+    import copy
+    c = copy.copy(s)
+    assert c["big"].sum() == 3 and calls == [1]
+    assert s["big"].sum() == 3 and calls == [1, 1] and s["big"] is s["big"]
+
+
+class _Res:
+    def __init__(self, C, S, D, rng):
+        self.draws = rng.normal(size=(C, S, D)).astype(np.float32)
+        self.diverging = np.zeros((C, S), bool); self.diverging[0, 3] = True
+        self.num_steps = np.full((C, S), 7, np.int32)
+        self.accept_prob = np.full((C, S), 0.8, np.float32)
+        self.potential_energy = np.zeros((C, S), np.float32)
+        self.step_size = np.ones(C, np.float32); self.inv_mass = np.ones((C, D), np.float32)
+
+
+def test_mcmc_shim_and_diagnostics():
+    rng = np.random.default_rng(0)
+    res = _Res(3, 200, 4, rng)
+    beta = res.draws[:, :, :2].reshape(3, 200, 1, 2)
+    alpha = res.draws[:, :, 2:].reshape(3, 200, 1, 2)
+    m = HipMCMC(res, dict(beta=beta, alpha=alpha), dict(psi=np.zeros((3, 200, 1, 5, 1)), prob_detection=lambda: np.ones((3, 200, 2, 1, 5, 1))),
+                num_warmup=10, spec_shape={})
+    assert m.num_chains == 3 and m.num_samples == 200
+    s = m.get_samples()
+    assert s["beta"].shape == (600, 1, 2) and s["psi"].shape == (600, 1, 5, 1) and s["prob_detection"].shape == (600, 2, 1, 5, 1)
+    assert m.get_samples(group_by_chain=True)["alpha"].shape == (3, 200, 1, 2)
+    assert m.get_extra_fields()["diverging"].shape == (600,)
+    d = diagnostics(m)  # reads _states/_sample_field/_last_state like diagnostics.py:10-13
+    assert set(d) == {"mean_r_hat", "mean_frac_eff", "frac_diverging", "mean_beta_sd", "mean_alpha_sd"}
+    assert d["frac_diverging"] == pytest.approx(1 / 600) and 0.9 < d["mean_r_hat"] < 1.1 and 0.6 < d["mean_frac_eff"] < 1.5
+    assert d["mean_beta_sd"] == pytest.approx(1.0, abs=0.1)
+    m.print_summary()
+
+
+def test_ess_and_rhat_against_oracle_restatement():
+    rng = np.random.default_rng(5)
+    x = np.zeros((4, 500, 3, 2))
+    for t in range(1, 500):
+        x[:, t] = 0.7 * x[:, t - 1] + rng.normal(size=(4, 3, 2))
+    assert np.allclose(effective_sample_size(x), oracle.effective_sample_size(x), rtol=1e-10)
+    assert np.allclose(split_gelman_rubin(x), oracle.split_gelman_rubin(x), rtol=1e-12)
+    assert np.allclose(effective_sample_size(x[:1]), oracle.effective_sample_size(x[:1]), rtol=1e-10)
+    # AR(1), rho=.7: ESS ~ n (1-rho)/(1+rho)
+    assert abs(effective_sample_size(x).mean() / (2000 * 0.3 / 1.7) - 1) < 0.25
+    t = summary(dict(x=x))
+    assert t["x"]["n_eff"].shape == (3, 2) and "5.0%" in t["x"] and "95.0%" in t["x"]
