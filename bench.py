@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: effective samples / second of psi for occu NUTS on 10k sites x 5 visits.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete pass of the hot path over the workload BASELINE.json's metric is quoted
+on (its configs[1]): simulate(n_sites=10000, 3 site + 3 obs covariates, 5 visits), 4 chains per
+GPU x (1000 warmup + 1000 draws) of NUTS, i.e. exactly what ``fit(occu, **data, num_chains=4)``
+runs behind the C-ABI.  The dataset is resident in HBM before the timed region.  With N > 1 GPUs
+every rank runs its own 4 chains (weak scaling; chains are the unit the path shards over, no
+data-path collective) and the draws are all-gathered over RCCL inside the timed region.
+ESS is computed afterwards with the NumPyro estimator (mean over sites of per-site ESS of psi).
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG2 = dict(n_sites=10000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=35, session_duration=7, random_seed=0)
+CHAINS_PER_GPU, NUM_WARMUP, NUM_SAMPLES = 4, 1000, 1000
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes_per_eval(N, T, J, Ks, Ko, S=1):
+    """float32 bytes one potential+gradient evaluation of one chain must read."""
+    return 4 * (N * Ks + N * T * J * Ko + S * N * T * J)
+
+
+def psi_draws(draws, X):
+    """draws (C, S, D) -> psi (C, S, N) float32 = sigmoid(beta0 + X beta)  (occu.py:198-207)."""
+    Ks = X.shape[1]
+    eta = draws[..., :1] + draws[..., 1:Ks + 1] @ X.T
+    return (1.0 / (1.0 + np.exp(-eta))).astype(np.float32)
+
+
+class _DevArray:
+    """Expose an engine-owned device buffer to torch (for the RCCL gather) without a copy."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr="<f4", data=(int(ptr), False), version=2)
+
+
+def cpu_baseline(data, threads):
+    """Oracle (port of the same algorithm, float64 C) on host cores, bounded sample of the workload."""
+    import oracle
+    from biolith_amd.evaluation import effective_sample_size
+
+    od = oracle.OracleData(data["site_covs"], data["obs_covs"], data["obs"])
+    w, s = 250, 250
+    t0 = time.perf_counter()
+    r = oracle.nuts_run(od, w, s, num_chains=CHAINS_PER_GPU, seed=0, threads=threads)
+    wall = time.perf_counter() - t0
+    X = np.asarray(data["site_covs"], dtype=np.float32).astype(np.float64)
+    ess = float(effective_sample_size(psi_draws(r["draws"], X)).mean())
+    nleap = int(r["n_leapfrog"].sum())
+    return dict(value=ess / wall, unit="ESS/s", cores=int(r["threads"]), kind="port",
+                sample=f"oracle NUTS (float64 C restatement), same data, {CHAINS_PER_GPU} chains x ({w} warmup + {s} draws) "
+                       f"on {int(r['threads'])} threads: {wall:.1f} s, {nleap} gradient evaluations, "
+                       f"{1e3 * wall * int(r['threads']) / nleap:.2f} ms per evaluation per core, ESS(psi) {ess:.0f}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--wgs-per-chain", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from biolith_amd.distributed import gather_draws
+    from biolith_amd.engine import OccuDataset
+    from biolith_amd.evaluation import effective_sample_size, split_gelman_rubin
+    from biolith_amd.models import simulate
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        data, truth = simulate(**CFG2)
+    X = np.asarray(data["site_covs"], dtype=np.float32).astype(np.float64)
+    ds = OccuDataset(data["site_covs"], data["obs_covs"], data["obs"], device=local_rank)  # resident in HBM from here on
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step(step_seed):
+        ds.launch(num_warmup=NUM_WARMUP, num_samples=NUM_SAMPLES, num_chains=CHAINS_PER_GPU, seed=step_seed,
+                  chain_offset=rank * CHAINS_PER_GPU, wgs_per_chain=args.wgs_per_chain, stream=stream)
+        ds.wait()
+        res = ds.fetch()
+        draws_all = res.draws
+        if dist is not None:
+            ptr, _ = ds.device_draws()
+            local = torch.as_tensor(_DevArray(ptr, res.draws.shape), device=f"cuda:{local_rank}")
+            draws_all = gather_draws(local).cpu().numpy()  # RCCL all-gather: the path's only collective
+        return res, draws_all
+
+    for w in range(args.warmup):
+        one_step(10_000 + w)
+    sync_all()
+    t0 = time.perf_counter()
+    steps = [one_step(s) for s in range(args.steps)]
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-rank kernel statistics (HIP events on the launch stream, recorded inside the timed region)
+    kernel_ms = np.array([r.kernel_ms for r, _ in steps])
+    leap = np.array([int(r.n_leapfrog.sum()) + CHAINS_PER_GPU for r, _ in steps])  # + the initial evaluation of each chain
+    if dist is not None:
+        agg = torch.tensor([kernel_ms.mean(), leap.mean()], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        kernel_ms_mean, leap_mean = float(agg[0].item()) / world, float(agg[1].item()) / world
+    else:
+        kernel_ms_mean, leap_mean = float(kernel_ms.mean()), float(leap.mean())
+
+    if rank == 0:
+        # ---- metric numerator: ESS(psi), NumPyro estimator, mean over sites (diagnostics.py:28-32) ----
+        ess_psi, ess_coef, rhat = [], [], []
+        for _, d in steps:
+            ess_psi.append(float(effective_sample_size(psi_draws(d.astype(np.float64), X)).mean()))
+            ess_coef.append(effective_sample_size(d).min())
+            rhat.append(float(split_gelman_rubin(d).max()))
+        total_ess = float(np.sum(ess_psi))
+        N, T, J, Ks, Ko = ds.N, ds.T, ds.J, ds.Ks, ds.Ko
+        bytes_eval = algorithmic_bytes_per_eval(N, T, J, Ks, Ko)
+        res0 = steps[0][0]
+        achieved = leap_mean * bytes_eval / (kernel_ms_mean * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "effective samples/sec (psi) for occu NUTS, 10k sites x 5 visits",
+            "value": total_ess / elapsed,
+            "unit": "ESS/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "biolith simulate(n_sites=10000, n_site_covs=3, n_obs_covs=3, 5 visits, seed 0); "
+                            "fit(occu): NUTS 4 chains per GPU x (1000 warmup + 1000 draws), one step = one full fit",
+                "chains_per_gpu": CHAINS_PER_GPU, "total_chains": CHAINS_PER_GPU * world,
+                "num_warmup": NUM_WARMUP, "num_samples": NUM_SAMPLES, "parallelism": f"chains x{world} (1 process per GPU)",
+                "wgs_per_chain": res0.wgs_per_chain, "threads_per_wg": 512, "lds_staged": res0.lds_staged,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel": "bl_nuts_kernel<3,3,true>", "kernel_ms": kernel_ms_mean,
+                "algorithmic_bytes_per_launch": leap_mean * bytes_eval, "bytes_per_gradient_evaluation": bytes_eval,
+                "gradient_evaluations_per_launch": leap_mean,
+                "us_per_leapfrog_per_chain": 1e3 * kernel_ms_mean / (leap_mean / CHAINS_PER_GPU),
+                "note": "data is LDS-resident after one HBM read, so this is an effective (algorithmic) bandwidth; "
+                        "the sequential-leapfrog latency is the real bound",
+            },
+            "ess": {"psi_mean_over_sites_per_step": ess_psi, "min_coef_per_step": [float(x) for x in ess_coef],
+                    "max_split_rhat": max(rhat), "draws_per_step": CHAINS_PER_GPU * world * NUM_SAMPLES},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(data, threads=min(CHAINS_PER_GPU, os.cpu_count() or 1))
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
