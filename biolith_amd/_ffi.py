@@ -10,7 +10,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbiolith_hip.so")
+LIB_PATH = os.environ.get("BIOLITH_HIP_LIB") or os.path.join(_HERE, "lib", "libbiolith_hip.so")
 
 BL_OK, BL_ERR_INVALID, BL_ERR_NO_DEVICE, BL_ERR_UNSUPPORTED, BL_ERR_TIMEOUT, BL_ERR_ABORTED, BL_ERR_BUSY = range(7)
 RNG_STREAMS_PER_CHAIN = 64
@@ -57,7 +57,7 @@ EXPORTS = (
     "bl_abi_version", "bl_last_error", "bl_device_count", "bl_dataset_create", "bl_dataset_destroy",
     "bl_dataset_param_dim", "bl_logp_grad", "bl_nuts_run", "bl_nuts_launch", "bl_nuts_poll",
     "bl_nuts_abort", "bl_nuts_wait", "bl_nuts_fetch", "bl_nuts_elapsed_ms", "bl_nuts_device_draws",
-    "bl_nuts_geometry", "bl_deterministic", "bl_rng_streams", "bl_adaptation_schedule",
+    "bl_nuts_geometry", "bl_nuts_debug_counters", "bl_deterministic", "bl_rng_streams", "bl_adaptation_schedule",
 )
 
 _lib = None
@@ -96,6 +96,7 @@ def load():
         L.bl_nuts_elapsed_ms.argtypes = [vp, fp]
         L.bl_nuts_device_draws.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
         L.bl_nuts_geometry.argtypes = [vp, ip, ip, ip, ip]
+        L.bl_nuts_debug_counters.argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
         L.bl_deterministic.argtypes = [vp, C.c_int, fp, fp, fp]
         L.bl_rng_streams.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
         L.bl_adaptation_schedule.argtypes = [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]

@@ -38,8 +38,12 @@ static int bl_fail(int code, const char *fmt, ...)
     } while (0)
 
 // ------------------------------------------- kernel instantiation dispatch ----
+#ifdef BL_STAMPS /* diagnostic build: one instantiation */
+#define BL_KK_LIST(X) X(3, 3)
+#else
 #define BL_K_LIST(X, a) X(a, 1) X(a, 2) X(a, 3) X(a, 4) X(a, 8) X(a, 16)
 #define BL_KK_LIST(X) BL_K_LIST(X, 1) BL_K_LIST(X, 2) BL_K_LIST(X, 3) BL_K_LIST(X, 4) BL_K_LIST(X, 8) BL_K_LIST(X, 16)
+#endif
 #define BL_DECL(ks, ko)                                                                                        \
     extern "C" int bl_launch_nuts_##ks##_##ko(const BlNutsParams *, int, int, int, hipStream_t);               \
     extern "C" int bl_launch_logp_##ks##_##ko(const BlLogpParams *, int, int, int, hipStream_t);
@@ -162,7 +166,7 @@ struct bl_dataset {
     float *d_draws = nullptr, *d_acc = nullptr, *d_pot = nullptr, *d_eps = nullptr, *d_minv = nullptr, *d_init = nullptr;
     unsigned char *d_div = nullptr;
     int *d_steps = nullptr, *d_status = nullptr;
-    long long *d_nleap = nullptr;
+    long long *d_nleap = nullptr, *d_dbg = nullptr;
     uint32_t *d_rng = nullptr;
     unsigned long long *d_xchg = nullptr;
     size_t xchg_bytes = 0;
@@ -428,7 +432,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     const size_t o_draws = carve((size_t)C * Sa * D * 4), o_div = carve((size_t)C * Sa), o_steps = carve((size_t)C * Sa * 4),
                  o_acc = carve((size_t)C * Sa * 4), o_pot = carve((size_t)C * Sa * 4), o_eps = carve((size_t)C * 4),
                  o_minv = carve((size_t)C * D * 4), o_nleap = carve((size_t)C * 16), o_status = carve(16),
-                 o_rng = carve((size_t)C * BL_RNG_STREAMS_PER_CHAIN * 16), o_init = carve((size_t)C * D * 4);
+                 o_rng = carve((size_t)C * BL_RNG_STREAMS_PER_CHAIN * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(16 * 8);
     if (off > ds->run_bytes) {
         if (ds->d_run) hipFree(ds->d_run);
         ds->d_run = nullptr; ds->run_bytes = 0;
@@ -439,7 +443,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     ds->d_draws = (float *)(base + o_draws); ds->d_div = (unsigned char *)(base + o_div); ds->d_steps = (int *)(base + o_steps);
     ds->d_acc = (float *)(base + o_acc); ds->d_pot = (float *)(base + o_pot); ds->d_eps = (float *)(base + o_eps);
     ds->d_minv = (float *)(base + o_minv); ds->d_nleap = (long long *)(base + o_nleap); ds->d_status = (int *)(base + o_status);
-    ds->d_rng = (uint32_t *)(base + o_rng); ds->d_init = (float *)(base + o_init);
+    ds->d_rng = (uint32_t *)(base + o_rng); ds->d_init = (float *)(base + o_init); ds->d_dbg = (long long *)(base + o_dbg);
     const size_t xb = align256((size_t)C * 2 * k * nvp * 8);
     if (xb > ds->xchg_bytes) {
         if (ds->d_xchg) hipFree(ds->d_xchg);
@@ -479,11 +483,13 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.spin_limit = 1u << 18;
     p.draws = ds->d_draws; p.diverging = ds->d_div; p.num_steps = ds->d_steps; p.accept_prob = ds->d_acc;
     p.potential = ds->d_pot; p.step_size = ds->d_eps; p.inv_mass = ds->d_minv; p.nleap = ds->d_nleap; p.status = ds->d_status;
+    p.dbg = ds->d_dbg;
 
     // timed region: state re-init (guide G16 "re-initialise every call") + the persistent kernel
     BL_HIP(hipEventRecord(ds->ev0, st));
     BL_HIP(hipMemsetAsync(ds->d_xchg, 0, xb, st));
     BL_HIP(hipMemsetAsync(ds->d_status, 0, 16, st));
+    BL_HIP(hipMemsetAsync(ds->d_dbg, 0, 128, st));
     const int lrc = ds->kern->nuts(&p, C * k, lds_bytes, staged, st);
     if (lrc != 0) return bl_fail(BL_ERR_NO_DEVICE, "NUTS kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     BL_HIP(hipEventRecord(ds->ev1, st));
@@ -569,6 +575,14 @@ extern "C" int bl_nuts_device_draws(bl_dataset *ds, void **dev_ptr, size_t *byte
     if (!ds->have_run) return bl_fail(BL_ERR_INVALID, "no NUTS launch on this handle");
     *dev_ptr = ds->d_draws;
     *bytes = (size_t)ds->C * ds->S * ds->D * 4;
+    return BL_OK;
+}
+
+extern "C" int bl_nuts_debug_counters(bl_dataset *ds, int64_t *out, int n)
+{
+    if (!ds || !out || n <= 0 || n > 16) return bl_fail(BL_ERR_INVALID, "bad argument");
+    if (!ds->have_run || ds->in_flight) return bl_fail(BL_ERR_BUSY, "no finished NUTS launch");
+    BL_HIP(hipMemcpy(out, ds->d_dbg, (size_t)n * 8, hipMemcpyDeviceToHost));
     return BL_OK;
 }
 

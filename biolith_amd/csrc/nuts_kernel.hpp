@@ -20,6 +20,16 @@
 #pragma once
 #include "occu_device.hpp"
 
+// In-kernel phase stamps (guide section 7 "In-kernel stamps"): diagnostic builds only
+// (make stamps); the shipped kernel executes none of this.
+#ifdef BL_STAMPS
+#define BL_STAMP_DECL long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long st_prev = (long long)clock64(); long long st_rt0 = (long long)wall_clock64();
+#define BL_STAMP(i) { const long long st_now = (long long)clock64(); st_acc[i] += st_now - st_prev; st_prev = st_now; }
+#else
+#define BL_STAMP_DECL
+#define BL_STAMP(i)
+#endif
+
 struct BlNutsParams {
     BlDevData dd;
     int num_warmup, num_samples, num_chains;
@@ -46,6 +56,7 @@ struct BlNutsParams {
     float *inv_mass;               // [C][D]
     long long *nleap;              // [C][2]
     int *status;                   // [1]
+    long long *dbg;                // [16] phase cycle counters (diagnostic BL_STAMPS builds only; else unused)
 };
 
 __device__ __forceinline__ float bl_logaddexp(float a, float b)
@@ -131,6 +142,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
     __syncthreads();
 
     unsigned epoch = 0;
+    BL_STAMP_DECL
     while (true) {
         // ------------------------------------------- phase A: all waves, site log-lik ----
         float beta[KS + 1], alpha[KO + 1];
@@ -142,7 +154,9 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
         for (int k = 0; k <= KO; k++) ga[k] = 0.0f;
         bl_eval_sites<KS, KO, LDS>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga);
         bl_wave_partials_to_lds<KS, KO>(Ks, Ko, ll, gb, ga);
+        BL_STAMP(0)
         __syncthreads();
+        BL_STAMP(1)
 
         if (wave == 0) {
             epoch++;
@@ -170,6 +184,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
                 __hip_atomic_store(rec + (size_t)member * nvp + lane,
                                    ((unsigned long long)epoch << 32) | __float_as_uint(comp),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            BL_STAMP(2)
             const int c_idx = lane & (nvp - 1), sub = lane / nvp;
             double acc = 0.0;
             bool timed_out = false;
@@ -210,6 +225,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
             if (timed_out) flag = 4;       // BL_ERR_TIMEOUT
             else if (abort_req) flag = 5;  // BL_ERR_ABORTED
 
+            BL_STAMP(3)
             // ------------------------------------------------ potential at cz (lane d) ----
             const float dth = cz - prior_loc;
             const double Un = -ll_tot + (double)(0.5f * bl_wave_sum(act ? dth * dth * prior_isc2 : 0.0f)) + p.dd.prior_const;
@@ -353,6 +369,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
             }
             sh_theta[lane] = act ? cz : 0.0f;
             if (lane == 0) sh_flag[0] = flag;
+            BL_STAMP(4)
             if (flag != 0 && member == 0) {
                 if (flag > 1 && lane == 0) atomicMax(p.status, flag);
                 if (act) p.inv_mass[chain * D + lane] = minv;
@@ -364,6 +381,14 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
             }
         }
         __syncthreads();
+        BL_STAMP(5)
         if (sh_flag[0] != 0) break;
     }
+#ifdef BL_STAMPS
+    if (p.dbg && blockIdx.x == 0 && tid == 0) {
+        for (int i = 0; i < 8; i++) p.dbg[i] = st_acc[i];
+        p.dbg[8] = (long long)epoch;
+        p.dbg[9] = (long long)wall_clock64() - st_rt0;
+    }
+#endif
 }

@@ -141,6 +141,12 @@ class OccuDataset:
         _ffi.check(self._lib.bl_nuts_elapsed_ms(self._h, C.byref(ms)))
         return float(ms.value)
 
+    def debug_counters(self, n: int = 16):
+        """In-kernel phase cycle counters (zeros unless a BL_STAMPS diagnostic library is loaded)."""
+        out = np.zeros(n, dtype=np.int64)
+        _ffi.check(self._lib.bl_nuts_debug_counters(self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), n))
+        return out
+
     def device_draws(self):
         """(device pointer, bytes) of the last launch's draws [C][S][D] float32."""
         p, n = C.c_void_p(), C.c_size_t()

@@ -124,6 +124,10 @@ int bl_nuts_device_draws(bl_dataset *ds, void **dev_ptr, size_t *bytes);
 /* Geometry the last launch used. */
 int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads_per_wg, int *lds_bytes, int *lds_staged);
 
+/* In-kernel phase cycle counters of the last launch; all zero unless the library is a diagnostic
+ * BL_STAMPS build (make -C biolith_amd/csrc stamps).  Not part of the reference's interface. */
+int bl_nuts_debug_counters(bl_dataset *ds, int64_t *out /*[n<=16]*/, int n);
+
 /*
  * Deterministic sites (occu.py:207, 221-228), recomputed from draws on the device:
  *   psi            [n_draws][T][N]      = sigmoid(beta_0 + X beta)       (constant over T)

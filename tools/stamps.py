@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Phase breakdown of one leapfrog tick from the BL_STAMPS diagnostic build (shares, not run time).
+   make -C biolith_amd/csrc stamps && BIOLITH_HIP_LIB=biolith_amd/lib/libbiolith_hip_stamps.so python tools/stamps.py"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("BIOLITH_HIP_LIB", os.path.join(ROOT, "biolith_amd", "lib", "libbiolith_hip_stamps.so"))
+from biolith_amd.engine import OccuDataset  # noqa: E402
+from biolith_amd.models import simulate  # noqa: E402
+
+NAMES = ["A compute+wave-reduce", "barrier1", "wg partial+publish", "sweep (poll)", "control", "barrier2"]
+
+
+def main():
+    with contextlib.redirect_stdout(io.StringIO()):
+        data, _ = simulate(n_sites=10000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=35, session_duration=7)
+    ds = OccuDataset(data["site_covs"], data["obs_covs"], data["obs"])
+    ks = [int(a) for a in sys.argv[1:]] or [0]
+    for k in ks:
+        for chains in (4,):
+            r = ds.nuts(num_warmup=1000, num_samples=1000, num_chains=chains, seed=0, wgs_per_chain=k)
+            c = ds.debug_counters()
+            ticks, rt = int(c[8]), int(c[9])
+            tot = c[:6].sum()
+            mhz = tot / (rt / 100.0) if rt else float("nan")  # s_memrealtime ticks at 100 MHz
+            print(f"k={r.wgs_per_chain} chains={chains} kernel {r.kernel_ms:.1f} ms ticks {ticks} "
+                  f"cycles/tick {tot / max(ticks, 1):.0f} clock {mhz:.0f} MHz us/tick {r.kernel_ms * 1e3 / max(ticks, 1):.2f}")
+            for n, v in zip(NAMES, c[:6]):
+                print(f"    {n:26s} {v / max(ticks, 1):8.0f} cyc  {100.0 * v / tot:5.1f} %")
+
+
+if __name__ == "__main__":
+    main()
