@@ -95,7 +95,7 @@ def load():
         L.bl_nuts_fetch.argtypes = [vp, C.POINTER(bl_nuts_output)]
         L.bl_nuts_elapsed_ms.argtypes = [vp, fp]
         L.bl_nuts_device_draws.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
-        L.bl_nuts_geometry.argtypes = [vp, ip, ip, ip, ip]
+        L.bl_nuts_geometry.argtypes = [vp, ip, ip, ip, ip, ip]
         L.bl_nuts_debug_counters.argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
         L.bl_deterministic.argtypes = [vp, C.c_int, fp, fp, fp]
         L.bl_rng_streams.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint32)]

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -167,6 +168,7 @@ struct bl_dataset {
     unsigned char *d_div = nullptr;
     int *d_steps = nullptr, *d_status = nullptr;
     long long *d_nleap = nullptr, *d_dbg = nullptr;
+    int *d_loc = nullptr;
     uint32_t *d_rng = nullptr;
     unsigned long long *d_xchg = nullptr;
     size_t xchg_bytes = 0;
@@ -329,9 +331,10 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
                             int *lds_bytes_out, int *staged_out)
 {
     const int N = ds->dims.n_sites;
-    int kmax = 256 / (chains > 0 ? chains : 1);
+    // chains are dealt to the 8 XCDs (32 CUs each); a chain's k workgroups share one XCD, one per CU
+    const int per_xcd = ((chains > 0 ? chains : 1) + 7) / 8;
+    int kmax = 32 / per_xcd;
     if (kmax < 1) kmax = 1;
-    if (kmax > 64) kmax = 64;
     int k = want_k > 0 ? want_k : (N + BL_THREADS - 1) / BL_THREADS;
     if (k > kmax) k = kmax;
     if (k < 1) k = 1;
@@ -423,7 +426,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
 
     int k, nloc, ld, lds_bytes, staged;
     choose_geometry(ds, C, cfg->wgs_per_chain, &k, &nloc, &ld, &lds_bytes, &staged);
-    const int nvp = (D + 3 <= 16) ? 16 : (D + 3 <= 32 ? 32 : 64);
+    const int nvp = (D + 5 <= 16) ? 16 : (D + 5 <= 32 ? 32 : 64);
 
     // ---- (re)allocate run slab ----
     size_t off = 0;
@@ -432,7 +435,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     const size_t o_draws = carve((size_t)C * Sa * D * 4), o_div = carve((size_t)C * Sa), o_steps = carve((size_t)C * Sa * 4),
                  o_acc = carve((size_t)C * Sa * 4), o_pot = carve((size_t)C * Sa * 4), o_eps = carve((size_t)C * 4),
                  o_minv = carve((size_t)C * D * 4), o_nleap = carve((size_t)C * 16), o_status = carve(16),
-                 o_rng = carve((size_t)C * BL_RNG_STREAMS_PER_CHAIN * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(16 * 8);
+                 o_rng = carve((size_t)C * BL_RNG_STREAMS_PER_CHAIN * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(16 * 8), o_loc = carve((size_t)C * 4);
     if (off > ds->run_bytes) {
         if (ds->d_run) hipFree(ds->d_run);
         ds->d_run = nullptr; ds->run_bytes = 0;
@@ -443,7 +446,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     ds->d_draws = (float *)(base + o_draws); ds->d_div = (unsigned char *)(base + o_div); ds->d_steps = (int *)(base + o_steps);
     ds->d_acc = (float *)(base + o_acc); ds->d_pot = (float *)(base + o_pot); ds->d_eps = (float *)(base + o_eps);
     ds->d_minv = (float *)(base + o_minv); ds->d_nleap = (long long *)(base + o_nleap); ds->d_status = (int *)(base + o_status);
-    ds->d_rng = (uint32_t *)(base + o_rng); ds->d_init = (float *)(base + o_init); ds->d_dbg = (long long *)(base + o_dbg);
+    ds->d_rng = (uint32_t *)(base + o_rng); ds->d_init = (float *)(base + o_init); ds->d_dbg = (long long *)(base + o_dbg); ds->d_loc = (int *)(base + o_loc);
     const size_t xb = align256((size_t)C * 2 * k * nvp * 8);
     if (xb > ds->xchg_bytes) {
         if (ds->d_xchg) hipFree(ds->d_xchg);
@@ -481,6 +484,13 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.xchg = ds->d_xchg;
     p.abort_flag = ds->d_abort;
     p.spin_limit = 1u << 18;
+    {   // developer knobs (A/B measurements): exchange form and poll spacing
+        const char *e1 = getenv("BIOLITH_HIP_NO_LOCAL"), *e2 = getenv("BIOLITH_HIP_POLL_SLEEP");
+        p.allow_local = (e1 && e1[0] == '1') ? 0 : 1;
+        p.poll_sleep = e2 ? atoi(e2) : 6;
+        if (p.poll_sleep < 0 || p.poll_sleep > 127) p.poll_sleep = 6;
+    }
+    p.xcd_local = ds->d_loc;
     p.draws = ds->d_draws; p.diverging = ds->d_div; p.num_steps = ds->d_steps; p.accept_prob = ds->d_acc;
     p.potential = ds->d_pot; p.step_size = ds->d_eps; p.inv_mass = ds->d_minv; p.nleap = ds->d_nleap; p.status = ds->d_status;
     p.dbg = ds->d_dbg;
@@ -490,7 +500,9 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     BL_HIP(hipMemsetAsync(ds->d_xchg, 0, xb, st));
     BL_HIP(hipMemsetAsync(ds->d_status, 0, 16, st));
     BL_HIP(hipMemsetAsync(ds->d_dbg, 0, 128, st));
-    const int lrc = ds->kern->nuts(&p, C * k, lds_bytes, staged, st);
+    BL_HIP(hipMemsetAsync(ds->d_loc, 0, (size_t)C * 4, st));
+    const int grid = 8 * k * ((C + 7) / 8); // XCD-aware mapping in the kernel; surplus blocks exit at once
+    const int lrc = ds->kern->nuts(&p, grid, lds_bytes, staged, st);
     if (lrc != 0) return bl_fail(BL_ERR_NO_DEVICE, "NUTS kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     BL_HIP(hipEventRecord(ds->ev1, st));
     ds->stream = st; ds->in_flight = true; ds->have_run = true;
@@ -586,7 +598,8 @@ extern "C" int bl_nuts_debug_counters(bl_dataset *ds, int64_t *out, int n)
     return BL_OK;
 }
 
-extern "C" int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads_per_wg, int *lds_bytes, int *lds_staged)
+extern "C" int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads_per_wg, int *lds_bytes, int *lds_staged,
+                                int *chains_on_l2_local_exchange)
 {
     if (!ds) return bl_fail(BL_ERR_INVALID, "NULL argument");
     if (!ds->have_run) return bl_fail(BL_ERR_INVALID, "no NUTS launch on this handle");
@@ -594,6 +607,14 @@ extern "C" int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads
     if (threads_per_wg) *threads_per_wg = BL_THREADS;
     if (lds_bytes) *lds_bytes = ds->lds_bytes;
     if (lds_staged) *lds_staged = ds->staged;
+    if (chains_on_l2_local_exchange) {
+        *chains_on_l2_local_exchange = 0;
+        if (!ds->in_flight) {
+            std::vector<int> loc(ds->C, 0);
+            BL_HIP(hipMemcpy(loc.data(), ds->d_loc, (size_t)ds->C * 4, hipMemcpyDeviceToHost));
+            for (int v : loc) *chains_on_l2_local_exchange += v;
+        }
+    }
     return BL_OK;
 }
 

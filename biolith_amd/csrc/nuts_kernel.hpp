@@ -6,14 +6,23 @@
 // between subtrees), dual-averaging step size, windowed Welford diagonal mass matrix.
 //
 // Mapping to the chip
-//   * one chain = k cooperating workgroups (512 threads each, ~1 per CU); a workgroup owns a
+//   * one chain = k cooperating workgroups (512 threads each, one per CU); a workgroup owns a
 //     contiguous slice of sites, staged ONCE into LDS (site-fastest rows; see occu_device.hpp);
+//   * blockIdx -> (chain, member) is XCD-aware: blocks b and b+8 share an XCD under the observed
+//     round-robin dealing, so chain c takes the blocks with b % 8 == c % 8 and its k workgroups
+//     share one L2.  That is a SPEED arrangement only: every workgroup reads HW_REG_XCC_ID and the
+//     chain switches to the L2-local exchange (below) only if the first, placement-independent
+//     exchange proves that all k workgroups really sit on one XCD;
 //   * every leapfrog ("tick"): all 8 waves evaluate their sites' log-lik + gradient from LDS ->
 //     DPP wave reduction -> LDS -> workgroup partial (D grads f32, log-lik as hi+lo f32 pair);
-//   * the k partials are all-gathered through 8-byte {epoch, value} granules written with ONE
-//     sc1 store each and polled with relaxed agent-scope loads (guide G16, form R2: the data is
-//     the flag; placement independent).  Every workgroup sums the k partials in the same fixed
-//     order in f64, so all k copies of the chain state stay bit-identical without any broadcast;
+//   * the k partials are all-gathered through 8-byte {epoch, value} granules (guide G16, form R2:
+//     the data is the flag), double-buffered by epoch parity, every spin bounded:
+//       - placement-independent form: ONE sc1 (write-through) store per granule, relaxed
+//         agent-scope (sc1) polls, two poll rounds in flight half a fabric round trip apart;
+//       - L2-local form (verified same-XCD chains only): workgroup-scope stores keep the line in
+//         the XCD's L2, sc1 polls bypass L1 and hit that L2: ~5x shorter hop;
+//     every workgroup sums the k records in the same fixed order in f64, so all k copies of the
+//     chain state stay bit-identical without any broadcast;
 //   * wave 0 of every workgroup then advances the (replicated) NUTS state machine by one leaf,
 //     lane d holding dimension d, and publishes the next position to its workgroup through LDS.
 // No host round trip, no kernel boundary and no HBM traffic inside the sampling loop.
@@ -37,11 +46,13 @@ struct BlNutsParams {
     int nloc;     // sites per workgroup
     int lds_ld;   // LDS row stride (floats) when staged
     int n_rows;   // rows of the data matrix
-    int nvp;      // granules per workgroup record: 16, 32 or 64 (>= D+3)
+    int nvp;      // granules per workgroup record: 16, 32 or 64 (>= D+5)
     int max_depth;
     float target_accept;
     int nwin;
     int win_end[32];               // numpyro adaptation windows (inclusive ends)
+    int allow_local;               // 0: always use the placement-independent exchange
+    int poll_sleep;                // s_sleep units between the two in-flight poll rounds
     const uint32_t *rng;           // [C][64][4] xoshiro states (host-jumped)
     const float *init_theta;       // [C][D] or null -> Uniform(-2,2)
     unsigned long long *xchg;      // [C][2][k][nvp] granules, zeroed before every launch
@@ -56,7 +67,8 @@ struct BlNutsParams {
     float *inv_mass;               // [C][D]
     long long *nleap;              // [C][2]
     int *status;                   // [1]
-    long long *dbg;                // [16] phase cycle counters (diagnostic BL_STAMPS builds only; else unused)
+    int *xcd_local;                // [C] 1 if the chain ran on the L2-local exchange
+    long long *dbg;                // [16] phase cycle counters (diagnostic BL_STAMPS builds only)
 };
 
 __device__ __forceinline__ float bl_logaddexp(float a, float b)
@@ -70,15 +82,42 @@ __device__ __forceinline__ float bl_logaddexp(float a, float b)
 __device__ __forceinline__ bool bl_is_turning(float minv, float rl, float rr, float rsum)
 {
     const float rho = rsum - 0.5f * (rl + rr);
-    const float dl = bl_wave_sum(minv * rl * rho);
-    const float dr = bl_wave_sum(minv * rr * rho);
+    float dl = minv * rl * rho, dr = minv * rr * rho;
+    bl_wave_sum2(dl, dr);
     return (dl <= 0.0f) || (dr <= 0.0f);
 }
+
+__device__ __forceinline__ unsigned bl_xcc_id()
+{
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 0xFu;
+}
+
+// One poll round: every lane loads its granule of up to 8 records (sc1: bypasses L1).
+#define BL_POLL_ISSUE(buf)                                                                                       \
+    _Pragma("unroll") for (int q = 0; q < 8; q++) {                                                              \
+        const int w_ = p0 + q * G + sub;                                                                         \
+        buf[q] = 0ull;                                                                                           \
+        if (w_ < p.k) buf[q] = __hip_atomic_load(rec + (size_t)w_ * nvp + c_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    }
+#define BL_POLL_CHECK(buf, okv)                                                                                  \
+    {                                                                                                            \
+        bool ok_ = true;                                                                                         \
+        _Pragma("unroll") for (int q = 0; q < 8; q++) {                                                          \
+            const int w_ = p0 + q * G + sub;                                                                     \
+            if (w_ < p.k) ok_ = ok_ && ((unsigned)(buf[q] >> 32) == epoch);                                      \
+        }                                                                                                        \
+        okv = __all(ok_);                                                                                        \
+    }
 
 template <int KS, int KO, bool LDS>
 __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams p)
 {
-    const int chain = blockIdx.x / p.k, member = blockIdx.x - chain * p.k;
+    // XCD-aware mapping (speed only; see header): label = b % 8 names a set of blocks that share an XCD
+    const int label = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int chain = label + 8 * (slot / p.k), member = slot % p.k;
+    if (chain >= p.num_chains) return; // whole block leaves before any barrier or exchange
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int Ks = p.dd.Ks, Ko = p.dd.Ko, D = Ks + Ko + 2;
     const int T = p.dd.T, J = p.dd.J;
@@ -126,8 +165,10 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
     float cz = 0, rh = 0;
     int it = -1; // -1: evaluating the initial position
     long long nleap_w = 0, nleap_s = 0;
+    bool local = false; // L2-local exchange proven safe for this chain
     const float prior_loc = (lane <= Ks) ? p.dd.loc_b : p.dd.loc_a;
     const float prior_isc2 = act ? ((lane <= Ks) ? p.dd.isc2_b : p.dd.isc2_a) : 0.0f;
+    const float xcc = (float)bl_xcc_id();
 
     if (wave == 0) {
         const uint32_t *rs = p.rng + ((size_t)chain * BL_NSTREAM + lane) * 4;
@@ -147,12 +188,14 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
         // ------------------------------------------- phase A: all waves, site log-lik ----
         float beta[KS + 1], alpha[KO + 1];
         bl_load_coefs<KS, KO>(sh_theta, Ks, Ko, beta, alpha);
+        BL_STAMP(6)
         float ll = 0.0f, gb[KS + 1], ga[KO + 1];
 #pragma unroll
         for (int k = 0; k <= KS; k++) gb[k] = 0.0f;
 #pragma unroll
         for (int k = 0; k <= KO; k++) ga[k] = 0.0f;
         bl_eval_sites<KS, KO, LDS>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga);
+        BL_STAMP(7)
         bl_wave_partials_to_lds<KS, KO>(Ks, Ko, ll, gb, ga);
         BL_STAMP(0)
         __syncthreads();
@@ -176,41 +219,59 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
             if (lane == D + 1) comp = ll_lo;
             if (lane == D + 2 && member == 0 && (epoch & 255u) == 0u)
                 comp = (__hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1.0f : 0.0f;
+            if (epoch == 1u) { // placement census: all k XCC ids equal  <=>  k * sum(x^2) == (sum x)^2
+                if (lane == D + 3) comp = xcc;
+                if (lane == D + 4) comp = xcc * xcc;
+            }
 
             // ------------------------------ all-gather of the k partials (G16 / R2) ----
             const int nvp = p.nvp, G = 64 / nvp;
             unsigned long long *rec = p.xchg + ((size_t)(chain * 2 + (epoch & 1u)) * p.k) * nvp;
-            if (lane < nvp)
-                __hip_atomic_store(rec + (size_t)member * nvp + lane,
-                                   ((unsigned long long)epoch << 32) | __float_as_uint(comp),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long granule = ((unsigned long long)epoch << 32) | __float_as_uint(comp);
+            if (lane < nvp) {
+                if (local) // line stays in this XCD's L2, where every consumer of this chain polls it
+                    __hip_atomic_store(rec + (size_t)member * nvp + lane, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else       // write-through: visible to any XCD
+                    __hip_atomic_store(rec + (size_t)member * nvp + lane, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             BL_STAMP(2)
             const int c_idx = lane & (nvp - 1), sub = lane / nvp;
             double acc = 0.0;
             bool timed_out = false;
             for (int p0 = 0; p0 < p.k; p0 += 8 * G) {
-                unsigned long long v[8];
+                unsigned long long va[8], vb[8];
                 unsigned spins = 0;
-                while (true) {
-                    bool ok = true;
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const int w = p0 + q * G + sub;
-                        v[q] = 0ull;
-                        if (w < p.k) {
-                            v[q] = __hip_atomic_load(rec + (size_t)w * nvp + c_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ok = ok && ((unsigned)(v[q] >> 32) == epoch);
-                        }
+                bool ok;
+                if (local) {
+                    while (true) {
+                        BL_POLL_ISSUE(va)
+                        BL_POLL_CHECK(va, ok)
+                        if (ok) break;
+                        if (++spins > p.spin_limit) { timed_out = true; break; }
                     }
-                    if (__all(ok)) break;
-                    if (++spins > p.spin_limit) { timed_out = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
+                } else {
+                    BL_POLL_ISSUE(va)
+                    while (true) {
+                        for (int z_ = 0; z_ < p.poll_sleep; z_++) __builtin_amdgcn_s_sleep(1);
+                        BL_POLL_ISSUE(vb)
+                        BL_POLL_CHECK(va, ok)
+                        if (ok) break;
+                        for (int z_ = 0; z_ < p.poll_sleep; z_++) __builtin_amdgcn_s_sleep(1);
+                        BL_POLL_ISSUE(va)
+                        BL_POLL_CHECK(vb, ok)
+                        if (ok) {
+#pragma unroll
+                            for (int q = 0; q < 8; q++) va[q] = vb[q];
+                            break;
+                        }
+                        if (++spins > p.spin_limit) { timed_out = true; break; }
+                    }
                 }
                 if (timed_out) break;
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const int w = p0 + q * G + sub;
-                    if (w < p.k) acc += (double)__uint_as_float((unsigned)v[q]);
+                    if (w < p.k) acc += (double)__uint_as_float((unsigned)va[q]);
                 }
             }
             for (int off = nvp; off < 64; off <<= 1) {
@@ -219,22 +280,26 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
                 const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(b >> 32), off);
                 acc += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
             }
+            BL_STAMP(3)
             const double ll_tot = bl_readlane_d(acc, D) + bl_readlane_d(acc, D + 1);
             const bool abort_req = bl_readlane_d(acc, D + 2) != 0.0;
+            if (epoch == 1u && p.allow_local) {
+                const double sx = bl_readlane_d(acc, D + 3), sxx = bl_readlane_d(acc, D + 4);
+                local = ((double)p.k * sxx == sx * sx); // exact: small integers
+            }
             int flag = 0;
             if (timed_out) flag = 4;       // BL_ERR_TIMEOUT
             else if (abort_req) flag = 5;  // BL_ERR_ABORTED
 
-            BL_STAMP(3)
             // ------------------------------------------------ potential at cz (lane d) ----
             const float dth = cz - prior_loc;
-            const double Un = -ll_tot + (double)(0.5f * bl_wave_sum(act ? dth * dth * prior_isc2 : 0.0f)) + p.dd.prior_const;
             const float cg = act ? (-(float)acc + dth * prior_isc2) : 0.0f;
 
             bool new_transition = false;
             if (flag == 0) {
                 if (it < 0) {
                     // initial evaluation done
+                    const double Un = -ll_tot + (double)(0.5f * bl_wave_sum(act ? dth * dth * prior_isc2 : 0.0f)) + p.dd.prior_const;
                     th = cz; gr = cg; U = Un;
                     it = 0;
                     new_transition = true;
@@ -242,7 +307,10 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
                     if (it < W) nleap_w++; else nleap_s++;
                     // ---------------- finish the leaf (_build_basetree) ----------------
                     const float cr = rh - 0.5f * epsdir * cg;
-                    const double Kn = (double)(0.5f * bl_wave_sum(minv * cr * cr));
+                    float s_prior = act ? dth * dth * prior_isc2 : 0.0f, s_kin = minv * cr * cr;
+                    bl_wave_sum2(s_prior, s_kin);
+                    const double Un = -ll_tot + (double)(0.5f * s_prior) + p.dd.prior_const;
+                    const double Kn = (double)(0.5f * s_kin);
                     double dE = (Un + Kn) - E0;
                     if (dE != dE) dE = (double)INFINITY;
                     const float dEf = (float)dE;
@@ -369,7 +437,6 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
             }
             sh_theta[lane] = act ? cz : 0.0f;
             if (lane == 0) sh_flag[0] = flag;
-            BL_STAMP(4)
             if (flag != 0 && member == 0) {
                 if (flag > 1 && lane == 0) atomicMax(p.status, flag);
                 if (act) p.inv_mass[chain * D + lane] = minv;
@@ -377,15 +444,17 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
                     p.step_size[chain] = eps;
                     p.nleap[chain * 2 + 0] = nleap_w;
                     p.nleap[chain * 2 + 1] = nleap_s;
+                    p.xcd_local[chain] = local ? 1 : 0;
                 }
             }
+            BL_STAMP(4)
         }
         __syncthreads();
         BL_STAMP(5)
         if (sh_flag[0] != 0) break;
     }
 #ifdef BL_STAMPS
-    if (p.dbg && blockIdx.x == 0 && tid == 0) {
+    if (p.dbg && chain == 0 && member == 0 && tid == 0) {
         for (int i = 0; i < 8; i++) p.dbg[i] = st_acc[i];
         p.dbg[8] = (long long)epoch;
         p.dbg[9] = (long long)wall_clock64() - st_rt0;

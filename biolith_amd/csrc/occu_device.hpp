@@ -101,6 +101,34 @@ __device__ __forceinline__ double bl_wave_sum_d(double x)
     return bl_readlane_d(x, 63);
 }
 
+// N independent sums with the butterfly steps outermost: the N DPP chains interleave, so no
+// s_nop padding between a VALU write and the DPP read of the same register is needed.
+template <int N>
+__device__ __forceinline__ void bl_wave_sum_vec(float (&v)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += bl_dpp<0xB1, 0xF>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += bl_dpp<0x4E, 0xF>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += bl_dpp<0x141, 0xF>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += bl_dpp<0x140, 0xF>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += bl_dpp<0x142, 0xA>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += bl_dpp<0x143, 0xC>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = bl_readlane(v[i], 63);
+}
+__device__ __forceinline__ void bl_wave_sum2(float &a, float &b)
+{
+    float v[2] = {a, b};
+    bl_wave_sum_vec<2>(v);
+    a = v[0];
+    b = v[1];
+}
+
 // ------------------------------------------------------------------- RNG ----
 // xoshiro128++ 1.0; identical sequence to oracle/occu_oracle.c (tests compare them).
 struct BlRng {
@@ -142,17 +170,16 @@ __device__ __forceinline__ float bl_ld(const float *__restrict__ grows, int row,
         return grows[(size_t)row * ld + i];
 }
 
-// Accumulates, over this thread's sites i = tid, tid+BL_THREADS, ... < cnt :
-//   ll     += sum_t l_it                        (log-lik, z marginalised)
-//   gb[k]  += d ll / d beta_k ,  ga[k] += d ll / d alpha_k
-// Per visit (all in f32, stable forms):  u = c*alpha0 + sum_k (c w_k) alpha_k ,
-//   log sigma(u) = min(u,0) - log(1+e^-|u|),  sigma(-u) = (u>0 ? e : 1)/(1+e),  e = e^-|u|
-template <int KS, int KO, bool LDS>
-__device__ __forceinline__ void bl_eval_sites(const float *__restrict__ grows, int ld, int cnt, int T, int J,
-                                              const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
-                                              float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
+template <int KS, int KO, bool LDS, int JC>
+__device__ __forceinline__ void bl_eval_sites_j(const float *__restrict__ grows, int ld, int cnt, int T, int J,
+                                                const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
+                                                float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
 {
-    const int V = T * J;
+    // JC > 0: J == JC known at compile time -> the visit loop is fully unrolled, its LDS reads are
+    // issued together and the JC independent exp/log/rcp chains interleave (latency, not issue,
+    // bounds this phase at 2 waves per SIMD).  JC == 0: runtime J.
+    const int Jn = JC > 0 ? JC : J;
+    const int V = T * Jn;
     const int row_wc = KS, row_ka = KS + V * (KO + 1), row_kb = row_ka + T;
     for (int i = threadIdx.x; i < cnt; i += BL_THREADS) {
         float x[KS > 0 ? KS : 1];
@@ -173,8 +200,8 @@ __device__ __forceinline__ void bl_eval_sites(const float *__restrict__ grows, i
             float g[KO + 1];
 #pragma unroll
             for (int k = 0; k <= KO; k++) g[k] = 0.0f;
-            for (int j = 0; j < J; j++) {
-                const int r0 = row_wc + (t * J + j) * (KO + 1);
+            auto visit = [&](int j) {
+                const int r0 = row_wc + (t * Jn + j) * (KO + 1);
                 float w[KO + 1];
 #pragma unroll
                 for (int k = 0; k <= KO; k++) w[k] = bl_ld<LDS>(grows, r0 + k, ld, i);
@@ -187,6 +214,13 @@ __device__ __forceinline__ void bl_eval_sites(const float *__restrict__ grows, i
                 const float s = (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(op);
 #pragma unroll
                 for (int k = 0; k <= KO; k++) g[k] = fmaf(s, w[k], g[k]);
+            };
+            if constexpr (JC > 0) {
+#pragma unroll
+                for (int j = 0; j < JC; j++) visit(j);
+            } else {
+#pragma unroll 4
+                for (int j = 0; j < Jn; j++) visit(j);
             }
             const float kb = bl_ld<LDS>(grows, row_kb + t, ld, i);
             // z=1 branch A = log psi + a ; z=0 branch B = log(1-psi) + n_det log(tiny)
@@ -203,6 +237,28 @@ __device__ __forceinline__ void bl_eval_sites(const float *__restrict__ grows, i
         gb[0] += dsum;
 #pragma unroll
         for (int k = 0; k < KS; k++) gb[k + 1] = fmaf(dsum, x[k], gb[k + 1]);
+    }
+}
+
+// Accumulates, over this thread's sites i = tid, tid+BL_THREADS, ... < cnt :
+//   ll     += sum_t l_it                        (log-lik, z marginalised)
+//   gb[k]  += d ll / d beta_k ,  ga[k] += d ll / d alpha_k
+// Per visit (all in f32, stable forms):  u = c*alpha0 + sum_k (c w_k) alpha_k ,
+//   log sigma(u) = min(u,0) - log(1+e^-|u|),  sigma(-u) = (u>0 ? e : 1)/(1+e),  e = e^-|u|
+template <int KS, int KO, bool LDS>
+__device__ __forceinline__ void bl_eval_sites(const float *__restrict__ grows, int ld, int cnt, int T, int J,
+                                              const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
+                                              float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
+{
+    switch (J) { // wave-uniform
+    case 1: bl_eval_sites_j<KS, KO, LDS, 1>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga); break;
+    case 2: bl_eval_sites_j<KS, KO, LDS, 2>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga); break;
+    case 3: bl_eval_sites_j<KS, KO, LDS, 3>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga); break;
+    case 4: bl_eval_sites_j<KS, KO, LDS, 4>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga); break;
+    case 5: bl_eval_sites_j<KS, KO, LDS, 5>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga); break;
+    case 6: bl_eval_sites_j<KS, KO, LDS, 6>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga); break;
+    case 8: bl_eval_sites_j<KS, KO, LDS, 8>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga); break;
+    default: bl_eval_sites_j<KS, KO, LDS, 0>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga); break;
     }
 }
 
@@ -232,17 +288,21 @@ template <int KS, int KO>
 __device__ __forceinline__ void bl_wave_partials_to_lds(int Ks, int Ko, float ll, const float (&gb)[KS + 1], const float (&ga)[KO + 1])
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float v[KS + KO + 2];
+#pragma unroll
+    for (int k = 0; k <= KS; k++) v[k] = gb[k];
+#pragma unroll
+    for (int k = 0; k <= KO; k++) v[KS + 1 + k] = ga[k];
+    bl_wave_sum_vec<KS + KO + 2>(v);
     const double llw = bl_wave_sum_d((double)ll);
     float *part = bl_lds_f(BL_OFF_PART) + wave * 64;
+    if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k <= KS; k++) {
-        const float s = bl_wave_sum(gb[k]);
-        if (k <= Ks && lane == 0) part[k] = s;
-    }
+        for (int k = 0; k <= KS; k++)
+            if (k <= Ks) part[k] = v[k];
 #pragma unroll
-    for (int k = 0; k <= KO; k++) {
-        const float s = bl_wave_sum(ga[k]);
-        if (k <= Ko && lane == 0) part[Ks + 1 + k] = s;
+        for (int k = 0; k <= KO; k++)
+            if (k <= Ko) part[Ks + 1 + k] = v[KS + 1 + k];
+        bl_lds_d(BL_OFF_LL)[wave] = llw;
     }
-    if (lane == 0) bl_lds_d(BL_OFF_LL)[wave] = llw;
 }

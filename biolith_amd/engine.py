@@ -38,6 +38,7 @@ class NutsResult:
     wgs_per_chain: int
     lds_bytes: int
     lds_staged: bool
+    chains_l2_local: int = 0      # chains that ran the verified same-XCD (L2-local) exchange
 
 
 class OccuDataset:
@@ -169,10 +170,10 @@ class OccuDataset:
             _fp(acc), _fp(pot), _fp(eps), _fp(minv), nleap.ctypes.data_as(C.POINTER(C.c_int64)),
         )
         _ffi.check(self._lib.bl_nuts_fetch(self._h, C.byref(out)))
-        k, thr, lds, staged = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        _ffi.check(self._lib.bl_nuts_geometry(self._h, C.byref(k), C.byref(thr), C.byref(lds), C.byref(staged)))
+        k, thr, lds, staged, loc = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _ffi.check(self._lib.bl_nuts_geometry(self._h, C.byref(k), C.byref(thr), C.byref(lds), C.byref(staged), C.byref(loc)))
         return NutsResult(draws, div.astype(bool), steps, acc, pot, eps, minv, nleap, self.elapsed_ms(),
-                          k.value, lds.value, bool(staged.value))
+                          k.value, lds.value, bool(staged.value), loc.value)
 
     def nuts(self, timeout: Optional[float] = None, **kw) -> NutsResult:
         """launch + wait + fetch.  With ``timeout`` (seconds) the kernel is aborted through its

@@ -121,8 +121,10 @@ int bl_nuts_fetch(bl_dataset *ds, bl_nuts_output *out);
 int bl_nuts_elapsed_ms(bl_dataset *ds, float *ms);
 /* Device address of the last launch's draws [C][S][D] float32 (for an RCCL gather). */
 int bl_nuts_device_draws(bl_dataset *ds, void **dev_ptr, size_t *bytes);
-/* Geometry the last launch used. */
-int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads_per_wg, int *lds_bytes, int *lds_staged);
+/* Geometry the last launch used; the last field counts the chains whose workgroups were verified
+ * (HW_REG_XCC_ID census) to share one XCD and therefore ran the L2-local exchange. */
+int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads_per_wg, int *lds_bytes, int *lds_staged,
+                     int *chains_on_l2_local_exchange);
 
 /* In-kernel phase cycle counters of the last launch; all zero unless the library is a diagnostic
  * BL_STAMPS build (make -C biolith_amd/csrc stamps).  Not part of the reference's interface. */

@@ -14,7 +14,7 @@ os.environ.setdefault("BIOLITH_HIP_LIB", os.path.join(ROOT, "biolith_amd", "lib"
 from biolith_amd.engine import OccuDataset  # noqa: E402
 from biolith_amd.models import simulate  # noqa: E402
 
-NAMES = ["A compute+wave-reduce", "barrier1", "wg partial+publish", "sweep (poll)", "control", "barrier2"]
+NAMES = ["A3 wave-reduce->LDS", "barrier1", "wg partial+publish", "sweep (poll)", "control", "barrier2", "A1 load coefs", "A2 eval sites"]
 
 
 def main():
@@ -27,11 +27,11 @@ def main():
             r = ds.nuts(num_warmup=1000, num_samples=1000, num_chains=chains, seed=0, wgs_per_chain=k)
             c = ds.debug_counters()
             ticks, rt = int(c[8]), int(c[9])
-            tot = c[:6].sum()
+            tot = c[:8].sum()
             mhz = tot / (rt / 100.0) if rt else float("nan")  # s_memrealtime ticks at 100 MHz
             print(f"k={r.wgs_per_chain} chains={chains} kernel {r.kernel_ms:.1f} ms ticks {ticks} "
-                  f"cycles/tick {tot / max(ticks, 1):.0f} clock {mhz:.0f} MHz us/tick {r.kernel_ms * 1e3 / max(ticks, 1):.2f}")
-            for n, v in zip(NAMES, c[:6]):
+                  f"cycles/tick {tot / max(ticks, 1):.0f} clock {mhz:.0f} MHz us/tick {r.kernel_ms * 1e3 / max(ticks, 1):.2f} l2local_chains {r.chains_l2_local}")
+            for n, v in zip(NAMES, c[:8]):
                 print(f"    {n:26s} {v / max(ticks, 1):8.0f} cyc  {100.0 * v / tot:5.1f} %")
 
 
