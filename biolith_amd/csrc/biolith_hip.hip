@@ -339,18 +339,19 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     if (k > kmax) k = kmax;
     if (k < 1) k = 1;
     const int lds_cap = BL_LDS_TOTAL - BL_OFF_DATA;
-    auto fits = [&](int kk, int *nloc, int *ld) {
+    // LDS keeps one record of `stride` floats per site (occu_device.hpp)
+    const int stride = bl_record_stride(ds->dims.n_periods, ds->dims.n_replicates, ds->KS, ds->KO);
+    auto fits = [&](int kk, int *nloc) {
         *nloc = (N + kk - 1) / kk;
-        *ld = (*nloc + 31) / 32 * 32;
-        return (long long)ds->n_rows * *ld * 4 <= lds_cap;
+        return (long long)*nloc * stride * 4 <= lds_cap;
     };
-    int nloc, ld;
-    bool ok = fits(k, &nloc, &ld);
+    int nloc;
+    bool ok = fits(k, &nloc);
     if (!ok && want_k <= 0)
-        for (int kk = k + 1; kk <= kmax && !ok; kk++) { ok = fits(kk, &nloc, &ld); if (ok) k = kk; }
-    if (!ok) fits(k, &nloc, &ld);
-    *k_out = k; *nloc_out = nloc; *ld_out = ld; *staged_out = ok ? 1 : 0;
-    *lds_bytes_out = ok ? BL_OFF_DATA + ds->n_rows * ld * 4 : BL_OFF_DATA;
+        for (int kk = k + 1; kk <= kmax && !ok; kk++) { ok = fits(kk, &nloc); if (ok) k = kk; }
+    if (!ok) fits(k, &nloc);
+    *k_out = k; *nloc_out = nloc; *ld_out = stride; *staged_out = ok ? 1 : 0;
+    *lds_bytes_out = ok ? BL_OFF_DATA + nloc * stride * 4 : BL_OFF_DATA;
 }
 
 // ------------------------------------------------------------- K1 logp ----
@@ -397,7 +398,7 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
     BL_HIP(hipMemcpy(d_th, theta, (size_t)B * D * 8, hipMemcpyHostToDevice));
     BL_HIP(hipMemset(d_partial, 0, (size_t)B * k * 64 * 8));
     BlLogpParams p{};
-    p.dd = ds->dd; p.k = k; p.nloc = nloc; p.lds_ld = ld; p.n_rows = ds->n_rows; p.B = B; p.theta = d_th32; p.partial = d_partial;
+    p.dd = ds->dd; p.k = k; p.nloc = nloc; p.rec_stride = ld; p.B = B; p.theta = d_th32; p.partial = d_partial;
     const int lrc = ds->kern->logp(&p, k, lds_bytes, use_staged, nullptr);
     if (lrc != 0) return bl_fail(BL_ERR_NO_DEVICE, "logp kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     hipLaunchKernelGGL(bl_logp_final_kernel, dim3(B), dim3(64), 0, nullptr, ds->dd, k, d_th, d_partial, d_U, d_grad);
@@ -426,7 +427,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
 
     int k, nloc, ld, lds_bytes, staged;
     choose_geometry(ds, C, cfg->wgs_per_chain, &k, &nloc, &ld, &lds_bytes, &staged);
-    const int nvp = (D + 5 <= 16) ? 16 : (D + 5 <= 32 ? 32 : 64);
+    const int nvp = (D + 4 <= 16) ? 16 : (D + 4 <= 32 ? 32 : 64);
 
     // ---- (re)allocate run slab ----
     size_t off = 0;
@@ -435,7 +436,8 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     const size_t o_draws = carve((size_t)C * Sa * D * 4), o_div = carve((size_t)C * Sa), o_steps = carve((size_t)C * Sa * 4),
                  o_acc = carve((size_t)C * Sa * 4), o_pot = carve((size_t)C * Sa * 4), o_eps = carve((size_t)C * 4),
                  o_minv = carve((size_t)C * D * 4), o_nleap = carve((size_t)C * 16), o_status = carve(16),
-                 o_rng = carve((size_t)C * BL_RNG_STREAMS_PER_CHAIN * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(16 * 8), o_loc = carve((size_t)C * 4);
+                 o_rng = carve((size_t)C * BL_RNG_STREAMS_PER_CHAIN * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(16 * 8), o_loc = carve((size_t)C * 4),
+                 o_cold = carve(sizeof(BlNutsCold));
     if (off > ds->run_bytes) {
         if (ds->d_run) hipFree(ds->d_run);
         ds->d_run = nullptr; ds->run_bytes = 0;
@@ -466,34 +468,42 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
         for (size_t i = 0; i < it32.size(); i++) it32[i] = (float)cfg->init_theta[i];
         BL_HIP(hipMemcpyAsync(ds->d_init, it32.data(), it32.size() * 4, hipMemcpyHostToDevice, st));
     }
-    BL_HIP(hipStreamSynchronize(st)); // staging vectors die with this scope
+    // rarely-read constants + output pointers: one device-memory block
+    BlNutsCold cold{};
+    cold.num_warmup = W; cold.num_samples = S;
+    cold.target_accept = (float)(cfg->target_accept > 0.0 ? cfg->target_accept : 0.8);
+    int32_t ws[32], we[32];
+    cold.nwin = adaptation_schedule(W, ws, we, 32);
+    if (cold.nwin > 32) return bl_fail(BL_ERR_INVALID, "adaptation schedule too long");
+    for (int i = 0; i < 32; i++) cold.win_end[i] = i < cold.nwin ? we[i] : 0x7fffffff;
+    cold.loc_b = ds->dd.loc_b; cold.isc2_b = ds->dd.isc2_b; cold.loc_a = ds->dd.loc_a; cold.isc2_a = ds->dd.isc2_a;
+    cold.prior_const = ds->dd.prior_const;
+    cold.rng = ds->d_rng;
+    cold.init_theta = cfg->init_theta ? ds->d_init : nullptr;
+    cold.abort_flag = ds->d_abort;
+    cold.draws = ds->d_draws; cold.diverging = ds->d_div; cold.num_steps = ds->d_steps; cold.accept_prob = ds->d_acc;
+    cold.potential = ds->d_pot; cold.step_size = ds->d_eps; cold.inv_mass = ds->d_minv; cold.nleap = ds->d_nleap;
+    cold.status = ds->d_status; cold.xcd_local = ds->d_loc; cold.dbg = ds->d_dbg;
+    BlNutsCold *d_cold = (BlNutsCold *)(base + o_cold);
+    BL_HIP(hipMemcpyAsync(d_cold, &cold, sizeof cold, hipMemcpyHostToDevice, st));
+    BL_HIP(hipStreamSynchronize(st)); // staging buffers die with this scope
     *ds->h_abort = 0;
 
     BlNutsParams p{};
-    p.dd = ds->dd;
-    p.num_warmup = W; p.num_samples = S; p.num_chains = C;
-    p.k = k; p.nloc = nloc; p.lds_ld = ld; p.n_rows = ds->n_rows; p.nvp = nvp;
+    p.rows = ds->dd.rows; p.n_sites = ds->dd.n_sites; p.n_stride = ds->dd.n_stride;
+    p.T = ds->dd.T; p.J = ds->dd.J; p.Ks = ds->dd.Ks; p.Ko = ds->dd.Ko;
+    p.num_chains = C;
+    p.k = k; p.nloc = nloc; p.rec_stride = ld; p.nvp = nvp;
     p.max_depth = max_depth;
-    p.target_accept = (float)(cfg->target_accept > 0.0 ? cfg->target_accept : 0.8);
-    int32_t ws[32], we[32];
-    p.nwin = adaptation_schedule(W, ws, we, 32);
-    if (p.nwin > 32) return bl_fail(BL_ERR_INVALID, "adaptation schedule too long");
-    for (int i = 0; i < 32; i++) p.win_end[i] = i < p.nwin ? we[i] : 0x7fffffff;
-    p.rng = ds->d_rng;
-    p.init_theta = cfg->init_theta ? ds->d_init : nullptr;
     p.xchg = ds->d_xchg;
-    p.abort_flag = ds->d_abort;
+    p.cold = d_cold;
     p.spin_limit = 1u << 18;
     {   // developer knobs (A/B measurements): exchange form and poll spacing
         const char *e1 = getenv("BIOLITH_HIP_NO_LOCAL"), *e2 = getenv("BIOLITH_HIP_POLL_SLEEP");
         p.allow_local = (e1 && e1[0] == '1') ? 0 : 1;
-        p.poll_sleep = e2 ? atoi(e2) : 6;
-        if (p.poll_sleep < 0 || p.poll_sleep > 127) p.poll_sleep = 6;
+        p.poll_sleep = e2 ? atoi(e2) : 3;
+        if (p.poll_sleep < 0 || p.poll_sleep > 127) p.poll_sleep = 3;
     }
-    p.xcd_local = ds->d_loc;
-    p.draws = ds->d_draws; p.diverging = ds->d_div; p.num_steps = ds->d_steps; p.accept_prob = ds->d_acc;
-    p.potential = ds->d_pot; p.step_size = ds->d_eps; p.inv_mass = ds->d_minv; p.nleap = ds->d_nleap; p.status = ds->d_status;
-    p.dbg = ds->d_dbg;
 
     // timed region: state re-init (guide G16 "re-initialise every call") + the persistent kernel
     BL_HIP(hipEventRecord(ds->ev0, st));

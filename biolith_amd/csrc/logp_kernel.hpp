@@ -1,12 +1,12 @@
 // logp_kernel.hpp -- K1: batched occupancy log-density + gradient (parity hook behind bl_logp_grad).
-// Uses exactly the device functions the persistent NUTS kernel uses (same LDS staging, same
+// Uses exactly the device functions the persistent NUTS kernel uses (same LDS records, same
 // per-site arithmetic, same wave/workgroup reduction order), one launch per batch.
 #pragma once
 #include "occu_device.hpp"
 
 struct BlLogpParams {
     BlDevData dd;
-    int k, nloc, lds_ld, n_rows;
+    int k, nloc, rec_stride;
     int B;
     const float *theta;  // [B][D] float32 view of the caller's double theta
     double *partial;     // [B][k][64]: c < D grad of log-lik, c == D log-lik
@@ -21,43 +21,38 @@ __global__ void __launch_bounds__(BL_THREADS) bl_logp_kernel(const BlLogpParams 
     const int s0 = member * p.nloc;
     int cnt = p.dd.n_sites - s0;
     cnt = cnt < 0 ? 0 : (cnt > p.nloc ? p.nloc : cnt);
-    const float *grows;
-    int ld;
+    const float *grows = nullptr;
+    int ld = p.rec_stride;
     if constexpr (LDS) {
-        bl_stage_rows(p.dd.rows, p.n_rows, p.dd.n_stride, s0, cnt, p.lds_ld);
-        grows = nullptr;
-        ld = p.lds_ld;
+        bl_stage_records(p.dd.rows, p.dd.n_stride, s0, cnt, p.dd.T, p.dd.J, KS, KO, p.rec_stride);
     } else {
         grows = p.dd.rows + s0;
         ld = p.dd.n_stride;
     }
-    float *sh_theta = bl_lds_f(BL_OFF_THETA);
+    float *sh_coef = bl_lds_f(BL_OFF_COEF);
+    if (tid < 64) sh_coef[tid] = 0.0f;
+    __syncthreads();
+    const int my_pos = lane < D ? bl_coef_pos(lane, Ks, KS) : (lane == D ? KS + KO + 2 : 0);
     for (int b = 0; b < p.B; b++) {
-        if (wave == 0) sh_theta[lane] = lane < D ? p.theta[(size_t)b * D + lane] : 0.0f;
+        if (wave == 0 && lane < D) sh_coef[my_pos] = p.theta[(size_t)b * D + lane];
         __syncthreads();
         float beta[KS + 1], alpha[KO + 1];
-        bl_load_coefs<KS, KO>(sh_theta, Ks, Ko, beta, alpha);
+        bl_load_coefs<KS, KO>(beta, alpha);
         float ll = 0.0f, gb[KS + 1], ga[KO + 1];
 #pragma unroll
         for (int k = 0; k <= KS; k++) gb[k] = 0.0f;
 #pragma unroll
         for (int k = 0; k <= KO; k++) ga[k] = 0.0f;
         bl_eval_sites<KS, KO, LDS>(grows, ld, cnt, p.dd.T, p.dd.J, beta, alpha, ll, gb, ga);
-        bl_wave_partials_to_lds<KS, KO>(Ks, Ko, ll, gb, ga);
+        bl_wave_partials_to_lds<KS, KO>(ll, gb, ga);
         __syncthreads();
         if (wave == 0) {
             const float *part = bl_lds_f(BL_OFF_PART);
-            const double *pll = bl_lds_d(BL_OFF_LL);
-            float g = 0.0f;
-            double llwg = 0.0;
+            double acc = 0.0;
 #pragma unroll
-            for (int w = 0; w < BL_WAVES; w++) {
-                g += lane < D ? part[w * 64 + lane] : 0.0f;
-                llwg += pll[w];
-            }
+            for (int w = 0; w < BL_WAVES; w++) acc += (double)part[w * BL_PART_STRIDE + my_pos];
             double *out = p.partial + ((size_t)b * p.k + member) * 64;
-            if (lane < D) out[lane] = (double)g;
-            if (lane == D) out[lane] = llwg;
+            if (lane <= D) out[lane] = acc;
         }
         __syncthreads();
     }

@@ -7,20 +7,21 @@
 //
 // Mapping to the chip
 //   * one chain = k cooperating workgroups (512 threads each, one per CU); a workgroup owns a
-//     contiguous slice of sites, staged ONCE into LDS (site-fastest rows; see occu_device.hpp);
+//     contiguous slice of sites, staged ONCE into LDS as per-site records (occu_device.hpp);
 //   * blockIdx -> (chain, member) is XCD-aware: blocks b and b+8 share an XCD under the observed
 //     round-robin dealing, so chain c takes the blocks with b % 8 == c % 8 and its k workgroups
 //     share one L2.  That is a SPEED arrangement only: every workgroup reads HW_REG_XCC_ID and the
 //     chain switches to the L2-local exchange (below) only if the first, placement-independent
 //     exchange proves that all k workgroups really sit on one XCD;
 //   * every leapfrog ("tick"): all 8 waves evaluate their sites' log-lik + gradient from LDS ->
-//     DPP wave reduction -> LDS -> workgroup partial (D grads f32, log-lik as hi+lo f32 pair);
+//     one interleaved DPP wave reduction -> LDS -> workgroup partial (D grads f32, log-lik hi+lo);
 //   * the k partials are all-gathered through 8-byte {epoch, value} granules (guide G16, form R2:
 //     the data is the flag), double-buffered by epoch parity, every spin bounded:
 //       - placement-independent form: ONE sc1 (write-through) store per granule, relaxed
-//         agent-scope (sc1) polls, two poll rounds in flight half a fabric round trip apart;
+//         agent-scope (sc1) polls;
 //       - L2-local form (verified same-XCD chains only): workgroup-scope stores keep the line in
-//         the XCD's L2, sc1 polls bypass L1 and hit that L2: ~5x shorter hop;
+//         the XCD's L2, sc1 polls bypass L1 and hit that L2: several times shorter hop;
+//     two poll rounds are kept in flight, spaced a fraction of a round trip apart;
 //     every workgroup sums the k records in the same fixed order in f64, so all k copies of the
 //     chain state stay bit-identical without any broadcast;
 //   * wave 0 of every workgroup then advances the (replicated) NUTS state machine by one leaf,
@@ -32,32 +33,26 @@
 // In-kernel phase stamps (guide section 7 "In-kernel stamps"): diagnostic builds only
 // (make stamps); the shipped kernel executes none of this.
 #ifdef BL_STAMPS
-#define BL_STAMP_DECL long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long st_prev = (long long)clock64(); long long st_rt0 = (long long)wall_clock64();
+#define BL_STAMP_DECL long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long st_prev = (long long)clock64(); long long st_rt0 = (long long)wall_clock64(); long long st_spins = 0;
 #define BL_STAMP(i) { const long long st_now = (long long)clock64(); st_acc[i] += st_now - st_prev; st_prev = st_now; }
+#define BL_COUNT_SPINS(n) st_spins += (long long)(n);
 #else
+#define BL_COUNT_SPINS(n)
 #define BL_STAMP_DECL
 #define BL_STAMP(i)
 #endif
 
-struct BlNutsParams {
-    BlDevData dd;
-    int num_warmup, num_samples, num_chains;
-    int k;        // workgroups per chain
-    int nloc;     // sites per workgroup
-    int lds_ld;   // LDS row stride (floats) when staged
-    int n_rows;   // rows of the data matrix
-    int nvp;      // granules per workgroup record: 16, 32 or 64 (>= D+5)
-    int max_depth;
+// Rarely-read launch constants and output pointers live in device memory (keeps the kernel's
+// SGPR budget for the loop).
+struct BlNutsCold {
+    int num_warmup, num_samples, nwin;
     float target_accept;
-    int nwin;
     int win_end[32];               // numpyro adaptation windows (inclusive ends)
-    int allow_local;               // 0: always use the placement-independent exchange
-    int poll_sleep;                // s_sleep units between the two in-flight poll rounds
+    float loc_b, isc2_b, loc_a, isc2_a;  // Normal prior loc, 1/scale^2
+    double prior_const;            // sum_k log(scale_k) + D/2 log(2 pi)
     const uint32_t *rng;           // [C][64][4] xoshiro states (host-jumped)
     const float *init_theta;       // [C][D] or null -> Uniform(-2,2)
-    unsigned long long *xchg;      // [C][2][k][nvp] granules, zeroed before every launch
     const int *abort_flag;         // host-mapped
-    unsigned spin_limit;
     float *draws;                  // [C][S][D]
     unsigned char *diverging;      // [C][S]
     int *num_steps;                // [C][S]
@@ -71,11 +66,41 @@ struct BlNutsParams {
     long long *dbg;                // [16] phase cycle counters (diagnostic BL_STAMPS builds only)
 };
 
+struct BlNutsParams {
+    const float *rows;             // HBM data matrix [n_rows][n_stride]
+    int n_sites, n_stride, T, J, Ks, Ko;
+    int num_chains;
+    int k;                         // workgroups per chain
+    int nloc;                      // sites per workgroup
+    int rec_stride;                // floats per LDS site record
+    int nvp;                       // granules per workgroup record: 16, 32 or 64 (>= D+4)
+    int max_depth;
+    int allow_local;               // 0: always use the placement-independent exchange
+    int poll_sleep;                // s_sleep(1) repeats between the two in-flight poll rounds (fabric form)
+    unsigned spin_limit;
+    unsigned long long *xchg;      // [C][2][k][nvp] granules, zeroed before every launch
+    const BlNutsCold *cold;
+};
+
+__device__ __forceinline__ float bl_exp(float x) { return __builtin_amdgcn_exp2f(x * BL_LOG2E); }
+__device__ __forceinline__ float bl_log(float x) { return BL_LN2 * __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float bl_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 __device__ __forceinline__ float bl_logaddexp(float a, float b)
 {
     const float m = fmaxf(a, b);
     if (m == -INFINITY) return m;
-    return m + __logf(1.0f + __expf(-fabsf(a - b)));
+    return m + bl_log(1.0f + bl_exp(-fabsf(a - b)));
+}
+// logaddexp(a, b) and sigmoid(b - a) = weight of b, from ONE exp / log / rcp
+__device__ __forceinline__ void bl_merge_weights(float a, float b, float &lse, float &pb)
+{
+    const float m = fmaxf(a, b);
+    if (m == -INFINITY) { lse = m; pb = 0.0f; return; }
+    const float d = b - a;
+    const float e = bl_exp(-fabsf(d)), op = 1.0f + e;
+    lse = m + bl_log(op);
+    pb = (d > 0.0f ? 1.0f : e) * bl_rcp(op); // NaN d (inf - inf) -> e NaN -> pb NaN -> "u < pb" false
 }
 
 // numpyro hmc_util._is_turning (diagonal mass); lane d = dim d, lanes >= D hold zeros.
@@ -94,21 +119,19 @@ __device__ __forceinline__ unsigned bl_xcc_id()
     return x & 0xFu;
 }
 
-// One poll round: every lane loads its granule of up to 8 records (sc1: bypasses L1).
+// One poll round: every lane loads its granule of 8 records (sc1: bypasses L1).  Record indices
+// beyond k are clamped to k-1: the duplicate loads carry valid tags and are ignored in the sum,
+// so the round needs no predication.
 #define BL_POLL_ISSUE(buf)                                                                                       \
     _Pragma("unroll") for (int q = 0; q < 8; q++) {                                                              \
-        const int w_ = p0 + q * G + sub;                                                                         \
-        buf[q] = 0ull;                                                                                           \
-        if (w_ < p.k) buf[q] = __hip_atomic_load(rec + (size_t)w_ * nvp + c_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+        const int w_ = min(p0 + q * G + sub, p.k - 1);                                                           \
+        buf[q] = __hip_atomic_load(rec + (size_t)w_ * nvp + c_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  \
     }
 #define BL_POLL_CHECK(buf, okv)                                                                                  \
     {                                                                                                            \
-        bool ok_ = true;                                                                                         \
-        _Pragma("unroll") for (int q = 0; q < 8; q++) {                                                          \
-            const int w_ = p0 + q * G + sub;                                                                     \
-            if (w_ < p.k) ok_ = ok_ && ((unsigned)(buf[q] >> 32) == epoch);                                      \
-        }                                                                                                        \
-        okv = __all(ok_);                                                                                        \
+        unsigned bad_ = 0u;                                                                                      \
+        _Pragma("unroll") for (int q = 0; q < 8; q++) bad_ |= ((unsigned)(buf[q] >> 32)) ^ epoch;                \
+        okv = __all(bad_ == 0u);                                                                                 \
     }
 
 template <int KS, int KO, bool LDS>
@@ -119,35 +142,38 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
     const int chain = label + 8 * (slot / p.k), member = slot % p.k;
     if (chain >= p.num_chains) return; // whole block leaves before any barrier or exchange
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int Ks = p.dd.Ks, Ko = p.dd.Ko, D = Ks + Ko + 2;
-    const int T = p.dd.T, J = p.dd.J;
+    const int Ks = p.Ks, Ko = p.Ko, D = Ks + Ko + 2;
+    const int T = p.T, J = p.J;
     const int s0 = member * p.nloc;
-    int cnt = p.dd.n_sites - s0;
+    int cnt = p.n_sites - s0;
     cnt = cnt < 0 ? 0 : (cnt > p.nloc ? p.nloc : cnt);
-    const float *grows;
-    int ld;
+    const float *grows = nullptr;
+    int ld = p.rec_stride;
     if constexpr (LDS) {
-        bl_stage_rows(p.dd.rows, p.n_rows, p.dd.n_stride, s0, cnt, p.lds_ld);
-        grows = nullptr;
-        ld = p.lds_ld;
+        bl_stage_records(p.rows, p.n_stride, s0, cnt, T, J, KS, KO, p.rec_stride);
     } else {
-        grows = p.dd.rows + s0;
-        ld = p.dd.n_stride;
+        grows = p.rows + s0;
+        ld = p.n_stride;
     }
-    float *sh_theta = bl_lds_f(BL_OFF_THETA);
+    float *sh_coef = bl_lds_f(BL_OFF_COEF);
     int *sh_flag = bl_lds_i(BL_OFF_FLAG);
     float *sh_ckr = bl_lds_f(BL_OFF_CKR), *sh_ckrs = bl_lds_f(BL_OFF_CKRS);
+    if (tid < 64) sh_coef[tid] = 0.0f;
+    __syncthreads();
 
     // ------------------------------------------------ replicated chain state (wave 0) ----
+    const BlNutsCold *cold = p.cold;
     const bool act = lane < D;
-    const int S = p.num_samples, W = p.num_warmup, total = W + S;
+    // where lane d's coefficient / partial lives in the padded LDS layouts; lanes >= D read the log-lik
+    const int my_pos = act ? bl_coef_pos(lane, Ks, KS) : KS + KO + 2;
+    int S = 0, W = 0, total = 0;
     BlRng rng_d, rng_s; // per-dimension stream, shared scalar stream
     float th = 0.f, gr = 0.f;           // current position / gradient of U
     double U = 0.0;                     // current potential
     float minv = act ? 1.0f : 0.0f;     // diagonal inverse mass (0 in idle lanes keeps sums clean)
     float eps = 1.0f;
     // dual averaging + Welford
-    float da_xt = 0.f, da_xavg = 0.f, da_gavg = 0.f, da_prox = __logf(10.0f);
+    float da_xt = 0.f, da_xavg = 0.f, da_gavg = 0.f, da_prox = 2.302585093f;
     int da_t = 0, wf_n = 0, win_idx = 0;
     float wf_mean = 0.f, wf_m2 = 0.f;
     // tree
@@ -166,18 +192,23 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
     int it = -1; // -1: evaluating the initial position
     long long nleap_w = 0, nleap_s = 0;
     bool local = false; // L2-local exchange proven safe for this chain
-    const float prior_loc = (lane <= Ks) ? p.dd.loc_b : p.dd.loc_a;
-    const float prior_isc2 = act ? ((lane <= Ks) ? p.dd.isc2_b : p.dd.isc2_a) : 0.0f;
+    float prior_loc = 0.f, prior_isc2 = 0.f;
+    double prior_const = 0.0;
     const float xcc = (float)bl_xcc_id();
 
     if (wave == 0) {
-        const uint32_t *rs = p.rng + ((size_t)chain * BL_NSTREAM + lane) * 4;
+        S = cold->num_samples; W = cold->num_warmup; total = W + S;
+        prior_loc = (lane <= Ks) ? cold->loc_b : cold->loc_a;
+        prior_isc2 = act ? ((lane <= Ks) ? cold->isc2_b : cold->isc2_a) : 0.0f;
+        prior_const = cold->prior_const;
+        const uint32_t *rs = cold->rng + ((size_t)chain * BL_NSTREAM + lane) * 4;
         rng_d.s0 = rs[0]; rng_d.s1 = rs[1]; rng_d.s2 = rs[2]; rng_d.s3 = rs[3];
-        const uint32_t *rc = p.rng + ((size_t)chain * BL_NSTREAM + BL_SCALAR_STREAM) * 4;
+        const uint32_t *rc = cold->rng + ((size_t)chain * BL_NSTREAM + BL_SCALAR_STREAM) * 4;
         rng_s.s0 = rc[0]; rng_s.s1 = rc[1]; rng_s.s2 = rc[2]; rng_s.s3 = rc[3];
         const float u0 = bl_rng_uniform(rng_d); // init_to_uniform(radius=2), fit.py:93
-        cz = act ? (p.init_theta ? p.init_theta[chain * D + lane] : 4.0f * u0 - 2.0f) : 0.0f;
-        sh_theta[lane] = cz;
+        const float *init = cold->init_theta;
+        cz = act ? (init ? init[chain * D + lane] : 4.0f * u0 - 2.0f) : 0.0f;
+        if (act) sh_coef[my_pos] = cz;
         if (lane == 0) sh_flag[0] = 0;
     }
     __syncthreads();
@@ -187,7 +218,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
     while (true) {
         // ------------------------------------------- phase A: all waves, site log-lik ----
         float beta[KS + 1], alpha[KO + 1];
-        bl_load_coefs<KS, KO>(sh_theta, Ks, Ko, beta, alpha);
+        bl_load_coefs<KS, KO>(beta, alpha);
         BL_STAMP(6)
         float ll = 0.0f, gb[KS + 1], ga[KO + 1];
 #pragma unroll
@@ -196,7 +227,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
         for (int k = 0; k <= KO; k++) ga[k] = 0.0f;
         bl_eval_sites<KS, KO, LDS>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga);
         BL_STAMP(7)
-        bl_wave_partials_to_lds<KS, KO>(Ks, Ko, ll, gb, ga);
+        bl_wave_partials_to_lds<KS, KO>(ll, gb, ga);
         BL_STAMP(0)
         __syncthreads();
         BL_STAMP(1)
@@ -204,24 +235,16 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
         if (wave == 0) {
             epoch++;
             // ---------------------------------- workgroup partial (fixed wave order) ----
-            const float *part = bl_lds_f(BL_OFF_PART);
-            const double *pll = bl_lds_d(BL_OFF_LL);
-            float gpart = 0.0f;
-            double llwg = 0.0;
+            const float *part = bl_lds_f(BL_OFF_PART) + my_pos;
+            float comp = 0.0f; // lanes < D: their gradient component; lane D: the log-lik
 #pragma unroll
-            for (int w = 0; w < BL_WAVES; w++) {
-                gpart += act ? part[w * 64 + lane] : 0.0f;
-                llwg += pll[w];
-            }
-            const float ll_hi = (float)llwg, ll_lo = (float)(llwg - (double)ll_hi);
-            float comp = act ? gpart : 0.0f;
-            if (lane == D) comp = ll_hi;
-            if (lane == D + 1) comp = ll_lo;
-            if (lane == D + 2 && member == 0 && (epoch & 255u) == 0u)
-                comp = (__hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1.0f : 0.0f;
+            for (int w = 0; w < BL_WAVES; w++) comp += part[w * BL_PART_STRIDE];
+            if (lane > D) comp = 0.0f;
+            if (lane == D + 1 && member == 0 && (epoch & 255u) == 0u)
+                comp = (__hip_atomic_load(cold->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1.0f : 0.0f;
             if (epoch == 1u) { // placement census: all k XCC ids equal  <=>  k * sum(x^2) == (sum x)^2
-                if (lane == D + 3) comp = xcc;
-                if (lane == D + 4) comp = xcc * xcc;
+                if (lane == D + 2) comp = xcc;
+                if (lane == D + 3) comp = xcc * xcc;
             }
 
             // ------------------------------ all-gather of the k partials (G16 / R2) ----
@@ -236,42 +259,35 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
             }
             BL_STAMP(2)
             const int c_idx = lane & (nvp - 1), sub = lane / nvp;
+            const int nsleep = local ? 1 : p.poll_sleep;
             double acc = 0.0;
             bool timed_out = false;
             for (int p0 = 0; p0 < p.k; p0 += 8 * G) {
                 unsigned long long va[8], vb[8];
                 unsigned spins = 0;
                 bool ok;
-                if (local) {
-                    while (true) {
-                        BL_POLL_ISSUE(va)
-                        BL_POLL_CHECK(va, ok)
-                        if (ok) break;
-                        if (++spins > p.spin_limit) { timed_out = true; break; }
-                    }
-                } else {
+                BL_POLL_ISSUE(va)
+                while (true) {
+                    for (int z = 0; z < nsleep; z++) __builtin_amdgcn_s_sleep(1);
+                    BL_POLL_ISSUE(vb)
+                    BL_POLL_CHECK(va, ok)
+                    if (ok) break;
+                    for (int z = 0; z < nsleep; z++) __builtin_amdgcn_s_sleep(1);
                     BL_POLL_ISSUE(va)
-                    while (true) {
-                        for (int z_ = 0; z_ < p.poll_sleep; z_++) __builtin_amdgcn_s_sleep(1);
-                        BL_POLL_ISSUE(vb)
-                        BL_POLL_CHECK(va, ok)
-                        if (ok) break;
-                        for (int z_ = 0; z_ < p.poll_sleep; z_++) __builtin_amdgcn_s_sleep(1);
-                        BL_POLL_ISSUE(va)
-                        BL_POLL_CHECK(vb, ok)
-                        if (ok) {
+                    BL_POLL_CHECK(vb, ok)
+                    if (ok) {
 #pragma unroll
-                            for (int q = 0; q < 8; q++) va[q] = vb[q];
-                            break;
-                        }
-                        if (++spins > p.spin_limit) { timed_out = true; break; }
+                        for (int q = 0; q < 8; q++) va[q] = vb[q];
+                        break;
                     }
+                    if (++spins > p.spin_limit) { timed_out = true; break; }
                 }
+                BL_COUNT_SPINS(spins)
                 if (timed_out) break;
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const int w = p0 + q * G + sub;
-                    if (w < p.k) acc += (double)__uint_as_float((unsigned)va[q]);
+                    acc += (w < p.k) ? (double)__uint_as_float((unsigned)va[q]) : 0.0;
                 }
             }
             for (int off = nvp; off < 64; off <<= 1) {
@@ -281,10 +297,10 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
                 acc += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
             }
             BL_STAMP(3)
-            const double ll_tot = bl_readlane_d(acc, D) + bl_readlane_d(acc, D + 1);
-            const bool abort_req = bl_readlane_d(acc, D + 2) != 0.0;
+            const double ll_tot = bl_readlane_d(acc, D);
+            const bool abort_req = bl_readlane_d(acc, D + 1) != 0.0;
             if (epoch == 1u && p.allow_local) {
-                const double sx = bl_readlane_d(acc, D + 3), sxx = bl_readlane_d(acc, D + 4);
+                const double sx = bl_readlane_d(acc, D + 2), sxx = bl_readlane_d(acc, D + 3);
                 local = ((double)p.k * sxx == sx * sx); // exact: small integers
             }
             int flag = 0;
@@ -299,7 +315,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
             if (flag == 0) {
                 if (it < 0) {
                     // initial evaluation done
-                    const double Un = -ll_tot + (double)(0.5f * bl_wave_sum(act ? dth * dth * prior_isc2 : 0.0f)) + p.dd.prior_const;
+                    const double Un = -ll_tot + (double)(0.5f * bl_wave_sum(dth * dth * prior_isc2)) + prior_const;
                     th = cz; gr = cg; U = Un;
                     it = 0;
                     new_transition = true;
@@ -307,26 +323,27 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
                     if (it < W) nleap_w++; else nleap_s++;
                     // ---------------- finish the leaf (_build_basetree) ----------------
                     const float cr = rh - 0.5f * epsdir * cg;
-                    float s_prior = act ? dth * dth * prior_isc2 : 0.0f, s_kin = minv * cr * cr;
+                    float s_prior = dth * dth * prior_isc2, s_kin = minv * cr * cr;
                     bl_wave_sum2(s_prior, s_kin);
-                    const double Un = -ll_tot + (double)(0.5f * s_prior) + p.dd.prior_const;
+                    const double Un = -ll_tot + (double)(0.5f * s_prior) + prior_const;
                     const double Kn = (double)(0.5f * s_kin);
                     double dE = (Un + Kn) - E0;
                     if (dE != dE) dE = (double)INFINITY;
                     const float dEf = (float)dE;
                     const float lw = -dEf;
                     const bool ldiv = dE > 1000.0;
-                    const float lacc = dEf <= 0.0f ? 1.0f : __expf(-dEf);
+                    const float lacc = dEf <= 0.0f ? 1.0f : bl_exp(-dEf);
                     const int leaf_idx = snprop;
                     if (leaf_idx == 0) {
                         szp = cz; sgp = cg; sUp = Un; swt = lw; srsum = cr;
                         sdiv = ldiv; ssumacc = lacc; snprop = 1;
                     } else {
                         // _combine_tree(..., biased=False): uniform transition kernel
-                        const float pr = 1.0f / (1.0f + __expf(-(lw - swt)));
+                        float pr, lse;
+                        bl_merge_weights(swt, lw, lse, pr); // pr = expit(lw - swt)
                         const float u = bl_rng_uniform(rng_s);
                         if (u < pr) { szp = cz; sgp = cg; sUp = Un; }
-                        swt = bl_logaddexp(swt, lw);
+                        swt = lse;
                         sdiv = ldiv;
                         ssumacc += lacc;
                         srsum += cr;
@@ -354,7 +371,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
                         if (going_right) { zr = cz; rr = cr; gR = cg; }
                         else { zl = cz; rl = cr; gl = cg; }
                         rsum += srsum;
-                        float pr = fminf(1.0f, __expf(swt - wt));
+                        float pr = fminf(1.0f, bl_exp(swt - wt));
                         if (sturn || sdiv) pr = 0.0f;
                         const bool turning = bl_is_turning(minv, rl, rr, rsum);
                         const float u = bl_rng_uniform(rng_s);
@@ -374,44 +391,45 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
                             cz = ez + epsdir * minv * rh;
                         } else {
                             // ---------------- transition complete ----------------
-                            const float accp = sumacc / (float)nprop;
+                            const float accp = sumacc * bl_rcp((float)nprop);
                             th = zp; gr = gp; U = Up;
                             if (it < W) {
                                 // warmup_adapter.update_fn: dual averaging (t0=10, kappa=.75, gamma=.05)
-                                const float g = p.target_accept - accp;
+                                const float g = cold->target_accept - accp;
                                 da_t += 1;
                                 const float tt = (float)da_t;
-                                da_gavg = (1.0f - 1.0f / (tt + 10.0f)) * da_gavg + g / (tt + 10.0f);
-                                da_xt = da_prox - sqrtf(tt) / 0.05f * da_gavg;
-                                const float wgt = __powf(tt, -0.75f);
+                                const float rt10 = bl_rcp(tt + 10.0f);
+                                da_gavg = (1.0f - rt10) * da_gavg + g * rt10;
+                                da_xt = da_prox - __builtin_amdgcn_sqrtf(tt) * 20.0f * da_gavg;
+                                const float wgt = __builtin_amdgcn_exp2f(-0.75f * __builtin_amdgcn_logf(tt));
                                 da_xavg = (1.0f - wgt) * da_xavg + wgt * da_xt;
-                                eps = (it == W - 1) ? __expf(da_xavg) : __expf(da_xt);
+                                eps = bl_exp((it == W - 1) ? da_xavg : da_xt);
                                 eps = fminf(fmaxf(eps, 1.1754944e-38f), 3.4028235e+38f);
-                                const bool middle = win_idx > 0 && win_idx < p.nwin - 1;
+                                const bool middle = win_idx > 0 && win_idx < cold->nwin - 1;
                                 if (middle) {
                                     wf_n += 1;
                                     const float dpre = th - wf_mean;
-                                    wf_mean += dpre / (float)wf_n;
+                                    wf_mean += dpre * bl_rcp((float)wf_n);
                                     wf_m2 += dpre * (th - wf_mean);
                                 }
-                                const bool at_end = it == p.win_end[win_idx];
+                                const bool at_end = it == cold->win_end[win_idx];
                                 if (at_end) win_idx++;
                                 if (at_end && middle) {
                                     const float n = (float)wf_n;
-                                    const float var = wf_m2 / (n - 1.0f);
-                                    minv = act ? ((n / (n + 5.0f)) * var + 1e-3f * (5.0f / (n + 5.0f))) : 0.0f;
+                                    const float var = wf_m2 * bl_rcp(n - 1.0f), rn5 = bl_rcp(n + 5.0f);
+                                    minv = act ? (n * rn5 * var + 1e-3f * 5.0f * rn5) : 0.0f;
                                     wf_mean = 0.f; wf_m2 = 0.f; wf_n = 0;
                                     da_xt = 0.f; da_xavg = 0.f; da_gavg = 0.f; da_t = 0;
-                                    da_prox = __logf(10.0f * eps);
+                                    da_prox = bl_log(10.0f * eps);
                                 }
                             } else if (member == 0) {
                                 const size_t s = (size_t)chain * S + (it - W);
-                                if (act) p.draws[s * D + lane] = th;
+                                if (act) cold->draws[s * D + lane] = th;
                                 if (lane == 0) {
-                                    p.num_steps[s] = nprop;
-                                    p.accept_prob[s] = accp;
-                                    p.diverging[s] = diverged ? 1 : 0;
-                                    p.potential[s] = (float)U;
+                                    cold->num_steps[s] = nprop;
+                                    cold->accept_prob[s] = accp;
+                                    cold->diverging[s] = diverged ? 1 : 0;
+                                    cold->potential[s] = (float)U;
                                 }
                             }
                             it++;
@@ -423,7 +441,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
                 if (new_transition) {
                     // sample momentum r = N(0,1)/sqrt(M^-1); start a fresh tree and its first doubling
                     const float z01 = bl_rng_normal(rng_d);
-                    const float r0 = act ? z01 * rsqrtf(minv) : 0.0f;
+                    const float r0 = act ? z01 * __builtin_amdgcn_rsqf(minv) : 0.0f;
                     E0 = U + (double)(0.5f * bl_wave_sum(minv * r0 * r0));
                     zl = th; rl = r0; gl = gr; zr = th; rr = r0; gR = gr;
                     zp = th; gp = gr; Up = U;
@@ -435,16 +453,16 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
                     cz = th + epsdir * minv * rh;
                 }
             }
-            sh_theta[lane] = act ? cz : 0.0f;
+            if (act) sh_coef[my_pos] = cz;
             if (lane == 0) sh_flag[0] = flag;
             if (flag != 0 && member == 0) {
-                if (flag > 1 && lane == 0) atomicMax(p.status, flag);
-                if (act) p.inv_mass[chain * D + lane] = minv;
+                if (flag > 1 && lane == 0) atomicMax(cold->status, flag);
+                if (act) cold->inv_mass[chain * D + lane] = minv;
                 if (lane == 0) {
-                    p.step_size[chain] = eps;
-                    p.nleap[chain * 2 + 0] = nleap_w;
-                    p.nleap[chain * 2 + 1] = nleap_s;
-                    p.xcd_local[chain] = local ? 1 : 0;
+                    cold->step_size[chain] = eps;
+                    cold->nleap[chain * 2 + 0] = nleap_w;
+                    cold->nleap[chain * 2 + 1] = nleap_s;
+                    cold->xcd_local[chain] = local ? 1 : 0;
                 }
             }
             BL_STAMP(4)
@@ -454,10 +472,11 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
         if (sh_flag[0] != 0) break;
     }
 #ifdef BL_STAMPS
-    if (p.dbg && chain == 0 && member == 0 && tid == 0) {
-        for (int i = 0; i < 8; i++) p.dbg[i] = st_acc[i];
-        p.dbg[8] = (long long)epoch;
-        p.dbg[9] = (long long)wall_clock64() - st_rt0;
+    if (cold->dbg && chain == 0 && member == 0 && tid == 0) {
+        for (int i = 0; i < 8; i++) cold->dbg[i] = st_acc[i];
+        cold->dbg[8] = (long long)epoch;
+        cold->dbg[9] = (long long)wall_clock64() - st_rt0;
+        cold->dbg[10] = st_spins;
     }
 #endif
 }

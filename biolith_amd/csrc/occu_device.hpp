@@ -17,19 +17,18 @@
 #define BL_SCALAR_STREAM 63
 
 // ---- dynamic LDS carve (bytes; every offset a multiple of 16: guide G17) ----
-#define BL_OFF_THETA 0      // 64 floats : theta being evaluated (lane d = dim d)
+#define BL_OFF_COEF 0       // 64 floats : coefficients being evaluated, PADDED layout (beta[0..KS], alpha[0..KO])
 #define BL_OFF_FLAG 256     // 4 ints    : loop control
-#define BL_OFF_LL 272       // 8 doubles : per-wave log-lik partial
-#define BL_OFF_PART 336     // 8 x 64 floats : per-wave gradient partials
-#define BL_OFF_CKR 2384     // 10 x 64 floats: r checkpoints      (numpyro r_ckpts)
-#define BL_OFF_CKRS 4944    // 10 x 64 floats: r_sum checkpoints  (numpyro r_sum_ckpts)
-#define BL_OFF_DATA 7680    // staged site data starts here
+#define BL_OFF_PART 272     // 8 waves x BL_PART_STRIDE floats : per-wave partial sums (padded layout + log-lik)
+#define BL_PART_STRIDE 48
+#define BL_OFF_CKR 1808     // 10 x 64 floats: r checkpoints      (numpyro r_ckpts)
+#define BL_OFF_CKRS 4368    // 10 x 64 floats: r_sum checkpoints  (numpyro r_sum_ckpts)
+#define BL_OFF_DATA 6928    // staged site records start here
 #define BL_LDS_TOTAL 163840
 
 extern __shared__ __attribute__((aligned(16))) unsigned char bl_smem_raw[];
 
 __device__ __forceinline__ float *bl_lds_f(int byte_off) { return reinterpret_cast<float *>(bl_smem_raw + byte_off); }
-__device__ __forceinline__ double *bl_lds_d(int byte_off) { return reinterpret_cast<double *>(bl_smem_raw + byte_off); }
 __device__ __forceinline__ int *bl_lds_i(int byte_off) { return reinterpret_cast<int *>(bl_smem_raw + byte_off); }
 
 // Dataset as it lives in HBM: one [rows][n_stride] float matrix, site index fastest
@@ -38,6 +37,13 @@ __device__ __forceinline__ int *bl_lds_i(int byte_off) { return reinterpret_cast
 //   rows [KS, KS + V*(KO+1))         visit v: c, c*w_1..c*w_KO  c = +1 detection / -1 non-detection / 0 masked
 //   next T rows                      ka = n_masked * ln2       (cancels the log sigma(0) of masked visits)
 //   next T rows                      kb = n_detections * log(tiny_f32)   (z=0 branch, numpyro clamp)
+//
+// In LDS a workgroup keeps its sites as per-site RECORDS (array of structures) so that a lane reads
+// its whole site with a few ds_read_b128 at immediate offsets and no address arithmetic:
+//   [ x_0..x_KS-1 | pad to 4 ]  then per period t a block of pb floats:
+//   [ visit 0: c, c*w_1..c*w_KO | visit 1 | ... | visit J-1 | ka | kb | pad to 4 ]
+// Record stride = 4 * (odd number) floats: 16-byte aligned and ds_read_b128 conflict-free
+// (any 16 lanes that are distinct mod 16 hit 16 distinct 4-bank slots).
 struct BlDevData {
     const float *rows;
     int n_sites, n_stride, T, J;
@@ -46,6 +52,16 @@ struct BlDevData {
     float loc_b, isc2_b, loc_a, isc2_a;  // Normal prior loc, 1/scale^2
     double prior_const;                  // sum_k log(scale_k) + D/2 log(2 pi)
 };
+
+__host__ __device__ inline int bl_round4(int x) { return (x + 3) & ~3; }
+// floats per period block / per site record (host and device must agree)
+__host__ __device__ inline int bl_period_block(int J, int KO) { return bl_round4(J * (KO + 1) + 2); }
+__host__ __device__ inline int bl_record_stride(int T, int J, int KS, int KO)
+{
+    int q = (bl_round4(KS) + T * bl_period_block(J, KO)) / 4;
+    if ((q & 1) == 0) q++;
+    return 4 * q;
+}
 
 // ------------------------------------------------------------------ math ----
 #define BL_LOG2E 1.4426950408889634f
@@ -103,8 +119,9 @@ __device__ __forceinline__ double bl_wave_sum_d(double x)
 
 // N independent sums with the butterfly steps outermost: the N DPP chains interleave, so no
 // s_nop padding between a VALU write and the DPP read of the same register is needed.
+// On return lane 63 of every v[i] holds the wave total (other lanes: partial sums).
 template <int N>
-__device__ __forceinline__ void bl_wave_sum_vec(float (&v)[N])
+__device__ __forceinline__ void bl_wave_sum_vec_l63(float (&v)[N])
 {
 #pragma unroll
     for (int i = 0; i < N; i++) v[i] += bl_dpp<0xB1, 0xF>(v[i]);
@@ -118,15 +135,13 @@ __device__ __forceinline__ void bl_wave_sum_vec(float (&v)[N])
     for (int i = 0; i < N; i++) v[i] += bl_dpp<0x142, 0xA>(v[i]);
 #pragma unroll
     for (int i = 0; i < N; i++) v[i] += bl_dpp<0x143, 0xC>(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; i++) v[i] = bl_readlane(v[i], 63);
 }
 __device__ __forceinline__ void bl_wave_sum2(float &a, float &b)
 {
     float v[2] = {a, b};
-    bl_wave_sum_vec<2>(v);
-    a = v[0];
-    b = v[1];
+    bl_wave_sum_vec_l63<2>(v);
+    a = bl_readlane(v[0], 63);
+    b = bl_readlane(v[1], 63);
 }
 
 // ------------------------------------------------------------------- RNG ----
@@ -156,83 +171,114 @@ __device__ __forceinline__ float bl_rng_uniform(BlRng &r)
 __device__ __forceinline__ float bl_rng_normal(BlRng &r)
 {
     const float u1 = bl_rng_uniform(r), u2 = bl_rng_uniform(r);
-    return sqrtf(-2.0f * __logf(u1)) * __builtin_amdgcn_cosf(u2);
+    return __builtin_amdgcn_sqrtf(-2.0f * BL_LN2 * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
 }
 
 // ------------------------------------------------- site log-lik + gradient ----
-// Source accessor: staged slice in LDS (row stride = ld floats) or the HBM matrix directly.
-template <bool LDS>
-__device__ __forceinline__ float bl_ld(const float *__restrict__ grows, int row, int ld, int i)
+// One visit (all f32, stable forms):  u = c*alpha0 + sum_k (c w_k) alpha_k ,
+//   log sigma(u) = min(u,0) - log(1+e^-|u|),  sigma(-u) = (u>0 ? e : 1)/(1+e),  e = e^-|u|
+template <int KO>
+__device__ __forceinline__ void bl_visit(const float (&w)[KO + 1], const float (&alpha)[KO + 1], float &a, float (&g)[KO + 1])
 {
-    if constexpr (LDS)
-        return bl_lds_f(BL_OFF_DATA)[row * ld + i];
-    else
-        return grows[(size_t)row * ld + i];
+    float u = w[0] * alpha[0];
+#pragma unroll
+    for (int k = 1; k <= KO; k++) u = fmaf(w[k], alpha[k], u);
+    const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E);
+    const float op = 1.0f + e;
+    a += fminf(u, 0.0f) - BL_LN2 * __builtin_amdgcn_logf(op);
+    const float s = (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(op);
+#pragma unroll
+    for (int k = 0; k <= KO; k++) g[k] = fmaf(s, w[k], g[k]);
 }
 
-template <int KS, int KO, bool LDS, int JC>
-__device__ __forceinline__ void bl_eval_sites_j(const float *__restrict__ grows, int ld, int cnt, int T, int J,
-                                                const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
-                                                float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
+// softplus(eta) and psi = sigmoid(eta)
+__device__ __forceinline__ void bl_site_head(float eta, float &sp, float &psi)
 {
-    // JC > 0: J == JC known at compile time -> the visit loop is fully unrolled, its LDS reads are
-    // issued together and the JC independent exp/log/rcp chains interleave (latency, not issue,
-    // bounds this phase at 2 waves per SIMD).  JC == 0: runtime J.
+    const float e_eta = __builtin_amdgcn_exp2f(-fabsf(eta) * BL_LOG2E);
+    const float op_eta = 1.0f + e_eta;
+    sp = fmaxf(eta, 0.0f) + BL_LN2 * __builtin_amdgcn_logf(op_eta);
+    psi = (eta > 0.0f ? 1.0f : e_eta) * __builtin_amdgcn_rcpf(op_eta);
+}
+
+// Sum over z of one (site, period): z=1 branch A = log psi + a ; z=0 branch B = log(1-psi) + n_det log(tiny)
+template <int KO>
+__device__ __forceinline__ void bl_period_tail(float eta, float sp, float psi, float a, float kb, const float (&g)[KO + 1],
+                                               float &ll, float &dsum, float (&ga)[KO + 1])
+{
+    const float A = eta - sp + a, B = kb - sp;
+    const float d = eta + a - kb; // = A - B
+    const float e_d = __builtin_amdgcn_exp2f(-fabsf(d) * BL_LOG2E);
+    const float op_d = 1.0f + e_d;
+    ll += fmaxf(A, B) + BL_LN2 * __builtin_amdgcn_logf(op_d);
+    const float q = (d > 0.0f ? 1.0f : e_d) * __builtin_amdgcn_rcpf(op_d); // P(z=1 | y, theta)
+    dsum += q - psi;
+#pragma unroll
+    for (int k = 0; k <= KO; k++) ga[k] = fmaf(q, g[k], ga[k]);
+}
+
+// Accumulates, over this thread's sites i = tid, tid+BL_THREADS, ... < cnt :
+//   ll += sum_t l_it ,  gb[k] += d ll / d beta_k ,  ga[k] += d ll / d alpha_k
+// LDS records; JC > 0: J == JC at compile time -> whole period block read as ds_read_b128s at
+// immediate offsets, visits fully unrolled (their exp/log/rcp chains interleave).  JC == 0: runtime J.
+template <int KS, int KO, int JC>
+__device__ __forceinline__ void bl_eval_sites_lds(int stride, int cnt, int T, int J,
+                                                  const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
+                                                  float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
+{
+    constexpr int XQ = (KS + 3) & ~3;
     const int Jn = JC > 0 ? JC : J;
-    const int V = T * Jn;
-    const int row_wc = KS, row_ka = KS + V * (KO + 1), row_kb = row_ka + T;
+    const int pb = bl_period_block(Jn, KO);
+    const float *data = bl_lds_f(BL_OFF_DATA);
     for (int i = threadIdx.x; i < cnt; i += BL_THREADS) {
-        float x[KS > 0 ? KS : 1];
+        const float4 *rec = reinterpret_cast<const float4 *>(data + (size_t)i * stride);
+        float x[XQ];
+#pragma unroll
+        for (int q = 0; q < XQ / 4; q++) {
+            const float4 v = rec[q];
+            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        }
         float eta = beta[0];
 #pragma unroll
-        for (int k = 0; k < KS; k++) {
-            x[k] = bl_ld<LDS>(grows, k, ld, i);
-            eta = fmaf(x[k], beta[k + 1], eta);
-        }
-        // softplus(eta), psi = sigmoid(eta)
-        const float e_eta = __builtin_amdgcn_exp2f(-fabsf(eta) * BL_LOG2E);
-        const float op_eta = 1.0f + e_eta;
-        const float sp = fmaxf(eta, 0.0f) + BL_LN2 * __builtin_amdgcn_logf(op_eta);
-        const float psi = (eta > 0.0f ? 1.0f : e_eta) * __builtin_amdgcn_rcpf(op_eta);
+        for (int k = 0; k < KS; k++) eta = fmaf(x[k], beta[k + 1], eta);
+        float sp, psi;
+        bl_site_head(eta, sp, psi);
         float dsum = 0.0f;
         for (int t = 0; t < T; t++) {
-            float a = bl_ld<LDS>(grows, row_ka + t, ld, i);
             float g[KO + 1];
 #pragma unroll
             for (int k = 0; k <= KO; k++) g[k] = 0.0f;
-            auto visit = [&](int j) {
-                const int r0 = row_wc + (t * Jn + j) * (KO + 1);
-                float w[KO + 1];
-#pragma unroll
-                for (int k = 0; k <= KO; k++) w[k] = bl_ld<LDS>(grows, r0 + k, ld, i);
-                float u = w[0] * alpha[0];
-#pragma unroll
-                for (int k = 1; k <= KO; k++) u = fmaf(w[k], alpha[k], u);
-                const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E);
-                const float op = 1.0f + e;
-                a += fminf(u, 0.0f) - BL_LN2 * __builtin_amdgcn_logf(op);
-                const float s = (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(op);
-#pragma unroll
-                for (int k = 0; k <= KO; k++) g[k] = fmaf(s, w[k], g[k]);
-            };
+            float a, kb;
             if constexpr (JC > 0) {
+                constexpr int PBC = (JC * (KO + 1) + 2 + 3) & ~3;
+                const float4 *pq = rec + XQ / 4 + t * (PBC / 4);
+                float blk[PBC];
 #pragma unroll
-                for (int j = 0; j < JC; j++) visit(j);
+                for (int q = 0; q < PBC / 4; q++) {
+                    const float4 v = pq[q];
+                    blk[4 * q] = v.x; blk[4 * q + 1] = v.y; blk[4 * q + 2] = v.z; blk[4 * q + 3] = v.w;
+                }
+                a = blk[JC * (KO + 1)];
+                kb = blk[JC * (KO + 1) + 1];
+#pragma unroll
+                for (int j = 0; j < JC; j++) {
+                    float w[KO + 1];
+#pragma unroll
+                    for (int k = 0; k <= KO; k++) w[k] = blk[j * (KO + 1) + k];
+                    bl_visit<KO>(w, alpha, a, g);
+                }
             } else {
-#pragma unroll 4
-                for (int j = 0; j < Jn; j++) visit(j);
-            }
-            const float kb = bl_ld<LDS>(grows, row_kb + t, ld, i);
-            // z=1 branch A = log psi + a ; z=0 branch B = log(1-psi) + n_det log(tiny)
-            const float A = eta - sp + a, B = kb - sp;
-            const float d = eta + a - kb; // = A - B
-            const float e_d = __builtin_amdgcn_exp2f(-fabsf(d) * BL_LOG2E);
-            const float op_d = 1.0f + e_d;
-            ll += fmaxf(A, B) + BL_LN2 * __builtin_amdgcn_logf(op_d);
-            const float q = (d > 0.0f ? 1.0f : e_d) * __builtin_amdgcn_rcpf(op_d); // P(z=1 | y, theta)
-            dsum += q - psi;
+                const float *pp = data + (size_t)i * stride + XQ + t * pb;
+                a = pp[Jn * (KO + 1)];
+                kb = pp[Jn * (KO + 1) + 1];
+#pragma unroll 2
+                for (int j = 0; j < Jn; j++) {
+                    float w[KO + 1];
 #pragma unroll
-            for (int k = 0; k <= KO; k++) ga[k] = fmaf(q, g[k], ga[k]);
+                    for (int k = 0; k <= KO; k++) w[k] = pp[j * (KO + 1) + k];
+                    bl_visit<KO>(w, alpha, a, g);
+                }
+            }
+            bl_period_tail<KO>(eta, sp, psi, a, kb, g, ll, dsum, ga);
         }
         gb[0] += dsum;
 #pragma unroll
@@ -240,69 +286,123 @@ __device__ __forceinline__ void bl_eval_sites_j(const float *__restrict__ grows,
     }
 }
 
-// Accumulates, over this thread's sites i = tid, tid+BL_THREADS, ... < cnt :
-//   ll     += sum_t l_it                        (log-lik, z marginalised)
-//   gb[k]  += d ll / d beta_k ,  ga[k] += d ll / d alpha_k
-// Per visit (all in f32, stable forms):  u = c*alpha0 + sum_k (c w_k) alpha_k ,
-//   log sigma(u) = min(u,0) - log(1+e^-|u|),  sigma(-u) = (u>0 ? e : 1)/(1+e),  e = e^-|u|
+// Same arithmetic straight from the HBM rows (slice too large for LDS); grows is already offset to
+// this workgroup's first site, ld = n_stride.
+template <int KS, int KO>
+__device__ __forceinline__ void bl_eval_sites_hbm(const float *__restrict__ grows, int ld, int cnt, int T, int J,
+                                                  const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
+                                                  float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
+{
+    const int V = T * J;
+    const int row_wc = KS, row_ka = KS + V * (KO + 1), row_kb = row_ka + T;
+    for (int i = threadIdx.x; i < cnt; i += BL_THREADS) {
+        float x[KS > 0 ? KS : 1];
+        float eta = beta[0];
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            x[k] = grows[(size_t)k * ld + i];
+            eta = fmaf(x[k], beta[k + 1], eta);
+        }
+        float sp, psi;
+        bl_site_head(eta, sp, psi);
+        float dsum = 0.0f;
+        for (int t = 0; t < T; t++) {
+            float a = grows[(size_t)(row_ka + t) * ld + i];
+            const float kb = grows[(size_t)(row_kb + t) * ld + i];
+            float g[KO + 1];
+#pragma unroll
+            for (int k = 0; k <= KO; k++) g[k] = 0.0f;
+#pragma unroll 4
+            for (int j = 0; j < J; j++) {
+                const size_t r0 = (size_t)(row_wc + (t * J + j) * (KO + 1));
+                float w[KO + 1];
+#pragma unroll
+                for (int k = 0; k <= KO; k++) w[k] = grows[(r0 + k) * ld + i];
+                bl_visit<KO>(w, alpha, a, g);
+            }
+            bl_period_tail<KO>(eta, sp, psi, a, kb, g, ll, dsum, ga);
+        }
+        gb[0] += dsum;
+#pragma unroll
+        for (int k = 0; k < KS; k++) gb[k + 1] = fmaf(dsum, x[k], gb[k + 1]);
+    }
+}
+
 template <int KS, int KO, bool LDS>
-__device__ __forceinline__ void bl_eval_sites(const float *__restrict__ grows, int ld, int cnt, int T, int J,
+__device__ __forceinline__ void bl_eval_sites(const float *__restrict__ grows, int ld_or_stride, int cnt, int T, int J,
                                               const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                               float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
 {
-    switch (J) { // wave-uniform
-    case 1: bl_eval_sites_j<KS, KO, LDS, 1>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga); break;
-    case 2: bl_eval_sites_j<KS, KO, LDS, 2>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga); break;
-    case 3: bl_eval_sites_j<KS, KO, LDS, 3>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga); break;
-    case 4: bl_eval_sites_j<KS, KO, LDS, 4>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga); break;
-    case 5: bl_eval_sites_j<KS, KO, LDS, 5>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga); break;
-    case 6: bl_eval_sites_j<KS, KO, LDS, 6>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga); break;
-    case 8: bl_eval_sites_j<KS, KO, LDS, 8>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga); break;
-    default: bl_eval_sites_j<KS, KO, LDS, 0>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga); break;
+    if constexpr (LDS) {
+        switch (J) { // wave-uniform
+        case 1: bl_eval_sites_lds<KS, KO, 1>(ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 2: bl_eval_sites_lds<KS, KO, 2>(ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 3: bl_eval_sites_lds<KS, KO, 3>(ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 4: bl_eval_sites_lds<KS, KO, 4>(ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 5: bl_eval_sites_lds<KS, KO, 5>(ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 6: bl_eval_sites_lds<KS, KO, 6>(ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 8: bl_eval_sites_lds<KS, KO, 8>(ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        default: bl_eval_sites_lds<KS, KO, 0>(ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        }
+    } else {
+        bl_eval_sites_hbm<KS, KO>(grows, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga);
     }
 }
 
-// Copy this workgroup's site slice [s0, s0+cnt) of every row into LDS (row stride ld).
-__device__ __forceinline__ void bl_stage_rows(const float *__restrict__ rows, int n_rows, int n_stride, int s0, int cnt, int ld)
+// Transpose this workgroup's site slice [s0, s0+cnt) of the HBM rows (coalesced reads along the
+// site axis) into per-site LDS records.
+__device__ __forceinline__ void bl_stage_records(const float *__restrict__ rows, int n_stride, int s0, int cnt,
+                                                 int T, int J, int KS, int KO, int stride)
 {
     float *dst = bl_lds_f(BL_OFF_DATA);
+    const int xq = bl_round4(KS), pb = bl_period_block(J, KO), V = T * J, vw = KO + 1;
+    const int n_rows = KS + V * vw + 2 * T;
     for (int r = 0; r < n_rows; r++) {
+        int pos;
+        if (r < KS) pos = r;
+        else if (r < KS + V * vw) {
+            const int v = (r - KS) / vw, k = (r - KS) - v * vw, t = v / J, j = v - t * J;
+            pos = xq + t * pb + j * vw + k;
+        } else if (r < KS + V * vw + T) pos = xq + (r - KS - V * vw) * pb + J * vw;
+        else pos = xq + (r - KS - V * vw - T) * pb + J * vw + 1;
         const float *src = rows + (size_t)r * n_stride + s0;
-        for (int i = threadIdx.x; i < ld; i += BL_THREADS) dst[r * ld + i] = (i < cnt) ? src[i] : 0.0f;
+        for (int i = threadIdx.x; i < cnt; i += BL_THREADS) dst[(size_t)i * stride + pos] = src[i];
     }
 }
 
-// theta (D floats in LDS, lane-d order) -> padded coefficient registers.
+// Padded coefficient layout in LDS: beta_k at k (k <= KS), alpha_k at KS+1+k.  dim d of theta
+// (d <= Ks: beta_d, else alpha_{d-Ks-1}) lives at:
+__device__ __forceinline__ int bl_coef_pos(int d, int Ks, int KS) { return d <= Ks ? d : KS + 1 + (d - Ks - 1); }
+
 template <int KS, int KO>
-__device__ __forceinline__ void bl_load_coefs(const float *th, int Ks, int Ko, float (&beta)[KS + 1], float (&alpha)[KO + 1])
+__device__ __forceinline__ void bl_load_coefs(float (&beta)[KS + 1], float (&alpha)[KO + 1])
 {
+    const float *c = bl_lds_f(BL_OFF_COEF); // unused (padded) slots were zeroed once at kernel start
 #pragma unroll
-    for (int k = 0; k <= KS; k++) beta[k] = (k <= Ks) ? th[k] : 0.0f;
+    for (int k = 0; k <= KS; k++) beta[k] = c[k];
 #pragma unroll
-    for (int k = 0; k <= KO; k++) alpha[k] = (k <= Ko) ? th[Ks + 1 + k] : 0.0f;
+    for (int k = 0; k <= KO; k++) alpha[k] = c[KS + 1 + k];
 }
 
-// Workgroup reduction of (ll, gb, ga) -> LDS per-wave partials.  Component layout (lane index in
-// the control wave): c in [0, Ks] dll/dbeta, [Ks+1, D) dll/dalpha.  ll is kept in double.
+// Wave reduction of (gb, ga, ll) -> this wave's row of the LDS partial table, padded layout:
+// [0..KS] d/dbeta, [KS+1..KS+KO+1] d/dalpha, [KS+KO+2] log-lik.  One interleaved DPP butterfly for
+// all values (f32: the per-term rounding of the f32 site math dominates the error budget anyway);
+// lane 63 holds the totals and stores them.  Cross-wave / cross-workgroup sums are done in f64.
 template <int KS, int KO>
-__device__ __forceinline__ void bl_wave_partials_to_lds(int Ks, int Ko, float ll, const float (&gb)[KS + 1], const float (&ga)[KO + 1])
+__device__ __forceinline__ void bl_wave_partials_to_lds(float ll, const float (&gb)[KS + 1], const float (&ga)[KO + 1])
 {
+    constexpr int NV = KS + KO + 3;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float v[KS + KO + 2];
+    float v[NV];
 #pragma unroll
     for (int k = 0; k <= KS; k++) v[k] = gb[k];
 #pragma unroll
     for (int k = 0; k <= KO; k++) v[KS + 1 + k] = ga[k];
-    bl_wave_sum_vec<KS + KO + 2>(v);
-    const double llw = bl_wave_sum_d((double)ll);
-    float *part = bl_lds_f(BL_OFF_PART) + wave * 64;
-    if (lane == 0) {
+    v[NV - 1] = ll;
+    bl_wave_sum_vec_l63<NV>(v);
+    if (lane == 63) {
+        float *part = bl_lds_f(BL_OFF_PART) + wave * BL_PART_STRIDE;
 #pragma unroll
-        for (int k = 0; k <= KS; k++)
-            if (k <= Ks) part[k] = v[k];
-#pragma unroll
-        for (int k = 0; k <= KO; k++)
-            if (k <= Ko) part[Ks + 1 + k] = v[KS + 1 + k];
-        bl_lds_d(BL_OFF_LL)[wave] = llw;
+        for (int k = 0; k < NV; k++) part[k] = v[k];
     }
 }
