@@ -335,15 +335,16 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     const int per_xcd = ((chains > 0 ? chains : 1) + 7) / 8;
     int kmax = 32 / per_xcd;
     if (kmax < 1) kmax = 1;
-    int k = want_k > 0 ? want_k : (N + BL_THREADS - 1) / BL_THREADS;
+    // a lane evaluates a PAIR of sites (packed f32 math): one pair per thread is the latency optimum
+    int k = want_k > 0 ? want_k : (N + 2 * BL_CTHREADS - 1) / (2 * BL_CTHREADS);
     if (k > kmax) k = kmax;
     if (k < 1) k = 1;
     const int lds_cap = BL_LDS_TOTAL - BL_OFF_DATA;
-    // LDS keeps one record of `stride` floats per site (occu_device.hpp)
+    // LDS keeps one record of `stride` floats per PAIR of sites (occu_device.hpp)
     const int stride = bl_record_stride(ds->dims.n_periods, ds->dims.n_replicates, ds->KS, ds->KO);
     auto fits = [&](int kk, int *nloc) {
         *nloc = (N + kk - 1) / kk;
-        return (long long)*nloc * stride * 4 <= lds_cap;
+        return (long long)((*nloc + 1) / 2) * stride * 4 <= lds_cap;
     };
     int nloc;
     bool ok = fits(k, &nloc);
@@ -351,7 +352,7 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
         for (int kk = k + 1; kk <= kmax && !ok; kk++) { ok = fits(kk, &nloc); if (ok) k = kk; }
     if (!ok) fits(k, &nloc);
     *k_out = k; *nloc_out = nloc; *ld_out = stride; *staged_out = ok ? 1 : 0;
-    *lds_bytes_out = ok ? BL_OFF_DATA + nloc * stride * 4 : BL_OFF_DATA;
+    *lds_bytes_out = ok ? BL_OFF_DATA + ((nloc + 1) / 2) * stride * 4 : BL_OFF_DATA;
 }
 
 // ------------------------------------------------------------- K1 logp ----
@@ -449,7 +450,9 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     ds->d_acc = (float *)(base + o_acc); ds->d_pot = (float *)(base + o_pot); ds->d_eps = (float *)(base + o_eps);
     ds->d_minv = (float *)(base + o_minv); ds->d_nleap = (long long *)(base + o_nleap); ds->d_status = (int *)(base + o_status);
     ds->d_rng = (uint32_t *)(base + o_rng); ds->d_init = (float *)(base + o_init); ds->d_dbg = (long long *)(base + o_dbg); ds->d_loc = (int *)(base + o_loc);
-    const size_t xb = align256((size_t)C * 2 * k * nvp * 8);
+    int pitch = nvp; // granules between workgroup records
+    { const char *e = getenv("BIOLITH_HIP_PITCH"); if (e && atoi(e) >= nvp && atoi(e) <= 4096) pitch = atoi(e); }
+    const size_t xb = align256((size_t)C * 2 * k * pitch * 8);
     if (xb > ds->xchg_bytes) {
         if (ds->d_xchg) hipFree(ds->d_xchg);
         ds->d_xchg = nullptr; ds->xchg_bytes = 0;
@@ -503,6 +506,10 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
         p.allow_local = (e1 && e1[0] == '1') ? 0 : 1;
         p.poll_sleep = e2 ? atoi(e2) : 3;
         if (p.poll_sleep < 0 || p.poll_sleep > 127) p.poll_sleep = 3;
+        const char *e3 = getenv("BIOLITH_HIP_FIRST_DELAY");
+        p.pitch = pitch;
+        p.first_delay = e3 ? atoi(e3) : 2;
+        if (p.first_delay < 0 || p.first_delay > 127) p.first_delay = 2;
     }
 
     // timed region: state re-init (guide G16 "re-initialise every call") + the persistent kernel

@@ -36,21 +36,23 @@ __global__ void __launch_bounds__(BL_THREADS) bl_logp_kernel(const BlLogpParams 
     for (int b = 0; b < p.B; b++) {
         if (wave == 0 && lane < D) sh_coef[my_pos] = p.theta[(size_t)b * D + lane];
         __syncthreads();
-        float beta[KS + 1], alpha[KO + 1];
-        bl_load_coefs<KS, KO>(beta, alpha);
-        float ll = 0.0f, gb[KS + 1], ga[KO + 1];
+        if (wave > 0) { // compute waves, exactly as in the NUTS kernel
+            float beta[KS + 1], alpha[KO + 1];
+            bl_load_coefs<KS, KO>(beta, alpha);
+            float ll = 0.0f, gb[KS + 1], ga[KO + 1];
 #pragma unroll
-        for (int k = 0; k <= KS; k++) gb[k] = 0.0f;
+            for (int k = 0; k <= KS; k++) gb[k] = 0.0f;
 #pragma unroll
-        for (int k = 0; k <= KO; k++) ga[k] = 0.0f;
-        bl_eval_sites<KS, KO, LDS>(grows, ld, cnt, p.dd.T, p.dd.J, beta, alpha, ll, gb, ga);
-        bl_wave_partials_to_lds<KS, KO>(ll, gb, ga);
+            for (int k = 0; k <= KO; k++) ga[k] = 0.0f;
+            bl_eval_sites<KS, KO, LDS>(tid - 64, grows, ld, cnt, p.dd.T, p.dd.J, beta, alpha, ll, gb, ga);
+            bl_wave_partials_to_lds<KS, KO>(wave - 1, ll, gb, ga);
+        }
         __syncthreads();
         if (wave == 0) {
             const float *part = bl_lds_f(BL_OFF_PART);
             double acc = 0.0;
 #pragma unroll
-            for (int w = 0; w < BL_WAVES; w++) acc += (double)part[w * BL_PART_STRIDE + my_pos];
+            for (int w = 0; w < BL_CWAVES; w++) acc += (double)part[w * BL_PART_STRIDE + my_pos];
             double *out = p.partial + ((size_t)b * p.k + member) * 64;
             if (lane <= D) out[lane] = acc;
         }

@@ -6,26 +6,32 @@
 // between subtrees), dual-averaging step size, windowed Welford diagonal mass matrix.
 //
 // Mapping to the chip
-//   * one chain = k cooperating workgroups (512 threads each, one per CU); a workgroup owns a
-//     contiguous slice of sites, staged ONCE into LDS as per-site records (occu_device.hpp);
+//   * one chain = k cooperating workgroups, one per CU; a workgroup = 4 compute waves (one per
+//     SIMD) + 1 control wave.  It owns a contiguous slice of sites, staged ONCE into LDS as pair
+//     records and evaluated two sites per lane (occu_device.hpp);
 //   * blockIdx -> (chain, member) is XCD-aware: blocks b and b+8 share an XCD under the observed
 //     round-robin dealing, so chain c takes the blocks with b % 8 == c % 8 and its k workgroups
 //     share one L2.  That is a SPEED arrangement only: every workgroup reads HW_REG_XCC_ID and the
 //     chain switches to the L2-local exchange (below) only if the first, placement-independent
 //     exchange proves that all k workgroups really sit on one XCD;
-//   * every leapfrog ("tick"): all 8 waves evaluate their sites' log-lik + gradient from LDS ->
-//     one interleaved DPP wave reduction -> LDS -> workgroup partial (D grads f32, log-lik hi+lo);
-//   * the k partials are all-gathered through 8-byte {epoch, value} granules (guide G16, form R2:
+//   * every leapfrog ("tick"): the compute waves evaluate their sites' log-lik + gradient from LDS
+//     -> one interleaved DPP wave reduction -> LDS; the control wave forms the workgroup partial
+//     (D gradients + log-lik, f32) and
+//   * all-gathers the k partials through 8-byte {epoch, value} granules (guide G16, form R2:
 //     the data is the flag), double-buffered by epoch parity, every spin bounded:
 //       - placement-independent form: ONE sc1 (write-through) store per granule, relaxed
 //         agent-scope (sc1) polls;
 //       - L2-local form (verified same-XCD chains only): workgroup-scope stores keep the line in
 //         the XCD's L2, sc1 polls bypass L1 and hit that L2: several times shorter hop;
-//     two poll rounds are kept in flight, spaced a fraction of a round trip apart;
 //     every workgroup sums the k records in the same fixed order in f64, so all k copies of the
 //     chain state stay bit-identical without any broadcast;
-//   * wave 0 of every workgroup then advances the (replicated) NUTS state machine by one leaf,
-//     lane d holding dimension d, and publishes the next position to its workgroup through LDS.
+//   * the control wave (lane d = dimension d) then runs only the CRITICAL part of NumPyro's
+//     per-leaf logic -- finish the velocity-Verlet step, energy error, checkpointed U-turn test,
+//     and the decision where the next leaf goes -- publishes that position through LDS, and
+//     DEFERS the bookkeeping that cannot change the next position (multinomial proposal updates,
+//     tree weights, accept-prob sums): it runs while the compute waves already evaluate the next
+//     leaf.  Direction bits and transition uniforms come from two separate xoshiro streams so
+//     that the deferral does not reorder any stream (the oracle draws from the same two).
 // No host round trip, no kernel boundary and no HBM traffic inside the sampling loop.
 #pragma once
 #include "occu_device.hpp"
@@ -72,15 +78,27 @@ struct BlNutsParams {
     int num_chains;
     int k;                         // workgroups per chain
     int nloc;                      // sites per workgroup
-    int rec_stride;                // floats per LDS site record
+    int rec_stride;                // floats per LDS pair record
     int nvp;                       // granules per workgroup record: 16, 32 or 64 (>= D+4)
     int max_depth;
     int allow_local;               // 0: always use the placement-independent exchange
-    int poll_sleep;                // s_sleep(1) repeats between the two in-flight poll rounds (fabric form)
+    int poll_sleep;                // s_sleep(1) repeats between re-polls (fabric form)
+    int first_delay;               // s_sleep(1) repeats between publishing and the first poll
+    int pitch;                     // granules between consecutive workgroup records (>= nvp)
     unsigned spin_limit;
     unsigned long long *xchg;      // [C][2][k][nvp] granules, zeroed before every launch
     const BlNutsCold *cold;
 };
+
+// Control-wave state that changes only at subtree / transition boundaries (LDS, control wave only).
+struct BlCtlScalars {
+    double U, Up;                  // potential at the current position / at the tree's proposal
+    float wt, sumacc, eps;         // tree log-weight, sum of accept probs, step size
+    float da_xt, da_xavg, da_gavg, da_prox;  // dual averaging
+    int nprop, diverged, da_t, wf_n, win_idx, it;
+    long long nleap_w, nleap_s;
+};
+enum { SV_TH = 0, SV_GR, SV_ZL, SV_RL, SV_GL, SV_ZR, SV_RR, SV_GRR, SV_ZP, SV_GP, SV_RSUM, SV_WFMEAN, SV_WFM2 };
 
 __device__ __forceinline__ float bl_exp(float x) { return __builtin_amdgcn_exp2f(x * BL_LOG2E); }
 __device__ __forceinline__ float bl_log(float x) { return BL_LN2 * __builtin_amdgcn_logf(x); }
@@ -104,11 +122,11 @@ __device__ __forceinline__ void bl_merge_weights(float a, float b, float &lse, f
 }
 
 // numpyro hmc_util._is_turning (diagonal mass); lane d = dim d, lanes >= D hold zeros.
-__device__ __forceinline__ bool bl_is_turning(float minv, float rl, float rr, float rsum)
+__device__ __forceinline__ bool bl_is_turning(float minv, float rl, float rr, float rsum, int D)
 {
     const float rho = rsum - 0.5f * (rl + rr);
     float dl = minv * rl * rho, dr = minv * rr * rho;
-    bl_wave_sum2(dl, dr);
+    bl_low_sum2(dl, dr, D);
     return (dl <= 0.0f) || (dr <= 0.0f);
 }
 
@@ -119,20 +137,10 @@ __device__ __forceinline__ unsigned bl_xcc_id()
     return x & 0xFu;
 }
 
-// One poll round: every lane loads its granule of 8 records (sc1: bypasses L1).  Record indices
-// beyond k are clamped to k-1: the duplicate loads carry valid tags and are ignored in the sum,
-// so the round needs no predication.
-#define BL_POLL_ISSUE(buf)                                                                                       \
-    _Pragma("unroll") for (int q = 0; q < 8; q++) {                                                              \
-        const int w_ = min(p0 + q * G + sub, p.k - 1);                                                           \
-        buf[q] = __hip_atomic_load(rec + (size_t)w_ * nvp + c_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  \
-    }
-#define BL_POLL_CHECK(buf, okv)                                                                                  \
-    {                                                                                                            \
-        unsigned bad_ = 0u;                                                                                      \
-        _Pragma("unroll") for (int q = 0; q < 8; q++) bad_ |= ((unsigned)(buf[q] >> 32)) ^ epoch;                \
-        okv = __all(bad_ == 0u);                                                                                 \
-    }
+__device__ __forceinline__ unsigned long long bl_poll_load(const unsigned char *base, unsigned off)
+{
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(base + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <int KS, int KO, bool LDS>
 __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams p)
@@ -158,43 +166,59 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
     float *sh_coef = bl_lds_f(BL_OFF_COEF);
     int *sh_flag = bl_lds_i(BL_OFF_FLAG);
     float *sh_ckr = bl_lds_f(BL_OFF_CKR), *sh_ckrs = bl_lds_f(BL_OFF_CKRS);
+    float *sv = bl_lds_f(BL_OFF_SV) + lane;  // state vector slot s of this lane: sv[s * 64]
+    BlCtlScalars *ss = reinterpret_cast<BlCtlScalars *>(bl_smem_raw + BL_OFF_SS);
     if (tid < 64) sh_coef[tid] = 0.0f;
     __syncthreads();
 
-    // ------------------------------------------------ replicated chain state (wave 0) ----
+    // ------------------------------------------------ replicated chain state (control wave) ----
     const BlNutsCold *cold = p.cold;
     const bool act = lane < D;
     // where lane d's coefficient / partial lives in the padded LDS layouts; lanes >= D read the log-lik
     const int my_pos = act ? bl_coef_pos(lane, Ks, KS) : KS + KO + 2;
-    int S = 0, W = 0, total = 0;
-    BlRng rng_d, rng_s; // per-dimension stream, shared scalar stream
-    float th = 0.f, gr = 0.f;           // current position / gradient of U
-    double U = 0.0;                     // current potential
+    // ---- loop-carried registers: only what the per-leaf path touches ----
+    BlRng rng_d, rng_u, rng_dir;        // per-dimension stream, transition uniforms, direction bits
     float minv = act ? 1.0f : 0.0f;     // diagonal inverse mass (0 in idle lanes keeps sums clean)
-    float eps = 1.0f;
-    // dual averaging + Welford
-    float da_xt = 0.f, da_xavg = 0.f, da_gavg = 0.f, da_prox = 2.302585093f;
-    int da_t = 0, wf_n = 0, win_idx = 0;
-    float wf_mean = 0.f, wf_m2 = 0.f;
-    // tree
-    double E0 = 0.0, Up = 0.0;
-    float zl = 0, rl = 0, gl = 0, zr = 0, rr = 0, gR = 0, zp = 0, gp = 0, rsum = 0, wt = 0, sumacc = 0;
-    int depth = 0, nprop = 0;
-    bool diverged = false;
+    float eps = 1.0f, epsdir = 0.f;
+    double E0 = 0.0;                    // energy at the start of the transition
+    int depth = 0;
     // subtree under construction
     double sUp = 0.0;
     float szp = 0, sgp = 0, srsum = 0, swt = 0, ssumacc = 0;
     int snprop = 0;
     bool sdiv = false, sturn = false, going_right = false;
-    float epsdir = 0.f;
     // leaf in flight
     float cz = 0, rh = 0;
-    int it = -1; // -1: evaluating the initial position
-    long long nleap_w = 0, nleap_s = 0;
-    bool local = false; // L2-local exchange proven safe for this chain
+    // bookkeeping deferred from the last leaf (runs while the compute waves evaluate the next one)
+    bool pend = false, pend_first = false, pend_end = false, pend_sturn = false, pend_sdiv = false;
+    float pend_dE = 0.f, pend_z = 0.f, pend_g = 0.f;
+    double pend_U = 0.0;
+    int pend_snprop = 0;
+    bool init_pending = true;           // evaluating the initial position
+    bool local = false;                 // L2-local exchange proven safe for this chain
     float prior_loc = 0.f, prior_isc2 = 0.f;
     double prior_const = 0.0;
+    int S = 0, W = 0, total = 0;
     const float xcc = (float)bl_xcc_id();
+
+    // exchange addressing (per lane, fixed for the whole launch): byte offsets of the <= 8 granules this
+    // lane polls per round; record indices beyond k are clamped to k-1 (duplicates carry valid
+    // tags and are ignored in the sum, so a round needs no predication)
+    const int nvp = p.nvp, G = 64 / nvp;
+    const int c_idx = lane & (nvp - 1), sub = lane / nvp;
+    const unsigned rec_bytes = (unsigned)(p.k * p.pitch * 8);
+    const unsigned char *xbase = reinterpret_cast<const unsigned char *>(p.xchg) + (size_t)chain * 2 * rec_bytes;
+    const unsigned my_store_off = (unsigned)((member * p.pitch + (lane & (nvp - 1))) * 8);
+    unsigned poff[8];
+    float pval[8]; // 1 if that load is a real (unclamped) record of this lane
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int w = q * G + sub;
+        poff[q] = (unsigned)(((w < p.k ? w : p.k - 1) * p.pitch + c_idx) * 8);
+        pval[q] = (w < p.k) ? 1.0f : 0.0f;
+    }
+    const int nq = (p.k + G - 1) / G; // loads per round actually needed (<= 8 when k <= 8 G)
+    const bool one_batch = p.k <= 8 * G;
 
     if (wave == 0) {
         S = cold->num_samples; W = cold->num_warmup; total = W + S;
@@ -203,32 +227,74 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
         prior_const = cold->prior_const;
         const uint32_t *rs = cold->rng + ((size_t)chain * BL_NSTREAM + lane) * 4;
         rng_d.s0 = rs[0]; rng_d.s1 = rs[1]; rng_d.s2 = rs[2]; rng_d.s3 = rs[3];
-        const uint32_t *rc = cold->rng + ((size_t)chain * BL_NSTREAM + BL_SCALAR_STREAM) * 4;
-        rng_s.s0 = rc[0]; rng_s.s1 = rc[1]; rng_s.s2 = rc[2]; rng_s.s3 = rc[3];
+        const uint32_t *ru = cold->rng + ((size_t)chain * BL_NSTREAM + BL_SCALAR_STREAM) * 4;
+        rng_u.s0 = ru[0]; rng_u.s1 = ru[1]; rng_u.s2 = ru[2]; rng_u.s3 = ru[3];
+        const uint32_t *rd = cold->rng + ((size_t)chain * BL_NSTREAM + BL_DIR_STREAM) * 4;
+        rng_dir.s0 = rd[0]; rng_dir.s1 = rd[1]; rng_dir.s2 = rd[2]; rng_dir.s3 = rd[3];
         const float u0 = bl_rng_uniform(rng_d); // init_to_uniform(radius=2), fit.py:93
         const float *init = cold->init_theta;
         cz = act ? (init ? init[chain * D + lane] : 4.0f * u0 - 2.0f) : 0.0f;
         if (act) sh_coef[my_pos] = cz;
-        if (lane == 0) sh_flag[0] = 0;
+#pragma unroll
+        for (int s = 0; s < 16; s++) sv[s * 64] = 0.0f;
+        if (lane == 0) {
+            sh_flag[0] = 0;
+            BlCtlScalars z{};
+            z.eps = 1.0f; z.da_prox = 2.302585093f; // log(10 * step_size0)
+            *ss = z;
+        }
     }
     __syncthreads();
+
+    // Deferred bookkeeping of the last finished leaf (hmc_util._combine_tree: proposal + weights).
+    // Nothing in here can change where the next leaf is evaluated.
+    auto run_deferred = [&]() {
+        if (!pend) return;
+        pend = false;
+        const float lw = -pend_dE;
+        const float lacc = pend_dE <= 0.0f ? 1.0f : bl_exp(-pend_dE); // min(1, exp(-dE))
+        if (pend_first) {
+            szp = pend_z; sgp = pend_g; sUp = pend_U; swt = lw; ssumacc = lacc;
+        } else {
+            // biased=False: uniform transition kernel inside the subtree
+            float pr, lse;
+            bl_merge_weights(swt, lw, lse, pr); // pr = expit(lw - swt)
+            const float u = bl_rng_uniform(rng_u);
+            if (u < pr) { szp = pend_z; sgp = pend_g; sUp = pend_U; }
+            swt = lse;
+            ssumacc += lacc;
+        }
+        if (pend_end) {
+            // biased=True: merge the finished subtree into the tree
+            const float wt = ss->wt;
+            float pr = fminf(1.0f, bl_exp(swt - wt));
+            if (pend_sturn || pend_sdiv) pr = 0.0f;
+            const float u = bl_rng_uniform(rng_u);
+            if (u < pr) { sv[SV_ZP * 64] = szp; sv[SV_GP * 64] = sgp; ss->Up = sUp; }
+            ss->wt = bl_logaddexp(wt, swt);
+            ss->sumacc += ssumacc;
+            ss->nprop += pend_snprop;
+        }
+    };
 
     unsigned epoch = 0;
     BL_STAMP_DECL
     while (true) {
-        // ------------------------------------------- phase A: all waves, site log-lik ----
-        float beta[KS + 1], alpha[KO + 1];
-        bl_load_coefs<KS, KO>(beta, alpha);
-        BL_STAMP(6)
-        float ll = 0.0f, gb[KS + 1], ga[KO + 1];
+        if (wave > 0) {
+            // ------------------------------------- phase A: compute waves, site log-lik ----
+            float beta[KS + 1], alpha[KO + 1];
+            bl_load_coefs<KS, KO>(beta, alpha);
+            float ll = 0.0f, gb[KS + 1], ga[KO + 1];
 #pragma unroll
-        for (int k = 0; k <= KS; k++) gb[k] = 0.0f;
+            for (int k = 0; k <= KS; k++) gb[k] = 0.0f;
 #pragma unroll
-        for (int k = 0; k <= KO; k++) ga[k] = 0.0f;
-        bl_eval_sites<KS, KO, LDS>(grows, ld, cnt, T, J, beta, alpha, ll, gb, ga);
-        BL_STAMP(7)
-        bl_wave_partials_to_lds<KS, KO>(ll, gb, ga);
-        BL_STAMP(0)
+            for (int k = 0; k <= KO; k++) ga[k] = 0.0f;
+            bl_eval_sites<KS, KO, LDS>(tid - 64, grows, ld, cnt, T, J, beta, alpha, ll, gb, ga);
+            bl_wave_partials_to_lds<KS, KO>(wave - 1, ll, gb, ga);
+        } else {
+            run_deferred(); // overlaps phase A
+            BL_STAMP(0)
+        }
         __syncthreads();
         BL_STAMP(1)
 
@@ -238,7 +304,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
             const float *part = bl_lds_f(BL_OFF_PART) + my_pos;
             float comp = 0.0f; // lanes < D: their gradient component; lane D: the log-lik
 #pragma unroll
-            for (int w = 0; w < BL_WAVES; w++) comp += part[w * BL_PART_STRIDE];
+            for (int w = 0; w < BL_CWAVES; w++) comp += part[w * BL_PART_STRIDE];
             if (lane > D) comp = 0.0f;
             if (lane == D + 1 && member == 0 && (epoch & 255u) == 0u)
                 comp = (__hip_atomic_load(cold->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1.0f : 0.0f;
@@ -248,46 +314,70 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
             }
 
             // ------------------------------ all-gather of the k partials (G16 / R2) ----
-            const int nvp = p.nvp, G = 64 / nvp;
-            unsigned long long *rec = p.xchg + ((size_t)(chain * 2 + (epoch & 1u)) * p.k) * nvp;
+            const unsigned char *rbase = xbase + ((epoch & 1u) ? rec_bytes : 0u);
             const unsigned long long granule = ((unsigned long long)epoch << 32) | __float_as_uint(comp);
             if (lane < nvp) {
+                unsigned long long *dst = reinterpret_cast<unsigned long long *>(const_cast<unsigned char *>(rbase) + my_store_off);
                 if (local) // line stays in this XCD's L2, where every consumer of this chain polls it
-                    __hip_atomic_store(rec + (size_t)member * nvp + lane, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(dst, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else       // write-through: visible to any XCD
-                    __hip_atomic_store(rec + (size_t)member * nvp + lane, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             BL_STAMP(2)
-            const int c_idx = lane & (nvp - 1), sub = lane / nvp;
-            const int nsleep = local ? 1 : p.poll_sleep;
+            // a first poll that misses costs a whole extra round trip: give the slowest peers' stores
+            // a moment to land before looking
+            for (int z = 0; z < p.first_delay; z++) __builtin_amdgcn_s_sleep(1);
             double acc = 0.0;
             bool timed_out = false;
-            for (int p0 = 0; p0 < p.k; p0 += 8 * G) {
-                unsigned long long va[8], vb[8];
+            if (one_batch) {
+                // common shape: one round of <= 8 loads per lane covers all k records
+                unsigned long long v[8];
                 unsigned spins = 0;
-                bool ok;
-                BL_POLL_ISSUE(va)
                 while (true) {
-                    for (int z = 0; z < nsleep; z++) __builtin_amdgcn_s_sleep(1);
-                    BL_POLL_ISSUE(vb)
-                    BL_POLL_CHECK(va, ok)
-                    if (ok) break;
-                    for (int z = 0; z < nsleep; z++) __builtin_amdgcn_s_sleep(1);
-                    BL_POLL_ISSUE(va)
-                    BL_POLL_CHECK(vb, ok)
-                    if (ok) {
 #pragma unroll
-                        for (int q = 0; q < 8; q++) va[q] = vb[q];
-                        break;
+                    for (int q = 0; q < 8; q += 2) {
+                        if (q < nq) { // wave-uniform: skip load pairs that would only re-read record k-1
+                            v[q] = bl_poll_load(rbase, poff[q]);
+                            v[q + 1] = bl_poll_load(rbase, poff[q + 1]);
+                        } else {
+                            v[q] = v[0];
+                            v[q + 1] = v[0];
+                        }
                     }
+                    unsigned bad = 0u;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) bad |= ((unsigned)(v[q] >> 32)) ^ epoch;
+                    if (__all(bad == 0u)) break;
                     if (++spins > p.spin_limit) { timed_out = true; break; }
+                    if (!local)
+                        for (int z = 0; z < p.poll_sleep; z++) __builtin_amdgcn_s_sleep(1);
                 }
                 BL_COUNT_SPINS(spins)
-                if (timed_out) break;
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int w = p0 + q * G + sub;
-                    acc += (w < p.k) ? (double)__uint_as_float((unsigned)va[q]) : 0.0;
+                for (int q = 0; q < 8; q++) acc += (double)(pval[q] * __uint_as_float((unsigned)v[q]));
+            } else {
+                for (int p0 = 0; p0 < p.k && !timed_out; p0 += 8 * G) {
+                    unsigned long long v[8];
+                    unsigned spins = 0;
+                    while (true) {
+                        unsigned bad = 0u;
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const int w = p0 + q * G + sub;
+                            v[q] = bl_poll_load(rbase, (unsigned)(((w < p.k ? w : p.k - 1) * p.pitch + c_idx) * 8));
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; q++) bad |= ((unsigned)(v[q] >> 32)) ^ epoch;
+                        if (__all(bad == 0u)) break;
+                        if (++spins > p.spin_limit) { timed_out = true; break; }
+                        if (!local)
+                            for (int z = 0; z < p.poll_sleep; z++) __builtin_amdgcn_s_sleep(1);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const int w = p0 + q * G + sub;
+                        acc += (w < p.k) ? (double)__uint_as_float((unsigned)v[q]) : 0.0;
+                    }
                 }
             }
             for (int off = nvp; off < 64; off <<= 1) {
@@ -313,42 +403,29 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
 
             bool new_transition = false;
             if (flag == 0) {
-                if (it < 0) {
+                if (init_pending) {
                     // initial evaluation done
                     const double Un = -ll_tot + (double)(0.5f * bl_wave_sum(dth * dth * prior_isc2)) + prior_const;
-                    th = cz; gr = cg; U = Un;
-                    it = 0;
+                    sv[SV_TH * 64] = cz; sv[SV_GR * 64] = cg;
+                    ss->U = Un;
+                    init_pending = false;
                     new_transition = true;
                 } else {
-                    if (it < W) nleap_w++; else nleap_s++;
-                    // ---------------- finish the leaf (_build_basetree) ----------------
+                    // ------- CRITICAL: finish the leaf (_build_basetree), decide where the next one goes -------
                     const float cr = rh - 0.5f * epsdir * cg;
                     float s_prior = dth * dth * prior_isc2, s_kin = minv * cr * cr;
-                    bl_wave_sum2(s_prior, s_kin);
+                    bl_low_sum2(s_prior, s_kin, D);
                     const double Un = -ll_tot + (double)(0.5f * s_prior) + prior_const;
                     const double Kn = (double)(0.5f * s_kin);
                     double dE = (Un + Kn) - E0;
                     if (dE != dE) dE = (double)INFINITY;
-                    const float dEf = (float)dE;
-                    const float lw = -dEf;
-                    const bool ldiv = dE > 1000.0;
-                    const float lacc = dEf <= 0.0f ? 1.0f : bl_exp(-dEf);
                     const int leaf_idx = snprop;
-                    if (leaf_idx == 0) {
-                        szp = cz; sgp = cg; sUp = Un; swt = lw; srsum = cr;
-                        sdiv = ldiv; ssumacc = lacc; snprop = 1;
-                    } else {
-                        // _combine_tree(..., biased=False): uniform transition kernel
-                        float pr, lse;
-                        bl_merge_weights(swt, lw, lse, pr); // pr = expit(lw - swt)
-                        const float u = bl_rng_uniform(rng_s);
-                        if (u < pr) { szp = cz; sgp = cg; sUp = Un; }
-                        swt = lse;
-                        sdiv = ldiv;
-                        ssumacc += lacc;
-                        srsum += cr;
-                        snprop++;
-                    }
+                    sdiv = dE > 1000.0;
+                    srsum = (leaf_idx == 0) ? cr : srsum + cr;
+                    snprop = leaf_idx + 1;
+                    // its multinomial / weight bookkeeping is deferred
+                    pend = true; pend_first = (leaf_idx == 0); pend_end = false;
+                    pend_dE = (float)dE; pend_U = Un; pend_z = cz; pend_g = cg;
                     // checkpointed U-turn (_leaf_idx_to_ckpt_idxs / _is_iterative_turning)
                     const int idx_max = __popc((unsigned)leaf_idx >> 1);
                     const int idx_min = idx_max - (int)__builtin_ctz(~(unsigned)leaf_idx) + 1;
@@ -359,7 +436,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
                         for (int i = idx_max; i >= idx_min && !sturn; i--) {
                             const float ck = sh_ckr[i * 64 + lane];
                             const float srs = srsum - sh_ckrs[i * 64 + lane] + ck;
-                            sturn = bl_is_turning(minv, ck, cr, srs);
+                            sturn = bl_is_turning(minv, ck, cr, srs, D);
                         }
                     }
                     if (snprop < (1 << depth) && !sturn && !sdiv) {
@@ -367,86 +444,102 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
                         rh = cr - 0.5f * epsdir * cg;
                         cz = cz + epsdir * minv * rh;
                     } else {
-                        // ---------- _combine_tree(tree, subtree, biased=True) ----------
-                        if (going_right) { zr = cz; rr = cr; gR = cg; }
-                        else { zl = cz; rl = cr; gl = cg; }
-                        rsum += srsum;
-                        float pr = fminf(1.0f, bl_exp(swt - wt));
-                        if (sturn || sdiv) pr = 0.0f;
-                        const bool turning = bl_is_turning(minv, rl, rr, rsum);
-                        const float u = bl_rng_uniform(rng_s);
-                        if (u < pr) { zp = szp; gp = sgp; Up = sUp; }
+                        // ---------- subtree complete: extend the tree edge, tree-level U-turn ----------
+                        pend_end = true; pend_sturn = sturn; pend_sdiv = sdiv; pend_snprop = snprop;
+                        const int e_out = going_right ? SV_ZR : SV_ZL;  // edge this subtree extends (z, r, g slots follow)
+                        const int e_in = going_right ? SV_ZL : SV_ZR;   // opposite edge
+                        sv[e_out * 64] = cz; sv[(e_out + 1) * 64] = cr; sv[(e_out + 2) * 64] = cg;
+                        const float r_other = sv[(e_in + 1) * 64];
+                        const float rsum = sv[SV_RSUM * 64] + srsum;
+                        sv[SV_RSUM * 64] = rsum;
+                        const bool turning = bl_is_turning(minv, going_right ? r_other : cr, going_right ? cr : r_other, rsum, D);
                         depth++;
-                        wt = bl_logaddexp(wt, swt);
-                        diverged = sdiv;
-                        sumacc += ssumacc;
-                        nprop += snprop;
-                        if (depth < p.max_depth && !turning && !diverged) {
+                        if (depth < p.max_depth && !turning && !sdiv) {
                             // next doubling
-                            going_right = (bl_rng_next(rng_s) >> 31) != 0u;
+                            going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
                             epsdir = going_right ? eps : -eps;
                             snprop = 0; sturn = false; sdiv = false;
-                            const float ez = going_right ? zr : zl, er = going_right ? rr : rl, eg = going_right ? gR : gl;
+                            const int e = going_right ? SV_ZR : SV_ZL;
+                            const float ez = sv[e * 64], er = sv[(e + 1) * 64], eg = sv[(e + 2) * 64];
                             rh = er - 0.5f * epsdir * eg;
                             cz = ez + epsdir * minv * rh;
                         } else {
-                            // ---------------- transition complete ----------------
-                            const float accp = sumacc * bl_rcp((float)nprop);
-                            th = zp; gr = gp; U = Up;
+                            // ---------------- transition complete (nothing left to overlap with) ----------------
+                            run_deferred();
+                            const int nprop = ss->nprop;
+                            const float accp = ss->sumacc * bl_rcp((float)nprop);
+                            const float th = sv[SV_ZP * 64];
+                            const double U = ss->Up;
+                            sv[SV_TH * 64] = th; sv[SV_GR * 64] = sv[SV_GP * 64];
+                            ss->U = U;
+                            const int it = ss->it;
                             if (it < W) {
+                                ss->nleap_w += nprop;
                                 // warmup_adapter.update_fn: dual averaging (t0=10, kappa=.75, gamma=.05)
                                 const float g = cold->target_accept - accp;
-                                da_t += 1;
+                                const int da_t = ss->da_t + 1;
                                 const float tt = (float)da_t;
                                 const float rt10 = bl_rcp(tt + 10.0f);
-                                da_gavg = (1.0f - rt10) * da_gavg + g * rt10;
-                                da_xt = da_prox - __builtin_amdgcn_sqrtf(tt) * 20.0f * da_gavg;
+                                const float da_gavg = (1.0f - rt10) * ss->da_gavg + g * rt10;
+                                const float da_xt = ss->da_prox - __builtin_amdgcn_sqrtf(tt) * 20.0f * da_gavg;
                                 const float wgt = __builtin_amdgcn_exp2f(-0.75f * __builtin_amdgcn_logf(tt));
-                                da_xavg = (1.0f - wgt) * da_xavg + wgt * da_xt;
+                                const float da_xavg = (1.0f - wgt) * ss->da_xavg + wgt * da_xt;
                                 eps = bl_exp((it == W - 1) ? da_xavg : da_xt);
                                 eps = fminf(fmaxf(eps, 1.1754944e-38f), 3.4028235e+38f);
+                                ss->da_t = da_t; ss->da_gavg = da_gavg; ss->da_xt = da_xt; ss->da_xavg = da_xavg;
+                                int win_idx = ss->win_idx;
                                 const bool middle = win_idx > 0 && win_idx < cold->nwin - 1;
                                 if (middle) {
-                                    wf_n += 1;
-                                    const float dpre = th - wf_mean;
-                                    wf_mean += dpre * bl_rcp((float)wf_n);
-                                    wf_m2 += dpre * (th - wf_mean);
+                                    const int wf_n = ss->wf_n + 1;
+                                    const float wf_mean0 = sv[SV_WFMEAN * 64];
+                                    const float dpre = th - wf_mean0;
+                                    const float wf_mean = wf_mean0 + dpre * bl_rcp((float)wf_n);
+                                    sv[SV_WFMEAN * 64] = wf_mean;
+                                    sv[SV_WFM2 * 64] += dpre * (th - wf_mean);
+                                    ss->wf_n = wf_n;
                                 }
                                 const bool at_end = it == cold->win_end[win_idx];
-                                if (at_end) win_idx++;
+                                if (at_end) ss->win_idx = win_idx + 1;
                                 if (at_end && middle) {
-                                    const float n = (float)wf_n;
-                                    const float var = wf_m2 * bl_rcp(n - 1.0f), rn5 = bl_rcp(n + 5.0f);
+                                    const float n = (float)ss->wf_n;
+                                    const float var = sv[SV_WFM2 * 64] * bl_rcp(n - 1.0f), rn5 = bl_rcp(n + 5.0f);
                                     minv = act ? (n * rn5 * var + 1e-3f * 5.0f * rn5) : 0.0f;
-                                    wf_mean = 0.f; wf_m2 = 0.f; wf_n = 0;
-                                    da_xt = 0.f; da_xavg = 0.f; da_gavg = 0.f; da_t = 0;
-                                    da_prox = bl_log(10.0f * eps);
+                                    sv[SV_WFMEAN * 64] = 0.f; sv[SV_WFM2 * 64] = 0.f; ss->wf_n = 0;
+                                    ss->da_xt = 0.f; ss->da_xavg = 0.f; ss->da_gavg = 0.f; ss->da_t = 0;
+                                    ss->da_prox = bl_log(10.0f * eps);
                                 }
-                            } else if (member == 0) {
-                                const size_t s = (size_t)chain * S + (it - W);
-                                if (act) cold->draws[s * D + lane] = th;
-                                if (lane == 0) {
-                                    cold->num_steps[s] = nprop;
-                                    cold->accept_prob[s] = accp;
-                                    cold->diverging[s] = diverged ? 1 : 0;
-                                    cold->potential[s] = (float)U;
+                            } else {
+                                ss->nleap_s += nprop;
+                                if (member == 0) {
+                                    const size_t s = (size_t)chain * S + (it - W);
+                                    if (act) cold->draws[s * D + lane] = th;
+                                    if (lane == 0) {
+                                        cold->num_steps[s] = nprop;
+                                        cold->accept_prob[s] = accp;
+                                        cold->diverging[s] = pend_sdiv ? 1 : 0;
+                                        cold->potential[s] = (float)U;
+                                    }
                                 }
                             }
-                            it++;
-                            if (it >= total) flag = 1; // done
+                            ss->it = it + 1;
+                            if (it + 1 >= total) flag = 1; // done
                             else new_transition = true;
                         }
                     }
                 }
                 if (new_transition) {
                     // sample momentum r = N(0,1)/sqrt(M^-1); start a fresh tree and its first doubling
+                    const float th = sv[SV_TH * 64], gr = sv[SV_GR * 64];
+                    const double U = ss->U;
                     const float z01 = bl_rng_normal(rng_d);
                     const float r0 = act ? z01 * __builtin_amdgcn_rsqf(minv) : 0.0f;
                     E0 = U + (double)(0.5f * bl_wave_sum(minv * r0 * r0));
-                    zl = th; rl = r0; gl = gr; zr = th; rr = r0; gR = gr;
-                    zp = th; gp = gr; Up = U;
-                    wt = 0.f; rsum = r0; sumacc = 0.f; nprop = 0; depth = 0; diverged = false;
-                    going_right = (bl_rng_next(rng_s) >> 31) != 0u;
+                    sv[SV_ZL * 64] = th; sv[SV_RL * 64] = r0; sv[SV_GL * 64] = gr;
+                    sv[SV_ZR * 64] = th; sv[SV_RR * 64] = r0; sv[SV_GRR * 64] = gr;
+                    sv[SV_ZP * 64] = th; sv[SV_GP * 64] = gr; sv[SV_RSUM * 64] = r0;
+                    ss->Up = U; ss->wt = 0.f; ss->sumacc = 0.f; ss->nprop = 0;
+                    depth = 0;
+                    going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
                     epsdir = going_right ? eps : -eps;
                     snprop = 0; sturn = false; sdiv = false;
                     rh = r0 - 0.5f * epsdir * gr;
@@ -460,8 +553,8 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
                 if (act) cold->inv_mass[chain * D + lane] = minv;
                 if (lane == 0) {
                     cold->step_size[chain] = eps;
-                    cold->nleap[chain * 2 + 0] = nleap_w;
-                    cold->nleap[chain * 2 + 1] = nleap_s;
+                    cold->nleap[chain * 2 + 0] = ss->nleap_w;
+                    cold->nleap[chain * 2 + 1] = ss->nleap_s;
                     cold->xcd_local[chain] = local ? 1 : 0;
                 }
             }

@@ -10,8 +10,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define BL_THREADS 512
-#define BL_WAVES (BL_THREADS / 64)
+// Workgroup = 1 control wave (wave 0: exchange + NUTS state machine) + 4 compute waves (one per
+// SIMD) that evaluate the sites.  BL_CTHREADS compute threads, BL_THREADS launched threads.
+#define BL_CWAVES 4
+#define BL_CTHREADS (BL_CWAVES * 64)
+#define BL_THREADS (BL_CTHREADS + 64)
+#define BL_DIR_STREAM 62
 #define BL_MAX_DEPTH 10
 #define BL_NSTREAM 64
 #define BL_SCALAR_STREAM 63
@@ -19,11 +23,13 @@
 // ---- dynamic LDS carve (bytes; every offset a multiple of 16: guide G17) ----
 #define BL_OFF_COEF 0       // 64 floats : coefficients being evaluated, PADDED layout (beta[0..KS], alpha[0..KO])
 #define BL_OFF_FLAG 256     // 4 ints    : loop control
-#define BL_OFF_PART 272     // 8 waves x BL_PART_STRIDE floats : per-wave partial sums (padded layout + log-lik)
+#define BL_OFF_PART 272     // 4 compute waves x BL_PART_STRIDE floats (room for 8) : per-wave partial sums (padded layout + log-lik)
 #define BL_PART_STRIDE 48
 #define BL_OFF_CKR 1808     // 10 x 64 floats: r checkpoints      (numpyro r_ckpts)
 #define BL_OFF_CKRS 4368    // 10 x 64 floats: r_sum checkpoints  (numpyro r_sum_ckpts)
-#define BL_OFF_DATA 6928    // staged site records start here
+#define BL_OFF_SV 6928      // 16 x 64 floats: control wave's rarely-touched per-dimension state (tree edges, proposal, ...)
+#define BL_OFF_SS 11024     // 256 bytes     : control wave's rarely-touched scalars (BlCtlScalars)
+#define BL_OFF_DATA 11280   // staged site records start here
 #define BL_LDS_TOTAL 163840
 
 extern __shared__ __attribute__((aligned(16))) unsigned char bl_smem_raw[];
@@ -38,11 +44,13 @@ __device__ __forceinline__ int *bl_lds_i(int byte_off) { return reinterpret_cast
 //   next T rows                      ka = n_masked * ln2       (cancels the log sigma(0) of masked visits)
 //   next T rows                      kb = n_detections * log(tiny_f32)   (z=0 branch, numpyro clamp)
 //
-// In LDS a workgroup keeps its sites as per-site RECORDS (array of structures) so that a lane reads
-// its whole site with a few ds_read_b128 at immediate offsets and no address arithmetic:
+// In LDS a workgroup keeps its sites as RECORDS (array of structures) so that a lane reads its data
+// with a few ds_read_b128 at immediate offsets and no address arithmetic.  One site's elements:
 //   [ x_0..x_KS-1 | pad to 4 ]  then per period t a block of pb floats:
 //   [ visit 0: c, c*w_1..c*w_KO | visit 1 | ... | visit J-1 | ka | kb | pad to 4 ]
-// Record stride = 4 * (odd number) floats: 16-byte aligned and ds_read_b128 conflict-free
+// and two consecutive sites are interleaved element by element into one PAIR record
+// (a0 b0 a1 b1 ...), because a lane evaluates two sites with packed f32 math (see bl_eval_sites_lds).
+// Pair stride = 4 * (odd number) floats: 16-byte aligned and ds_read_b128 conflict-free
 // (any 16 lanes that are distinct mod 16 hit 16 distinct 4-bank slots).
 struct BlDevData {
     const float *rows;
@@ -56,9 +64,10 @@ struct BlDevData {
 __host__ __device__ inline int bl_round4(int x) { return (x + 3) & ~3; }
 // floats per period block / per site record (host and device must agree)
 __host__ __device__ inline int bl_period_block(int J, int KO) { return bl_round4(J * (KO + 1) + 2); }
+// floats per PAIR record (two sites interleaved element-wise)
 __host__ __device__ inline int bl_record_stride(int T, int J, int KS, int KO)
 {
-    int q = (bl_round4(KS) + T * bl_period_block(J, KO)) / 4;
+    int q = (bl_round4(KS) + T * bl_period_block(J, KO)) / 2;
     if ((q & 1) == 0) q++;
     return 4 * q;
 }
@@ -143,6 +152,23 @@ __device__ __forceinline__ void bl_wave_sum2(float &a, float &b)
     a = bl_readlane(v[0], 63);
     b = bl_readlane(v[1], 63);
 }
+// Two sums over lanes [0, n) only (all other lanes hold zeros): the butterfly stops as soon as
+// lane 0's group covers n lanes; totals are read from lane 0.  n is wave-uniform.
+__device__ __forceinline__ void bl_low_sum2(float &a, float &b, int n)
+{
+    a += bl_dpp<0xB1, 0xF>(a); b += bl_dpp<0xB1, 0xF>(b);   // xor 1
+    a += bl_dpp<0x4E, 0xF>(a); b += bl_dpp<0x4E, 0xF>(b);   // xor 2
+    if (n > 4) { a += bl_dpp<0x141, 0xF>(a); b += bl_dpp<0x141, 0xF>(b); }  // 8 lanes
+    if (n > 8) { a += bl_dpp<0x140, 0xF>(a); b += bl_dpp<0x140, 0xF>(b); }  // 16 lanes
+    if (n > 16) {
+        // rows 1..3 still to fold: take the generic path for the remaining steps
+        a += bl_dpp<0x142, 0xA>(a); b += bl_dpp<0x142, 0xA>(b);
+        a += bl_dpp<0x143, 0xC>(a); b += bl_dpp<0x143, 0xC>(b);
+        a = bl_readlane(a, 63); b = bl_readlane(b, 63);
+        return;
+    }
+    a = bl_readlane(a, 0); b = bl_readlane(b, 0);
+}
 
 // ------------------------------------------------------------------- RNG ----
 // xoshiro128++ 1.0; identical sequence to oracle/occu_oracle.c (tests compare them).
@@ -216,12 +242,52 @@ __device__ __forceinline__ void bl_period_tail(float eta, float sp, float psi, f
     for (int k = 0; k <= KO; k++) ga[k] = fmaf(q, g[k], ga[k]);
 }
 
-// Accumulates, over this thread's sites i = tid, tid+BL_THREADS, ... < cnt :
+// ---- packed two-sites-per-lane forms (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) ----
+// Non-packed f32 VALU ops issue at 4 cycles per wave64 on a CDNA SIMD and one site per lane needs
+// ~160 of them, which made this phase VALU-issue-bound with two waves per SIMD.  Each lane therefore
+// evaluates TWO sites: .x / .y of every value belong to the two sites of a pair, FMA/mul/add run
+// packed (one issue slot for both sites), only exp/log/rcp/min/max/select are per component.
+typedef float bl_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bl_f2 bl2(float a) { return bl_f2{a, a}; }
+__device__ __forceinline__ bl_f2 bl_fma2(bl_f2 a, bl_f2 b, bl_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ bl_f2 bl_exp2_2(bl_f2 x) { return bl_f2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
+__device__ __forceinline__ bl_f2 bl_log2_2(bl_f2 x) { return bl_f2{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)}; }
+__device__ __forceinline__ bl_f2 bl_rcp_2(bl_f2 x) { return bl_f2{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+// (u > 0 ? 1 : e)
+__device__ __forceinline__ bl_f2 bl_sel_pos_one(bl_f2 u, bl_f2 e) { return bl_f2{u.x > 0.0f ? 1.0f : e.x, u.y > 0.0f ? 1.0f : e.y}; }
+// (u > 0 ? e : 1)
+__device__ __forceinline__ bl_f2 bl_sel_pos_e(bl_f2 u, bl_f2 e) { return bl_f2{u.x > 0.0f ? e.x : 1.0f, u.y > 0.0f ? e.y : 1.0f}; }
+
+// exp(-max(u, -87)): the clamp keeps e^-u finite in f32; beyond |u| = 87 the log-lik goes flat,
+// far outside anything a posterior visits (numpyro's own clamp_probs flattens it at 15.9 / 87.3).
+__device__ __forceinline__ bl_f2 bl_expneg_2(bl_f2 u)
+{
+    return bl_exp2_2(__builtin_elementwise_max(u, bl2(-87.0f)) * bl2(-BL_LOG2E));
+}
+
+// One visit of both sites:  u = c*alpha0 + sum_k (c w_k) alpha_k ,  t = e^-u ,
+//   log sigma(u) = -log(1+t) ,  sigma(-u) = t/(1+t)     (no branches, no selects)
+template <int KO>
+__device__ __forceinline__ void bl_visit2(const bl_f2 (&w)[KO + 1], const float (&alpha)[KO + 1], bl_f2 &a, bl_f2 (&g)[KO + 1])
+{
+    bl_f2 u = w[0] * bl2(alpha[0]);
+#pragma unroll
+    for (int k = 1; k <= KO; k++) u = bl_fma2(w[k], bl2(alpha[k]), u);
+    const bl_f2 t = bl_expneg_2(u);
+    const bl_f2 op = t + bl2(1.0f);
+    a = bl_fma2(bl_log2_2(op), bl2(-BL_LN2), a);
+    const bl_f2 s = t * bl_rcp_2(op);
+#pragma unroll
+    for (int k = 0; k <= KO; k++) g[k] = bl_fma2(s, w[k], g[k]);
+}
+
+// Accumulates, over this thread's site PAIRS m = tid, tid+BL_THREADS, ... :
 //   ll += sum_t l_it ,  gb[k] += d ll / d beta_k ,  ga[k] += d ll / d alpha_k
-// LDS records; JC > 0: J == JC at compile time -> whole period block read as ds_read_b128s at
-// immediate offsets, visits fully unrolled (their exp/log/rcp chains interleave).  JC == 0: runtime J.
+// LDS pair records (element e of the two sites adjacent); JC > 0: J == JC at compile time -> the
+// whole period block is read with ds_read_b128 at immediate offsets and the visits are unrolled
+// (their exp/log/rcp chains interleave).  JC == 0: runtime J.
 template <int KS, int KO, int JC>
-__device__ __forceinline__ void bl_eval_sites_lds(int stride, int cnt, int T, int J,
+__device__ __forceinline__ void bl_eval_sites_lds(int ct, int pstride, int cnt, int T, int J,
                                                   const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                                   float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
 {
@@ -229,73 +295,105 @@ __device__ __forceinline__ void bl_eval_sites_lds(int stride, int cnt, int T, in
     const int Jn = JC > 0 ? JC : J;
     const int pb = bl_period_block(Jn, KO);
     const float *data = bl_lds_f(BL_OFF_DATA);
-    for (int i = threadIdx.x; i < cnt; i += BL_THREADS) {
-        const float4 *rec = reinterpret_cast<const float4 *>(data + (size_t)i * stride);
-        float x[XQ];
+    const int npairs = (cnt + 1) >> 1;
+    bl_f2 ll2 = bl2(0.0f), gb2[KS + 1], ga2[KO + 1];
 #pragma unroll
-        for (int q = 0; q < XQ / 4; q++) {
+    for (int k = 0; k <= KS; k++) gb2[k] = bl2(0.0f);
+#pragma unroll
+    for (int k = 0; k <= KO; k++) ga2[k] = bl2(0.0f);
+    for (int m = ct; m < npairs; m += BL_CTHREADS) {
+        const float4 *rec = reinterpret_cast<const float4 *>(data + (size_t)m * pstride);
+        const bl_f2 vmask = bl_f2{1.0f, (2 * m + 1 < cnt) ? 1.0f : 0.0f}; // odd slice: the last pair's second site is a dummy
+        bl_f2 x[XQ];
+#pragma unroll
+        for (int q = 0; q < XQ / 2; q++) {
             const float4 v = rec[q];
-            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+            x[2 * q] = bl_f2{v.x, v.y};
+            x[2 * q + 1] = bl_f2{v.z, v.w};
         }
-        float eta = beta[0];
+        bl_f2 eta = bl2(beta[0]);
 #pragma unroll
-        for (int k = 0; k < KS; k++) eta = fmaf(x[k], beta[k + 1], eta);
-        float sp, psi;
-        bl_site_head(eta, sp, psi);
-        float dsum = 0.0f;
+        for (int k = 0; k < KS; k++) eta = bl_fma2(x[k], bl2(beta[k + 1]), eta);
+        // softplus(eta), psi = sigmoid(eta)   (exact forms: once per site)
+        const bl_f2 e_eta = bl_exp2_2(__builtin_elementwise_abs(eta) * bl2(-BL_LOG2E));
+        const bl_f2 op_eta = e_eta + bl2(1.0f);
+        const bl_f2 sp = bl_fma2(bl_log2_2(op_eta), bl2(BL_LN2), __builtin_elementwise_max(eta, bl2(0.0f)));
+        const bl_f2 psi = bl_sel_pos_one(eta, e_eta) * bl_rcp_2(op_eta);
+        bl_f2 dsum = bl2(0.0f), lsite = bl2(0.0f);
         for (int t = 0; t < T; t++) {
-            float g[KO + 1];
+            bl_f2 g[KO + 1];
 #pragma unroll
-            for (int k = 0; k <= KO; k++) g[k] = 0.0f;
-            float a, kb;
+            for (int k = 0; k <= KO; k++) g[k] = bl2(0.0f);
+            bl_f2 a, kb;
             if constexpr (JC > 0) {
                 constexpr int PBC = (JC * (KO + 1) + 2 + 3) & ~3;
-                const float4 *pq = rec + XQ / 4 + t * (PBC / 4);
-                float blk[PBC];
+                const float4 *pq = rec + XQ / 2 + t * (PBC / 2);
+                bl_f2 blk[PBC];
 #pragma unroll
-                for (int q = 0; q < PBC / 4; q++) {
+                for (int q = 0; q < PBC / 2; q++) {
                     const float4 v = pq[q];
-                    blk[4 * q] = v.x; blk[4 * q + 1] = v.y; blk[4 * q + 2] = v.z; blk[4 * q + 3] = v.w;
+                    blk[2 * q] = bl_f2{v.x, v.y};
+                    blk[2 * q + 1] = bl_f2{v.z, v.w};
                 }
                 a = blk[JC * (KO + 1)];
                 kb = blk[JC * (KO + 1) + 1];
 #pragma unroll
                 for (int j = 0; j < JC; j++) {
-                    float w[KO + 1];
+                    bl_f2 w[KO + 1];
 #pragma unroll
                     for (int k = 0; k <= KO; k++) w[k] = blk[j * (KO + 1) + k];
-                    bl_visit<KO>(w, alpha, a, g);
+                    bl_visit2<KO>(w, alpha, a, g);
                 }
             } else {
-                const float *pp = data + (size_t)i * stride + XQ + t * pb;
-                a = pp[Jn * (KO + 1)];
-                kb = pp[Jn * (KO + 1) + 1];
+                const float2 *pp = reinterpret_cast<const float2 *>(data + (size_t)m * pstride) + XQ + t * pb;
+                const float2 a_ = pp[Jn * (KO + 1)], kb_ = pp[Jn * (KO + 1) + 1];
+                a = bl_f2{a_.x, a_.y};
+                kb = bl_f2{kb_.x, kb_.y};
 #pragma unroll 2
                 for (int j = 0; j < Jn; j++) {
-                    float w[KO + 1];
+                    bl_f2 w[KO + 1];
 #pragma unroll
-                    for (int k = 0; k <= KO; k++) w[k] = pp[j * (KO + 1) + k];
-                    bl_visit<KO>(w, alpha, a, g);
+                    for (int k = 0; k <= KO; k++) {
+                        const float2 v = pp[j * (KO + 1) + k];
+                        w[k] = bl_f2{v.x, v.y};
+                    }
+                    bl_visit2<KO>(w, alpha, a, g);
                 }
             }
-            bl_period_tail<KO>(eta, sp, psi, a, kb, g, ll, dsum, ga);
-        }
-        gb[0] += dsum;
+            // sum over z: z=1 branch A = log psi + a ; z=0 branch B = log(1-psi) + n_det log(tiny)
+            const bl_f2 A = eta - sp + a, B = kb - sp;
+            const bl_f2 d = eta + a - kb; // = A - B
+            const bl_f2 e_d = bl_exp2_2(__builtin_elementwise_abs(d) * bl2(-BL_LOG2E));
+            const bl_f2 op_d = e_d + bl2(1.0f);
+            lsite += bl_fma2(bl_log2_2(op_d), bl2(BL_LN2), __builtin_elementwise_max(A, B));
+            const bl_f2 q = bl_sel_pos_one(d, e_d) * bl_rcp_2(op_d); // P(z=1 | y, theta)
+            dsum += q - psi;
 #pragma unroll
-        for (int k = 0; k < KS; k++) gb[k + 1] = fmaf(dsum, x[k], gb[k + 1]);
+            for (int k = 0; k <= KO; k++) ga2[k] = bl_fma2(q, g[k], ga2[k]); // dummy site: g == 0
+        }
+        ll2 = bl_fma2(lsite, vmask, ll2);
+        dsum *= vmask;
+        gb2[0] += dsum;
+#pragma unroll
+        for (int k = 0; k < KS; k++) gb2[k + 1] = bl_fma2(dsum, x[k], gb2[k + 1]);
     }
+    ll += ll2.x + ll2.y;
+#pragma unroll
+    for (int k = 0; k <= KS; k++) gb[k] += gb2[k].x + gb2[k].y;
+#pragma unroll
+    for (int k = 0; k <= KO; k++) ga[k] += ga2[k].x + ga2[k].y;
 }
 
 // Same arithmetic straight from the HBM rows (slice too large for LDS); grows is already offset to
 // this workgroup's first site, ld = n_stride.
 template <int KS, int KO>
-__device__ __forceinline__ void bl_eval_sites_hbm(const float *__restrict__ grows, int ld, int cnt, int T, int J,
+__device__ __forceinline__ void bl_eval_sites_hbm(int ct, const float *__restrict__ grows, int ld, int cnt, int T, int J,
                                                   const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                                   float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
 {
     const int V = T * J;
     const int row_wc = KS, row_ka = KS + V * (KO + 1), row_kb = row_ka + T;
-    for (int i = threadIdx.x; i < cnt; i += BL_THREADS) {
+    for (int i = ct; i < cnt; i += BL_CTHREADS) {
         float x[KS > 0 ? KS : 1];
         float eta = beta[0];
 #pragma unroll
@@ -329,34 +427,38 @@ __device__ __forceinline__ void bl_eval_sites_hbm(const float *__restrict__ grow
 }
 
 template <int KS, int KO, bool LDS>
-__device__ __forceinline__ void bl_eval_sites(const float *__restrict__ grows, int ld_or_stride, int cnt, int T, int J,
+__device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ grows, int ld_or_stride, int cnt, int T, int J,
                                               const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                               float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
 {
     if constexpr (LDS) {
         switch (J) { // wave-uniform
-        case 1: bl_eval_sites_lds<KS, KO, 1>(ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 2: bl_eval_sites_lds<KS, KO, 2>(ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 3: bl_eval_sites_lds<KS, KO, 3>(ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 4: bl_eval_sites_lds<KS, KO, 4>(ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 5: bl_eval_sites_lds<KS, KO, 5>(ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 6: bl_eval_sites_lds<KS, KO, 6>(ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 8: bl_eval_sites_lds<KS, KO, 8>(ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        default: bl_eval_sites_lds<KS, KO, 0>(ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 1: bl_eval_sites_lds<KS, KO, 1>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 2: bl_eval_sites_lds<KS, KO, 2>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 3: bl_eval_sites_lds<KS, KO, 3>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 4: bl_eval_sites_lds<KS, KO, 4>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 5: bl_eval_sites_lds<KS, KO, 5>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 6: bl_eval_sites_lds<KS, KO, 6>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 8: bl_eval_sites_lds<KS, KO, 8>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        default: bl_eval_sites_lds<KS, KO, 0>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
         }
     } else {
-        bl_eval_sites_hbm<KS, KO>(grows, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga);
+        bl_eval_sites_hbm<KS, KO>(ct, grows, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga);
     }
 }
 
 // Transpose this workgroup's site slice [s0, s0+cnt) of the HBM rows (coalesced reads along the
-// site axis) into per-site LDS records.
+// site axis) into LDS pair records: element `pos` of site i lands at pair (i/2), float 2*pos + (i&1).
 __device__ __forceinline__ void bl_stage_records(const float *__restrict__ rows, int n_stride, int s0, int cnt,
-                                                 int T, int J, int KS, int KO, int stride)
+                                                 int T, int J, int KS, int KO, int pstride)
 {
     float *dst = bl_lds_f(BL_OFF_DATA);
     const int xq = bl_round4(KS), pb = bl_period_block(J, KO), V = T * J, vw = KO + 1;
     const int n_rows = KS + V * vw + 2 * T;
+    if (cnt & 1) { // dummy second site of the last pair: all zeros (its contributions are masked)
+        float *last = dst + (size_t)(cnt >> 1) * pstride;
+        for (int e = threadIdx.x; e < xq + T * pb; e += BL_THREADS) last[2 * e + 1] = 0.0f;
+    }
     for (int r = 0; r < n_rows; r++) {
         int pos;
         if (r < KS) pos = r;
@@ -366,7 +468,7 @@ __device__ __forceinline__ void bl_stage_records(const float *__restrict__ rows,
         } else if (r < KS + V * vw + T) pos = xq + (r - KS - V * vw) * pb + J * vw;
         else pos = xq + (r - KS - V * vw - T) * pb + J * vw + 1;
         const float *src = rows + (size_t)r * n_stride + s0;
-        for (int i = threadIdx.x; i < cnt; i += BL_THREADS) dst[(size_t)i * stride + pos] = src[i];
+        for (int i = threadIdx.x; i < cnt; i += BL_THREADS) dst[(size_t)(i >> 1) * pstride + 2 * pos + (i & 1)] = src[i];
     }
 }
 
@@ -389,10 +491,10 @@ __device__ __forceinline__ void bl_load_coefs(float (&beta)[KS + 1], float (&alp
 // all values (f32: the per-term rounding of the f32 site math dominates the error budget anyway);
 // lane 63 holds the totals and stores them.  Cross-wave / cross-workgroup sums are done in f64.
 template <int KS, int KO>
-__device__ __forceinline__ void bl_wave_partials_to_lds(float ll, const float (&gb)[KS + 1], const float (&ga)[KO + 1])
+__device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, const float (&gb)[KS + 1], const float (&ga)[KO + 1])
 {
     constexpr int NV = KS + KO + 3;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = cwave, lane = threadIdx.x & 63;
     float v[NV];
 #pragma unroll
     for (int k = 0; k <= KS; k++) v[k] = gb[k];
