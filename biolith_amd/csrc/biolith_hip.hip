@@ -46,12 +46,12 @@ static int bl_fail(int code, const char *fmt, ...)
 #define BL_KK_LIST(X) BL_K_LIST(X, 1) BL_K_LIST(X, 2) BL_K_LIST(X, 3) BL_K_LIST(X, 4) BL_K_LIST(X, 8) BL_K_LIST(X, 16)
 #endif
 #define BL_DECL(ks, ko)                                                                                        \
-    extern "C" int bl_launch_nuts_##ks##_##ko(const BlNutsParams *, int, int, int, hipStream_t);               \
-    extern "C" int bl_launch_logp_##ks##_##ko(const BlLogpParams *, int, int, int, hipStream_t);
+    extern "C" int bl_launch_nuts_##ks##_##ko(const BlNutsParams *, int, int, int, int, hipStream_t);          \
+    extern "C" int bl_launch_logp_##ks##_##ko(const BlLogpParams *, int, int, int, int, hipStream_t);
 BL_KK_LIST(BL_DECL)
 
-typedef int (*nuts_launch_fn)(const BlNutsParams *, int, int, int, hipStream_t);
-typedef int (*logp_launch_fn)(const BlLogpParams *, int, int, int, hipStream_t);
+typedef int (*nuts_launch_fn)(const BlNutsParams *, int, int, int, int, hipStream_t);
+typedef int (*logp_launch_fn)(const BlLogpParams *, int, int, int, int, hipStream_t);
 struct KernelEntry {
     int ks, ko;
     nuts_launch_fn nuts;
@@ -147,6 +147,8 @@ static int adaptation_schedule(int num_steps, int32_t *starts, int32_t *ends, in
 // ----------------------------------------------------------------- handle ----
 struct bl_dataset {
     int device = 0;
+    int model = 0;          // 0 occu, 1 occu_rn
+    int max_abundance = 0;  // occu_rn only
     bl_dims dims{};
     int Ks = 0, Ko = 0, KS = 0, KO = 0, D = 0;
     int n_stride = 0, n_rows = 0;
@@ -207,9 +209,32 @@ extern "C" int bl_adaptation_schedule(int num_warmup, int32_t *starts, int32_t *
     return adaptation_schedule(num_warmup, starts, ends, capacity);
 }
 
+static int dataset_create_impl(int model, int max_abundance, const bl_dims *dims, const float *site_covs, const float *obs_covs,
+                               const float *obs, const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha,
+                               int device, bl_dataset **out);
+
 extern "C" int bl_dataset_create(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
                                  const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha, int device,
                                  bl_dataset **out)
+{
+    return dataset_create_impl(0, 0, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
+}
+
+extern "C" int bl_dataset_create_rn(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
+                                    int max_abundance, const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha,
+                                    int device, bl_dataset **out)
+{
+    if (max_abundance < 1 || max_abundance >= BL_RN_NB)
+        return bl_fail(BL_ERR_UNSUPPORTED, "max_abundance=%d outside 1..%d", max_abundance, BL_RN_NB - 1);
+    if (dims && (dims->n_site_covs > 4 || dims->n_obs_covs > 4))
+        return bl_fail(BL_ERR_UNSUPPORTED, "occu_rn kernels are built for at most 4 covariates per side (Ks=%d, Ko=%d)",
+                       dims->n_site_covs, dims->n_obs_covs);
+    return dataset_create_impl(1, max_abundance, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
+}
+
+static int dataset_create_impl(int model, int max_abundance, const bl_dims *dims, const float *site_covs, const float *obs_covs,
+                               const float *obs, const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha,
+                               int device, bl_dataset **out)
 {
     if (!dims || !out) return bl_fail(BL_ERR_INVALID, "dims/out is NULL");
     *out = nullptr;
@@ -233,6 +258,7 @@ extern "C" int bl_dataset_create(const bl_dims *dims, const float *site_covs, co
 
     bl_dataset *ds = new bl_dataset();
     ds->device = device; ds->dims = *dims; ds->Ks = Ks; ds->Ko = Ko; ds->D = Ks + Ko + 2;
+    ds->model = model; ds->max_abundance = max_abundance;
     ds->KS = pad_covs(Ks); ds->KO = pad_covs(Ko);
     ds->kern = find_kernels(ds->KS, ds->KO);
     ds->pb = pb; ds->pa = pa;
@@ -336,7 +362,9 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     int kmax = 32 / per_xcd;
     if (kmax < 1) kmax = 1;
     // a lane evaluates a PAIR of sites (packed f32 math): one pair per thread is the latency optimum
-    int k = want_k > 0 ? want_k : (N + 2 * BL_CTHREADS - 1) / (2 * BL_CTHREADS);
+    // occu_rn: one site per lane on 3 compute waves
+    const int per_wg = ds->model == 1 ? BL_CWAVES_RN * 64 : 2 * BL_CTHREADS;
+    int k = want_k > 0 ? want_k : (N + per_wg - 1) / per_wg;
     if (k > kmax) k = kmax;
     if (k < 1) k = 1;
     const int lds_cap = BL_LDS_TOTAL - BL_OFF_DATA;
@@ -400,7 +428,10 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
     BL_HIP(hipMemset(d_partial, 0, (size_t)B * k * 64 * 8));
     BlLogpParams p{};
     p.dd = ds->dd; p.k = k; p.nloc = nloc; p.rec_stride = ld; p.B = B; p.theta = d_th32; p.partial = d_partial;
-    const int lrc = ds->kern->logp(&p, k, lds_bytes, use_staged, nullptr);
+    p.max_abundance = ds->max_abundance;
+    if (ds->model == 1 && !use_staged)
+        return bl_fail(BL_ERR_UNSUPPORTED, "occu_rn needs the LDS-staged path (slice too large, or staged=0 requested)");
+    const int lrc = ds->kern->logp(&p, k, lds_bytes, use_staged, ds->model, nullptr);
     if (lrc != 0) return bl_fail(BL_ERR_NO_DEVICE, "logp kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     hipLaunchKernelGGL(bl_logp_final_kernel, dim3(B), dim3(64), 0, nullptr, ds->dd, k, d_th, d_partial, d_U, d_grad);
     BL_HIP(hipGetLastError());
@@ -498,6 +529,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.num_chains = C;
     p.k = k; p.nloc = nloc; p.rec_stride = ld; p.nvp = nvp;
     p.max_depth = max_depth;
+    p.max_abundance = ds->max_abundance;
     p.xchg = ds->d_xchg;
     p.cold = d_cold;
     p.spin_limit = 1u << 18;
@@ -519,7 +551,9 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     BL_HIP(hipMemsetAsync(ds->d_dbg, 0, 128, st));
     BL_HIP(hipMemsetAsync(ds->d_loc, 0, (size_t)C * 4, st));
     const int grid = 8 * k * ((C + 7) / 8); // XCD-aware mapping in the kernel; surplus blocks exit at once
-    const int lrc = ds->kern->nuts(&p, grid, lds_bytes, staged, st);
+    if (ds->model == 1 && !staged)
+        return bl_fail(BL_ERR_UNSUPPORTED, "occu_rn: the dataset slice does not fit the LDS-staged path");
+    const int lrc = ds->kern->nuts(&p, grid, lds_bytes, staged, ds->model, st);
     if (lrc != 0) return bl_fail(BL_ERR_NO_DEVICE, "NUTS kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     BL_HIP(hipEventRecord(ds->ev1, st));
     ds->stream = st; ds->in_flight = true; ds->have_run = true;
@@ -621,7 +655,7 @@ extern "C" int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads
     if (!ds) return bl_fail(BL_ERR_INVALID, "NULL argument");
     if (!ds->have_run) return bl_fail(BL_ERR_INVALID, "no NUTS launch on this handle");
     if (wgs_per_chain) *wgs_per_chain = ds->k;
-    if (threads_per_wg) *threads_per_wg = BL_THREADS;
+    if (threads_per_wg) *threads_per_wg = ds->model == 1 ? BL_THREADS_RN : BL_THREADS;
     if (lds_bytes) *lds_bytes = ds->lds_bytes;
     if (lds_staged) *lds_staged = ds->staged;
     if (chains_on_l2_local_exchange) {
@@ -638,7 +672,7 @@ extern "C" int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads
 // ------------------------------------------------- deterministic sites ----
 // psi[n][t][i] = sigmoid(beta0 + x_i . beta)      (occu.py:198-207; constant over t)
 __global__ void bl_psi_kernel(const float *__restrict__ rows, int n_stride, int N, int T, int Ks, int D,
-                              const float *__restrict__ draws, int n0, int n1, float *__restrict__ psi)
+                              const float *__restrict__ draws, int n0, int n1, float *__restrict__ psi, int model)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -648,7 +682,8 @@ __global__ void bl_psi_kernel(const float *__restrict__ rows, int n_stride, int 
         const float *th = draws + (size_t)n * D;
         float eta = th[0];
         for (int k = 0; k < Ks; k++) eta = fmaf(x[k], th[k + 1], eta);
-        const float v = 1.0f / (1.0f + __expf(-eta));
+        // occu: psi = sigmoid(eta) (occu.py:207); occu_rn: abundance = exp(eta) (occu_rn.py:192)
+        const float v = model == 1 ? __expf(eta) : 1.0f / (1.0f + __expf(-eta));
         for (int t = 0; t < T; t++) psi[((size_t)(n - n0) * T + t) * N + i] = v;
     }
 }
@@ -695,7 +730,7 @@ extern "C" int bl_deterministic(bl_dataset *ds, int n_draws, const float *draws,
         const int n1 = (n0 + chunk < n_draws) ? n0 + chunk : n_draws;
         const dim3 grid((N + 255) / 256, (n1 - n0) < 1024 ? (n1 - n0) : 1024);
         if (psi) {
-            hipLaunchKernelGGL(bl_psi_kernel, grid, block, 0, nullptr, ds->d_rows, ds->n_stride, N, T, ds->Ks, D, d_draws, n0, n1, d_out);
+            hipLaunchKernelGGL(bl_psi_kernel, grid, block, 0, nullptr, ds->d_rows, ds->n_stride, N, T, ds->Ks, D, d_draws, n0, n1, d_out, ds->model);
             BL_HIP(hipGetLastError());
             BL_HIP(hipMemcpy(psi + (size_t)n0 * T * N, d_out, (size_t)(n1 - n0) * T * N * 4, hipMemcpyDeviceToHost));
         }

@@ -1,5 +1,6 @@
 // kernels_inst.hip -- one translation unit per padded covariate capacity pair (BL_KS, BL_KO).
 // Built N times by the Makefile (-DBL_KS=.. -DBL_KO=..) so the instantiations compile in parallel.
+// model 0 = occu (LDS-staged and HBM-row forms); model 1 = occu_rn (LDS-staged form, capacities <= 4).
 #include "logp_kernel.hpp"
 #include "nuts_kernel.hpp"
 
@@ -8,35 +9,41 @@
 #endif
 #define BL_CAT3(a, b, c) a##_##b##_##c
 #define BL_NAME(base, ks, ko) BL_CAT3(base, ks, ko)
+#if BL_KS <= 4 && BL_KO <= 4
+#define BL_HAVE_RN 1
+#else
+#define BL_HAVE_RN 0
+#endif
 
-template <typename K>
-static hipError_t bl_set_lds(K kernel, int lds_bytes)
+template <typename K, typename P>
+static int bl_launch(K kernel, const P *p, int grid, int threads, int lds_bytes, hipStream_t stream)
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-}
-
-extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int grid, int lds_bytes, int staged, hipStream_t stream)
-{
-    hipError_t e;
-    if (staged) {
-        if ((e = bl_set_lds(bl_nuts_kernel<BL_KS, BL_KO, true>, lds_bytes)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((bl_nuts_kernel<BL_KS, BL_KO, true>), dim3(grid), dim3(BL_THREADS), lds_bytes, stream, *p);
-    } else {
-        if ((e = bl_set_lds(bl_nuts_kernel<BL_KS, BL_KO, false>, lds_bytes)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((bl_nuts_kernel<BL_KS, BL_KO, false>), dim3(grid), dim3(BL_THREADS), lds_bytes, stream, *p);
-    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds_bytes, stream, *p);
     return (int)hipGetLastError();
 }
 
-extern "C" int BL_NAME(bl_launch_logp, BL_KS, BL_KO)(const BlLogpParams *p, int grid, int lds_bytes, int staged, hipStream_t stream)
+extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int grid, int lds_bytes, int staged, int model, hipStream_t stream)
 {
-    hipError_t e;
-    if (staged) {
-        if ((e = bl_set_lds(bl_logp_kernel<BL_KS, BL_KO, true>, lds_bytes)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((bl_logp_kernel<BL_KS, BL_KO, true>), dim3(grid), dim3(BL_THREADS), lds_bytes, stream, *p);
-    } else {
-        if ((e = bl_set_lds(bl_logp_kernel<BL_KS, BL_KO, false>, lds_bytes)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((bl_logp_kernel<BL_KS, BL_KO, false>), dim3(grid), dim3(BL_THREADS), lds_bytes, stream, *p);
+    if (model == 1) {
+#if BL_HAVE_RN
+        if (staged) return bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, 1>, p, grid, BL_THREADS_RN, lds_bytes, stream);
+#endif
+        return (int)hipErrorNotSupported;
     }
-    return (int)hipGetLastError();
+    if (staged) return bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, 0>, p, grid, BL_THREADS, lds_bytes, stream);
+    return bl_launch(bl_nuts_kernel<BL_KS, BL_KO, false, 0>, p, grid, BL_THREADS, lds_bytes, stream);
+}
+
+extern "C" int BL_NAME(bl_launch_logp, BL_KS, BL_KO)(const BlLogpParams *p, int grid, int lds_bytes, int staged, int model, hipStream_t stream)
+{
+    if (model == 1) {
+#if BL_HAVE_RN
+        if (staged) return bl_launch(bl_logp_kernel<BL_KS, BL_KO, true, 1>, p, grid, BL_THREADS_RN, lds_bytes, stream);
+#endif
+        return (int)hipErrorNotSupported;
+    }
+    if (staged) return bl_launch(bl_logp_kernel<BL_KS, BL_KO, true, 0>, p, grid, BL_THREADS, lds_bytes, stream);
+    return bl_launch(bl_logp_kernel<BL_KS, BL_KO, false, 0>, p, grid, BL_THREADS, lds_bytes, stream);
 }

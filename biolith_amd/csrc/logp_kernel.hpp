@@ -7,13 +7,14 @@
 struct BlLogpParams {
     BlDevData dd;
     int k, nloc, rec_stride;
+    int max_abundance;   // occu_rn only
     int B;
     const float *theta;  // [B][D] float32 view of the caller's double theta
     double *partial;     // [B][k][64]: c < D grad of log-lik, c == D log-lik
 };
 
-template <int KS, int KO, bool LDS>
-__global__ void __launch_bounds__(BL_THREADS) bl_logp_kernel(const BlLogpParams p)
+template <int KS, int KO, bool LDS, int MODEL>
+__global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_logp_kernel(const BlLogpParams p)
 {
     const int member = blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -24,7 +25,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_logp_kernel(const BlLogpParams 
     const float *grows = nullptr;
     int ld = p.rec_stride;
     if constexpr (LDS) {
-        bl_stage_records(p.dd.rows, p.dd.n_stride, s0, cnt, p.dd.T, p.dd.J, KS, KO, p.rec_stride);
+        bl_stage_records(p.dd.rows, p.dd.n_stride, s0, cnt, p.dd.T, p.dd.J, KS, KO, p.rec_stride, BlGeom<MODEL>::THREADS);
     } else {
         grows = p.dd.rows + s0;
         ld = p.dd.n_stride;
@@ -44,7 +45,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_logp_kernel(const BlLogpParams 
             for (int k = 0; k <= KS; k++) gb[k] = 0.0f;
 #pragma unroll
             for (int k = 0; k <= KO; k++) ga[k] = 0.0f;
-            bl_eval_sites<KS, KO, LDS>(tid - 64, grows, ld, cnt, p.dd.T, p.dd.J, beta, alpha, ll, gb, ga);
+            bl_eval_sites<KS, KO, LDS, MODEL>(tid - 64, grows, ld, cnt, p.dd.T, p.dd.J, p.max_abundance, beta, alpha, ll, gb, ga);
             bl_wave_partials_to_lds<KS, KO>(wave - 1, ll, gb, ga);
         }
         __syncthreads();
@@ -52,7 +53,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_logp_kernel(const BlLogpParams 
             const float *part = bl_lds_f(BL_OFF_PART);
             double acc = 0.0;
 #pragma unroll
-            for (int w = 0; w < BL_CWAVES; w++) acc += (double)part[w * BL_PART_STRIDE + my_pos];
+            for (int w = 0; w < BlGeom<MODEL>::CWAVES; w++) acc += (double)part[w * BL_PART_STRIDE + my_pos];
             double *out = p.partial + ((size_t)b * p.k + member) * 64;
             if (lane <= D) out[lane] = acc;
         }

@@ -81,6 +81,7 @@ struct BlNutsParams {
     int rec_stride;                // floats per LDS pair record
     int nvp;                       // granules per workgroup record: 16, 32 or 64 (>= D+4)
     int max_depth;
+    int max_abundance;             // occu_rn only (occu_rn.py:26)
     int allow_local;               // 0: always use the placement-independent exchange
     int poll_sleep;                // s_sleep(1) repeats between re-polls (fabric form)
     int first_delay;               // s_sleep(1) repeats between publishing and the first poll
@@ -142,8 +143,8 @@ __device__ __forceinline__ unsigned long long bl_poll_load(const unsigned char *
     return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(base + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int KS, int KO, bool LDS>
-__global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams p)
+template <int KS, int KO, bool LDS, int MODEL>
+__global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const BlNutsParams p)
 {
     // XCD-aware mapping (speed only; see header): label = b % 8 names a set of blocks that share an XCD
     const int label = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
     const float *grows = nullptr;
     int ld = p.rec_stride;
     if constexpr (LDS) {
-        bl_stage_records(p.rows, p.n_stride, s0, cnt, T, J, KS, KO, p.rec_stride);
+        bl_stage_records(p.rows, p.n_stride, s0, cnt, T, J, KS, KO, p.rec_stride, BlGeom<MODEL>::THREADS);
     } else {
         grows = p.rows + s0;
         ld = p.n_stride;
@@ -289,7 +290,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
             for (int k = 0; k <= KS; k++) gb[k] = 0.0f;
 #pragma unroll
             for (int k = 0; k <= KO; k++) ga[k] = 0.0f;
-            bl_eval_sites<KS, KO, LDS>(tid - 64, grows, ld, cnt, T, J, beta, alpha, ll, gb, ga);
+            bl_eval_sites<KS, KO, LDS, MODEL>(tid - 64, grows, ld, cnt, T, J, p.max_abundance, beta, alpha, ll, gb, ga);
             bl_wave_partials_to_lds<KS, KO>(wave - 1, ll, gb, ga);
         } else {
             run_deferred(); // overlaps phase A
@@ -304,7 +305,7 @@ __global__ void __launch_bounds__(BL_THREADS) bl_nuts_kernel(const BlNutsParams 
             const float *part = bl_lds_f(BL_OFF_PART) + my_pos;
             float comp = 0.0f; // lanes < D: their gradient component; lane D: the log-lik
 #pragma unroll
-            for (int w = 0; w < BL_CWAVES; w++) comp += part[w * BL_PART_STRIDE];
+            for (int w = 0; w < BlGeom<MODEL>::CWAVES; w++) comp += part[w * BL_PART_STRIDE];
             if (lane > D) comp = 0.0f;
             if (lane == D + 1 && member == 0 && (epoch & 255u) == 0u)
                 comp = (__hip_atomic_load(cold->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1.0f : 0.0f;

@@ -15,6 +15,15 @@
 #define BL_CWAVES 4
 #define BL_CTHREADS (BL_CWAVES * 64)
 #define BL_THREADS (BL_CTHREADS + 64)
+// occu_rn keeps a 128-entry per-lane table in registers: 3 compute waves + the control wave = one
+// wave per SIMD, so each may use the full 512-register file.
+#define BL_CWAVES_RN 3
+#define BL_THREADS_RN (BL_CWAVES_RN * 64 + 64)
+template <int MODEL> struct BlGeom {
+    static constexpr int CWAVES = MODEL == 1 ? BL_CWAVES_RN : BL_CWAVES;
+    static constexpr int CTHREADS = CWAVES * 64;
+    static constexpr int THREADS = CTHREADS + 64;
+};
 #define BL_DIR_STREAM 62
 #define BL_MAX_DEPTH 10
 #define BL_NSTREAM 64
@@ -75,6 +84,8 @@ __host__ __device__ inline int bl_record_stride(int T, int J, int KS, int KO)
 // ------------------------------------------------------------------ math ----
 #define BL_LOG2E 1.4426950408889634f
 #define BL_LN2 0.6931471805599453f
+
+__device__ __forceinline__ float bl_exp_f(float x) { return __builtin_amdgcn_exp2f(x * BL_LOG2E); }
 
 // ------------------------------------------------------------ DPP helpers ----
 template <int CTRL, int ROW_MASK>
@@ -426,12 +437,163 @@ __device__ __forceinline__ void bl_eval_sites_hbm(int ct, const float *__restric
     }
 }
 
-template <int KS, int KO, bool LDS>
-__device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ grows, int ld_or_stride, int cnt, int T, int J,
+
+// ---------------------------------------------------------------- Royle-Nichols (occu_rn) ----
+// biolith/models/occu_rn.py:179-222 + utils/distributions.py:31-40 with N summed out:
+//   lambda = exp(eta);  pi_n = Poisson(lambda)(n) renormalised over n <= K   (K = max_abundance)
+//   P(y=1 | n) = 1 - q^n = r * b_n ,  q = 1 - r ,  b_n = 1 + q + ... + q^(n-1)  (b_n = b_(n-1) q + 1:
+//   no cancellation);  non-detections contribute n log q: rank-1 in n.
+//   l = logsumexp_n [ n (eta + sum_nondet log q) - lgamma(n+1) + sum_det (log r + log b_n) ] - log Z
+// One site per lane.  LP[n] = sum over detection visits of log2 b_n lives in registers: every
+// n-loop is fully unrolled so the array is indexed statically; lgamma(n+1) folds to literals.
+// The gradient w.r.t. nu_j of a detection visit, sum_n w_n (q - q r b'_n / b_n), reuses the
+// posterior weights W[n] (stored over LP) in a second pass per detection: no per-visit state.
+#define BL_RN_NB 128
+__device__ constexpr float BL_LGAMMA1P[BL_RN_NB] = {0.000000000e+00f, 0.000000000e+00f, 6.931471806e-01f, 1.791759469e+00f, 3.178053830e+00f, 4.787491743e+00f, 6.579251212e+00f, 8.525161361e+00f, 1.060460290e+01f, 1.280182748e+01f, 1.510441257e+01f, 1.750230785e+01f, 1.998721450e+01f, 2.255216385e+01f, 2.519122118e+01f, 2.789927138e+01f, 3.067186011e+01f, 3.350507345e+01f, 3.639544521e+01f, 3.933988419e+01f, 4.233561646e+01f, 4.538013890e+01f, 4.847118135e+01f, 5.160667557e+01f, 5.478472940e+01f, 5.800360522e+01f, 6.126170176e+01f, 6.455753863e+01f, 6.788974314e+01f, 7.125703897e+01f, 7.465823635e+01f, 7.809222355e+01f, 8.155795946e+01f, 8.505446702e+01f, 8.858082754e+01f, 9.213617560e+01f, 9.571969454e+01f, 9.933061245e+01f, 1.029681986e+02f, 1.066317603e+02f, 1.103206397e+02f, 1.140342118e+02f, 1.177718814e+02f, 1.215330815e+02f, 1.253172711e+02f, 1.291239336e+02f, 1.329525750e+02f, 1.368027226e+02f, 1.406739236e+02f, 1.445657439e+02f, 1.484777670e+02f, 1.524095926e+02f, 1.563608363e+02f, 1.603311282e+02f, 1.643201123e+02f, 1.683274454e+02f, 1.723527971e+02f, 1.763958484e+02f, 1.804562914e+02f, 1.845338289e+02f, 1.886281734e+02f, 1.927390473e+02f, 1.968661817e+02f, 2.010093164e+02f, 2.051681995e+02f, 2.093425868e+02f, 2.135322415e+02f, 2.177369341e+02f, 2.219564418e+02f, 2.261905483e+02f, 2.304390436e+02f, 2.347017234e+02f, 2.389783896e+02f, 2.432688490e+02f, 2.475729141e+02f, 2.518904022e+02f, 2.562211356e+02f, 2.605649410e+02f, 2.649216498e+02f, 2.692910977e+02f, 2.736731243e+02f, 2.780675734e+02f, 2.824742927e+02f, 2.868931333e+02f, 2.913239501e+02f, 2.957666014e+02f, 3.002209486e+02f, 3.046868568e+02f, 3.091641936e+02f, 3.136528299e+02f, 3.181526396e+02f, 3.226634991e+02f, 3.271852877e+02f, 3.317178872e+02f, 3.362611820e+02f, 3.408150589e+02f, 3.453794071e+02f, 3.499541180e+02f, 3.545390855e+02f, 3.591342054e+02f, 3.637393756e+02f, 3.683544961e+02f, 3.729794689e+02f, 3.776141979e+02f, 3.822585888e+02f, 3.869125491e+02f, 3.915759882e+02f, 3.962488171e+02f, 4.009309483e+02f, 4.056222962e+02f, 4.103227765e+02f, 4.150323067e+02f, 4.197508056e+02f, 4.244781934e+02f, 4.292143919e+02f, 4.339593240e+02f, 4.387129142e+02f, 4.434750881e+02f, 4.482457727e+02f, 4.530248962e+02f, 4.578123880e+02f, 4.626081785e+02f, 4.674121996e+02f, 4.722243839e+02f, 4.770446655e+02f, 4.818729792e+02f, 4.867092611e+02f, 4.915534482e+02f};
+
+template <int KS, int KO, int CT>
+__device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, int T, int J, int K,
+                                                 const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
+                                                 float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
+{
+    constexpr int XQ = (KS + 3) & ~3;
+    const int pb = bl_period_block(J, KO);
+    const float *data = bl_lds_f(BL_OFF_DATA);
+    const float LOG_TINY = -87.33654475f;
+    for (int i = ct; i < cnt; i += CT) {
+        const float *rec = data + (size_t)(i >> 1) * pstride + (i & 1); // element e of this site: rec[2 e]
+        float x[KS > 0 ? KS : 1];
+        float eta = beta[0];
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            x[k] = rec[2 * k];
+            eta = fmaf(x[k], beta[k + 1], eta);
+        }
+        // renormalised truncated-Poisson prior: max, sum and mean of exp(n eta - lgamma(n+1)), n <= K
+        float mz = 0.0f; // n = 0 term
+#pragma unroll
+        for (int n = 1; n < BL_RN_NB; n++)
+            if (n <= K) mz = fmaxf(mz, fmaf((float)n, eta, -BL_LGAMMA1P[n]));
+        float sz = bl_exp_f(-mz), b1 = 0.0f;
+#pragma unroll
+        for (int n = 1; n < BL_RN_NB; n++)
+            if (n <= K) {
+                const float e = bl_exp_f(fmaf((float)n, eta, -BL_LGAMMA1P[n]) - mz);
+                sz += e;
+                b1 = fmaf((float)n, e, b1);
+            }
+        const float rsz = __builtin_amdgcn_rcpf(sz);
+        const float log_z = mz + BL_LN2 * __builtin_amdgcn_logf(sz);
+        const float en_prior = b1 * rsz;
+        float deta = 0.0f;
+        for (int t = 0; t < T; t++) {
+            const float *pv = rec + 2 * (XQ + t * pb);
+            float LP[BL_RN_NB];
+#pragma unroll
+            for (int n = 0; n < BL_RN_NB; n++) LP[n] = 0.0f;
+            float cnon = 0.0f, clr = 0.0f, ndet = 0.0f;
+            float Rv[KO + 1];
+#pragma unroll
+            for (int k = 0; k <= KO; k++) Rv[k] = 0.0f;
+            // ---- A: visits.  u = c nu;  log sigma(u) = log r (detection) or log q (non-detection) ----
+            for (int j = 0; j < J; j++) {
+                float w[KO + 1];
+#pragma unroll
+                for (int k = 0; k <= KO; k++) w[k] = pv[2 * (j * (KO + 1) + k)];
+                const float c = w[0];
+                float u = c * alpha[0];
+#pragma unroll
+                for (int k = 1; k <= KO; k++) u = fmaf(w[k], alpha[k], u);
+                const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E), op = 1.0f + e;
+                const float logsig = fminf(u, 0.0f) - BL_LN2 * __builtin_amdgcn_logf(op);
+                const float sm = (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(op); // sigma(-u)
+                if (c > 0.0f) {
+                    clr += logsig;
+                    ndet += 1.0f;
+                    const float q = sm;
+                    float b = 0.0f;
+#pragma unroll
+                    for (int n = 1; n < BL_RN_NB; n++)
+                        if (n <= K) {
+                            b = fmaf(b, q, 1.0f);
+                            LP[n] += __builtin_amdgcn_logf(b);
+                        }
+                } else if (c < 0.0f) {
+                    cnon += logsig;
+                    // d/dnu of n log q is -n r: rank-1; dnu * (1, w) = r E[n] * (c, c w)
+#pragma unroll
+                    for (int k = 0; k <= KO; k++) Rv[k] = fmaf(sm, w[k], Rv[k]);
+                }
+            }
+            // ---- B: sum over n ----
+            const float a = eta + cnon;
+            const float term0 = ndet * LOG_TINY; // n = 0: detections impossible -> numpyro's clamp tiny
+            float m = term0;
+#pragma unroll
+            for (int n = 1; n < BL_RN_NB; n++)
+                if (n <= K) {
+                    LP[n] = fmaf((float)n, a, fmaf(BL_LN2, LP[n], clr - BL_LGAMMA1P[n])); // term_n (prior unnormalised)
+                    m = fmaxf(m, LP[n]);
+                }
+            const float t0 = bl_exp_f(term0 - m);
+            float s = t0, a1 = 0.0f;
+#pragma unroll
+            for (int n = 1; n < BL_RN_NB; n++)
+                if (n <= K) {
+                    const float wn = bl_exp_f(LP[n] - m);
+                    LP[n] = wn; // unnormalised posterior weight of N = n
+                    s += wn;
+                    a1 = fmaf((float)n, wn, a1);
+                }
+            const float rs = __builtin_amdgcn_rcpf(s);
+            ll += m + BL_LN2 * __builtin_amdgcn_logf(s) - log_z;
+            const float en_post = a1 * rs;
+            deta += en_post - en_prior;
+#pragma unroll
+            for (int k = 0; k <= KO; k++) ga[k] = fmaf(en_post, Rv[k], ga[k]);
+            // ---- C: detection visits' d/dnu = sum_n w_n (q - q r b'_n / b_n),  b'_n = b'_(n-1) q + b_(n-1) ----
+            if (ndet > 0.0f) {
+                for (int j = 0; j < J; j++) {
+                    float w[KO + 1];
+#pragma unroll
+                    for (int k = 0; k <= KO; k++) w[k] = pv[2 * (j * (KO + 1) + k)];
+                    if (w[0] > 0.0f) {
+                        float u = w[0] * alpha[0];
+#pragma unroll
+                        for (int k = 1; k <= KO; k++) u = fmaf(w[k], alpha[k], u);
+                        const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E), op = 1.0f + e;
+                        const float rop = __builtin_amdgcn_rcpf(op);
+                        const float q = (u > 0.0f ? e : 1.0f) * rop, r = (u > 0.0f ? 1.0f : e) * rop;
+                        float b = 0.0f, bp = 0.0f, h = 0.0f;
+#pragma unroll
+                        for (int n = 1; n < BL_RN_NB; n++)
+                            if (n <= K) {
+                                bp = fmaf(bp, q, b);
+                                b = fmaf(b, q, 1.0f);
+                                h = fmaf(LP[n] * bp, __builtin_amdgcn_rcpf(b), h);
+                            }
+                        const float dnu = q * ((s - t0) - r * h) * rs;
+#pragma unroll
+                        for (int k = 0; k <= KO; k++) ga[k] = fmaf(dnu, w[k], ga[k]);
+                    }
+                }
+            }
+        }
+        gb[0] += deta;
+#pragma unroll
+        for (int k = 0; k < KS; k++) gb[k + 1] = fmaf(deta, x[k], gb[k + 1]);
+    }
+}
+
+// MODEL 0 = occu (occu.py), MODEL 1 = occu_rn (occu_rn.py; LDS records only)
+template <int KS, int KO, bool LDS, int MODEL>
+__device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ grows, int ld_or_stride, int cnt, int T, int J, int K,
                                               const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                               float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
 {
-    if constexpr (LDS) {
+    if constexpr (MODEL == 1) {
+        if constexpr (LDS) bl_eval_sites_rn<KS, KO, BL_CWAVES_RN * 64>(ct, ld_or_stride, cnt, T, J, K, beta, alpha, ll, gb, ga);
+    } else if constexpr (LDS) {
         switch (J) { // wave-uniform
         case 1: bl_eval_sites_lds<KS, KO, 1>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
         case 2: bl_eval_sites_lds<KS, KO, 2>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
@@ -450,14 +612,14 @@ __device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ 
 // Transpose this workgroup's site slice [s0, s0+cnt) of the HBM rows (coalesced reads along the
 // site axis) into LDS pair records: element `pos` of site i lands at pair (i/2), float 2*pos + (i&1).
 __device__ __forceinline__ void bl_stage_records(const float *__restrict__ rows, int n_stride, int s0, int cnt,
-                                                 int T, int J, int KS, int KO, int pstride)
+                                                 int T, int J, int KS, int KO, int pstride, int nthreads)
 {
     float *dst = bl_lds_f(BL_OFF_DATA);
     const int xq = bl_round4(KS), pb = bl_period_block(J, KO), V = T * J, vw = KO + 1;
     const int n_rows = KS + V * vw + 2 * T;
     if (cnt & 1) { // dummy second site of the last pair: all zeros (its contributions are masked)
         float *last = dst + (size_t)(cnt >> 1) * pstride;
-        for (int e = threadIdx.x; e < xq + T * pb; e += BL_THREADS) last[2 * e + 1] = 0.0f;
+        for (int e = threadIdx.x; e < xq + T * pb; e += nthreads) last[2 * e + 1] = 0.0f;
     }
     for (int r = 0; r < n_rows; r++) {
         int pos;
@@ -468,7 +630,7 @@ __device__ __forceinline__ void bl_stage_records(const float *__restrict__ rows,
         } else if (r < KS + V * vw + T) pos = xq + (r - KS - V * vw) * pb + J * vw;
         else pos = xq + (r - KS - V * vw - T) * pb + J * vw + 1;
         const float *src = rows + (size_t)r * n_stride + s0;
-        for (int i = threadIdx.x; i < cnt; i += BL_THREADS) dst[(size_t)(i >> 1) * pstride + 2 * pos + (i & 1)] = src[i];
+        for (int i = threadIdx.x; i < cnt; i += nthreads) dst[(size_t)(i >> 1) * pstride + 2 * pos + (i & 1)] = src[i];
     }
 }
 

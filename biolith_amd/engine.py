@@ -48,8 +48,12 @@ class OccuDataset:
     ``site_covs (N, Ks)``, ``obs_covs (N, T, J, Ko)``, ``obs (S=1, N, T, J)``; NaN = missing.
     """
 
-    def __init__(self, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0), device: int = 0):
+    def __init__(self, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0), device: int = 0,
+                 model: str = "occu", max_abundance: int = 100):
         lib = _ffi.load()
+        if model not in ("occu", "occu_rn"):
+            raise ValueError(f"unknown model {model!r}")
+        self.model, self.max_abundance = model, int(max_abundance)
         X = np.ascontiguousarray(site_covs, dtype=np.float32)
         W = np.ascontiguousarray(obs_covs, dtype=np.float32)
         Y = np.ascontiguousarray(obs, dtype=np.float32)
@@ -72,8 +76,12 @@ class OccuDataset:
         pb = _ffi.bl_normal_prior(float(prior_beta[0]), float(prior_beta[1]))
         pa = _ffi.bl_normal_prior(float(prior_alpha[0]), float(prior_alpha[1]))
         h = C.c_void_p()
-        _ffi.check(lib.bl_dataset_create(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), C.byref(pb), C.byref(pa),
-                                         device, C.byref(h)))
+        if model == "occu_rn":
+            _ffi.check(lib.bl_dataset_create_rn(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), int(max_abundance),
+                                                C.byref(pb), C.byref(pa), device, C.byref(h)))
+        else:
+            _ffi.check(lib.bl_dataset_create(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), C.byref(pb), C.byref(pa),
+                                             device, C.byref(h)))
         self._h = h
         self._lib = lib
 
@@ -199,7 +207,8 @@ class OccuDataset:
 
     # ------------------------------------------------------------ deterministic sites ----
     def deterministic(self, draws, psi: bool = True, prob_detection: bool = False):
-        """psi (n, T, N) and/or prob_detection (n, J, T, N) for draws (n, D) (occu.py:207,221-228)."""
+        """psi -- or, for occu_rn, abundance -- (n, T, N) and/or prob_detection (n, J, T, N) for draws (n, D)
+        (occu.py:207,221-228; occu_rn.py:192,209-218)."""
         d = np.ascontiguousarray(draws, dtype=np.float32).reshape(-1, self.D)
         n = d.shape[0]
         out_psi = np.empty((n, self.T, self.N), dtype=np.float32) if psi else None

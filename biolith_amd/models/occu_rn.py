@@ -1,0 +1,153 @@
+"""``occu_rn`` / ``simulate_rn`` -- host-side mirror of biolith/models/occu_rn.py for the HIP engine.
+
+Royle & Nichols (2003): latent abundance ``N_it ~ RightTruncatedPoisson(exp(beta0 + x beta), max_abundance)``
+(enumerated; utils/distributions.py:6-40), detection ``y_itj ~ Bernoulli(1 - (1 - r_itj)^N_it)`` with
+``r = sigmoid(alpha0 + w alpha)`` (occu_rn.py:194-222).  As with :func:`occu`, the callable keeps the
+reference's signature (occu_rn.py:20-40), validates, and resolves to an :class:`OccuSpec` that
+``fit`` lowers onto the C-ABI; the marginal density, gradient and sampler run in gfx950 kernels.
+"""
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+
+from ..distributions import Beta, HalfNormal, Normal, as_normal
+from ..regression import LinearRegression
+from .occu import OccuSpec
+
+MAX_ABUNDANCE_LIMIT = 127  # the kernel's per-lane table over N (BL_RN_NB - 1)
+MAX_RN_COVS = 4            # covariates per side the occu_rn kernels are instantiated for
+
+
+def occu_rn(
+    site_covs,
+    obs_covs,
+    coords=None,
+    ell: float = 1.0,
+    false_positives_constant: bool = False,
+    max_abundance: int = 100,
+    obs=None,
+    n_species: int = 1,
+    prior_beta: Any = Normal(),
+    prior_alpha: Any = Normal(),
+    regressor_abu=LinearRegression,
+    regressor_det=LinearRegression,
+    prior_prob_fp_constant: Any = Beta(2, 5),
+    prior_gp_sd: Any = HalfNormal(1.0),
+    prior_gp_length: Any = HalfNormal(1.0),
+    site_random_effects: bool = False,
+    obs_random_effects: bool = False,
+    prior_site_re_sd: Any = HalfNormal(1.0),
+    prior_obs_re_sd: Any = HalfNormal(1.0),
+) -> OccuSpec:
+    """Royle-Nichols abundance-occupancy model on the HIP engine (parameters: occu_rn.py:20-40).
+
+    Built: the default option path (linear regressors, Normal priors, no false positives, no
+    spatial / random effects, one species).  Everything else raises ``NotImplementedError``.
+
+    Examples
+    --------
+    >>> from biolith_amd.models import occu_rn, simulate_rn
+    >>> from biolith_amd.utils import fit
+    >>> data, _ = simulate_rn()
+    >>> results = fit(occu_rn, **data)
+    >>> print(results.samples['abundance'].mean())
+    """
+    site_covs = np.asarray(site_covs, dtype=np.float32)
+    obs_covs = np.asarray(obs_covs, dtype=np.float32)
+    obs = None if obs is None else np.asarray(obs, dtype=np.float32)
+    # occu_rn.py:101-108
+    assert obs is None or obs.ndim == 4, "obs must be None or of shape (n_species, n_sites, n_periods, n_replicates)"
+    assert site_covs.ndim == 2, "site_covs must be (n_sites, n_site_covs)"
+    assert obs_covs.ndim == 4, "obs_covs must be (n_sites, n_periods, n_replicates, n_obs_covs)"
+    if obs is not None:
+        n_species = obs.shape[0]
+    unsupported = []
+    if coords is not None:
+        unsupported.append("coords (spatial effect, occu_rn.py:140-148)")
+    if false_positives_constant:
+        unsupported.append("false positives (occu_rn.py:133-138)")
+    if site_random_effects or obs_random_effects:
+        unsupported.append("random effects (occu_rn.py:151-154)")
+    if regressor_abu is not LinearRegression or regressor_det is not LinearRegression:
+        unsupported.append("non-linear regressors (occu_rn.py:166-167)")
+    if n_species != 1:
+        unsupported.append(f"n_species={n_species}")
+    if obs is None:
+        unsupported.append("obs=None (prior predictive)")
+    if not 1 <= int(max_abundance) <= MAX_ABUNDANCE_LIMIT:
+        unsupported.append(f"max_abundance={max_abundance} (1..{MAX_ABUNDANCE_LIMIT})")
+    if site_covs.shape[1] > MAX_RN_COVS or obs_covs.shape[3] > MAX_RN_COVS:
+        unsupported.append(f"more than {MAX_RN_COVS} covariates per side for occu_rn")
+    if unsupported:
+        raise NotImplementedError(
+            "biolith_amd.occu_rn runs the default-option Royle-Nichols path on the HIP engine; not built: "
+            + "; ".join(unsupported)
+        )
+    if obs.shape[1:] != obs_covs.shape[:3] or site_covs.shape[0] != obs_covs.shape[0]:
+        raise ValueError("site_covs, obs_covs and obs disagree on (n_sites, n_periods, n_replicates)")
+    return OccuSpec(site_covs, obs_covs, obs, n_species, as_normal(prior_beta, "prior_beta"),
+                    as_normal(prior_alpha, "prior_alpha"), model="occu_rn",
+                    extras=dict(max_abundance=int(max_abundance)))
+
+
+occu_rn.__biolith_amd_model__ = "occu_rn"
+
+
+def simulate_rn(
+    n_site_covs: int = 1,
+    n_obs_covs: int = 1,
+    n_sites: int = 100,
+    n_periods: int = 1,
+    n_species: int = 1,
+    deployment_days_per_site: int = 365,
+    session_duration: int = 7,
+    prob_fp: float = 0.0,
+    simulate_missing: bool = False,
+    min_occupancy: float = 0.25,
+    max_occupancy: float = 0.75,
+    min_observation_rate: float = 0.1,
+    max_observation_rate: float = 0.5,
+    random_seed: int = 0,
+    spatial: bool = False,
+    gp_sd: float = 1.0,
+    gp_l: float = 0.2,
+):
+    """Synthetic dataset for :func:`occu_rn`; returns ``(data, true_params)`` (occu_rn.py:225-358).
+
+    Bit-identical to the reference for equal arguments: per rejection-loop iteration the PCG64
+    calls are beta, alpha, site_covs, Poisson N, obs_covs, binomial obs, [3 missingness masks].
+    """
+    if spatial:
+        raise NotImplementedError("simulate_rn(spatial=True) is outside the built path (utils/spatial.py:52-76)")
+    rng = np.random.default_rng(random_seed)
+    coords = None
+    n_replicates = round(deployment_days_per_site / session_duration)
+    while True:
+        beta = rng.normal(size=(n_species, n_site_covs + 1))
+        alpha = rng.normal(size=(n_species, n_obs_covs + 1))
+        site_covs = rng.normal(size=(n_sites, n_site_covs))
+        w, ell = np.zeros(n_sites), 0.0
+        abundance = np.exp(beta[:, 0][:, None] + np.tensordot(beta[:, 1:], site_covs, axes=([1], [1])) + w[None, :])
+        N_i = rng.poisson(abundance[:, None, :], size=(n_species, n_periods, n_sites))
+        obs_covs = rng.normal(size=(n_sites, n_periods, n_replicates, n_obs_covs))
+        r_it = 1 / (1 + np.exp(-(alpha[:, 0][:, None, None, None] + np.tensordot(alpha[:, 1:], obs_covs, axes=([1], [3])))))
+        N_i_site = N_i.transpose(0, 2, 1)
+        p_it = 1.0 - (1.0 - r_it) ** N_i_site[..., None]
+        obs = rng.binomial(n=1, p=1 - (1 - p_it) * (1 - prob_fp), size=(n_species, n_sites, n_periods, n_replicates))
+        obs = (obs >= 1) * 1.0
+        if simulate_missing:
+            obs[rng.choice([True, False], size=obs.shape, p=[0.2, 0.8])] = np.nan
+            obs_covs[rng.choice([True, False], size=obs_covs.shape, p=[0.05, 0.95])] = np.nan
+            site_covs[rng.choice([True, False], size=site_covs.shape, p=[0.05, 0.95])] = np.nan
+        occ = (N_i > 0).mean()
+        rate = np.mean(obs[np.isfinite(obs)])
+        # negation of the reference's while-condition (occu_rn.py:272-278)
+        if not (occ < min_occupancy or occ > max_occupancy or rate < min_observation_rate or rate > max_observation_rate):
+            break
+    print(f"True occupancy: {np.mean(N_i > 0):.4f}")
+    print(f"True abundance: {np.mean(abundance):.4f}")
+    print(f"Proportion of timesteps with observation: {np.mean(obs[np.isfinite(obs)]):.4f}")
+    data = dict(site_covs=site_covs, obs_covs=obs_covs, obs=obs, coords=coords, ell=ell)
+    return data, dict(abundance=abundance, beta=beta, alpha=alpha, w=w, gp_sd=gp_sd, gp_l=gp_l)

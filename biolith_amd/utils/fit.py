@@ -38,7 +38,7 @@ def fit(
     """Fit an occupancy model with NUTS on an MI355X.
 
     Parameters are those of the reference ``fit`` (fit.py:33-66).  ``model_fn`` must be
-    :func:`biolith_amd.models.occu`.  ``kernel`` must be ``None`` or ``"nuts"``; ``init_strategy``
+    :func:`biolith_amd.models.occu` or :func:`biolith_amd.models.occu_rn`.  ``kernel`` must be ``None`` or ``"nuts"``; ``init_strategy``
     must be ``None`` (= ``init_to_uniform``, fit.py:93).  Extra keyword arguments go to the model,
     plus two engine knobs that the reference does not have: ``device`` (GPU index, default 0) and
     ``chain_offset`` (global id of the first chain, for sharding chains over processes).
@@ -75,7 +75,8 @@ def fit(
 
     from ..engine import OccuDataset
 
-    ds = OccuDataset(spec.site_covs, spec.obs_covs, spec.obs, spec.prior_beta, spec.prior_alpha, device=device)
+    ds = OccuDataset(spec.site_covs, spec.obs_covs, spec.obs, spec.prior_beta, spec.prior_alpha, device=device,
+                     model=spec.model, max_abundance=spec.extras.get("max_abundance", 100))
     try:
         run_kw = dict(num_warmup=num_warmup, num_samples=num_samples, num_chains=num_chains,
                       seed=random_seed, chain_offset=chain_offset)
@@ -109,6 +110,8 @@ def _assemble(ds, spec, res, num_warmup) -> HipMCMC:
         _, pd = ds.deterministic(flat, psi=False, prob_detection=True)
         return pd.reshape(C, S, ds.J, ds.T, ds.N, nsp)
 
+    # occu emits "psi" (occu.py:207); occu_rn emits "abundance" = exp(linear predictor) (occu_rn.py:192)
+    first = "abundance" if spec.model == "occu_rn" else "psi"
     return HipMCMC(res, latent=dict(beta=beta, alpha=alpha),
-                   deterministic=dict(psi=psi, prob_detection=prob_detection),
+                   deterministic={first: psi, "prob_detection": prob_detection},
                    num_warmup=num_warmup, spec_shape=spec.shape)

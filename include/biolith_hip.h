@@ -70,6 +70,17 @@ int bl_device_count(int *count);
 int bl_dataset_create(const bl_dims *dims, const float *site_covs, const float *obs_covs,
                       const float *obs, const bl_normal_prior *prior_beta,
                       const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
+/*
+ * Same for the Royle-Nichols model biolith.models.occu_rn (models/occu_rn.py:20-222): latent
+ * abundance N ~ RightTruncatedPoisson(exp(beta0 + x beta), max_abundance) (utils/distributions.py:6-40)
+ * summed out in the kernel, detection 1 - (1 - sigmoid(alpha0 + w alpha))^N.  Built for
+ * max_abundance <= 127 and at most 4 covariates per side.  The handle then behaves exactly like an
+ * occu handle (bl_logp_grad, bl_nuts_*); bl_deterministic's first output becomes
+ * `abundance` = exp(beta0 + x beta) (occu_rn.py:192).
+ */
+int bl_dataset_create_rn(const bl_dims *dims, const float *site_covs, const float *obs_covs,
+                         const float *obs, int max_abundance, const bl_normal_prior *prior_beta,
+                         const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
 int bl_dataset_destroy(bl_dataset *ds);
 /* D = Ks+1 + Ko+1; theta = [beta_0..beta_Ks, alpha_0..alpha_Ko] */
 int bl_dataset_param_dim(const bl_dataset *ds, int *D);

@@ -46,6 +46,7 @@ def lib():
             L.orc_data_create.argtypes = [C.c_int] * 5 + [dp, dp, dp] + [C.c_double] * 4
             L.orc_data_destroy.argtypes = [C.c_void_p]
             L.orc_data_dim.argtypes = [C.c_void_p]
+            L.orc_data_set_model.argtypes = [C.c_void_p, C.c_int, C.c_int]
             L.orc_potential_grad.restype = C.c_double
             L.orc_potential_grad.argtypes = [C.c_void_p, dp, dp]
             L.orc_rng_streams.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
@@ -79,7 +80,8 @@ def _as_f32_f64(a):
 class OracleData:
     """Prepared dataset for ONE species: site_covs (N,Ks), obs_covs (N,T,J,Ko), obs (N,T,J)."""
 
-    def __init__(self, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):
+    def __init__(self, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0), model="occu",
+                 max_abundance=100):
         X = _as_f32_f64(site_covs)
         W = _as_f32_f64(obs_covs)
         Y = _as_f32_f64(obs)
@@ -98,6 +100,9 @@ class OracleData:
         )
         self.X, self.W, self.Y = X, W, Y
         self.prior_beta, self.prior_alpha = tuple(prior_beta), tuple(prior_alpha)
+        self.model, self.max_abundance = model, int(max_abundance)
+        assert model in ("occu", "occu_rn")
+        lib().orc_data_set_model(self._h, 1 if model == "occu_rn" else 0, int(max_abundance))
 
     def __del__(self):
         try:
@@ -227,6 +232,42 @@ def literal_log_joint(theta, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), pr
         lz = _bernoulli_logpmf_clamped(psi, z)[:, None]        # z ~ Bernoulli(psi) per period
         per_z.append(lz + ly)
     ll = np.logaddexp(per_z[0], per_z[1]).sum()
+
+    def normal_logpdf(v, loc, scale):
+        return (-0.5 * ((v - loc) / scale) ** 2 - np.log(scale) - 0.5 * np.log(2 * np.pi)).sum()
+
+    return ll + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
+
+
+def literal_log_joint_rn(theta, site_covs, obs_covs, obs, max_abundance=100, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):
+    """log p(theta, y) of the Royle-Nichols model, stated literally (biolith/models/occu_rn.py:123-222):
+    N enumerated over 0..max_abundance under Categorical(logits=Poisson(lambda).log_prob(support))
+    (utils/distributions.py:31-40; Categorical renormalises), Bernoulli(1-(1-r)^N) with clamp_probs."""
+    from scipy.special import gammaln, logsumexp
+
+    X = _as_f32_f64(site_covs)
+    W = _as_f32_f64(obs_covs)
+    Y = _as_f32_f64(obs)
+    if Y.ndim == 4:
+        Y = Y[0]
+    Ks = X.shape[1]
+    theta = np.asarray(theta, dtype=np.float64)
+    beta, alpha = theta[: Ks + 1], theta[Ks + 1:]
+    obs_mask = np.isnan(W).any(-1) | np.isnan(X).any(-1)[:, None, None]       # occu_rn.py:124-130
+    Y = np.where(obs_mask, np.nan, Y)
+    W = np.nan_to_num(W)
+    X = np.nan_to_num(X)
+    abundance = np.exp(beta[0] + X @ beta[1:])                                  # occu_rn.py:179-192
+    support = np.arange(max_abundance + 1)
+    logits = np.log(abundance)[:, None] * support - gammaln(support + 1) - abundance[:, None]   # Poisson.log_prob
+    log_prior = logits - logsumexp(logits, axis=1, keepdims=True)              # (N, K+1)
+    r = 1.0 / (1.0 + np.exp(-(alpha[0] + np.tensordot(W, alpha[1:], axes=([3], [0])))))   # (N,T,J)  occu_rn.py:209-218
+    finite = np.isfinite(Y)
+    y0 = np.where(finite, Y, 0.0)
+    p = 1.0 - (1.0 - r[..., None]) ** support                                   # (N,T,J,K+1)  occu_rn.py:219
+    ly = _bernoulli_logpmf_clamped(p, y0[..., None])
+    ly = np.where(finite[..., None], ly, 0.0).sum(axis=2)                       # (N,T,K+1)
+    ll = logsumexp(log_prior[:, None, :] + ly, axis=2).sum()
 
     def normal_logpdf(v, loc, scale):
         return (-0.5 * ((v - loc) / scale) ** 2 - np.log(scale) - 0.5 * np.log(2 * np.pi)).sum()

@@ -50,6 +50,10 @@ def load_reference_simulate():
     return sys.modules["biolith.models.occu"].simulate
 
 
+def load_reference_simulate_rn():
+    return sys.modules["biolith.models.occu_rn"].simulate_rn
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
 
@@ -70,6 +74,41 @@ CASES = {
     "bench_i3": dict(store=False, kw=dict(n_sites=800, n_site_covs=2, n_obs_covs=1, random_seed=45,
                                           deployment_days_per_site=23 * 7, session_duration=7)),
 }
+
+
+# Royle-Nichols generator (biolith/models/occu_rn.py:225-358)
+RN_CASES = {
+    "rn_default": dict(store=True, kw=dict()),
+    "rn_small_2x2": dict(store=True, kw=dict(n_sites=60, n_site_covs=2, n_obs_covs=2, deployment_days_per_site=42, random_seed=3)),
+    "rn_missing": dict(store=True, kw=dict(n_sites=50, simulate_missing=True, deployment_days_per_site=56, n_periods=2, random_seed=1)),
+    "rn_cfg4": dict(store=False, kw=dict(n_sites=5000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7)),
+}
+
+
+def main_rn():
+    simulate_rn = load_reference_simulate_rn()
+    index = {}
+    for name, case in RN_CASES.items():
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            data, truth = simulate_rn(**case["kw"])
+        entry = dict(
+            kwargs=case["kw"], stdout=buf.getvalue(),
+            shapes={k: list(np.shape(data[k])) for k in ("site_covs", "obs_covs", "obs")},
+            sha256={k: sha(data[k]) for k in ("site_covs", "obs_covs", "obs")},
+            coords=data["coords"], ell=float(data["ell"]),
+            beta=np.asarray(truth["beta"]).tolist(), alpha=np.asarray(truth["alpha"]).tolist(),
+            mean_abundance=float(np.mean(truth["abundance"])), sha256_abundance=sha(truth["abundance"]),
+            mean_obs=float(np.nanmean(data["obs"])), stored=bool(case["store"]),
+        )
+        if case["store"]:
+            np.savez_compressed(os.path.join(HERE, f"simulate_{name}.npz"), site_covs=data["site_covs"],
+                                obs_covs=data["obs_covs"], obs=data["obs"], abundance=truth["abundance"],
+                                beta=truth["beta"], alpha=truth["alpha"])
+        index[name] = entry
+        print(name, entry["shapes"], entry["sha256"]["obs"][:24])
+    with open(os.path.join(HERE, "simulate_rn_index.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
 
 
 def main():
@@ -108,3 +147,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    main_rn()

@@ -1,0 +1,94 @@
+"""Royle-Nichols kernel (config 4 family) through the C-ABI against the CPU oracle, plus the reference's
+own fit(occu_rn) assertions (biolith/models/occu_rn.py:361-407)."""
+import numpy as np
+import pytest
+
+import oracle
+from biolith_amd.engine import OccuDataset
+from biolith_amd.evaluation import effective_sample_size, split_gelman_rubin
+from biolith_amd.models import occu_rn, simulate_rn
+from biolith_amd.utils import fit
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(name, **kw):
+    g = load_golden(name)
+    return (g, oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], model="occu_rn", **kw),
+            OccuDataset(g["site_covs"], g["obs_covs"], g["obs"], model="occu_rn", **kw))
+
+
+@pytest.mark.parametrize("name", ["rn_small_2x2", "rn_missing", "rn_default"])
+def test_rn_logp_grad_parity(name):
+    """float32 kernel vs float64 oracle: |dU|/|U| <= 1e-5, max|dgrad| <= 1e-4 max|grad| (the 101-term
+    sums over N accumulate more float32 rounding than the occu kernel's)."""
+    _, od, ds = _pair(name)
+    th = np.random.default_rng(4).uniform(-1.2, 1.2, size=(4, od.D)).astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.all(np.isfinite(Ug)) and np.all(np.isfinite(Gg))
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= 1e-5, (Ug, Uo)
+    assert np.max(np.abs(Gg - Go)) <= 1e-4 * np.max(np.abs(Go)), np.max(np.abs(Gg - Go))
+
+
+def test_rn_small_cutoff_and_priors():
+    g = load_golden("rn_small_2x2")
+    th = np.random.default_rng(1).uniform(-1, 1, size=(2, 6)).astype(np.float32).astype(np.float64)
+    for K, pri in ((7, ((0.0, 1.0), (0.0, 1.0))), (40, ((0.3, 2.0), (-0.2, 0.5)))):
+        od = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], *pri, model="occu_rn", max_abundance=K)
+        ds = OccuDataset(g["site_covs"], g["obs_covs"], g["obs"], *pri, model="occu_rn", max_abundance=K)
+        Uo, Go = od.potential_grad(th)
+        Ug, Gg = ds.logp_grad(th)
+        assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= 1e-5
+        assert np.max(np.abs(Gg - Go)) <= 1e-4 * np.max(np.abs(Go))
+
+
+def test_rn_first_transitions_match_oracle():
+    _, od, ds = _pair("rn_small_2x2")
+    o = oracle.nuts_run(od, 0, 5, num_chains=2, seed=3)
+    r = ds.nuts(num_warmup=0, num_samples=5, num_chains=2, seed=3)
+    assert np.array_equal(o["num_steps"][:, :3], r.num_steps[:, :3]), (o["num_steps"], r.num_steps)
+    assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=2e-3)
+
+
+def test_rn_posterior_matches_oracle():
+    _, od, ds = _pair("rn_small_2x2")
+    o = oracle.nuts_run(od, 300, 400, num_chains=4, seed=0)
+    r = ds.nuts(num_warmup=300, num_samples=400, num_chains=4, seed=50)
+    fg, fo = r.draws.reshape(-1, od.D).astype(np.float64), o["draws"].reshape(-1, od.D)
+    mcse = np.sqrt(fg.var(0) / effective_sample_size(r.draws) + fo.var(0) / oracle.effective_sample_size(o["draws"]))
+    assert np.all(np.abs(fg.mean(0) - fo.mean(0)) <= 4 * mcse), (fg.mean(0) - fo.mean(0), mcse)
+    ratio = fg.std(0) / fo.std(0)
+    assert np.all((ratio > 0.8) & (ratio < 1.25)), ratio
+    assert split_gelman_rubin(r.draws).max() < 1.03
+
+
+def test_occu_rn_like_reference():  # occu_rn.py:361-388 (simulate_rn default: 100 sites x 52 visits)
+    data, true_params = simulate_rn(simulate_missing=True)
+    results = fit(occu_rn, **data, timeout=600)
+    assert np.allclose(results.samples["abundance"].mean(), true_params["abundance"].mean(), rtol=0.1)
+    assert np.allclose([results.samples[k].mean() for k in [f"cov_state_{i}" for i in range(true_params["beta"].shape[1])]],
+                       true_params["beta"].mean(axis=0), atol=0.5)
+    assert np.allclose([results.samples[k].mean() for k in [f"cov_det_{i}" for i in range(true_params["alpha"].shape[1])]],
+                       true_params["alpha"].mean(axis=0), atol=0.5)
+    assert results.samples["abundance"].shape == (5000, 1, 100, 1)
+    assert "psi" not in results.samples
+
+
+def test_occu_rn_multi_season():  # occu_rn.py:391-407
+    data, true_params = simulate_rn(simulate_missing=True, n_periods=3)
+    results = fit(occu_rn, **data, num_chains=1, num_samples=300, num_warmup=300, timeout=600)
+    assert np.allclose(results.samples["abundance"].mean(), true_params["abundance"].mean(), rtol=0.2)
+
+
+def test_rn_config4_runs_and_recovers_truth():
+    """BASELINE config 4: 5 000 sites x 10 visits, 3+3 covariates, 4 chains."""
+    data, truth = simulate_rn(n_sites=5000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7)
+    res = fit(occu_rn, **data, num_chains=4, num_warmup=500, num_samples=500)
+    assert np.allclose(res.samples["abundance"].mean(), truth["abundance"].mean(), rtol=0.1)  # occu_rn.py:368-372
+    est = np.array([res.samples[f"cov_state_{i}"].mean() for i in range(4)] + [res.samples[f"cov_det_{i}"].mean() for i in range(4)])
+    assert np.allclose(est, np.concatenate([truth["beta"][0], truth["alpha"][0]]), atol=0.15)
+    assert split_gelman_rubin(res.mcmc.get_samples(group_by_chain=True)["beta"]).max() < 1.05
+    print("cfg4 kernel ms", res.mcmc.result.kernel_ms, "leapfrogs", res.mcmc.result.n_leapfrog.sum(),
+          "us/leapfrog/chain", res.mcmc.result.kernel_ms * 1e3 / (res.mcmc.result.n_leapfrog.sum() / 4))

@@ -1,0 +1,84 @@
+"""Royle-Nichols row (biolith/models/occu_rn.py): simulator pinned bit-exactly by fixtures made from
+the reference itself; oracle closed form pinned against a literal NumPy statement of the model
+(enumerated N, Categorical(logits=Poisson.log_prob) prior, clamped Bernoulli) and finite differences."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from biolith_amd.models import occu_rn, simulate_rn
+from conftest import GOLDEN, load_golden
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def rn_index():
+    with open(os.path.join(GOLDEN, "simulate_rn_index.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", ["rn_default", "rn_small_2x2", "rn_missing", "rn_cfg4"])
+def test_simulate_rn_matches_reference(rn_index, name, capsys):
+    e = rn_index[name]
+    data, truth = simulate_rn(**e["kwargs"])
+    out = capsys.readouterr().out
+    for k in ("site_covs", "obs_covs", "obs"):
+        assert list(data[k].shape) == e["shapes"][k]
+        assert _sha(data[k]) == e["sha256"][k], k
+    assert _sha(truth["abundance"]) == e["sha256_abundance"]
+    assert out == e["stdout"]  # three progress lines, occu_rn.py:339-344
+    assert data["coords"] is None and data["ell"] == 0.0
+    if e["stored"]:
+        g = load_golden(name)
+        assert np.array_equal(data["obs"], g["obs"], equal_nan=True)
+
+
+def test_simulate_rn_survey_hashes(rn_index):
+    assert rn_index["rn_default"]["sha256"]["obs"].startswith("41c72a953cac02eb726cd4de")
+    assert rn_index["rn_cfg4"]["sha256"]["obs"].startswith("3ce75212309294aa3db0d990")
+    assert abs(rn_index["rn_cfg4"]["mean_abundance"] - 1.4133) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["rn_small_2x2", "rn_missing"])
+def test_rn_closed_form_equals_literal_model(name):
+    g = load_golden(name)
+    od = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], model="occu_rn")
+    rng = np.random.default_rng(2)
+    for _ in range(3):
+        th = rng.uniform(-1, 1, od.D)
+        U, grad = od.potential_grad(th)
+        lit = oracle.literal_log_joint_rn(th, g["site_covs"], g["obs_covs"], g["obs"][0])
+        assert abs(U + lit) <= 1e-10 * abs(U)
+        h = 1e-6
+        fd = np.array([(od.potential_grad(th + h * e)[0] - od.potential_grad(th - h * e)[0]) / (2 * h) for e in np.eye(od.D)])
+        assert np.max(np.abs(fd - grad)) <= 1e-5 * max(1.0, np.max(np.abs(grad)))
+
+
+def test_rn_max_abundance_renormalises_the_prior():
+    """Categorical(logits) renormalises the truncated Poisson (utils/distributions.py:31-40): with all
+    data masked the marginal likelihood is exactly 1 whatever the cutoff."""
+    g = load_golden("rn_small_2x2")
+    Y = np.full_like(g["obs"], np.nan)
+    th = np.array([1.5, 0.3, -0.2, 0.1, 0.2, 0.3])
+    prior = 0.5 * np.sum(th ** 2) + 6 * 0.9189385332046727
+    for K in (5, 20, 100):
+        od = oracle.OracleData(g["site_covs"], g["obs_covs"], Y, model="occu_rn", max_abundance=K)
+        assert od.potential_grad(th)[0] == pytest.approx(prior, rel=1e-12)
+
+
+def test_occu_rn_validation():
+    g = load_golden("rn_small_2x2")
+    spec = occu_rn(g["site_covs"], g["obs_covs"], obs=g["obs"], coords=None, ell=0.0)
+    assert spec.model == "occu_rn" and spec.extras["max_abundance"] == 100
+    for kw in (dict(false_positives_constant=True), dict(site_random_effects=True), dict(coords=np.zeros((60, 2))),
+               dict(max_abundance=500)):
+        with pytest.raises(NotImplementedError):
+            occu_rn(g["site_covs"], g["obs_covs"], obs=g["obs"], **kw)
+    with pytest.raises(AssertionError):
+        occu_rn(g["site_covs"], g["obs_covs"], obs=g["obs"][0])
