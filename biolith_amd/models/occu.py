@@ -66,7 +66,8 @@ def occu(
 
     Same parameters as the reference (biolith/models/occu.py:19-40).  Supported here: the default
     option path -- linear regressors on both sides, Normal priors, no false positives, no spatial
-    effect, no random effects, one species.  Anything else raises ``NotImplementedError`` (the
+    effect, no random effects; several species are sampled species by species (their joint density
+    factorises over the ``species`` plate, occu.py:182-186).  Anything else raises ``NotImplementedError`` (the
     engine has no silent fallback).  ``coords=None`` / any ``ell`` are accepted and ignored, as the
     reference does when ``coords`` is None (occu.py:159-167); ``simulate()`` returns both.
 
@@ -106,8 +107,6 @@ def occu(
         unsupported.append("random effects (occu.py:170-173)")
     if regressor_occ is not LinearRegression or regressor_det is not LinearRegression:
         unsupported.append("non-linear regressors (occu.py:185-186)")
-    if n_species != 1:
-        unsupported.append(f"n_species={n_species} (occu.py:182)")
     if obs is None:
         unsupported.append("obs=None (prior predictive)")
     if unsupported:

@@ -72,8 +72,6 @@ def occu_rn(
         unsupported.append("random effects (occu_rn.py:151-154)")
     if regressor_abu is not LinearRegression or regressor_det is not LinearRegression:
         unsupported.append("non-linear regressors (occu_rn.py:166-167)")
-    if n_species != 1:
-        unsupported.append(f"n_species={n_species}")
     if obs is None:
         unsupported.append("obs=None (prior predictive)")
     if not 1 <= int(max_abundance) <= MAX_ABUNDANCE_LIMIT:

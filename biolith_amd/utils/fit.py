@@ -75,41 +75,63 @@ def fit(
 
     from ..engine import OccuDataset
 
-    ds = OccuDataset(spec.site_covs, spec.obs_covs, spec.obs, spec.prior_beta, spec.prior_alpha, device=device,
-                     model=spec.model, max_abundance=spec.extras.get("max_abundance", 100))
-    try:
+    # The "species" plate (occu.py:182-186) carries its own beta/alpha per species over shared covariates,
+    # so the joint posterior is a product over species: each species gets its own device dataset and
+    # its own chains (distinct RNG streams); the draws are stacked on the trailing species axis.
+    n_species = spec.obs.shape[0]
+    per_species = []
+    for sp in range(n_species):
+        ds = OccuDataset(spec.site_covs, spec.obs_covs, spec.obs[sp:sp + 1], spec.prior_beta, spec.prior_alpha,
+                         device=device, model=spec.model, max_abundance=spec.extras.get("max_abundance", 100))
         run_kw = dict(num_warmup=num_warmup, num_samples=num_samples, num_chains=num_chains,
-                      seed=random_seed, chain_offset=chain_offset)
+                      seed=random_seed, chain_offset=chain_offset + sp * num_chains)
         if timeout is not None:
             from .misc import time_limit
 
             with time_limit(timeout):
-                res = ds.nuts(timeout=None if timeout is None else float(timeout) + 1.0, **run_kw)
+                res = ds.nuts(timeout=float(timeout) + 1.0, **run_kw)
         else:
             res = ds.nuts(**run_kw)
-        mcmc = _assemble(ds, spec, res, num_warmup)
-    finally:
-        pass  # ds stays alive inside the lazy prob_detection thunk; freed with the FitResult
+        per_species.append((ds, res))
+    mcmc = _assemble(per_species, spec, num_warmup)
     samples = rename_samples(mcmc.get_samples(), site_names, obs_names)
     return FitResult(samples, mcmc)
 
 
-def _assemble(ds, spec, res, num_warmup) -> HipMCMC:
-    """Draws (C, S, D) -> the sample sites the reference's model emits (occu.py:185-228)."""
-    C, S, D = res.draws.shape
-    Ks, Ko = ds.Ks, ds.Ko
-    nsp = 1
+def _assemble(per_species, spec, num_warmup) -> HipMCMC:
+    """Draws (C, S, D) per species -> the sample sites the reference's model emits (occu.py:185-228)."""
+    ds0, res0 = per_species[0]
+    C, S, D = res0.draws.shape
+    Ks, Ko = ds0.Ks, ds0.Ko
+    nsp = len(per_species)
     # plate "species" is the last axis of every site (occu.py:182, dim=-1)
-    beta = res.draws[:, :, : Ks + 1].reshape(C, S, nsp, Ks + 1)
-    alpha = res.draws[:, :, Ks + 1:].reshape(C, S, nsp, Ko + 1)
-    flat = res.draws.reshape(C * S, D)
-    psi, _ = ds.deterministic(flat, psi=True, prob_detection=False) if S else (np.empty((0, ds.T, ds.N), np.float32), None)
-    psi = psi.reshape(C, S, ds.T, ds.N, nsp)
+    beta = np.stack([r.draws[:, :, : Ks + 1] for _, r in per_species], axis=2)     # (C, S, nsp, Ks+1)
+    alpha = np.stack([r.draws[:, :, Ks + 1:] for _, r in per_species], axis=2)     # (C, S, nsp, Ko+1)
+    if S:
+        psi = np.stack([d.deterministic(r.draws.reshape(C * S, D), psi=True, prob_detection=False)[0]
+                        for d, r in per_species], axis=-1)
+    else:
+        psi = np.empty((0, ds0.T, ds0.N, nsp), np.float32)
+    psi = psi.reshape(C, S, ds0.T, ds0.N, nsp)
 
     def prob_detection():
-        _, pd = ds.deterministic(flat, psi=False, prob_detection=True)
-        return pd.reshape(C, S, ds.J, ds.T, ds.N, nsp)
+        pd = np.stack([d.deterministic(r.draws.reshape(C * S, D), psi=False, prob_detection=True)[1]
+                       for d, r in per_species], axis=-1)
+        return pd.reshape(C, S, ds0.J, ds0.T, ds0.N, nsp)
 
+    # one result object for the mcmc shim: extras concatenated over species along the chain axis
+    import copy
+
+    res = copy.copy(res0)
+    if nsp > 1:
+        res.diverging = np.logical_or.reduce([r.diverging for _, r in per_species])
+        res.num_steps = np.sum([r.num_steps for _, r in per_species], axis=0)
+        res.accept_prob = np.mean([r.accept_prob for _, r in per_species], axis=0)
+        res.potential_energy = np.sum([r.potential_energy for _, r in per_species], axis=0)
+        res.n_leapfrog = np.sum([r.n_leapfrog for _, r in per_species], axis=0)
+        res.kernel_ms = float(np.sum([r.kernel_ms for _, r in per_species]))
+        res.inv_mass = np.concatenate([r.inv_mass for _, r in per_species], axis=1)
+    res.draws = np.concatenate([r.draws for _, r in per_species], axis=2) if nsp > 1 else res0.draws
     # occu emits "psi" (occu.py:207); occu_rn emits "abundance" = exp(linear predictor) (occu_rn.py:192)
     first = "abundance" if spec.model == "occu_rn" else "psi"
     return HipMCMC(res, latent=dict(beta=beta, alpha=alpha),

@@ -48,6 +48,19 @@ def test_occu_multi_season():  # occu.py:459-475
     assert np.allclose(results.samples["psi"].mean(), true_params["z"].mean(), atol=0.15)
 
 
+def test_occu_multi_species():  # occu.py:478-492
+    data, _ = simulate(simulate_missing=True, n_species=2, n_sites=30)
+    results = fit(occu, **data, num_chains=1, num_samples=100, num_warmup=100, timeout=600)
+    assert results.samples["psi"].shape[-1] == 2
+    assert results.samples["psi"].shape == (100, 1, 30, 2)
+    assert results.samples["cov_state_0"].shape == (100, 2) and results.samples["prob_detection"].shape == (100, 52, 1, 30, 2)
+    # species are independent given the shared covariates: species 0 alone gives the same draws
+    one = dict(data, obs=data["obs"][:1])
+    r1 = fit(occu, **one, num_chains=1, num_samples=100, num_warmup=100)
+    assert np.array_equal(r1.samples["cov_state_0"][:, 0], results.samples["cov_state_0"][:, 0])
+    assert not np.allclose(results.samples["cov_det_0"][:, 0], results.samples["cov_det_0"][:, 1])
+
+
 def test_fit_is_seeded():
     data, _ = simulate(n_sites=50, random_seed=3)
     a = fit(occu, **data, num_chains=2, num_samples=50, num_warmup=50, random_seed=1)

@@ -72,8 +72,8 @@ def test_occu_validates_like_reference():
                dict(obs_random_effects=True), dict(regressor_occ=AbstractRegression)):
         with pytest.raises(NotImplementedError):
             occu(g["site_covs"], g["obs_covs"], obs=g["obs"], **kw)
-    with pytest.raises(NotImplementedError):
-        occu(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]))
+    two = occu(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]))
+    assert two.n_species == 2 and two.shape["S"] == 2  # the species plate is sampled species by species
     assert occu(g["site_covs"], g["obs_covs"], obs=g["obs"], prior_beta=Normal(0.5, 2.0)).prior_beta == (0.5, 2.0)
 
     class Laplace:
