@@ -87,7 +87,7 @@ def main():
     import torch
 
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":  # the env knob exercises the RCCL path on one GPU
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)

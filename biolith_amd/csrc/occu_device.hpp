@@ -451,6 +451,42 @@ __device__ __forceinline__ void bl_eval_sites_hbm(int ct, const float *__restric
 #define BL_RN_NB 128
 __device__ constexpr float BL_LGAMMA1P[BL_RN_NB] = {0.000000000e+00f, 0.000000000e+00f, 6.931471806e-01f, 1.791759469e+00f, 3.178053830e+00f, 4.787491743e+00f, 6.579251212e+00f, 8.525161361e+00f, 1.060460290e+01f, 1.280182748e+01f, 1.510441257e+01f, 1.750230785e+01f, 1.998721450e+01f, 2.255216385e+01f, 2.519122118e+01f, 2.789927138e+01f, 3.067186011e+01f, 3.350507345e+01f, 3.639544521e+01f, 3.933988419e+01f, 4.233561646e+01f, 4.538013890e+01f, 4.847118135e+01f, 5.160667557e+01f, 5.478472940e+01f, 5.800360522e+01f, 6.126170176e+01f, 6.455753863e+01f, 6.788974314e+01f, 7.125703897e+01f, 7.465823635e+01f, 7.809222355e+01f, 8.155795946e+01f, 8.505446702e+01f, 8.858082754e+01f, 9.213617560e+01f, 9.571969454e+01f, 9.933061245e+01f, 1.029681986e+02f, 1.066317603e+02f, 1.103206397e+02f, 1.140342118e+02f, 1.177718814e+02f, 1.215330815e+02f, 1.253172711e+02f, 1.291239336e+02f, 1.329525750e+02f, 1.368027226e+02f, 1.406739236e+02f, 1.445657439e+02f, 1.484777670e+02f, 1.524095926e+02f, 1.563608363e+02f, 1.603311282e+02f, 1.643201123e+02f, 1.683274454e+02f, 1.723527971e+02f, 1.763958484e+02f, 1.804562914e+02f, 1.845338289e+02f, 1.886281734e+02f, 1.927390473e+02f, 1.968661817e+02f, 2.010093164e+02f, 2.051681995e+02f, 2.093425868e+02f, 2.135322415e+02f, 2.177369341e+02f, 2.219564418e+02f, 2.261905483e+02f, 2.304390436e+02f, 2.347017234e+02f, 2.389783896e+02f, 2.432688490e+02f, 2.475729141e+02f, 2.518904022e+02f, 2.562211356e+02f, 2.605649410e+02f, 2.649216498e+02f, 2.692910977e+02f, 2.736731243e+02f, 2.780675734e+02f, 2.824742927e+02f, 2.868931333e+02f, 2.913239501e+02f, 2.957666014e+02f, 3.002209486e+02f, 3.046868568e+02f, 3.091641936e+02f, 3.136528299e+02f, 3.181526396e+02f, 3.226634991e+02f, 3.271852877e+02f, 3.317178872e+02f, 3.362611820e+02f, 3.408150589e+02f, 3.453794071e+02f, 3.499541180e+02f, 3.545390855e+02f, 3.591342054e+02f, 3.637393756e+02f, 3.683544961e+02f, 3.729794689e+02f, 3.776141979e+02f, 3.822585888e+02f, 3.869125491e+02f, 3.915759882e+02f, 3.962488171e+02f, 4.009309483e+02f, 4.056222962e+02f, 4.103227765e+02f, 4.150323067e+02f, 4.197508056e+02f, 4.244781934e+02f, 4.292143919e+02f, 4.339593240e+02f, 4.387129142e+02f, 4.434750881e+02f, 4.482457727e+02f, 4.530248962e+02f, 4.578123880e+02f, 4.626081785e+02f, 4.674121996e+02f, 4.722243839e+02f, 4.770446655e+02f, 4.818729792e+02f, 4.867092611e+02f, 4.915534482e+02f};
 
+// wave-uniform maximum of a non-negative per-lane integer (inactive lanes count as 0)
+__device__ __forceinline__ int bl_wave_max_u(int x)
+{
+#define BL_MAXSTEP(ctrl, rm) x = max(x, __builtin_amdgcn_update_dpp(0, x, ctrl, rm, 0xF, false));
+    BL_MAXSTEP(0xB1, 0xF) BL_MAXSTEP(0x4E, 0xF) BL_MAXSTEP(0x141, 0xF) BL_MAXSTEP(0x140, 0xF)
+    BL_MAXSTEP(0x142, 0xA) BL_MAXSTEP(0x143, 0xC)
+#undef BL_MAXSTEP
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+// Largest n that can still matter when the best term is at least m_lb:  every term is bounded by the
+// (unnormalised) Poisson part n eta - lgamma(n+1) <= n (eta + 1 - log n)  (Stirling), which is <= -n once
+// n >= e^(eta+2); so beyond max(e^(eta+2), 25 - m_lb) each term is below e^-25 of the maximum.
+__device__ __forceinline__ int bl_rn_cutoff(float eta, float m_lb)
+{
+    const float nc = fmaxf(bl_exp_f(eta + 2.0f), 25.0f - m_lb) + 1.0f;
+    return (int)fminf(nc, 1.0e6f);
+}
+
+// lower bound of max_n (n a - lgamma(n+1)) over 1 <= n <= K: evaluate at the Poisson mode with
+// lgamma(n+1) <= (n + 1/2) ln n - n + 1  (n >= 1)
+__device__ __forceinline__ float bl_rn_mode_lb(float a, float K)
+{
+    const float n1 = fminf(fmaxf(floorf(bl_exp_f(a)), 1.0f), K);
+    return fmaf(n1, a, -(fmaf(n1 + 0.5f, BL_LN2 * __builtin_amdgcn_logf(n1), 1.0f - n1)));
+}
+
+// n = 1 .. min(KB, BL_RN_NB-1), fully unrolled in blocks of 8, each block under a wave-uniform guard:
+// indices into the per-lane table stay static, blocks beyond the cutoff are skipped by a scalar branch.
+#define BL_RN_LOOP_BEGIN(KB)                                                            \
+    _Pragma("unroll") for (int nb_ = 1; nb_ < BL_RN_NB; nb_ += 8)                       \
+        if (nb_ <= (KB)) {                                                              \
+            _Pragma("unroll") for (int n = nb_; n < nb_ + 8; n++)                       \
+                if (n < BL_RN_NB && n <= (KB)) {
+#define BL_RN_LOOP_END }}
+
 template <int KS, int KO, int CT>
 __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, int T, int J, int K,
                                                  const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
@@ -460,7 +496,12 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
     const int pb = bl_period_block(J, KO);
     const float *data = bl_lds_f(BL_OFF_DATA);
     const float LOG_TINY = -87.33654475f;
-    for (int i = ct; i < cnt; i += CT) {
+    // Every lane of a wave stays active through the loop (the cutoffs below are wave-level
+    // reductions): lanes beyond the slice evaluate the last site again and are masked out.
+    for (int i0 = 0; i0 < cnt; i0 += CT) {
+        if (i0 + (ct & ~63) >= cnt) continue; // wave-uniform: this wave has no site in this round
+        const int i = min(i0 + ct, cnt - 1);
+        const float live = (i0 + ct < cnt) ? 1.0f : 0.0f;
         const float *rec = data + (size_t)(i >> 1) * pstride + (i & 1); // element e of this site: rec[2 e]
         float x[KS > 0 ? KS : 1];
         float eta = beta[0];
@@ -469,33 +510,39 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
             x[k] = rec[2 * k];
             eta = fmaf(x[k], beta[k + 1], eta);
         }
-        // renormalised truncated-Poisson prior: max, sum and mean of exp(n eta - lgamma(n+1)), n <= K
+        float ll_s = 0.0f, ga_s[KO + 1];
+#pragma unroll
+        for (int k = 0; k <= KO; k++) ga_s[k] = 0.0f;
+        // renormalised truncated-Poisson prior: max, sum and mean of exp(n eta - lgamma(n+1)), n <= K.
+        // Kl: loose wave-uniform bound (Stirling); one scan over n <= Kl finds the exact maximum mz and
+        // the last n whose term is within e^-25 of a lower bound of it -> Kz.
+        const int Kl = min(K, bl_wave_max_u(bl_rn_cutoff(eta, 0.0f)));
+        const float mz_lb = bl_rn_mode_lb(eta, (float)K);
         float mz = 0.0f; // n = 0 term
-#pragma unroll
-        for (int n = 1; n < BL_RN_NB; n++)
-            if (n <= K) mz = fmaxf(mz, fmaf((float)n, eta, -BL_LGAMMA1P[n]));
+        int nz = 0;
+        BL_RN_LOOP_BEGIN(Kl)
+            const float pn = fmaf((float)n, eta, -BL_LGAMMA1P[n]);
+            mz = fmaxf(mz, pn);
+            nz = (pn >= mz_lb - 25.0f) ? n : nz;
+        BL_RN_LOOP_END
+        const int Kz = min(Kl, bl_wave_max_u(nz));
         float sz = bl_exp_f(-mz), b1 = 0.0f;
-#pragma unroll
-        for (int n = 1; n < BL_RN_NB; n++)
-            if (n <= K) {
-                const float e = bl_exp_f(fmaf((float)n, eta, -BL_LGAMMA1P[n]) - mz);
-                sz += e;
-                b1 = fmaf((float)n, e, b1);
-            }
+        BL_RN_LOOP_BEGIN(Kz)
+            const float e = bl_exp_f(fmaf((float)n, eta, -BL_LGAMMA1P[n]) - mz);
+            sz += e;
+            b1 = fmaf((float)n, e, b1);
+        BL_RN_LOOP_END
         const float rsz = __builtin_amdgcn_rcpf(sz);
         const float log_z = mz + BL_LN2 * __builtin_amdgcn_logf(sz);
         const float en_prior = b1 * rsz;
         float deta = 0.0f;
         for (int t = 0; t < T; t++) {
             const float *pv = rec + 2 * (XQ + t * pb);
-            float LP[BL_RN_NB];
-#pragma unroll
-            for (int n = 0; n < BL_RN_NB; n++) LP[n] = 0.0f;
             float cnon = 0.0f, clr = 0.0f, ndet = 0.0f;
             float Rv[KO + 1];
 #pragma unroll
             for (int k = 0; k <= KO; k++) Rv[k] = 0.0f;
-            // ---- A: visits.  u = c nu;  log sigma(u) = log r (detection) or log q (non-detection) ----
+            // ---- A0: visits, no sum over n yet.  u = c nu;  log sigma(u) = log r (detection) or log q (non-detection) ----
             for (int j = 0; j < J; j++) {
                 float w[KO + 1];
 #pragma unroll
@@ -510,14 +557,6 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
                 if (c > 0.0f) {
                     clr += logsig;
                     ndet += 1.0f;
-                    const float q = sm;
-                    float b = 0.0f;
-#pragma unroll
-                    for (int n = 1; n < BL_RN_NB; n++)
-                        if (n <= K) {
-                            b = fmaf(b, q, 1.0f);
-                            LP[n] += __builtin_amdgcn_logf(b);
-                        }
                 } else if (c < 0.0f) {
                     cnon += logsig;
                     // d/dnu of n log q is -n r: rank-1; dnu * (1, w) = r E[n] * (c, c w)
@@ -525,32 +564,60 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
                     for (int k = 0; k <= KO; k++) Rv[k] = fmaf(sm, w[k], Rv[k]);
                 }
             }
-            // ---- B: sum over n ----
             const float a = eta + cnon;
             const float term0 = ndet * LOG_TINY; // n = 0: detections impossible -> numpyro's clamp tiny
-            float m = term0;
+            // Every term_n is bounded above by the Poisson part p_n = n eta - lgamma(n+1) (all other parts
+            // are <= 0), and the best term is at least m_lb = max(term_0, term_1, term at the mode of
+            // n a - lgamma(n+1), with log b >= 0): keep n up to the last p_n >= m_lb - 25.
+            const float m_lb = fmaxf(fmaxf(term0, a + clr), bl_rn_mode_lb(a, (float)K) + clr);
+            int nw = 1;
+            BL_RN_LOOP_BEGIN(Kl)
+                nw = (fmaf((float)n, eta, -BL_LGAMMA1P[n]) >= m_lb - 25.0f) ? n : nw;
+            BL_RN_LOOP_END
+            const int Kw = min(Kl, bl_wave_max_u(nw));
+            // ---- A1: LP[n] = sum over detection visits of log2 b_n ----
+            float LP[BL_RN_NB];
 #pragma unroll
-            for (int n = 1; n < BL_RN_NB; n++)
-                if (n <= K) {
-                    LP[n] = fmaf((float)n, a, fmaf(BL_LN2, LP[n], clr - BL_LGAMMA1P[n])); // term_n (prior unnormalised)
-                    m = fmaxf(m, LP[n]);
+            for (int n = 0; n < BL_RN_NB; n++) LP[n] = 0.0f;
+            if (ndet > 0.0f) {
+                for (int j = 0; j < J; j++) {
+                    float w[KO + 1];
+#pragma unroll
+                    for (int k = 0; k <= KO; k++) w[k] = pv[2 * (j * (KO + 1) + k)];
+                    if (w[0] > 0.0f) {
+                        float u = w[0] * alpha[0];
+#pragma unroll
+                        for (int k = 1; k <= KO; k++) u = fmaf(w[k], alpha[k], u);
+                        const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E);
+                        const float q = (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(1.0f + e);
+                        float b = 0.0f;
+                        BL_RN_LOOP_BEGIN(Kw)
+                            b = fmaf(b, q, 1.0f);
+                            LP[n] += __builtin_amdgcn_logf(b);
+                        BL_RN_LOOP_END
+                    }
                 }
+            }
+            // ---- B: sum over n ----
+            float m = term0;
+            BL_RN_LOOP_BEGIN(Kw)
+                LP[n] = fmaf((float)n, a, fmaf(BL_LN2, LP[n], clr - BL_LGAMMA1P[n])); // term_n (prior unnormalised)
+                m = fmaxf(m, LP[n]);
+            BL_RN_LOOP_END
             const float t0 = bl_exp_f(term0 - m);
             float s = t0, a1 = 0.0f;
-#pragma unroll
-            for (int n = 1; n < BL_RN_NB; n++)
-                if (n <= K) {
-                    const float wn = bl_exp_f(LP[n] - m);
-                    LP[n] = wn; // unnormalised posterior weight of N = n
-                    s += wn;
-                    a1 = fmaf((float)n, wn, a1);
-                }
+            BL_RN_LOOP_BEGIN(Kw)
+                const float wn = bl_exp_f(LP[n] - m);
+                LP[n] = wn; // unnormalised posterior weight of N = n
+                s += wn;
+                a1 = fmaf((float)n, wn, a1);
+            BL_RN_LOOP_END
             const float rs = __builtin_amdgcn_rcpf(s);
-            ll += m + BL_LN2 * __builtin_amdgcn_logf(s) - log_z;
+            ll_s += m + BL_LN2 * __builtin_amdgcn_logf(s) - log_z;
             const float en_post = a1 * rs;
             deta += en_post - en_prior;
 #pragma unroll
-            for (int k = 0; k <= KO; k++) ga[k] = fmaf(en_post, Rv[k], ga[k]);
+            for (int k = 0; k <= KO; k++) ga_s[k] = fmaf(en_post, Rv[k], ga_s[k]);
             // ---- C: detection visits' d/dnu = sum_n w_n (q - q r b'_n / b_n),  b'_n = b'_(n-1) q + b_(n-1) ----
             if (ndet > 0.0f) {
                 for (int j = 0; j < J; j++) {
@@ -565,20 +632,22 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
                         const float rop = __builtin_amdgcn_rcpf(op);
                         const float q = (u > 0.0f ? e : 1.0f) * rop, r = (u > 0.0f ? 1.0f : e) * rop;
                         float b = 0.0f, bp = 0.0f, h = 0.0f;
-#pragma unroll
-                        for (int n = 1; n < BL_RN_NB; n++)
-                            if (n <= K) {
-                                bp = fmaf(bp, q, b);
-                                b = fmaf(b, q, 1.0f);
-                                h = fmaf(LP[n] * bp, __builtin_amdgcn_rcpf(b), h);
-                            }
+                        BL_RN_LOOP_BEGIN(Kw)
+                            bp = fmaf(bp, q, b);
+                            b = fmaf(b, q, 1.0f);
+                            h = fmaf(LP[n] * bp, __builtin_amdgcn_rcpf(b), h);
+                        BL_RN_LOOP_END
                         const float dnu = q * ((s - t0) - r * h) * rs;
 #pragma unroll
-                        for (int k = 0; k <= KO; k++) ga[k] = fmaf(dnu, w[k], ga[k]);
+                        for (int k = 0; k <= KO; k++) ga_s[k] = fmaf(dnu, w[k], ga_s[k]);
                     }
                 }
             }
         }
+        deta *= live;
+        ll = fmaf(live, ll_s, ll);
+#pragma unroll
+        for (int k = 0; k <= KO; k++) ga[k] = fmaf(live, ga_s[k], ga[k]);
         gb[0] += deta;
 #pragma unroll
         for (int k = 0; k < KS; k++) gb[k + 1] = fmaf(deta, x[k], gb[k + 1]);
