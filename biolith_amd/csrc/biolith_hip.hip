@@ -196,6 +196,118 @@ extern "C" int bl_device_count(int *count)
     return BL_OK;
 }
 
+// ------------------------------------------------------------------ posterior predictive ----
+// One generator per (draw, period, site): xoshiro128++ keyed by splitmix64 of the flat index, so the
+// sample does not depend on the launch geometry or on how the draws are chunked.
+__device__ inline unsigned long long bl_splitmix(unsigned long long &x)
+{
+    unsigned long long z = (x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+struct BlPredRng {
+    unsigned s0, s1, s2, s3;
+    __device__ BlPredRng(unsigned long long seed, unsigned long long index)
+    {
+        unsigned long long x = seed ^ (index * 0xD1342543DE82EF95ull);
+        const unsigned long long a = bl_splitmix(x), b = bl_splitmix(x);
+        s0 = (unsigned)a; s1 = (unsigned)(a >> 32); s2 = (unsigned)b; s3 = (unsigned)(b >> 32) | 1u;
+    }
+    __device__ float uniform() // [0, 1)
+    {
+        const unsigned r0 = s0 + s3, r = ((r0 << 7) | (r0 >> 25)) + s0, t = s1 << 9;
+        s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t; s3 = (s3 << 11) | (s3 >> 21);
+        return (float)(r >> 8) * 5.9604644775390625e-08f;
+    }
+};
+// occu (occu.py:207-241 with obs=None):  z ~ Bernoulli(psi),  y_j ~ Bernoulli(z * p_j)
+// occu_rn (occu_rn.py:192-221):          N ~ Categorical(Poisson(lambda) pmf on 0..K),  y_j ~ Bernoulli(1 - (1 - r_j)^N)
+__global__ void bl_predict_kernel(const float *__restrict__ rows, const float *__restrict__ wraw, int n_stride, int N, int T, int J,
+                                  int Ks, int Ko, int D, const float *__restrict__ draws, int n0, int n1,
+                                  unsigned long long seed, int model, int max_abundance,
+                                  unsigned char *__restrict__ latent, unsigned char *__restrict__ y)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float x[BL_MAX_COVS];
+    for (int k = 0; k < Ks; k++) x[k] = rows[(size_t)k * n_stride + i];
+    for (int n = n0 + blockIdx.y; n < n1; n += gridDim.y) {
+        const float *th = draws + (size_t)n * D;
+        const float *al = th + Ks + 1;
+        float eta = th[0];
+        for (int k = 0; k < Ks; k++) eta = fmaf(x[k], th[k + 1], eta);
+        for (int t = 0; t < T; t++) {
+            BlPredRng rng(seed, ((unsigned long long)n * T + t) * N + i);
+            int zn;
+            if (model == 1) {
+                // inversion over the (renormalised) truncated Poisson pmf, float64 recursion p_n = p_{n-1} lambda / n
+                const double lam = exp((double)eta);
+                double p = exp(-lam), tot = 0.0;
+                for (int m = 0; m <= max_abundance; m++) { tot += p; p *= lam / (double)(m + 1); }
+                const double target = (double)rng.uniform() * tot;
+                p = exp(-lam);
+                double cum = 0.0;
+                zn = max_abundance;
+                for (int m = 0; m <= max_abundance; m++) {
+                    cum += p;
+                    if (target < cum) { zn = m; break; }
+                    p *= lam / (double)(m + 1);
+                }
+            } else {
+                const float psi = 1.0f / (1.0f + __expf(-eta));
+                zn = rng.uniform() < psi ? 1 : 0;
+            }
+            if (latent) latent[((size_t)(n - n0) * T + t) * N + i] = (unsigned char)zn;
+            if (!y) continue;
+            for (int j = 0; j < J; j++) {
+                const int v = t * J + j;
+                float nu = al[0];
+                for (int k = 0; k < Ko; k++) nu = fmaf(wraw[((size_t)v * Ko + k) * n_stride + i], al[k + 1], nu);
+                const float r = 1.0f / (1.0f + __expf(-nu));
+                const float pd = model == 1 ? 1.0f - __powf(1.0f - r, (float)zn) : (float)zn * r;
+                const float u = rng.uniform();
+                y[(((size_t)(n - n0) * J + j) * T + t) * N + i] = (zn > 0 && u < pd) ? 1 : 0;
+            }
+        }
+    }
+}
+
+extern "C" int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint64_t seed, uint8_t *latent, uint8_t *y)
+{
+    if (!ds || !draws || n_draws <= 0 || (!latent && !y)) return bl_fail(BL_ERR_INVALID, "bl_predict: bad argument");
+    if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
+    int rc = set_device(ds);
+    if (rc) return rc;
+    const int N = ds->dims.n_sites, T = ds->dims.n_periods, J = ds->dims.n_replicates, D = ds->D;
+    float *d_draws = nullptr;
+    unsigned char *d_lat = nullptr, *d_y = nullptr;
+    struct Guard { float *&a; unsigned char *&b; unsigned char *&c; ~Guard() { hipFree(a); hipFree(b); hipFree(c); } } guard{d_draws, d_lat, d_y};
+    BL_HIP(hipMalloc((void **)&d_draws, (size_t)n_draws * D * 4));
+    BL_HIP(hipMemcpy(d_draws, draws, (size_t)n_draws * D * 4, hipMemcpyHostToDevice));
+    const size_t per_draw = (size_t)T * N * (y ? (size_t)J : 1); // bytes of the larger output
+    int chunk = (int)((256u << 20) / (per_draw ? per_draw : 1));
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_draws) chunk = n_draws;
+    if (latent) BL_HIP(hipMalloc((void **)&d_lat, (size_t)chunk * T * N));
+    if (y) BL_HIP(hipMalloc((void **)&d_y, (size_t)chunk * J * T * N));
+    if (!ds->d_wraw) {
+        BL_HIP(hipMalloc((void **)&ds->d_wraw, ds->h_wraw.size() * 4));
+        BL_HIP(hipMemcpy(ds->d_wraw, ds->h_wraw.data(), ds->h_wraw.size() * 4, hipMemcpyHostToDevice));
+    }
+    const dim3 block(256);
+    for (int n0 = 0; n0 < n_draws; n0 += chunk) {
+        const int n1 = (n0 + chunk < n_draws) ? n0 + chunk : n_draws;
+        const dim3 grid((N + 255) / 256, (n1 - n0) < 1024 ? (n1 - n0) : 1024);
+        hipLaunchKernelGGL(bl_predict_kernel, grid, block, 0, nullptr, ds->d_rows, ds->d_wraw, ds->n_stride, N, T, J, ds->Ks, ds->Ko, D,
+                           d_draws, n0, n1, (unsigned long long)seed, ds->model, ds->max_abundance, d_lat, d_y);
+        BL_HIP(hipGetLastError());
+        if (latent) BL_HIP(hipMemcpy(latent + (size_t)n0 * T * N, d_lat, (size_t)(n1 - n0) * T * N, hipMemcpyDeviceToHost));
+        if (y) BL_HIP(hipMemcpy(y + (size_t)n0 * J * T * N, d_y, (size_t)(n1 - n0) * J * T * N, hipMemcpyDeviceToHost));
+    }
+    return BL_OK;
+}
+
 extern "C" int bl_rng_streams(uint64_t seed, int chain, int nstreams, uint32_t *out)
 {
     if (!out || chain < 0 || nstreams < 0) return bl_fail(BL_ERR_INVALID, "bl_rng_streams: bad argument");

@@ -217,6 +217,20 @@ class OccuDataset:
         return out_psi, out_pd
 
 
+    def predictive(self, draws, seed: int = 0, latent: bool = True, y: bool = True):
+        """Posterior predictive draws of the discrete sites for draws (n, D): the latent state
+        (``z`` for occu, ``N_i`` for occu_rn) as (n, T, N) uint8 and ``y`` as (n, J, T, N) uint8
+        (biolith/utils/predict.py:66-92; occu.py:208-241; occu_rn.py:194-221)."""
+        d = np.ascontiguousarray(draws, dtype=np.float32).reshape(-1, self.D)
+        n = d.shape[0]
+        out_l = np.empty((n, self.T, self.N), dtype=np.uint8) if latent else None
+        out_y = np.empty((n, self.J, self.T, self.N), dtype=np.uint8) if y else None
+        if n:
+            u8 = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint8))
+            _ffi.check(self._lib.bl_predict(self._h, n, _fp(d), C.c_uint64(int(seed) & (2 ** 64 - 1)), u8(out_l), u8(out_y)))
+        return out_l, out_y
+
+
 def rng_streams(seed: int, chain: int, nstreams: int = _ffi.RNG_STREAMS_PER_CHAIN) -> np.ndarray:
     out = np.zeros((nstreams, 4), dtype=np.uint32)
     _ffi.check(_ffi.load().bl_rng_streams(int(seed), int(chain), int(nstreams),

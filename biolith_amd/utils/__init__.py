@@ -1,3 +1,4 @@
 from .fit import FitResult, fit
+from .predict import predict
 
-__all__ = ["fit", "FitResult"]
+__all__ = ["fit", "FitResult", "predict"]

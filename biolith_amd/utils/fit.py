@@ -7,6 +7,7 @@ calls ``mcmc.run`` (fit.py:92-130), this lowers the model onto the C-ABI in
 """
 from __future__ import annotations
 
+import time
 from collections import namedtuple
 from typing import Callable, Optional
 
@@ -40,8 +41,10 @@ def fit(
     Parameters are those of the reference ``fit`` (fit.py:33-66).  ``model_fn`` must be
     :func:`biolith_amd.models.occu` or :func:`biolith_amd.models.occu_rn`.  ``kernel`` must be ``None`` or ``"nuts"``; ``init_strategy``
     must be ``None`` (= ``init_to_uniform``, fit.py:93).  Extra keyword arguments go to the model,
-    plus two engine knobs that the reference does not have: ``device`` (GPU index, default 0) and
-    ``chain_offset`` (global id of the first chain, for sharding chains over processes).
+    plus engine knobs that the reference does not have: ``device`` (GPU index, default 0), ``devices``
+    (list of GPU indices: the chains are dealt over them in contiguous blocks and sampled concurrently,
+    the in-process counterpart of ``chain_method="parallel"``, fit.py:109-113) and ``chain_offset``
+    (global id of the first chain, for sharding chains over processes).
 
     Returns
     -------
@@ -64,6 +67,10 @@ def fit(
     if init_strategy is not None:
         raise NotImplementedError("init_strategy: only the default init_to_uniform (fit.py:93) is built")
     device = int(kwargs.pop("device", 0))
+    devices = kwargs.pop("devices", None)
+    devices = [device] if devices is None else [int(d) for d in devices]
+    if not devices:
+        raise ValueError("devices must name at least one GPU")
     chain_offset = int(kwargs.pop("chain_offset", 0))
 
     site_covs, obs_covs, obs, session_duration, site_names, obs_names = prepare_data(
@@ -73,29 +80,80 @@ def fit(
     valid = {k: v for k, v in arguments.items() if v is not None}
     spec = model_fn(**valid, **kwargs)
 
+    from ..distributed import shard_chains
     from ..engine import OccuDataset
 
     # The "species" plate (occu.py:182-186) carries its own beta/alpha per species over shared covariates,
     # so the joint posterior is a product over species: each species gets its own device dataset and
     # its own chains (distinct RNG streams); the draws are stacked on the trailing species axis.
     n_species = spec.obs.shape[0]
+    # chain_method="parallel" (fit.py:109-113) deals chains over the local devices; here ``devices``
+    # names the GPUs, chains go to them in contiguous blocks, every shard is an asynchronous launch and
+    # the draws are concatenated on the chain axis afterwards (no exchange while sampling).
+    world = len(devices)
+    jobs = []
+    for sp in range(n_species):
+        for r, dev in enumerate(devices):
+            count, first = shard_chains(num_chains, world, r)
+            if count == 0:
+                continue
+            ds = OccuDataset(spec.site_covs, spec.obs_covs, spec.obs[sp:sp + 1], spec.prior_beta, spec.prior_alpha,
+                             device=dev, model=spec.model, max_abundance=spec.extras.get("max_abundance", 100))
+            jobs.append((sp, ds, dict(num_warmup=num_warmup, num_samples=num_samples, num_chains=count,
+                                      seed=random_seed, chain_offset=chain_offset + sp * num_chains + first)))
+
+    def run_all():
+        t_end = None if timeout is None else time.monotonic() + float(timeout) + 1.0
+        launched = []
+        try:
+            for _, ds, kw in jobs:   # launches on one device queue behind each other, devices overlap
+                ds.launch(**kw)
+                launched.append(ds)
+            for ds in launched:
+                while t_end is not None and not ds.done():
+                    if time.monotonic() > t_end:
+                        raise TimeoutError("Timed out")
+                    time.sleep(0.0005)
+                ds.wait()
+        except BaseException:
+            for ds in launched:      # reference-style SIGALRM TimeoutException, Ctrl-C or an engine error
+                ds.abort()
+            for ds in launched:
+                try:
+                    ds.wait()
+                except Exception:
+                    pass
+            raise
+        return [ds.fetch() for _, ds, _ in jobs]
+
+    if timeout is not None:
+        from .misc import time_limit
+
+        with time_limit(timeout):
+            results = run_all()
+    else:
+        results = run_all()
     per_species = []
     for sp in range(n_species):
-        ds = OccuDataset(spec.site_covs, spec.obs_covs, spec.obs[sp:sp + 1], spec.prior_beta, spec.prior_alpha,
-                         device=device, model=spec.model, max_abundance=spec.extras.get("max_abundance", 100))
-        run_kw = dict(num_warmup=num_warmup, num_samples=num_samples, num_chains=num_chains,
-                      seed=random_seed, chain_offset=chain_offset + sp * num_chains)
-        if timeout is not None:
-            from .misc import time_limit
-
-            with time_limit(timeout):
-                res = ds.nuts(timeout=float(timeout) + 1.0, **run_kw)
-        else:
-            res = ds.nuts(**run_kw)
-        per_species.append((ds, res))
+        shard = [(ds, res) for (s, ds, _), res in zip(jobs, results) if s == sp]
+        per_species.append((shard[0][0], _concat_chains([r for _, r in shard])))
     mcmc = _assemble(per_species, spec, num_warmup)
     samples = rename_samples(mcmc.get_samples(), site_names, obs_names)
     return FitResult(samples, mcmc)
+
+
+def _concat_chains(parts):
+    """Shards of one species' chains (one NutsResult per device) -> one NutsResult, chain axis first."""
+    if len(parts) == 1:
+        return parts[0]
+    import copy
+
+    res = copy.copy(parts[0])
+    for name in ("draws", "diverging", "num_steps", "accept_prob", "potential_energy", "step_size", "inv_mass", "n_leapfrog"):
+        setattr(res, name, np.concatenate([getattr(r, name) for r in parts], axis=0))
+    res.kernel_ms = float(max(r.kernel_ms for r in parts))   # shards on different devices overlap
+    res.chains_l2_local = int(sum(r.chains_l2_local for r in parts))
+    return res
 
 
 def _assemble(per_species, spec, num_warmup) -> HipMCMC:

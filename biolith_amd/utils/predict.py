@@ -1,0 +1,120 @@
+"""``predict`` -- drop-in for biolith/utils/predict.py:9-94 on the HIP engine.
+
+The reference wraps the model in ``numpyro.infer.Predictive(model_fn, posterior_samples=mcmc.get_samples())``
+and calls it on the (possibly new) covariates with ``obs`` withheld (predict.py:66-85), which
+recomputes the deterministic sites for every posterior draw and samples the discrete sites.  Here the
+same sites come from two C-ABI calls per species -- ``bl_deterministic`` and ``bl_predict``
+(``include/biolith_hip.h``) -- on a device-resident copy of the covariates.  No NumPyro/JAX, no CPU fallback.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Callable, Optional
+
+import numpy as np
+
+from .data import prepare_data, rename_samples
+from .mcmc import LazySamples
+
+
+def predict(
+    model_fn: Callable,
+    mcmc,
+    site_covs=None,
+    obs_covs=None,
+    obs=None,
+    session_duration=None,
+    num_samples: int = 1000,
+    random_seed: int = 0,
+    infer_discrete: bool = False,
+    timeout: Optional[int] = None,
+    **kwargs,
+) -> dict:
+    """Posterior predictive samples from a fitted model.
+
+    Parameters are those of the reference ``predict`` (predict.py:9-62).  ``mcmc`` is the
+    ``FitResult.mcmc`` that :func:`biolith_amd.utils.fit` returned; ``obs`` is accepted and ignored, as
+    the reference drops it before calling the model (predict.py:78-80).  As with ``Predictive``, one
+    predictive draw is made per posterior draw, so ``num_samples`` only triggers NumPyro's warning when
+    it differs from the number of posterior draws.  ``infer_discrete=True`` is not built.
+
+    Returns
+    -------
+    dict
+        occu: ``psi`` (n, T, N, S), ``z`` (n, T, N, S) int32, ``prob_detection`` / ``prob_detection_fp``
+        (n, J, T, N, S), ``y`` (n, J, T, N, S) int32 -- the sites of occu.py:207-241.
+        occu_rn: ``abundance``, ``N_i``, ``prob_detection``, ``y`` (occu_rn.py:192-221).
+        The three replicate-level arrays are materialised on first access.
+
+    Examples
+    --------
+    >>> from biolith_amd.models import simulate, occu
+    >>> from biolith_amd.utils import fit, predict
+    >>> data, _ = simulate()
+    >>> results = fit(occu, **data, num_samples=10, num_warmup=10, num_chains=1)
+    >>> preds = predict(occu, results.mcmc, **data, num_samples=5)
+    """
+    if not callable(model_fn) or getattr(model_fn, "__biolith_amd_model__", None) is None:
+        raise TypeError("predict(): model_fn must be a biolith_amd model (biolith_amd.models.occu / occu_rn)")
+    if infer_discrete:
+        raise NotImplementedError("infer_discrete=True (predict.py:70) is not built on the HIP engine")
+    device = int(kwargs.pop("device", 0))
+
+    site_covs, obs_covs, obs, session_duration, site_names, obs_names = prepare_data(
+        site_covs, obs_covs, obs, session_duration
+    )
+    posterior = mcmc.get_samples()
+    beta = np.asarray(posterior["beta"], dtype=np.float32)    # (n, S, Ks+1)
+    alpha = np.asarray(posterior["alpha"], dtype=np.float32)  # (n, S, Ko+1)
+    n, n_species = beta.shape[0], beta.shape[1]
+    if num_samples is not None and num_samples != n:
+        warnings.warn(f"Sample's batch dimension size {n} is different from the provided {num_samples} "
+                      f"num_samples argument. Defaulting to {n}.", UserWarning, stacklevel=2)
+
+    # the model is called without obs (predict.py:78-80); the validators want the species count, so an
+    # all-missing observation array of the fitted species count stands in for it
+    arguments = dict(site_covs=site_covs, obs_covs=obs_covs, session_duration=session_duration)
+    valid = {k: v for k, v in arguments.items() if v is not None}
+    blank = np.full((n_species,) + np.shape(obs_covs)[:3], np.nan, dtype=np.float32)
+    spec = model_fn(**valid, obs=blank, **kwargs)
+    if beta.shape[2] != spec.site_covs.shape[1] + 1 or alpha.shape[2] != spec.obs_covs.shape[3] + 1:
+        raise ValueError("predict(): covariate counts differ from the fitted model's coefficients")
+
+    from ..engine import OccuDataset
+
+    def run():
+        handles, first, latent, y8 = [], [], [], []
+        for sp in range(n_species):
+            ds = OccuDataset(spec.site_covs, spec.obs_covs, spec.obs[sp:sp + 1], spec.prior_beta, spec.prior_alpha,
+                             device=device, model=spec.model, max_abundance=spec.extras.get("max_abundance", 100))
+            draws = np.concatenate([beta[:, sp, :], alpha[:, sp, :]], axis=1)
+            first.append(ds.deterministic(draws, psi=True, prob_detection=False)[0])
+            lat, yy = ds.predictive(draws, seed=(int(random_seed) + (sp << 32)) & (2 ** 64 - 1))
+            latent.append(lat)
+            y8.append(yy)
+            handles.append((ds, draws))
+        return handles, first, latent, y8
+
+    if timeout is not None:
+        from .misc import time_limit
+
+        with time_limit(timeout):
+            handles, first, latent, y8 = run()
+    else:
+        handles, first, latent, y8 = run()
+
+    rn = spec.model == "occu_rn"
+    out = LazySamples()
+    out["abundance" if rn else "psi"] = np.stack(first, axis=-1)                      # (n, T, N, S)
+    out["N_i" if rn else "z"] = np.stack(latent, axis=-1).astype(np.int32)            # (n, T, N, S)
+
+    def prob_detection():
+        return np.stack([d.deterministic(dr, psi=False, prob_detection=True)[1] for d, dr in handles], axis=-1)
+
+    out.set_lazy("prob_detection", prob_detection)                                    # (n, J, T, N, S)
+    if not rn:
+        # occu.py:229-235 with prob_fp_constant = prob_fp_unoccupied = 0:  1 - (1 - z p) = z p
+        out.set_lazy("prob_detection_fp",
+                     lambda: prob_detection() * np.stack(latent, axis=-1)[:, None].astype(np.float32))
+    out.set_lazy("y", lambda: np.stack(y8, axis=-1).astype(np.int32))                 # (n, J, T, N, S)
+    return rename_samples(out, site_names, obs_names)

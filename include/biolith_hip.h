@@ -149,6 +149,19 @@ int bl_nuts_debug_counters(bl_dataset *ds, int64_t *out /*[n<=16]*/, int n);
  */
 int bl_deterministic(bl_dataset *ds, int n_draws, const float *draws, float *psi, float *prob_detection);
 
+/*
+ * Posterior predictive draws of the discrete sites, one per posterior draw -- what
+ * numpyro.infer.Predictive(model_fn, posterior_samples)(key, site_covs, obs_covs) samples in
+ * biolith/utils/predict.py:66-92 (obs withheld, so no observation is masked):
+ *   occu     latent = z   [n_draws][T][N]  ~ Bernoulli(psi)                         (occu.py:208-210)
+ *            y            [n_draws][J][T][N] ~ Bernoulli(z * prob_detection)        (occu.py:229-241)
+ *   occu_rn  latent = N_i [n_draws][T][N]  ~ truncated Poisson(abundance) on 0..max_abundance (occu_rn.py:194-198)
+ *            y            ~ Bernoulli(1 - (1 - prob_detection)^N_i)                 (occu_rn.py:211-221)
+ * uint8 on the host (NULL = skip).  The sample is a function of (seed, draw, period, site) only; it is
+ * distributionally, not bitwise, the reference's (JAX threefry keys are not reproduced).
+ */
+int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint64_t seed, uint8_t *latent, uint8_t *y);
+
 /* The engine's xoshiro128++ streams (host-side; no GPU needed): out[nstreams][4]. */
 int bl_rng_streams(uint64_t seed, int chain, int nstreams, uint32_t *out);
 /* numpyro build_adaptation_schedule restatement used by the kernel: returns window count. */

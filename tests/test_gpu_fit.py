@@ -84,3 +84,22 @@ def test_timeout_raises_like_reference():  # fit.py:124-128 -> misc.py:11-21
     with pytest.raises((TimeoutException, TimeoutError)):
         fit(occu, **data, num_chains=4, num_samples=500000, num_warmup=500000, timeout=1)
     assert time.time() - t0 < 10
+
+
+def test_chains_dealt_over_devices_reproduce_the_single_launch():  # fit.py:109-113 chain_method="parallel"
+    # the same GPU named twice stands in for two GPUs: chains 0-1 and 2-3 run as two launches, and each
+    # chain's RNG streams depend on its global id only, so the draws equal those of one 4-chain launch
+    # (the workgroup count per chain is pinned by the data size, not the chain count)
+    data, _ = simulate(n_sites=300, n_site_covs=2, n_obs_covs=2, deployment_days_per_site=35, random_seed=2)
+    kw = dict(num_chains=4, num_samples=60, num_warmup=60, random_seed=9)
+    one = fit(occu, **data, **kw)
+    two = fit(occu, **data, **kw, devices=[0, 0])
+    three = fit(occu, **data, **kw, devices=[0, 0, 0])  # ragged deal: 2 + 1 + 1
+    assert set(one.samples) == set(two.samples) == set(three.samples)
+    for k in one.samples:
+        assert np.array_equal(one.samples[k], two.samples[k]), k
+        assert np.array_equal(one.samples[k], three.samples[k]), k
+    assert np.array_equal(one.mcmc.get_extra_fields()["diverging"], two.mcmc.get_extra_fields()["diverging"])
+    assert two.mcmc.num_chains == 4
+    with pytest.raises(ValueError):
+        fit(occu, **data, **kw, devices=[])
