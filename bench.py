@@ -27,7 +27,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CFG2 = dict(n_sites=10000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=35, session_duration=7, random_seed=0)
-CHAINS_PER_GPU, NUM_WARMUP, NUM_SAMPLES = 4, 1000, 1000
+CFG4 = dict(n_sites=5000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7, random_seed=0)
+CHAINS_PER_GPU = 4
+# --workload: "occu" is the headline (BASELINE.json configs[1], what the driver runs); "occu_rn" is the
+# secondary line for configs[3] (same JSON shape, metric on `abundance`), run by hand for profiles/.
+WORKLOADS = {
+    "occu": dict(model="occu", cfg=CFG2, num_warmup=1000, num_samples=1000, cpu_sample=(250, 250), site="psi",
+                 metric="effective samples/sec (psi) for occu NUTS, 10k sites x 5 visits",
+                 text="biolith simulate(n_sites=10000, n_site_covs=3, n_obs_covs=3, 5 visits, seed 0); fit(occu)"),
+    "occu_rn": dict(model="occu_rn", cfg=CFG4, num_warmup=500, num_samples=500, cpu_sample=(40, 40), site="abundance",
+                    metric="effective samples/sec (abundance) for occu_rn NUTS, 5k sites x 10 visits",
+                    text="biolith simulate_rn(n_sites=5000, n_site_covs=3, n_obs_covs=3, 10 visits, seed 0); "
+                         "fit(occu_rn, max_abundance=100)"),
+}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -36,11 +48,12 @@ def algorithmic_bytes_per_eval(N, T, J, Ks, Ko, S=1):
     return 4 * (N * Ks + N * T * J * Ko + S * N * T * J)
 
 
-def psi_draws(draws, X):
-    """draws (C, S, D) -> psi (C, S, N) float32 = sigmoid(beta0 + X beta)  (occu.py:198-207)."""
+def psi_draws(draws, X, site="psi"):
+    """draws (C, S, D) -> psi (C, S, N) float32 = sigmoid(beta0 + X beta)  (occu.py:198-207), or
+    abundance = exp(beta0 + X beta) for occu_rn (occu_rn.py:192)."""
     Ks = X.shape[1]
     eta = draws[..., :1] + draws[..., 1:Ks + 1] @ X.T
-    return (1.0 / (1.0 + np.exp(-eta))).astype(np.float32)
+    return (np.exp(eta) if site == "abundance" else 1.0 / (1.0 + np.exp(-eta))).astype(np.float32)
 
 
 class _DevArray:
@@ -50,23 +63,23 @@ class _DevArray:
         self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr="<f4", data=(int(ptr), False), version=2)
 
 
-def cpu_baseline(data, threads):
+def cpu_baseline(data, threads, wl):
     """Oracle (port of the same algorithm, float64 C) on host cores, bounded sample of the workload."""
     import oracle
     from biolith_amd.evaluation import effective_sample_size
 
-    od = oracle.OracleData(data["site_covs"], data["obs_covs"], data["obs"])
-    w, s = 250, 250
+    od = oracle.OracleData(data["site_covs"], data["obs_covs"], data["obs"], model=wl["model"])
+    w, s = wl["cpu_sample"]
     t0 = time.perf_counter()
     r = oracle.nuts_run(od, w, s, num_chains=CHAINS_PER_GPU, seed=0, threads=threads)
     wall = time.perf_counter() - t0
     X = np.asarray(data["site_covs"], dtype=np.float32).astype(np.float64)
-    ess = float(effective_sample_size(psi_draws(r["draws"], X)).mean())
+    ess = float(effective_sample_size(psi_draws(r["draws"], X, wl["site"])).mean())
     nleap = int(r["n_leapfrog"].sum())
     return dict(value=ess / wall, unit="ESS/s", cores=int(r["threads"]), kind="port",
                 sample=f"oracle NUTS (float64 C restatement), same data, {CHAINS_PER_GPU} chains x ({w} warmup + {s} draws) "
                        f"on {int(r['threads'])} threads: {wall:.1f} s, {nleap} gradient evaluations, "
-                       f"{1e3 * wall * int(r['threads']) / nleap:.2f} ms per evaluation per core, ESS(psi) {ess:.0f}")
+                       f"{1e3 * wall * int(r['threads']) / nleap:.2f} ms per evaluation per core, ESS({wl['site']}) {ess:.0f}")
 
 
 def main():
@@ -75,8 +88,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", action="store_true",
+                    help="occu_rn only: also time the oracle (about 9 minutes on 4 cores; off by default)")
     ap.add_argument("--wgs-per-chain", type=int, default=0)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="occu")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    NUM_WARMUP, NUM_SAMPLES = wl["num_warmup"], wl["num_samples"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -98,12 +116,13 @@ def main():
     from biolith_amd.distributed import gather_draws
     from biolith_amd.engine import OccuDataset
     from biolith_amd.evaluation import effective_sample_size, split_gelman_rubin
-    from biolith_amd.models import simulate
+    from biolith_amd.models import simulate, simulate_rn
 
     with contextlib.redirect_stdout(io.StringIO()):
-        data, truth = simulate(**CFG2)
+        data, truth = (simulate_rn if wl["model"] == "occu_rn" else simulate)(**wl["cfg"])
     X = np.asarray(data["site_covs"], dtype=np.float32).astype(np.float64)
-    ds = OccuDataset(data["site_covs"], data["obs_covs"], data["obs"], device=local_rank)  # resident in HBM from here on
+    ds = OccuDataset(data["site_covs"], data["obs_covs"], data["obs"], device=local_rank,
+                     model=wl["model"])  # resident in HBM from here on
     stream = torch.cuda.current_stream().cuda_stream
 
     def sync_all():
@@ -150,7 +169,7 @@ def main():
         # ---- metric numerator: ESS(psi), NumPyro estimator, mean over sites (diagnostics.py:28-32) ----
         ess_psi, ess_coef, rhat = [], [], []
         for _, d in steps:
-            ess_psi.append(float(effective_sample_size(psi_draws(d.astype(np.float64), X)).mean()))
+            ess_psi.append(float(effective_sample_size(psi_draws(d.astype(np.float64), X, wl["site"])).mean()))
             ess_coef.append(effective_sample_size(d).min())
             rhat.append(float(split_gelman_rubin(d).max()))
         total_ess = float(np.sum(ess_psi))
@@ -160,11 +179,11 @@ def main():
         achieved = leap_mean * bytes_eval / (kernel_ms_mean * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload == "occu":  # the PMC passes were taken on the headline workload
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         out = {
-            "metric": "effective samples/sec (psi) for occu NUTS, 10k sites x 5 visits",
+            "metric": wl["metric"],
             "value": total_ess / elapsed,
             "unit": "ESS/s",
             "n_gpus": world,
@@ -177,27 +196,28 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "biolith simulate(n_sites=10000, n_site_covs=3, n_obs_covs=3, 5 visits, seed 0); "
-                            "fit(occu): NUTS 4 chains per GPU x (1000 warmup + 1000 draws), one step = one full fit",
+                "workload": f"{wl['text']}: NUTS {CHAINS_PER_GPU} chains per GPU x ({NUM_WARMUP} warmup + {NUM_SAMPLES} draws), "
+                            "one step = one full fit",
                 "chains_per_gpu": CHAINS_PER_GPU, "total_chains": CHAINS_PER_GPU * world,
                 "num_warmup": NUM_WARMUP, "num_samples": NUM_SAMPLES, "parallelism": f"chains x{world} (1 process per GPU)",
-                "wgs_per_chain": res0.wgs_per_chain, "threads_per_wg": 512, "lds_staged": res0.lds_staged,
+                "wgs_per_chain": res0.wgs_per_chain, "lds_bytes_per_wg": res0.lds_bytes, "lds_staged": res0.lds_staged,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "bl_nuts_kernel<3,3,true>", "kernel_ms": kernel_ms_mean,
+                "kernel": f"bl_nuts_kernel<{ds.Ks},{ds.Ko},true,{1 if wl['model'] == 'occu_rn' else 0}>", "kernel_ms": kernel_ms_mean,
                 "algorithmic_bytes_per_launch": leap_mean * bytes_eval, "bytes_per_gradient_evaluation": bytes_eval,
                 "gradient_evaluations_per_launch": leap_mean,
                 "us_per_leapfrog_per_chain": 1e3 * kernel_ms_mean / (leap_mean / CHAINS_PER_GPU),
                 "note": "data is LDS-resident after one HBM read, so this is an effective (algorithmic) bandwidth; "
                         "the sequential-leapfrog latency is the real bound",
             },
-            "ess": {"psi_mean_over_sites_per_step": ess_psi, "min_coef_per_step": [float(x) for x in ess_coef],
+            "ess": {f"{wl['site']}_mean_over_sites_per_step": ess_psi, "min_coef_per_step": [float(x) for x in ess_coef],
                     "max_split_rhat": max(rhat), "draws_per_step": CHAINS_PER_GPU * world * NUM_SAMPLES},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(data, threads=min(CHAINS_PER_GPU, os.cpu_count() or 1))
+        want_cpu = not args.no_cpu_baseline and (args.workload == "occu" or args.cpu_baseline)
+        if world == 1 and want_cpu:
+            out["cpu_baseline"] = cpu_baseline(data, threads=min(CHAINS_PER_GPU, os.cpu_count() or 1), wl=wl)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if dist is not None:
