@@ -139,7 +139,8 @@ def main():
         draws_all = res.draws
         if dist is not None:
             ptr, _ = ds.device_draws()
-            local = torch.as_tensor(_DevArray(ptr, res.draws.shape), device=f"cuda:{local_rank}")
+            # clone: the collective then runs on torch-allocated memory, not on the engine's own hipMalloc block
+            local = torch.as_tensor(_DevArray(ptr, res.draws.shape), device=f"cuda:{local_rank}").clone()
             draws_all = gather_draws(local).cpu().numpy()  # RCCL all-gather: the path's only collective
         return res, draws_all
 
