@@ -30,6 +30,13 @@ class bl_dims(C.Structure):
                 ("n_species", "n_sites", "n_periods", "n_replicates", "n_site_covs", "n_obs_covs")]
 
 
+class bl_beta_prior(C.Structure):
+    _fields_ = [("a", C.c_double), ("b", C.c_double)]
+
+
+FP_CONSTANT, FP_UNOCCUPIED = 1, 2
+
+
 class bl_normal_prior(C.Structure):
     _fields_ = [("loc", C.c_double), ("scale", C.c_double)]
 
@@ -57,7 +64,7 @@ EXPORTS = (
     "bl_abi_version", "bl_last_error", "bl_device_count", "bl_dataset_create", "bl_dataset_create_rn", "bl_dataset_destroy",
     "bl_dataset_param_dim", "bl_logp_grad", "bl_nuts_run", "bl_nuts_launch", "bl_nuts_poll",
     "bl_nuts_abort", "bl_nuts_wait", "bl_nuts_fetch", "bl_nuts_elapsed_ms", "bl_nuts_device_draws",
-    "bl_nuts_geometry", "bl_nuts_debug_counters", "bl_deterministic", "bl_predict", "bl_rng_streams", "bl_adaptation_schedule",
+    "bl_nuts_geometry", "bl_nuts_debug_counters", "bl_deterministic", "bl_predict", "bl_dataset_create_fp", "bl_rng_streams", "bl_adaptation_schedule",
 )
 
 _lib = None
@@ -86,6 +93,8 @@ def load():
                                         C.POINTER(bl_normal_prior), C.c_int, C.POINTER(vp)]
         L.bl_dataset_create_rn.argtypes = [C.POINTER(bl_dims), fp, fp, fp, C.c_int, C.POINTER(bl_normal_prior),
                                            C.POINTER(bl_normal_prior), C.c_int, C.POINTER(vp)]
+        L.bl_dataset_create_fp.argtypes = [C.POINTER(bl_dims), fp, fp, fp, C.c_int, C.POINTER(bl_beta_prior),
+                                           C.POINTER(bl_normal_prior), C.POINTER(bl_normal_prior), C.c_int, C.POINTER(vp)]
         L.bl_dataset_destroy.argtypes = [vp]
         L.bl_dataset_param_dim.argtypes = [vp, ip]
         L.bl_logp_grad.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]

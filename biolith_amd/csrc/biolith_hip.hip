@@ -147,8 +147,10 @@ static int adaptation_schedule(int num_steps, int32_t *starts, int32_t *ends, in
 // ----------------------------------------------------------------- handle ----
 struct bl_dataset {
     int device = 0;
-    int model = 0;          // 0 occu, 1 occu_rn
+    int model = 0;          // 0 occu, 1 occu_rn, 2 occu with false positives
     int max_abundance = 0;  // occu_rn only
+    int fp_mode = 0;        // model 2: BL_FP_CONSTANT / BL_FP_UNOCCUPIED
+    double fp_a = 2.0, fp_b = 5.0;  // model 2: Beta prior of the false-positive rate
     bl_dims dims{};
     int Ks = 0, Ko = 0, KS = 0, KO = 0, D = 0;
     int n_stride = 0, n_rows = 0;
@@ -225,7 +227,7 @@ struct BlPredRng {
 // occu_rn (occu_rn.py:192-221):          N ~ Categorical(Poisson(lambda) pmf on 0..K),  y_j ~ Bernoulli(1 - (1 - r_j)^N)
 __global__ void bl_predict_kernel(const float *__restrict__ rows, const float *__restrict__ wraw, int n_stride, int N, int T, int J,
                                   int Ks, int Ko, int D, const float *__restrict__ draws, int n0, int n1,
-                                  unsigned long long seed, int model, int max_abundance,
+                                  unsigned long long seed, int model, int max_abundance, int fp_mode,
                                   unsigned char *__restrict__ latent, unsigned char *__restrict__ y)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -237,6 +239,9 @@ __global__ void bl_predict_kernel(const float *__restrict__ rows, const float *_
         const float *al = th + Ks + 1;
         float eta = th[0];
         for (int k = 0; k < Ks; k++) eta = fmaf(x[k], th[k + 1], eta);
+        // false-positive rate (model 2): acts on every site ("constant") or on unoccupied ones only
+        const float fpr = model == 2 ? 1.0f / (1.0f + __expf(-th[D - 1])) : 0.0f;
+        const float f_c = fp_mode == BL_FP_CONSTANT ? fpr : 0.0f, f_u = fp_mode == BL_FP_UNOCCUPIED ? fpr : 0.0f;
         for (int t = 0; t < T; t++) {
             BlPredRng rng(seed, ((unsigned long long)n * T + t) * N + i);
             int zn;
@@ -265,9 +270,10 @@ __global__ void bl_predict_kernel(const float *__restrict__ rows, const float *_
                 float nu = al[0];
                 for (int k = 0; k < Ko; k++) nu = fmaf(wraw[((size_t)v * Ko + k) * n_stride + i], al[k + 1], nu);
                 const float r = 1.0f / (1.0f + __expf(-nu));
-                const float pd = model == 1 ? 1.0f - __powf(1.0f - r, (float)zn) : (float)zn * r;
+                float pd = model == 1 ? 1.0f - __powf(1.0f - r, (float)zn) : (float)zn * r;
+                if (model == 2) pd = 1.0f - (1.0f - pd) * (1.0f - f_c) * (1.0f - (zn ? 0.0f : f_u));
                 const float u = rng.uniform();
-                y[(((size_t)(n - n0) * J + j) * T + t) * N + i] = (zn > 0 && u < pd) ? 1 : 0;
+                y[(((size_t)(n - n0) * J + j) * T + t) * N + i] = (u < pd) ? 1 : 0;
             }
         }
     }
@@ -300,7 +306,7 @@ extern "C" int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint6
         const int n1 = (n0 + chunk < n_draws) ? n0 + chunk : n_draws;
         const dim3 grid((N + 255) / 256, (n1 - n0) < 1024 ? (n1 - n0) : 1024);
         hipLaunchKernelGGL(bl_predict_kernel, grid, block, 0, nullptr, ds->d_rows, ds->d_wraw, ds->n_stride, N, T, J, ds->Ks, ds->Ko, D,
-                           d_draws, n0, n1, (unsigned long long)seed, ds->model, ds->max_abundance, d_lat, d_y);
+                           d_draws, n0, n1, (unsigned long long)seed, ds->model, ds->max_abundance, ds->fp_mode, d_lat, d_y);
         BL_HIP(hipGetLastError());
         if (latent) BL_HIP(hipMemcpy(latent + (size_t)n0 * T * N, d_lat, (size_t)(n1 - n0) * T * N, hipMemcpyDeviceToHost));
         if (y) BL_HIP(hipMemcpy(y + (size_t)n0 * J * T * N, d_y, (size_t)(n1 - n0) * J * T * N, hipMemcpyDeviceToHost));
@@ -321,7 +327,8 @@ extern "C" int bl_adaptation_schedule(int num_warmup, int32_t *starts, int32_t *
     return adaptation_schedule(num_warmup, starts, ends, capacity);
 }
 
-static int dataset_create_impl(int model, int max_abundance, const bl_dims *dims, const float *site_covs, const float *obs_covs,
+struct ModelOpts { int model = 0, max_abundance = 0, fp_mode = 0; double fp_a = 2.0, fp_b = 5.0; };
+static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const float *site_covs, const float *obs_covs,
                                const float *obs, const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha,
                                int device, bl_dataset **out);
 
@@ -329,7 +336,7 @@ extern "C" int bl_dataset_create(const bl_dims *dims, const float *site_covs, co
                                  const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha, int device,
                                  bl_dataset **out)
 {
-    return dataset_create_impl(0, 0, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
+    return dataset_create_impl(ModelOpts{}, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
 }
 
 extern "C" int bl_dataset_create_rn(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
@@ -341,13 +348,31 @@ extern "C" int bl_dataset_create_rn(const bl_dims *dims, const float *site_covs,
     if (dims && (dims->n_site_covs > 4 || dims->n_obs_covs > 4))
         return bl_fail(BL_ERR_UNSUPPORTED, "occu_rn kernels are built for at most 4 covariates per side (Ks=%d, Ko=%d)",
                        dims->n_site_covs, dims->n_obs_covs);
-    return dataset_create_impl(1, max_abundance, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
+    ModelOpts mo; mo.model = 1; mo.max_abundance = max_abundance;
+    return dataset_create_impl(mo, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
 }
 
-static int dataset_create_impl(int model, int max_abundance, const bl_dims *dims, const float *site_covs, const float *obs_covs,
+extern "C" int bl_dataset_create_fp(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
+                                    int fp_mode, const bl_beta_prior *prior_fp, const bl_normal_prior *prior_beta,
+                                    const bl_normal_prior *prior_alpha, int device, bl_dataset **out)
+{
+    if (fp_mode != BL_FP_CONSTANT && fp_mode != BL_FP_UNOCCUPIED)
+        return bl_fail(BL_ERR_INVALID, "fp_mode must be BL_FP_CONSTANT or BL_FP_UNOCCUPIED");
+    if (dims && (dims->n_site_covs > 4 || dims->n_obs_covs > 4))
+        return bl_fail(BL_ERR_UNSUPPORTED, "false-positive kernels are built for at most 4 covariates per side (Ks=%d, Ko=%d)",
+                       dims->n_site_covs, dims->n_obs_covs);
+    ModelOpts mo; mo.model = 2; mo.fp_mode = fp_mode;
+    if (prior_fp) { mo.fp_a = prior_fp->a; mo.fp_b = prior_fp->b; }
+    if (!(mo.fp_a > 0.0) || !(mo.fp_b > 0.0) || !std::isfinite(mo.fp_a) || !std::isfinite(mo.fp_b))
+        return bl_fail(BL_ERR_INVALID, "Beta prior needs finite a, b > 0");
+    return dataset_create_impl(mo, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
+}
+
+static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const float *site_covs, const float *obs_covs,
                                const float *obs, const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha,
                                int device, bl_dataset **out)
 {
+    const int model = mo.model, max_abundance = mo.max_abundance;
     if (!dims || !out) return bl_fail(BL_ERR_INVALID, "dims/out is NULL");
     *out = nullptr;
     const int S = dims->n_species, N = dims->n_sites, T = dims->n_periods, J = dims->n_replicates;
@@ -369,8 +394,9 @@ static int dataset_create_impl(int model, int max_abundance, const bl_dims *dims
     if (device < 0 || device >= ndev) return bl_fail(BL_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
 
     bl_dataset *ds = new bl_dataset();
-    ds->device = device; ds->dims = *dims; ds->Ks = Ks; ds->Ko = Ko; ds->D = Ks + Ko + 2;
+    ds->device = device; ds->dims = *dims; ds->Ks = Ks; ds->Ko = Ko; ds->D = Ks + Ko + 2 + (model == 2 ? 1 : 0);
     ds->model = model; ds->max_abundance = max_abundance;
+    ds->fp_mode = mo.fp_mode; ds->fp_a = mo.fp_a; ds->fp_b = mo.fp_b;
     ds->KS = pad_covs(Ks); ds->KO = pad_covs(Ko);
     ds->kern = find_kernels(ds->KS, ds->KO);
     ds->pb = pb; ds->pa = pa;
@@ -435,7 +461,10 @@ static int dataset_create_impl(int model, int max_abundance, const bl_dims *dims
     dd.Ks = Ks; dd.Ko = Ko; dd.KS = KS; dd.KO = KO;
     dd.loc_b = (float)pb.loc; dd.isc2_b = (float)(1.0 / (pb.scale * pb.scale));
     dd.loc_a = (float)pa.loc; dd.isc2_a = (float)(1.0 / (pa.scale * pa.scale));
-    dd.prior_const = (Ks + 1) * std::log(pb.scale) + (Ko + 1) * std::log(pa.scale) + ds->D * 0.91893853320467274178;
+    dd.prior_const = (Ks + 1) * std::log(pb.scale) + (Ko + 1) * std::log(pa.scale) + (Ks + Ko + 2) * 0.91893853320467274178;
+    dd.has_fp = model == 2 ? 1 : 0; dd.fp_a = (float)mo.fp_a; dd.fp_b = (float)mo.fp_b;
+    if (model == 2) // phi = logit f, f ~ Beta(a, b): the energy a softplus(-phi) + b softplus(phi) carries + log B(a, b)
+        dd.prior_const += std::lgamma(mo.fp_a) + std::lgamma(mo.fp_b) - std::lgamma(mo.fp_a + mo.fp_b);
     *out = ds;
     return BL_OK;
 }
@@ -499,12 +528,18 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
 __global__ void bl_logp_final_kernel(BlDevData dd, int k, const double *theta, const double *partial, double *U, double *grad)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
-    const int D = dd.Ks + dd.Ko + 2;
+    const int D = dd.Ks + dd.Ko + 2 + dd.has_fp;
     double acc = 0.0;
     if (lane <= D)
         for (int m = 0; m < k; m++) acc += partial[((size_t)b * k + m) * 64 + lane];
     double pr = 0.0;
-    if (lane < D) {
+    if (lane < D && dd.has_fp && lane == D - 1) {
+        // phi = logit f, f ~ Beta(a, b), Jacobian included: a softplus(-phi) + b softplus(phi)
+        const double phi = theta[(size_t)b * D + lane], l = log1p(exp(-fabs(phi)));
+        const double sig = 1.0 / (1.0 + exp(-phi));
+        pr = dd.fp_a * (fmax(-phi, 0.0) + l) + dd.fp_b * (fmax(phi, 0.0) + l);
+        grad[(size_t)b * D + lane] = -acc + (dd.fp_a + dd.fp_b) * sig - dd.fp_a;
+    } else if (lane < D) {
         const bool is_b = lane <= dd.Ks;
         const double loc = is_b ? dd.loc_b : dd.loc_a, isc2 = is_b ? dd.isc2_b : dd.isc2_a;
         const double dth = theta[(size_t)b * D + lane] - loc;
@@ -541,8 +576,9 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
     BlLogpParams p{};
     p.dd = ds->dd; p.k = k; p.nloc = nloc; p.rec_stride = ld; p.B = B; p.theta = d_th32; p.partial = d_partial;
     p.max_abundance = ds->max_abundance;
-    if (ds->model == 1 && !use_staged)
-        return bl_fail(BL_ERR_UNSUPPORTED, "occu_rn needs the LDS-staged path (slice too large, or staged=0 requested)");
+    p.fp_z1 = ds->fp_mode == BL_FP_CONSTANT ? 1 : 0;
+    if (ds->model != 0 && !use_staged)
+        return bl_fail(BL_ERR_UNSUPPORTED, "occu_rn / false-positive models need the LDS-staged path (slice too large, or staged=0 requested)");
     const int lrc = ds->kern->logp(&p, k, lds_bytes, use_staged, ds->model, nullptr);
     if (lrc != 0) return bl_fail(BL_ERR_NO_DEVICE, "logp kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     hipLaunchKernelGGL(bl_logp_final_kernel, dim3(B), dim3(64), 0, nullptr, ds->dd, k, d_th, d_partial, d_U, d_grad);
@@ -624,6 +660,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     for (int i = 0; i < 32; i++) cold.win_end[i] = i < cold.nwin ? we[i] : 0x7fffffff;
     cold.loc_b = ds->dd.loc_b; cold.isc2_b = ds->dd.isc2_b; cold.loc_a = ds->dd.loc_a; cold.isc2_a = ds->dd.isc2_a;
     cold.prior_const = ds->dd.prior_const;
+    cold.fp_a = (float)ds->fp_a; cold.fp_b = (float)ds->fp_b;
     cold.rng = ds->d_rng;
     cold.init_theta = cfg->init_theta ? ds->d_init : nullptr;
     cold.abort_flag = ds->d_abort;
@@ -642,6 +679,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.k = k; p.nloc = nloc; p.rec_stride = ld; p.nvp = nvp;
     p.max_depth = max_depth;
     p.max_abundance = ds->max_abundance;
+    p.fp_z1 = ds->fp_mode == BL_FP_CONSTANT ? 1 : 0;
     p.xchg = ds->d_xchg;
     p.cold = d_cold;
     p.spin_limit = 1u << 18;
@@ -663,8 +701,8 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     BL_HIP(hipMemsetAsync(ds->d_dbg, 0, 128, st));
     BL_HIP(hipMemsetAsync(ds->d_loc, 0, (size_t)C * 4, st));
     const int grid = 8 * k * ((C + 7) / 8); // XCD-aware mapping in the kernel; surplus blocks exit at once
-    if (ds->model == 1 && !staged)
-        return bl_fail(BL_ERR_UNSUPPORTED, "occu_rn: the dataset slice does not fit the LDS-staged path");
+    if (ds->model != 0 && !staged)
+        return bl_fail(BL_ERR_UNSUPPORTED, "occu_rn / false-positive model: the dataset slice does not fit the LDS-staged path");
     const int lrc = ds->kern->nuts(&p, grid, lds_bytes, staged, ds->model, st);
     if (lrc != 0) return bl_fail(BL_ERR_NO_DEVICE, "NUTS kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     BL_HIP(hipEventRecord(ds->ev1, st));

@@ -1,6 +1,7 @@
 // kernels_inst.hip -- one translation unit per padded covariate capacity pair (BL_KS, BL_KO).
 // Built N times by the Makefile (-DBL_KS=.. -DBL_KO=..) so the instantiations compile in parallel.
-// model 0 = occu (LDS-staged and HBM-row forms); model 1 = occu_rn (LDS-staged form, capacities <= 4).
+// model 0 = occu (LDS-staged and HBM-row forms); model 1 = occu_rn and model 2 = occu with false
+// positives (LDS-staged form, capacities <= 4).
 #include "logp_kernel.hpp"
 #include "nuts_kernel.hpp"
 
@@ -32,6 +33,12 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
 #endif
         return (int)hipErrorNotSupported;
     }
+    if (model == 2) {
+#if BL_HAVE_RN
+        if (staged) return bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, 2>, p, grid, BL_THREADS, lds_bytes, stream);
+#endif
+        return (int)hipErrorNotSupported;
+    }
     if (staged) return bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, 0>, p, grid, BL_THREADS, lds_bytes, stream);
     return bl_launch(bl_nuts_kernel<BL_KS, BL_KO, false, 0>, p, grid, BL_THREADS, lds_bytes, stream);
 }
@@ -41,6 +48,12 @@ extern "C" int BL_NAME(bl_launch_logp, BL_KS, BL_KO)(const BlLogpParams *p, int 
     if (model == 1) {
 #if BL_HAVE_RN
         if (staged) return bl_launch(bl_logp_kernel<BL_KS, BL_KO, true, 1>, p, grid, BL_THREADS_RN, lds_bytes, stream);
+#endif
+        return (int)hipErrorNotSupported;
+    }
+    if (model == 2) {
+#if BL_HAVE_RN
+        if (staged) return bl_launch(bl_logp_kernel<BL_KS, BL_KO, true, 2>, p, grid, BL_THREADS, lds_bytes, stream);
 #endif
         return (int)hipErrorNotSupported;
     }

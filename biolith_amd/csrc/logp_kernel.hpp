@@ -8,6 +8,7 @@ struct BlLogpParams {
     BlDevData dd;
     int k, nloc, rec_stride;
     int max_abundance;   // occu_rn only
+    int fp_z1;           // false-positive model only (see BlNutsParams)
     int B;
     const float *theta;  // [B][D] float32 view of the caller's double theta
     double *partial;     // [B][k][64]: c < D grad of log-lik, c == D log-lik
@@ -18,7 +19,7 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_logp_kernel(const B
 {
     const int member = blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int Ks = p.dd.Ks, Ko = p.dd.Ko, D = Ks + Ko + 2;
+    const int Ks = p.dd.Ks, Ko = p.dd.Ko, D = bl_model_dim<MODEL>(Ks, Ko);
     const int s0 = member * p.nloc;
     int cnt = p.dd.n_sites - s0;
     cnt = cnt < 0 ? 0 : (cnt > p.nloc ? p.nloc : cnt);
@@ -33,20 +34,12 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_logp_kernel(const B
     float *sh_coef = bl_lds_f(BL_OFF_COEF);
     if (tid < 64) sh_coef[tid] = 0.0f;
     __syncthreads();
-    const int my_pos = lane < D ? bl_coef_pos(lane, Ks, KS) : (lane == D ? KS + KO + 2 : 0);
+    const int my_pos = lane < D ? bl_coef_pos(lane, Ks, Ko, KS, KO) : (lane == D ? KS + KO + 2 : 0);
     for (int b = 0; b < p.B; b++) {
         if (wave == 0 && lane < D) sh_coef[my_pos] = p.theta[(size_t)b * D + lane];
         __syncthreads();
         if (wave > 0) { // compute waves, exactly as in the NUTS kernel
-            float beta[KS + 1], alpha[KO + 1];
-            bl_load_coefs<KS, KO>(beta, alpha);
-            float ll = 0.0f, gb[KS + 1], ga[KO + 1];
-#pragma unroll
-            for (int k = 0; k <= KS; k++) gb[k] = 0.0f;
-#pragma unroll
-            for (int k = 0; k <= KO; k++) ga[k] = 0.0f;
-            bl_eval_sites<KS, KO, LDS, MODEL>(tid - 64, grows, ld, cnt, p.dd.T, p.dd.J, p.max_abundance, beta, alpha, ll, gb, ga);
-            bl_wave_partials_to_lds<KS, KO>(wave - 1, ll, gb, ga);
+            bl_phase_a<KS, KO, LDS, MODEL>(tid - 64, wave - 1, grows, ld, cnt, p.dd.T, p.dd.J, p.max_abundance, p.fp_z1);
         }
         __syncthreads();
         if (wave == 0) {

@@ -55,7 +55,8 @@ struct BlNutsCold {
     float target_accept;
     int win_end[32];               // numpyro adaptation windows (inclusive ends)
     float loc_b, isc2_b, loc_a, isc2_a;  // Normal prior loc, 1/scale^2
-    double prior_const;            // sum_k log(scale_k) + D/2 log(2 pi)
+    double prior_const;            // sum_k log(scale_k) + D/2 log(2 pi)  (+ log B(a,b) for MODEL 2)
+    float fp_a, fp_b;              // MODEL 2: Beta(a, b) prior of the false-positive rate
     const uint32_t *rng;           // [C][64][4] xoshiro states (host-jumped)
     const float *init_theta;       // [C][D] or null -> Uniform(-2,2)
     const int *abort_flag;         // host-mapped
@@ -80,6 +81,7 @@ struct BlNutsParams {
     int nloc;                      // sites per workgroup
     int rec_stride;                // floats per LDS pair record
     int nvp;                       // granules per workgroup record: 16, 32 or 64 (>= D+4)
+    int fp_z1;                     // MODEL 2: 1 = the false-positive rate also acts on occupied sites ("constant")
     int max_depth;
     int max_abundance;             // occu_rn only (occu_rn.py:26)
     int allow_local;               // 0: always use the placement-independent exchange
@@ -151,7 +153,7 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
     const int chain = label + 8 * (slot / p.k), member = slot % p.k;
     if (chain >= p.num_chains) return; // whole block leaves before any barrier or exchange
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int Ks = p.Ks, Ko = p.Ko, D = Ks + Ko + 2;
+    const int Ks = p.Ks, Ko = p.Ko, D = bl_model_dim<MODEL>(Ks, Ko);
     const int T = p.T, J = p.J;
     const int s0 = member * p.nloc;
     int cnt = p.n_sites - s0;
@@ -176,7 +178,8 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
     const BlNutsCold *cold = p.cold;
     const bool act = lane < D;
     // where lane d's coefficient / partial lives in the padded LDS layouts; lanes >= D read the log-lik
-    const int my_pos = act ? bl_coef_pos(lane, Ks, KS) : KS + KO + 2;
+    const int my_pos = act ? bl_coef_pos(lane, Ks, Ko, KS, KO) : KS + KO + 2;
+    const bool is_phi = MODEL == 2 && lane == D - 1; // the logit false-positive rate: Beta prior, not Normal
     // ---- loop-carried registers: only what the per-leaf path touches ----
     BlRng rng_d, rng_u, rng_dir;        // per-dimension stream, transition uniforms, direction bits
     float minv = act ? 1.0f : 0.0f;     // diagonal inverse mass (0 in idle lanes keeps sums clean)
@@ -225,6 +228,7 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
         S = cold->num_samples; W = cold->num_warmup; total = W + S;
         prior_loc = (lane <= Ks) ? cold->loc_b : cold->loc_a;
         prior_isc2 = act ? ((lane <= Ks) ? cold->isc2_b : cold->isc2_a) : 0.0f;
+        if (is_phi) { prior_loc = cold->fp_a; prior_isc2 = cold->fp_b; }
         prior_const = cold->prior_const;
         const uint32_t *rs = cold->rng + ((size_t)chain * BL_NSTREAM + lane) * 4;
         rng_d.s0 = rs[0]; rng_d.s1 = rs[1]; rng_d.s2 = rs[2]; rng_d.s3 = rs[3];
@@ -283,15 +287,7 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
     while (true) {
         if (wave > 0) {
             // ------------------------------------- phase A: compute waves, site log-lik ----
-            float beta[KS + 1], alpha[KO + 1];
-            bl_load_coefs<KS, KO>(beta, alpha);
-            float ll = 0.0f, gb[KS + 1], ga[KO + 1];
-#pragma unroll
-            for (int k = 0; k <= KS; k++) gb[k] = 0.0f;
-#pragma unroll
-            for (int k = 0; k <= KO; k++) ga[k] = 0.0f;
-            bl_eval_sites<KS, KO, LDS, MODEL>(tid - 64, grows, ld, cnt, T, J, p.max_abundance, beta, alpha, ll, gb, ga);
-            bl_wave_partials_to_lds<KS, KO>(wave - 1, ll, gb, ga);
+            bl_phase_a<KS, KO, LDS, MODEL>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_z1);
         } else {
             run_deferred(); // overlaps phase A
             BL_STAMP(0)
@@ -399,14 +395,27 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
             else if (abort_req) flag = 5;  // BL_ERR_ABORTED
 
             // ------------------------------------------------ potential at cz (lane d) ----
+            // prior of lane d: pe2 = 2 x its energy, pg = d energy / d theta_d
+            //   Normal(loc, scale):            pe2 = (theta-loc)^2 / scale^2 ,  pg = (theta-loc) / scale^2
+            //   phi = logit f, f ~ Beta(a,b):  energy = a softplus(-phi) + b softplus(phi)  (Jacobian included),
+            //                                  pg = (a+b) sigmoid(phi) - a        (prior_loc = a, prior_isc2 = b)
             const float dth = cz - prior_loc;
-            const float cg = act ? (-(float)acc + dth * prior_isc2) : 0.0f;
+            float pe2 = dth * dth * prior_isc2, pg = dth * prior_isc2;
+            if constexpr (MODEL == 2) {
+                if (is_phi) {
+                    const float e = bl_exp(-fabsf(cz)), op = 1.0f + e, l = bl_log(op);
+                    const float sig = (cz > 0.0f ? 1.0f : e) * bl_rcp(op);
+                    pe2 = 2.0f * (prior_loc * (fmaxf(-cz, 0.0f) + l) + prior_isc2 * (fmaxf(cz, 0.0f) + l));
+                    pg = (prior_loc + prior_isc2) * sig - prior_loc;
+                }
+            }
+            const float cg = act ? (-(float)acc + pg) : 0.0f;
 
             bool new_transition = false;
             if (flag == 0) {
                 if (init_pending) {
                     // initial evaluation done
-                    const double Un = -ll_tot + (double)(0.5f * bl_wave_sum(dth * dth * prior_isc2)) + prior_const;
+                    const double Un = -ll_tot + (double)(0.5f * bl_wave_sum(pe2)) + prior_const;
                     sv[SV_TH * 64] = cz; sv[SV_GR * 64] = cg;
                     ss->U = Un;
                     init_pending = false;
@@ -414,7 +423,7 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
                 } else {
                     // ------- CRITICAL: finish the leaf (_build_basetree), decide where the next one goes -------
                     const float cr = rh - 0.5f * epsdir * cg;
-                    float s_prior = dth * dth * prior_isc2, s_kin = minv * cr * cr;
+                    float s_prior = pe2, s_kin = minv * cr * cr;
                     bl_low_sum2(s_prior, s_kin, D);
                     const double Un = -ll_tot + (double)(0.5f * s_prior) + prior_const;
                     const double Kn = (double)(0.5f * s_kin);

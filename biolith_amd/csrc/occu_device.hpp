@@ -20,7 +20,7 @@
 #define BL_CWAVES_RN 3
 #define BL_THREADS_RN (BL_CWAVES_RN * 64 + 64)
 template <int MODEL> struct BlGeom {
-    static constexpr int CWAVES = MODEL == 1 ? BL_CWAVES_RN : BL_CWAVES;
+    static constexpr int CWAVES = MODEL == 1 ? BL_CWAVES_RN : BL_CWAVES; // MODEL 2 (false positives) runs the occu geometry
     static constexpr int CTHREADS = CWAVES * 64;
     static constexpr int THREADS = CTHREADS + 64;
 };
@@ -67,7 +67,9 @@ struct BlDevData {
     int Ks, Ko;     // actual covariate counts (theta layout)
     int KS, KO;     // padded counts the rows were packed for (= kernel template capacity)
     float loc_b, isc2_b, loc_a, isc2_a;  // Normal prior loc, 1/scale^2
-    double prior_const;                  // sum_k log(scale_k) + D/2 log(2 pi)
+    double prior_const;                  // sum_k log(scale_k) + D/2 log(2 pi)  (+ log B(a,b) with has_fp)
+    int has_fp;                          // 1: theta carries phi = logit(false-positive rate) as its last coordinate
+    float fp_a, fp_b;                    // its Beta(a, b) prior
 };
 
 __host__ __device__ inline int bl_round4(int x) { return (x + 3) & ~3; }
@@ -438,6 +440,139 @@ __device__ __forceinline__ void bl_eval_sites_hbm(int ct, const float *__restric
 }
 
 
+// ------------------------------------------------- occu with false positives (MODEL 2) ----
+// biolith/models/occu.py:146-157,229-241: P(y=1 | z) = 1 - (1 - z p)(1 - f_c)(1 - (1 - z) f_u) with one of
+// f_c ("constant") / f_u ("unoccupied") sampled, the other 0.  Both are the same likelihood with
+//   z = 1:  P = p + f1 (1 - p)   (f1 = f for "constant", 0 for "unoccupied"),      z = 0:  P = f
+// and one extra unconstrained coordinate phi = logit f.  On the sign-folded records (u = c nu):
+//   detection      log P     = log sigma(u) + log(1 + f1 e^-u)
+//   non-detection  log(1-P)  = log sigma(u) + log(1 - f1)
+//   z = 0 branch   n_det log f + n_nondet log(1 - f)     (replaces n_det log(tiny))
+// so the occu visit arithmetic stays and each visit adds one log and one rcp.  The counts come from
+// the record's ka = n_masked ln2 and kb = n_det log(tiny).  Accumulates d/dphi (chain rule through
+// f = sigmoid(phi) included) into gphi.  Pair records, runtime J.
+struct BlFpScalars {
+    float f, f1, lf, l1f, l1f1, ff1; // f, f1, log f, log(1-f), log(1-f1), f (1-f)
+    float z1;                        // 1 if f also acts on occupied sites ("constant")
+};
+__device__ __forceinline__ BlFpScalars bl_fp_scalars(float phi, int fp_z1)
+{
+    const float e = __builtin_amdgcn_exp2f(-fabsf(phi) * BL_LOG2E), op = 1.0f + e;
+    const float l = BL_LN2 * __builtin_amdgcn_logf(op), r = __builtin_amdgcn_rcpf(op);
+    BlFpScalars s;
+    s.f = (phi > 0.0f ? 1.0f : e) * r;
+    s.lf = fminf(phi, 0.0f) - l;    // -softplus(-phi)
+    s.l1f = -fmaxf(phi, 0.0f) - l;  // -softplus(phi)
+    s.ff1 = e * r * r;              // f (1 - f)
+    s.z1 = fp_z1 ? 1.0f : 0.0f;
+    s.f1 = fp_z1 ? s.f : 0.0f;
+    s.l1f1 = fp_z1 ? s.l1f : 0.0f;
+    return s;
+}
+
+template <int KS, int KO>
+__device__ __forceinline__ void bl_eval_sites_fp(int ct, int pstride, int cnt, int T, int J, const BlFpScalars fp,
+                                                 const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
+                                                 float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], float &gphi)
+{
+    constexpr int XQ = (KS + 3) & ~3;
+    const int pb = bl_period_block(J, KO);
+    const float *data = bl_lds_f(BL_OFF_DATA);
+    const int npairs = (cnt + 1) >> 1;
+    const float Jf = (float)J;
+    bl_f2 ll2 = bl2(0.0f), gb2[KS + 1], ga2[KO + 1], gp2 = bl2(0.0f);
+#pragma unroll
+    for (int k = 0; k <= KS; k++) gb2[k] = bl2(0.0f);
+#pragma unroll
+    for (int k = 0; k <= KO; k++) ga2[k] = bl2(0.0f);
+    for (int m = ct; m < npairs; m += BL_CTHREADS) {
+        const float4 *rec = reinterpret_cast<const float4 *>(data + (size_t)m * pstride);
+        const bl_f2 vmask = bl_f2{1.0f, (2 * m + 1 < cnt) ? 1.0f : 0.0f};
+        bl_f2 x[XQ];
+#pragma unroll
+        for (int q = 0; q < XQ / 2; q++) {
+            const float4 v = rec[q];
+            x[2 * q] = bl_f2{v.x, v.y};
+            x[2 * q + 1] = bl_f2{v.z, v.w};
+        }
+        bl_f2 eta = bl2(beta[0]);
+#pragma unroll
+        for (int k = 0; k < KS; k++) eta = bl_fma2(x[k], bl2(beta[k + 1]), eta);
+        const bl_f2 e_eta = bl_exp2_2(__builtin_elementwise_abs(eta) * bl2(-BL_LOG2E));
+        const bl_f2 op_eta = e_eta + bl2(1.0f);
+        const bl_f2 sp = bl_fma2(bl_log2_2(op_eta), bl2(BL_LN2), __builtin_elementwise_max(eta, bl2(0.0f)));
+        const bl_f2 psi = bl_sel_pos_one(eta, e_eta) * bl_rcp_2(op_eta);
+        bl_f2 dsum = bl2(0.0f), lsite = bl2(0.0f), gpsite = bl2(0.0f);
+        const float2 *pp0 = reinterpret_cast<const float2 *>(data + (size_t)m * pstride) + XQ;
+        for (int t = 0; t < T; t++) {
+            const float2 *pp = pp0 + t * pb;
+            bl_f2 g[KO + 1];
+#pragma unroll
+            for (int k = 0; k <= KO; k++) g[k] = bl2(0.0f);
+            const float2 a_ = pp[J * (KO + 1)], kb_ = pp[J * (KO + 1) + 1];
+            bl_f2 a = bl_f2{a_.x, a_.y};
+            bl_f2 gf = bl2(0.0f); // d a / d f1
+            // counts of this (site, period): detections, non-detections (the rest of J is masked)
+            const bl_f2 ndet = bl_f2{__builtin_rintf(kb_.x * (1.0f / -87.33654475f)), __builtin_rintf(kb_.y * (1.0f / -87.33654475f))};
+            const bl_f2 nmask = bl_f2{__builtin_rintf(a_.x * (1.0f / BL_LN2)), __builtin_rintf(a_.y * (1.0f / BL_LN2))};
+            const bl_f2 nnon = bl2(Jf) - ndet - nmask;
+#pragma unroll 2
+            for (int j = 0; j < J; j++) {
+                bl_f2 w[KO + 1];
+#pragma unroll
+                for (int k = 0; k <= KO; k++) {
+                    const float2 v = pp[j * (KO + 1) + k];
+                    w[k] = bl_f2{v.x, v.y};
+                }
+                bl_f2 u = w[0] * bl2(alpha[0]);
+#pragma unroll
+                for (int k = 1; k <= KO; k++) u = bl_fma2(w[k], bl2(alpha[k]), u);
+                const bl_f2 tt = bl_expneg_2(u);
+                const bl_f2 op = tt + bl2(1.0f);
+                a = bl_fma2(bl_log2_2(op), bl2(-BL_LN2), a);
+                // c = +1 -> 1, else 0; and 0 throughout when f does not act on occupied sites
+                const bl_f2 det = __builtin_elementwise_max(w[0], bl2(0.0f)) * bl2(fp.z1);
+                const bl_f2 td = tt * det;
+                const bl_f2 opf = bl_fma2(td, bl2(fp.f1), bl2(1.0f));         // 1 + f1 e^-u on detections, else 1
+                a = bl_fma2(bl_log2_2(opf), bl2(BL_LN2), a);
+                const bl_f2 tr = td * bl_rcp_2(opf);                          // e^-u / (1 + f1 e^-u)
+                gf += tr;
+                const bl_f2 s = bl_fma2(tr, bl2(-fp.f1), tt * bl_rcp_2(op));  // d/du
+#pragma unroll
+                for (int k = 0; k <= KO; k++) g[k] = bl_fma2(s, w[k], g[k]);
+            }
+            a = bl_fma2(nnon, bl2(fp.l1f1), a);
+            const bl_f2 kb = bl_fma2(ndet, bl2(fp.lf), nnon * bl2(fp.l1f));
+            const bl_f2 A = eta - sp + a, B = kb - sp;
+            const bl_f2 d = eta + a - kb;
+            const bl_f2 e_d = bl_exp2_2(__builtin_elementwise_abs(d) * bl2(-BL_LOG2E));
+            const bl_f2 op_d = e_d + bl2(1.0f);
+            lsite += bl_fma2(bl_log2_2(op_d), bl2(BL_LN2), __builtin_elementwise_max(A, B));
+            const bl_f2 q = bl_sel_pos_one(d, e_d) * bl_rcp_2(op_d); // P(z=1 | y, theta)
+            dsum += q - psi;
+#pragma unroll
+            for (int k = 0; k <= KO; k++) ga2[k] = bl_fma2(q, g[k], ga2[k]);
+            // d/dphi: z=1 branch (only when f acts there) and z=0 branch, each times f(1-f)
+            const bl_f2 d1 = bl_fma2(gf, bl2(fp.ff1), nnon * bl2(-fp.f * fp.z1));
+            const bl_f2 d0 = bl_fma2(ndet, bl2(1.0f - fp.f), nnon * bl2(-fp.f));
+            gpsite += bl_fma2(q, d1 - d0, d0);
+        }
+        ll2 = bl_fma2(lsite, vmask, ll2);
+        gp2 = bl_fma2(gpsite, vmask, gp2);
+        dsum *= vmask;
+        gb2[0] += dsum;
+#pragma unroll
+        for (int k = 0; k < KS; k++) gb2[k + 1] = bl_fma2(dsum, x[k], gb2[k + 1]);
+    }
+    ll += ll2.x + ll2.y;
+    gphi += gp2.x + gp2.y;
+#pragma unroll
+    for (int k = 0; k <= KS; k++) gb[k] += gb2[k].x + gb2[k].y;
+#pragma unroll
+    for (int k = 0; k <= KO; k++) ga[k] += ga2[k].x + ga2[k].y;
+}
+
+
 // ---------------------------------------------------------------- Royle-Nichols (occu_rn) ----
 // biolith/models/occu_rn.py:179-222 + utils/distributions.py:31-40 with N summed out:
 //   lambda = exp(eta);  pi_n = Poisson(lambda)(n) renormalised over n <= K   (K = max_abundance)
@@ -654,7 +789,8 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
     }
 }
 
-// MODEL 0 = occu (occu.py), MODEL 1 = occu_rn (occu_rn.py; LDS records only)
+// MODEL 0 = occu (occu.py), MODEL 1 = occu_rn (occu_rn.py; LDS records only);
+// MODEL 2 (occu with false positives) is dispatched by bl_phase_a below
 template <int KS, int KO, bool LDS, int MODEL>
 __device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ grows, int ld_or_stride, int cnt, int T, int J, int K,
                                               const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
@@ -705,7 +841,13 @@ __device__ __forceinline__ void bl_stage_records(const float *__restrict__ rows,
 
 // Padded coefficient layout in LDS: beta_k at k (k <= KS), alpha_k at KS+1+k.  dim d of theta
 // (d <= Ks: beta_d, else alpha_{d-Ks-1}) lives at:
-__device__ __forceinline__ int bl_coef_pos(int d, int Ks, int KS) { return d <= Ks ? d : KS + 1 + (d - Ks - 1); }
+// MODEL 2's extra coordinate phi (d = Ks+Ko+2) lives at KS+KO+3, after the log-lik slot of the partial rows.
+__device__ __forceinline__ int bl_coef_pos(int d, int Ks, int Ko, int KS, int KO)
+{
+    return d <= Ks ? d : (d <= Ks + Ko + 1 ? KS + 1 + (d - Ks - 1) : KS + KO + 3);
+}
+// theta dimension of a model
+template <int MODEL> __device__ __forceinline__ int bl_model_dim(int Ks, int Ko) { return Ks + Ko + 2 + (MODEL == 2 ? 1 : 0); }
 
 template <int KS, int KO>
 __device__ __forceinline__ void bl_load_coefs(float (&beta)[KS + 1], float (&alpha)[KO + 1])
@@ -718,24 +860,51 @@ __device__ __forceinline__ void bl_load_coefs(float (&beta)[KS + 1], float (&alp
 }
 
 // Wave reduction of (gb, ga, ll) -> this wave's row of the LDS partial table, padded layout:
-// [0..KS] d/dbeta, [KS+1..KS+KO+1] d/dalpha, [KS+KO+2] log-lik.  One interleaved DPP butterfly for
+// [0..KS] d/dbeta, [KS+1..KS+KO+1] d/dalpha, [KS+KO+2] log-lik, [KS+KO+3] d/dphi (MODEL 2).  One interleaved DPP butterfly for
 // all values (f32: the per-term rounding of the f32 site math dominates the error budget anyway);
 // lane 63 holds the totals and stores them.  Cross-wave / cross-workgroup sums are done in f64.
-template <int KS, int KO>
-__device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, const float (&gb)[KS + 1], const float (&ga)[KO + 1])
+template <int KS, int KO, bool EXTRA = false>
+__device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, const float (&gb)[KS + 1], const float (&ga)[KO + 1],
+                                                        float gextra = 0.0f)
 {
-    constexpr int NV = KS + KO + 3;
+    constexpr int NV = KS + KO + 3 + (EXTRA ? 1 : 0);
     const int wave = cwave, lane = threadIdx.x & 63;
     float v[NV];
 #pragma unroll
     for (int k = 0; k <= KS; k++) v[k] = gb[k];
 #pragma unroll
     for (int k = 0; k <= KO; k++) v[KS + 1 + k] = ga[k];
-    v[NV - 1] = ll;
+    v[KS + KO + 2] = ll;
+    if constexpr (EXTRA) v[KS + KO + 3] = gextra;
     bl_wave_sum_vec_l63<NV>(v);
     if (lane == 63) {
         float *part = bl_lds_f(BL_OFF_PART) + wave * BL_PART_STRIDE;
 #pragma unroll
         for (int k = 0; k < NV; k++) part[k] = v[k];
+    }
+}
+
+// Phase A of one evaluation for a compute thread `ct` of the workgroup: coefficients from LDS, the
+// workgroup's site slice, wave partials into the LDS table.  Shared by the NUTS and logp kernels.
+template <int KS, int KO, bool LDS, int MODEL>
+__device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__restrict__ grows, int ld_or_stride, int cnt,
+                                           int T, int J, int max_abundance, int fp_z1)
+{
+    float beta[KS + 1], alpha[KO + 1];
+    bl_load_coefs<KS, KO>(beta, alpha);
+    float ll = 0.0f, gb[KS + 1], ga[KO + 1];
+#pragma unroll
+    for (int k = 0; k <= KS; k++) gb[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k <= KO; k++) ga[k] = 0.0f;
+    if constexpr (MODEL == 2) {
+        static_assert(LDS, "false-positive model: LDS records only");
+        float gphi = 0.0f;
+        const BlFpScalars fp = bl_fp_scalars(bl_lds_f(BL_OFF_COEF)[KS + KO + 3], fp_z1);
+        bl_eval_sites_fp<KS, KO>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi);
+        bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi);
+    } else {
+        bl_eval_sites<KS, KO, LDS, MODEL>(ct, grows, ld_or_stride, cnt, T, J, max_abundance, beta, alpha, ll, gb, ga);
+        bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga);
     }
 }

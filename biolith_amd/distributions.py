@@ -41,3 +41,18 @@ def as_normal(prior, name: str = "prior") -> tuple:
     if not scale > 0:
         raise ValueError(f"{name}: scale must be positive")
     return loc, scale
+
+
+def as_beta(prior, name: str = "prior") -> tuple:
+    """(a, b) of a Beta prior; duck-types numpyro's ``dist.Beta`` (concentration1 / concentration0)."""
+    if type(prior).__name__ != "Beta" or not hasattr(prior, "concentration1") or not hasattr(prior, "concentration0"):
+        raise NotImplementedError(f"{name}: the HIP engine supports Beta(a, b) priors here, got {prior!r}")
+    import numpy as np
+
+    a, b = np.asarray(prior.concentration1, dtype=float), np.asarray(prior.concentration0, dtype=float)
+    if a.size != 1 or b.size != 1:
+        raise NotImplementedError(f"{name}: scalar concentrations only")
+    a, b = float(a.reshape(())), float(b.reshape(()))
+    if not (a > 0 and b > 0):
+        raise ValueError(f"{name}: concentrations must be positive")
+    return a, b

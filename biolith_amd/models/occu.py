@@ -16,7 +16,7 @@ from typing import Any, Optional
 
 import numpy as np
 
-from ..distributions import Beta, HalfNormal, Normal, as_normal
+from ..distributions import Beta, HalfNormal, Normal, as_beta, as_normal
 from ..regression import AbstractRegression, LinearRegression
 
 
@@ -65,8 +65,9 @@ def occu(
     """Bernoulli occupancy model (MacKenzie et al. 2002), z marginalised, on the HIP engine.
 
     Same parameters as the reference (biolith/models/occu.py:19-40).  Supported here: the default
-    option path -- linear regressors on both sides, Normal priors, no false positives, no spatial
-    effect, no random effects; several species are sampled species by species (their joint density
+    option path -- linear regressors on both sides, Normal priors, no spatial effect, no random
+    effects -- plus ``false_positives_constant`` / ``false_positives_unoccupied`` with a Beta prior on the
+    rate (occu.py:146-157, 229-241; one species, at most 4 covariates per side); several species are sampled species by species (their joint density
     factorises over the ``species`` plate, occu.py:182-186).  Anything else raises ``NotImplementedError`` (the
     engine has no silent fallback).  ``coords=None`` / any ``ell`` are accepted and ignored, as the
     reference does when ``coords`` is None (occu.py:159-167); ``simulate()`` returns both.
@@ -101,8 +102,13 @@ def occu(
     unsupported = []
     if coords is not None:
         unsupported.append("coords (spatial HSGP effect, occu.py:159-165)")
-    if false_positives_constant or false_positives_unoccupied:
-        unsupported.append("false positives (occu.py:146-157)")
+    fp_mode = "constant" if false_positives_constant else ("unoccupied" if false_positives_unoccupied else None)
+    if fp_mode is not None:
+        # prob_fp_* is sampled outside the species plate (occu.py:146-157): with several species it couples them
+        if n_species != 1:
+            unsupported.append("false positives with n_species > 1 (the rate is shared across species, occu.py:146-157)")
+        if site_covs.shape[1] > 4 or obs_covs.shape[3] > 4:
+            unsupported.append("false positives with more than 4 covariates per side")
     if site_random_effects or obs_random_effects:
         unsupported.append("random effects (occu.py:170-173)")
     if regressor_occ is not LinearRegression or regressor_det is not LinearRegression:
@@ -114,8 +120,13 @@ def occu(
             "biolith_amd.occu runs the default-option occupancy path on the HIP engine; not built: "
             + "; ".join(unsupported)
         )
-    return OccuSpec(site_covs, obs_covs, obs, n_species, as_normal(prior_beta, "prior_beta"),
+    spec = OccuSpec(site_covs, obs_covs, obs, n_species, as_normal(prior_beta, "prior_beta"),
                     as_normal(prior_alpha, "prior_alpha"))
+    if fp_mode is not None:
+        prior = prior_prob_fp_constant if fp_mode == "constant" else prior_prob_fp_unoccupied
+        spec.model = "occu_fp"
+        spec.extras.update(fp_mode=fp_mode, prior_fp=as_beta(prior, f"prior_prob_fp_{fp_mode}"))
+    return spec
 
 
 occu.__biolith_amd_model__ = "occu"

@@ -98,7 +98,7 @@ def fit(
             if count == 0:
                 continue
             ds = OccuDataset(spec.site_covs, spec.obs_covs, spec.obs[sp:sp + 1], spec.prior_beta, spec.prior_alpha,
-                             device=dev, model=spec.model, max_abundance=spec.extras.get("max_abundance", 100))
+                             device=dev, model=spec.model, **engine_options(spec))
             jobs.append((sp, ds, dict(num_warmup=num_warmup, num_samples=num_samples, num_chains=count,
                                       seed=random_seed, chain_offset=chain_offset + sp * num_chains + first)))
 
@@ -142,6 +142,14 @@ def fit(
     return FitResult(samples, mcmc)
 
 
+def engine_options(spec) -> dict:
+    """Model options of an ``OccuSpec`` as ``OccuDataset`` keyword arguments."""
+    opts = dict(max_abundance=spec.extras.get("max_abundance", 100))
+    if spec.model == "occu_fp":
+        opts.update(fp_mode=spec.extras["fp_mode"], prior_fp=spec.extras["prior_fp"])
+    return opts
+
+
 def _concat_chains(parts):
     """Shards of one species' chains (one NutsResult per device) -> one NutsResult, chain axis first."""
     if len(parts) == 1:
@@ -164,7 +172,12 @@ def _assemble(per_species, spec, num_warmup) -> HipMCMC:
     nsp = len(per_species)
     # plate "species" is the last axis of every site (occu.py:182, dim=-1)
     beta = np.stack([r.draws[:, :, : Ks + 1] for _, r in per_species], axis=2)     # (C, S, nsp, Ks+1)
-    alpha = np.stack([r.draws[:, :, Ks + 1:] for _, r in per_species], axis=2)     # (C, S, nsp, Ko+1)
+    alpha = np.stack([r.draws[:, :, Ks + 1: Ks + Ko + 2] for _, r in per_species], axis=2)  # (C, S, nsp, Ko+1)
+    latent = dict(beta=beta, alpha=alpha)
+    if spec.model == "occu_fp":
+        # the engine samples phi = logit(rate); the model's site is the rate itself, shape (C, S) (occu.py:146-157)
+        phi = res0.draws[:, :, Ks + Ko + 2].astype(np.float64)
+        latent[f"prob_fp_{spec.extras['fp_mode']}"] = (1.0 / (1.0 + np.exp(-phi))).astype(np.float32)
     if S:
         psi = np.stack([d.deterministic(r.draws.reshape(C * S, D), psi=True, prob_detection=False)[0]
                         for d, r in per_species], axis=-1)
@@ -192,6 +205,6 @@ def _assemble(per_species, spec, num_warmup) -> HipMCMC:
     res.draws = np.concatenate([r.draws for _, r in per_species], axis=2) if nsp > 1 else res0.draws
     # occu emits "psi" (occu.py:207); occu_rn emits "abundance" = exp(linear predictor) (occu_rn.py:192)
     first = "abundance" if spec.model == "occu_rn" else "psi"
-    return HipMCMC(res, latent=dict(beta=beta, alpha=alpha),
+    return HipMCMC(res, latent=latent,
                    deterministic={first: psi, "prob_detection": prob_detection},
                    num_warmup=num_warmup, spec_shape=spec.shape)

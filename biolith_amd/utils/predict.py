@@ -81,13 +81,19 @@ def predict(
         raise ValueError("predict(): covariate counts differ from the fitted model's coefficients")
 
     from ..engine import OccuDataset
+    from .fit import engine_options
+
+    fp_site = f"prob_fp_{spec.extras['fp_mode']}" if spec.model == "occu_fp" else None
+    if fp_site is not None:
+        rate = np.clip(np.asarray(posterior[fp_site], dtype=np.float64).reshape(n), 1e-300, 1 - 1e-16)
+        phi = np.log(rate / (1.0 - rate)).astype(np.float32)[:, None]   # the engine's coordinate: logit(rate)
 
     def run():
         handles, first, latent, y8 = [], [], [], []
         for sp in range(n_species):
             ds = OccuDataset(spec.site_covs, spec.obs_covs, spec.obs[sp:sp + 1], spec.prior_beta, spec.prior_alpha,
-                             device=device, model=spec.model, max_abundance=spec.extras.get("max_abundance", 100))
-            draws = np.concatenate([beta[:, sp, :], alpha[:, sp, :]], axis=1)
+                             device=device, model=spec.model, **engine_options(spec))
+            draws = np.concatenate([beta[:, sp, :], alpha[:, sp, :]] + ([phi] if fp_site else []), axis=1)
             first.append(ds.deterministic(draws, psi=True, prob_detection=False)[0])
             lat, yy = ds.predictive(draws, seed=(int(random_seed) + (sp << 32)) & (2 ** 64 - 1))
             latent.append(lat)
@@ -113,8 +119,15 @@ def predict(
 
     out.set_lazy("prob_detection", prob_detection)                                    # (n, J, T, N, S)
     if not rn:
-        # occu.py:229-235 with prob_fp_constant = prob_fp_unoccupied = 0:  1 - (1 - z p) = z p
-        out.set_lazy("prob_detection_fp",
-                     lambda: prob_detection() * np.stack(latent, axis=-1)[:, None].astype(np.float32))
+        def prob_detection_fp():  # occu.py:229-235
+            z = np.stack(latent, axis=-1)[:, None].astype(np.float32)
+            zp = prob_detection() * z
+            if fp_site is None:   # both rates 0:  1 - (1 - z p) = z p
+                return zp
+            f = rate.astype(np.float32).reshape((n,) + (1,) * 4)
+            f_c, f_u = (f, 0.0) if fp_site == "prob_fp_constant" else (0.0, f)
+            return 1.0 - (1.0 - zp) * (1.0 - f_c) * (1.0 - (1.0 - z) * f_u)
+
+        out.set_lazy("prob_detection_fp", prob_detection_fp)
     out.set_lazy("y", lambda: np.stack(y8, axis=-1).astype(np.int32))                 # (n, J, T, N, S)
     return rename_samples(out, site_names, obs_names)

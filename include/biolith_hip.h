@@ -81,6 +81,22 @@ int bl_dataset_create(const bl_dims *dims, const float *site_covs, const float *
 int bl_dataset_create_rn(const bl_dims *dims, const float *site_covs, const float *obs_covs,
                          const float *obs, int max_abundance, const bl_normal_prior *prior_beta,
                          const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
+/*
+ * Same for occu with a false-positive rate (models/occu.py:146-157, 229-241):
+ *   P(y=1 | z) = 1 - (1 - z p)(1 - f_c)(1 - (1 - z) f_u),  exactly one of f_c / f_u sampled:
+ *   fp_mode BL_FP_CONSTANT   = false_positives_constant=True   (site "prob_fp_constant",   prior occu.py:32)
+ *   fp_mode BL_FP_UNOCCUPIED = false_positives_unoccupied=True (site "prob_fp_unoccupied", prior occu.py:33)
+ * prior_fp is the Beta(a, b) prior of that rate (NULL = Beta(2, 5), the reference default).  The handle's
+ * parameter vector gains one trailing coordinate phi = logit(rate) (NumPyro's unconstrained space for
+ * a unit-interval site), so bl_dataset_param_dim = Ks + Ko + 3 and draws[..., D-1] is phi.
+ * Built for at most 4 covariates per side.
+ */
+typedef struct { double a, b; } bl_beta_prior;
+enum { BL_FP_CONSTANT = 1, BL_FP_UNOCCUPIED = 2 };
+int bl_dataset_create_fp(const bl_dims *dims, const float *site_covs, const float *obs_covs,
+                         const float *obs, int fp_mode, const bl_beta_prior *prior_fp,
+                         const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha,
+                         int device, bl_dataset **out);
 int bl_dataset_destroy(bl_dataset *ds);
 /* D = Ks+1 + Ko+1; theta = [beta_0..beta_Ks, alpha_0..alpha_Ko] */
 int bl_dataset_param_dim(const bl_dataset *ds, int *D);
@@ -157,6 +173,7 @@ int bl_deterministic(bl_dataset *ds, int n_draws, const float *draws, float *psi
  *            y            [n_draws][J][T][N] ~ Bernoulli(z * prob_detection)        (occu.py:229-241)
  *   occu_rn  latent = N_i [n_draws][T][N]  ~ truncated Poisson(abundance) on 0..max_abundance (occu_rn.py:194-198)
  *            y            ~ Bernoulli(1 - (1 - prob_detection)^N_i)                 (occu_rn.py:211-221)
+ *   false-positive handles: y ~ Bernoulli(1 - (1 - z p)(1 - f_c)(1 - (1 - z) f_u))   (occu.py:229-241)
  * uint8 on the host (NULL = skip).  The sample is a function of (seed, draw, period, site) only; it is
  * distributionally, not bitwise, the reference's (JAX threefry keys are not reproduced).
  */

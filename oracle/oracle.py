@@ -47,6 +47,7 @@ def lib():
             L.orc_data_destroy.argtypes = [C.c_void_p]
             L.orc_data_dim.argtypes = [C.c_void_p]
             L.orc_data_set_model.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            L.orc_data_set_fp.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
             L.orc_potential_grad.restype = C.c_double
             L.orc_potential_grad.argtypes = [C.c_void_p, dp, dp]
             L.orc_rng_streams.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
@@ -81,7 +82,7 @@ class OracleData:
     """Prepared dataset for ONE species: site_covs (N,Ks), obs_covs (N,T,J,Ko), obs (N,T,J)."""
 
     def __init__(self, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0), model="occu",
-                 max_abundance=100):
+                 max_abundance=100, fp_mode="constant", prior_fp=(2.0, 5.0)):
         X = _as_f32_f64(site_covs)
         W = _as_f32_f64(obs_covs)
         Y = _as_f32_f64(obs)
@@ -101,8 +102,13 @@ class OracleData:
         self.X, self.W, self.Y = X, W, Y
         self.prior_beta, self.prior_alpha = tuple(prior_beta), tuple(prior_alpha)
         self.model, self.max_abundance = model, int(max_abundance)
-        assert model in ("occu", "occu_rn")
+        assert model in ("occu", "occu_rn", "occu_fp")
         lib().orc_data_set_model(self._h, 1 if model == "occu_rn" else 0, int(max_abundance))
+        if model == "occu_fp":  # theta gains phi = logit(false-positive rate) as its last coordinate
+            assert fp_mode in ("constant", "unoccupied")
+            lib().orc_data_set_fp(self._h, 1 if fp_mode == "constant" else 2, float(prior_fp[0]), float(prior_fp[1]))
+            self.D += 1
+        self.fp_mode, self.prior_fp = fp_mode, tuple(prior_fp)
 
     def __del__(self):
         try:
@@ -198,9 +204,11 @@ def _bernoulli_logpmf_clamped(p, y):
 
 
 def literal_log_joint(theta, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0),
-                      clamp_z1=False):
+                      clamp_z1=False, prob_fp_constant=0.0, prob_fp_unoccupied=0.0):
     """log p(theta, y) for one species; obs (N,T,J).  ``clamp_z1`` applies numpyro's prob clamp
-    in the z=1 branch too (the C oracle does not; they differ only for |nu| > ~15.9)."""
+    in the z=1 branch too (the C oracle does not; they differ only for |nu| > ~15.9).
+    ``prob_fp_*``: the false-positive rates of occu.py:146-157 as given numbers (their own prior is
+    added by :func:`literal_log_joint_fp`)."""
     X = _as_f32_f64(site_covs)
     W = _as_f32_f64(obs_covs)
     Y = _as_f32_f64(obs)
@@ -223,8 +231,8 @@ def literal_log_joint(theta, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), pr
     y0 = np.where(finite, Y, 0.0)
     per_z = []
     for z in (0.0, 1.0):
-        p_fp = 1.0 - (1.0 - z * p) * (1.0 - 0.0) * (1.0 - (1.0 - z) * 0.0)   # occu.py:229-235
-        if z == 1.0 and not clamp_z1:
+        p_fp = 1.0 - (1.0 - z * p) * (1.0 - prob_fp_constant) * (1.0 - (1.0 - z) * prob_fp_unoccupied)   # occu.py:229-235
+        if z == 1.0 and not clamp_z1 and prob_fp_constant == 0.0:
             ly = y0 * (-np.logaddexp(0.0, -det_linear)) + (1.0 - y0) * (-np.logaddexp(0.0, det_linear))
         else:
             ly = _bernoulli_logpmf_clamped(p_fp, y0)
@@ -237,6 +245,22 @@ def literal_log_joint(theta, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), pr
         return (-0.5 * ((v - loc) / scale) ** 2 - np.log(scale) - 0.5 * np.log(2 * np.pi)).sum()
 
     return ll + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
+
+
+def literal_log_joint_fp(theta, site_covs, obs_covs, obs, fp_mode="constant", prior_fp=(2.0, 5.0),
+                         prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):
+    """log density of the false-positive model in NumPyro's unconstrained space: theta = [beta, alpha, phi],
+    rate = sigmoid(phi) ~ Beta(a, b) (occu.py:32-33,146-157), plus the log-Jacobian of the sigmoid."""
+    from scipy.special import betaln
+
+    theta = np.asarray(theta, dtype=np.float64)
+    phi = theta[-1]
+    f = 1.0 / (1.0 + np.exp(-phi))
+    kw = {"prob_fp_constant": f} if fp_mode == "constant" else {"prob_fp_unoccupied": f}
+    a, b = prior_fp
+    beta_logpdf = (a - 1.0) * np.log(f) + (b - 1.0) * np.log1p(-f) - betaln(a, b)
+    return (literal_log_joint(theta[:-1], site_covs, obs_covs, obs, prior_beta, prior_alpha, **kw)
+            + beta_logpdf + np.log(f) + np.log1p(-f))
 
 
 def literal_log_joint_rn(theta, site_covs, obs_covs, obs, max_abundance=100, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):

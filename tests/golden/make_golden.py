@@ -71,6 +71,9 @@ CASES = {
                                       deployment_days_per_site=35, session_duration=7)),
     "stacked": dict(store=False, kw=dict(n_sites=2000, n_periods=8, n_site_covs=3, n_obs_covs=3,
                                          deployment_days_per_site=28, session_duration=7)),
+    "fp_constant": dict(store=True, kw=dict(simulate_missing=True, prob_fp_constant=0.1)),   # occu.py:495-499
+    "fp_unoccupied": dict(store=True, kw=dict(n_sites=150, n_site_covs=2, n_obs_covs=2, deployment_days_per_site=49,
+                                              prob_fp_unoccupied=0.08, random_seed=11)),
     "bench_i3": dict(store=False, kw=dict(n_sites=800, n_site_covs=2, n_obs_covs=1, random_seed=45,
                                           deployment_days_per_site=23 * 7, session_duration=7)),
 }

@@ -6,7 +6,7 @@ import pandas as pd
 import pytest
 
 import oracle
-from biolith_amd.distributions import Normal
+from biolith_amd.distributions import Beta, Normal
 from biolith_amd.evaluation import diagnostics, effective_sample_size, split_gelman_rubin, summary
 from biolith_amd.models import occu
 from biolith_amd.regression import AbstractRegression, LinearRegression
@@ -68,10 +68,19 @@ def test_occu_validates_like_reference():
         occu(g["site_covs"][:10], g["obs_covs"], obs=g["obs"])
     with pytest.raises(AssertionError, match="cannot both be True"):
         occu(g["site_covs"], g["obs_covs"], obs=g["obs"], false_positives_constant=True, false_positives_unoccupied=True)
-    for kw in (dict(coords=np.zeros((64, 2))), dict(false_positives_constant=True), dict(site_random_effects=True),
+    for kw in (dict(coords=np.zeros((64, 2))), dict(site_random_effects=True),
                dict(obs_random_effects=True), dict(regressor_occ=AbstractRegression)):
         with pytest.raises(NotImplementedError):
             occu(g["site_covs"], g["obs_covs"], obs=g["obs"], **kw)
+    # false positives (occu.py:146-157): one species, Beta prior on the rate
+    fp = occu(g["site_covs"], g["obs_covs"], obs=g["obs"], false_positives_constant=True)
+    assert fp.model == "occu_fp" and fp.extras == dict(fp_mode="constant", prior_fp=(2.0, 5.0))
+    fu = occu(g["site_covs"], g["obs_covs"], obs=g["obs"], false_positives_unoccupied=True, prior_prob_fp_unoccupied=Beta(1.0, 9.0))
+    assert fu.extras == dict(fp_mode="unoccupied", prior_fp=(1.0, 9.0))
+    with pytest.raises(NotImplementedError, match="Beta"):
+        occu(g["site_covs"], g["obs_covs"], obs=g["obs"], false_positives_constant=True, prior_prob_fp_constant=Normal())
+    with pytest.raises(NotImplementedError, match="shared across species"):
+        occu(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]), false_positives_constant=True)
     two = occu(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]))
     assert two.n_species == 2 and two.shape["S"] == 2  # the species plate is sampled species by species
     assert occu(g["site_covs"], g["obs_covs"], obs=g["obs"], prior_beta=Normal(0.5, 2.0)).prior_beta == (0.5, 2.0)

@@ -13,7 +13,8 @@ def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
 
 
-CASES = ["default", "missing", "missing_3periods", "small_3x3", "seed7_2x1", "cfg2", "stacked", "bench_i3"]
+CASES = ["default", "missing", "missing_3periods", "small_3x3", "seed7_2x1", "cfg2", "stacked", "bench_i3", "fp_constant",
+         "fp_unoccupied"]
 
 
 @pytest.mark.parametrize("name", CASES)
