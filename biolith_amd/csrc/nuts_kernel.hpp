@@ -39,13 +39,19 @@
 // In-kernel phase stamps (guide section 7 "In-kernel stamps"): diagnostic builds only
 // (make stamps); the shipped kernel executes none of this.
 #ifdef BL_STAMPS
-#define BL_STAMP_DECL long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long st_prev = (long long)clock64(); long long st_rt0 = (long long)wall_clock64(); long long st_spins = 0;
+#define BL_STAMP_DECL long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long st_prev = (long long)clock64(); long long st_rt0 = (long long)wall_clock64(); long long st_spins = 0; \
+    long long st_kn[3] = {0, 0, 0}, st_kc[3] = {0, 0, 0}; int st_kind = 0;
 #define BL_STAMP(i) { const long long st_now = (long long)clock64(); st_acc[i] += st_now - st_prev; st_prev = st_now; }
+// critical-control time split by what the tick decided: 0 next leaf of the subtree, 1 next doubling, 2 transition end / init
+#define BL_STAMP_KIND(k) st_kind = (k);
+#define BL_STAMP_CRIT { const long long st_now = (long long)clock64(); st_kn[st_kind]++; st_kc[st_kind] += st_now - st_prev; }
 #define BL_COUNT_SPINS(n) st_spins += (long long)(n);
 #else
 #define BL_COUNT_SPINS(n)
 #define BL_STAMP_DECL
 #define BL_STAMP(i)
+#define BL_STAMP_KIND(k)
+#define BL_STAMP_CRIT
 #endif
 
 // Rarely-read launch constants and output pointers live in device memory (keeps the kernel's
@@ -412,8 +418,10 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
             const float cg = act ? (-(float)acc + pg) : 0.0f;
 
             bool new_transition = false;
+            BL_STAMP_KIND(0)
             if (flag == 0) {
                 if (init_pending) {
+                    BL_STAMP_KIND(2)
                     // initial evaluation done
                     const double Un = -ll_tot + (double)(0.5f * bl_wave_sum(pe2)) + prior_const;
                     sv[SV_TH * 64] = cz; sv[SV_GR * 64] = cg;
@@ -455,6 +463,7 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
                         cz = cz + epsdir * minv * rh;
                     } else {
                         // ---------- subtree complete: extend the tree edge, tree-level U-turn ----------
+                        BL_STAMP_KIND(1)
                         pend_end = true; pend_sturn = sturn; pend_sdiv = sdiv; pend_snprop = snprop;
                         const int e_out = going_right ? SV_ZR : SV_ZL;  // edge this subtree extends (z, r, g slots follow)
                         const int e_in = going_right ? SV_ZL : SV_ZR;   // opposite edge
@@ -462,7 +471,8 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
                         const float r_other = sv[(e_in + 1) * 64];
                         const float rsum = sv[SV_RSUM * 64] + srsum;
                         sv[SV_RSUM * 64] = rsum;
-                        const bool turning = bl_is_turning(minv, going_right ? r_other : cr, going_right ? cr : r_other, rsum, D);
+                        // numpyro _combine_tree (biased): turning = new_tree.turning | _is_turning(edges, r_sum)
+                        const bool turning = sturn || bl_is_turning(minv, going_right ? r_other : cr, going_right ? cr : r_other, rsum, D);
                         depth++;
                         if (depth < p.max_depth && !turning && !sdiv) {
                             // next doubling
@@ -475,6 +485,7 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
                             cz = ez + epsdir * minv * rh;
                         } else {
                             // ---------------- transition complete (nothing left to overlap with) ----------------
+                            BL_STAMP_KIND(2)
                             run_deferred();
                             const int nprop = ss->nprop;
                             const float accp = ss->sumacc * bl_rcp((float)nprop);
@@ -568,6 +579,7 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
                     cold->xcd_local[chain] = local ? 1 : 0;
                 }
             }
+            BL_STAMP_CRIT
             BL_STAMP(4)
         }
         __syncthreads();
@@ -580,6 +592,8 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
         cold->dbg[8] = (long long)epoch;
         cold->dbg[9] = (long long)wall_clock64() - st_rt0;
         cold->dbg[10] = st_spins;
+        for (int i = 0; i < 3; i++) { cold->dbg[11 + i] = st_kn[i]; }
+        cold->dbg[14] = st_kc[0]; cold->dbg[15] = st_kc[1];  // kind 2 = critical total - these two
     }
 #endif
 }

@@ -33,6 +33,10 @@ def main():
                   f"cycles/tick {tot / max(ticks, 1):.0f} clock {mhz:.0f} MHz us/tick {r.kernel_ms * 1e3 / max(ticks, 1):.2f} l2local_chains {r.chains_l2_local} poll-rounds/tick {int(c[10]) / max(ticks, 1) + 1:.2f}")
             for n, v in zip(NAMES, c[:8]):
                 print(f"    {n:26s} {v / max(ticks, 1):8.0f} cyc  {100.0 * v / tot:5.1f} %")
+            kn = c[11:14].astype(float)
+            kc = np.array([c[14], c[15], c[4] - c[14] - c[15]], dtype=float)
+            for name, n_, cyc in zip(("next leaf of the subtree", "next doubling", "transition end / init"), kn, kc):
+                print(f"    critical control, {name:26s}: {int(n_):7d} ticks ({100 * n_ / max(ticks, 1):4.1f} %), {cyc / max(n_, 1):7.0f} cyc each")
 
 
 if __name__ == "__main__":
