@@ -39,7 +39,7 @@ static int bl_fail(int code, const char *fmt, ...)
     } while (0)
 
 // ------------------------------------------- kernel instantiation dispatch ----
-#ifdef BL_STAMPS /* diagnostic build: one instantiation */
+#if defined(BL_STAMPS) || defined(BL_ONLY33) /* diagnostic / experimental builds: one instantiation */
 #define BL_KK_LIST(X) X(3, 3)
 #else
 #define BL_K_LIST(X, a) X(a, 1) X(a, 2) X(a, 3) X(a, 4) X(a, 8) X(a, 16)
@@ -163,7 +163,7 @@ struct bl_dataset {
     float *d_wraw = nullptr;
     // ---- last NUTS launch ----
     bool in_flight = false, have_run = false;
-    int C = 0, S = 0, W = 0, k = 0, nloc = 0, lds_ld = 0, lds_bytes = 0, staged = 0, nvp = 0;
+    int C = 0, S = 0, W = 0, k = 0, nloc = 0, lds_ld = 0, lds_bytes = 0, staged = 0, nvp = 0, ncw = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *d_run = nullptr;  // one slab for all run buffers
@@ -495,16 +495,23 @@ extern "C" int bl_dataset_param_dim(const bl_dataset *ds, int *D)
 // Workgroups per chain / LDS staging decision.  One site per thread is the latency optimum
 // (DESIGN.md "geometry"); fall back to several sites per thread, then to un-staged HBM rows.
 static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k_out, int *nloc_out, int *ld_out,
-                            int *lds_bytes_out, int *staged_out)
+                            int *lds_bytes_out, int *staged_out, int *ncw_out)
 {
     const int N = ds->dims.n_sites;
     // chains are dealt to the 8 XCDs (32 CUs each); a chain's k workgroups share one XCD, one per CU
     const int per_xcd = ((chains > 0 ? chains : 1) + 7) / 8;
     int kmax = 32 / per_xcd;
     if (kmax < 1) kmax = 1;
-    // a lane evaluates a PAIR of sites (packed f32 math): one pair per thread is the latency optimum
-    // occu_rn: one site per lane on 3 compute waves
-    const int per_wg = ds->model == 1 ? BL_CWAVES_RN * 64 : 2 * BL_CTHREADS;
+    // occu / false positives: a lane evaluates a PAIR of sites (packed f32 math); one pair per lane is the
+    // latency optimum.  With 3 compute waves every wave, the control wave included, owns a SIMD; that is
+    // used whenever one pair per lane still fits the chain's workgroup budget, else 4 compute waves.
+    // occu_rn: one site per lane on 3 compute waves.
+    int ncw = BL_CWAVES_RN, per_wg = BL_CWAVES_RN * 64;
+    if (ds->model != 1) {
+        ncw = ((N + 2 * 3 * 64 - 1) / (2 * 3 * 64) <= kmax) ? 3 : 4;
+        if (const char *e = getenv("BIOLITH_HIP_CWAVES")) { const int v = atoi(e); if (v == 3 || v == 4) ncw = v; } // A/B knob
+        per_wg = 2 * ncw * 64;
+    }
     int k = want_k > 0 ? want_k : (N + per_wg - 1) / per_wg;
     if (k > kmax) k = kmax;
     if (k < 1) k = 1;
@@ -520,7 +527,8 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     if (!ok && want_k <= 0)
         for (int kk = k + 1; kk <= kmax && !ok; kk++) { ok = fits(kk, &nloc); if (ok) k = kk; }
     if (!ok) fits(k, &nloc);
-    *k_out = k; *nloc_out = nloc; *ld_out = stride; *staged_out = ok ? 1 : 0;
+    if (!ok && ds->model == 0) ncw = 4; // HBM-row form is built for 4 compute waves only
+    *k_out = k; *nloc_out = nloc; *ld_out = stride; *staged_out = ok ? 1 : 0; *ncw_out = ncw;
     *lds_bytes_out = ok ? BL_OFF_DATA + ((nloc + 1) / 2) * stride * 4 : BL_OFF_DATA;
 }
 
@@ -557,10 +565,10 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
     int rc = set_device(ds);
     if (rc) return rc;
     const int D = ds->D;
-    int k, nloc, ld, lds_bytes, can_stage;
-    choose_geometry(ds, 1, 0, &k, &nloc, &ld, &lds_bytes, &can_stage);
+    int k, nloc, ld, lds_bytes, can_stage, ncw;
+    choose_geometry(ds, 1, 0, &k, &nloc, &ld, &lds_bytes, &can_stage, &ncw);
     const int use_staged = staged && can_stage;
-    if (!use_staged) lds_bytes = BL_OFF_DATA;
+    if (!use_staged) { lds_bytes = BL_OFF_DATA; ncw = 4; }
     std::vector<float> th32((size_t)B * D);
     for (size_t i = 0; i < th32.size(); i++) th32[i] = (float)theta[i];
     float *d_th32 = nullptr;
@@ -577,6 +585,7 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
     p.dd = ds->dd; p.k = k; p.nloc = nloc; p.rec_stride = ld; p.B = B; p.theta = d_th32; p.partial = d_partial;
     p.max_abundance = ds->max_abundance;
     p.fp_z1 = ds->fp_mode == BL_FP_CONSTANT ? 1 : 0;
+    p.ncw = ncw;
     if (ds->model != 0 && !use_staged)
         return bl_fail(BL_ERR_UNSUPPORTED, "occu_rn / false-positive models need the LDS-staged path (slice too large, or staged=0 requested)");
     const int lrc = ds->kern->logp(&p, k, lds_bytes, use_staged, ds->model, nullptr);
@@ -606,7 +615,8 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     if (rc) return rc;
 
     int k, nloc, ld, lds_bytes, staged;
-    choose_geometry(ds, C, cfg->wgs_per_chain, &k, &nloc, &ld, &lds_bytes, &staged);
+    int ncw;
+    choose_geometry(ds, C, cfg->wgs_per_chain, &k, &nloc, &ld, &lds_bytes, &staged, &ncw);
     const int nvp = (D + 4 <= 16) ? 16 : (D + 4 <= 32 ? 32 : 64);
 
     // ---- (re)allocate run slab ----
@@ -680,6 +690,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.max_depth = max_depth;
     p.max_abundance = ds->max_abundance;
     p.fp_z1 = ds->fp_mode == BL_FP_CONSTANT ? 1 : 0;
+    p.ncw = ncw;
     p.xchg = ds->d_xchg;
     p.cold = d_cold;
     p.spin_limit = 1u << 18;
@@ -707,7 +718,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     if (lrc != 0) return bl_fail(BL_ERR_NO_DEVICE, "NUTS kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     BL_HIP(hipEventRecord(ds->ev1, st));
     ds->stream = st; ds->in_flight = true; ds->have_run = true;
-    ds->C = C; ds->S = S; ds->W = W; ds->k = k; ds->nloc = nloc; ds->lds_ld = ld; ds->lds_bytes = lds_bytes; ds->staged = staged; ds->nvp = nvp;
+    ds->C = C; ds->S = S; ds->W = W; ds->k = k; ds->nloc = nloc; ds->lds_ld = ld; ds->lds_bytes = lds_bytes; ds->staged = staged; ds->nvp = nvp; ds->ncw = ncw;
     return BL_OK;
 }
 
@@ -805,7 +816,7 @@ extern "C" int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads
     if (!ds) return bl_fail(BL_ERR_INVALID, "NULL argument");
     if (!ds->have_run) return bl_fail(BL_ERR_INVALID, "no NUTS launch on this handle");
     if (wgs_per_chain) *wgs_per_chain = ds->k;
-    if (threads_per_wg) *threads_per_wg = ds->model == 1 ? BL_THREADS_RN : BL_THREADS;
+    if (threads_per_wg) *threads_per_wg = 64 * (ds->ncw + 1);
     if (lds_bytes) *lds_bytes = ds->lds_bytes;
     if (lds_staged) *lds_staged = ds->staged;
     if (chains_on_l2_local_exchange) {

@@ -25,38 +25,48 @@ static int bl_launch(K kernel, const P *p, int grid, int threads, int lds_bytes,
     return (int)hipGetLastError();
 }
 
+// Instantiations (CW = compute waves per workgroup, chosen by the host's choose_geometry):
+//   occu, LDS-staged: CW 3 and 4;  occu, HBM rows: CW 4;  occu_rn: CW 3;  false positives: CW 3 and 4.
+#define BL_PICK(KERNEL, P, LDS, MODEL, CW) bl_launch(KERNEL<BL_KS, BL_KO, LDS, MODEL, CW>, P, grid, 64 * (CW + 1), lds_bytes, stream)
+
 extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int grid, int lds_bytes, int staged, int model, hipStream_t stream)
 {
     if (model == 1) {
 #if BL_HAVE_RN
-        if (staged) return bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, 1>, p, grid, BL_THREADS_RN, lds_bytes, stream);
+        if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 1, 3);
 #endif
         return (int)hipErrorNotSupported;
     }
     if (model == 2) {
 #if BL_HAVE_RN
-        if (staged) return bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, 2>, p, grid, BL_THREADS, lds_bytes, stream);
+        if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 2, 3);
+        if (staged && p->ncw == 4) return BL_PICK(bl_nuts_kernel, p, true, 2, 4);
 #endif
         return (int)hipErrorNotSupported;
     }
-    if (staged) return bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, 0>, p, grid, BL_THREADS, lds_bytes, stream);
-    return bl_launch(bl_nuts_kernel<BL_KS, BL_KO, false, 0>, p, grid, BL_THREADS, lds_bytes, stream);
+    if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 0, 3);
+    if (staged && p->ncw == 4) return BL_PICK(bl_nuts_kernel, p, true, 0, 4);
+    if (!staged && p->ncw == 4) return BL_PICK(bl_nuts_kernel, p, false, 0, 4);
+    return (int)hipErrorNotSupported;
 }
 
 extern "C" int BL_NAME(bl_launch_logp, BL_KS, BL_KO)(const BlLogpParams *p, int grid, int lds_bytes, int staged, int model, hipStream_t stream)
 {
     if (model == 1) {
 #if BL_HAVE_RN
-        if (staged) return bl_launch(bl_logp_kernel<BL_KS, BL_KO, true, 1>, p, grid, BL_THREADS_RN, lds_bytes, stream);
+        if (staged && p->ncw == 3) return BL_PICK(bl_logp_kernel, p, true, 1, 3);
 #endif
         return (int)hipErrorNotSupported;
     }
     if (model == 2) {
 #if BL_HAVE_RN
-        if (staged) return bl_launch(bl_logp_kernel<BL_KS, BL_KO, true, 2>, p, grid, BL_THREADS, lds_bytes, stream);
+        if (staged && p->ncw == 3) return BL_PICK(bl_logp_kernel, p, true, 2, 3);
+        if (staged && p->ncw == 4) return BL_PICK(bl_logp_kernel, p, true, 2, 4);
 #endif
         return (int)hipErrorNotSupported;
     }
-    if (staged) return bl_launch(bl_logp_kernel<BL_KS, BL_KO, true, 0>, p, grid, BL_THREADS, lds_bytes, stream);
-    return bl_launch(bl_logp_kernel<BL_KS, BL_KO, false, 0>, p, grid, BL_THREADS, lds_bytes, stream);
+    if (staged && p->ncw == 3) return BL_PICK(bl_logp_kernel, p, true, 0, 3);
+    if (staged && p->ncw == 4) return BL_PICK(bl_logp_kernel, p, true, 0, 4);
+    if (!staged && p->ncw == 4) return BL_PICK(bl_logp_kernel, p, false, 0, 4);
+    return (int)hipErrorNotSupported;
 }

@@ -9,13 +9,14 @@ struct BlLogpParams {
     int k, nloc, rec_stride;
     int max_abundance;   // occu_rn only
     int fp_z1;           // false-positive model only (see BlNutsParams)
+    int ncw;             // compute waves per workgroup: selects the CW instantiation (host side)
     int B;
     const float *theta;  // [B][D] float32 view of the caller's double theta
     double *partial;     // [B][k][64]: c < D grad of log-lik, c == D log-lik
 };
 
-template <int KS, int KO, bool LDS, int MODEL>
-__global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_logp_kernel(const BlLogpParams p)
+template <int KS, int KO, bool LDS, int MODEL, int CW>
+__global__ void __launch_bounds__(64 * (CW + 1)) bl_logp_kernel(const BlLogpParams p)
 {
     const int member = blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -26,7 +27,7 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_logp_kernel(const B
     const float *grows = nullptr;
     int ld = p.rec_stride;
     if constexpr (LDS) {
-        bl_stage_records(p.dd.rows, p.dd.n_stride, s0, cnt, p.dd.T, p.dd.J, KS, KO, p.rec_stride, BlGeom<MODEL>::THREADS);
+        bl_stage_records(p.dd.rows, p.dd.n_stride, s0, cnt, p.dd.T, p.dd.J, KS, KO, p.rec_stride, 64 * (CW + 1));
     } else {
         grows = p.dd.rows + s0;
         ld = p.dd.n_stride;
@@ -39,14 +40,14 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_logp_kernel(const B
         if (wave == 0 && lane < D) sh_coef[my_pos] = p.theta[(size_t)b * D + lane];
         __syncthreads();
         if (wave > 0) { // compute waves, exactly as in the NUTS kernel
-            bl_phase_a<KS, KO, LDS, MODEL>(tid - 64, wave - 1, grows, ld, cnt, p.dd.T, p.dd.J, p.max_abundance, p.fp_z1);
+            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, p.dd.T, p.dd.J, p.max_abundance, p.fp_z1);
         }
         __syncthreads();
         if (wave == 0) {
             const float *part = bl_lds_f(BL_OFF_PART);
             double acc = 0.0;
 #pragma unroll
-            for (int w = 0; w < BlGeom<MODEL>::CWAVES; w++) acc += (double)part[w * BL_PART_STRIDE + my_pos];
+            for (int w = 0; w < CW; w++) acc += (double)part[w * BL_PART_STRIDE + my_pos];
             double *out = p.partial + ((size_t)b * p.k + member) * 64;
             if (lane <= D) out[lane] = acc;
         }

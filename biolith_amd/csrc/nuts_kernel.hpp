@@ -87,6 +87,7 @@ struct BlNutsParams {
     int nloc;                      // sites per workgroup
     int rec_stride;                // floats per LDS pair record
     int nvp;                       // granules per workgroup record: 16, 32 or 64 (>= D+4)
+    int ncw;                       // compute waves per workgroup: selects the CW instantiation (host side)
     int fp_z1;                     // MODEL 2: 1 = the false-positive rate also acts on occupied sites ("constant")
     int max_depth;
     int max_abundance;             // occu_rn only (occu_rn.py:26)
@@ -139,6 +140,17 @@ __device__ __forceinline__ bool bl_is_turning(float minv, float rl, float rr, fl
     return (dl <= 0.0f) || (dr <= 0.0f);
 }
 
+// Velocity-Verlet pieces, written once so that the speculative and the deciding code paths round identically:
+// end-of-leaf momentum r' = r_half - (eps/2) g', and the start of the next leaf from (z, r, g):
+// r_half = r - (eps/2) g ,  z' = z + eps M^-1 r_half        (epsdir = +-eps)
+__device__ __forceinline__ float bl_leaf_momentum(float rh, float epsdir, float g) { return fmaf(-0.5f * epsdir, g, rh); }
+__device__ __forceinline__ void bl_next_leaf(float z, float r, float g, float epsdir, float minv, float &rh_out, float &z_out)
+{
+    const float rh = fmaf(-0.5f * epsdir, g, r);
+    rh_out = rh;
+    z_out = fmaf(epsdir * minv, rh, z);
+}
+
 __device__ __forceinline__ unsigned bl_xcc_id()
 {
     unsigned x;
@@ -151,8 +163,8 @@ __device__ __forceinline__ unsigned long long bl_poll_load(const unsigned char *
     return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(base + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int KS, int KO, bool LDS, int MODEL>
-__global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const BlNutsParams p)
+template <int KS, int KO, bool LDS, int MODEL, int CW>
+__global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsParams p)
 {
     // XCD-aware mapping (speed only; see header): label = b % 8 names a set of blocks that share an XCD
     const int label = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -167,7 +179,7 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
     const float *grows = nullptr;
     int ld = p.rec_stride;
     if constexpr (LDS) {
-        bl_stage_records(p.rows, p.n_stride, s0, cnt, T, J, KS, KO, p.rec_stride, BlGeom<MODEL>::THREADS);
+        bl_stage_records(p.rows, p.n_stride, s0, cnt, T, J, KS, KO, p.rec_stride, 64 * (CW + 1));
     } else {
         grows = p.rows + s0;
         ld = p.n_stride;
@@ -289,25 +301,207 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
     };
 
     unsigned epoch = 0;
+    // Result of the last exchange, waiting for its decisions (made while the compute waves already
+    // evaluate the position those decisions are EXPECTED to choose -- see "speculative position" below).
+    bool have_pending = false, p_timed_out = false;
+    double p_acc = 0.0;                 // lane d: d log-lik / d theta_d summed over the chain's workgroups; lane D: log-lik
+    float p_cg = 0.f, p_pe2 = 0.f;      // gradient of the potential / twice the prior energy at the evaluated position
+    float cz_spec = 0.f;                // position written to LDS for the evaluation in flight
+    int flag = 0;
     BL_STAMP_DECL
     while (true) {
+        bool redo = false; // the evaluation in flight is not the one the sampler needs next
         if (wave > 0) {
             // ------------------------------------- phase A: compute waves, site log-lik ----
-            bl_phase_a<KS, KO, LDS, MODEL>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_z1);
-        } else {
-            run_deferred(); // overlaps phase A
+            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_z1);
+        } else if (have_pending) {
+            have_pending = false;
+            const double acc = p_acc;
+            const float cg = p_cg, pe2 = p_pe2;
+            const double ll_tot = bl_readlane_d(acc, D);
+            const bool abort_req = bl_readlane_d(acc, D + 1) != 0.0;
+            flag = 0;
+            if (p_timed_out) flag = 4;     // BL_ERR_TIMEOUT
+            else if (abort_req) flag = 5;  // BL_ERR_ABORTED
+            bool new_transition = false;
+            BL_STAMP_KIND(0)
+            if (flag == 0) {
+                if (init_pending) {
+                    BL_STAMP_KIND(2)
+                    // initial evaluation done
+                    const double Un = -ll_tot + (double)(0.5f * bl_wave_sum(pe2)) + prior_const;
+                    sv[SV_TH * 64] = cz; sv[SV_GR * 64] = cg;
+                    ss->U = Un;
+                    init_pending = false;
+                    new_transition = true;
+                } else {
+                    // ------- CRITICAL: finish the leaf (_build_basetree), decide where the next one goes -------
+                    const float cr = bl_leaf_momentum(rh, epsdir, cg);
+                    float s_prior = pe2, s_kin = minv * cr * cr;
+                    bl_low_sum2(s_prior, s_kin, D);
+                    const double Un = -ll_tot + (double)(0.5f * s_prior) + prior_const;
+                    const double Kn = (double)(0.5f * s_kin);
+                    double dE = (Un + Kn) - E0;
+                    if (dE != dE) dE = (double)INFINITY;
+                    const int leaf_idx = snprop;
+                    sdiv = dE > 1000.0;
+                    srsum = (leaf_idx == 0) ? cr : srsum + cr;
+                    snprop = leaf_idx + 1;
+                    // its multinomial / weight bookkeeping is deferred
+                    pend = true; pend_first = (leaf_idx == 0); pend_end = false;
+                    pend_dE = (float)dE; pend_U = Un; pend_z = cz; pend_g = cg;
+                    // checkpointed U-turn (_leaf_idx_to_ckpt_idxs / _is_iterative_turning)
+                    const int idx_max = __popc((unsigned)leaf_idx >> 1);
+                    const int idx_min = idx_max - (int)__builtin_ctz(~(unsigned)leaf_idx) + 1;
+                    if ((leaf_idx & 1) == 0) {
+                        sh_ckr[idx_max * 64 + lane] = cr;
+                        sh_ckrs[idx_max * 64 + lane] = srsum;
+                    } else {
+                        for (int i = idx_max; i >= idx_min && !sturn; i--) {
+                            const float ck = sh_ckr[i * 64 + lane];
+                            const float srs = srsum - sh_ckrs[i * 64 + lane] + ck;
+                            sturn = bl_is_turning(minv, ck, cr, srs, D);
+                        }
+                    }
+                    if (snprop < (1 << depth) && !sturn && !sdiv) {
+                        // next leaf continues from this one
+                        bl_next_leaf(cz, cr, cg, epsdir, minv, rh, cz);
+                    } else {
+                        // ---------- subtree complete: extend the tree edge, tree-level U-turn ----------
+                        BL_STAMP_KIND(1)
+                        pend_end = true; pend_sturn = sturn; pend_sdiv = sdiv; pend_snprop = snprop;
+                        const int e_out = going_right ? SV_ZR : SV_ZL;  // edge this subtree extends (z, r, g slots follow)
+                        const int e_in = going_right ? SV_ZL : SV_ZR;   // opposite edge
+                        sv[e_out * 64] = cz; sv[(e_out + 1) * 64] = cr; sv[(e_out + 2) * 64] = cg;
+                        const float r_other = sv[(e_in + 1) * 64];
+                        const float rsum = sv[SV_RSUM * 64] + srsum;
+                        sv[SV_RSUM * 64] = rsum;
+                        // numpyro _combine_tree (biased): turning = new_tree.turning | _is_turning(edges, r_sum)
+                        const bool turning = sturn || bl_is_turning(minv, going_right ? r_other : cr, going_right ? cr : r_other, rsum, D);
+                        depth++;
+                        if (depth < p.max_depth && !turning && !sdiv) {
+                            // next doubling
+                            going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
+                            epsdir = going_right ? eps : -eps;
+                            snprop = 0; sturn = false; sdiv = false;
+                            const int e = going_right ? SV_ZR : SV_ZL;
+                            const float ez = sv[e * 64], er = sv[(e + 1) * 64], eg = sv[(e + 2) * 64];
+                            bl_next_leaf(ez, er, eg, epsdir, minv, rh, cz);
+                        } else {
+                            // ---------------- transition complete (nothing left to overlap with) ----------------
+                            BL_STAMP_KIND(2)
+                            run_deferred();
+                            const int nprop = ss->nprop;
+                            const float accp = ss->sumacc * bl_rcp((float)nprop);
+                            const float th = sv[SV_ZP * 64];
+                            const double U = ss->Up;
+                            sv[SV_TH * 64] = th; sv[SV_GR * 64] = sv[SV_GP * 64];
+                            ss->U = U;
+                            const int it = ss->it;
+                            if (it < W) {
+                                ss->nleap_w += nprop;
+                                // warmup_adapter.update_fn: dual averaging (t0=10, kappa=.75, gamma=.05)
+                                const float g = cold->target_accept - accp;
+                                const int da_t = ss->da_t + 1;
+                                const float tt = (float)da_t;
+                                const float rt10 = bl_rcp(tt + 10.0f);
+                                const float da_gavg = (1.0f - rt10) * ss->da_gavg + g * rt10;
+                                const float da_xt = ss->da_prox - __builtin_amdgcn_sqrtf(tt) * 20.0f * da_gavg;
+                                const float wgt = __builtin_amdgcn_exp2f(-0.75f * __builtin_amdgcn_logf(tt));
+                                const float da_xavg = (1.0f - wgt) * ss->da_xavg + wgt * da_xt;
+                                eps = bl_exp((it == W - 1) ? da_xavg : da_xt);
+                                eps = fminf(fmaxf(eps, 1.1754944e-38f), 3.4028235e+38f);
+                                ss->da_t = da_t; ss->da_gavg = da_gavg; ss->da_xt = da_xt; ss->da_xavg = da_xavg;
+                                int win_idx = ss->win_idx;
+                                const bool middle = win_idx > 0 && win_idx < cold->nwin - 1;
+                                if (middle) {
+                                    const int wf_n = ss->wf_n + 1;
+                                    const float wf_mean0 = sv[SV_WFMEAN * 64];
+                                    const float dpre = th - wf_mean0;
+                                    const float wf_mean = wf_mean0 + dpre * bl_rcp((float)wf_n);
+                                    sv[SV_WFMEAN * 64] = wf_mean;
+                                    sv[SV_WFM2 * 64] += dpre * (th - wf_mean);
+                                    ss->wf_n = wf_n;
+                                }
+                                const bool at_end = it == cold->win_end[win_idx];
+                                if (at_end) ss->win_idx = win_idx + 1;
+                                if (at_end && middle) {
+                                    const float n = (float)ss->wf_n;
+                                    const float var = sv[SV_WFM2 * 64] * bl_rcp(n - 1.0f), rn5 = bl_rcp(n + 5.0f);
+                                    minv = act ? (n * rn5 * var + 1e-3f * 5.0f * rn5) : 0.0f;
+                                    sv[SV_WFMEAN * 64] = 0.f; sv[SV_WFM2 * 64] = 0.f; ss->wf_n = 0;
+                                    ss->da_xt = 0.f; ss->da_xavg = 0.f; ss->da_gavg = 0.f; ss->da_t = 0;
+                                    ss->da_prox = bl_log(10.0f * eps);
+                                }
+                            } else {
+                                ss->nleap_s += nprop;
+                                if (member == 0) {
+                                    const size_t s = (size_t)chain * S + (it - W);
+                                    if (act) cold->draws[s * D + lane] = th;
+                                    if (lane == 0) {
+                                        cold->num_steps[s] = nprop;
+                                        cold->accept_prob[s] = accp;
+                                        cold->diverging[s] = pend_sdiv ? 1 : 0;
+                                        cold->potential[s] = (float)U;
+                                    }
+                                }
+                            }
+                            ss->it = it + 1;
+                            if (it + 1 >= total) flag = 1; // done
+                            else new_transition = true;
+                        }
+                    }
+                }
+                if (new_transition) {
+                    // sample momentum r = N(0,1)/sqrt(M^-1); start a fresh tree and its first doubling
+                    const float th = sv[SV_TH * 64], gr = sv[SV_GR * 64];
+                    const double U = ss->U;
+                    const float z01 = bl_rng_normal(rng_d);
+                    const float r0 = act ? z01 * __builtin_amdgcn_rsqf(minv) : 0.0f;
+                    E0 = U + (double)(0.5f * bl_wave_sum(minv * r0 * r0));
+                    sv[SV_ZL * 64] = th; sv[SV_RL * 64] = r0; sv[SV_GL * 64] = gr;
+                    sv[SV_ZR * 64] = th; sv[SV_RR * 64] = r0; sv[SV_GRR * 64] = gr;
+                    sv[SV_ZP * 64] = th; sv[SV_GP * 64] = gr; sv[SV_RSUM * 64] = r0;
+                    ss->Up = U; ss->wt = 0.f; ss->sumacc = 0.f; ss->nprop = 0;
+                    depth = 0;
+                    going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
+                    epsdir = going_right ? eps : -eps;
+                    snprop = 0; sturn = false; sdiv = false;
+                    bl_next_leaf(th, r0, gr, epsdir, minv, rh, cz);
+                }
+            }
+            if (flag != 0 && member == 0) {
+                if (flag > 1 && lane == 0) atomicMax(cold->status, flag);
+                if (act) cold->inv_mass[chain * D + lane] = minv;
+                if (lane == 0) {
+                    cold->step_size[chain] = eps;
+                    cold->nleap[chain * 2 + 0] = ss->nleap_w;
+                    cold->nleap[chain * 2 + 1] = ss->nleap_s;
+                    cold->xcd_local[chain] = local ? 1 : 0;
+                }
+            }
+            // was the position being evaluated right now the one just chosen?  (bit-equal or redo: correctness
+            // never depends on the guess)
+            redo = flag != 0 || __any(act && !(cz == cz_spec));
+            if (flag == 0) run_deferred(); // this leaf's proposal / weight bookkeeping, still under phase A
+            BL_STAMP_CRIT
             BL_STAMP(0)
         }
         __syncthreads();
         BL_STAMP(1)
 
-        if (wave == 0) {
+        if (wave == 0 && redo) {
+            // the decisions chose another position (transition end, U-turn, divergence, ...) or the run is over:
+            // publish nothing, hand the compute waves the right position
+            if (act) sh_coef[my_pos] = cz;
+            if (lane == 0) sh_flag[0] = flag;
+        } else if (wave == 0) {
             epoch++;
             // ---------------------------------- workgroup partial (fixed wave order) ----
             const float *part = bl_lds_f(BL_OFF_PART) + my_pos;
             float comp = 0.0f; // lanes < D: their gradient component; lane D: the log-lik
 #pragma unroll
-            for (int w = 0; w < BlGeom<MODEL>::CWAVES; w++) comp += part[w * BL_PART_STRIDE];
+            for (int w = 0; w < CW; w++) comp += part[w * BL_PART_STRIDE];
             if (lane > D) comp = 0.0f;
             if (lane == D + 1 && member == 0 && (epoch & 255u) == 0u)
                 comp = (__hip_atomic_load(cold->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1.0f : 0.0f;
@@ -390,16 +584,10 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
                 acc += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
             }
             BL_STAMP(3)
-            const double ll_tot = bl_readlane_d(acc, D);
-            const bool abort_req = bl_readlane_d(acc, D + 1) != 0.0;
             if (epoch == 1u && p.allow_local) {
                 const double sx = bl_readlane_d(acc, D + 2), sxx = bl_readlane_d(acc, D + 3);
                 local = ((double)p.k * sxx == sx * sx); // exact: small integers
             }
-            int flag = 0;
-            if (timed_out) flag = 4;       // BL_ERR_TIMEOUT
-            else if (abort_req) flag = 5;  // BL_ERR_ABORTED
-
             // ------------------------------------------------ potential at cz (lane d) ----
             // prior of lane d: pe2 = 2 x its energy, pg = d energy / d theta_d
             //   Normal(loc, scale):            pe2 = (theta-loc)^2 / scale^2 ,  pg = (theta-loc) / scale^2
@@ -416,170 +604,35 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
                 }
             }
             const float cg = act ? (-(float)acc + pg) : 0.0f;
-
-            bool new_transition = false;
-            BL_STAMP_KIND(0)
-            if (flag == 0) {
-                if (init_pending) {
-                    BL_STAMP_KIND(2)
-                    // initial evaluation done
-                    const double Un = -ll_tot + (double)(0.5f * bl_wave_sum(pe2)) + prior_const;
-                    sv[SV_TH * 64] = cz; sv[SV_GR * 64] = cg;
-                    ss->U = Un;
-                    init_pending = false;
-                    new_transition = true;
-                } else {
-                    // ------- CRITICAL: finish the leaf (_build_basetree), decide where the next one goes -------
-                    const float cr = rh - 0.5f * epsdir * cg;
-                    float s_prior = pe2, s_kin = minv * cr * cr;
-                    bl_low_sum2(s_prior, s_kin, D);
-                    const double Un = -ll_tot + (double)(0.5f * s_prior) + prior_const;
-                    const double Kn = (double)(0.5f * s_kin);
-                    double dE = (Un + Kn) - E0;
-                    if (dE != dE) dE = (double)INFINITY;
-                    const int leaf_idx = snprop;
-                    sdiv = dE > 1000.0;
-                    srsum = (leaf_idx == 0) ? cr : srsum + cr;
-                    snprop = leaf_idx + 1;
-                    // its multinomial / weight bookkeeping is deferred
-                    pend = true; pend_first = (leaf_idx == 0); pend_end = false;
-                    pend_dE = (float)dE; pend_U = Un; pend_z = cz; pend_g = cg;
-                    // checkpointed U-turn (_leaf_idx_to_ckpt_idxs / _is_iterative_turning)
-                    const int idx_max = __popc((unsigned)leaf_idx >> 1);
-                    const int idx_min = idx_max - (int)__builtin_ctz(~(unsigned)leaf_idx) + 1;
-                    if ((leaf_idx & 1) == 0) {
-                        sh_ckr[idx_max * 64 + lane] = cr;
-                        sh_ckrs[idx_max * 64 + lane] = srsum;
-                    } else {
-                        for (int i = idx_max; i >= idx_min && !sturn; i--) {
-                            const float ck = sh_ckr[i * 64 + lane];
-                            const float srs = srsum - sh_ckrs[i * 64 + lane] + ck;
-                            sturn = bl_is_turning(minv, ck, cr, srs, D);
-                        }
+            p_acc = acc; p_cg = cg; p_pe2 = pe2; p_timed_out = timed_out;
+            have_pending = true;
+            // ---------------------------------------------------- speculative position ----
+            // Where the next leaf goes depends on this one's energy / U-turn tests, but almost always it is
+            // "the next leaf of the subtree" or, when the subtree is full, "the first leaf of the next doubling".
+            // Both follow from this gradient in a handful of FMAs, so the compute waves start on that position
+            // at once and the tests run beside them (loop head).  A wrong guess costs nothing extra: it happens
+            // when a transition ends, and the decisions of that tick outlast a phase A anyway.
+            cz_spec = __builtin_nanf("");
+            if (!init_pending && !timed_out) {
+                const float cr = bl_leaf_momentum(rh, epsdir, cg);
+                if (snprop + 1 < (1 << depth)) {
+                    float rh2;
+                    bl_next_leaf(cz, cr, cg, epsdir, minv, rh2, cz_spec);
+                } else if (depth + 1 < p.max_depth) {
+                    BlRng peek = rng_dir; // the real draw is made by the decisions
+                    const bool gr2 = (bl_rng_next(peek) >> 31) != 0u;
+                    const float ed2 = gr2 ? eps : -eps;
+                    float ez = cz, er = cr, eg = cg; // same side: the edge is the leaf just finished
+                    if (gr2 != going_right) {        // other side: that edge is in LDS, untouched by this subtree
+                        const int e = gr2 ? SV_ZR : SV_ZL;
+                        ez = sv[e * 64]; er = sv[(e + 1) * 64]; eg = sv[(e + 2) * 64];
                     }
-                    if (snprop < (1 << depth) && !sturn && !sdiv) {
-                        // next leaf continues from this one
-                        rh = cr - 0.5f * epsdir * cg;
-                        cz = cz + epsdir * minv * rh;
-                    } else {
-                        // ---------- subtree complete: extend the tree edge, tree-level U-turn ----------
-                        BL_STAMP_KIND(1)
-                        pend_end = true; pend_sturn = sturn; pend_sdiv = sdiv; pend_snprop = snprop;
-                        const int e_out = going_right ? SV_ZR : SV_ZL;  // edge this subtree extends (z, r, g slots follow)
-                        const int e_in = going_right ? SV_ZL : SV_ZR;   // opposite edge
-                        sv[e_out * 64] = cz; sv[(e_out + 1) * 64] = cr; sv[(e_out + 2) * 64] = cg;
-                        const float r_other = sv[(e_in + 1) * 64];
-                        const float rsum = sv[SV_RSUM * 64] + srsum;
-                        sv[SV_RSUM * 64] = rsum;
-                        // numpyro _combine_tree (biased): turning = new_tree.turning | _is_turning(edges, r_sum)
-                        const bool turning = sturn || bl_is_turning(minv, going_right ? r_other : cr, going_right ? cr : r_other, rsum, D);
-                        depth++;
-                        if (depth < p.max_depth && !turning && !sdiv) {
-                            // next doubling
-                            going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
-                            epsdir = going_right ? eps : -eps;
-                            snprop = 0; sturn = false; sdiv = false;
-                            const int e = going_right ? SV_ZR : SV_ZL;
-                            const float ez = sv[e * 64], er = sv[(e + 1) * 64], eg = sv[(e + 2) * 64];
-                            rh = er - 0.5f * epsdir * eg;
-                            cz = ez + epsdir * minv * rh;
-                        } else {
-                            // ---------------- transition complete (nothing left to overlap with) ----------------
-                            BL_STAMP_KIND(2)
-                            run_deferred();
-                            const int nprop = ss->nprop;
-                            const float accp = ss->sumacc * bl_rcp((float)nprop);
-                            const float th = sv[SV_ZP * 64];
-                            const double U = ss->Up;
-                            sv[SV_TH * 64] = th; sv[SV_GR * 64] = sv[SV_GP * 64];
-                            ss->U = U;
-                            const int it = ss->it;
-                            if (it < W) {
-                                ss->nleap_w += nprop;
-                                // warmup_adapter.update_fn: dual averaging (t0=10, kappa=.75, gamma=.05)
-                                const float g = cold->target_accept - accp;
-                                const int da_t = ss->da_t + 1;
-                                const float tt = (float)da_t;
-                                const float rt10 = bl_rcp(tt + 10.0f);
-                                const float da_gavg = (1.0f - rt10) * ss->da_gavg + g * rt10;
-                                const float da_xt = ss->da_prox - __builtin_amdgcn_sqrtf(tt) * 20.0f * da_gavg;
-                                const float wgt = __builtin_amdgcn_exp2f(-0.75f * __builtin_amdgcn_logf(tt));
-                                const float da_xavg = (1.0f - wgt) * ss->da_xavg + wgt * da_xt;
-                                eps = bl_exp((it == W - 1) ? da_xavg : da_xt);
-                                eps = fminf(fmaxf(eps, 1.1754944e-38f), 3.4028235e+38f);
-                                ss->da_t = da_t; ss->da_gavg = da_gavg; ss->da_xt = da_xt; ss->da_xavg = da_xavg;
-                                int win_idx = ss->win_idx;
-                                const bool middle = win_idx > 0 && win_idx < cold->nwin - 1;
-                                if (middle) {
-                                    const int wf_n = ss->wf_n + 1;
-                                    const float wf_mean0 = sv[SV_WFMEAN * 64];
-                                    const float dpre = th - wf_mean0;
-                                    const float wf_mean = wf_mean0 + dpre * bl_rcp((float)wf_n);
-                                    sv[SV_WFMEAN * 64] = wf_mean;
-                                    sv[SV_WFM2 * 64] += dpre * (th - wf_mean);
-                                    ss->wf_n = wf_n;
-                                }
-                                const bool at_end = it == cold->win_end[win_idx];
-                                if (at_end) ss->win_idx = win_idx + 1;
-                                if (at_end && middle) {
-                                    const float n = (float)ss->wf_n;
-                                    const float var = sv[SV_WFM2 * 64] * bl_rcp(n - 1.0f), rn5 = bl_rcp(n + 5.0f);
-                                    minv = act ? (n * rn5 * var + 1e-3f * 5.0f * rn5) : 0.0f;
-                                    sv[SV_WFMEAN * 64] = 0.f; sv[SV_WFM2 * 64] = 0.f; ss->wf_n = 0;
-                                    ss->da_xt = 0.f; ss->da_xavg = 0.f; ss->da_gavg = 0.f; ss->da_t = 0;
-                                    ss->da_prox = bl_log(10.0f * eps);
-                                }
-                            } else {
-                                ss->nleap_s += nprop;
-                                if (member == 0) {
-                                    const size_t s = (size_t)chain * S + (it - W);
-                                    if (act) cold->draws[s * D + lane] = th;
-                                    if (lane == 0) {
-                                        cold->num_steps[s] = nprop;
-                                        cold->accept_prob[s] = accp;
-                                        cold->diverging[s] = pend_sdiv ? 1 : 0;
-                                        cold->potential[s] = (float)U;
-                                    }
-                                }
-                            }
-                            ss->it = it + 1;
-                            if (it + 1 >= total) flag = 1; // done
-                            else new_transition = true;
-                        }
-                    }
-                }
-                if (new_transition) {
-                    // sample momentum r = N(0,1)/sqrt(M^-1); start a fresh tree and its first doubling
-                    const float th = sv[SV_TH * 64], gr = sv[SV_GR * 64];
-                    const double U = ss->U;
-                    const float z01 = bl_rng_normal(rng_d);
-                    const float r0 = act ? z01 * __builtin_amdgcn_rsqf(minv) : 0.0f;
-                    E0 = U + (double)(0.5f * bl_wave_sum(minv * r0 * r0));
-                    sv[SV_ZL * 64] = th; sv[SV_RL * 64] = r0; sv[SV_GL * 64] = gr;
-                    sv[SV_ZR * 64] = th; sv[SV_RR * 64] = r0; sv[SV_GRR * 64] = gr;
-                    sv[SV_ZP * 64] = th; sv[SV_GP * 64] = gr; sv[SV_RSUM * 64] = r0;
-                    ss->Up = U; ss->wt = 0.f; ss->sumacc = 0.f; ss->nprop = 0;
-                    depth = 0;
-                    going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
-                    epsdir = going_right ? eps : -eps;
-                    snprop = 0; sturn = false; sdiv = false;
-                    rh = r0 - 0.5f * epsdir * gr;
-                    cz = th + epsdir * minv * rh;
+                    float rh2;
+                    bl_next_leaf(ez, er, eg, ed2, minv, rh2, cz_spec);
                 }
             }
-            if (act) sh_coef[my_pos] = cz;
-            if (lane == 0) sh_flag[0] = flag;
-            if (flag != 0 && member == 0) {
-                if (flag > 1 && lane == 0) atomicMax(cold->status, flag);
-                if (act) cold->inv_mass[chain * D + lane] = minv;
-                if (lane == 0) {
-                    cold->step_size[chain] = eps;
-                    cold->nleap[chain * 2 + 0] = ss->nleap_w;
-                    cold->nleap[chain * 2 + 1] = ss->nleap_s;
-                    cold->xcd_local[chain] = local ? 1 : 0;
-                }
-            }
-            BL_STAMP_CRIT
+            if (act && cz_spec == cz_spec) sh_coef[my_pos] = cz_spec;
+            if (lane == 0) sh_flag[0] = 0;
             BL_STAMP(4)
         }
         __syncthreads();
@@ -593,7 +646,7 @@ __global__ void __launch_bounds__(BlGeom<MODEL>::THREADS) bl_nuts_kernel(const B
         cold->dbg[9] = (long long)wall_clock64() - st_rt0;
         cold->dbg[10] = st_spins;
         for (int i = 0; i < 3; i++) { cold->dbg[11 + i] = st_kn[i]; }
-        cold->dbg[14] = st_kc[0]; cold->dbg[15] = st_kc[1];  // kind 2 = critical total - these two
+        cold->dbg[14] = st_kc[0]; cold->dbg[15] = st_kc[1]; cold->dbg[7] = st_kc[2];
     }
 #endif
 }

@@ -10,20 +10,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// Workgroup = 1 control wave (wave 0: exchange + NUTS state machine) + 4 compute waves (one per
-// SIMD) that evaluate the sites.  BL_CTHREADS compute threads, BL_THREADS launched threads.
-#define BL_CWAVES 4
-#define BL_CTHREADS (BL_CWAVES * 64)
-#define BL_THREADS (BL_CTHREADS + 64)
-// occu_rn keeps a 128-entry per-lane table in registers: 3 compute waves + the control wave = one
-// wave per SIMD, so each may use the full 512-register file.
+// Workgroup = 1 control wave (wave 0: exchange + NUTS state machine) + CW compute waves that
+// evaluate the sites; CW is a template parameter of the kernels (blockDim.x = 64 * (CW + 1)):
+// 3 -> every wave has a SIMD to itself, so the control wave's decisions, which overlap the site
+//      evaluation, do not steal issue slots from a compute wave, and one wave per SIMD may use the
+//      whole 512-entry register file (the latency optimum while one site pair per lane still fits:
+//      N <= 384 sites per workgroup); occu_rn always runs this form (128-entry per-lane table);
+// 4 -> all four SIMDs evaluate sites (larger slices, where the evaluation dominates the tick).
+#define BL_CWAVES_MAX 4
 #define BL_CWAVES_RN 3
 #define BL_THREADS_RN (BL_CWAVES_RN * 64 + 64)
-template <int MODEL> struct BlGeom {
-    static constexpr int CWAVES = MODEL == 1 ? BL_CWAVES_RN : BL_CWAVES; // MODEL 2 (false positives) runs the occu geometry
-    static constexpr int CTHREADS = CWAVES * 64;
-    static constexpr int THREADS = CTHREADS + 64;
-};
 #define BL_DIR_STREAM 62
 #define BL_MAX_DEPTH 10
 #define BL_NSTREAM 64
@@ -32,7 +28,7 @@ template <int MODEL> struct BlGeom {
 // ---- dynamic LDS carve (bytes; every offset a multiple of 16: guide G17) ----
 #define BL_OFF_COEF 0       // 64 floats : coefficients being evaluated, PADDED layout (beta[0..KS], alpha[0..KO])
 #define BL_OFF_FLAG 256     // 4 ints    : loop control
-#define BL_OFF_PART 272     // 4 compute waves x BL_PART_STRIDE floats (room for 8) : per-wave partial sums (padded layout + log-lik)
+#define BL_OFF_PART 272     // <= 4 compute waves x BL_PART_STRIDE floats (room for 8) : per-wave partial sums (padded layout + log-lik)
 #define BL_PART_STRIDE 48
 #define BL_OFF_CKR 1808     // 10 x 64 floats: r checkpoints      (numpyro r_ckpts)
 #define BL_OFF_CKRS 4368    // 10 x 64 floats: r_sum checkpoints  (numpyro r_sum_ckpts)
@@ -294,12 +290,12 @@ __device__ __forceinline__ void bl_visit2(const bl_f2 (&w)[KO + 1], const float 
     for (int k = 0; k <= KO; k++) g[k] = bl_fma2(s, w[k], g[k]);
 }
 
-// Accumulates, over this thread's site PAIRS m = tid, tid+BL_THREADS, ... :
+// Accumulates, over this thread's site PAIRS m = ct, ct+CT, ... (CT compute threads):
 //   ll += sum_t l_it ,  gb[k] += d ll / d beta_k ,  ga[k] += d ll / d alpha_k
 // LDS pair records (element e of the two sites adjacent); JC > 0: J == JC at compile time -> the
 // whole period block is read with ds_read_b128 at immediate offsets and the visits are unrolled
 // (their exp/log/rcp chains interleave).  JC == 0: runtime J.
-template <int KS, int KO, int JC>
+template <int KS, int KO, int JC, int CT>
 __device__ __forceinline__ void bl_eval_sites_lds(int ct, int pstride, int cnt, int T, int J,
                                                   const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                                   float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
@@ -314,7 +310,7 @@ __device__ __forceinline__ void bl_eval_sites_lds(int ct, int pstride, int cnt, 
     for (int k = 0; k <= KS; k++) gb2[k] = bl2(0.0f);
 #pragma unroll
     for (int k = 0; k <= KO; k++) ga2[k] = bl2(0.0f);
-    for (int m = ct; m < npairs; m += BL_CTHREADS) {
+    for (int m = ct; m < npairs; m += CT) {
         const float4 *rec = reinterpret_cast<const float4 *>(data + (size_t)m * pstride);
         const bl_f2 vmask = bl_f2{1.0f, (2 * m + 1 < cnt) ? 1.0f : 0.0f}; // odd slice: the last pair's second site is a dummy
         bl_f2 x[XQ];
@@ -399,14 +395,14 @@ __device__ __forceinline__ void bl_eval_sites_lds(int ct, int pstride, int cnt, 
 
 // Same arithmetic straight from the HBM rows (slice too large for LDS); grows is already offset to
 // this workgroup's first site, ld = n_stride.
-template <int KS, int KO>
+template <int KS, int KO, int CT>
 __device__ __forceinline__ void bl_eval_sites_hbm(int ct, const float *__restrict__ grows, int ld, int cnt, int T, int J,
                                                   const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                                   float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
 {
     const int V = T * J;
     const int row_wc = KS, row_ka = KS + V * (KO + 1), row_kb = row_ka + T;
-    for (int i = ct; i < cnt; i += BL_CTHREADS) {
+    for (int i = ct; i < cnt; i += CT) {
         float x[KS > 0 ? KS : 1];
         float eta = beta[0];
 #pragma unroll
@@ -470,7 +466,7 @@ __device__ __forceinline__ BlFpScalars bl_fp_scalars(float phi, int fp_z1)
     return s;
 }
 
-template <int KS, int KO>
+template <int KS, int KO, int CT>
 __device__ __forceinline__ void bl_eval_sites_fp(int ct, int pstride, int cnt, int T, int J, const BlFpScalars fp,
                                                  const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                                  float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], float &gphi)
@@ -485,7 +481,7 @@ __device__ __forceinline__ void bl_eval_sites_fp(int ct, int pstride, int cnt, i
     for (int k = 0; k <= KS; k++) gb2[k] = bl2(0.0f);
 #pragma unroll
     for (int k = 0; k <= KO; k++) ga2[k] = bl2(0.0f);
-    for (int m = ct; m < npairs; m += BL_CTHREADS) {
+    for (int m = ct; m < npairs; m += CT) {
         const float4 *rec = reinterpret_cast<const float4 *>(data + (size_t)m * pstride);
         const bl_f2 vmask = bl_f2{1.0f, (2 * m + 1 < cnt) ? 1.0f : 0.0f};
         bl_f2 x[XQ];
@@ -791,26 +787,26 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
 
 // MODEL 0 = occu (occu.py), MODEL 1 = occu_rn (occu_rn.py; LDS records only);
 // MODEL 2 (occu with false positives) is dispatched by bl_phase_a below
-template <int KS, int KO, bool LDS, int MODEL>
+template <int KS, int KO, bool LDS, int MODEL, int CT>
 __device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ grows, int ld_or_stride, int cnt, int T, int J, int K,
                                               const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                               float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
 {
     if constexpr (MODEL == 1) {
-        if constexpr (LDS) bl_eval_sites_rn<KS, KO, BL_CWAVES_RN * 64>(ct, ld_or_stride, cnt, T, J, K, beta, alpha, ll, gb, ga);
+        if constexpr (LDS) bl_eval_sites_rn<KS, KO, CT>(ct, ld_or_stride, cnt, T, J, K, beta, alpha, ll, gb, ga);
     } else if constexpr (LDS) {
         switch (J) { // wave-uniform
-        case 1: bl_eval_sites_lds<KS, KO, 1>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 2: bl_eval_sites_lds<KS, KO, 2>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 3: bl_eval_sites_lds<KS, KO, 3>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 4: bl_eval_sites_lds<KS, KO, 4>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 5: bl_eval_sites_lds<KS, KO, 5>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 6: bl_eval_sites_lds<KS, KO, 6>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 8: bl_eval_sites_lds<KS, KO, 8>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        default: bl_eval_sites_lds<KS, KO, 0>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 1: bl_eval_sites_lds<KS, KO, 1, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 2: bl_eval_sites_lds<KS, KO, 2, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 3: bl_eval_sites_lds<KS, KO, 3, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 4: bl_eval_sites_lds<KS, KO, 4, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 5: bl_eval_sites_lds<KS, KO, 5, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 6: bl_eval_sites_lds<KS, KO, 6, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 8: bl_eval_sites_lds<KS, KO, 8, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        default: bl_eval_sites_lds<KS, KO, 0, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
         }
     } else {
-        bl_eval_sites_hbm<KS, KO>(ct, grows, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga);
+        bl_eval_sites_hbm<KS, KO, CT>(ct, grows, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga);
     }
 }
 
@@ -886,7 +882,7 @@ __device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, con
 
 // Phase A of one evaluation for a compute thread `ct` of the workgroup: coefficients from LDS, the
 // workgroup's site slice, wave partials into the LDS table.  Shared by the NUTS and logp kernels.
-template <int KS, int KO, bool LDS, int MODEL>
+template <int KS, int KO, bool LDS, int MODEL, int CW>
 __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__restrict__ grows, int ld_or_stride, int cnt,
                                            int T, int J, int max_abundance, int fp_z1)
 {
@@ -901,10 +897,10 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         static_assert(LDS, "false-positive model: LDS records only");
         float gphi = 0.0f;
         const BlFpScalars fp = bl_fp_scalars(bl_lds_f(BL_OFF_COEF)[KS + KO + 3], fp_z1);
-        bl_eval_sites_fp<KS, KO>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi);
+        bl_eval_sites_fp<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi);
         bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi);
     } else {
-        bl_eval_sites<KS, KO, LDS, MODEL>(ct, grows, ld_or_stride, cnt, T, J, max_abundance, beta, alpha, ll, gb, ga);
+        bl_eval_sites<KS, KO, LDS, MODEL, CW * 64>(ct, grows, ld_or_stride, cnt, T, J, max_abundance, beta, alpha, ll, gb, ga);
         bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga);
     }
 }

@@ -14,7 +14,8 @@ os.environ.setdefault("BIOLITH_HIP_LIB", os.path.join(ROOT, "biolith_amd", "lib"
 from biolith_amd.engine import OccuDataset  # noqa: E402
 from biolith_amd.models import simulate  # noqa: E402
 
-NAMES = ["deferred bookkeeping", "wait for compute waves", "wg partial+publish", "sweep (poll)", "critical control", "barrier2", "-", "-"]
+NAMES = ["decisions + bookkeeping (under phase A)", "wait for compute waves", "wg partial+publish", "sweep (poll)",
+         "speculative position", "barrier2", "-", "-"]
 
 
 def main():
@@ -27,16 +28,16 @@ def main():
             r = ds.nuts(num_warmup=1000, num_samples=1000, num_chains=chains, seed=0, wgs_per_chain=k)
             c = ds.debug_counters()
             ticks, rt = int(c[8]), int(c[9])
-            tot = c[:8].sum()
+            tot = c[:7].sum()
             mhz = tot / (rt / 100.0) if rt else float("nan")  # s_memrealtime ticks at 100 MHz
             print(f"k={r.wgs_per_chain} chains={chains} kernel {r.kernel_ms:.1f} ms ticks {ticks} "
                   f"cycles/tick {tot / max(ticks, 1):.0f} clock {mhz:.0f} MHz us/tick {r.kernel_ms * 1e3 / max(ticks, 1):.2f} l2local_chains {r.chains_l2_local} poll-rounds/tick {int(c[10]) / max(ticks, 1) + 1:.2f}")
-            for n, v in zip(NAMES, c[:8]):
-                print(f"    {n:26s} {v / max(ticks, 1):8.0f} cyc  {100.0 * v / tot:5.1f} %")
+            for n, v in zip(NAMES[:6], c[:6]):
+                print(f"    {n:40s} {v / max(ticks, 1):8.0f} cyc  {100.0 * v / tot:5.1f} %")
             kn = c[11:14].astype(float)
-            kc = np.array([c[14], c[15], c[4] - c[14] - c[15]], dtype=float)
+            kc = np.array([c[14], c[15], c[7]], dtype=float)
             for name, n_, cyc in zip(("next leaf of the subtree", "next doubling", "transition end / init"), kn, kc):
-                print(f"    critical control, {name:26s}: {int(n_):7d} ticks ({100 * n_ / max(ticks, 1):4.1f} %), {cyc / max(n_, 1):7.0f} cyc each")
+                print(f"    decisions, {name:26s}: {int(n_):7d} ticks ({100 * n_ / max(ticks, 1):4.1f} %), {cyc / max(n_, 1):7.0f} cyc each")
 
 
 if __name__ == "__main__":
