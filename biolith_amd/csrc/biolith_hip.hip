@@ -626,7 +626,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     const size_t o_draws = carve((size_t)C * Sa * D * 4), o_div = carve((size_t)C * Sa), o_steps = carve((size_t)C * Sa * 4),
                  o_acc = carve((size_t)C * Sa * 4), o_pot = carve((size_t)C * Sa * 4), o_eps = carve((size_t)C * 4),
                  o_minv = carve((size_t)C * D * 4), o_nleap = carve((size_t)C * 16), o_status = carve(16),
-                 o_rng = carve((size_t)C * BL_RNG_STREAMS_PER_CHAIN * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(16 * 8), o_loc = carve((size_t)C * 4),
+                 o_rng = carve((size_t)C * BL_RNG_STREAMS_PER_CHAIN * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(32 * 8), o_loc = carve((size_t)C * 4),
                  o_cold = carve(sizeof(BlNutsCold));
     if (off > ds->run_bytes) {
         if (ds->d_run) hipFree(ds->d_run);
@@ -709,7 +709,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     BL_HIP(hipEventRecord(ds->ev0, st));
     BL_HIP(hipMemsetAsync(ds->d_xchg, 0, xb, st));
     BL_HIP(hipMemsetAsync(ds->d_status, 0, 16, st));
-    BL_HIP(hipMemsetAsync(ds->d_dbg, 0, 128, st));
+    BL_HIP(hipMemsetAsync(ds->d_dbg, 0, 256, st));
     BL_HIP(hipMemsetAsync(ds->d_loc, 0, (size_t)C * 4, st));
     const int grid = 8 * k * ((C + 7) / 8); // XCD-aware mapping in the kernel; surplus blocks exit at once
     if (ds->model != 0 && !staged)
@@ -804,7 +804,7 @@ extern "C" int bl_nuts_device_draws(bl_dataset *ds, void **dev_ptr, size_t *byte
 
 extern "C" int bl_nuts_debug_counters(bl_dataset *ds, int64_t *out, int n)
 {
-    if (!ds || !out || n <= 0 || n > 16) return bl_fail(BL_ERR_INVALID, "bad argument");
+    if (!ds || !out || n <= 0 || n > 32) return bl_fail(BL_ERR_INVALID, "bad argument");
     if (!ds->have_run || ds->in_flight) return bl_fail(BL_ERR_BUSY, "no finished NUTS launch");
     BL_HIP(hipMemcpy(out, ds->d_dbg, (size_t)n * 8, hipMemcpyDeviceToHost));
     return BL_OK;

@@ -40,13 +40,18 @@
 // (make stamps); the shipped kernel executes none of this.
 #ifdef BL_STAMPS
 #define BL_STAMP_DECL long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long st_prev = (long long)clock64(); long long st_rt0 = (long long)wall_clock64(); long long st_spins = 0; \
-    long long st_kn[3] = {0, 0, 0}, st_kc[3] = {0, 0, 0}; int st_kind = 0;
+    long long st_kn[3] = {0, 0, 0}, st_kc[3] = {0, 0, 0}; int st_kind = 0; long long st_sub[6] = {0, 0, 0, 0, 0, 0}; long long st_t = 0;
 #define BL_STAMP(i) { const long long st_now = (long long)clock64(); st_acc[i] += st_now - st_prev; st_prev = st_now; }
 // critical-control time split by what the tick decided: 0 next leaf of the subtree, 1 next doubling, 2 transition end / init
 #define BL_STAMP_KIND(k) st_kind = (k);
 #define BL_STAMP_CRIT { const long long st_now = (long long)clock64(); st_kn[st_kind]++; st_kc[st_kind] += st_now - st_prev; }
 #define BL_COUNT_SPINS(n) st_spins += (long long)(n);
+// sub-steps of a decision: BL_SUB0 starts the clock, BL_SUB(i) charges the time since the last mark to slot i
+#define BL_SUB0 st_t = (long long)clock64();
+#define BL_SUB(i) { const long long st_n2 = (long long)clock64(); st_sub[i] += st_n2 - st_t; st_t = st_n2; }
 #else
+#define BL_SUB0
+#define BL_SUB(i)
 #define BL_COUNT_SPINS(n)
 #define BL_STAMP_DECL
 #define BL_STAMP(i)
@@ -313,7 +318,13 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         bool redo = false; // the evaluation in flight is not the one the sampler needs next
         if (wave > 0) {
             // ------------------------------------- phase A: compute waves, site log-lik ----
+#ifdef BL_STAMPS
+            const long long st_a0 = (long long)clock64();
+#endif
             bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_z1);
+#ifdef BL_STAMPS
+            st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
+#endif
         } else if (have_pending) {
             have_pending = false;
             const double acc = p_acc;
@@ -328,6 +339,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             if (flag == 0) {
                 if (init_pending) {
                     BL_STAMP_KIND(2)
+                    BL_SUB0
                     // initial evaluation done
                     const double Un = -ll_tot + (double)(0.5f * bl_wave_sum(pe2)) + prior_const;
                     sv[SV_TH * 64] = cz; sv[SV_GR * 64] = cg;
@@ -390,7 +402,9 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                         } else {
                             // ---------------- transition complete (nothing left to overlap with) ----------------
                             BL_STAMP_KIND(2)
+                            BL_SUB0
                             run_deferred();
+                            BL_SUB(0)
                             const int nprop = ss->nprop;
                             const float accp = ss->sumacc * bl_rcp((float)nprop);
                             const float th = sv[SV_ZP * 64];
@@ -449,6 +463,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                             ss->it = it + 1;
                             if (it + 1 >= total) flag = 1; // done
                             else new_transition = true;
+                            BL_SUB(1)
                         }
                     }
                 }
@@ -468,6 +483,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                     epsdir = going_right ? eps : -eps;
                     snprop = 0; sturn = false; sdiv = false;
                     bl_next_leaf(th, r0, gr, epsdir, minv, rh, cz);
+                    BL_SUB(2)
                 }
             }
             if (flag != 0 && member == 0) {
@@ -647,6 +663,10 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         cold->dbg[10] = st_spins;
         for (int i = 0; i < 3; i++) { cold->dbg[11 + i] = st_kn[i]; }
         cold->dbg[14] = st_kc[0]; cold->dbg[15] = st_kc[1]; cold->dbg[7] = st_kc[2];
+        for (int i = 0; i < 4; i++) cold->dbg[16 + i] = st_sub[i];
+    }
+    if (cold->dbg && chain == 0 && member == 0 && tid == 64) { // first compute wave: site-evaluation passes and their cycles
+        cold->dbg[20] = st_sub[4]; cold->dbg[21] = st_sub[5];
     }
 #endif
 }

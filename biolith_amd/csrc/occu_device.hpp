@@ -135,24 +135,56 @@ __device__ __forceinline__ double bl_wave_sum_d(double x)
     return bl_readlane_d(x, 63);
 }
 
+// x += dpp(x) as ONE instruction (v_add_f32_dpp).  Written in assembly because the compiler's SLP
+// vectoriser otherwise pairs the adds of neighbouring values into v_pk_add_f32 and feeds them through
+// v_mov_b32 + v_mov_b32_dpp copies: 5 instructions (24 issue cycles) per pair and level instead of 2 (8).
+// The assembler does not see through inline asm, so the caller guarantees the DPP read-after-VALU-write
+// distance (2 wait states): interleave >= 3 independent chains, or put BL_DPP_GAP between levels.
+// For the row_bcast steps the rows masked out by row_mask keep x (= x + 0), which is what a fold wants.
+#define BL_DPP_ADD(x, MOD) asm volatile("v_add_f32_dpp %0, %0, %0 " MOD : "+v"(x))
+#define BL_DPP_GAP asm volatile("s_nop 1")
+#define BL_DPP_XOR1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define BL_DPP_XOR2 "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define BL_DPP_HALF "row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define BL_DPP_ROW "row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define BL_DPP_B15 "row_bcast:15 row_mask:0xa bank_mask:0xf"
+#define BL_DPP_B31 "row_bcast:31 row_mask:0xc bank_mask:0xf"
+
 // N independent sums with the butterfly steps outermost: the N DPP chains interleave, so no
-// s_nop padding between a VALU write and the DPP read of the same register is needed.
+// padding between a VALU write and the DPP read of the same register is needed (N >= 3).
 // On return lane 63 of every v[i] holds the wave total (other lanes: partial sums).
 template <int N>
 __device__ __forceinline__ void bl_wave_sum_vec_l63(float (&v)[N])
 {
+    if constexpr (N >= 3) {
+        BL_DPP_GAP; // the values were just produced by ordinary VALU code
 #pragma unroll
-    for (int i = 0; i < N; i++) v[i] += bl_dpp<0xB1, 0xF>(v[i]);
+        for (int i = 0; i < N; i++) BL_DPP_ADD(v[i], BL_DPP_XOR1);
 #pragma unroll
-    for (int i = 0; i < N; i++) v[i] += bl_dpp<0x4E, 0xF>(v[i]);
+        for (int i = 0; i < N; i++) BL_DPP_ADD(v[i], BL_DPP_XOR2);
 #pragma unroll
-    for (int i = 0; i < N; i++) v[i] += bl_dpp<0x141, 0xF>(v[i]);
+        for (int i = 0; i < N; i++) BL_DPP_ADD(v[i], BL_DPP_HALF);
 #pragma unroll
-    for (int i = 0; i < N; i++) v[i] += bl_dpp<0x140, 0xF>(v[i]);
+        for (int i = 0; i < N; i++) BL_DPP_ADD(v[i], BL_DPP_ROW);
 #pragma unroll
-    for (int i = 0; i < N; i++) v[i] += bl_dpp<0x142, 0xA>(v[i]);
+        for (int i = 0; i < N; i++) BL_DPP_ADD(v[i], BL_DPP_B15);
 #pragma unroll
-    for (int i = 0; i < N; i++) v[i] += bl_dpp<0x143, 0xC>(v[i]);
+        for (int i = 0; i < N; i++) BL_DPP_ADD(v[i], BL_DPP_B31);
+        BL_DPP_GAP;
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] += bl_dpp<0xB1, 0xF>(v[i]);
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] += bl_dpp<0x4E, 0xF>(v[i]);
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] += bl_dpp<0x141, 0xF>(v[i]);
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] += bl_dpp<0x140, 0xF>(v[i]);
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] += bl_dpp<0x142, 0xA>(v[i]);
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] += bl_dpp<0x143, 0xC>(v[i]);
+    }
 }
 __device__ __forceinline__ void bl_wave_sum2(float &a, float &b)
 {
@@ -165,17 +197,20 @@ __device__ __forceinline__ void bl_wave_sum2(float &a, float &b)
 // lane 0's group covers n lanes; totals are read from lane 0.  n is wave-uniform.
 __device__ __forceinline__ void bl_low_sum2(float &a, float &b, int n)
 {
-    a += bl_dpp<0xB1, 0xF>(a); b += bl_dpp<0xB1, 0xF>(b);   // xor 1
-    a += bl_dpp<0x4E, 0xF>(a); b += bl_dpp<0x4E, 0xF>(b);   // xor 2
-    if (n > 4) { a += bl_dpp<0x141, 0xF>(a); b += bl_dpp<0x141, 0xF>(b); }  // 8 lanes
-    if (n > 8) { a += bl_dpp<0x140, 0xF>(a); b += bl_dpp<0x140, 0xF>(b); }  // 16 lanes
+    // two chains only: a gap between levels provides the DPP read-after-write distance
+    BL_DPP_GAP; BL_DPP_ADD(a, BL_DPP_XOR1); BL_DPP_ADD(b, BL_DPP_XOR1);
+    BL_DPP_GAP; BL_DPP_ADD(a, BL_DPP_XOR2); BL_DPP_ADD(b, BL_DPP_XOR2);
+    if (n > 4) { BL_DPP_GAP; BL_DPP_ADD(a, BL_DPP_HALF); BL_DPP_ADD(b, BL_DPP_HALF); }  // 8 lanes
+    if (n > 8) { BL_DPP_GAP; BL_DPP_ADD(a, BL_DPP_ROW); BL_DPP_ADD(b, BL_DPP_ROW); }    // 16 lanes
     if (n > 16) {
-        // rows 1..3 still to fold: take the generic path for the remaining steps
-        a += bl_dpp<0x142, 0xA>(a); b += bl_dpp<0x142, 0xA>(b);
-        a += bl_dpp<0x143, 0xC>(a); b += bl_dpp<0x143, 0xC>(b);
+        // rows 1..3 still to fold: the generic steps, totals in lane 63
+        BL_DPP_GAP; BL_DPP_ADD(a, BL_DPP_B15); BL_DPP_ADD(b, BL_DPP_B15);
+        BL_DPP_GAP; BL_DPP_ADD(a, BL_DPP_B31); BL_DPP_ADD(b, BL_DPP_B31);
+        BL_DPP_GAP;
         a = bl_readlane(a, 63); b = bl_readlane(b, 63);
         return;
     }
+    BL_DPP_GAP;
     a = bl_readlane(a, 0); b = bl_readlane(b, 0);
 }
 

@@ -158,7 +158,7 @@ class OccuDataset:
         _ffi.check(self._lib.bl_nuts_elapsed_ms(self._h, C.byref(ms)))
         return float(ms.value)
 
-    def debug_counters(self, n: int = 16):
+    def debug_counters(self, n: int = 32):
         """In-kernel phase cycle counters (zeros unless a BL_STAMPS diagnostic library is loaded)."""
         out = np.zeros(n, dtype=np.int64)
         _ffi.check(self._lib.bl_nuts_debug_counters(self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), n))

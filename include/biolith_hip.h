@@ -155,7 +155,7 @@ int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads_per_wg, in
 
 /* In-kernel phase cycle counters of the last launch; all zero unless the library is a diagnostic
  * BL_STAMPS build (make -C biolith_amd/csrc stamps).  Not part of the reference's interface. */
-int bl_nuts_debug_counters(bl_dataset *ds, int64_t *out /*[n<=16]*/, int n);
+int bl_nuts_debug_counters(bl_dataset *ds, int64_t *out /*[n<=32]*/, int n);
 
 /*
  * Deterministic sites (occu.py:207, 221-228), recomputed from draws on the device:

@@ -36,6 +36,10 @@ def main():
                 print(f"    {n:40s} {v / max(ticks, 1):8.0f} cyc  {100.0 * v / tot:5.1f} %")
             kn = c[11:14].astype(float)
             kc = np.array([c[14], c[15], c[7]], dtype=float)
+            print(f"    site evaluation (compute wave 1): {int(c[20])} passes, {c[21] / max(float(c[20]), 1.0):.0f} cyc each")
+            n_end = max(float(c[13]), 1.0)
+            print("    transition end, per tick: flush bookkeeping %.0f | select/adapt/output %.0f | new momentum+tree %.0f cyc"
+                  % (c[16] / n_end, c[17] / n_end, c[18] / n_end))
             for name, n_, cyc in zip(("next leaf of the subtree", "next doubling", "transition end / init"), kn, kc):
                 print(f"    decisions, {name:26s}: {int(n_):7d} ticks ({100 * n_ / max(ticks, 1):4.1f} %), {cyc / max(n_, 1):7.0f} cyc each")
 
