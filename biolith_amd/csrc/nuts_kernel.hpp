@@ -547,6 +547,9 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 unsigned long long v[8];
                 unsigned spins = 0;
                 while (true) {
+#ifdef BL_STAMPS
+                    const long long st_r0 = (long long)clock64();
+#endif
 #pragma unroll
                     for (int q = 0; q < 8; q += 2) {
                         if (q < nq) { // wave-uniform: skip load pairs that would only re-read record k-1
@@ -560,7 +563,11 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                     unsigned bad = 0u;
 #pragma unroll
                     for (int q = 0; q < 8; q++) bad |= ((unsigned)(v[q] >> 32)) ^ epoch;
-                    if (__all(bad == 0u)) break;
+                    const bool all_in = __all(bad == 0u);
+#ifdef BL_STAMPS
+                    st_sub[3] += (long long)clock64() - st_r0; // cycles in poll rounds (loads issued -> tags checked)
+#endif
+                    if (all_in) break;
                     if (++spins > p.spin_limit) { timed_out = true; break; }
                     if (!local)
                         for (int z = 0; z < p.poll_sleep; z++) __builtin_amdgcn_s_sleep(1);
@@ -593,12 +600,10 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                     }
                 }
             }
-            for (int off = nvp; off < 64; off <<= 1) {
-                const unsigned long long b = (unsigned long long)__double_as_longlong(acc);
-                const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)b, off);
-                const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(b >> 32), off);
-                acc += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-            }
+            // fold the 64/nvp lane groups (each summed a different subset of the workgroups): element-wise
+            // across rows, by gfx950's v_permlane16_swap / v_permlane32_swap (one VALU op per 32-bit half)
+            if (nvp <= 16) acc = bl_fold_rows16_d(acc);
+            if (nvp <= 32) acc = bl_fold_halves32_d(acc);
             BL_STAMP(3)
             if (epoch == 1u && p.allow_local) {
                 const double sx = bl_readlane_d(acc, D + 2), sxx = bl_readlane_d(acc, D + 3);

@@ -111,6 +111,28 @@ __device__ __forceinline__ double bl_readlane_d(double x, int l)
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// x[l] + x[l ^ 16] in every lane (rows 0+1 and 2+3 of 16 lanes), and x[l] + x[l ^ 32], for doubles.
+// v_permlane16_swap(a, b): odd rows of a <-> even rows of b; with a = b = x the two results are
+// {r0, r0, r2, r2} and {r1, r1, r3, r3}.  v_permlane32_swap likewise for the 32-lane halves.
+__device__ __forceinline__ double bl_fold_rows16_d(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __longlong_as_double((long long)(((unsigned long long)h[0] << 32) | l[0])) +
+           __longlong_as_double((long long)(((unsigned long long)h[1] << 32) | l[1]));
+}
+__device__ __forceinline__ double bl_fold_halves32_d(double x)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __longlong_as_double((long long)(((unsigned long long)h[0] << 32) | l[0])) +
+           __longlong_as_double((long long)(((unsigned long long)h[1] << 32) | l[1]));
+}
+
 // Sum over the 64 lanes of a wave; result is wave-uniform (read from lane 63).
 // quad xor1, quad xor2, half-row mirror, row mirror -> every lane holds its 16-lane row sum;
 // row_bcast15 / row_bcast31 fold the four rows into lane 63.  Fixed order => reproducible.

@@ -37,6 +37,8 @@ def main():
             kn = c[11:14].astype(float)
             kc = np.array([c[14], c[15], c[7]], dtype=float)
             print(f"    site evaluation (compute wave 1): {int(c[20])} passes, {c[21] / max(float(c[20]), 1.0):.0f} cyc each")
+            rounds = float(c[10]) + ticks
+            print(f"    poll rounds: {rounds / max(ticks, 1):.2f} per exchange, {c[19] / max(rounds, 1.0):.0f} cyc each (loads issued -> tags checked)")
             n_end = max(float(c[13]), 1.0)
             print("    transition end, per tick: flush bookkeeping %.0f | select/adapt/output %.0f | new momentum+tree %.0f cyc"
                   % (c[16] / n_end, c[17] / n_end, c[18] / n_end))
