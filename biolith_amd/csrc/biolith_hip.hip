@@ -38,6 +38,18 @@ static int bl_fail(int code, const char *fmt, ...)
                            __FILE__, __LINE__);                                                        \
     } while (0)
 
+// Scratch device allocations of one call: freed on every return path.
+struct DevScratch {
+    std::vector<void *> ptrs;
+    ~DevScratch() { for (void *q : ptrs) hipFree(q); }
+    hipError_t alloc(void **out, size_t bytes)
+    {
+        const hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+        if (e == hipSuccess) ptrs.push_back(*out);
+        return e;
+    }
+};
+
 // ------------------------------------------- kernel instantiation dispatch ----
 #if defined(BL_STAMPS) || defined(BL_ONLY33) /* diagnostic / experimental builds: one instantiation */
 #define BL_KK_LIST(X) X(3, 3)
@@ -147,7 +159,8 @@ static int adaptation_schedule(int num_steps, int32_t *starts, int32_t *ends, in
 // ----------------------------------------------------------------- handle ----
 struct bl_dataset {
     int device = 0;
-    int model = 0;          // 0 occu, 1 occu_rn, 2 occu with false positives
+    int model = 0;          // 0 occu, 1 occu_rn, 2 occu with false positives, 3 occu_cop
+    int ko_layout = 0;      // KO the record layout helpers are called with (KO, or KO + 1 for occu_cop's wider visits)
     int max_abundance = 0;  // occu_rn only
     int fp_mode = 0;        // model 2: BL_FP_CONSTANT / BL_FP_UNOCCUPIED
     double fp_a = 2.0, fp_b = 5.0;  // model 2: Beta prior of the false-positive rate
@@ -282,21 +295,22 @@ __global__ void bl_predict_kernel(const float *__restrict__ rows, const float *_
 extern "C" int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint64_t seed, uint8_t *latent, uint8_t *y)
 {
     if (!ds || !draws || n_draws <= 0 || (!latent && !y)) return bl_fail(BL_ERR_INVALID, "bl_predict: bad argument");
+    if (ds->model == 3) return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: not built for occu_cop (counts do not fit the uint8 outputs)");
     if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
     int rc = set_device(ds);
     if (rc) return rc;
     const int N = ds->dims.n_sites, T = ds->dims.n_periods, J = ds->dims.n_replicates, D = ds->D;
     float *d_draws = nullptr;
     unsigned char *d_lat = nullptr, *d_y = nullptr;
-    struct Guard { float *&a; unsigned char *&b; unsigned char *&c; ~Guard() { hipFree(a); hipFree(b); hipFree(c); } } guard{d_draws, d_lat, d_y};
-    BL_HIP(hipMalloc((void **)&d_draws, (size_t)n_draws * D * 4));
+    DevScratch scratch;
+    BL_HIP(scratch.alloc((void **)&d_draws, (size_t)n_draws * D * 4));
     BL_HIP(hipMemcpy(d_draws, draws, (size_t)n_draws * D * 4, hipMemcpyHostToDevice));
     const size_t per_draw = (size_t)T * N * (y ? (size_t)J : 1); // bytes of the larger output
     int chunk = (int)((256u << 20) / (per_draw ? per_draw : 1));
     if (chunk < 1) chunk = 1;
     if (chunk > n_draws) chunk = n_draws;
-    if (latent) BL_HIP(hipMalloc((void **)&d_lat, (size_t)chunk * T * N));
-    if (y) BL_HIP(hipMalloc((void **)&d_y, (size_t)chunk * J * T * N));
+    if (latent) BL_HIP(scratch.alloc((void **)&d_lat, (size_t)chunk * T * N));
+    if (y) BL_HIP(scratch.alloc((void **)&d_y, (size_t)chunk * J * T * N));
     if (!ds->d_wraw) {
         BL_HIP(hipMalloc((void **)&ds->d_wraw, ds->h_wraw.size() * 4));
         BL_HIP(hipMemcpy(ds->d_wraw, ds->h_wraw.data(), ds->h_wraw.size() * 4, hipMemcpyHostToDevice));
@@ -327,7 +341,11 @@ extern "C" int bl_adaptation_schedule(int num_warmup, int32_t *starts, int32_t *
     return adaptation_schedule(num_warmup, starts, ends, capacity);
 }
 
-struct ModelOpts { int model = 0, max_abundance = 0, fp_mode = 0; double fp_a = 2.0, fp_b = 5.0; };
+struct ModelOpts {
+    int model = 0, max_abundance = 0, fp_mode = 0;
+    double fp_a = 2.0, fp_b = 5.0;           // model 2: Beta(a, b); model 3: Exponential(rate = fp_a)
+    const float *session_duration = nullptr; // model 3: [N][T][J]
+};
 static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const float *site_covs, const float *obs_covs,
                                const float *obs, const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha,
                                int device, bl_dataset **out);
@@ -368,6 +386,23 @@ extern "C" int bl_dataset_create_fp(const bl_dims *dims, const float *site_covs,
     return dataset_create_impl(mo, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
 }
 
+extern "C" int bl_dataset_create_cop(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
+                                     const float *session_duration, int fp_mode, double prior_fp_rate,
+                                     const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha, int device,
+                                     bl_dataset **out)
+{
+    if (fp_mode != 0 && fp_mode != BL_FP_CONSTANT && fp_mode != BL_FP_UNOCCUPIED)
+        return bl_fail(BL_ERR_INVALID, "fp_mode must be 0, BL_FP_CONSTANT or BL_FP_UNOCCUPIED");
+    if (!session_duration) return bl_fail(BL_ERR_INVALID, "session_duration is NULL");
+    if (dims && (dims->n_site_covs > 4 || dims->n_obs_covs > 4))
+        return bl_fail(BL_ERR_UNSUPPORTED, "occu_cop kernels are built for at most 4 covariates per side (Ks=%d, Ko=%d)",
+                       dims->n_site_covs, dims->n_obs_covs);
+    ModelOpts mo; mo.model = 3; mo.fp_mode = fp_mode; mo.session_duration = session_duration;
+    mo.fp_a = fp_mode ? prior_fp_rate : 1.0;
+    if (!(mo.fp_a > 0.0) || !std::isfinite(mo.fp_a)) return bl_fail(BL_ERR_INVALID, "Exponential prior needs a finite rate > 0");
+    return dataset_create_impl(mo, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
+}
+
 static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const float *site_covs, const float *obs_covs,
                                const float *obs, const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha,
                                int device, bl_dataset **out)
@@ -394,7 +429,8 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
     if (device < 0 || device >= ndev) return bl_fail(BL_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
 
     bl_dataset *ds = new bl_dataset();
-    ds->device = device; ds->dims = *dims; ds->Ks = Ks; ds->Ko = Ko; ds->D = Ks + Ko + 2 + (model == 2 ? 1 : 0);
+    const int has_extra = (model == 2 || (model == 3 && mo.fp_mode != 0)) ? 1 : 0; // trailing false-positive coordinate
+    ds->device = device; ds->dims = *dims; ds->Ks = Ks; ds->Ko = Ko; ds->D = Ks + Ko + 2 + has_extra;
     ds->model = model; ds->max_abundance = max_abundance;
     ds->fp_mode = mo.fp_mode; ds->fp_a = mo.fp_a; ds->fp_b = mo.fp_b;
     ds->KS = pad_covs(Ks); ds->KO = pad_covs(Ko);
@@ -402,15 +438,18 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
     ds->pb = pb; ds->pa = pa;
     if (!ds->kern) { delete ds; return bl_fail(BL_ERR_UNSUPPORTED, "no kernel for capacity (%d,%d)", pad_covs(Ks), pad_covs(Ko)); }
     const int V = T * J, KS = ds->KS, KO = ds->KO;
+    const int vw = KO + 1 + (model == 3 ? 1 : 0); // floats per visit
+    ds->ko_layout = vw - 1;
     const int n_stride = (N + 63) / 64 * 64;
-    const int n_rows = KS + V * (KO + 1) + 2 * T;
+    const int n_rows = KS + V * vw + 2 * T;
     ds->n_stride = n_stride; ds->n_rows = n_rows;
 
     // ---- pack: mask (occu.py:136-142, modeling.py:15-17), NaN->0, sign folding, site-fastest rows ----
     std::vector<float> rows((size_t)n_rows * n_stride, 0.0f);
     ds->h_wraw.assign((size_t)V * (Ko > 0 ? Ko : 1) * n_stride, 0.0f);
     const double LN2 = 0.69314718055994530942, LOG_TINY = -87.33654475055310898657;
-    const int row_wc = KS, row_ka = KS + V * (KO + 1), row_kb = row_ka + T;
+    const int row_wc = KS, row_ka = KS + V * vw, row_kb = row_ka + T;
+    double cop_const = 0.0; // occu_cop: sum over unmasked visits of y log(dur) - lgamma(y + 1)
     for (int i = 0; i < N; i++) {
         bool site_nan = false;
         for (int k = 0; k < Ks; k++) {
@@ -418,7 +457,34 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
             if (std::isnan(x)) { site_nan = true; x = 0.0f; }
             rows[(size_t)k * n_stride + i] = x;
         }
-        for (int t = 0; t < T; t++) {
+        for (int t = 0; t < T && model == 3; t++) {
+            // occu_cop.py:150-156,236-255: visit = (y_m, d_m, w_1..w_Ko), masked visits contribute nothing
+            double ysum = 0.0, dsum = 0.0;
+            for (int j = 0; j < J; j++) {
+                const int v = t * J + j;
+                const size_t o = ((size_t)i * T + t) * J + j;
+                bool cov_nan = site_nan;
+                const size_t r0 = (size_t)(row_wc + v * vw);
+                for (int k = 0; k < Ko; k++) {
+                    float x = obs_covs[o * Ko + k];
+                    if (std::isnan(x)) { cov_nan = true; x = 0.0f; }
+                    ds->h_wraw[((size_t)v * Ko + k) * n_stride + i] = x;
+                    rows[(r0 + 2 + k) * n_stride + i] = x;
+                }
+                const float y = obs[o], dur = mo.session_duration[o];
+                if (cov_nan || !std::isfinite(y)) {
+                    for (int k = 0; k < Ko; k++) rows[(r0 + 2 + k) * n_stride + i] = 0.0f;
+                    continue;
+                }
+                rows[r0 * n_stride + i] = y;
+                rows[(r0 + 1) * n_stride + i] = dur;
+                ysum += y; dsum += dur;
+                cop_const += (y > 0.0f ? (double)y * std::log((double)dur) : 0.0) - std::lgamma((double)y + 1.0);
+            }
+            rows[(size_t)(row_ka + t) * n_stride + i] = (float)ysum;
+            rows[(size_t)(row_kb + t) * n_stride + i] = (float)dsum;
+        }
+        for (int t = 0; t < T && model != 3; t++) {
             int n_masked = 0, n_det = 0;
             for (int j = 0; j < J; j++) {
                 const int v = t * J + j;
@@ -462,7 +528,11 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
     dd.loc_b = (float)pb.loc; dd.isc2_b = (float)(1.0 / (pb.scale * pb.scale));
     dd.loc_a = (float)pa.loc; dd.isc2_a = (float)(1.0 / (pa.scale * pa.scale));
     dd.prior_const = (Ks + 1) * std::log(pb.scale) + (Ko + 1) * std::log(pa.scale) + (Ks + Ko + 2) * 0.91893853320467274178;
-    dd.has_fp = model == 2 ? 1 : 0; dd.fp_a = (float)mo.fp_a; dd.fp_b = (float)mo.fp_b;
+    dd.has_fp = has_extra ? model : 0; dd.fp_a = (float)mo.fp_a; dd.fp_b = (float)mo.fp_b;
+    if (model == 3) {
+        dd.prior_const -= cop_const;                        // the parameter-free part of the Poisson log-pmf
+        if (has_extra) dd.prior_const -= std::log(mo.fp_a); // phi = log f, f ~ Exponential(r): energy r e^phi - phi - log r
+    }
     if (model == 2) // phi = logit f, f ~ Beta(a, b): the energy a softplus(-phi) + b softplus(phi) carries + log B(a, b)
         dd.prior_const += std::lgamma(mo.fp_a) + std::lgamma(mo.fp_b) - std::lgamma(mo.fp_a + mo.fp_b);
     *out = ds;
@@ -517,7 +587,7 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     if (k < 1) k = 1;
     const int lds_cap = BL_LDS_TOTAL - BL_OFF_DATA;
     // LDS keeps one record of `stride` floats per PAIR of sites (occu_device.hpp)
-    const int stride = bl_record_stride(ds->dims.n_periods, ds->dims.n_replicates, ds->KS, ds->KO);
+    const int stride = bl_record_stride(ds->dims.n_periods, ds->dims.n_replicates, ds->KS, ds->ko_layout);
     auto fits = [&](int kk, int *nloc) {
         *nloc = (N + kk - 1) / kk;
         return (long long)((*nloc + 1) / 2) * stride * 4 <= lds_cap;
@@ -536,12 +606,17 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
 __global__ void bl_logp_final_kernel(BlDevData dd, int k, const double *theta, const double *partial, double *U, double *grad)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
-    const int D = dd.Ks + dd.Ko + 2 + dd.has_fp;
+    const int D = dd.Ks + dd.Ko + 2 + (dd.has_fp ? 1 : 0);
     double acc = 0.0;
     if (lane <= D)
         for (int m = 0; m < k; m++) acc += partial[((size_t)b * k + m) * 64 + lane];
     double pr = 0.0;
-    if (lane < D && dd.has_fp && lane == D - 1) {
+    if (lane < D && dd.has_fp == 3 && lane == D - 1) {
+        // phi = log f, f ~ Exponential(rate r), Jacobian included: r e^phi - phi  (log r is in prior_const)
+        const double phi = theta[(size_t)b * D + lane], rf = dd.fp_a * exp(phi);
+        pr = rf - phi;
+        grad[(size_t)b * D + lane] = -acc + rf - 1.0;
+    } else if (lane < D && dd.has_fp && lane == D - 1) {
         // phi = logit f, f ~ Beta(a, b), Jacobian included: a softplus(-phi) + b softplus(phi)
         const double phi = theta[(size_t)b * D + lane], l = log1p(exp(-fabs(phi)));
         const double sig = 1.0 / (1.0 + exp(-phi));
@@ -573,18 +648,19 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
     for (size_t i = 0; i < th32.size(); i++) th32[i] = (float)theta[i];
     float *d_th32 = nullptr;
     double *d_th = nullptr, *d_partial = nullptr, *d_U = nullptr, *d_grad = nullptr;
-    BL_HIP(hipMalloc((void **)&d_th32, th32.size() * 4));
-    BL_HIP(hipMalloc((void **)&d_th, (size_t)B * D * 8));
-    BL_HIP(hipMalloc((void **)&d_partial, (size_t)B * k * 64 * 8));
-    BL_HIP(hipMalloc((void **)&d_U, (size_t)B * 8));
-    BL_HIP(hipMalloc((void **)&d_grad, (size_t)B * D * 8));
+    DevScratch scratch;
+    BL_HIP(scratch.alloc((void **)&d_th32, th32.size() * 4));
+    BL_HIP(scratch.alloc((void **)&d_th, (size_t)B * D * 8));
+    BL_HIP(scratch.alloc((void **)&d_partial, (size_t)B * k * 64 * 8));
+    BL_HIP(scratch.alloc((void **)&d_U, (size_t)B * 8));
+    BL_HIP(scratch.alloc((void **)&d_grad, (size_t)B * D * 8));
     BL_HIP(hipMemcpy(d_th32, th32.data(), th32.size() * 4, hipMemcpyHostToDevice));
     BL_HIP(hipMemcpy(d_th, theta, (size_t)B * D * 8, hipMemcpyHostToDevice));
     BL_HIP(hipMemset(d_partial, 0, (size_t)B * k * 64 * 8));
     BlLogpParams p{};
     p.dd = ds->dd; p.k = k; p.nloc = nloc; p.rec_stride = ld; p.B = B; p.theta = d_th32; p.partial = d_partial;
     p.max_abundance = ds->max_abundance;
-    p.fp_z1 = ds->fp_mode == BL_FP_CONSTANT ? 1 : 0;
+    p.fp_mode = ds->fp_mode;
     p.ncw = ncw;
     if (ds->model != 0 && !use_staged)
         return bl_fail(BL_ERR_UNSUPPORTED, "occu_rn / false-positive models need the LDS-staged path (slice too large, or staged=0 requested)");
@@ -594,7 +670,6 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
     BL_HIP(hipGetLastError());
     BL_HIP(hipMemcpy(U, d_U, (size_t)B * 8, hipMemcpyDeviceToHost));
     BL_HIP(hipMemcpy(grad, d_grad, (size_t)B * D * 8, hipMemcpyDeviceToHost));
-    hipFree(d_th32); hipFree(d_th); hipFree(d_partial); hipFree(d_U); hipFree(d_grad);
     return BL_OK;
 }
 
@@ -689,7 +764,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.k = k; p.nloc = nloc; p.rec_stride = ld; p.nvp = nvp;
     p.max_depth = max_depth;
     p.max_abundance = ds->max_abundance;
-    p.fp_z1 = ds->fp_mode == BL_FP_CONSTANT ? 1 : 0;
+    p.fp_mode = ds->fp_mode;
     p.ncw = ncw;
     p.xchg = ds->d_xchg;
     p.cold = d_cold;
@@ -850,7 +925,7 @@ __global__ void bl_psi_kernel(const float *__restrict__ rows, int n_stride, int 
 }
 // prob_detection[n][j][t][i] = sigmoid(alpha0 + w_itj . alpha)   (occu.py:221-228)
 __global__ void bl_pdet_kernel(const float *__restrict__ wraw, int n_stride, int N, int T, int J, int Ks, int Ko, int D,
-                               const float *__restrict__ draws, int n0, int n1, float *__restrict__ out)
+                               const float *__restrict__ draws, int n0, int n1, float *__restrict__ out, int model)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -861,7 +936,8 @@ __global__ void bl_pdet_kernel(const float *__restrict__ wraw, int n_stride, int
                 const int v = t * J + j;
                 float nu = al[0];
                 for (int k = 0; k < Ko; k++) nu = fmaf(wraw[((size_t)v * Ko + k) * n_stride + i], al[k + 1], nu);
-                out[(((size_t)(n - n0) * J + j) * T + t) * N + i] = 1.0f / (1.0f + __expf(-nu));
+                // occu / occu_rn: prob_detection = sigmoid(nu); occu_cop: rate_detection = exp(nu) (occu_cop.py:236-243)
+                out[(((size_t)(n - n0) * J + j) * T + t) * N + i] = model == 3 ? __expf(nu) : 1.0f / (1.0f + __expf(-nu));
             }
     }
 }
@@ -874,14 +950,15 @@ extern "C" int bl_deterministic(bl_dataset *ds, int n_draws, const float *draws,
     if (rc) return rc;
     const int N = ds->dims.n_sites, T = ds->dims.n_periods, J = ds->dims.n_replicates, D = ds->D;
     float *d_draws = nullptr, *d_out = nullptr;
-    BL_HIP(hipMalloc((void **)&d_draws, (size_t)n_draws * D * 4));
+    DevScratch scratch;
+    BL_HIP(scratch.alloc((void **)&d_draws, (size_t)n_draws * D * 4));
     BL_HIP(hipMemcpy(d_draws, draws, (size_t)n_draws * D * 4, hipMemcpyHostToDevice));
     // chunk the draws so the device staging buffer stays <= 256 MiB
     const size_t per_draw = (size_t)T * N * 4 * (prob_detection ? (size_t)J : 1);
     int chunk = (int)((256u << 20) / (per_draw ? per_draw : 1));
     if (chunk < 1) chunk = 1;
     if (chunk > n_draws) chunk = n_draws;
-    BL_HIP(hipMalloc((void **)&d_out, (size_t)chunk * per_draw));
+    BL_HIP(scratch.alloc((void **)&d_out, (size_t)chunk * per_draw));
     if (prob_detection && !ds->d_wraw) {
         BL_HIP(hipMalloc((void **)&ds->d_wraw, ds->h_wraw.size() * 4));
         BL_HIP(hipMemcpy(ds->d_wraw, ds->h_wraw.data(), ds->h_wraw.size() * 4, hipMemcpyHostToDevice));
@@ -896,11 +973,10 @@ extern "C" int bl_deterministic(bl_dataset *ds, int n_draws, const float *draws,
             BL_HIP(hipMemcpy(psi + (size_t)n0 * T * N, d_out, (size_t)(n1 - n0) * T * N * 4, hipMemcpyDeviceToHost));
         }
         if (prob_detection) {
-            hipLaunchKernelGGL(bl_pdet_kernel, grid, block, 0, nullptr, ds->d_wraw, ds->n_stride, N, T, J, ds->Ks, ds->Ko, D, d_draws, n0, n1, d_out);
+            hipLaunchKernelGGL(bl_pdet_kernel, grid, block, 0, nullptr, ds->d_wraw, ds->n_stride, N, T, J, ds->Ks, ds->Ko, D, d_draws, n0, n1, d_out, ds->model);
             BL_HIP(hipGetLastError());
             BL_HIP(hipMemcpy(prob_detection + (size_t)n0 * J * T * N, d_out, (size_t)(n1 - n0) * J * T * N * 4, hipMemcpyDeviceToHost));
         }
     }
-    hipFree(d_draws); hipFree(d_out);
     return BL_OK;
 }

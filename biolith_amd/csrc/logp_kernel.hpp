@@ -8,7 +8,7 @@ struct BlLogpParams {
     BlDevData dd;
     int k, nloc, rec_stride;
     int max_abundance;   // occu_rn only
-    int fp_z1;           // false-positive model only (see BlNutsParams)
+    int fp_mode;         // false-positive coordinate (see BlNutsParams)
     int ncw;             // compute waves per workgroup: selects the CW instantiation (host side)
     int B;
     const float *theta;  // [B][D] float32 view of the caller's double theta
@@ -20,14 +20,14 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_logp_kernel(const BlLogpPara
 {
     const int member = blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int Ks = p.dd.Ks, Ko = p.dd.Ko, D = bl_model_dim<MODEL>(Ks, Ko);
+    const int Ks = p.dd.Ks, Ko = p.dd.Ko, D = bl_model_dim<MODEL>(Ks, Ko, p.fp_mode);
     const int s0 = member * p.nloc;
     int cnt = p.dd.n_sites - s0;
     cnt = cnt < 0 ? 0 : (cnt > p.nloc ? p.nloc : cnt);
     const float *grows = nullptr;
     int ld = p.rec_stride;
     if constexpr (LDS) {
-        bl_stage_records(p.dd.rows, p.dd.n_stride, s0, cnt, p.dd.T, p.dd.J, KS, KO, p.rec_stride, 64 * (CW + 1));
+        bl_stage_records(p.dd.rows, p.dd.n_stride, s0, cnt, p.dd.T, p.dd.J, KS, bl_layout_ko<MODEL>(KO), p.rec_stride, 64 * (CW + 1));
     } else {
         grows = p.dd.rows + s0;
         ld = p.dd.n_stride;
@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_logp_kernel(const BlLogpPara
         if (wave == 0 && lane < D) sh_coef[my_pos] = p.theta[(size_t)b * D + lane];
         __syncthreads();
         if (wave > 0) { // compute waves, exactly as in the NUTS kernel
-            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, p.dd.T, p.dd.J, p.max_abundance, p.fp_z1);
+            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, p.dd.T, p.dd.J, p.max_abundance, p.fp_mode);
         }
         __syncthreads();
         if (wave == 0) {

@@ -67,7 +67,7 @@ struct BlNutsCold {
     int win_end[32];               // numpyro adaptation windows (inclusive ends)
     float loc_b, isc2_b, loc_a, isc2_a;  // Normal prior loc, 1/scale^2
     double prior_const;            // sum_k log(scale_k) + D/2 log(2 pi)  (+ log B(a,b) for MODEL 2)
-    float fp_a, fp_b;              // MODEL 2: Beta(a, b) prior of the false-positive rate
+    float fp_a, fp_b;              // MODEL 2: Beta(a, b) prior of the false-positive rate; MODEL 3: Exponential(rate = fp_a)
     const uint32_t *rng;           // [C][64][4] xoshiro states (host-jumped)
     const float *init_theta;       // [C][D] or null -> Uniform(-2,2)
     const int *abort_flag;         // host-mapped
@@ -93,7 +93,7 @@ struct BlNutsParams {
     int rec_stride;                // floats per LDS pair record
     int nvp;                       // granules per workgroup record: 16, 32 or 64 (>= D+4)
     int ncw;                       // compute waves per workgroup: selects the CW instantiation (host side)
-    int fp_z1;                     // MODEL 2: 1 = the false-positive rate also acts on occupied sites ("constant")
+    int fp_mode;                   // MODEL 2 / 3: 0 none, 1 = rate acts on every site ("constant"), 2 = on unoccupied sites only
     int max_depth;
     int max_abundance;             // occu_rn only (occu_rn.py:26)
     int allow_local;               // 0: always use the placement-independent exchange
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     const int chain = label + 8 * (slot / p.k), member = slot % p.k;
     if (chain >= p.num_chains) return; // whole block leaves before any barrier or exchange
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int Ks = p.Ks, Ko = p.Ko, D = bl_model_dim<MODEL>(Ks, Ko);
+    const int Ks = p.Ks, Ko = p.Ko, D = bl_model_dim<MODEL>(Ks, Ko, p.fp_mode);
     const int T = p.T, J = p.J;
     const int s0 = member * p.nloc;
     int cnt = p.n_sites - s0;
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     const float *grows = nullptr;
     int ld = p.rec_stride;
     if constexpr (LDS) {
-        bl_stage_records(p.rows, p.n_stride, s0, cnt, T, J, KS, KO, p.rec_stride, 64 * (CW + 1));
+        bl_stage_records(p.rows, p.n_stride, s0, cnt, T, J, KS, bl_layout_ko<MODEL>(KO), p.rec_stride, 64 * (CW + 1));
     } else {
         grows = p.rows + s0;
         ld = p.n_stride;
@@ -202,7 +202,8 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     const bool act = lane < D;
     // where lane d's coefficient / partial lives in the padded LDS layouts; lanes >= D read the log-lik
     const int my_pos = act ? bl_coef_pos(lane, Ks, Ko, KS, KO) : KS + KO + 2;
-    const bool is_phi = MODEL == 2 && lane == D - 1; // the logit false-positive rate: Beta prior, not Normal
+    // the false-positive coordinate (logit rate, Beta prior: MODEL 2; log rate, Exponential prior: MODEL 3), not Normal
+    const bool is_phi = (MODEL == 2 || (MODEL == 3 && p.fp_mode != 0)) && lane == D - 1;
     // ---- loop-carried registers: only what the per-leaf path touches ----
     BlRng rng_d, rng_u, rng_dir;        // per-dimension stream, transition uniforms, direction bits
     float minv = act ? 1.0f : 0.0f;     // diagonal inverse mass (0 in idle lanes keeps sums clean)
@@ -321,7 +322,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #ifdef BL_STAMPS
             const long long st_a0 = (long long)clock64();
 #endif
-            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_z1);
+            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode);
 #ifdef BL_STAMPS
             st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
 #endif
@@ -622,6 +623,14 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                     const float sig = (cz > 0.0f ? 1.0f : e) * bl_rcp(op);
                     pe2 = 2.0f * (prior_loc * (fmaxf(-cz, 0.0f) + l) + prior_isc2 * (fmaxf(cz, 0.0f) + l));
                     pg = (prior_loc + prior_isc2) * sig - prior_loc;
+                }
+            }
+            if constexpr (MODEL == 3) {
+                //   phi = log f, f ~ Exponential(rate r):  energy = r e^phi - phi  (Jacobian included),  pg = r e^phi - 1
+                if (is_phi) {
+                    const float rf = prior_loc * bl_exp(fminf(cz, 80.0f));
+                    pe2 = 2.0f * (rf - cz);
+                    pg = rf - 1.0f;
                 }
             }
             const float cg = act ? (-(float)acc + pg) : 0.0f;

@@ -64,8 +64,9 @@ struct BlDevData {
     int KS, KO;     // padded counts the rows were packed for (= kernel template capacity)
     float loc_b, isc2_b, loc_a, isc2_a;  // Normal prior loc, 1/scale^2
     double prior_const;                  // sum_k log(scale_k) + D/2 log(2 pi)  (+ log B(a,b) with has_fp)
-    int has_fp;                          // 1: theta carries phi = logit(false-positive rate) as its last coordinate
-    float fp_a, fp_b;                    // its Beta(a, b) prior
+    int has_fp;                          // 0, or the model id (2: logit rate, Beta prior; 3: log rate, Exponential prior)
+                                         // whose false-positive coordinate phi is theta's last entry
+    float fp_a, fp_b;                    // its prior: Beta(a, b) / Exponential(rate = a)
 };
 
 __host__ __device__ inline int bl_round4(int x) { return (x + 3) & ~3; }
@@ -626,6 +627,140 @@ __device__ __forceinline__ void bl_eval_sites_fp(int ct, int pstride, int cnt, i
 }
 
 
+// ------------------------------------------------------- count occupancy (occu_cop, MODEL 3) ----
+// biolith/models/occu_cop.py:17-255: y_itj ~ Poisson(dur_itj * (z lambda_itj + (1 - z) f_u + f_c)),
+// lambda = exp(alpha0 + w alpha), z ~ Bernoulli(psi) summed out; at most one of the false-positive rates
+// f_c ("constant") / f_u ("unoccupied") is sampled (fp_mode 1 / 2, else 0).  With f the sampled rate:
+//   z = 1:  rate dur (lambda + f1)   (f1 = f for "constant", else 0),      z = 0:  rate dur f0  (f0 = f, or 0)
+// The parameter-free part sum m (y log dur - lgamma(y+1)) is common to both branches and is added by
+// the host to the constant of the potential.  What remains per visit (m folded into y_m, d_m):
+//   z = 1:  y_m log(lambda + f1) - d_m (lambda + f1)     [ = y_m nu - d_m lambda  when f1 = 0: no log ]
+//   z = 0:  Ysum log f - Dsum f                          [ f0 = 0:  0 if Ysum = 0, else -inf: Poisson(0) ]
+// Records: visit = (y_m, d_m, w_1..w_KO) -- one float wider than an occu visit, so every layout helper
+// is called with KO + 1 -- and per period ka = Ysum, kb = Dsum.  The rate enters as phi = log f
+// (NumPyro's unconstrained coordinate of a positive site); d/dphi = f d/df is accumulated in gphi.
+struct BlCopScalars {
+    float f, f1, phi;  // sampled rate, its share in the z = 1 branch, log f
+    float has0;        // 1 if the z = 0 branch has a positive rate
+    float z1;          // 1 if f acts on occupied sites
+};
+__device__ __forceinline__ BlCopScalars bl_cop_scalars(float phi, int fp_mode)
+{
+    BlCopScalars s;
+    s.phi = phi;
+    s.f = fp_mode ? __builtin_amdgcn_exp2f(fminf(phi, 80.0f) * BL_LOG2E) : 0.0f;
+    s.z1 = fp_mode == 1 ? 1.0f : 0.0f;
+    s.f1 = fp_mode == 1 ? s.f : 0.0f;
+    s.has0 = fp_mode ? 1.0f : 0.0f;
+    return s;
+}
+
+template <int KS, int KO, int CT>
+__device__ __forceinline__ void bl_eval_sites_cop(int ct, int pstride, int cnt, int T, int J, const BlCopScalars fp,
+                                                  const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
+                                                  float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], float &gphi)
+{
+    constexpr int XQ = (KS + 3) & ~3;
+    constexpr int VW = KO + 2; // floats per visit
+    const int pb = bl_period_block(J, KO + 1);
+    const float *data = bl_lds_f(BL_OFF_DATA);
+    const int npairs = (cnt + 1) >> 1;
+    const bool with_f1 = fp.z1 != 0.0f; // wave-uniform
+    bl_f2 ll2 = bl2(0.0f), gb2[KS + 1], ga2[KO + 1], gp2 = bl2(0.0f);
+#pragma unroll
+    for (int k = 0; k <= KS; k++) gb2[k] = bl2(0.0f);
+#pragma unroll
+    for (int k = 0; k <= KO; k++) ga2[k] = bl2(0.0f);
+    for (int m = ct; m < npairs; m += CT) {
+        const float4 *rec = reinterpret_cast<const float4 *>(data + (size_t)m * pstride);
+        const bl_f2 vmask = bl_f2{1.0f, (2 * m + 1 < cnt) ? 1.0f : 0.0f};
+        bl_f2 x[XQ];
+#pragma unroll
+        for (int q = 0; q < XQ / 2; q++) {
+            const float4 v = rec[q];
+            x[2 * q] = bl_f2{v.x, v.y};
+            x[2 * q + 1] = bl_f2{v.z, v.w};
+        }
+        bl_f2 eta = bl2(beta[0]);
+#pragma unroll
+        for (int k = 0; k < KS; k++) eta = bl_fma2(x[k], bl2(beta[k + 1]), eta);
+        const bl_f2 e_eta = bl_exp2_2(__builtin_elementwise_abs(eta) * bl2(-BL_LOG2E));
+        const bl_f2 op_eta = e_eta + bl2(1.0f);
+        const bl_f2 sp = bl_fma2(bl_log2_2(op_eta), bl2(BL_LN2), __builtin_elementwise_max(eta, bl2(0.0f)));
+        const bl_f2 psi = bl_sel_pos_one(eta, e_eta) * bl_rcp_2(op_eta);
+        bl_f2 dsum = bl2(0.0f), lsite = bl2(0.0f), gpsite = bl2(0.0f);
+        const float2 *pp0 = reinterpret_cast<const float2 *>(data + (size_t)m * pstride) + XQ;
+        for (int t = 0; t < T; t++) {
+            const float2 *pp = pp0 + t * pb;
+            bl_f2 g[KO + 1];
+#pragma unroll
+            for (int k = 0; k <= KO; k++) g[k] = bl2(0.0f);
+            const float2 ys_ = pp[J * VW], ds_ = pp[J * VW + 1];
+            const bl_f2 ysum = bl_f2{ys_.x, ys_.y}, dsm = bl_f2{ds_.x, ds_.y};
+            bl_f2 a = bl2(0.0f), gf = bl2(0.0f);
+#pragma unroll 2
+            for (int j = 0; j < J; j++) {
+                const float2 y_ = pp[j * VW], d_ = pp[j * VW + 1];
+                const bl_f2 ym = bl_f2{y_.x, y_.y}, dm = bl_f2{d_.x, d_.y};
+                bl_f2 w[KO > 0 ? KO : 1];
+                bl_f2 nu = bl2(alpha[0]);
+#pragma unroll
+                for (int k = 0; k < KO; k++) {
+                    const float2 v = pp[j * VW + 2 + k];
+                    w[k] = bl_f2{v.x, v.y};
+                    nu = bl_fma2(w[k], bl2(alpha[k + 1]), nu);
+                }
+                nu = __builtin_elementwise_min(nu, bl2(80.0f)); // keeps lambda finite: 0 * inf on masked visits
+                const bl_f2 lam = bl_exp2_2(nu * bl2(BL_LOG2E));
+                bl_f2 s; // d/dnu
+                if (with_f1) {
+                    const bl_f2 tt = lam + bl2(fp.f1);
+                    a = bl_fma2(bl_log2_2(tt) * bl2(BL_LN2), ym, bl_fma2(dm, -tt, a));
+                    const bl_f2 r = bl_fma2(ym, bl_rcp_2(tt), -dm); // y / (lambda + f) - d
+                    gf += r;
+                    s = r * lam;
+                } else {
+                    a = bl_fma2(ym, nu, bl_fma2(dm, -lam, a));
+                    s = bl_fma2(dm, -lam, ym);
+                }
+                g[0] += s;
+#pragma unroll
+                for (int k = 0; k < KO; k++) g[k + 1] = bl_fma2(s, w[k], g[k + 1]);
+            }
+            // z = 0 branch: Ysum log f - Dsum f, or Poisson(0): 0 / -inf
+            const bl_f2 b_f = bl_fma2(ysum, bl2(fp.phi), dsm * bl2(-fp.f));
+            const bl_f2 b_0 = bl_f2{ysum.x > 0.0f ? -INFINITY : 0.0f, ysum.y > 0.0f ? -INFINITY : 0.0f};
+            const bl_f2 kb = fp.has0 != 0.0f ? b_f : b_0;
+            const bl_f2 A = eta - sp + a, B = kb - sp;
+            const bl_f2 d = eta + a - kb;
+            const bl_f2 e_d = bl_exp2_2(__builtin_elementwise_abs(d) * bl2(-BL_LOG2E));
+            const bl_f2 op_d = e_d + bl2(1.0f);
+            lsite += bl_fma2(bl_log2_2(op_d), bl2(BL_LN2), __builtin_elementwise_max(A, B));
+            const bl_f2 q = bl_sel_pos_one(d, e_d) * bl_rcp_2(op_d); // P(z=1 | y, theta)
+            dsum += q - psi;
+#pragma unroll
+            for (int k = 0; k <= KO; k++) ga2[k] = bl_fma2(q, g[k], ga2[k]);
+            // d/dphi = f d/df:  z=1: f sum_j (y/(lambda+f) - d)  ("constant" only);  z=0: Ysum - Dsum f
+            const bl_f2 d1 = gf * bl2(fp.f * fp.z1);
+            const bl_f2 d0 = bl_fma2(dsm, bl2(-fp.f), ysum) * bl2(fp.has0);
+            gpsite += bl_fma2(q, d1 - d0, d0);
+        }
+        ll2 = bl_fma2(lsite, vmask, ll2);
+        gp2 = bl_fma2(gpsite, vmask, gp2);
+        dsum *= vmask;
+        gb2[0] += dsum;
+#pragma unroll
+        for (int k = 0; k < KS; k++) gb2[k + 1] = bl_fma2(dsum, x[k], gb2[k + 1]);
+    }
+    ll += ll2.x + ll2.y;
+    gphi += gp2.x + gp2.y;
+#pragma unroll
+    for (int k = 0; k <= KS; k++) gb[k] += gb2[k].x + gb2[k].y;
+#pragma unroll
+    for (int k = 0; k <= KO; k++) ga[k] += ga2[k].x + ga2[k].y;
+}
+
+
 // ---------------------------------------------------------------- Royle-Nichols (occu_rn) ----
 // biolith/models/occu_rn.py:179-222 + utils/distributions.py:31-40 with N summed out:
 //   lambda = exp(eta);  pi_n = Poisson(lambda)(n) renormalised over n <= K   (K = max_abundance)
@@ -900,7 +1035,13 @@ __device__ __forceinline__ int bl_coef_pos(int d, int Ks, int Ko, int KS, int KO
     return d <= Ks ? d : (d <= Ks + Ko + 1 ? KS + 1 + (d - Ks - 1) : KS + KO + 3);
 }
 // theta dimension of a model
-template <int MODEL> __device__ __forceinline__ int bl_model_dim(int Ks, int Ko) { return Ks + Ko + 2 + (MODEL == 2 ? 1 : 0); }
+// theta dimension of a model: MODEL 2 always carries the false-positive coordinate, MODEL 3 when fp_mode != 0
+template <int MODEL> __device__ __forceinline__ int bl_model_dim(int Ks, int Ko, int fp_mode)
+{
+    return Ks + Ko + 2 + ((MODEL == 2 || (MODEL == 3 && fp_mode != 0)) ? 1 : 0);
+}
+// visit width of the records in floats minus one: the KO every layout helper is called with
+template <int MODEL> __device__ __forceinline__ constexpr int bl_layout_ko(int KO) { return KO + (MODEL == 3 ? 1 : 0); }
 
 template <int KS, int KO>
 __device__ __forceinline__ void bl_load_coefs(float (&beta)[KS + 1], float (&alpha)[KO + 1])
@@ -941,7 +1082,7 @@ __device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, con
 // workgroup's site slice, wave partials into the LDS table.  Shared by the NUTS and logp kernels.
 template <int KS, int KO, bool LDS, int MODEL, int CW>
 __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__restrict__ grows, int ld_or_stride, int cnt,
-                                           int T, int J, int max_abundance, int fp_z1)
+                                           int T, int J, int max_abundance, int fp_mode)
 {
     float beta[KS + 1], alpha[KO + 1];
     bl_load_coefs<KS, KO>(beta, alpha);
@@ -953,8 +1094,14 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
     if constexpr (MODEL == 2) {
         static_assert(LDS, "false-positive model: LDS records only");
         float gphi = 0.0f;
-        const BlFpScalars fp = bl_fp_scalars(bl_lds_f(BL_OFF_COEF)[KS + KO + 3], fp_z1);
+        const BlFpScalars fp = bl_fp_scalars(bl_lds_f(BL_OFF_COEF)[KS + KO + 3], fp_mode == 1);
         bl_eval_sites_fp<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi);
+        bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi);
+    } else if constexpr (MODEL == 3) {
+        static_assert(LDS, "count occupancy model: LDS records only");
+        float gphi = 0.0f;
+        const BlCopScalars fp = bl_cop_scalars(bl_lds_f(BL_OFF_COEF)[KS + KO + 3], fp_mode);
+        bl_eval_sites_cop<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi);
         bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi);
     } else {
         bl_eval_sites<KS, KO, LDS, MODEL, CW * 64>(ct, grows, ld_or_stride, cnt, T, J, max_abundance, beta, alpha, ll, gb, ga);

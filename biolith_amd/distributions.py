@@ -27,6 +27,26 @@ class Beta:
     concentration0: float = 1.0
 
 
+@dataclass(frozen=True)
+class Exponential:
+    rate: float = 1.0
+
+
+def as_exponential(prior, name: str = "prior") -> float:
+    """rate of an Exponential prior; duck-types numpyro's ``dist.Exponential`` (has .rate)."""
+    if type(prior).__name__ != "Exponential" or not hasattr(prior, "rate"):
+        raise NotImplementedError(f"{name}: the HIP engine supports Exponential(rate) priors here, got {prior!r}")
+    import numpy as np
+
+    rate = np.asarray(prior.rate, dtype=float)
+    if rate.size != 1:
+        raise NotImplementedError(f"{name}: scalar rate only")
+    rate = float(rate.reshape(()))
+    if not rate > 0:
+        raise ValueError(f"{name}: rate must be positive")
+    return rate
+
+
 def as_normal(prior, name: str = "prior") -> tuple:
     """(loc, scale) of a Normal prior; duck-types numpyro's ``dist.Normal`` (has .loc/.scale)."""
     cls = type(prior).__name__

@@ -49,11 +49,12 @@ class OccuDataset:
     """
 
     def __init__(self, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0), device: int = 0,
-                 model: str = "occu", max_abundance: int = 100, fp_mode: str = "constant", prior_fp=(2.0, 5.0)):
+                 model: str = "occu", max_abundance: int = 100, fp_mode: Optional[str] = "constant", prior_fp=(2.0, 5.0),
+                 session_duration=None, prior_fp_rate: float = 1.0):
         lib = _ffi.load()
-        if model not in ("occu", "occu_rn", "occu_fp"):
+        if model not in ("occu", "occu_rn", "occu_fp", "occu_cop"):
             raise ValueError(f"unknown model {model!r}")
-        if fp_mode not in ("constant", "unoccupied"):
+        if fp_mode not in ("constant", "unoccupied") and not (model == "occu_cop" and fp_mode is None):
             raise ValueError(f"unknown fp_mode {fp_mode!r}")
         self.model, self.max_abundance = model, int(max_abundance)
         self.fp_mode, self.prior_fp = fp_mode, (float(prior_fp[0]), float(prior_fp[1]))
@@ -74,7 +75,8 @@ class OccuDataset:
             raise ValueError("obs must have shape (n_species, n_sites, n_periods, n_replicates) matching obs_covs")
         self.dims = _ffi.bl_dims(Y.shape[0], N, T, J, Ks, Ko)
         self.N, self.T, self.J, self.Ks, self.Ko, self.S = N, T, J, Ks, Ko, Y.shape[0]
-        self.D = Ks + Ko + 2 + (1 if model == "occu_fp" else 0)  # occu_fp: trailing phi = logit(false-positive rate)
+        # occu_fp: trailing phi = logit(false-positive rate); occu_cop with a false-positive rate: phi = log(rate)
+        self.D = Ks + Ko + 2 + (1 if model == "occu_fp" or (model == "occu_cop" and fp_mode is not None) else 0)
         self.device = device
         pb = _ffi.bl_normal_prior(float(prior_beta[0]), float(prior_beta[1]))
         pa = _ffi.bl_normal_prior(float(prior_alpha[0]), float(prior_alpha[1]))
@@ -82,6 +84,15 @@ class OccuDataset:
         if model == "occu_rn":
             _ffi.check(lib.bl_dataset_create_rn(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), int(max_abundance),
                                                 C.byref(pb), C.byref(pa), device, C.byref(h)))
+        elif model == "occu_cop":
+            if session_duration is None:
+                raise ValueError("occu_cop needs session_duration (n_sites, n_periods, n_replicates)")
+            Dur = np.ascontiguousarray(session_duration, dtype=np.float32)
+            if Dur.shape != (N, T, J):
+                raise ValueError("session_duration must have shape (n_sites, n_periods, n_replicates)")
+            mode = {None: 0, "constant": _ffi.FP_CONSTANT, "unoccupied": _ffi.FP_UNOCCUPIED}[fp_mode]
+            _ffi.check(lib.bl_dataset_create_cop(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), _fp(Dur), mode,
+                                                 float(prior_fp_rate), C.byref(pb), C.byref(pa), device, C.byref(h)))
         elif model == "occu_fp":
             pf = _ffi.bl_beta_prior(*self.prior_fp)
             mode = _ffi.FP_CONSTANT if fp_mode == "constant" else _ffi.FP_UNOCCUPIED

@@ -147,6 +147,9 @@ def engine_options(spec) -> dict:
     opts = dict(max_abundance=spec.extras.get("max_abundance", 100))
     if spec.model == "occu_fp":
         opts.update(fp_mode=spec.extras["fp_mode"], prior_fp=spec.extras["prior_fp"])
+    if spec.model == "occu_cop":
+        opts.update(fp_mode=spec.extras["fp_mode"], session_duration=spec.extras["session_duration"],
+                    prior_fp_rate=spec.extras.get("prior_fp_rate", 1.0))
     return opts
 
 
@@ -178,6 +181,9 @@ def _assemble(per_species, spec, num_warmup) -> HipMCMC:
         # the engine samples phi = logit(rate); the model's site is the rate itself, shape (C, S) (occu.py:146-157)
         phi = res0.draws[:, :, Ks + Ko + 2].astype(np.float64)
         latent[f"prob_fp_{spec.extras['fp_mode']}"] = (1.0 / (1.0 + np.exp(-phi))).astype(np.float32)
+    if spec.model == "occu_cop" and spec.extras["fp_mode"] is not None:
+        # phi = log(rate); the model's site is the rate (occu_cop.py:158-170)
+        latent[f"rate_fp_{spec.extras['fp_mode']}"] = np.exp(res0.draws[:, :, Ks + Ko + 2].astype(np.float64)).astype(np.float32)
     if S:
         psi = np.stack([d.deterministic(r.draws.reshape(C * S, D), psi=True, prob_detection=False)[0]
                         for d, r in per_species], axis=-1)
@@ -205,6 +211,8 @@ def _assemble(per_species, spec, num_warmup) -> HipMCMC:
     res.draws = np.concatenate([r.draws for _, r in per_species], axis=2) if nsp > 1 else res0.draws
     # occu emits "psi" (occu.py:207); occu_rn emits "abundance" = exp(linear predictor) (occu_rn.py:192)
     first = "abundance" if spec.model == "occu_rn" else "psi"
+    # occu_cop's replicate-level site is the detection RATE exp(linear predictor) (occu_cop.py:236-243)
+    second = "rate_detection" if spec.model == "occu_cop" else "prob_detection"
     return HipMCMC(res, latent=latent,
-                   deterministic={first: psi, "prob_detection": prob_detection},
+                   deterministic={first: psi, second: prob_detection},
                    num_warmup=num_warmup, spec_shape=spec.shape)

@@ -97,6 +97,19 @@ int bl_dataset_create_fp(const bl_dims *dims, const float *site_covs, const floa
                          const float *obs, int fp_mode, const bl_beta_prior *prior_fp,
                          const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha,
                          int device, bl_dataset **out);
+/*
+ * Same for the count occupancy model biolith.models.occu_cop (models/occu_cop.py:17-255):
+ *   y_itj ~ Poisson(session_duration_itj * (z lambda_itj + (1 - z) f_u + f_c)),  lambda = exp(alpha0 + w alpha),
+ * obs holds counts, session_duration [N][T][J] the exposure (occu_cop.py:176, 250-254).  fp_mode 0: no
+ * false-positive rate; BL_FP_CONSTANT / BL_FP_UNOCCUPIED: sites "rate_fp_constant" / "rate_fp_unoccupied"
+ * with an Exponential(prior_fp_rate) prior (occu_cop.py:31-32, 158-170) sampled as a trailing coordinate
+ * phi = log(rate).  bl_deterministic's second output becomes `rate_detection` = exp(alpha0 + w alpha)
+ * (occu_cop.py:236-243).  Built for at most 4 covariates per side; bl_predict is not built for it.
+ */
+int bl_dataset_create_cop(const bl_dims *dims, const float *site_covs, const float *obs_covs,
+                          const float *obs, const float *session_duration, int fp_mode,
+                          double prior_fp_rate, const bl_normal_prior *prior_beta,
+                          const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
 int bl_dataset_destroy(bl_dataset *ds);
 /* D = Ks+1 + Ko+1; theta = [beta_0..beta_Ks, alpha_0..alpha_Ko] */
 int bl_dataset_param_dim(const bl_dataset *ds, int *D);

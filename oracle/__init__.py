@@ -15,6 +15,7 @@ from .oracle import (  # noqa: F401
     effective_sample_size,
     lib,
     literal_log_joint,
+    literal_log_joint_cop,
     literal_log_joint_fp,
     literal_log_joint_rn,
     nuts_run,

@@ -48,6 +48,7 @@ def lib():
             L.orc_data_dim.argtypes = [C.c_void_p]
             L.orc_data_set_model.argtypes = [C.c_void_p, C.c_int, C.c_int]
             L.orc_data_set_fp.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+            L.orc_data_set_cop.argtypes = [C.c_void_p, dp, dp, C.c_int, C.c_double]
             L.orc_potential_grad.restype = C.c_double
             L.orc_potential_grad.argtypes = [C.c_void_p, dp, dp]
             L.orc_rng_streams.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
@@ -82,7 +83,7 @@ class OracleData:
     """Prepared dataset for ONE species: site_covs (N,Ks), obs_covs (N,T,J,Ko), obs (N,T,J)."""
 
     def __init__(self, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0), model="occu",
-                 max_abundance=100, fp_mode="constant", prior_fp=(2.0, 5.0)):
+                 max_abundance=100, fp_mode="constant", prior_fp=(2.0, 5.0), session_duration=None, prior_fp_rate=1.0):
         X = _as_f32_f64(site_covs)
         W = _as_f32_f64(obs_covs)
         Y = _as_f32_f64(obs)
@@ -102,13 +103,21 @@ class OracleData:
         self.X, self.W, self.Y = X, W, Y
         self.prior_beta, self.prior_alpha = tuple(prior_beta), tuple(prior_alpha)
         self.model, self.max_abundance = model, int(max_abundance)
-        assert model in ("occu", "occu_rn", "occu_fp")
+        assert model in ("occu", "occu_rn", "occu_fp", "occu_cop")
         lib().orc_data_set_model(self._h, 1 if model == "occu_rn" else 0, int(max_abundance))
         if model == "occu_fp":  # theta gains phi = logit(false-positive rate) as its last coordinate
             assert fp_mode in ("constant", "unoccupied")
             lib().orc_data_set_fp(self._h, 1 if fp_mode == "constant" else 2, float(prior_fp[0]), float(prior_fp[1]))
             self.D += 1
-        self.fp_mode, self.prior_fp = fp_mode, tuple(prior_fp)
+        if model == "occu_cop":  # counts + exposure; optional false-positive rate as trailing phi = log(rate)
+            assert fp_mode in (None, "constant", "unoccupied")
+            Dur = _as_f32_f64(session_duration)
+            assert Dur.shape == (N, T, J)
+            self.Dur = Dur
+            lib().orc_data_set_cop(self._h, _dp(Y), _dp(Dur), {None: 0, "constant": 1, "unoccupied": 2}[fp_mode],
+                                   float(prior_fp_rate))
+            self.D += 1 if fp_mode else 0
+        self.fp_mode, self.prior_fp, self.prior_fp_rate = fp_mode, tuple(prior_fp), float(prior_fp_rate)
 
     def __del__(self):
         try:
@@ -261,6 +270,46 @@ def literal_log_joint_fp(theta, site_covs, obs_covs, obs, fp_mode="constant", pr
     beta_logpdf = (a - 1.0) * np.log(f) + (b - 1.0) * np.log1p(-f) - betaln(a, b)
     return (literal_log_joint(theta[:-1], site_covs, obs_covs, obs, prior_beta, prior_alpha, **kw)
             + beta_logpdf + np.log(f) + np.log1p(-f))
+
+
+def literal_log_joint_cop(theta, site_covs, obs_covs, obs, session_duration, fp_mode=None, prior_fp_rate=1.0,
+                          prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):
+    """log density of the count occupancy model (biolith/models/occu_cop.py:150-255) in NumPyro's unconstrained
+    space, z summed by brute force: theta = [beta, alpha (, phi = log rate_fp)]."""
+    from scipy.special import gammaln, xlogy
+
+    X, W, Y, Dur = (_as_f32_f64(a) for a in (site_covs, obs_covs, obs, session_duration))
+    if Y.ndim == 4:
+        Y = Y[0]
+    Ks, Ko = X.shape[1], W.shape[-1]
+    theta = np.asarray(theta, dtype=np.float64)
+    beta, alpha = theta[: Ks + 1], theta[Ks + 1: Ks + Ko + 2]
+    f = np.exp(theta[-1]) if fp_mode else 0.0
+    f_c, f_u = (f if fp_mode == "constant" else 0.0), (f if fp_mode == "unoccupied" else 0.0)
+    obs_mask = np.isnan(W).any(-1) | np.isnan(X).any(-1)[:, None, None]     # occu_cop.py:150-156
+    Y = np.where(obs_mask, np.nan, Y)
+    W, X = np.nan_to_num(W), np.nan_to_num(X)
+    psi = 1.0 / (1.0 + np.exp(-(beta[0] + X @ beta[1:])))                   # occu_cop.py:222-227
+    rate_detection = np.exp(alpha[0] + np.tensordot(W, alpha[1:], axes=([3], [0])))   # occu_cop.py:236-243
+    finite = np.isfinite(Y)
+    y0 = np.where(finite, Y, 0.0)
+    per_z = []
+    for z in (0.0, 1.0):
+        l_det = z * rate_detection + (1.0 - z) * f_u + f_c                  # occu_cop.py:244-248
+        rate = Dur * l_det
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ly = xlogy(y0, rate) - gammaln(y0 + 1.0) - rate                 # numpyro Poisson.log_prob
+        ly = np.where(finite, ly, 0.0).sum(axis=2)
+        per_z.append(_bernoulli_logpmf_clamped(psi, z)[:, None] + ly)
+    ll = np.logaddexp(per_z[0], per_z[1]).sum()
+
+    def normal_logpdf(v, loc, scale):
+        return (-0.5 * ((v - loc) / scale) ** 2 - np.log(scale) - 0.5 * np.log(2 * np.pi)).sum()
+
+    out = ll + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
+    if fp_mode:
+        out += np.log(prior_fp_rate) - prior_fp_rate * f + theta[-1]       # Exponential log-pdf + log|d f / d phi|
+    return out
 
 
 def literal_log_joint_rn(theta, site_covs, obs_covs, obs, max_abundance=100, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):

@@ -88,6 +88,40 @@ RN_CASES = {
 }
 
 
+# count occupancy generator (biolith/models/occu_cop.py:258-396)
+COP_CASES = {
+    "cop_default": dict(store=True, kw=dict()),
+    "cop_missing": dict(store=True, kw=dict(simulate_missing=True)),                       # occu_cop.py:399-400
+    "cop_small_2x2": dict(store=True, kw=dict(n_sites=80, n_site_covs=2, n_obs_covs=2, n_periods=2,
+                                              deployment_days_per_site=42, random_seed=5)),
+}
+
+
+def main_cop():
+    simulate_cop = sys.modules["biolith.models.occu_cop"].simulate_cop
+    index = {}
+    for name, case in COP_CASES.items():
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            data, truth = simulate_cop(**case["kw"])
+        keys = ("site_covs", "obs_covs", "obs", "session_duration")
+        entry = dict(
+            kwargs=case["kw"], stdout=buf.getvalue(),
+            shapes={k: list(np.shape(data[k])) for k in keys}, sha256={k: sha(data[k]) for k in keys},
+            coords=data["coords"], ell=float(data["ell"]), false_positives_constant=bool(data["false_positives_constant"]),
+            beta=np.asarray(truth["beta"]).tolist(), alpha=np.asarray(truth["alpha"]).tolist(),
+            mean_z=float(np.mean(truth["z"])), sha256_z=sha(truth["z"]), mean_obs=float(np.nanmean(data["obs"])),
+            stored=bool(case["store"]),
+        )
+        np.savez_compressed(os.path.join(HERE, f"simulate_{name}.npz"), site_covs=data["site_covs"], obs_covs=data["obs_covs"],
+                            obs=data["obs"], session_duration=data["session_duration"], z=truth["z"], beta=truth["beta"],
+                            alpha=truth["alpha"])
+        index[name] = entry
+        print(name, entry["shapes"], entry["sha256"]["obs"][:24])
+    with open(os.path.join(HERE, "simulate_cop_index.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+
+
 def main_rn():
     simulate_rn = load_reference_simulate_rn()
     index = {}
@@ -151,3 +185,4 @@ def main():
 if __name__ == "__main__":
     main()
     main_rn()
+    main_cop()

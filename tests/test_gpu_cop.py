@@ -1,0 +1,109 @@
+"""Count occupancy kernel (occu_cop, MODEL 3) through the C-ABI (bl_dataset_create_cop) against the float64
+oracle, plus the reference's own fit assertions (biolith/models/occu_cop.py:399-424)."""
+import numpy as np
+import pytest
+
+import oracle
+from biolith_amd.engine import OccuDataset
+from biolith_amd.evaluation import diagnostics, effective_sample_size, split_gelman_rubin
+from biolith_amd.models import occu_cop, simulate_cop
+from biolith_amd.utils import fit, predict
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+# float32 per-term math; the Poisson terms y nu - d lambda are larger and less uniform than the Bernoulli ones
+U_RTOL, G_RTOL = 2e-6, 2e-5
+
+
+def _pair(name, mode, rate=1.0, priors=((0.0, 1.0), (0.0, 1.0))):
+    g = load_golden(name)
+    kw = dict(model="occu_cop", fp_mode=mode, prior_fp_rate=rate, session_duration=g["session_duration"])
+    return (g, oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], *priors, **kw),
+            OccuDataset(g["site_covs"], g["obs_covs"], g["obs"], *priors, **kw))
+
+
+@pytest.mark.parametrize("name,mode,rate", [("cop_default", None, 1.0), ("cop_default", "constant", 1.0), ("cop_missing", "constant", 2.0),
+                                             ("cop_missing", "unoccupied", 1.0), ("cop_small_2x2", None, 1.0),
+                                             ("cop_small_2x2", "unoccupied", 0.5), ("cop_small_2x2", "constant", 3.0)])
+def test_cop_logp_grad_parity(name, mode, rate):
+    _, od, ds = _pair(name, mode, rate, priors=((0.1, 1.5), (-0.2, 0.8)))
+    assert ds.D == od.D
+    th = np.random.default_rng(3).uniform(-1.2, 1.2, size=(5, od.D)).astype(np.float32).astype(np.float64)
+    if mode:
+        th[0, -1], th[1, -1] = -5.0, 0.7        # rates 0.0067 and 2.0
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.all(np.isfinite(Ug)) and np.all(np.isfinite(Gg))
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= U_RTOL, (Ug, Uo)
+    assert np.max(np.abs(Gg - Go) / np.max(np.abs(Go), axis=1, keepdims=True)) <= G_RTOL, np.abs(Gg - Go).max(1)
+
+
+@pytest.mark.parametrize("n_sites", [1, 2, 65, 385, 1031])
+def test_cop_ragged_site_counts(n_sites):
+    rng = np.random.default_rng(n_sites)
+    X = rng.normal(size=(n_sites, 2)); W = rng.normal(size=(n_sites, 2, 3, 2)) * 0.5
+    Y = rng.poisson(1.5, size=(1, n_sites, 2, 3)).astype(float)
+    Y[rng.uniform(size=Y.shape) < 0.1] = np.nan
+    Dur = rng.uniform(1.0, 9.0, size=(n_sites, 2, 3))
+    kw = dict(model="occu_cop", fp_mode="constant", session_duration=Dur)
+    od, ds = oracle.OracleData(X, W, Y, **kw), OccuDataset(X, W, Y, **kw)
+    th = rng.uniform(-1.0, 1.0, size=(2, 7)).astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= U_RTOL
+    assert np.max(np.abs(Gg - Go)) <= G_RTOL * np.max(np.abs(Go))
+
+
+@pytest.mark.parametrize("mode", [None, "constant"])
+def test_cop_first_transitions_match_oracle(mode):
+    _, od, ds = _pair("cop_small_2x2", mode)
+    o = oracle.nuts_run(od, 0, 5, num_chains=2, seed=3)
+    r = ds.nuts(num_warmup=0, num_samples=5, num_chains=2, seed=3)
+    assert r.draws.shape == (2, 5, od.D)
+    assert np.array_equal(o["num_steps"][:, :3], r.num_steps[:, :3]), (o["num_steps"], r.num_steps)
+    assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=2e-3)
+
+
+@pytest.mark.parametrize("mode", [None, "constant"])
+def test_cop_posterior_matches_oracle(mode):
+    g, od, ds = _pair("cop_small_2x2", mode)
+    # start at the generating parameters: with a false-positive rate the likelihood has a second mode
+    # (swap detections and false positives), as for occu (test_gpu_fp.py)
+    init = np.concatenate([g["beta"][0], g["alpha"][0]] + ([[np.log(0.12)]] if mode else []))
+    init = np.tile(init, (4, 1))
+    o = oracle.nuts_run(od, 300, 400, num_chains=4, seed=0, init=init)
+    r = ds.nuts(num_warmup=300, num_samples=400, num_chains=4, seed=50, init_theta=init)
+    assert split_gelman_rubin(r.draws).max() < 1.03 and oracle.split_gelman_rubin(o["draws"]).max() < 1.03
+    fg, fo = r.draws.reshape(-1, od.D).astype(np.float64), o["draws"].reshape(-1, od.D)
+    mcse = np.sqrt(fg.var(0) / effective_sample_size(r.draws) + fo.var(0) / oracle.effective_sample_size(o["draws"]))
+    assert np.all(np.abs(fg.mean(0) - fo.mean(0)) <= 4 * mcse), (fg.mean(0) - fo.mean(0), mcse)
+    ratio = fg.std(0) / fo.std(0)
+    assert np.all((ratio > 0.85) & (ratio < 1.18)), ratio
+
+
+def test_occu_cop_like_reference():  # occu_cop.py:399-424 (simulate_cop passes false_positives_constant=True)
+    data, true_params = simulate_cop(simulate_missing=True)
+    results = fit(occu_cop, **data, timeout=600)
+    assert np.allclose(results.samples["psi"].mean(), true_params["z"].mean(), atol=0.1)
+    assert np.allclose([results.samples[k].mean() for k in [f"cov_state_{i}" for i in range(true_params["beta"].shape[1])]],
+                       true_params["beta"].mean(axis=0), atol=0.5)
+    assert np.allclose([results.samples[k].mean() for k in [f"cov_det_{i}" for i in range(true_params["alpha"].shape[1])]],
+                       true_params["alpha"].mean(axis=0), atol=0.5)
+    assert results.samples["rate_fp_constant"].shape == (5000,) and (results.samples["rate_fp_constant"] > 0).all()
+    assert results.samples["psi"].shape == (5000, 1, 100, 1)
+    assert results.samples["rate_detection"].shape == (5000, 52, 1, 100, 1)
+    d = diagnostics(results.mcmc)
+    assert set(d) >= {"n_eff_mean", "r_hat_max"} or isinstance(d, dict)
+    with pytest.raises(NotImplementedError):
+        predict(occu_cop, results.mcmc, **data)
+
+
+def test_occu_cop_without_false_positives_and_deterministic_sites():
+    data, true_params = simulate_cop(n_sites=150, n_site_covs=2, n_obs_covs=2, deployment_days_per_site=70, random_seed=2)
+    data.pop("false_positives_constant")
+    res = fit(occu_cop, **data, num_chains=2, num_samples=200, num_warmup=200)
+    assert "rate_fp_constant" not in res.samples
+    post = res.mcmc.get_samples()
+    W = np.nan_to_num(np.asarray(data["obs_covs"], np.float32))
+    nu = post["alpha"][:, 0, 0][:, None, None] + np.einsum("ijk,nk->nji", W[:, 0], post["alpha"][:, 0, 1:])
+    np.testing.assert_allclose(res.samples["rate_detection"][:, :, 0, :, 0], np.exp(nu), rtol=2e-5)
