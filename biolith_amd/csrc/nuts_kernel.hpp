@@ -315,6 +315,186 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     float cz_spec = 0.f;                // position written to LDS for the evaluation in flight
     int flag = 0;
     BL_STAMP_DECL
+    // The NumPyro decisions that follow one gathered gradient (hmc_util: _build_basetree tail, _iterative_build_subtree
+    // step, _double_tree / _combine_tree, and at transition end the warmup adapter): takes the stashed exchange
+    // result, leaves the next position to evaluate in cz and the run status in flag.
+    // Speculative overlap pays while a dropped evaluation is cheap: the LDS-staged occu / false-positive / occu_cop
+    // forms (<= ~3 site pairs per lane).  occu_rn's evaluation is ~95 % of its tick and the HBM-row form serves huge
+    // slices: there the decisions are taken right after the exchange and only the bookkeeping overlaps.
+    constexpr bool SPEC = LDS && MODEL != 1;
+    auto decide = [&]() {
+        have_pending = false;
+        const double acc = p_acc;
+        const float cg = p_cg, pe2 = p_pe2;
+        const double ll_tot = bl_readlane_d(acc, D);
+        const bool abort_req = bl_readlane_d(acc, D + 1) != 0.0;
+        flag = 0;
+        if (p_timed_out) flag = 4;     // BL_ERR_TIMEOUT
+        else if (abort_req) flag = 5;  // BL_ERR_ABORTED
+        bool new_transition = false;
+        BL_STAMP_KIND(0)
+        if (flag == 0) {
+            if (init_pending) {
+                BL_STAMP_KIND(2)
+                BL_SUB0
+                // initial evaluation done
+                const double Un = -ll_tot + (double)(0.5f * bl_wave_sum(pe2)) + prior_const;
+                sv[SV_TH * 64] = cz; sv[SV_GR * 64] = cg;
+                ss->U = Un;
+                init_pending = false;
+                new_transition = true;
+            } else {
+                // ------- CRITICAL: finish the leaf (_build_basetree), decide where the next one goes -------
+                const float cr = bl_leaf_momentum(rh, epsdir, cg);
+                float s_prior = pe2, s_kin = minv * cr * cr;
+                bl_low_sum2(s_prior, s_kin, D);
+                const double Un = -ll_tot + (double)(0.5f * s_prior) + prior_const;
+                const double Kn = (double)(0.5f * s_kin);
+                double dE = (Un + Kn) - E0;
+                if (dE != dE) dE = (double)INFINITY;
+                const int leaf_idx = snprop;
+                sdiv = dE > 1000.0;
+                srsum = (leaf_idx == 0) ? cr : srsum + cr;
+                snprop = leaf_idx + 1;
+                // its multinomial / weight bookkeeping is deferred
+                pend = true; pend_first = (leaf_idx == 0); pend_end = false;
+                pend_dE = (float)dE; pend_U = Un; pend_z = cz; pend_g = cg;
+                // checkpointed U-turn (_leaf_idx_to_ckpt_idxs / _is_iterative_turning)
+                const int idx_max = __popc((unsigned)leaf_idx >> 1);
+                const int idx_min = idx_max - (int)__builtin_ctz(~(unsigned)leaf_idx) + 1;
+                if ((leaf_idx & 1) == 0) {
+                    sh_ckr[idx_max * 64 + lane] = cr;
+                    sh_ckrs[idx_max * 64 + lane] = srsum;
+                } else {
+                    for (int i = idx_max; i >= idx_min && !sturn; i--) {
+                        const float ck = sh_ckr[i * 64 + lane];
+                        const float srs = srsum - sh_ckrs[i * 64 + lane] + ck;
+                        sturn = bl_is_turning(minv, ck, cr, srs, D);
+                    }
+                }
+                if (snprop < (1 << depth) && !sturn && !sdiv) {
+                    // next leaf continues from this one
+                    bl_next_leaf(cz, cr, cg, epsdir, minv, rh, cz);
+                } else {
+                    // ---------- subtree complete: extend the tree edge, tree-level U-turn ----------
+                    BL_STAMP_KIND(1)
+                    pend_end = true; pend_sturn = sturn; pend_sdiv = sdiv; pend_snprop = snprop;
+                    const int e_out = going_right ? SV_ZR : SV_ZL;  // edge this subtree extends (z, r, g slots follow)
+                    const int e_in = going_right ? SV_ZL : SV_ZR;   // opposite edge
+                    sv[e_out * 64] = cz; sv[(e_out + 1) * 64] = cr; sv[(e_out + 2) * 64] = cg;
+                    const float r_other = sv[(e_in + 1) * 64];
+                    const float rsum = sv[SV_RSUM * 64] + srsum;
+                    sv[SV_RSUM * 64] = rsum;
+                    // numpyro _combine_tree (biased): turning = new_tree.turning | _is_turning(edges, r_sum)
+                    const bool turning = sturn || bl_is_turning(minv, going_right ? r_other : cr, going_right ? cr : r_other, rsum, D);
+                    depth++;
+                    if (depth < p.max_depth && !turning && !sdiv) {
+                        // next doubling
+                        going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
+                        epsdir = going_right ? eps : -eps;
+                        snprop = 0; sturn = false; sdiv = false;
+                        const int e = going_right ? SV_ZR : SV_ZL;
+                        const float ez = sv[e * 64], er = sv[(e + 1) * 64], eg = sv[(e + 2) * 64];
+                        bl_next_leaf(ez, er, eg, epsdir, minv, rh, cz);
+                    } else {
+                        // ---------------- transition complete (nothing left to overlap with) ----------------
+                        BL_STAMP_KIND(2)
+                        BL_SUB0
+                        run_deferred();
+                        BL_SUB(0)
+                        const int nprop = ss->nprop;
+                        const float accp = ss->sumacc * bl_rcp((float)nprop);
+                        const float th = sv[SV_ZP * 64];
+                        const double U = ss->Up;
+                        sv[SV_TH * 64] = th; sv[SV_GR * 64] = sv[SV_GP * 64];
+                        ss->U = U;
+                        const int it = ss->it;
+                        if (it < W) {
+                            ss->nleap_w += nprop;
+                            // warmup_adapter.update_fn: dual averaging (t0=10, kappa=.75, gamma=.05)
+                            const float g = cold->target_accept - accp;
+                            const int da_t = ss->da_t + 1;
+                            const float tt = (float)da_t;
+                            const float rt10 = bl_rcp(tt + 10.0f);
+                            const float da_gavg = (1.0f - rt10) * ss->da_gavg + g * rt10;
+                            const float da_xt = ss->da_prox - __builtin_amdgcn_sqrtf(tt) * 20.0f * da_gavg;
+                            const float wgt = __builtin_amdgcn_exp2f(-0.75f * __builtin_amdgcn_logf(tt));
+                            const float da_xavg = (1.0f - wgt) * ss->da_xavg + wgt * da_xt;
+                            eps = bl_exp((it == W - 1) ? da_xavg : da_xt);
+                            eps = fminf(fmaxf(eps, 1.1754944e-38f), 3.4028235e+38f);
+                            ss->da_t = da_t; ss->da_gavg = da_gavg; ss->da_xt = da_xt; ss->da_xavg = da_xavg;
+                            int win_idx = ss->win_idx;
+                            const bool middle = win_idx > 0 && win_idx < cold->nwin - 1;
+                            if (middle) {
+                                const int wf_n = ss->wf_n + 1;
+                                const float wf_mean0 = sv[SV_WFMEAN * 64];
+                                const float dpre = th - wf_mean0;
+                                const float wf_mean = wf_mean0 + dpre * bl_rcp((float)wf_n);
+                                sv[SV_WFMEAN * 64] = wf_mean;
+                                sv[SV_WFM2 * 64] += dpre * (th - wf_mean);
+                                ss->wf_n = wf_n;
+                            }
+                            const bool at_end = it == cold->win_end[win_idx];
+                            if (at_end) ss->win_idx = win_idx + 1;
+                            if (at_end && middle) {
+                                const float n = (float)ss->wf_n;
+                                const float var = sv[SV_WFM2 * 64] * bl_rcp(n - 1.0f), rn5 = bl_rcp(n + 5.0f);
+                                minv = act ? (n * rn5 * var + 1e-3f * 5.0f * rn5) : 0.0f;
+                                sv[SV_WFMEAN * 64] = 0.f; sv[SV_WFM2 * 64] = 0.f; ss->wf_n = 0;
+                                ss->da_xt = 0.f; ss->da_xavg = 0.f; ss->da_gavg = 0.f; ss->da_t = 0;
+                                ss->da_prox = bl_log(10.0f * eps);
+                            }
+                        } else {
+                            ss->nleap_s += nprop;
+                            if (member == 0) {
+                                const size_t s = (size_t)chain * S + (it - W);
+                                if (act) cold->draws[s * D + lane] = th;
+                                if (lane == 0) {
+                                    cold->num_steps[s] = nprop;
+                                    cold->accept_prob[s] = accp;
+                                    cold->diverging[s] = pend_sdiv ? 1 : 0;
+                                    cold->potential[s] = (float)U;
+                                }
+                            }
+                        }
+                        ss->it = it + 1;
+                        if (it + 1 >= total) flag = 1; // done
+                        else new_transition = true;
+                        BL_SUB(1)
+                    }
+                }
+            }
+            if (new_transition) {
+                // sample momentum r = N(0,1)/sqrt(M^-1); start a fresh tree and its first doubling
+                const float th = sv[SV_TH * 64], gr = sv[SV_GR * 64];
+                const double U = ss->U;
+                const float z01 = bl_rng_normal(rng_d);
+                const float r0 = act ? z01 * __builtin_amdgcn_rsqf(minv) : 0.0f;
+                E0 = U + (double)(0.5f * bl_wave_sum(minv * r0 * r0));
+                sv[SV_ZL * 64] = th; sv[SV_RL * 64] = r0; sv[SV_GL * 64] = gr;
+                sv[SV_ZR * 64] = th; sv[SV_RR * 64] = r0; sv[SV_GRR * 64] = gr;
+                sv[SV_ZP * 64] = th; sv[SV_GP * 64] = gr; sv[SV_RSUM * 64] = r0;
+                ss->Up = U; ss->wt = 0.f; ss->sumacc = 0.f; ss->nprop = 0;
+                depth = 0;
+                going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
+                epsdir = going_right ? eps : -eps;
+                snprop = 0; sturn = false; sdiv = false;
+                bl_next_leaf(th, r0, gr, epsdir, minv, rh, cz);
+                BL_SUB(2)
+            }
+        }
+        if (flag != 0 && member == 0) {
+            if (flag > 1 && lane == 0) atomicMax(cold->status, flag);
+            if (act) cold->inv_mass[chain * D + lane] = minv;
+            if (lane == 0) {
+                cold->step_size[chain] = eps;
+                cold->nleap[chain * 2 + 0] = ss->nleap_w;
+                cold->nleap[chain * 2 + 1] = ss->nleap_s;
+                cold->xcd_local[chain] = local ? 1 : 0;
+            }
+        }
+    };
+
     while (true) {
         bool redo = false; // the evaluation in flight is not the one the sampler needs next
         if (wave > 0) {
@@ -326,182 +506,16 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #ifdef BL_STAMPS
             st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
 #endif
-        } else if (have_pending) {
-            have_pending = false;
-            const double acc = p_acc;
-            const float cg = p_cg, pe2 = p_pe2;
-            const double ll_tot = bl_readlane_d(acc, D);
-            const bool abort_req = bl_readlane_d(acc, D + 1) != 0.0;
-            flag = 0;
-            if (p_timed_out) flag = 4;     // BL_ERR_TIMEOUT
-            else if (abort_req) flag = 5;  // BL_ERR_ABORTED
-            bool new_transition = false;
-            BL_STAMP_KIND(0)
-            if (flag == 0) {
-                if (init_pending) {
-                    BL_STAMP_KIND(2)
-                    BL_SUB0
-                    // initial evaluation done
-                    const double Un = -ll_tot + (double)(0.5f * bl_wave_sum(pe2)) + prior_const;
-                    sv[SV_TH * 64] = cz; sv[SV_GR * 64] = cg;
-                    ss->U = Un;
-                    init_pending = false;
-                    new_transition = true;
-                } else {
-                    // ------- CRITICAL: finish the leaf (_build_basetree), decide where the next one goes -------
-                    const float cr = bl_leaf_momentum(rh, epsdir, cg);
-                    float s_prior = pe2, s_kin = minv * cr * cr;
-                    bl_low_sum2(s_prior, s_kin, D);
-                    const double Un = -ll_tot + (double)(0.5f * s_prior) + prior_const;
-                    const double Kn = (double)(0.5f * s_kin);
-                    double dE = (Un + Kn) - E0;
-                    if (dE != dE) dE = (double)INFINITY;
-                    const int leaf_idx = snprop;
-                    sdiv = dE > 1000.0;
-                    srsum = (leaf_idx == 0) ? cr : srsum + cr;
-                    snprop = leaf_idx + 1;
-                    // its multinomial / weight bookkeeping is deferred
-                    pend = true; pend_first = (leaf_idx == 0); pend_end = false;
-                    pend_dE = (float)dE; pend_U = Un; pend_z = cz; pend_g = cg;
-                    // checkpointed U-turn (_leaf_idx_to_ckpt_idxs / _is_iterative_turning)
-                    const int idx_max = __popc((unsigned)leaf_idx >> 1);
-                    const int idx_min = idx_max - (int)__builtin_ctz(~(unsigned)leaf_idx) + 1;
-                    if ((leaf_idx & 1) == 0) {
-                        sh_ckr[idx_max * 64 + lane] = cr;
-                        sh_ckrs[idx_max * 64 + lane] = srsum;
-                    } else {
-                        for (int i = idx_max; i >= idx_min && !sturn; i--) {
-                            const float ck = sh_ckr[i * 64 + lane];
-                            const float srs = srsum - sh_ckrs[i * 64 + lane] + ck;
-                            sturn = bl_is_turning(minv, ck, cr, srs, D);
-                        }
-                    }
-                    if (snprop < (1 << depth) && !sturn && !sdiv) {
-                        // next leaf continues from this one
-                        bl_next_leaf(cz, cr, cg, epsdir, minv, rh, cz);
-                    } else {
-                        // ---------- subtree complete: extend the tree edge, tree-level U-turn ----------
-                        BL_STAMP_KIND(1)
-                        pend_end = true; pend_sturn = sturn; pend_sdiv = sdiv; pend_snprop = snprop;
-                        const int e_out = going_right ? SV_ZR : SV_ZL;  // edge this subtree extends (z, r, g slots follow)
-                        const int e_in = going_right ? SV_ZL : SV_ZR;   // opposite edge
-                        sv[e_out * 64] = cz; sv[(e_out + 1) * 64] = cr; sv[(e_out + 2) * 64] = cg;
-                        const float r_other = sv[(e_in + 1) * 64];
-                        const float rsum = sv[SV_RSUM * 64] + srsum;
-                        sv[SV_RSUM * 64] = rsum;
-                        // numpyro _combine_tree (biased): turning = new_tree.turning | _is_turning(edges, r_sum)
-                        const bool turning = sturn || bl_is_turning(minv, going_right ? r_other : cr, going_right ? cr : r_other, rsum, D);
-                        depth++;
-                        if (depth < p.max_depth && !turning && !sdiv) {
-                            // next doubling
-                            going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
-                            epsdir = going_right ? eps : -eps;
-                            snprop = 0; sturn = false; sdiv = false;
-                            const int e = going_right ? SV_ZR : SV_ZL;
-                            const float ez = sv[e * 64], er = sv[(e + 1) * 64], eg = sv[(e + 2) * 64];
-                            bl_next_leaf(ez, er, eg, epsdir, minv, rh, cz);
-                        } else {
-                            // ---------------- transition complete (nothing left to overlap with) ----------------
-                            BL_STAMP_KIND(2)
-                            BL_SUB0
-                            run_deferred();
-                            BL_SUB(0)
-                            const int nprop = ss->nprop;
-                            const float accp = ss->sumacc * bl_rcp((float)nprop);
-                            const float th = sv[SV_ZP * 64];
-                            const double U = ss->Up;
-                            sv[SV_TH * 64] = th; sv[SV_GR * 64] = sv[SV_GP * 64];
-                            ss->U = U;
-                            const int it = ss->it;
-                            if (it < W) {
-                                ss->nleap_w += nprop;
-                                // warmup_adapter.update_fn: dual averaging (t0=10, kappa=.75, gamma=.05)
-                                const float g = cold->target_accept - accp;
-                                const int da_t = ss->da_t + 1;
-                                const float tt = (float)da_t;
-                                const float rt10 = bl_rcp(tt + 10.0f);
-                                const float da_gavg = (1.0f - rt10) * ss->da_gavg + g * rt10;
-                                const float da_xt = ss->da_prox - __builtin_amdgcn_sqrtf(tt) * 20.0f * da_gavg;
-                                const float wgt = __builtin_amdgcn_exp2f(-0.75f * __builtin_amdgcn_logf(tt));
-                                const float da_xavg = (1.0f - wgt) * ss->da_xavg + wgt * da_xt;
-                                eps = bl_exp((it == W - 1) ? da_xavg : da_xt);
-                                eps = fminf(fmaxf(eps, 1.1754944e-38f), 3.4028235e+38f);
-                                ss->da_t = da_t; ss->da_gavg = da_gavg; ss->da_xt = da_xt; ss->da_xavg = da_xavg;
-                                int win_idx = ss->win_idx;
-                                const bool middle = win_idx > 0 && win_idx < cold->nwin - 1;
-                                if (middle) {
-                                    const int wf_n = ss->wf_n + 1;
-                                    const float wf_mean0 = sv[SV_WFMEAN * 64];
-                                    const float dpre = th - wf_mean0;
-                                    const float wf_mean = wf_mean0 + dpre * bl_rcp((float)wf_n);
-                                    sv[SV_WFMEAN * 64] = wf_mean;
-                                    sv[SV_WFM2 * 64] += dpre * (th - wf_mean);
-                                    ss->wf_n = wf_n;
-                                }
-                                const bool at_end = it == cold->win_end[win_idx];
-                                if (at_end) ss->win_idx = win_idx + 1;
-                                if (at_end && middle) {
-                                    const float n = (float)ss->wf_n;
-                                    const float var = sv[SV_WFM2 * 64] * bl_rcp(n - 1.0f), rn5 = bl_rcp(n + 5.0f);
-                                    minv = act ? (n * rn5 * var + 1e-3f * 5.0f * rn5) : 0.0f;
-                                    sv[SV_WFMEAN * 64] = 0.f; sv[SV_WFM2 * 64] = 0.f; ss->wf_n = 0;
-                                    ss->da_xt = 0.f; ss->da_xavg = 0.f; ss->da_gavg = 0.f; ss->da_t = 0;
-                                    ss->da_prox = bl_log(10.0f * eps);
-                                }
-                            } else {
-                                ss->nleap_s += nprop;
-                                if (member == 0) {
-                                    const size_t s = (size_t)chain * S + (it - W);
-                                    if (act) cold->draws[s * D + lane] = th;
-                                    if (lane == 0) {
-                                        cold->num_steps[s] = nprop;
-                                        cold->accept_prob[s] = accp;
-                                        cold->diverging[s] = pend_sdiv ? 1 : 0;
-                                        cold->potential[s] = (float)U;
-                                    }
-                                }
-                            }
-                            ss->it = it + 1;
-                            if (it + 1 >= total) flag = 1; // done
-                            else new_transition = true;
-                            BL_SUB(1)
-                        }
-                    }
-                }
-                if (new_transition) {
-                    // sample momentum r = N(0,1)/sqrt(M^-1); start a fresh tree and its first doubling
-                    const float th = sv[SV_TH * 64], gr = sv[SV_GR * 64];
-                    const double U = ss->U;
-                    const float z01 = bl_rng_normal(rng_d);
-                    const float r0 = act ? z01 * __builtin_amdgcn_rsqf(minv) : 0.0f;
-                    E0 = U + (double)(0.5f * bl_wave_sum(minv * r0 * r0));
-                    sv[SV_ZL * 64] = th; sv[SV_RL * 64] = r0; sv[SV_GL * 64] = gr;
-                    sv[SV_ZR * 64] = th; sv[SV_RR * 64] = r0; sv[SV_GRR * 64] = gr;
-                    sv[SV_ZP * 64] = th; sv[SV_GP * 64] = gr; sv[SV_RSUM * 64] = r0;
-                    ss->Up = U; ss->wt = 0.f; ss->sumacc = 0.f; ss->nprop = 0;
-                    depth = 0;
-                    going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
-                    epsdir = going_right ? eps : -eps;
-                    snprop = 0; sturn = false; sdiv = false;
-                    bl_next_leaf(th, r0, gr, epsdir, minv, rh, cz);
-                    BL_SUB(2)
-                }
-            }
-            if (flag != 0 && member == 0) {
-                if (flag > 1 && lane == 0) atomicMax(cold->status, flag);
-                if (act) cold->inv_mass[chain * D + lane] = minv;
-                if (lane == 0) {
-                    cold->step_size[chain] = eps;
-                    cold->nleap[chain * 2 + 0] = ss->nleap_w;
-                    cold->nleap[chain * 2 + 1] = ss->nleap_s;
-                    cold->xcd_local[chain] = local ? 1 : 0;
-                }
-            }
+        } else if (SPEC && have_pending) {
+            decide();
             // was the position being evaluated right now the one just chosen?  (bit-equal or redo: correctness
             // never depends on the guess)
             redo = flag != 0 || __any(act && !(cz == cz_spec));
             if (flag == 0) run_deferred(); // this leaf's proposal / weight bookkeeping, still under phase A
             BL_STAMP_CRIT
+            BL_STAMP(0)
+        } else if (!SPEC) {
+            run_deferred(); // non-speculative form: only the bookkeeping overlaps the evaluation
             BL_STAMP(0)
         }
         __syncthreads();
@@ -643,6 +657,14 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             // at once and the tests run beside them (loop head).  A wrong guess costs nothing extra: it happens
             // when a transition ends, and the decisions of that tick outlast a phase A anyway.
             cz_spec = __builtin_nanf("");
+            if constexpr (!SPEC) {
+                // Long site evaluations (occu_rn; many site pairs per lane): a dropped evaluation would cost more than
+                // the overlap saves, so the decisions are taken here and the compute waves get the decided position.
+                decide();
+                if (act) sh_coef[my_pos] = cz;
+                if (lane == 0) sh_flag[0] = flag;
+                BL_STAMP_CRIT
+            } else {
             if (!init_pending && !timed_out) {
                 const float cr = bl_leaf_momentum(rh, epsdir, cg);
                 if (snprop + 1 < (1 << depth)) {
@@ -663,6 +685,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             }
             if (act && cz_spec == cz_spec) sh_coef[my_pos] = cz_spec;
             if (lane == 0) sh_flag[0] = 0;
+            }
             BL_STAMP(4)
         }
         __syncthreads();
