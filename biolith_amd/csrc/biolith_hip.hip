@@ -159,7 +159,8 @@ static int adaptation_schedule(int num_steps, int32_t *starts, int32_t *ends, in
 // ----------------------------------------------------------------- handle ----
 struct bl_dataset {
     int device = 0;
-    int model = 0;          // 0 occu, 1 occu_rn, 2 occu with false positives, 3 occu_cop
+    int model = 0;          // 0 occu, 1 occu_rn, 2 occu with false positives, 3 occu_cop, 4 nmixture
+    float *d_tab = nullptr; // nmixture: B[t][n][site] = sum_j m log C(n, y_j), -inf below the largest count
     int ko_layout = 0;      // KO the record layout helpers are called with (KO, or KO + 1 for occu_cop's wider visits)
     int max_abundance = 0;  // occu_rn only
     int fp_mode = 0;        // model 2: BL_FP_CONSTANT / BL_FP_UNOCCUPIED
@@ -295,7 +296,8 @@ __global__ void bl_predict_kernel(const float *__restrict__ rows, const float *_
 extern "C" int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint64_t seed, uint8_t *latent, uint8_t *y)
 {
     if (!ds || !draws || n_draws <= 0 || (!latent && !y)) return bl_fail(BL_ERR_INVALID, "bl_predict: bad argument");
-    if (ds->model == 3) return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: not built for occu_cop (counts do not fit the uint8 outputs)");
+    if (ds->model == 3 || ds->model == 4)
+        return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: not built for the count models (occu_cop, nmixture)");
     if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
     int rc = set_device(ds);
     if (rc) return rc;
@@ -386,6 +388,19 @@ extern "C" int bl_dataset_create_fp(const bl_dims *dims, const float *site_covs,
     return dataset_create_impl(mo, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
 }
 
+extern "C" int bl_dataset_create_nmix(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
+                                      int max_abundance, const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha,
+                                      int device, bl_dataset **out)
+{
+    if (max_abundance < 1 || max_abundance >= BL_RN_NB)
+        return bl_fail(BL_ERR_UNSUPPORTED, "max_abundance=%d outside 1..%d", max_abundance, BL_RN_NB - 1);
+    if (dims && (dims->n_site_covs > 4 || dims->n_obs_covs > 4))
+        return bl_fail(BL_ERR_UNSUPPORTED, "nmixture kernels are built for at most 4 covariates per side (Ks=%d, Ko=%d)",
+                       dims->n_site_covs, dims->n_obs_covs);
+    ModelOpts mo; mo.model = 4; mo.max_abundance = max_abundance;
+    return dataset_create_impl(mo, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
+}
+
 extern "C" int bl_dataset_create_cop(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
                                      const float *session_duration, int fp_mode, double prior_fp_rate,
                                      const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha, int device,
@@ -438,7 +453,7 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
     ds->pb = pb; ds->pa = pa;
     if (!ds->kern) { delete ds; return bl_fail(BL_ERR_UNSUPPORTED, "no kernel for capacity (%d,%d)", pad_covs(Ks), pad_covs(Ko)); }
     const int V = T * J, KS = ds->KS, KO = ds->KO;
-    const int vw = KO + 1 + (model == 3 ? 1 : 0); // floats per visit
+    const int vw = KO + 1 + ((model == 3 || model == 4) ? 1 : 0); // floats per visit
     ds->ko_layout = vw - 1;
     const int n_stride = (N + 63) / 64 * 64;
     const int n_rows = KS + V * vw + 2 * T;
@@ -450,12 +465,49 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
     const double LN2 = 0.69314718055994530942, LOG_TINY = -87.33654475055310898657;
     const int row_wc = KS, row_ka = KS + V * vw, row_kb = row_ka + T;
     double cop_const = 0.0; // occu_cop: sum over unmasked visits of y log(dur) - lgamma(y + 1)
+    // nmixture: B[t][n][site] = sum over unmasked visits of log C(n, y), -inf for n below the largest count
+    // (nmixture.py:150-155, 186-190 and numpyro's BinomialProbs.log_prob); one spare row for pair reads
+    const int Kn = max_abundance;
+    std::vector<float> tab(model == 4 ? ((size_t)T * (Kn + 1) + 1) * n_stride : 0, 0.0f);
     for (int i = 0; i < N; i++) {
         bool site_nan = false;
         for (int k = 0; k < Ks; k++) {
             float x = site_covs[(size_t)i * Ks + k];
             if (std::isnan(x)) { site_nan = true; x = 0.0f; }
             rows[(size_t)k * n_stride + i] = x;
+        }
+        for (int t = 0; t < T && model == 4; t++) {
+            std::vector<double> ys;
+            for (int j = 0; j < J; j++) {
+                const int v = t * J + j;
+                const size_t o = ((size_t)i * T + t) * J + j;
+                bool cov_nan = site_nan;
+                const size_t r0 = (size_t)(row_wc + v * vw);
+                for (int k = 0; k < Ko; k++) {
+                    float x = obs_covs[o * Ko + k];
+                    if (std::isnan(x)) { cov_nan = true; x = 0.0f; }
+                    ds->h_wraw[((size_t)v * Ko + k) * n_stride + i] = x;
+                    rows[(r0 + 2 + k) * n_stride + i] = x;
+                }
+                const float y = obs[o];
+                if (cov_nan || !std::isfinite(y)) {
+                    for (int k = 0; k < Ko; k++) rows[(r0 + 2 + k) * n_stride + i] = 0.0f;
+                    continue;
+                }
+                rows[r0 * n_stride + i] = y;          // m y
+                rows[(r0 + 1) * n_stride + i] = 1.0f; // m
+                ys.push_back((double)y);
+            }
+            double ymax = 0.0;
+            for (double y : ys) ymax = std::max(ymax, y);
+            for (int n = 0; n <= Kn; n++) {
+                double b = 0.0;
+                if ((double)n < ymax) b = -INFINITY;
+                else for (double y : ys) b += std::lgamma(n + 1.0) - std::lgamma(y + 1.0) - std::lgamma(n - y + 1.0);
+                tab[((size_t)t * (Kn + 1) + n) * n_stride + i] = (float)b;
+            }
+            rows[(size_t)(row_ka + t) * n_stride + i] = (float)ymax;
+            rows[(size_t)(row_kb + t) * n_stride + i] = (float)ys.size();
         }
         for (int t = 0; t < T && model == 3; t++) {
             // occu_cop.py:150-156,236-255: visit = (y_m, d_m, w_1..w_Ko), masked visits contribute nothing
@@ -484,7 +536,7 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
             rows[(size_t)(row_ka + t) * n_stride + i] = (float)ysum;
             rows[(size_t)(row_kb + t) * n_stride + i] = (float)dsum;
         }
-        for (int t = 0; t < T && model != 3; t++) {
+        for (int t = 0; t < T && model != 3 && model != 4; t++) {
             int n_masked = 0, n_det = 0;
             for (int j = 0; j < J; j++) {
                 const int v = t * J + j;
@@ -513,6 +565,8 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc((void **)&ds->d_rows, rows.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(ds->d_rows, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && model == 4) e = hipMalloc((void **)&ds->d_tab, tab.size() * sizeof(float));
+    if (e == hipSuccess && model == 4) e = hipMemcpy(ds->d_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipHostMalloc((void **)&ds->h_abort, 64, hipHostMallocMapped);
     if (e == hipSuccess) { *ds->h_abort = 0; e = hipHostGetDevicePointer((void **)&ds->d_abort, ds->h_abort, 0); }
     if (e == hipSuccess) e = hipEventCreate(&ds->ev0);
@@ -546,6 +600,7 @@ extern "C" int bl_dataset_destroy(bl_dataset *ds)
     if (ds->in_flight) { *ds->h_abort = 1; hipStreamSynchronize(ds->stream); }
     if (ds->d_rows) hipFree(ds->d_rows);
     if (ds->d_wraw) hipFree(ds->d_wraw);
+    if (ds->d_tab) hipFree(ds->d_tab);
     if (ds->d_run) hipFree(ds->d_run);
     if (ds->d_xchg) hipFree(ds->d_xchg);
     if (ds->h_abort) hipHostFree(ds->h_abort);
@@ -661,6 +716,7 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
     p.dd = ds->dd; p.k = k; p.nloc = nloc; p.rec_stride = ld; p.B = B; p.theta = d_th32; p.partial = d_partial;
     p.max_abundance = ds->max_abundance;
     p.fp_mode = ds->fp_mode;
+    p.nmix_tab = ds->d_tab;
     p.ncw = ncw;
     if (ds->model != 0 && !use_staged)
         return bl_fail(BL_ERR_UNSUPPORTED, "occu_rn / false-positive models need the LDS-staged path (slice too large, or staged=0 requested)");
@@ -765,6 +821,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.max_depth = max_depth;
     p.max_abundance = ds->max_abundance;
     p.fp_mode = ds->fp_mode;
+    p.nmix_tab = ds->d_tab;
     p.ncw = ncw;
     p.xchg = ds->d_xchg;
     p.cold = d_cold;
@@ -919,7 +976,7 @@ __global__ void bl_psi_kernel(const float *__restrict__ rows, int n_stride, int 
         float eta = th[0];
         for (int k = 0; k < Ks; k++) eta = fmaf(x[k], th[k + 1], eta);
         // occu: psi = sigmoid(eta) (occu.py:207); occu_rn: abundance = exp(eta) (occu_rn.py:192)
-        const float v = model == 1 ? __expf(eta) : 1.0f / (1.0f + __expf(-eta));
+        const float v = (model == 1 || model == 4) ? __expf(eta) : 1.0f / (1.0f + __expf(-eta));
         for (int t = 0; t < T; t++) psi[((size_t)(n - n0) * T + t) * N + i] = v;
     }
 }

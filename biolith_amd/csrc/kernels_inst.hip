@@ -1,7 +1,7 @@
 // kernels_inst.hip -- one translation unit per padded covariate capacity pair (BL_KS, BL_KO).
 // Built N times by the Makefile (-DBL_KS=.. -DBL_KO=..) so the instantiations compile in parallel.
 // model 0 = occu (LDS-staged and HBM-row forms); model 1 = occu_rn and model 2 = occu with false
-// positives, model 3 = occu_cop (LDS-staged form, capacities <= 4).
+// positives, model 3 = occu_cop, model 4 = nmixture (LDS-staged form, capacities <= 4).
 #include "logp_kernel.hpp"
 #include "nuts_kernel.hpp"
 
@@ -26,7 +26,7 @@ static int bl_launch(K kernel, const P *p, int grid, int threads, int lds_bytes,
 }
 
 // Instantiations (CW = compute waves per workgroup, chosen by the host's choose_geometry):
-//   occu, LDS-staged: CW 3 and 4;  occu, HBM rows: CW 4;  occu_rn: CW 3;  false positives, occu_cop: CW 3 and 4.
+//   occu, LDS-staged: CW 3 and 4;  occu, HBM rows: CW 4;  occu_rn: CW 3;  false positives, occu_cop, nmixture: CW 3 and 4.
 #define BL_PICK(KERNEL, P, LDS, MODEL, CW) bl_launch(KERNEL<BL_KS, BL_KO, LDS, MODEL, CW>, P, grid, 64 * (CW + 1), lds_bytes, stream)
 
 extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int grid, int lds_bytes, int staged, int model, hipStream_t stream)
@@ -41,6 +41,13 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
 #if BL_HAVE_RN
         if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 2, 3);
         if (staged && p->ncw == 4) return BL_PICK(bl_nuts_kernel, p, true, 2, 4);
+#endif
+        return (int)hipErrorNotSupported;
+    }
+    if (model == 4) {
+#if BL_HAVE_RN
+        if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 4, 3);
+        if (staged && p->ncw == 4) return BL_PICK(bl_nuts_kernel, p, true, 4, 4);
 #endif
         return (int)hipErrorNotSupported;
     }
@@ -69,6 +76,13 @@ extern "C" int BL_NAME(bl_launch_logp, BL_KS, BL_KO)(const BlLogpParams *p, int 
 #if BL_HAVE_RN
         if (staged && p->ncw == 3) return BL_PICK(bl_logp_kernel, p, true, 2, 3);
         if (staged && p->ncw == 4) return BL_PICK(bl_logp_kernel, p, true, 2, 4);
+#endif
+        return (int)hipErrorNotSupported;
+    }
+    if (model == 4) {
+#if BL_HAVE_RN
+        if (staged && p->ncw == 3) return BL_PICK(bl_logp_kernel, p, true, 4, 3);
+        if (staged && p->ncw == 4) return BL_PICK(bl_logp_kernel, p, true, 4, 4);
 #endif
         return (int)hipErrorNotSupported;
     }

@@ -93,6 +93,7 @@ struct BlNutsParams {
     int rec_stride;                // floats per LDS pair record
     int nvp;                       // granules per workgroup record: 16, 32 or 64 (>= D+4)
     int ncw;                       // compute waves per workgroup: selects the CW instantiation (host side)
+    const float *nmix_tab;         // MODEL 4: B[t][n][site] = sum_j m log C(n, y_j) (-inf below the largest count), row length n_stride
     int fp_mode;                   // MODEL 2 / 3: 0 none, 1 = rate acts on every site ("constant"), 2 = on unoccupied sites only
     int max_depth;
     int max_abundance;             // occu_rn only (occu_rn.py:26)
@@ -319,9 +320,9 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     // step, _double_tree / _combine_tree, and at transition end the warmup adapter): takes the stashed exchange
     // result, leaves the next position to evaluate in cz and the run status in flag.
     // Speculative overlap pays while a dropped evaluation is cheap: the LDS-staged occu / false-positive / occu_cop
-    // forms (<= ~3 site pairs per lane).  occu_rn's evaluation is ~95 % of its tick and the HBM-row form serves huge
+    // forms (<= ~3 site pairs per lane).  occu_rn's and nmixture's evaluations (sums over N) dominate their ticks and the HBM-row form serves huge
     // slices: there the decisions are taken right after the exchange and only the bookkeeping overlaps.
-    constexpr bool SPEC = LDS && MODEL != 1;
+    constexpr bool SPEC = LDS && MODEL != 1 && MODEL != 4;
     auto decide = [&]() {
         have_pending = false;
         const double acc = p_acc;
@@ -502,7 +503,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #ifdef BL_STAMPS
             const long long st_a0 = (long long)clock64();
 #endif
-            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode);
+            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, p.n_stride);
 #ifdef BL_STAMPS
             st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
 #endif

@@ -761,6 +761,119 @@ __device__ __forceinline__ void bl_eval_sites_cop(int ct, int pstride, int cnt, 
 }
 
 
+// lgamma(n + 1) for n < 128 (occu_rn, nmixture)
+#define BL_RN_NB 128
+__device__ constexpr float BL_LGAMMA1P[BL_RN_NB] = {0.000000000e+00f, 0.000000000e+00f, 6.931471806e-01f, 1.791759469e+00f, 3.178053830e+00f, 4.787491743e+00f, 6.579251212e+00f, 8.525161361e+00f, 1.060460290e+01f, 1.280182748e+01f, 1.510441257e+01f, 1.750230785e+01f, 1.998721450e+01f, 2.255216385e+01f, 2.519122118e+01f, 2.789927138e+01f, 3.067186011e+01f, 3.350507345e+01f, 3.639544521e+01f, 3.933988419e+01f, 4.233561646e+01f, 4.538013890e+01f, 4.847118135e+01f, 5.160667557e+01f, 5.478472940e+01f, 5.800360522e+01f, 6.126170176e+01f, 6.455753863e+01f, 6.788974314e+01f, 7.125703897e+01f, 7.465823635e+01f, 7.809222355e+01f, 8.155795946e+01f, 8.505446702e+01f, 8.858082754e+01f, 9.213617560e+01f, 9.571969454e+01f, 9.933061245e+01f, 1.029681986e+02f, 1.066317603e+02f, 1.103206397e+02f, 1.140342118e+02f, 1.177718814e+02f, 1.215330815e+02f, 1.253172711e+02f, 1.291239336e+02f, 1.329525750e+02f, 1.368027226e+02f, 1.406739236e+02f, 1.445657439e+02f, 1.484777670e+02f, 1.524095926e+02f, 1.563608363e+02f, 1.603311282e+02f, 1.643201123e+02f, 1.683274454e+02f, 1.723527971e+02f, 1.763958484e+02f, 1.804562914e+02f, 1.845338289e+02f, 1.886281734e+02f, 1.927390473e+02f, 1.968661817e+02f, 2.010093164e+02f, 2.051681995e+02f, 2.093425868e+02f, 2.135322415e+02f, 2.177369341e+02f, 2.219564418e+02f, 2.261905483e+02f, 2.304390436e+02f, 2.347017234e+02f, 2.389783896e+02f, 2.432688490e+02f, 2.475729141e+02f, 2.518904022e+02f, 2.562211356e+02f, 2.605649410e+02f, 2.649216498e+02f, 2.692910977e+02f, 2.736731243e+02f, 2.780675734e+02f, 2.824742927e+02f, 2.868931333e+02f, 2.913239501e+02f, 2.957666014e+02f, 3.002209486e+02f, 3.046868568e+02f, 3.091641936e+02f, 3.136528299e+02f, 3.181526396e+02f, 3.226634991e+02f, 3.271852877e+02f, 3.317178872e+02f, 3.362611820e+02f, 3.408150589e+02f, 3.453794071e+02f, 3.499541180e+02f, 3.545390855e+02f, 3.591342054e+02f, 3.637393756e+02f, 3.683544961e+02f, 3.729794689e+02f, 3.776141979e+02f, 3.822585888e+02f, 3.869125491e+02f, 3.915759882e+02f, 3.962488171e+02f, 4.009309483e+02f, 4.056222962e+02f, 4.103227765e+02f, 4.150323067e+02f, 4.197508056e+02f, 4.244781934e+02f, 4.292143919e+02f, 4.339593240e+02f, 4.387129142e+02f, 4.434750881e+02f, 4.482457727e+02f, 4.530248962e+02f, 4.578123880e+02f, 4.626081785e+02f, 4.674121996e+02f, 4.722243839e+02f, 4.770446655e+02f, 4.818729792e+02f, 4.867092611e+02f, 4.915534482e+02f};
+
+// --------------------------------------------------------------- N-mixture (nmixture, MODEL 4) ----
+// biolith/models/nmixture.py:150-220: N_it enumerated over 0..K with raw Poisson(lambda) weights (the model's
+// "N_i_trunc_norm" factor cancels the Categorical's normalisation), cut off below the largest count of the
+// (site, period); y_itj ~ Binomial(N_it, p_itj).  With nu = logit p, m the mask and c = sum_j m log(1 - p_j):
+//   l = sum_j m y_j nu_j  - lambda + logsumexp_n [ n (eta + c) - lgamma(n+1) + B_n ]
+//   B_n = sum_j m log C(n, y_j)   (data only: tabulated by the host, -inf below the largest count)
+//   d l / d eta = E[n] - lambda ,   d l / d nu_j = m (y_j - E[n] p_j) ,   E[n] = posterior mean of N
+// Records as for occu_cop: visit = (m y, m, w_1..w_KO) (layout KO + 1); B lives in HBM/L2 as
+// tab[t][n][site] (site fastest: lanes read consecutive floats).  Two passes over n (max, then sums).
+template <int KS, int KO, int CT>
+__device__ __forceinline__ void bl_eval_sites_nmix(int ct, int pstride, int cnt, int T, int J, int K,
+                                                   const float *__restrict__ tab, int tab_ld,
+                                                   const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
+                                                   float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
+{
+    constexpr int XQ = (KS + 3) & ~3;
+    constexpr int VW = KO + 2;
+    const int pb = bl_period_block(J, KO + 1);
+    const float *data = bl_lds_f(BL_OFF_DATA);
+    const int npairs = (cnt + 1) >> 1;
+    bl_f2 ll2 = bl2(0.0f), gb2[KS + 1], ga2[KO + 1];
+#pragma unroll
+    for (int k = 0; k <= KS; k++) gb2[k] = bl2(0.0f);
+#pragma unroll
+    for (int k = 0; k <= KO; k++) ga2[k] = bl2(0.0f);
+    for (int m = ct; m < npairs; m += CT) {
+        const float4 *rec = reinterpret_cast<const float4 *>(data + (size_t)m * pstride);
+        const bool second = 2 * m + 1 < cnt;
+        const bl_f2 vmask = bl_f2{1.0f, second ? 1.0f : 0.0f};
+        const float *t0 = tab + 2 * m, *t1 = tab + (second ? 2 * m + 1 : 2 * m); // dummy second site: re-read the first
+        bl_f2 x[XQ];
+#pragma unroll
+        for (int q = 0; q < XQ / 2; q++) {
+            const float4 v = rec[q];
+            x[2 * q] = bl_f2{v.x, v.y};
+            x[2 * q + 1] = bl_f2{v.z, v.w};
+        }
+        bl_f2 eta = bl2(beta[0]);
+#pragma unroll
+        for (int k = 0; k < KS; k++) eta = bl_fma2(x[k], bl2(beta[k + 1]), eta);
+        const bl_f2 lam = bl_exp2_2(__builtin_elementwise_min(eta, bl2(80.0f)) * bl2(BL_LOG2E));
+        bl_f2 dsum = bl2(0.0f), lsite = bl2(0.0f);
+        const float2 *pp0 = reinterpret_cast<const float2 *>(data + (size_t)m * pstride) + XQ;
+        for (int t = 0; t < T; t++) {
+            const float2 *pp = pp0 + t * pb;
+            bl_f2 gy[KO + 1], gp[KO + 1];
+#pragma unroll
+            for (int k = 0; k <= KO; k++) { gy[k] = bl2(0.0f); gp[k] = bl2(0.0f); }
+            bl_f2 a = bl2(0.0f), c = bl2(0.0f);
+#pragma unroll 2
+            for (int j = 0; j < J; j++) {
+                const float2 y_ = pp[j * VW], m_ = pp[j * VW + 1];
+                const bl_f2 ym = bl_f2{y_.x, y_.y}, mk = bl_f2{m_.x, m_.y};
+                bl_f2 w[KO > 0 ? KO : 1];
+                bl_f2 nu = bl2(alpha[0]);
+#pragma unroll
+                for (int k = 0; k < KO; k++) {
+                    const float2 v = pp[j * VW + 2 + k];
+                    w[k] = bl_f2{v.x, v.y};
+                    nu = bl_fma2(w[k], bl2(alpha[k + 1]), nu);
+                }
+                const bl_f2 e = bl_exp2_2(__builtin_elementwise_abs(nu) * bl2(-BL_LOG2E));
+                const bl_f2 op = e + bl2(1.0f);
+                const bl_f2 sp = bl_fma2(bl_log2_2(op), bl2(BL_LN2), __builtin_elementwise_max(nu, bl2(0.0f))); // softplus(nu)
+                const bl_f2 p = bl_sel_pos_one(nu, e) * bl_rcp_2(op) * mk;                                        // m sigmoid(nu)
+                a = bl_fma2(ym, nu, a);
+                c = bl_fma2(mk, -sp, c);
+                gy[0] += ym; gp[0] += p;
+#pragma unroll
+                for (int k = 0; k < KO; k++) { gy[k + 1] = bl_fma2(ym, w[k], gy[k + 1]); gp[k + 1] = bl_fma2(p, w[k], gp[k + 1]); }
+            }
+            // logsumexp over n of  n (eta + c) - lgamma(n+1) + B_n
+            const bl_f2 slope = eta + c;
+            const float *b0 = t0 + (size_t)t * (K + 1) * tab_ld, *b1 = t1 + (size_t)t * (K + 1) * tab_ld;
+            bl_f2 mx = bl2(-INFINITY);
+#pragma unroll 4
+            for (int n = 0; n <= K; n++) {
+                const bl_f2 B = bl_f2{b0[(size_t)n * tab_ld], b1[(size_t)n * tab_ld]};
+                mx = __builtin_elementwise_max(mx, bl_fma2(bl2((float)n), slope, B - bl2(BL_LGAMMA1P[n])));
+            }
+            bl_f2 S = bl2(0.0f), S1 = bl2(0.0f);
+#pragma unroll 4
+            for (int n = 0; n <= K; n++) {
+                const bl_f2 B = bl_f2{b0[(size_t)n * tab_ld], b1[(size_t)n * tab_ld]};
+                const bl_f2 tn = bl_fma2(bl2((float)n), slope, B - bl2(BL_LGAMMA1P[n])) - mx;
+                const bl_f2 en = bl_exp2_2(tn * bl2(BL_LOG2E));
+                S += en;
+                S1 = bl_fma2(bl2((float)n), en, S1);
+            }
+            const bl_f2 En = S1 * bl_rcp_2(S);
+            lsite += a - lam + mx + bl_log2_2(S) * bl2(BL_LN2);
+            dsum += En - lam;
+#pragma unroll
+            for (int k = 0; k <= KO; k++) ga2[k] += (gy[k] - En * gp[k]) * vmask;
+        }
+        ll2 = bl_fma2(lsite, vmask, ll2);
+        dsum *= vmask;
+        gb2[0] += dsum;
+#pragma unroll
+        for (int k = 0; k < KS; k++) gb2[k + 1] = bl_fma2(dsum, x[k], gb2[k + 1]);
+    }
+    ll += ll2.x + ll2.y;
+#pragma unroll
+    for (int k = 0; k <= KS; k++) gb[k] += gb2[k].x + gb2[k].y;
+#pragma unroll
+    for (int k = 0; k <= KO; k++) ga[k] += ga2[k].x + ga2[k].y;
+}
+
+
 // ---------------------------------------------------------------- Royle-Nichols (occu_rn) ----
 // biolith/models/occu_rn.py:179-222 + utils/distributions.py:31-40 with N summed out:
 //   lambda = exp(eta);  pi_n = Poisson(lambda)(n) renormalised over n <= K   (K = max_abundance)
@@ -771,8 +884,6 @@ __device__ __forceinline__ void bl_eval_sites_cop(int ct, int pstride, int cnt, 
 // n-loop is fully unrolled so the array is indexed statically; lgamma(n+1) folds to literals.
 // The gradient w.r.t. nu_j of a detection visit, sum_n w_n (q - q r b'_n / b_n), reuses the
 // posterior weights W[n] (stored over LP) in a second pass per detection: no per-visit state.
-#define BL_RN_NB 128
-__device__ constexpr float BL_LGAMMA1P[BL_RN_NB] = {0.000000000e+00f, 0.000000000e+00f, 6.931471806e-01f, 1.791759469e+00f, 3.178053830e+00f, 4.787491743e+00f, 6.579251212e+00f, 8.525161361e+00f, 1.060460290e+01f, 1.280182748e+01f, 1.510441257e+01f, 1.750230785e+01f, 1.998721450e+01f, 2.255216385e+01f, 2.519122118e+01f, 2.789927138e+01f, 3.067186011e+01f, 3.350507345e+01f, 3.639544521e+01f, 3.933988419e+01f, 4.233561646e+01f, 4.538013890e+01f, 4.847118135e+01f, 5.160667557e+01f, 5.478472940e+01f, 5.800360522e+01f, 6.126170176e+01f, 6.455753863e+01f, 6.788974314e+01f, 7.125703897e+01f, 7.465823635e+01f, 7.809222355e+01f, 8.155795946e+01f, 8.505446702e+01f, 8.858082754e+01f, 9.213617560e+01f, 9.571969454e+01f, 9.933061245e+01f, 1.029681986e+02f, 1.066317603e+02f, 1.103206397e+02f, 1.140342118e+02f, 1.177718814e+02f, 1.215330815e+02f, 1.253172711e+02f, 1.291239336e+02f, 1.329525750e+02f, 1.368027226e+02f, 1.406739236e+02f, 1.445657439e+02f, 1.484777670e+02f, 1.524095926e+02f, 1.563608363e+02f, 1.603311282e+02f, 1.643201123e+02f, 1.683274454e+02f, 1.723527971e+02f, 1.763958484e+02f, 1.804562914e+02f, 1.845338289e+02f, 1.886281734e+02f, 1.927390473e+02f, 1.968661817e+02f, 2.010093164e+02f, 2.051681995e+02f, 2.093425868e+02f, 2.135322415e+02f, 2.177369341e+02f, 2.219564418e+02f, 2.261905483e+02f, 2.304390436e+02f, 2.347017234e+02f, 2.389783896e+02f, 2.432688490e+02f, 2.475729141e+02f, 2.518904022e+02f, 2.562211356e+02f, 2.605649410e+02f, 2.649216498e+02f, 2.692910977e+02f, 2.736731243e+02f, 2.780675734e+02f, 2.824742927e+02f, 2.868931333e+02f, 2.913239501e+02f, 2.957666014e+02f, 3.002209486e+02f, 3.046868568e+02f, 3.091641936e+02f, 3.136528299e+02f, 3.181526396e+02f, 3.226634991e+02f, 3.271852877e+02f, 3.317178872e+02f, 3.362611820e+02f, 3.408150589e+02f, 3.453794071e+02f, 3.499541180e+02f, 3.545390855e+02f, 3.591342054e+02f, 3.637393756e+02f, 3.683544961e+02f, 3.729794689e+02f, 3.776141979e+02f, 3.822585888e+02f, 3.869125491e+02f, 3.915759882e+02f, 3.962488171e+02f, 4.009309483e+02f, 4.056222962e+02f, 4.103227765e+02f, 4.150323067e+02f, 4.197508056e+02f, 4.244781934e+02f, 4.292143919e+02f, 4.339593240e+02f, 4.387129142e+02f, 4.434750881e+02f, 4.482457727e+02f, 4.530248962e+02f, 4.578123880e+02f, 4.626081785e+02f, 4.674121996e+02f, 4.722243839e+02f, 4.770446655e+02f, 4.818729792e+02f, 4.867092611e+02f, 4.915534482e+02f};
 
 // wave-uniform maximum of a non-negative per-lane integer (inactive lanes count as 0)
 __device__ __forceinline__ int bl_wave_max_u(int x)
@@ -1041,7 +1152,7 @@ template <int MODEL> __device__ __forceinline__ int bl_model_dim(int Ks, int Ko,
     return Ks + Ko + 2 + ((MODEL == 2 || (MODEL == 3 && fp_mode != 0)) ? 1 : 0);
 }
 // visit width of the records in floats minus one: the KO every layout helper is called with
-template <int MODEL> __device__ __forceinline__ constexpr int bl_layout_ko(int KO) { return KO + (MODEL == 3 ? 1 : 0); }
+template <int MODEL> __device__ __forceinline__ constexpr int bl_layout_ko(int KO) { return KO + ((MODEL == 3 || MODEL == 4) ? 1 : 0); }
 
 template <int KS, int KO>
 __device__ __forceinline__ void bl_load_coefs(float (&beta)[KS + 1], float (&alpha)[KO + 1])
@@ -1082,7 +1193,8 @@ __device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, con
 // workgroup's site slice, wave partials into the LDS table.  Shared by the NUTS and logp kernels.
 template <int KS, int KO, bool LDS, int MODEL, int CW>
 __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__restrict__ grows, int ld_or_stride, int cnt,
-                                           int T, int J, int max_abundance, int fp_mode)
+                                           int T, int J, int max_abundance, int fp_mode, const float *__restrict__ tab = nullptr,
+                                           int tab_ld = 0)
 {
     float beta[KS + 1], alpha[KO + 1];
     bl_load_coefs<KS, KO>(beta, alpha);
@@ -1097,6 +1209,10 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         const BlFpScalars fp = bl_fp_scalars(bl_lds_f(BL_OFF_COEF)[KS + KO + 3], fp_mode == 1);
         bl_eval_sites_fp<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi);
         bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi);
+    } else if constexpr (MODEL == 4) {
+        static_assert(LDS, "N-mixture model: LDS records only");
+        bl_eval_sites_nmix<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, max_abundance, tab, tab_ld, beta, alpha, ll, gb, ga);
+        bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga);
     } else if constexpr (MODEL == 3) {
         static_assert(LDS, "count occupancy model: LDS records only");
         float gphi = 0.0f;

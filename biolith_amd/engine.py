@@ -52,7 +52,7 @@ class OccuDataset:
                  model: str = "occu", max_abundance: int = 100, fp_mode: Optional[str] = "constant", prior_fp=(2.0, 5.0),
                  session_duration=None, prior_fp_rate: float = 1.0):
         lib = _ffi.load()
-        if model not in ("occu", "occu_rn", "occu_fp", "occu_cop"):
+        if model not in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture"):
             raise ValueError(f"unknown model {model!r}")
         if fp_mode not in ("constant", "unoccupied") and not (model == "occu_cop" and fp_mode is None):
             raise ValueError(f"unknown fp_mode {fp_mode!r}")
@@ -84,6 +84,12 @@ class OccuDataset:
         if model == "occu_rn":
             _ffi.check(lib.bl_dataset_create_rn(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), int(max_abundance),
                                                 C.byref(pb), C.byref(pa), device, C.byref(h)))
+        elif model == "nmixture":
+            with np.errstate(invalid="ignore"):
+                if np.isfinite(Y).any() and np.nanmax(Y) > max_abundance:
+                    raise ValueError(f"max_abundance={max_abundance} is below the largest count {np.nanmax(Y):g}")
+            _ffi.check(lib.bl_dataset_create_nmix(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), int(max_abundance),
+                                                  C.byref(pb), C.byref(pa), device, C.byref(h)))
         elif model == "occu_cop":
             if session_duration is None:
                 raise ValueError("occu_cop needs session_duration (n_sites, n_periods, n_replicates)")

@@ -1,5 +1,6 @@
+from .nmixture import nmixture, simulate_nmixture
 from .occu import OccuSpec, occu, simulate
 from .occu_cop import occu_cop, simulate_cop
 from .occu_rn import occu_rn, simulate_rn
 
-__all__ = ["occu", "simulate", "occu_rn", "simulate_rn", "occu_cop", "simulate_cop", "OccuSpec"]
+__all__ = ["occu", "simulate", "occu_rn", "simulate_rn", "occu_cop", "simulate_cop", "nmixture", "simulate_nmixture", "OccuSpec"]

@@ -1,0 +1,159 @@
+"""``nmixture`` / ``simulate_nmixture`` -- host-side mirror of biolith/models/nmixture.py for the HIP engine.
+
+N-mixture model for repeated counts (Royle 2004): abundance ``lambda_i = exp(beta0 + x beta)``, latent
+``N_it`` enumerated over ``0..max_abundance`` with Poisson weights cut off below the largest count of the
+(site, period) (nmixture.py:150-155, 183-196), counts ``y_itj ~ Binomial(N_it, sigmoid(alpha0 + w alpha))``
+(nmixture.py:206-220).  The callable keeps the reference's signature (nmixture.py:17-35), validates, and
+resolves to an :class:`OccuSpec`; the N-marginalised density, its gradient and the sampler run in gfx950 kernels.
+"""
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+
+from ..distributions import HalfNormal, Normal, as_normal
+from ..regression import LinearRegression
+from .occu import OccuSpec
+
+MAX_ABUNDANCE_LIMIT = 127  # the kernel's lgamma table over N
+MAX_NMIX_COVS = 4          # covariates per side the nmixture kernels are instantiated for
+
+
+def nmixture(
+    site_covs,
+    obs_covs,
+    coords=None,
+    ell: float = 1.0,
+    max_abundance: int = 100,
+    obs=None,
+    n_species: int = 1,
+    prior_beta: Any = Normal(),
+    prior_alpha: Any = Normal(),
+    regressor_abu=LinearRegression,
+    regressor_det=LinearRegression,
+    prior_gp_sd: Any = HalfNormal(1.0),
+    prior_gp_length: Any = HalfNormal(1.0),
+    site_random_effects: bool = False,
+    obs_random_effects: bool = False,
+    prior_site_re_sd: Any = HalfNormal(1.0),
+    prior_obs_re_sd: Any = HalfNormal(1.0),
+) -> OccuSpec:
+    """N-mixture model on the HIP engine (parameters: nmixture.py:17-35).
+
+    Built: linear regressors, Normal priors, no spatial / random effects, ``max_abundance`` <= 127, at most 4
+    covariates per side; several species are sampled species by species.  Everything else raises
+    ``NotImplementedError``.
+
+    Examples
+    --------
+    >>> from biolith_amd.models import nmixture, simulate_nmixture
+    >>> from biolith_amd.utils import fit
+    >>> data, _ = simulate_nmixture()
+    >>> results = fit(nmixture, **data)
+    >>> print(results.samples['abundance'].mean())
+    """
+    site_covs = np.asarray(site_covs, dtype=np.float32)
+    obs_covs = np.asarray(obs_covs, dtype=np.float32)
+    obs = None if obs is None else np.asarray(obs, dtype=np.float32)
+    # nmixture.py:85-115
+    assert obs is None or obs.ndim == 4, "obs must be None or of shape (n_species, n_sites, n_periods, n_replicates)"
+    assert site_covs.ndim == 2, "site_covs must be of shape (n_sites, n_site_covs)"
+    assert obs_covs.ndim == 4, "obs_covs must be of shape (n_sites, n_periods, n_replicates, n_obs_covs)"
+    n_sites, n_periods, n_replicates = site_covs.shape[0], obs_covs.shape[1], obs_covs.shape[2]
+    if obs is not None:
+        n_species = obs.shape[0]
+    assert n_sites == obs_covs.shape[0], "site_covs and obs_covs must have the same number of sites"
+    if obs is not None:
+        assert n_sites == obs.shape[1], "obs must have n_sites rows"
+        assert n_periods == obs.shape[2], "obs must have n_periods columns"
+        assert n_replicates == obs.shape[3], "obs must have n_replicates columns"
+
+    unsupported = []
+    if coords is not None:
+        unsupported.append("coords (spatial HSGP effect, nmixture.py:125-133)")
+    if site_random_effects or obs_random_effects:
+        unsupported.append("random effects (nmixture.py:136-139)")
+    if regressor_abu is not LinearRegression or regressor_det is not LinearRegression:
+        unsupported.append("non-linear regressors (nmixture.py:160-161)")
+    if obs is None:
+        unsupported.append("obs=None (prior predictive)")
+    if not 1 <= int(max_abundance) <= MAX_ABUNDANCE_LIMIT:
+        unsupported.append(f"max_abundance outside 1..{MAX_ABUNDANCE_LIMIT}")
+    if site_covs.shape[1] > MAX_NMIX_COVS or obs_covs.shape[3] > MAX_NMIX_COVS:
+        unsupported.append(f"more than {MAX_NMIX_COVS} covariates per side")
+    if unsupported:
+        raise NotImplementedError("biolith_amd.nmixture: not built: " + "; ".join(unsupported))
+    spec = OccuSpec(site_covs, obs_covs, obs, n_species, as_normal(prior_beta, "prior_beta"),
+                    as_normal(prior_alpha, "prior_alpha"), model="nmixture")
+    spec.extras["max_abundance"] = int(max_abundance)
+    return spec
+
+
+nmixture.__biolith_amd_model__ = "nmixture"
+
+
+def simulate_nmixture(
+    n_site_covs: int = 1,
+    n_obs_covs: int = 1,
+    n_sites: int = 100,
+    n_periods: int = 1,
+    n_species: int = 1,
+    deployment_days_per_site: int = 365,
+    session_duration: int = 7,
+    simulate_missing: bool = False,
+    min_abundance: float = 0.5,
+    max_abundance: float = 6.0,
+    min_observation_rate: float = 0.5,
+    max_observation_rate: float = 4.0,
+    random_seed: int = 0,
+    spatial: bool = False,
+    gp_sd: float = 1.0,
+    gp_l: float = 0.2,
+    site_random_effects: bool = False,
+    obs_random_effects: bool = False,
+    site_re_sd: float = 0.5,
+    obs_re_sd: float = 0.3,
+):
+    """Generator of :func:`nmixture` data, bit-identical to the reference's (nmixture.py:223-369) for
+    ``spatial=False`` and no random effects: same NumPy PCG64 stream, draw order and rejection loop.
+
+    Examples
+    --------
+    >>> from biolith_amd.models import simulate_nmixture
+    >>> data, params = simulate_nmixture()
+    >>> sorted(data.keys())
+    ['coords', 'ell', 'obs', 'obs_covs', 'site_covs']
+    """
+    if spatial or site_random_effects or obs_random_effects:
+        raise NotImplementedError("simulate_nmixture: spatial and random effects are not built")
+    rng = np.random.default_rng(random_seed)
+    coords = None
+    N_i = obs = None
+    while (N_i is None or np.mean(N_i) < min_abundance or np.mean(N_i) > max_abundance
+           or np.mean(obs[np.isfinite(obs)]) < min_observation_rate
+           or np.mean(obs[np.isfinite(obs)]) > max_observation_rate):
+        beta = rng.normal(size=(n_species, n_site_covs + 1))
+        alpha = rng.normal(size=(n_species, n_obs_covs + 1))
+        site_covs = rng.normal(size=(n_sites, n_site_covs))
+        w, ell = np.zeros(n_sites), 0.0
+        site_re_abu = np.zeros((n_species, n_sites))
+        site_re_det = np.zeros((n_species, n_sites))
+        abundance = np.exp(beta[:, 0][:, None] + np.tensordot(beta[:, 1:], site_covs, axes=([1], [1])) + w[None, :] + site_re_abu)
+        N_i = rng.poisson(abundance[:, None, :], size=(n_species, n_periods, n_sites))
+        n_replicates = round(deployment_days_per_site / session_duration)
+        obs_covs = rng.normal(size=(n_sites, n_periods, n_replicates, n_obs_covs))
+        obs_re = np.zeros((n_species, n_sites, n_periods, n_replicates))
+        prob_detection = 1 / (1 + np.exp(-(alpha[:, 0][:, None, None, None] + np.tensordot(alpha[:, 1:], obs_covs, axes=([1], [3]))
+                                           + site_re_det[:, :, None, None] + obs_re)))
+        N_i_site = N_i.transpose(0, 2, 1)
+        obs = rng.binomial(n=N_i_site[..., None], p=prob_detection).astype(float)
+        if simulate_missing:
+            obs[rng.choice([True, False], size=obs.shape, p=[0.2, 0.8])] = np.nan
+            obs_covs[rng.choice([True, False], size=obs_covs.shape, p=[0.05, 0.95])] = np.nan
+            site_covs[rng.choice([True, False], size=site_covs.shape, p=[0.05, 0.95])] = np.nan
+
+    print(f"True abundance: {np.mean(N_i):.4f}")
+    print(f"Mean count: {np.mean(obs[np.isfinite(obs)]):.4f}")
+    true_params = dict(N_i=N_i, abundance=abundance, beta=beta, alpha=alpha, w=w, gp_sd=gp_sd, gp_l=gp_l)
+    return dict(site_covs=site_covs, obs_covs=obs_covs, obs=obs, coords=coords, ell=ell), true_params

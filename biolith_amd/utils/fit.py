@@ -210,7 +210,7 @@ def _assemble(per_species, spec, num_warmup) -> HipMCMC:
         res.inv_mass = np.concatenate([r.inv_mass for _, r in per_species], axis=1)
     res.draws = np.concatenate([r.draws for _, r in per_species], axis=2) if nsp > 1 else res0.draws
     # occu emits "psi" (occu.py:207); occu_rn emits "abundance" = exp(linear predictor) (occu_rn.py:192)
-    first = "abundance" if spec.model == "occu_rn" else "psi"
+    first = "abundance" if spec.model in ("occu_rn", "nmixture") else "psi"
     # occu_cop's replicate-level site is the detection RATE exp(linear predictor) (occu_cop.py:236-243)
     second = "rate_detection" if spec.model == "occu_cop" else "prob_detection"
     return HipMCMC(res, latent=latent,

@@ -77,8 +77,8 @@ def predict(
     valid = {k: v for k, v in arguments.items() if v is not None}
     blank = np.full((n_species,) + np.shape(obs_covs)[:3], np.nan, dtype=np.float32)
     spec = model_fn(**valid, obs=blank, **kwargs)
-    if spec.model == "occu_cop":
-        raise NotImplementedError("predict(): not built for occu_cop")
+    if spec.model in ("occu_cop", "nmixture"):
+        raise NotImplementedError(f"predict(): not built for {spec.model}")
     if beta.shape[2] != spec.site_covs.shape[1] + 1 or alpha.shape[2] != spec.obs_covs.shape[3] + 1:
         raise ValueError("predict(): covariate counts differ from the fitted model's coefficients")
 

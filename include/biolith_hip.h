@@ -110,6 +110,16 @@ int bl_dataset_create_cop(const bl_dims *dims, const float *site_covs, const flo
                           const float *obs, const float *session_duration, int fp_mode,
                           double prior_fp_rate, const bl_normal_prior *prior_beta,
                           const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
+/*
+ * Same for the N-mixture model biolith.models.nmixture (models/nmixture.py:17-220): obs holds counts,
+ * N ~ Poisson(exp(beta0 + x beta)) enumerated over 0..max_abundance (raw, un-renormalised weights: the model's
+ * "N_i_trunc_norm" factor, nmixture.py:183-196; support cut below the largest count of each (site, period),
+ * nmixture.py:150-155), y ~ Binomial(N, sigmoid(alpha0 + w alpha)).  bl_deterministic's outputs are `abundance`
+ * and `prob_detection`.  Built for max_abundance <= 127 and at most 4 covariates per side; bl_predict is not built for it.
+ */
+int bl_dataset_create_nmix(const bl_dims *dims, const float *site_covs, const float *obs_covs,
+                           const float *obs, int max_abundance, const bl_normal_prior *prior_beta,
+                           const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
 int bl_dataset_destroy(bl_dataset *ds);
 /* D = Ks+1 + Ko+1; theta = [beta_0..beta_Ks, alpha_0..alpha_Ko] */
 int bl_dataset_param_dim(const bl_dataset *ds, int *D);

@@ -49,6 +49,7 @@ def lib():
             L.orc_data_set_model.argtypes = [C.c_void_p, C.c_int, C.c_int]
             L.orc_data_set_fp.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_cop.argtypes = [C.c_void_p, dp, dp, C.c_int, C.c_double]
+            L.orc_data_set_nmix.argtypes = [C.c_void_p, dp, C.c_int]
             L.orc_potential_grad.restype = C.c_double
             L.orc_potential_grad.argtypes = [C.c_void_p, dp, dp]
             L.orc_rng_streams.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
@@ -103,12 +104,14 @@ class OracleData:
         self.X, self.W, self.Y = X, W, Y
         self.prior_beta, self.prior_alpha = tuple(prior_beta), tuple(prior_alpha)
         self.model, self.max_abundance = model, int(max_abundance)
-        assert model in ("occu", "occu_rn", "occu_fp", "occu_cop")
+        assert model in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture")
         lib().orc_data_set_model(self._h, 1 if model == "occu_rn" else 0, int(max_abundance))
         if model == "occu_fp":  # theta gains phi = logit(false-positive rate) as its last coordinate
             assert fp_mode in ("constant", "unoccupied")
             lib().orc_data_set_fp(self._h, 1 if fp_mode == "constant" else 2, float(prior_fp[0]), float(prior_fp[1]))
             self.D += 1
+        if model == "nmixture":  # counts, N enumerated over 0..max_abundance with raw (un-renormalised) Poisson weights
+            lib().orc_data_set_nmix(self._h, _dp(Y), int(max_abundance))
         if model == "occu_cop":  # counts + exposure; optional false-positive rate as trailing phi = log(rate)
             assert fp_mode in (None, "constant", "unoccupied")
             Dur = _as_f32_f64(session_duration)
@@ -310,6 +313,49 @@ def literal_log_joint_cop(theta, site_covs, obs_covs, obs, session_duration, fp_
     if fp_mode:
         out += np.log(prior_fp_rate) - prior_fp_rate * f + theta[-1]       # Exponential log-pdf + log|d f / d phi|
     return out
+
+
+def literal_log_joint_nmix(theta, site_covs, obs_covs, obs, max_abundance=100, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):
+    """log density of the N-mixture model (biolith/models/nmixture.py:150-220), N summed by brute force with the
+    model's own ingredients: Poisson logits masked below the largest count, the ``N_i_trunc_norm`` factor and the
+    (normalising) Categorical, Binomial log-pmf as numpyro states it."""
+    from scipy.special import gammaln, logsumexp, xlog1py, xlogy
+
+    X, W, Y = (_as_f32_f64(a) for a in (site_covs, obs_covs, obs))
+    if Y.ndim == 4:
+        Y = Y[0]
+    Ks, Ko = X.shape[1], W.shape[-1]
+    theta = np.asarray(theta, dtype=np.float64)
+    beta, alpha = theta[: Ks + 1], theta[Ks + 1:]
+    obs_mask = np.isnan(W).any(-1) | np.isnan(X).any(-1)[:, None, None]     # nmixture.py:117-123
+    Y = np.where(obs_mask, np.nan, Y)
+    W, X = np.nan_to_num(W), np.nan_to_num(X)
+    with np.errstate(invalid="ignore"):
+        obs_max = np.max(np.where(np.isnan(Y), -np.inf, Y), axis=2)          # nmixture.py:150-155 (over replicates)
+    min_counts = np.where(np.isfinite(obs_max), obs_max, 0).astype(int)     # (N, T)
+    abundance = np.exp(beta[0] + X @ beta[1:])                              # (N,)
+    support = np.arange(max_abundance + 1)
+    logits = xlogy(support[None, :], abundance[:, None]) - gammaln(support + 1.0)[None, :] - abundance[:, None]   # Poisson.log_prob
+    logits = np.broadcast_to(logits[:, None, :], min_counts.shape + (max_abundance + 1,)).copy()
+    logits[support[None, None, :] < min_counts[..., None]] = -np.inf        # nmixture.py:186-190
+    trunc_norm = logsumexp(logits, axis=-1)                                 # factor "N_i_trunc_norm"
+    log_cat = logits - trunc_norm[..., None]                                # Categorical(logits).log_prob
+    p = 1.0 / (1.0 + np.exp(-(alpha[0] + np.tensordot(W, alpha[1:], axes=([3], [0])))))   # (N, T, J)
+    finite = np.isfinite(Y)
+    y0 = np.where(finite, Y, 0.0)
+    n = support[None, None, None, :].astype(np.float64)                     # (1,1,1,K+1)
+    yy, pp = y0[..., None], p[..., None]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        lb = (gammaln(n + 1.0) - gammaln(yy + 1.0) - gammaln(n - yy + 1.0) + xlogy(yy, pp) + xlog1py(n - yy, -pp))
+    lb = np.where(finite[..., None], lb, 0.0).sum(axis=2)                   # (N, T, K+1)
+    with np.errstate(invalid="ignore"):
+        per_n = np.where(np.isfinite(log_cat), log_cat + lb, -np.inf)
+    ll = (trunc_norm + logsumexp(per_n, axis=-1)).sum()
+
+    def normal_logpdf(v, loc, scale):
+        return (-0.5 * ((v - loc) / scale) ** 2 - np.log(scale) - 0.5 * np.log(2 * np.pi)).sum()
+
+    return ll + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
 
 
 def literal_log_joint_rn(theta, site_covs, obs_covs, obs, max_abundance=100, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):

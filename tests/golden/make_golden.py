@@ -122,6 +122,40 @@ def main_cop():
         json.dump(index, f, indent=1, sort_keys=True)
 
 
+# N-mixture generator (biolith/models/nmixture.py:223-369)
+NMIX_REF_TEST = dict(simulate_missing=True, deployment_days_per_site=70, session_duration=7, min_abundance=1.0,
+                     min_observation_rate=1.0, max_observation_rate=6.0)          # nmixture.py:372-380
+NMIX_CASES = {
+    "nmix_default": dict(kw=dict()),
+    "nmix_ref_test": dict(kw=NMIX_REF_TEST),
+    "nmix_ref_test_3periods": dict(kw=dict(NMIX_REF_TEST, n_periods=3)),           # nmixture.py:423-431
+    "nmix_small_2x2": dict(kw=dict(n_sites=60, n_site_covs=2, n_obs_covs=2, deployment_days_per_site=42, random_seed=4)),
+}
+
+
+def main_nmix():
+    simulate_nmixture = sys.modules["biolith.models.nmixture"].simulate_nmixture
+    index = {}
+    for name, case in NMIX_CASES.items():
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            data, truth = simulate_nmixture(**case["kw"])
+        keys = ("site_covs", "obs_covs", "obs")
+        index[name] = dict(
+            kwargs=case["kw"], stdout=buf.getvalue(),
+            shapes={k: list(np.shape(data[k])) for k in keys}, sha256={k: sha(data[k]) for k in keys},
+            coords=data["coords"], ell=float(data["ell"]),
+            beta=np.asarray(truth["beta"]).tolist(), alpha=np.asarray(truth["alpha"]).tolist(),
+            mean_N=float(np.mean(truth["N_i"])), sha256_N=sha(truth["N_i"]), mean_obs=float(np.nanmean(data["obs"])),
+            max_obs=float(np.nanmax(data["obs"])),
+        )
+        np.savez_compressed(os.path.join(HERE, f"simulate_{name}.npz"), site_covs=data["site_covs"], obs_covs=data["obs_covs"],
+                            obs=data["obs"], N_i=truth["N_i"], abundance=truth["abundance"], beta=truth["beta"], alpha=truth["alpha"])
+        print(name, index[name]["shapes"], index[name]["sha256"]["obs"][:24])
+    with open(os.path.join(HERE, "simulate_nmix_index.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+
+
 def main_rn():
     simulate_rn = load_reference_simulate_rn()
     index = {}
@@ -186,3 +220,4 @@ if __name__ == "__main__":
     main()
     main_rn()
     main_cop()
+    main_nmix()

@@ -1,0 +1,104 @@
+"""N-mixture kernel (MODEL 4) through the C-ABI (bl_dataset_create_nmix) against the float64 oracle, plus the
+reference's own fit assertions (biolith/models/nmixture.py:372-449)."""
+import numpy as np
+import pytest
+
+import oracle
+from biolith_amd.engine import OccuDataset
+from biolith_amd.evaluation import effective_sample_size, split_gelman_rubin
+from biolith_amd.models import nmixture, simulate_nmixture
+from biolith_amd.utils import fit
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+U_RTOL, G_RTOL = 2e-6, 2e-5   # float32 per-term math, sums over N in float32
+
+REF_TEST = dict(simulate_missing=True, deployment_days_per_site=70, session_duration=7, min_abundance=1.0,
+                min_observation_rate=1.0, max_observation_rate=6.0)
+
+
+def _pair(name, K, priors=((0.0, 1.0), (0.0, 1.0))):
+    g = load_golden(name)
+    kw = dict(model="nmixture", max_abundance=K)
+    return (g, oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], *priors, **kw),
+            OccuDataset(g["site_covs"], g["obs_covs"], g["obs"], *priors, **kw))
+
+
+@pytest.mark.parametrize("name,K", [("nmix_ref_test", 9), ("nmix_ref_test", 60), ("nmix_ref_test_3periods", 19),
+                                     ("nmix_small_2x2", 40), ("nmix_default", 100), ("nmix_default", 127)])
+def test_nmix_logp_grad_parity(name, K):
+    _, od, ds = _pair(name, K, priors=((0.1, 1.5), (-0.2, 0.8)))
+    th = np.random.default_rng(3).uniform(-1.0, 1.0, size=(5, od.D)).astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.all(np.isfinite(Ug)) and np.all(np.isfinite(Gg))
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= U_RTOL, (Ug, Uo)
+    assert np.max(np.abs(Gg - Go) / np.max(np.abs(Go), axis=1, keepdims=True)) <= G_RTOL, np.abs(Gg - Go).max(1)
+
+
+@pytest.mark.parametrize("n_sites", [1, 2, 65, 385, 1031])
+def test_nmix_ragged_site_counts(n_sites):
+    rng = np.random.default_rng(n_sites)
+    X = rng.normal(size=(n_sites, 2)) * 0.5; W = rng.normal(size=(n_sites, 2, 3, 2)) * 0.5
+    Nn = rng.poisson(2.0, size=(n_sites, 2, 1))
+    Y = rng.binomial(Nn, 0.4, size=(n_sites, 2, 3)).astype(float)[None]
+    Y[rng.uniform(size=Y.shape) < 0.1] = np.nan
+    kw = dict(model="nmixture", max_abundance=25)
+    od, ds = oracle.OracleData(X, W, Y, **kw), OccuDataset(X, W, Y, **kw)
+    th = rng.uniform(-0.8, 0.8, size=(2, 6)).astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= U_RTOL
+    assert np.max(np.abs(Gg - Go)) <= G_RTOL * np.max(np.abs(Go))
+
+
+def test_nmix_limits():
+    g = load_golden("nmix_small_2x2")
+    with pytest.raises(ValueError, match="below the largest count"):
+        OccuDataset(g["site_covs"], g["obs_covs"], g["obs"], model="nmixture", max_abundance=5)
+    with pytest.raises((RuntimeError, NotImplementedError, ValueError)):
+        OccuDataset(g["site_covs"], g["obs_covs"], g["obs"], model="nmixture", max_abundance=128)
+
+
+def test_nmix_first_transitions_match_oracle():
+    _, od, ds = _pair("nmix_small_2x2", 40)
+    o = oracle.nuts_run(od, 0, 5, num_chains=2, seed=3)
+    r = ds.nuts(num_warmup=0, num_samples=5, num_chains=2, seed=3)
+    assert np.array_equal(o["num_steps"][:, :3], r.num_steps[:, :3]), (o["num_steps"], r.num_steps)
+    assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=2e-3)
+
+
+def test_nmix_posterior_matches_oracle():
+    _, od, ds = _pair("nmix_small_2x2", 40)
+    o = oracle.nuts_run(od, 300, 400, num_chains=4, seed=0)
+    r = ds.nuts(num_warmup=300, num_samples=400, num_chains=4, seed=50)
+    assert split_gelman_rubin(r.draws).max() < 1.03
+    fg, fo = r.draws.reshape(-1, od.D).astype(np.float64), o["draws"].reshape(-1, od.D)
+    mcse = np.sqrt(fg.var(0) / effective_sample_size(r.draws) + fo.var(0) / oracle.effective_sample_size(o["draws"]))
+    assert np.all(np.abs(fg.mean(0) - fo.mean(0)) <= 4 * mcse), (fg.mean(0) - fo.mean(0), mcse)
+    ratio = fg.std(0) / fo.std(0)
+    assert np.all((ratio > 0.85) & (ratio < 1.18)), ratio
+
+
+def _assert_recovery(results, true_params):  # nmixture.py:400-420
+    assert np.allclose(results.samples["abundance"].mean(), true_params["abundance"].mean(), rtol=0.2)
+    assert np.allclose([results.samples[k].mean() for k in [f"cov_state_{i}" for i in range(true_params["beta"].shape[1])]],
+                       true_params["beta"].mean(axis=0), atol=0.5)
+    assert np.allclose([results.samples[k].mean() for k in [f"cov_det_{i}" for i in range(true_params["alpha"].shape[1])]],
+                       true_params["alpha"].mean(axis=0), atol=0.5)
+
+
+def test_nmixture_like_reference():  # nmixture.py:372-420
+    data, true_params = simulate_nmixture(**REF_TEST)
+    max_abundance = int(np.nanmax(data["obs"]))
+    results = fit(nmixture, **data, max_abundance=max_abundance, num_chains=1, num_samples=300, num_warmup=300, timeout=600)
+    _assert_recovery(results, true_params)
+    assert results.samples["abundance"].shape == (300, 1, 100, 1)
+    assert results.samples["prob_detection"].shape == (300, 10, 1, 100, 1)
+
+
+def test_nmixture_multi_season():  # nmixture.py:423-449
+    data, true_params = simulate_nmixture(**REF_TEST, n_periods=3)
+    max_abundance = int(np.nanmax(data["obs"]))
+    results = fit(nmixture, **data, max_abundance=max_abundance, num_chains=1, num_samples=300, num_warmup=300, timeout=600)
+    _assert_recovery(results, true_params)
