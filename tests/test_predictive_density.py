@@ -116,3 +116,46 @@ def test_lppd_waic_after_fit_and_predict():  # lppd.py:98-123, waic.py:127-156, 
     ll = log_likelihood(occu, ps, **data)["y"].transpose(0, 4, 3, 2, 1)[:, valid]
     llm = log_likelihood_manual(ps, data)[:, valid]
     np.testing.assert_allclose(logsumexp(ll, 0) - np.log(len(ll)), logsumexp(llm, 0) - np.log(len(llm)), rtol=1e-1)
+
+
+def test_deviance_residuals_and_ppc_on_hand_made_samples():  # deviance.py, residuals.py, posterior_predictive_check.py
+    from biolith_amd.evaluation import deviance, deviance_manual, posterior_predictive_check, residuals
+
+    rng = np.random.default_rng(4)
+    n, N, T, J = 500, 12, 2, 3
+    ps, data = _fake_predictive(rng, n, N, T, J), _data(rng, N, T, J)
+    # deviance = -2 log mean_q exp(sum of valid log-likelihoods of draw q)
+    ll = log_likelihood(occu, ps, **data)["y"].astype(np.float64)
+    valid = (np.isfinite(data["obs"]) & np.isfinite(data["obs_covs"]).all(-1)[None]
+             & np.isfinite(data["site_covs"]).all(-1)[None, :, None, None])
+    per_draw = ll.transpose(0, 4, 3, 2, 1)[:, valid].sum(1)
+    want = -2 * (np.log(np.mean(np.exp(per_draw - per_draw.max()))) + per_draw.max())
+    assert deviance(occu, ps, **data) == pytest.approx(want, rel=1e-10)
+    dm = deviance_manual(ps, data)
+    assert 0 < dm < np.inf
+    # residuals: o = z - psi everywhere; d = y - p where the draw is occupied, NaN elsewhere
+    occ, det = residuals(ps, data["obs"])
+    assert occ.shape == (n, T, N, 1) and det.shape == (n, 1, N, T, J)
+    np.testing.assert_allclose(occ, ps["z"] - ps["psi"])
+    q, t, i = np.argwhere(ps["z"][..., 0] == 1)[0]
+    want_d = data["obs"][0, i, t, 1] - ps["prob_detection"][q, 1, t, i, 0]
+    assert np.isnan(want_d) or det[q, 0, i, t, 1] == pytest.approx(want_d)
+    q, t, i = np.argwhere(ps["z"][..., 0] == 0)[0]
+    assert np.isnan(det[q, 0, i, t]).all()
+    # posterior predictive check: a p-value in [0, 1]; replicated data drawn from the same (psi, p) as "observed" data
+    # gives a p-value away from the extremes, grossly different observed data an extreme one
+    psi = np.broadcast_to(rng.uniform(0.4, 0.8, size=(1, T, N, 1)), (n, T, N, 1))
+    p = np.broadcast_to(rng.uniform(0.3, 0.6, size=(1, J, T, N, 1)), (n, J, T, N, 1))
+    z = (rng.uniform(size=psi.shape) < psi).astype(np.int32)
+    y = (rng.uniform(size=p.shape) < p * z[:, None]).astype(np.int32)
+    good = y[0].transpose(3, 2, 1, 0).astype(float)          # one replicate plays the observed data (S, N, T, J)
+    sam = {"psi": psi, "prob_detection": p, "z": z, "y": y}
+    for group_by in ("site", "revisit"):
+        for statistic in ("freeman-tukey", "chi-squared"):
+            pv = posterior_predictive_check(sam, good, group_by=group_by, statistic=statistic)
+            assert 0.02 < pv < 0.98, (group_by, statistic, pv)
+    assert posterior_predictive_check(sam, np.ones_like(good)) < 0.01
+    with pytest.raises(ValueError):
+        posterior_predictive_check(sam, good, statistic="g-test")
+    with pytest.raises(ValueError):
+        posterior_predictive_check(sam, good, group_by="period")
