@@ -185,15 +185,16 @@ def _assemble(per_species, spec, num_warmup) -> HipMCMC:
         # phi = log(rate); the model's site is the rate (occu_cop.py:158-170)
         latent[f"rate_fp_{spec.extras['fp_mode']}"] = np.exp(res0.draws[:, :, Ks + Ko + 2].astype(np.float64)).astype(np.float32)
     if S:
-        psi = np.stack([d.deterministic(r.draws.reshape(C * S, D), psi=True, prob_detection=False)[0]
-                        for d, r in per_species], axis=-1)
+        parts = [d.deterministic(r.draws.reshape(C * S, D), psi=True, prob_detection=False)[0] for d, r in per_species]
+        # one species (the common case): a view, not a 160 MB copy at the headline size
+        psi = parts[0][..., None] if nsp == 1 else np.stack(parts, axis=-1)
     else:
         psi = np.empty((0, ds0.T, ds0.N, nsp), np.float32)
     psi = psi.reshape(C, S, ds0.T, ds0.N, nsp)
 
     def prob_detection():
-        pd = np.stack([d.deterministic(r.draws.reshape(C * S, D), psi=False, prob_detection=True)[1]
-                       for d, r in per_species], axis=-1)
+        parts = [d.deterministic(r.draws.reshape(C * S, D), psi=False, prob_detection=True)[1] for d, r in per_species]
+        pd = parts[0][..., None] if nsp == 1 else np.stack(parts, axis=-1)
         return pd.reshape(C, S, ds0.J, ds0.T, ds0.N, nsp)
 
     # one result object for the mcmc shim: extras concatenated over species along the chain axis
