@@ -6,9 +6,10 @@
 // between subtrees), dual-averaging step size, windowed Welford diagonal mass matrix.
 //
 // Mapping to the chip
-//   * one chain = k cooperating workgroups, one per CU; a workgroup = 4 compute waves (one per
-//     SIMD) + 1 control wave.  It owns a contiguous slice of sites, staged ONCE into LDS as pair
-//     records and evaluated two sites per lane (occu_device.hpp);
+//   * one chain = k cooperating workgroups, one per CU; a workgroup = CW compute waves + 1 control
+//     wave (CW = 3: every wave owns a SIMD; CW = 4 for larger slices, occu_device.hpp).  It owns a
+//     contiguous slice of sites, staged ONCE into LDS as pair records and evaluated two sites per
+//     lane (occu_rn: one);
 //   * blockIdx -> (chain, member) is XCD-aware: blocks b and b+8 share an XCD under the observed
 //     round-robin dealing, so chain c takes the blocks with b % 8 == c % 8 and its k workgroups
 //     share one L2.  That is a SPEED arrangement only: every workgroup reads HW_REG_XCC_ID and the
@@ -25,13 +26,16 @@
 //         the XCD's L2, sc1 polls bypass L1 and hit that L2: several times shorter hop;
 //     every workgroup sums the k records in the same fixed order in f64, so all k copies of the
 //     chain state stay bit-identical without any broadcast;
-//   * the control wave (lane d = dimension d) then runs only the CRITICAL part of NumPyro's
-//     per-leaf logic -- finish the velocity-Verlet step, energy error, checkpointed U-turn test,
-//     and the decision where the next leaf goes -- publishes that position through LDS, and
-//     DEFERS the bookkeeping that cannot change the next position (multinomial proposal updates,
-//     tree weights, accept-prob sums): it runs while the compute waves already evaluate the next
-//     leaf.  Direction bits and transition uniforms come from two separate xoshiro streams so
-//     that the deferral does not reorder any stream (the oracle draws from the same two).
+//   * the control wave (lane d = dimension d) then writes the SPECULATIVE next position -- the next
+//     leaf of the subtree or the first leaf of the next doubling, a few FMAs from the gathered
+//     gradient -- and releases the compute waves; NumPyro's per-leaf decisions (finish the
+//     velocity-Verlet step, energy error, checkpointed U-turn tests, tree edges, transition end with
+//     dual averaging / Welford windows / new momentum) and the multinomial bookkeeping run BESIDE
+//     that evaluation.  If the decided position is not bit-equal to the guess the evaluation is
+//     dropped and redone (transition ends), so correctness never depends on the guess.  occu_rn,
+//     nmixture and the HBM-row form (long evaluations) decide first and overlap only the
+//     bookkeeping.  Direction bits and transition uniforms come from two separate xoshiro streams
+//     so that neither form reorders a stream (the oracle draws from the same two).
 // No host round trip, no kernel boundary and no HBM traffic inside the sampling loop.
 #pragma once
 #include "occu_device.hpp"
