@@ -14,6 +14,7 @@ import numpy as np
 
 from ..distributions import HalfNormal, Normal, as_normal
 from ..regression import LinearRegression
+from ._generators import Generator, expit, observed_mean, within
 from .occu import OccuSpec
 
 MAX_ABUNDANCE_LIMIT = 127  # the kernel's lgamma table over N
@@ -127,33 +128,22 @@ def simulate_nmixture(
     """
     if spatial or site_random_effects or obs_random_effects:
         raise NotImplementedError("simulate_nmixture: spatial and random effects are not built")
-    rng = np.random.default_rng(random_seed)
-    coords = None
-    N_i = obs = None
-    while (N_i is None or np.mean(N_i) < min_abundance or np.mean(N_i) > max_abundance
-           or np.mean(obs[np.isfinite(obs)]) < min_observation_rate
-           or np.mean(obs[np.isfinite(obs)]) > max_observation_rate):
-        beta = rng.normal(size=(n_species, n_site_covs + 1))
-        alpha = rng.normal(size=(n_species, n_obs_covs + 1))
-        site_covs = rng.normal(size=(n_sites, n_site_covs))
-        w, ell = np.zeros(n_sites), 0.0
-        site_re_abu = np.zeros((n_species, n_sites))
-        site_re_det = np.zeros((n_species, n_sites))
-        abundance = np.exp(beta[:, 0][:, None] + np.tensordot(beta[:, 1:], site_covs, axes=([1], [1])) + w[None, :] + site_re_abu)
-        N_i = rng.poisson(abundance[:, None, :], size=(n_species, n_periods, n_sites))
-        n_replicates = round(deployment_days_per_site / session_duration)
-        obs_covs = rng.normal(size=(n_sites, n_periods, n_replicates, n_obs_covs))
-        obs_re = np.zeros((n_species, n_sites, n_periods, n_replicates))
-        prob_detection = 1 / (1 + np.exp(-(alpha[:, 0][:, None, None, None] + np.tensordot(alpha[:, 1:], obs_covs, axes=([1], [3]))
-                                           + site_re_det[:, :, None, None] + obs_re)))
-        N_i_site = N_i.transpose(0, 2, 1)
-        obs = rng.binomial(n=N_i_site[..., None], p=prob_detection).astype(float)
-        if simulate_missing:
-            obs[rng.choice([True, False], size=obs.shape, p=[0.2, 0.8])] = np.nan
-            obs_covs[rng.choice([True, False], size=obs_covs.shape, p=[0.05, 0.95])] = np.nan
-            site_covs[rng.choice([True, False], size=site_covs.shape, p=[0.05, 0.95])] = np.nan
 
-    print(f"True abundance: {np.mean(N_i):.4f}")
-    print(f"Mean count: {np.mean(obs[np.isfinite(obs)]):.4f}")
-    true_params = dict(N_i=N_i, abundance=abundance, beta=beta, alpha=alpha, w=w, gp_sd=gp_sd, gp_l=gp_l)
-    return dict(site_covs=site_covs, obs_covs=obs_covs, obs=obs, coords=coords, ell=ell), true_params
+    def latent(rng, abu_linear):  # nmixture.py:295-296
+        return rng.poisson(np.exp(abu_linear)[:, None, :], size=(n_species, n_periods, n_sites))
+
+    def observe(rng, det_linear, N_site, _):  # nmixture.py:322-323
+        return rng.binomial(n=N_site[..., None], p=expit(det_linear)).astype(float)
+
+    def accept(d):  # negation of the reference's while-condition (nmixture.py:262-268)
+        return (within(np.mean(d.latent), min_abundance, max_abundance)
+                and within(observed_mean(d.obs), min_observation_rate, max_observation_rate))
+
+    n_replicates = round(deployment_days_per_site / session_duration)
+    d = Generator(n_species, n_sites, n_periods, n_replicates, n_site_covs, n_obs_covs, latent, observe, accept,
+                  simulate_missing=simulate_missing).run(random_seed)
+    print(f"True abundance: {np.mean(d.latent):.4f}")
+    print(f"Mean count: {np.mean(d.obs[np.isfinite(d.obs)]):.4f}")
+    true_params = dict(N_i=d.latent, abundance=np.exp(d.site_linear), beta=d.beta, alpha=d.alpha, w=d.extra["w"],
+                       gp_sd=gp_sd, gp_l=gp_l)
+    return dict(site_covs=d.site_covs, obs_covs=d.obs_covs, obs=d.obs, coords=None, ell=0.0), true_params

@@ -18,6 +18,7 @@ import numpy as np
 
 from ..distributions import Beta, HalfNormal, Normal, as_beta, as_normal
 from ..regression import AbstractRegression, LinearRegression
+from ._generators import Generator, expit, observed_mean, within
 
 
 @dataclass
@@ -132,11 +133,6 @@ def occu(
 occu.__biolith_amd_model__ = "occu"
 
 
-def _expit_ref(x):
-    # written exactly as the reference evaluates it (1 / (1 + exp(-x))) so the Bernoulli draws agree bitwise
-    return 1 / (1 + np.exp(-x))
-
-
 def simulate(
     n_site_covs: int = 1,
     n_obs_covs: int = 1,
@@ -170,62 +166,35 @@ def simulate(
     """
     if spatial:
         raise NotImplementedError("simulate(spatial=True) is outside the built path (utils/spatial.py:52-76)")
-    rng = np.random.default_rng(random_seed)
-    coords = None
-    n_replicates = round(deployment_days_per_site / session_duration)
 
-    def in_range(z, obs):
-        occ = z.mean()
-        rate = np.mean(obs[np.isfinite(obs)])
-        # negation of the reference's while-condition (occu.py:290-296), NaN behaviour included
-        return not (occ < min_occupancy or occ > max_occupancy
-                    or rate < min_observation_rate or rate > max_observation_rate)
+    def latent(rng, occ_linear):  # z ~ Bernoulli(psi) per period (occu.py:333-337)
+        return rng.binomial(n=1, p=expit(occ_linear)[:, None, :], size=(n_species, n_periods, n_sites))
 
-    while True:
-        beta = rng.normal(size=(n_species, n_site_covs + 1))
-        alpha = rng.normal(size=(n_species, n_obs_covs + 1))
-        site_covs = rng.normal(size=(n_sites, n_site_covs))
-        w, ell = np.zeros(n_sites), 0.0
-        if site_random_effects:
-            site_re_occ = rng.normal(0, site_re_sd, size=(n_species, n_sites))
-            site_re_det = rng.normal(0, site_re_sd, size=(n_species, n_sites))
-        else:
-            site_re_occ = np.zeros((n_species, n_sites))
-            site_re_det = np.zeros((n_species, n_sites))
-
-        occ_linear = beta[:, 0][:, None] + np.tensordot(beta[:, 1:], site_covs, axes=([1], [1])) + w[None, :] + site_re_occ
-        psi = _expit_ref(occ_linear)
-        z = rng.binomial(n=1, p=psi[:, None, :], size=(n_species, n_periods, n_sites))
-
-        obs_covs = rng.normal(size=(n_sites, n_periods, n_replicates, n_obs_covs))
-        if obs_random_effects:
-            obs_re = rng.normal(0, obs_re_sd, size=(n_species, n_sites, n_periods, n_replicates))
-        else:
-            obs_re = np.zeros((n_species, n_sites, n_periods, n_replicates))
-        det_linear = (alpha[:, 0][:, None, None, None] + np.tensordot(alpha[:, 1:], obs_covs, axes=([1], [3]))
-                      + site_re_det[:, :, None, None] + obs_re)
-        prob_detection = _expit_ref(det_linear)
-
-        z_site = z.transpose(0, 2, 1)[..., None]
-        prob_detection_fp = 1 - (1 - (z_site * prob_detection)) * (1 - prob_fp_constant) * (
+    def observe(rng, det_linear, z_site, _):  # occu.py:360-374
+        z_site = z_site[..., None]
+        prob_detection_fp = 1 - (1 - (z_site * expit(det_linear))) * (1 - prob_fp_constant) * (
             1 - ((1 - z_site) * prob_fp_unoccupied))
         obs = rng.binomial(n=1, p=prob_detection_fp, size=(n_species, n_sites, n_periods, n_replicates))
-        obs = (obs >= 1) * 1.0
+        return (obs >= 1) * 1.0
 
-        if simulate_missing:
-            obs[rng.choice([True, False], size=obs.shape, p=[0.2, 0.8])] = np.nan
-            obs_covs[rng.choice([True, False], size=obs_covs.shape, p=[0.05, 0.95])] = np.nan
-            site_covs[rng.choice([True, False], size=site_covs.shape, p=[0.05, 0.95])] = np.nan
-        if in_range(z, obs):
-            break
+    def accept(d):  # negation of the reference's while-condition (occu.py:290-296)
+        return (within(d.latent.mean(), min_occupancy, max_occupancy)
+                and within(observed_mean(d.obs), min_observation_rate, max_observation_rate))
+
+    n_replicates = round(deployment_days_per_site / session_duration)
+    d = Generator(n_species, n_sites, n_periods, n_replicates, n_site_covs, n_obs_covs, latent, observe, accept,
+                  site_re_sd=site_re_sd if site_random_effects else None,
+                  obs_re_sd=obs_re_sd if obs_random_effects else None,
+                  simulate_missing=simulate_missing).run(random_seed)
+    z, obs = d.latent, d.obs
 
     print(f"True occupancy: {np.mean(z):.4f}")
     print(f"Proportion of timesteps with observation: {np.mean(obs[np.isfinite(obs)]):.4f}")
 
-    true_params = dict(z=z, beta=beta, alpha=alpha, w=w, gp_sd=gp_sd, gp_l=gp_l)
+    true_params = dict(z=z, beta=d.beta, alpha=d.alpha, w=d.extra["w"], gp_sd=gp_sd, gp_l=gp_l)
     if site_random_effects:
-        true_params.update(site_re_occ=site_re_occ, site_re_det=site_re_det, site_re_sd=site_re_sd)
+        true_params.update(site_re_occ=d.extra["site_re_a"], site_re_det=d.extra["site_re_b"], site_re_sd=site_re_sd)
     if obs_random_effects:
-        true_params.update(obs_re=obs_re, obs_re_sd=obs_re_sd)
-    data = dict(site_covs=site_covs, obs_covs=obs_covs, obs=obs, coords=coords, ell=ell)
+        true_params.update(obs_re=d.extra["obs_re"], obs_re_sd=obs_re_sd)
+    data = dict(site_covs=d.site_covs, obs_covs=d.obs_covs, obs=obs, coords=None, ell=0.0)
     return data, true_params

@@ -14,6 +14,7 @@ import numpy as np
 
 from ..distributions import Exponential, HalfNormal, Normal, as_exponential, as_normal
 from ..regression import LinearRegression
+from ._generators import Generator, expit, observed_mean, within
 from .occu import OccuSpec
 
 MAX_COP_COVS = 4  # covariates per side the occu_cop kernels are instantiated for
@@ -142,35 +143,30 @@ def simulate_cop(
     """
     if spatial:
         raise NotImplementedError("simulate_cop(spatial=True): the spatial HSGP effect is not built")
-    rng = np.random.default_rng(random_seed)
-    coords = None
-    z = obs = None
-    while (z is None or z.mean() < min_occupancy or z.mean() > max_occupancy
-           or np.mean(obs[np.isfinite(obs)]) < min_observation_rate
-           or np.mean(obs[np.isfinite(obs)]) > max_observation_rate):
-        rate_fp = rng.uniform(0.05, 0.2)                                   # occu_cop.py:305
-        beta = rng.normal(size=(n_species, n_site_covs + 1))
-        alpha = rng.normal(size=(n_species, n_obs_covs + 1))
-        site_covs = rng.normal(size=(n_sites, n_site_covs))
-        w, ell = np.zeros(n_sites), 0.0
-        psi = 1 / (1 + np.exp(-(beta[:, 0][:, None] + np.tensordot(beta[:, 1:], site_covs, axes=([1], [1])) + w[None, :])))
-        z = rng.binomial(n=1, p=psi[:, None, :], size=(n_species, n_periods, n_sites))
-        n_replicates = round(deployment_days_per_site / session_duration)
-        obs_covs = rng.normal(size=(n_sites, n_periods, n_replicates, n_obs_covs))
-        detection_rate = np.exp(alpha[:, 0][:, None, None, None] + np.tensordot(alpha[:, 1:], obs_covs, axes=([1], [3])))
-        z_site = z.transpose(0, 2, 1)
-        obs = rng.poisson(lam=(session_duration * (detection_rate * z_site[..., None] + rate_fp * (1 - z_site[..., None]))),
-                          size=(n_species, n_sites, n_periods, n_replicates))
-        obs = obs.astype(float)
-        if simulate_missing:
-            obs[rng.choice([True, False], size=obs.shape, p=[0.2, 0.8])] = np.nan
-            obs_covs[rng.choice([True, False], size=obs_covs.shape, p=[0.05, 0.95])] = np.nan
-            site_covs[rng.choice([True, False], size=site_covs.shape, p=[0.05, 0.95])] = np.nan
 
+    def leading(rng):  # the false-positive rate is drawn first in every pass (occu_cop.py:305)
+        return dict(rate_fp=rng.uniform(0.05, 0.2))
+
+    def latent(rng, occ_linear):  # occu_cop.py:329-331
+        return rng.binomial(n=1, p=expit(occ_linear)[:, None, :], size=(n_species, n_periods, n_sites))
+
+    def observe(rng, det_linear, z_site, extra):  # occu_cop.py:343-357
+        z_site = z_site[..., None]
+        lam = session_duration * (np.exp(det_linear) * z_site + extra["rate_fp"] * (1 - z_site))
+        return rng.poisson(lam=lam, size=(n_species, n_sites, n_periods, n_replicates)).astype(float)
+
+    def accept(d):  # negation of the reference's while-condition (occu_cop.py:296-302)
+        return (within(d.latent.mean(), min_occupancy, max_occupancy)
+                and within(observed_mean(d.obs), min_observation_rate, max_observation_rate))
+
+    n_replicates = round(deployment_days_per_site / session_duration)
+    d = Generator(n_species, n_sites, n_periods, n_replicates, n_site_covs, n_obs_covs, latent, observe, accept,
+                  leading=leading, simulate_missing=simulate_missing).run(random_seed)
+    z, obs = d.latent, d.obs
     print(f"True occupancy: {np.mean(z):.4f}")
     print(f"Fraction of observations with at least one observation: {np.mean(obs[np.isfinite(obs)] >= 1):.4f}")
     print(f"Mean rate: {np.mean(obs[np.isfinite(obs)]):.4f}")
     session_duration_arr = np.full((n_sites, n_periods, n_replicates), session_duration)
-    return dict(site_covs=site_covs, obs_covs=obs_covs, session_duration=session_duration_arr, obs=obs,
-                false_positives_constant=True, coords=coords, ell=ell), \
-        dict(z=z, beta=beta, alpha=alpha, w=w, gp_sd=gp_sd, gp_l=gp_l)
+    return dict(site_covs=d.site_covs, obs_covs=d.obs_covs, session_duration=session_duration_arr, obs=obs,
+                false_positives_constant=True, coords=None, ell=0.0), \
+        dict(z=z, beta=d.beta, alpha=d.alpha, w=d.extra["w"], gp_sd=gp_sd, gp_l=gp_l)

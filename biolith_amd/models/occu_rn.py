@@ -14,6 +14,7 @@ import numpy as np
 
 from ..distributions import Beta, HalfNormal, Normal, as_normal
 from ..regression import LinearRegression
+from ._generators import Generator, expit, observed_mean, within
 from .occu import OccuSpec
 
 MAX_ABUNDANCE_LIMIT = 127  # the kernel's per-lane table over N (BL_RN_NB - 1)
@@ -119,33 +120,25 @@ def simulate_rn(
     """
     if spatial:
         raise NotImplementedError("simulate_rn(spatial=True) is outside the built path (utils/spatial.py:52-76)")
-    rng = np.random.default_rng(random_seed)
-    coords = None
-    n_replicates = round(deployment_days_per_site / session_duration)
-    while True:
-        beta = rng.normal(size=(n_species, n_site_covs + 1))
-        alpha = rng.normal(size=(n_species, n_obs_covs + 1))
-        site_covs = rng.normal(size=(n_sites, n_site_covs))
-        w, ell = np.zeros(n_sites), 0.0
-        abundance = np.exp(beta[:, 0][:, None] + np.tensordot(beta[:, 1:], site_covs, axes=([1], [1])) + w[None, :])
-        N_i = rng.poisson(abundance[:, None, :], size=(n_species, n_periods, n_sites))
-        obs_covs = rng.normal(size=(n_sites, n_periods, n_replicates, n_obs_covs))
-        r_it = 1 / (1 + np.exp(-(alpha[:, 0][:, None, None, None] + np.tensordot(alpha[:, 1:], obs_covs, axes=([1], [3])))))
-        N_i_site = N_i.transpose(0, 2, 1)
-        p_it = 1.0 - (1.0 - r_it) ** N_i_site[..., None]
+
+    def latent(rng, abu_linear):  # N ~ Poisson(abundance) per period (occu_rn.py:296-303)
+        return rng.poisson(np.exp(abu_linear)[:, None, :], size=(n_species, n_periods, n_sites))
+
+    def observe(rng, det_linear, N_site, _):  # occu_rn.py:310-330
+        p_it = 1.0 - (1.0 - expit(det_linear)) ** N_site[..., None]
         obs = rng.binomial(n=1, p=1 - (1 - p_it) * (1 - prob_fp), size=(n_species, n_sites, n_periods, n_replicates))
-        obs = (obs >= 1) * 1.0
-        if simulate_missing:
-            obs[rng.choice([True, False], size=obs.shape, p=[0.2, 0.8])] = np.nan
-            obs_covs[rng.choice([True, False], size=obs_covs.shape, p=[0.05, 0.95])] = np.nan
-            site_covs[rng.choice([True, False], size=site_covs.shape, p=[0.05, 0.95])] = np.nan
-        occ = (N_i > 0).mean()
-        rate = np.mean(obs[np.isfinite(obs)])
-        # negation of the reference's while-condition (occu_rn.py:272-278)
-        if not (occ < min_occupancy or occ > max_occupancy or rate < min_observation_rate or rate > max_observation_rate):
-            break
-    print(f"True occupancy: {np.mean(N_i > 0):.4f}")
+        return (obs >= 1) * 1.0
+
+    def accept(d):  # negation of the reference's while-condition (occu_rn.py:272-278)
+        return (within((d.latent > 0).mean(), min_occupancy, max_occupancy)
+                and within(observed_mean(d.obs), min_observation_rate, max_observation_rate))
+
+    n_replicates = round(deployment_days_per_site / session_duration)
+    d = Generator(n_species, n_sites, n_periods, n_replicates, n_site_covs, n_obs_covs, latent, observe, accept,
+                  simulate_missing=simulate_missing).run(random_seed)
+    abundance = np.exp(d.site_linear)
+    print(f"True occupancy: {np.mean(d.latent > 0):.4f}")
     print(f"True abundance: {np.mean(abundance):.4f}")
-    print(f"Proportion of timesteps with observation: {np.mean(obs[np.isfinite(obs)]):.4f}")
-    data = dict(site_covs=site_covs, obs_covs=obs_covs, obs=obs, coords=coords, ell=ell)
-    return data, dict(abundance=abundance, beta=beta, alpha=alpha, w=w, gp_sd=gp_sd, gp_l=gp_l)
+    print(f"Proportion of timesteps with observation: {np.mean(d.obs[np.isfinite(d.obs)]):.4f}")
+    data = dict(site_covs=d.site_covs, obs_covs=d.obs_covs, obs=d.obs, coords=None, ell=0.0)
+    return data, dict(abundance=abundance, beta=d.beta, alpha=d.alpha, w=d.extra["w"], gp_sd=gp_sd, gp_l=gp_l)
