@@ -17,6 +17,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The engine library is a build product (git-ignored): build it once if a fresh checkout lacks it, so that the
+    ABI tests test the library rather than its absence.  hipcc cross-compiles gfx950 without a GPU (about two minutes)."""
+    lib = os.path.join(ROOT, "biolith_amd", "lib", "libbiolith_hip.so")
+    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import subprocess
+
+        subprocess.run(["make", "-C", os.path.join(ROOT, "biolith_amd", "csrc"), "-j8"], check=False,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1800)
+
+
 @pytest.fixture(scope="session")
 def golden_index():
     with open(os.path.join(GOLDEN, "simulate_index.json")) as f:
