@@ -161,7 +161,11 @@ typedef struct bl_nuts_output {
 /* Blocking convenience: launch + wait + fetch. */
 int bl_nuts_run(bl_dataset *ds, const bl_nuts_config *cfg, bl_nuts_output *out);
 
-/* Asynchronous form (timeouts, overlap, timing).  `stream` is a hipStream_t or NULL. */
+/* Asynchronous form (timeouts, overlap, timing).  `stream` is a hipStream_t or NULL.
+ * The kernel is persistent and its workgroups exchange data while they run, so all of them must be resident
+ * at once: launches on ONE device belong on one stream (they then run back to back), launches on different
+ * devices overlap freely.  If the device is shared and a workgroup cannot become resident, the bounded spins
+ * expire and bl_nuts_wait returns BL_ERR_TIMEOUT instead of hanging. */
 int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *stream);
 int bl_nuts_poll(bl_dataset *ds, int *done);
 int bl_nuts_abort(bl_dataset *ds); /* fit(timeout=...) (fit.py:124-128): kernel exits at its next leapfrog */
