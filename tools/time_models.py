@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Per-leapfrog time of the secondary models on comparable synthetic sizes (4 chains x (300 + 300))."""
+import contextlib, io, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from biolith_amd.engine import OccuDataset
+from biolith_amd.models import simulate, simulate_cop, simulate_nmixture, simulate_rn
+
+def run(name, ds):
+    r = ds.nuts(num_warmup=300, num_samples=300, num_chains=4, seed=0)
+    r = ds.nuts(num_warmup=300, num_samples=300, num_chains=4, seed=1)
+    n = r.n_leapfrog.sum() / 4
+    print(f"{name:34s} kernel {r.kernel_ms:8.2f} ms  {1e3 * r.kernel_ms / n:7.2f} us/leapfrog/chain  k={r.wgs_per_chain} D={ds.D}")
+
+with contextlib.redirect_stdout(io.StringIO()):
+    kw = dict(n_sites=5000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7)
+    d0, _ = simulate(**kw)
+    dfp, _ = simulate(**kw, prob_fp_constant=0.1)
+    drn, _ = simulate_rn(**kw)
+    dcop, _ = simulate_cop(**kw)
+    dnm, _ = simulate_nmixture(**kw, min_abundance=0.5, max_abundance=8.0, max_observation_rate=6.0)
+run("occu 5000x10", OccuDataset(d0["site_covs"], d0["obs_covs"], d0["obs"]))
+run("occu_fp constant 5000x10", OccuDataset(dfp["site_covs"], dfp["obs_covs"], dfp["obs"], model="occu_fp", fp_mode="constant"))
+run("occu_cop (fp constant) 5000x10", OccuDataset(dcop["site_covs"], dcop["obs_covs"], dcop["obs"], model="occu_cop", fp_mode="constant",
+                                                   session_duration=dcop["session_duration"]))
+K = int(np.nanmax(dnm["obs"])) + 10
+run(f"nmixture K={K} 5000x10", OccuDataset(dnm["site_covs"], dnm["obs_covs"], dnm["obs"], model="nmixture", max_abundance=K))
+run("nmixture K=100 5000x10", OccuDataset(dnm["site_covs"], dnm["obs_covs"], dnm["obs"], model="nmixture", max_abundance=100))
+run("occu_rn K=100 5000x10", OccuDataset(drn["site_covs"], drn["obs_covs"], drn["obs"], model="occu_rn"))
