@@ -175,6 +175,9 @@ struct bl_dataset {
     // raw nan_to_num'd obs covariates, site-fastest [V][Ko][n_stride], for prob_detection (lazy upload)
     std::vector<float> h_wraw;
     float *d_wraw = nullptr;
+    // occu_cop: raw session durations, site-fastest [V][n_stride], for the predictive counts (lazy upload)
+    std::vector<float> h_dur;
+    float *d_dur = nullptr;
     // ---- last NUTS launch ----
     bool in_flight = false, have_run = false;
     int C = 0, S = 0, W = 0, k = 0, nloc = 0, lds_ld = 0, lds_bytes = 0, staged = 0, nvp = 0, ncw = 0;
@@ -297,7 +300,7 @@ extern "C" int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint6
 {
     if (!ds || !draws || n_draws <= 0 || (!latent && !y)) return bl_fail(BL_ERR_INVALID, "bl_predict: bad argument");
     if (ds->model == 3 || ds->model == 4)
-        return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: not built for the count models (occu_cop, nmixture)");
+        return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: the count models (occu_cop, nmixture) use bl_predict_counts");
     if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
     int rc = set_device(ds);
     if (rc) return rc;
@@ -326,6 +329,131 @@ extern "C" int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint6
         BL_HIP(hipGetLastError());
         if (latent) BL_HIP(hipMemcpy(latent + (size_t)n0 * T * N, d_lat, (size_t)(n1 - n0) * T * N, hipMemcpyDeviceToHost));
         if (y) BL_HIP(hipMemcpy(y + (size_t)n0 * J * T * N, d_y, (size_t)(n1 - n0) * J * T * N, hipMemcpyDeviceToHost));
+    }
+    return BL_OK;
+}
+
+// ---- predictive counts of the count models (occu_cop, nmixture) ----
+// Poisson(lam): inversion by sequential search for lam < 10, else Hoermann's PTRS transformed rejection
+// ("The transformed rejection method for generating Poisson random variables", 1993); both exact.
+__device__ inline int bl_poisson(BlPredRng &rng, double lam)
+{
+    if (!(lam > 0.0)) return 0;
+    if (lam < 10.0) {
+        const double enlam = exp(-lam);
+        int k = 0;
+        double prod = (double)rng.uniform();
+        while (prod > enlam && k < 1000) { prod *= (double)rng.uniform(); k++; }
+        return k;
+    }
+    const double slam = sqrt(lam), loglam = log(lam);
+    const double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
+    const double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2.0);
+    for (int it = 0; it < 1000; it++) {
+        const double U = (double)rng.uniform() - 0.5, V = (double)rng.uniform();
+        const double us = 0.5 - fabs(U);
+        const double kf = floor((2.0 * a / us + b) * U + lam + 0.43);
+        if (us >= 0.07 && V <= vr) return (int)kf;
+        if (kf < 0.0 || (us < 0.013 && V > us)) continue;
+        if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + kf * loglam - lgamma(kf + 1.0)) return (int)kf;
+    }
+    return (int)lam;
+}
+// occu_cop (occu_cop.py:222-255, obs withheld):  z ~ Bernoulli(psi),  y_j ~ Poisson(dur_j (z lambda_j + (1 - z) f_u + f_c))
+// nmixture (nmixture.py:183-220, obs withheld):  N ~ Poisson(lambda) restricted to 0..K,  y_j ~ Binomial(N, p_j)
+__global__ void bl_predict_counts_kernel(const float *__restrict__ rows, const float *__restrict__ wraw, const float *__restrict__ dur,
+                                         int n_stride, int N, int T, int J, int Ks, int Ko, int D,
+                                         const float *__restrict__ draws, int n0, int n1, unsigned long long seed, int model,
+                                         int max_abundance, int fp_mode, int *__restrict__ latent, int *__restrict__ y)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float x[BL_MAX_COVS];
+    for (int k = 0; k < Ks; k++) x[k] = rows[(size_t)k * n_stride + i];
+    for (int n = n0 + blockIdx.y; n < n1; n += gridDim.y) {
+        const float *th = draws + (size_t)n * D;
+        const float *al = th + Ks + 1;
+        float eta = th[0];
+        for (int k = 0; k < Ks; k++) eta = fmaf(x[k], th[k + 1], eta);
+        const float f = (model == 3 && fp_mode) ? __expf(th[D - 1]) : 0.0f;
+        const float f_c = fp_mode == BL_FP_CONSTANT ? f : 0.0f, f_u = fp_mode == BL_FP_UNOCCUPIED ? f : 0.0f;
+        for (int t = 0; t < T; t++) {
+            BlPredRng rng(seed, ((unsigned long long)n * T + t) * N + i);
+            int zn;
+            if (model == 4) { // inversion over the renormalised truncated Poisson pmf (float64 recursion)
+                const double lam = exp((double)eta);
+                double p = exp(-lam), tot = 0.0;
+                for (int m = 0; m <= max_abundance; m++) { tot += p; p *= lam / (double)(m + 1); }
+                const double target = (double)rng.uniform() * tot;
+                p = exp(-lam);
+                double cum = 0.0;
+                zn = max_abundance;
+                for (int m = 0; m <= max_abundance; m++) {
+                    cum += p;
+                    if (target < cum) { zn = m; break; }
+                    p *= lam / (double)(m + 1);
+                }
+            } else {
+                zn = rng.uniform() < 1.0f / (1.0f + __expf(-eta)) ? 1 : 0;
+            }
+            if (latent) latent[((size_t)(n - n0) * T + t) * N + i] = zn;
+            if (!y) continue;
+            for (int j = 0; j < J; j++) {
+                const int v = t * J + j;
+                float nu = al[0];
+                for (int k = 0; k < Ko; k++) nu = fmaf(wraw[((size_t)v * Ko + k) * n_stride + i], al[k + 1], nu);
+                int cnt = 0;
+                if (model == 4) {
+                    const float p = 1.0f / (1.0f + __expf(-nu));
+                    for (int m = 0; m < zn; m++) cnt += rng.uniform() < p ? 1 : 0; // Binomial(N, p), N <= 127
+                } else {
+                    const double rate = (double)dur[(size_t)v * n_stride + i] * ((zn ? (double)__expf(nu) : (double)f_u) + (double)f_c);
+                    cnt = bl_poisson(rng, rate);
+                }
+                y[(((size_t)(n - n0) * J + j) * T + t) * N + i] = cnt;
+            }
+        }
+    }
+}
+
+extern "C" int bl_predict_counts(bl_dataset *ds, int n_draws, const float *draws, uint64_t seed, int32_t *latent, int32_t *y)
+{
+    if (!ds || !draws || n_draws <= 0 || (!latent && !y)) return bl_fail(BL_ERR_INVALID, "bl_predict_counts: bad argument");
+    if (ds->model != 3 && ds->model != 4)
+        return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict_counts: for the count models (occu_cop, nmixture); use bl_predict");
+    if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
+    int rc = set_device(ds);
+    if (rc) return rc;
+    const int N = ds->dims.n_sites, T = ds->dims.n_periods, J = ds->dims.n_replicates, D = ds->D;
+    float *d_draws = nullptr;
+    int *d_lat = nullptr, *d_y = nullptr;
+    DevScratch scratch;
+    BL_HIP(scratch.alloc((void **)&d_draws, (size_t)n_draws * D * 4));
+    BL_HIP(hipMemcpy(d_draws, draws, (size_t)n_draws * D * 4, hipMemcpyHostToDevice));
+    const size_t per_draw = (size_t)T * N * 4 * (y ? (size_t)J : 1);
+    int chunk = (int)((256u << 20) / (per_draw ? per_draw : 1));
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_draws) chunk = n_draws;
+    if (latent) BL_HIP(scratch.alloc((void **)&d_lat, (size_t)chunk * T * N * 4));
+    if (y) BL_HIP(scratch.alloc((void **)&d_y, (size_t)chunk * J * T * N * 4));
+    if (!ds->d_wraw) {
+        BL_HIP(hipMalloc((void **)&ds->d_wraw, ds->h_wraw.size() * 4));
+        BL_HIP(hipMemcpy(ds->d_wraw, ds->h_wraw.data(), ds->h_wraw.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (ds->model == 3 && !ds->d_dur) {
+        BL_HIP(hipMalloc((void **)&ds->d_dur, ds->h_dur.size() * 4));
+        BL_HIP(hipMemcpy(ds->d_dur, ds->h_dur.data(), ds->h_dur.size() * 4, hipMemcpyHostToDevice));
+    }
+    const dim3 block(256);
+    for (int n0 = 0; n0 < n_draws; n0 += chunk) {
+        const int n1 = (n0 + chunk < n_draws) ? n0 + chunk : n_draws;
+        const dim3 grid((N + 255) / 256, (n1 - n0) < 1024 ? (n1 - n0) : 1024);
+        hipLaunchKernelGGL(bl_predict_counts_kernel, grid, block, 0, nullptr, ds->d_rows, ds->d_wraw, ds->d_dur, ds->n_stride, N, T, J,
+                           ds->Ks, ds->Ko, D, d_draws, n0, n1, (unsigned long long)seed, ds->model, ds->max_abundance, ds->fp_mode,
+                           d_lat, d_y);
+        BL_HIP(hipGetLastError());
+        if (latent) BL_HIP(hipMemcpy(latent + (size_t)n0 * T * N, d_lat, (size_t)(n1 - n0) * T * N * 4, hipMemcpyDeviceToHost));
+        if (y) BL_HIP(hipMemcpy(y + (size_t)n0 * J * T * N, d_y, (size_t)(n1 - n0) * J * T * N * 4, hipMemcpyDeviceToHost));
     }
     return BL_OK;
 }
@@ -462,6 +590,7 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
     // ---- pack: mask (occu.py:136-142, modeling.py:15-17), NaN->0, sign folding, site-fastest rows ----
     std::vector<float> rows((size_t)n_rows * n_stride, 0.0f);
     ds->h_wraw.assign((size_t)V * (Ko > 0 ? Ko : 1) * n_stride, 0.0f);
+    if (model == 3) ds->h_dur.assign((size_t)V * n_stride, 0.0f);
     const double LN2 = 0.69314718055994530942, LOG_TINY = -87.33654475055310898657;
     const int row_wc = KS, row_ka = KS + V * vw, row_kb = row_ka + T;
     double cop_const = 0.0; // occu_cop: sum over unmasked visits of y log(dur) - lgamma(y + 1)
@@ -524,6 +653,7 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
                     rows[(r0 + 2 + k) * n_stride + i] = x;
                 }
                 const float y = obs[o], dur = mo.session_duration[o];
+                ds->h_dur[(size_t)v * n_stride + i] = dur;
                 if (cov_nan || !std::isfinite(y)) {
                     for (int k = 0; k < Ko; k++) rows[(r0 + 2 + k) * n_stride + i] = 0.0f;
                     continue;
@@ -601,6 +731,7 @@ extern "C" int bl_dataset_destroy(bl_dataset *ds)
     if (ds->d_rows) hipFree(ds->d_rows);
     if (ds->d_wraw) hipFree(ds->d_wraw);
     if (ds->d_tab) hipFree(ds->d_tab);
+    if (ds->d_dur) hipFree(ds->d_dur);
     if (ds->d_run) hipFree(ds->d_run);
     if (ds->d_xchg) hipFree(ds->d_xchg);
     if (ds->h_abort) hipHostFree(ds->h_abort);

@@ -244,15 +244,19 @@ class OccuDataset:
 
     def predictive(self, draws, seed: int = 0, latent: bool = True, y: bool = True):
         """Posterior predictive draws of the discrete sites for draws (n, D): the latent state
-        (``z`` for occu, ``N_i`` for occu_rn) as (n, T, N) uint8 and ``y`` as (n, J, T, N) uint8
+        (``z`` for occu / occu_cop, ``N_i`` for occu_rn / nmixture) as (n, T, N) and ``y`` as (n, J, T, N); uint8, or
+        int32 for the count models
         (biolith/utils/predict.py:66-92; occu.py:208-241; occu_rn.py:194-221)."""
         d = np.ascontiguousarray(draws, dtype=np.float32).reshape(-1, self.D)
         n = d.shape[0]
-        out_l = np.empty((n, self.T, self.N), dtype=np.uint8) if latent else None
-        out_y = np.empty((n, self.J, self.T, self.N), dtype=np.uint8) if y else None
+        counts = self.model in ("occu_cop", "nmixture")  # their sampled sites are counts: int32 (bl_predict_counts)
+        dt, ct = (np.int32, C.c_int32) if counts else (np.uint8, C.c_uint8)
+        out_l = np.empty((n, self.T, self.N), dtype=dt) if latent else None
+        out_y = np.empty((n, self.J, self.T, self.N), dtype=dt) if y else None
         if n:
-            u8 = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint8))
-            _ffi.check(self._lib.bl_predict(self._h, n, _fp(d), C.c_uint64(int(seed) & (2 ** 64 - 1)), u8(out_l), u8(out_y)))
+            ptr = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(ct))
+            fn = self._lib.bl_predict_counts if counts else self._lib.bl_predict
+            _ffi.check(fn(self._h, n, _fp(d), C.c_uint64(int(seed) & (2 ** 64 - 1)), ptr(out_l), ptr(out_y)))
         return out_l, out_y
 
 

@@ -43,7 +43,8 @@ def predict(
     dict
         occu: ``psi`` (n, T, N, S), ``z`` (n, T, N, S) int32, ``prob_detection`` / ``prob_detection_fp``
         (n, J, T, N, S), ``y`` (n, J, T, N, S) int32 -- the sites of occu.py:207-241.
-        occu_rn: ``abundance``, ``N_i``, ``prob_detection``, ``y`` (occu_rn.py:192-221).
+        occu_rn / nmixture: ``abundance``, ``N_i``, ``prob_detection``, ``y`` (occu_rn.py:192-221, nmixture.py:181-220).
+        occu_cop: ``psi``, ``z``, ``rate_detection``, ``y`` (counts; occu_cop.py:222-255).
         The three replicate-level arrays are materialised on first access.
 
     Examples
@@ -77,8 +78,6 @@ def predict(
     valid = {k: v for k, v in arguments.items() if v is not None}
     blank = np.full((n_species,) + np.shape(obs_covs)[:3], np.nan, dtype=np.float32)
     spec = model_fn(**valid, obs=blank, **kwargs)
-    if spec.model in ("occu_cop", "nmixture"):
-        raise NotImplementedError(f"predict(): not built for {spec.model}")
     if beta.shape[2] != spec.site_covs.shape[1] + 1 or alpha.shape[2] != spec.obs_covs.shape[3] + 1:
         raise ValueError("predict(): covariate counts differ from the fitted model's coefficients")
 
@@ -89,6 +88,10 @@ def predict(
     if fp_site is not None:
         rate = np.clip(np.asarray(posterior[fp_site], dtype=np.float64).reshape(n), 1e-300, 1 - 1e-16)
         phi = np.log(rate / (1.0 - rate)).astype(np.float32)[:, None]   # the engine's coordinate: logit(rate)
+    if spec.model == "occu_cop" and spec.extras["fp_mode"] is not None:
+        fp_site = f"rate_fp_{spec.extras['fp_mode']}"
+        rate = np.maximum(np.asarray(posterior[fp_site], dtype=np.float64).reshape(n), 1e-300)
+        phi = np.log(rate).astype(np.float32)[:, None]                  # the engine's coordinate: log(rate)
 
     def run():
         handles, first, latent, y8 = [], [], [], []
@@ -111,7 +114,7 @@ def predict(
     else:
         handles, first, latent, y8 = run()
 
-    rn = spec.model == "occu_rn"
+    rn = spec.model in ("occu_rn", "nmixture")   # the abundance models: sites "abundance" and "N_i"
     out = LazySamples()
     out["abundance" if rn else "psi"] = np.stack(first, axis=-1)                      # (n, T, N, S)
     out["N_i" if rn else "z"] = np.stack(latent, axis=-1).astype(np.int32)            # (n, T, N, S)
@@ -119,8 +122,9 @@ def predict(
     def prob_detection():
         return np.stack([d.deterministic(dr, psi=False, prob_detection=True)[1] for d, dr in handles], axis=-1)
 
-    out.set_lazy("prob_detection", prob_detection)                                    # (n, J, T, N, S)
-    if not rn:
+    # occu_cop's replicate-level deterministic site is the detection rate (occu_cop.py:236-243)
+    out.set_lazy("rate_detection" if spec.model == "occu_cop" else "prob_detection", prob_detection)   # (n, J, T, N, S)
+    if spec.model in ("occu", "occu_fp"):
         def prob_detection_fp():  # occu.py:229-235
             z = np.stack(latent, axis=-1)[:, None].astype(np.float32)
             zp = prob_detection() * z

@@ -104,7 +104,7 @@ int bl_dataset_create_fp(const bl_dims *dims, const float *site_covs, const floa
  * false-positive rate; BL_FP_CONSTANT / BL_FP_UNOCCUPIED: sites "rate_fp_constant" / "rate_fp_unoccupied"
  * with an Exponential(prior_fp_rate) prior (occu_cop.py:31-32, 158-170) sampled as a trailing coordinate
  * phi = log(rate).  bl_deterministic's second output becomes `rate_detection` = exp(alpha0 + w alpha)
- * (occu_cop.py:236-243).  Built for at most 4 covariates per side; bl_predict is not built for it.
+ * (occu_cop.py:236-243).  Built for at most 4 covariates per side; predictive draws: bl_predict_counts.
  */
 int bl_dataset_create_cop(const bl_dims *dims, const float *site_covs, const float *obs_covs,
                           const float *obs, const float *session_duration, int fp_mode,
@@ -115,7 +115,7 @@ int bl_dataset_create_cop(const bl_dims *dims, const float *site_covs, const flo
  * N ~ Poisson(exp(beta0 + x beta)) enumerated over 0..max_abundance (raw, un-renormalised weights: the model's
  * "N_i_trunc_norm" factor, nmixture.py:183-196; support cut below the largest count of each (site, period),
  * nmixture.py:150-155), y ~ Binomial(N, sigmoid(alpha0 + w alpha)).  bl_deterministic's outputs are `abundance`
- * and `prob_detection`.  Built for max_abundance <= 127 and at most 4 covariates per side; bl_predict is not built for it.
+ * and `prob_detection`.  Built for max_abundance <= 127 and at most 4 covariates per side; predictive draws: bl_predict_counts.
  */
 int bl_dataset_create_nmix(const bl_dims *dims, const float *site_covs, const float *obs_covs,
                            const float *obs, int max_abundance, const bl_normal_prior *prior_beta,
@@ -205,6 +205,15 @@ int bl_deterministic(bl_dataset *ds, int n_draws, const float *draws, float *psi
  * distributionally, not bitwise, the reference's (JAX threefry keys are not reproduced).
  */
 int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint64_t seed, uint8_t *latent, uint8_t *y);
+
+/*
+ * The same for the count models, whose sampled sites do not fit a byte (predict.py:66-92):
+ *   occu_cop  latent = z,  y ~ Poisson(session_duration * (z rate_detection + (1 - z) f_u + f_c))   (occu_cop.py:222-255)
+ *   nmixture  latent = N_i ~ Poisson(abundance) restricted to 0..max_abundance,  y ~ Binomial(N_i, prob_detection)
+ *             (nmixture.py:183-220; with obs withheld there is no largest-count cut-off)
+ * int32 on the host, shapes as in bl_predict.  Poisson draws by inversion (rate < 10) or Hoermann's PTRS.
+ */
+int bl_predict_counts(bl_dataset *ds, int n_draws, const float *draws, uint64_t seed, int32_t *latent, int32_t *y);
 
 /* The engine's xoshiro128++ streams (host-side; no GPU needed): out[nstreams][4]. */
 int bl_rng_streams(uint64_t seed, int chain, int nstreams, uint32_t *out);

@@ -94,8 +94,10 @@ def test_occu_cop_like_reference():  # occu_cop.py:399-424 (simulate_cop passes 
     assert results.samples["rate_detection"].shape == (5000, 52, 1, 100, 1)
     d = diagnostics(results.mcmc)
     assert set(d) >= {"n_eff_mean", "r_hat_max"} or isinstance(d, dict)
-    with pytest.raises(NotImplementedError):
-        predict(occu_cop, results.mcmc, **data)
+    preds = predict(occu_cop, results.mcmc, **data, num_samples=None)
+    assert set(preds) == {"psi", "z", "rate_detection", "y"}
+    assert preds["y"].shape == (5000, 52, 1, 100, 1) and preds["y"].dtype == np.int32 and preds["z"].shape == (5000, 1, 100, 1)
+    np.testing.assert_array_equal(preds["psi"], results.samples["psi"])
 
 
 def test_occu_cop_without_false_positives_and_deterministic_sites():
@@ -107,3 +109,32 @@ def test_occu_cop_without_false_positives_and_deterministic_sites():
     W = np.nan_to_num(np.asarray(data["obs_covs"], np.float32))
     nu = post["alpha"][:, 0, 0][:, None, None] + np.einsum("ijk,nk->nji", W[:, 0], post["alpha"][:, 0, 1:])
     np.testing.assert_allclose(res.samples["rate_detection"][:, :, 0, :, 0], np.exp(nu), rtol=2e-5)
+
+
+def test_predictive_counts_follow_the_poisson_rates():
+    # hand-made "posterior" with identical draws: the predictive sample over draws is i.i.d. from the model
+    # (occu_cop.py:222-255); covers both Poisson samplers (rate < 10: inversion, else PTRS)
+    N, J, n = 40, 3, 3000
+    X = np.linspace(-1.0, 1.0, N, dtype=np.float32)[:, None]
+    W = np.zeros((N, 1, J, 1), np.float32); W[:, 0, :, 0] = np.array([-1.0, 0.0, 1.5])
+    Dur = np.tile(np.array([1.0, 4.0, 9.0], np.float32), (N, 1))[:, None, :]
+    obs = np.full((1, N, 1, J), np.nan, np.float32)
+    ds = OccuDataset(X, W, obs, model="occu_cop", fp_mode="constant", session_duration=Dur)
+    beta, alpha, f = np.array([0.3, 1.0]), np.array([0.4, 0.9]), 0.25
+    draws = np.tile(np.concatenate([beta, alpha, [np.log(f)]]).astype(np.float32), (n, 1))
+    z, y = ds.predictive(draws, seed=5)
+    assert z.dtype == np.int32 and y.dtype == np.int32 and z.shape == (n, 1, N) and y.shape == (n, J, 1, N)
+    psi = 1 / (1 + np.exp(-(beta[0] + beta[1] * X[:, 0].astype(np.float64))))
+    assert np.abs(z[:, 0].mean(0) - psi).max() < 5 * np.sqrt(0.25 / n)
+    lam = np.exp(alpha[0] + alpha[1] * W[0, 0, :, 0].astype(np.float64))                       # (J,)
+    rate = Dur[0, 0].astype(np.float64)[None, :, None] * (z[:, 0][:, None, :] * lam[None, :, None] + f)   # (n, J, N)
+    yy = y[:, :, 0].astype(np.float64)
+    assert abs(yy.sum() - rate.sum()) < 5 * np.sqrt(rate.sum())
+    for j in range(J):                                                                         # mean and variance per visit type
+        occ = z[:, 0] == 1
+        r1 = Dur[0, 0, j] * (lam[j] + f)
+        sample = yy[:, j][occ]
+        assert abs(sample.mean() - r1) < 5 * np.sqrt(r1 / sample.size)
+        assert abs(sample.var() / r1 - 1) < 0.1
+        r0 = Dur[0, 0, j] * f
+        assert abs(yy[:, j][~occ].mean() - r0) < 5 * np.sqrt(r0 / (~occ).sum())

@@ -7,7 +7,7 @@ import oracle
 from biolith_amd.engine import OccuDataset
 from biolith_amd.evaluation import effective_sample_size, split_gelman_rubin
 from biolith_amd.models import nmixture, simulate_nmixture
-from biolith_amd.utils import fit
+from biolith_amd.utils import fit, predict
 from conftest import load_golden
 
 pytestmark = pytest.mark.gpu
@@ -102,3 +102,27 @@ def test_nmixture_multi_season():  # nmixture.py:423-449
     max_abundance = int(np.nanmax(data["obs"]))
     results = fit(nmixture, **data, max_abundance=max_abundance, num_chains=1, num_samples=300, num_warmup=300, timeout=600)
     _assert_recovery(results, true_params)
+
+
+def test_predict_nmixture_sites_and_distributions():
+    data, _ = simulate_nmixture(**REF_TEST)
+    K = int(np.nanmax(data["obs"])) + 5
+    res = fit(nmixture, **data, max_abundance=K, num_chains=1, num_samples=200, num_warmup=200)
+    preds = predict(nmixture, res.mcmc, **data, max_abundance=K, num_samples=None)
+    assert set(preds) == {"abundance", "N_i", "prob_detection", "y"}
+    assert preds["N_i"].shape == (200, 1, 100, 1) and preds["y"].shape == (200, 10, 1, 100, 1) and preds["y"].dtype == np.int32
+    np.testing.assert_array_equal(preds["abundance"], res.samples["abundance"])
+    Ni, y, p = preds["N_i"], preds["y"], preds["prob_detection"]
+    assert Ni.max() <= K and (y <= Ni[:, None]).all() and (y >= 0).all()
+    want = p * Ni[:, None]                                       # E[y | N, p]
+    var = (p * (1 - p) * Ni[:, None]).sum()
+    assert abs(y.sum() - want.sum()) < 5 * np.sqrt(var)
+    # hand-made identical draws: N over draws is an i.i.d. truncated-Poisson sample
+    n = 4000
+    ds = OccuDataset(data["site_covs"][:8], data["obs_covs"][:8], np.full((1, 8, 1, 10), np.nan), model="nmixture", max_abundance=6)
+    draws = np.tile(np.array([1.0, 0.0, 0.0, 0.0], np.float32), (n, 1))
+    N6, _ = ds.predictive(draws, seed=2)
+    from scipy.stats import poisson
+    pmf = poisson.pmf(np.arange(7), np.e); pmf /= pmf.sum()
+    cnt = np.bincount(N6[:, 0, 0], minlength=7) / n
+    assert np.abs(cnt - pmf).max() < 5 * np.sqrt(0.25 / n)
