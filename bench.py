@@ -213,6 +213,11 @@ def main():
                 "note": "data is LDS-resident after one HBM read, so this is an effective (algorithmic) bandwidth; "
                         "the sequential-leapfrog latency is the real bound",
             },
+            "sampler": {  # rank 0's chains, last timed step (SURVEY.md section 8d "also report")
+                "mean_num_steps": float(steps[-1][0].num_steps.mean()), "divergences": int(steps[-1][0].diverging.sum()),
+                "step_size": [float(x) for x in steps[-1][0].step_size], "mean_accept_prob": float(steps[-1][0].accept_prob.mean()),
+                "leapfrogs_per_s_per_chain": 1e3 * (leap_mean / CHAINS_PER_GPU) / kernel_ms_mean,
+            },
             "ess": {f"{wl['site']}_mean_over_sites_per_step": ess_psi, "min_coef_per_step": [float(x) for x in ess_coef],
                     "max_split_rhat": max(rhat), "draws_per_step": CHAINS_PER_GPU * world * NUM_SAMPLES},
         }
