@@ -773,7 +773,8 @@ __device__ constexpr float BL_LGAMMA1P[BL_RN_NB] = {0.000000000e+00f, 0.00000000
 //   B_n = sum_j m log C(n, y_j)   (data only: tabulated by the host, -inf below the largest count)
 //   d l / d eta = E[n] - lambda ,   d l / d nu_j = m (y_j - E[n] p_j) ,   E[n] = posterior mean of N
 // Records as for occu_cop: visit = (m y, m, w_1..w_KO) (layout KO + 1); B lives in HBM/L2 as
-// tab[t][n][site] (site fastest: lanes read consecutive floats).  Two passes over n (max, then sums).
+// tab[t][n][site] (site fastest: lanes read consecutive floats).  Two passes over n (max, then sums); the second
+// stops at the last term that can matter.
 template <int KS, int KO, int CT>
 __device__ __forceinline__ void bl_eval_sites_nmix(int ct, int pstride, int cnt, int T, int J, int K,
                                                    const float *__restrict__ tab, int tab_ld,
@@ -839,15 +840,35 @@ __device__ __forceinline__ void bl_eval_sites_nmix(int ct, int pstride, int cnt,
             // logsumexp over n of  n (eta + c) - lgamma(n+1) + B_n
             const bl_f2 slope = eta + c;
             const float *b0 = t0 + (size_t)t * (K + 1) * tab_ld, *b1 = t1 + (size_t)t * (K + 1) * tab_ld;
+            // pass 1: the maximum, and the last n whose term is within 25 nats of the running maximum -- a superset of
+            // the terms within 25 nats of the final one, so pass 2 may stop there (what it skips is < e^-25 of the sum).
+            // The terms are concave in n above the largest count (n slope, -lgamma(n+1) and every log C(n, y) are), so
+            // once one falls 25 nats below the running maximum all later ones do: pass 1 stops there too.
             bl_f2 mx = bl2(-INFINITY);
-#pragma unroll 4
-            for (int n = 0; n <= K; n++) {
-                const bl_f2 B = bl_f2{b0[(size_t)n * tab_ld], b1[(size_t)n * tab_ld]};
-                mx = __builtin_elementwise_max(mx, bl_fma2(bl2((float)n), slope, B - bl2(BL_LGAMMA1P[n])));
+            int hi0 = 0, hi1 = 0;
+            for (int nb = 0; nb <= K; nb += 4) { // blocks of 4: their table loads are in flight together
+                bl_f2 B[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int n = min(nb + q, K);
+                    B[q] = bl_f2{b0[(size_t)n * tab_ld], b1[(size_t)n * tab_ld]};
+                }
+                bool in0 = false, in1 = false;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int n = min(nb + q, K); // the clamped tail repeats term K: harmless for max / hi
+                    const bl_f2 tn = bl_fma2(bl2((float)n), slope, B[q] - bl2(BL_LGAMMA1P[n]));
+                    mx = __builtin_elementwise_max(mx, tn);
+                    in0 = tn.x >= mx.x - 25.0f; in1 = tn.y >= mx.y - 25.0f;
+                    hi0 = in0 ? n : hi0;
+                    hi1 = in1 ? n : hi1;
+                }
+                if (!in0 && !in1 && mx.x > -INFINITY && mx.y > -INFINITY) break; // the block's last term is out: so is the rest
             }
+            const int n_hi = max(hi0, hi1);
             bl_f2 S = bl2(0.0f), S1 = bl2(0.0f);
 #pragma unroll 4
-            for (int n = 0; n <= K; n++) {
+            for (int n = 0; n <= n_hi; n++) {
                 const bl_f2 B = bl_f2{b0[(size_t)n * tab_ld], b1[(size_t)n * tab_ld]};
                 const bl_f2 tn = bl_fma2(bl2((float)n), slope, B - bl2(BL_LGAMMA1P[n])) - mx;
                 const bl_f2 en = bl_exp2_2(tn * bl2(BL_LOG2E));
