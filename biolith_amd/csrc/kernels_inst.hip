@@ -31,8 +31,9 @@ static int bl_launch(K kernel, const P *p, int grid, int threads, int lds_bytes,
 
 extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int grid, int lds_bytes, int staged, int model, hipStream_t stream)
 {
-    if (model == 1) {
+    if (model == 1) { // occu_rn: the smaller per-lane table (model id 5) whenever max_abundance allows
 #if BL_HAVE_RN
+        if (staged && p->ncw == 3 && p->max_abundance < BL_RN_NB_SMALL) return BL_PICK(bl_nuts_kernel, p, true, 5, 3);
         if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 1, 3);
 #endif
         return (int)hipErrorNotSupported;
@@ -68,6 +69,7 @@ extern "C" int BL_NAME(bl_launch_logp, BL_KS, BL_KO)(const BlLogpParams *p, int 
 {
     if (model == 1) {
 #if BL_HAVE_RN
+        if (staged && p->ncw == 3 && p->max_abundance < BL_RN_NB_SMALL) return BL_PICK(bl_logp_kernel, p, true, 5, 3);
         if (staged && p->ncw == 3) return BL_PICK(bl_logp_kernel, p, true, 1, 3);
 #endif
         return (int)hipErrorNotSupported;

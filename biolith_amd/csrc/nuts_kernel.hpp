@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     // Speculative overlap pays while a dropped evaluation is cheap: the LDS-staged occu / false-positive / occu_cop
     // forms (<= ~3 site pairs per lane).  occu_rn's and nmixture's evaluations (sums over N) dominate their ticks and the HBM-row form serves huge
     // slices: there the decisions are taken right after the exchange and only the bookkeeping overlaps.
-    constexpr bool SPEC = LDS && MODEL != 1 && MODEL != 4;
+    constexpr bool SPEC = LDS && MODEL != 1 && MODEL != 5 && MODEL != 4;
     auto decide = [&]() {
         have_pending = false;
         const double acc = p_acc;

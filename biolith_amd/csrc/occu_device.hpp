@@ -762,8 +762,8 @@ __device__ __forceinline__ void bl_eval_sites_cop(int ct, int pstride, int cnt, 
 
 
 // lgamma(n + 1) for n < 128 (occu_rn, nmixture)
-#define BL_RN_NB 128
-__device__ constexpr float BL_LGAMMA1P[BL_RN_NB] = {0.000000000e+00f, 0.000000000e+00f, 6.931471806e-01f, 1.791759469e+00f, 3.178053830e+00f, 4.787491743e+00f, 6.579251212e+00f, 8.525161361e+00f, 1.060460290e+01f, 1.280182748e+01f, 1.510441257e+01f, 1.750230785e+01f, 1.998721450e+01f, 2.255216385e+01f, 2.519122118e+01f, 2.789927138e+01f, 3.067186011e+01f, 3.350507345e+01f, 3.639544521e+01f, 3.933988419e+01f, 4.233561646e+01f, 4.538013890e+01f, 4.847118135e+01f, 5.160667557e+01f, 5.478472940e+01f, 5.800360522e+01f, 6.126170176e+01f, 6.455753863e+01f, 6.788974314e+01f, 7.125703897e+01f, 7.465823635e+01f, 7.809222355e+01f, 8.155795946e+01f, 8.505446702e+01f, 8.858082754e+01f, 9.213617560e+01f, 9.571969454e+01f, 9.933061245e+01f, 1.029681986e+02f, 1.066317603e+02f, 1.103206397e+02f, 1.140342118e+02f, 1.177718814e+02f, 1.215330815e+02f, 1.253172711e+02f, 1.291239336e+02f, 1.329525750e+02f, 1.368027226e+02f, 1.406739236e+02f, 1.445657439e+02f, 1.484777670e+02f, 1.524095926e+02f, 1.563608363e+02f, 1.603311282e+02f, 1.643201123e+02f, 1.683274454e+02f, 1.723527971e+02f, 1.763958484e+02f, 1.804562914e+02f, 1.845338289e+02f, 1.886281734e+02f, 1.927390473e+02f, 1.968661817e+02f, 2.010093164e+02f, 2.051681995e+02f, 2.093425868e+02f, 2.135322415e+02f, 2.177369341e+02f, 2.219564418e+02f, 2.261905483e+02f, 2.304390436e+02f, 2.347017234e+02f, 2.389783896e+02f, 2.432688490e+02f, 2.475729141e+02f, 2.518904022e+02f, 2.562211356e+02f, 2.605649410e+02f, 2.649216498e+02f, 2.692910977e+02f, 2.736731243e+02f, 2.780675734e+02f, 2.824742927e+02f, 2.868931333e+02f, 2.913239501e+02f, 2.957666014e+02f, 3.002209486e+02f, 3.046868568e+02f, 3.091641936e+02f, 3.136528299e+02f, 3.181526396e+02f, 3.226634991e+02f, 3.271852877e+02f, 3.317178872e+02f, 3.362611820e+02f, 3.408150589e+02f, 3.453794071e+02f, 3.499541180e+02f, 3.545390855e+02f, 3.591342054e+02f, 3.637393756e+02f, 3.683544961e+02f, 3.729794689e+02f, 3.776141979e+02f, 3.822585888e+02f, 3.869125491e+02f, 3.915759882e+02f, 3.962488171e+02f, 4.009309483e+02f, 4.056222962e+02f, 4.103227765e+02f, 4.150323067e+02f, 4.197508056e+02f, 4.244781934e+02f, 4.292143919e+02f, 4.339593240e+02f, 4.387129142e+02f, 4.434750881e+02f, 4.482457727e+02f, 4.530248962e+02f, 4.578123880e+02f, 4.626081785e+02f, 4.674121996e+02f, 4.722243839e+02f, 4.770446655e+02f, 4.818729792e+02f, 4.867092611e+02f, 4.915534482e+02f};
+#define BL_RN_NB 128 // upper bound of the per-lane table over N (max_abundance <= 127)
+__device__ constexpr float BL_LGAMMA1P[128] = {0.000000000e+00f, 0.000000000e+00f, 6.931471806e-01f, 1.791759469e+00f, 3.178053830e+00f, 4.787491743e+00f, 6.579251212e+00f, 8.525161361e+00f, 1.060460290e+01f, 1.280182748e+01f, 1.510441257e+01f, 1.750230785e+01f, 1.998721450e+01f, 2.255216385e+01f, 2.519122118e+01f, 2.789927138e+01f, 3.067186011e+01f, 3.350507345e+01f, 3.639544521e+01f, 3.933988419e+01f, 4.233561646e+01f, 4.538013890e+01f, 4.847118135e+01f, 5.160667557e+01f, 5.478472940e+01f, 5.800360522e+01f, 6.126170176e+01f, 6.455753863e+01f, 6.788974314e+01f, 7.125703897e+01f, 7.465823635e+01f, 7.809222355e+01f, 8.155795946e+01f, 8.505446702e+01f, 8.858082754e+01f, 9.213617560e+01f, 9.571969454e+01f, 9.933061245e+01f, 1.029681986e+02f, 1.066317603e+02f, 1.103206397e+02f, 1.140342118e+02f, 1.177718814e+02f, 1.215330815e+02f, 1.253172711e+02f, 1.291239336e+02f, 1.329525750e+02f, 1.368027226e+02f, 1.406739236e+02f, 1.445657439e+02f, 1.484777670e+02f, 1.524095926e+02f, 1.563608363e+02f, 1.603311282e+02f, 1.643201123e+02f, 1.683274454e+02f, 1.723527971e+02f, 1.763958484e+02f, 1.804562914e+02f, 1.845338289e+02f, 1.886281734e+02f, 1.927390473e+02f, 1.968661817e+02f, 2.010093164e+02f, 2.051681995e+02f, 2.093425868e+02f, 2.135322415e+02f, 2.177369341e+02f, 2.219564418e+02f, 2.261905483e+02f, 2.304390436e+02f, 2.347017234e+02f, 2.389783896e+02f, 2.432688490e+02f, 2.475729141e+02f, 2.518904022e+02f, 2.562211356e+02f, 2.605649410e+02f, 2.649216498e+02f, 2.692910977e+02f, 2.736731243e+02f, 2.780675734e+02f, 2.824742927e+02f, 2.868931333e+02f, 2.913239501e+02f, 2.957666014e+02f, 3.002209486e+02f, 3.046868568e+02f, 3.091641936e+02f, 3.136528299e+02f, 3.181526396e+02f, 3.226634991e+02f, 3.271852877e+02f, 3.317178872e+02f, 3.362611820e+02f, 3.408150589e+02f, 3.453794071e+02f, 3.499541180e+02f, 3.545390855e+02f, 3.591342054e+02f, 3.637393756e+02f, 3.683544961e+02f, 3.729794689e+02f, 3.776141979e+02f, 3.822585888e+02f, 3.869125491e+02f, 3.915759882e+02f, 3.962488171e+02f, 4.009309483e+02f, 4.056222962e+02f, 4.103227765e+02f, 4.150323067e+02f, 4.197508056e+02f, 4.244781934e+02f, 4.292143919e+02f, 4.339593240e+02f, 4.387129142e+02f, 4.434750881e+02f, 4.482457727e+02f, 4.530248962e+02f, 4.578123880e+02f, 4.626081785e+02f, 4.674121996e+02f, 4.722243839e+02f, 4.770446655e+02f, 4.818729792e+02f, 4.867092611e+02f, 4.915534482e+02f};
 
 // --------------------------------------------------------------- N-mixture (nmixture, MODEL 4) ----
 // biolith/models/nmixture.py:150-220: N_it enumerated over 0..K with raw Poisson(lambda) weights (the model's
@@ -933,16 +933,21 @@ __device__ __forceinline__ float bl_rn_mode_lb(float a, float K)
     return fmaf(n1, a, -(fmaf(n1 + 0.5f, BL_LN2 * __builtin_amdgcn_logf(n1), 1.0f - n1)));
 }
 
-// n = 1 .. min(KB, BL_RN_NB-1), fully unrolled in blocks of 8, each block under a wave-uniform guard:
+// n = 1 .. min(KB, NB-1) (NB: the enclosing function's table size), fully unrolled in blocks of 8, each block under a wave-uniform guard:
 // indices into the per-lane table stay static, blocks beyond the cutoff are skipped by a scalar branch.
 #define BL_RN_LOOP_BEGIN(KB)                                                            \
-    _Pragma("unroll") for (int nb_ = 1; nb_ < BL_RN_NB; nb_ += 8)                       \
+    _Pragma("unroll") for (int nb_ = 1; nb_ < NB; nb_ += 8)                             \
         if (nb_ <= (KB)) {                                                              \
             _Pragma("unroll") for (int n = nb_; n < nb_ + 8; n++)                       \
-                if (n < BL_RN_NB && n <= (KB)) {
+                if (n < NB && n <= (KB)) {
 #define BL_RN_LOOP_END }}
+// Two instantiations (chosen by the host from max_abundance), both free of scratch spills:
+//   NB = 128, GC = 1: max_abundance <= 127;   NB = 112, GC = 2: max_abundance <= 111 (the reference default is 100) --
+// the 16 table registers saved pay for a second gradient recursion running beside the first.
+#define BL_RN_NB_SMALL 112
+#define BL_RN_GA 10 // visits whose b_n recursions run side by side in pass A1 (one log per group and n)
 
-template <int KS, int KO, int CT>
+template <int KS, int KO, int CT, int NB, int BL_RN_GC>
 __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, int T, int J, int K,
                                                  const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                                  float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
@@ -1031,26 +1036,43 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
             BL_RN_LOOP_END
             const int Kw = min(Kl, bl_wave_max_u(nw));
             // ---- A1: LP[n] = sum over detection visits of log2 b_n ----
-            float LP[BL_RN_NB];
+            float LP[NB];
 #pragma unroll
-            for (int n = 0; n < BL_RN_NB; n++) LP[n] = 0.0f;
-            if (ndet > 0.0f) {
-                for (int j = 0; j < J; j++) {
-                    float w[KO + 1];
+            for (int n = 0; n < NB; n++) LP[n] = 0.0f;
+            // Visits are taken BL_RN_GA at a time with their b_n recursions side by side (independent chains keep the
+            // VALU busy; one wave per SIMD has no other wave to hide latencies) and ONE log per n for the group:
+            // sum_j log b_jn = log prod_j b_jn (b <= n <= 127, so ten factors stay far inside float32).  A
+            // non-detection visit gets q = 0, hence b = 1: its factor is 1 and it needs no mask.
+            if (__any(ndet > 0.0f)) {
+                for (int j0 = 0; j0 < J; j0 += BL_RN_GA) {
+                    float q[BL_RN_GA];
+                    bool det = false;
 #pragma unroll
-                    for (int k = 0; k <= KO; k++) w[k] = pv[2 * (j * (KO + 1) + k)];
-                    if (w[0] > 0.0f) {
-                        float u = w[0] * alpha[0];
+                    for (int g = 0; g < BL_RN_GA; g++) {
+                        q[g] = 0.0f;
+                        if (j0 + g < J) { // wave-uniform
+                            const float *wv = pv + 2 * ((j0 + g) * (KO + 1));
+                            float u = wv[0] * alpha[0];
 #pragma unroll
-                        for (int k = 1; k <= KO; k++) u = fmaf(w[k], alpha[k], u);
-                        const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E);
-                        const float q = (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(1.0f + e);
-                        float b = 0.0f;
-                        BL_RN_LOOP_BEGIN(Kw)
-                            b = fmaf(b, q, 1.0f);
-                            LP[n] += __builtin_amdgcn_logf(b);
-                        BL_RN_LOOP_END
+                            for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
+                            const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E);
+                            q[g] = wv[0] > 0.0f ? (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(1.0f + e) : 0.0f;
+                            det = det || wv[0] > 0.0f;
+                        }
                     }
+                    if (!__any(det)) continue; // no lane of the wave has a detection in this group
+                    float b[BL_RN_GA];
+#pragma unroll
+                    for (int g = 0; g < BL_RN_GA; g++) b[g] = 0.0f;
+                    BL_RN_LOOP_BEGIN(Kw)
+                        float prod = 1.0f;
+#pragma unroll
+                        for (int g = 0; g < BL_RN_GA; g++) {
+                            b[g] = fmaf(b[g], q[g], 1.0f);
+                            prod *= b[g];
+                        }
+                        LP[n] += __builtin_amdgcn_logf(prod);
+                    BL_RN_LOOP_END
                 }
             }
             // ---- B: sum over n ----
@@ -1074,27 +1096,46 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
 #pragma unroll
             for (int k = 0; k <= KO; k++) ga_s[k] = fmaf(en_post, Rv[k], ga_s[k]);
             // ---- C: detection visits' d/dnu = sum_n w_n (q - q r b'_n / b_n),  b'_n = b'_(n-1) q + b_(n-1) ----
-            if (ndet > 0.0f) {
-                for (int j = 0; j < J; j++) {
-                    float w[KO + 1];
+            if (__any(ndet > 0.0f)) {
+                for (int j0 = 0; j0 < J; j0 += BL_RN_GC) {
+                    float q[BL_RN_GC], r[BL_RN_GC];
+                    bool det = false;
 #pragma unroll
-                    for (int k = 0; k <= KO; k++) w[k] = pv[2 * (j * (KO + 1) + k)];
-                    if (w[0] > 0.0f) {
-                        float u = w[0] * alpha[0];
+                    for (int g = 0; g < BL_RN_GC; g++) {
+                        q[g] = 0.0f; r[g] = 0.0f;
+                        if (j0 + g < J) {
+                            const float *wv = pv + 2 * ((j0 + g) * (KO + 1));
+                            float u = wv[0] * alpha[0];
 #pragma unroll
-                        for (int k = 1; k <= KO; k++) u = fmaf(w[k], alpha[k], u);
-                        const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E), op = 1.0f + e;
-                        const float rop = __builtin_amdgcn_rcpf(op);
-                        const float q = (u > 0.0f ? e : 1.0f) * rop, r = (u > 0.0f ? 1.0f : e) * rop;
-                        float b = 0.0f, bp = 0.0f, h = 0.0f;
-                        BL_RN_LOOP_BEGIN(Kw)
-                            bp = fmaf(bp, q, b);
-                            b = fmaf(b, q, 1.0f);
-                            h = fmaf(LP[n] * bp, __builtin_amdgcn_rcpf(b), h);
-                        BL_RN_LOOP_END
-                        const float dnu = q * ((s - t0) - r * h) * rs;
+                            for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
+                            const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E), rop = __builtin_amdgcn_rcpf(1.0f + e);
+                            const bool d = wv[0] > 0.0f;
+                            q[g] = d ? (u > 0.0f ? e : 1.0f) * rop : 0.0f;
+                            r[g] = (u > 0.0f ? 1.0f : e) * rop;
+                            det = det || d;
+                        }
+                    }
+                    if (!__any(det)) continue;
+                    float b[BL_RN_GC], bp[BL_RN_GC], h[BL_RN_GC];
 #pragma unroll
-                        for (int k = 0; k <= KO; k++) ga_s[k] = fmaf(dnu, w[k], ga_s[k]);
+                    for (int g = 0; g < BL_RN_GC; g++) { b[g] = 0.0f; bp[g] = 0.0f; h[g] = 0.0f; }
+                    BL_RN_LOOP_BEGIN(Kw)
+                        const float wn = LP[n];
+#pragma unroll
+                        for (int g = 0; g < BL_RN_GC; g++) {
+                            bp[g] = fmaf(bp[g], q[g], b[g]);
+                            b[g] = fmaf(b[g], q[g], 1.0f);
+                            h[g] = fmaf(wn * bp[g], __builtin_amdgcn_rcpf(b[g]), h[g]);
+                        }
+                    BL_RN_LOOP_END
+#pragma unroll
+                    for (int g = 0; g < BL_RN_GC; g++) {
+                        if (j0 + g < J) {
+                            const float *wv = pv + 2 * ((j0 + g) * (KO + 1));
+                            const float dnu = q[g] * ((s - t0) - r[g] * h[g]) * rs; // q = 0 for a non-detection: no term
+#pragma unroll
+                            for (int k = 0; k <= KO; k++) ga_s[k] = fmaf(dnu, wv[2 * k], ga_s[k]);
+                        }
                     }
                 }
             }
@@ -1109,7 +1150,7 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
     }
 }
 
-// MODEL 0 = occu (occu.py), MODEL 1 = occu_rn (occu_rn.py; LDS records only);
+// MODEL 0 = occu (occu.py), MODEL 1 / 5 = occu_rn (occu_rn.py; LDS records only; table of 128 / 112 entries);
 // MODEL 2 (occu with false positives) is dispatched by bl_phase_a below
 template <int KS, int KO, bool LDS, int MODEL, int CT>
 __device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ grows, int ld_or_stride, int cnt, int T, int J, int K,
@@ -1117,7 +1158,9 @@ __device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ 
                                               float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
 {
     if constexpr (MODEL == 1) {
-        if constexpr (LDS) bl_eval_sites_rn<KS, KO, CT>(ct, ld_or_stride, cnt, T, J, K, beta, alpha, ll, gb, ga);
+        if constexpr (LDS) bl_eval_sites_rn<KS, KO, CT, BL_RN_NB, 1>(ct, ld_or_stride, cnt, T, J, K, beta, alpha, ll, gb, ga);
+    } else if constexpr (MODEL == 5) {
+        if constexpr (LDS) bl_eval_sites_rn<KS, KO, CT, BL_RN_NB_SMALL, 2>(ct, ld_or_stride, cnt, T, J, K, beta, alpha, ll, gb, ga);
     } else if constexpr (LDS) {
         switch (J) { // wave-uniform
         case 1: bl_eval_sites_lds<KS, KO, 1, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
