@@ -206,7 +206,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": f"bl_nuts_kernel<{ds.Ks},{ds.Ko},true,{1 if wl['model'] == 'occu_rn' else 0}>", "kernel_ms": kernel_ms_mean,
+                # <KS, KO, LDS-staged, model id, compute waves>: occu = 0; occu_rn = 5 (112-entry table, max_abundance <= 111)
+                "kernel": f"bl_nuts_kernel<{ds.Ks}, {ds.Ko}, true, {5 if wl['model'] == 'occu_rn' else 0}, {res0.threads_per_wg // 64 - 1}>",
+                "kernel_ms": kernel_ms_mean,
                 "algorithmic_bytes_per_launch": leap_mean * bytes_eval, "bytes_per_gradient_evaluation": bytes_eval,
                 "gradient_evaluations_per_launch": leap_mean,
                 "us_per_leapfrog_per_chain": 1e3 * kernel_ms_mean / (leap_mean / CHAINS_PER_GPU),

@@ -39,6 +39,7 @@ class NutsResult:
     lds_bytes: int
     lds_staged: bool
     chains_l2_local: int = 0      # chains that ran the verified same-XCD (L2-local) exchange
+    threads_per_wg: int = 0       # 64 x (compute waves + 1 control wave)
 
 
 class OccuDataset:
@@ -206,7 +207,7 @@ class OccuDataset:
         k, thr, lds, staged, loc = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
         _ffi.check(self._lib.bl_nuts_geometry(self._h, C.byref(k), C.byref(thr), C.byref(lds), C.byref(staged), C.byref(loc)))
         return NutsResult(draws, div.astype(bool), steps, acc, pot, eps, minv, nleap, self.elapsed_ms(),
-                          k.value, lds.value, bool(staged.value), loc.value)
+                          k.value, lds.value, bool(staged.value), loc.value, thr.value)
 
     def nuts(self, timeout: Optional[float] = None, **kw) -> NutsResult:
         """launch + wait + fetch.  With ``timeout`` (seconds) the kernel is aborted through its
