@@ -188,3 +188,22 @@ def test_four_compute_wave_form_matches_the_three_wave_form(monkeypatch):
     assert r.lds_staged and r.wgs_per_chain == 32
     assert np.array_equal(o["num_steps"][:, :3], r.num_steps[:, :3]), (o["num_steps"], r.num_steps)
     assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=2e-3)
+
+
+@pytest.mark.parametrize("ks,ko", [(0, 0), (8, 3), (16, 16)])
+def test_dimension_extremes_build_the_same_trees(ks, ko):
+    """D = 2 (intercepts only), D = 13 and D = 34: the exchange record holds 16, 32 or 64 granules (D + 4 rounded up),
+    so the lane-group fold runs over 4, 2 or 1 groups; the control wave's per-dimension lanes cover all of them."""
+    rng = np.random.default_rng(10 * ks + ko)
+    N, T, J = 400, 1, 4
+    X = rng.normal(size=(N, ks)) * 0.5
+    W = rng.normal(size=(N, T, J, ko)) * 0.5
+    Y = (rng.uniform(size=(1, N, T, J)) < 0.3) * 1.0
+    od, ds = oracle.OracleData(X, W, Y), OccuDataset(X, W, Y)
+    assert ds.D == ks + ko + 2
+    o = oracle.nuts_run(od, 8, 4, num_chains=2, seed=7)
+    r = ds.nuts(num_warmup=8, num_samples=4, num_chains=2, seed=7)
+    assert np.array_equal(o["num_steps"][:, :3], r.num_steps[:, :3]), (o["num_steps"], r.num_steps)
+    assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=2e-2)
+    r = ds.nuts(num_warmup=200, num_samples=200, num_chains=2, seed=1)
+    assert r.diverging.sum() == 0 and split_gelman_rubin(r.draws).max() < 1.1
