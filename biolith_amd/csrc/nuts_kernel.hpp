@@ -32,8 +32,8 @@
 //     velocity-Verlet step, energy error, checkpointed U-turn tests, tree edges, transition end with
 //     dual averaging / Welford windows / new momentum) and the multinomial bookkeeping run BESIDE
 //     that evaluation.  If the decided position is not bit-equal to the guess the evaluation is
-//     dropped and redone (transition ends), so correctness never depends on the guess.  occu_rn,
-//     nmixture and the HBM-row form (long evaluations) decide first and overlap only the
+//     dropped and redone (transition ends), so correctness never depends on the guess.  occu_rn
+//     and the HBM-row form (long evaluations) decide first and overlap only the
 //     bookkeeping.  Direction bits and transition uniforms come from two separate xoshiro streams
 //     so that neither form reorders a stream (the oracle draws from the same two).
 // No host round trip, no kernel boundary and no HBM traffic inside the sampling loop.
@@ -324,9 +324,9 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     // step, _double_tree / _combine_tree, and at transition end the warmup adapter): takes the stashed exchange
     // result, leaves the next position to evaluate in cz and the run status in flag.
     // Speculative overlap pays while a dropped evaluation is cheap: the LDS-staged occu / false-positive / occu_cop
-    // forms (<= ~3 site pairs per lane).  occu_rn's and nmixture's evaluations (sums over N) dominate their ticks and the HBM-row form serves huge
+    // forms (<= ~3 site pairs per lane) and nmixture (measured: 8.0 -> 7.6 us).  occu_rn's evaluation (sums over N) dominates its tick and the HBM-row form serves huge
     // slices: there the decisions are taken right after the exchange and only the bookkeeping overlaps.
-    constexpr bool SPEC = LDS && MODEL != 1 && MODEL != 5 && MODEL != 4;
+    constexpr bool SPEC = LDS && MODEL != 1 && MODEL != 5;
     auto decide = [&]() {
         have_pending = false;
         const double acc = p_acc;
