@@ -751,7 +751,7 @@ extern "C" int bl_dataset_param_dim(const bl_dataset *ds, int *D)
 // Workgroups per chain / LDS staging decision.  One site per thread is the latency optimum
 // (DESIGN.md "geometry"); fall back to several sites per thread, then to un-staged HBM rows.
 static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k_out, int *nloc_out, int *ld_out,
-                            int *lds_bytes_out, int *staged_out, int *ncw_out)
+                            int *lds_bytes_out, int *staged_out, int *ncw_out, int *wide_out)
 {
     const int N = ds->dims.n_sites;
     // chains are dealt to the 8 XCDs (32 CUs each); a chain's k workgroups share one XCD, one per CU
@@ -782,9 +782,20 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     bool ok = fits(k, &nloc);
     if (!ok && want_k <= 0)
         for (int kk = k + 1; kk <= kmax && !ok; kk++) { ok = fits(kk, &nloc); if (ok) k = kk; }
+    // Wide geometry: the slice does not fit the LDS of one XCD's workgroups, but it does when the chain takes more
+    // CUs than one XCD has.  The exchange then crosses XCDs (the kernel's placement census makes it take the fabric
+    // form), which costs a few thousand cycles per tick -- little next to re-reading the rows from HBM every tick.
+    int wide = 0;
+    if (!ok && want_k <= 0) {
+        const char *e = getenv("BIOLITH_HIP_NO_WIDE");
+        const int kwide = 256 / (chains > 0 ? chains : 1);
+        if (!(e && e[0] == '1'))
+            for (int kk = kmax + 1; kk <= kwide && !ok; kk++) { ok = fits(kk, &nloc); if (ok) { k = kk; wide = 1; } }
+    }
     if (!ok) fits(k, &nloc);
     if (!ok && ds->model == 0) ncw = 4; // HBM-row form is built for 4 compute waves only
-    *k_out = k; *nloc_out = nloc; *ld_out = stride; *staged_out = ok ? 1 : 0; *ncw_out = ncw;
+    if (wide) ncw = ds->model == 1 ? BL_CWAVES_RN : 4; // full slices: all four SIMDs evaluate
+    *k_out = k; *nloc_out = nloc; *ld_out = stride; *staged_out = ok ? 1 : 0; *ncw_out = ncw; *wide_out = wide;
     *lds_bytes_out = ok ? BL_OFF_DATA + ((nloc + 1) / 2) * stride * 4 : BL_OFF_DATA;
 }
 
@@ -826,8 +837,8 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
     int rc = set_device(ds);
     if (rc) return rc;
     const int D = ds->D;
-    int k, nloc, ld, lds_bytes, can_stage, ncw;
-    choose_geometry(ds, 1, 0, &k, &nloc, &ld, &lds_bytes, &can_stage, &ncw);
+    int k, nloc, ld, lds_bytes, can_stage, ncw, wide;
+    choose_geometry(ds, 1, 0, &k, &nloc, &ld, &lds_bytes, &can_stage, &ncw, &wide);
     const int use_staged = staged && can_stage;
     if (!use_staged) { lds_bytes = BL_OFF_DATA; ncw = 4; }
     std::vector<float> th32((size_t)B * D);
@@ -877,8 +888,8 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     if (rc) return rc;
 
     int k, nloc, ld, lds_bytes, staged;
-    int ncw;
-    choose_geometry(ds, C, cfg->wgs_per_chain, &k, &nloc, &ld, &lds_bytes, &staged, &ncw);
+    int ncw, wide;
+    choose_geometry(ds, C, cfg->wgs_per_chain, &k, &nloc, &ld, &lds_bytes, &staged, &ncw, &wide);
     const int nvp = (D + 4 <= 16) ? 16 : (D + 4 <= 32 ? 32 : 64);
 
     // ---- (re)allocate run slab ----
@@ -954,6 +965,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.fp_mode = ds->fp_mode;
     p.nmix_tab = ds->d_tab;
     p.ncw = ncw;
+    p.wide = wide;
     p.xchg = ds->d_xchg;
     p.cold = d_cold;
     p.spin_limit = 1u << 18;
@@ -974,7 +986,8 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     BL_HIP(hipMemsetAsync(ds->d_status, 0, 16, st));
     BL_HIP(hipMemsetAsync(ds->d_dbg, 0, 256, st));
     BL_HIP(hipMemsetAsync(ds->d_loc, 0, (size_t)C * 4, st));
-    const int grid = 8 * k * ((C + 7) / 8); // XCD-aware mapping in the kernel; surplus blocks exit at once
+    // XCD-aware mapping in the kernel (surplus blocks exit at once), or consecutive blocks per chain in the wide geometry
+    const int grid = wide ? C * k : 8 * k * ((C + 7) / 8);
     if (ds->model != 0 && !staged)
         return bl_fail(BL_ERR_UNSUPPORTED, "occu_rn / false-positive model: the dataset slice does not fit the LDS-staged path");
     const int lrc = ds->kern->nuts(&p, grid, lds_bytes, staged, ds->model, st);

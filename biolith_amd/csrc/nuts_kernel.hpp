@@ -97,6 +97,7 @@ struct BlNutsParams {
     int rec_stride;                // floats per LDS pair record
     int nvp;                       // granules per workgroup record: 16, 32 or 64 (>= D+4)
     int ncw;                       // compute waves per workgroup: selects the CW instantiation (host side)
+    int wide;                      // 1: the chain's workgroups span XCDs (blocks chain*k .. chain*k + k - 1), fabric exchange
     const float *nmix_tab;         // MODEL 4: B[t][n][site] = sum_j m log C(n, y_j) (-inf below the largest count), row length n_stride
     int fp_mode;                   // MODEL 2 / 3: 0 none, 1 = rate acts on every site ("constant"), 2 = on unoccupied sites only
     int max_depth;
@@ -176,9 +177,11 @@ __device__ __forceinline__ unsigned long long bl_poll_load(const unsigned char *
 template <int KS, int KO, bool LDS, int MODEL, int CW>
 __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsParams p)
 {
-    // XCD-aware mapping (speed only; see header): label = b % 8 names a set of blocks that share an XCD
+    // XCD-aware mapping (speed only; see header): label = b % 8 names a set of blocks that share an XCD.
+    // Wide geometry (slices that only fit LDS when a chain takes more than one XCD's CUs): consecutive blocks, any XCD.
     const int label = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int chain = label + 8 * (slot / p.k), member = slot % p.k;
+    const int chain = p.wide ? (int)blockIdx.x / p.k : label + 8 * (slot / p.k);
+    const int member = p.wide ? (int)blockIdx.x % p.k : slot % p.k;
     if (chain >= p.num_chains) return; // whole block leaves before any barrier or exchange
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int Ks = p.Ks, Ko = p.Ko, D = bl_model_dim<MODEL>(Ks, Ko, p.fp_mode);
