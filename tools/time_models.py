@@ -10,7 +10,7 @@ def run(name, ds):
     r = ds.nuts(num_warmup=300, num_samples=300, num_chains=4, seed=0)
     r = ds.nuts(num_warmup=300, num_samples=300, num_chains=4, seed=1)
     n = r.n_leapfrog.sum() / 4
-    print(f"{name:34s} kernel {r.kernel_ms:8.2f} ms  {1e3 * r.kernel_ms / n:7.2f} us/leapfrog/chain  k={r.wgs_per_chain} D={ds.D}")
+    print(f"{name:44s} kernel {r.kernel_ms:8.2f} ms  {1e3 * r.kernel_ms / n:7.2f} us/leapfrog/chain  k={r.wgs_per_chain} D={ds.D}")
 
 with contextlib.redirect_stdout(io.StringIO()):
     kw = dict(n_sites=5000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7)
@@ -19,7 +19,9 @@ with contextlib.redirect_stdout(io.StringIO()):
     drn, _ = simulate_rn(**kw)
     dcop, _ = simulate_cop(**kw)
     dnm, _ = simulate_nmixture(**kw, min_abundance=0.5, max_abundance=8.0, max_observation_rate=6.0)
+    dst, _ = simulate(n_sites=2000, n_periods=8, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=28, session_duration=7)
 run("occu 5000x10", OccuDataset(d0["site_covs"], d0["obs_covs"], d0["obs"]))
+run("occu stacked 2000x8x4 (configs[4] stand-in)", OccuDataset(dst["site_covs"], dst["obs_covs"], dst["obs"]))
 run("occu_fp constant 5000x10", OccuDataset(dfp["site_covs"], dfp["obs_covs"], dfp["obs"], model="occu_fp", fp_mode="constant"))
 run("occu_cop (fp constant) 5000x10", OccuDataset(dcop["site_covs"], dcop["obs_covs"], dcop["obs"], model="occu_cop", fp_mode="constant",
                                                    session_duration=dcop["session_duration"]))
