@@ -108,6 +108,10 @@ def main():
     if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":  # the env knob exercises the RCCL path on one GPU
         import torch.distributed as dist
 
+        # NCCL_DEBUG=VERSION (set on the GPU boxes) makes RCCL print a five-line banner on STDOUT when the first
+        # communicator is created; stdout is reserved for the one JSON line, so that banner is turned off
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            del os.environ["NCCL_DEBUG"]
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
