@@ -119,3 +119,27 @@ def test_rn_nondetection_clamp_regime():
     Uo, _ = od.potential_grad(far)
     Ug, _ = ds.logp_grad(far)
     assert np.all(np.isfinite(Ug)) and Ug[0] >= Uo[0] - 1e-5 * abs(Uo[0])
+
+
+@pytest.mark.parametrize("ks,ko", [(4, 4), (4, 2), (1, 4)])
+def test_rn_covariate_capacities(ks, ko):
+    """Every padded capacity pair has its own instantiation of the two occu_rn kernels (register allocation differs: the
+    (4,4) one is the fullest): K1 parity, same first trees as the oracle, and a sane warmed-up sampler on each."""
+    import contextlib
+    import io
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        d, t = simulate_rn(n_sites=300, n_site_covs=ks, n_obs_covs=ko, deployment_days_per_site=56, session_duration=7, random_seed=2)
+    od = oracle.OracleData(d["site_covs"], d["obs_covs"], d["obs"], model="occu_rn")
+    ds = OccuDataset(d["site_covs"], d["obs_covs"], d["obs"], model="occu_rn")
+    th = np.random.default_rng(0).uniform(-0.6, 0.6, size=(3, od.D)).astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= 1e-5 and np.max(np.abs(Gg - Go)) <= 1e-4 * np.max(np.abs(Go))
+    o = oracle.nuts_run(od, 0, 4, num_chains=2, seed=3)
+    r = ds.nuts(num_warmup=0, num_samples=4, num_chains=2, seed=3)
+    assert np.array_equal(o["num_steps"][:, :3], r.num_steps[:, :3])
+    r = ds.nuts(num_warmup=150, num_samples=150, num_chains=2, seed=1)
+    assert r.num_steps.mean() < 40 and np.all(r.step_size > 0.05) and r.diverging.sum() == 0
+    want = np.concatenate([t["beta"][0], t["alpha"][0]])
+    assert np.abs(r.draws.reshape(-1, od.D).mean(0) - want).max() < 0.5   # the reference's coefficient tolerance
