@@ -560,6 +560,51 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                     __hip_atomic_store(dst, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             BL_STAMP(2)
+            // ------------------------------------------------ potential at cz (lane d) ----
+            // prior of lane d: pe2 = 2 x its energy, pg = d energy / d theta_d
+            //   Normal(loc, scale):            pe2 = (theta-loc)^2 / scale^2 ,  pg = (theta-loc) / scale^2
+            //   phi = logit f, f ~ Beta(a,b):  energy = a softplus(-phi) + b softplus(phi)  (Jacobian included),
+            //                                  pg = (a+b) sigmoid(phi) - a        (prior_loc = a, prior_isc2 = b)
+            const float dth = cz - prior_loc;
+            float pe2 = dth * dth * prior_isc2, pg = dth * prior_isc2;
+            if constexpr (MODEL == 2) {
+                if (is_phi) {
+                    const float e = bl_exp(-fabsf(cz)), op = 1.0f + e, l = bl_log(op);
+                    const float sig = (cz > 0.0f ? 1.0f : e) * bl_rcp(op);
+                    pe2 = 2.0f * (prior_loc * (fmaxf(-cz, 0.0f) + l) + prior_isc2 * (fmaxf(cz, 0.0f) + l));
+                    pg = (prior_loc + prior_isc2) * sig - prior_loc;
+                }
+            }
+            if constexpr (MODEL == 3) {
+                //   phi = log f, f ~ Exponential(rate r):  energy = r e^phi - phi  (Jacobian included),  pg = r e^phi - 1
+                if (is_phi) {
+                    const float rf = prior_loc * bl_exp(fminf(cz, 80.0f));
+                    pe2 = 2.0f * (rf - cz);
+                    pg = rf - 1.0f;
+                }
+            }
+            // Everything of the speculative position that does not need the gathered gradient is prepared here, in the
+            // shadow of the store -> poll latency: which kind of leaf comes next, the peeked direction bit, and -- when
+            // the next doubling starts from the tree's OTHER edge -- the whole position (it does not depend on this leaf).
+            int spec_kind = 0;           // 0 none, 1 next leaf of the subtree, 2 / 3 next doubling from this leaf / from the other edge
+            float spec_ed = epsdir, spec_other = 0.0f;
+            if constexpr (SPEC) {
+                if (!init_pending) {
+                    if (snprop + 1 < (1 << depth)) spec_kind = 1;
+                    else if (depth + 1 < p.max_depth) {
+                        BlRng peek = rng_dir; // the real draw is made by the decisions
+                        const bool gr2 = (bl_rng_next(peek) >> 31) != 0u;
+                        spec_ed = gr2 ? eps : -eps;
+                        spec_kind = 2;
+                        if (gr2 != going_right) { // that edge is in LDS, untouched by the subtree in progress
+                            const int e = gr2 ? SV_ZR : SV_ZL;
+                            float rh2;
+                            bl_next_leaf(sv[e * 64], sv[(e + 1) * 64], sv[(e + 2) * 64], spec_ed, minv, rh2, spec_other);
+                            spec_kind = 3;
+                        }
+                    }
+                }
+            }
             // a first poll that misses costs a whole extra round trip: give the slowest peers' stores
             // a moment to land before looking
             for (int z = 0; z < p.first_delay; z++) __builtin_amdgcn_s_sleep(1);
@@ -632,29 +677,6 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 const double sx = bl_readlane_d(acc, D + 2), sxx = bl_readlane_d(acc, D + 3);
                 local = ((double)p.k * sxx == sx * sx); // exact: small integers
             }
-            // ------------------------------------------------ potential at cz (lane d) ----
-            // prior of lane d: pe2 = 2 x its energy, pg = d energy / d theta_d
-            //   Normal(loc, scale):            pe2 = (theta-loc)^2 / scale^2 ,  pg = (theta-loc) / scale^2
-            //   phi = logit f, f ~ Beta(a,b):  energy = a softplus(-phi) + b softplus(phi)  (Jacobian included),
-            //                                  pg = (a+b) sigmoid(phi) - a        (prior_loc = a, prior_isc2 = b)
-            const float dth = cz - prior_loc;
-            float pe2 = dth * dth * prior_isc2, pg = dth * prior_isc2;
-            if constexpr (MODEL == 2) {
-                if (is_phi) {
-                    const float e = bl_exp(-fabsf(cz)), op = 1.0f + e, l = bl_log(op);
-                    const float sig = (cz > 0.0f ? 1.0f : e) * bl_rcp(op);
-                    pe2 = 2.0f * (prior_loc * (fmaxf(-cz, 0.0f) + l) + prior_isc2 * (fmaxf(cz, 0.0f) + l));
-                    pg = (prior_loc + prior_isc2) * sig - prior_loc;
-                }
-            }
-            if constexpr (MODEL == 3) {
-                //   phi = log f, f ~ Exponential(rate r):  energy = r e^phi - phi  (Jacobian included),  pg = r e^phi - 1
-                if (is_phi) {
-                    const float rf = prior_loc * bl_exp(fminf(cz, 80.0f));
-                    pe2 = 2.0f * (rf - cz);
-                    pg = rf - 1.0f;
-                }
-            }
             const float cg = act ? (-(float)acc + pg) : 0.0f;
             p_acc = acc; p_cg = cg; p_pe2 = pe2; p_timed_out = timed_out;
             have_pending = true;
@@ -673,22 +695,12 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 if (lane == 0) sh_flag[0] = flag;
                 BL_STAMP_CRIT
             } else {
-            if (!init_pending && !timed_out) {
-                const float cr = bl_leaf_momentum(rh, epsdir, cg);
-                if (snprop + 1 < (1 << depth)) {
+            if (spec_kind != 0 && !timed_out) {
+                if (spec_kind == 3) cz_spec = spec_other;
+                else {
+                    const float cr = bl_leaf_momentum(rh, epsdir, cg);
                     float rh2;
-                    bl_next_leaf(cz, cr, cg, epsdir, minv, rh2, cz_spec);
-                } else if (depth + 1 < p.max_depth) {
-                    BlRng peek = rng_dir; // the real draw is made by the decisions
-                    const bool gr2 = (bl_rng_next(peek) >> 31) != 0u;
-                    const float ed2 = gr2 ? eps : -eps;
-                    float ez = cz, er = cr, eg = cg; // same side: the edge is the leaf just finished
-                    if (gr2 != going_right) {        // other side: that edge is in LDS, untouched by this subtree
-                        const int e = gr2 ? SV_ZR : SV_ZL;
-                        ez = sv[e * 64]; er = sv[(e + 1) * 64]; eg = sv[(e + 2) * 64];
-                    }
-                    float rh2;
-                    bl_next_leaf(ez, er, eg, ed2, minv, rh2, cz_spec);
+                    bl_next_leaf(cz, cr, cg, spec_ed, minv, rh2, cz_spec); // spec_ed = epsdir for the next leaf of the subtree
                 }
             }
             if (act && cz_spec == cz_spec) sh_coef[my_pos] = cz_spec;
