@@ -53,3 +53,16 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
                 assert "liboccu_oracle" not in src, f
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: the header must compile as C99 on its own (no C++ or HIP types in the signatures)."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    hdr = os.path.join(ROOT, "include", "biolith_hip.h")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
