@@ -1,0 +1,35 @@
+"""Resource usage of the compiled gfx950 kernels (hipcc cross-compiles without a GPU).
+
+The persistent kernels are written to live in registers: the per-lane tables of occu_rn (112 / 128 entries), the
+control wave's loop-carried state, and two site records per lane.  A change that tips one of them into scratch does
+not fail to build, it just gets slower -- or worse (occu_rn) -- so the budget is asserted here
+for the headline capacity pair and for the fullest one."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HIPCC = "/opt/rocm/bin/hipcc"
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
+         "-fgpu-flush-denormals-to-zero", "--cuda-device-only", "-S"]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+@pytest.mark.parametrize("ks,ko,max_scratch", [(3, 3, 0), (4, 4, 64)])
+def test_kernels_stay_in_registers(tmp_path, ks, ko, max_scratch):
+    out = tmp_path / "inst.s"
+    src = os.path.join(ROOT, "biolith_amd", "csrc", "kernels_inst.hip")
+    r = subprocess.run([HIPCC, *FLAGS, f"-DBL_KS={ks}", f"-DBL_KO={ko}", "-o", str(out), src], capture_output=True, text=True,
+                       cwd=os.path.join(ROOT, "biolith_amd", "csrc"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+    kernels = re.findall(r"^(_Z\w*bl_(?:nuts|logp)_kernel\w*):", text, flags=re.M)
+    scratch = [int(x) for x in re.findall(r"; ScratchSize: (\d+)", text)]
+    vgprs = [int(x) for x in re.findall(r"; NumVgprs: (\d+)", text)]
+    assert len(kernels) >= 16 and len(scratch) >= len(kernels)
+    assert max(scratch) <= max_scratch, sorted(scratch)[-3:]
+    assert max(vgprs) <= 256
