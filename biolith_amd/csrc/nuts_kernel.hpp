@@ -724,6 +724,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     }
     if (cold->dbg && chain == 0 && member == 0 && tid == 64) { // first compute wave: site-evaluation passes and their cycles
         cold->dbg[20] = st_sub[4]; cold->dbg[21] = st_sub[5];
+        if constexpr (MODEL == 1 || MODEL == 5) for (int i = 0; i < 8; i++) cold->dbg[22 + i] = bl_rn_dbg[i];
     }
 #endif
 }

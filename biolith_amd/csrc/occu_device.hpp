@@ -916,15 +916,6 @@ __device__ __forceinline__ int bl_wave_max_u(int x)
     return __builtin_amdgcn_readlane(x, 63);
 }
 
-// Largest n that can still matter when the best term is at least m_lb:  every term is bounded by the
-// (unnormalised) Poisson part n eta - lgamma(n+1) <= n (eta + 1 - log n)  (Stirling), which is <= -n once
-// n >= e^(eta+2); so beyond max(e^(eta+2), 25 - m_lb) each term is below e^-25 of the maximum.
-__device__ __forceinline__ int bl_rn_cutoff(float eta, float m_lb)
-{
-    const float nc = fmaxf(bl_exp_f(eta + 2.0f), 25.0f - m_lb) + 1.0f;
-    return (int)fminf(nc, 1.0e6f);
-}
-
 // lower bound of max_n (n a - lgamma(n+1)) over 1 <= n <= K: evaluate at the Poisson mode with
 // lgamma(n+1) <= (n + 1/2) ln n - n + 1  (n >= 1)
 __device__ __forceinline__ float bl_rn_mode_lb(float a, float K)
@@ -933,20 +924,35 @@ __device__ __forceinline__ float bl_rn_mode_lb(float a, float K)
     return fmaf(n1, a, -(fmaf(n1 + 0.5f, BL_LN2 * __builtin_amdgcn_logf(n1), 1.0f - n1)));
 }
 
-// n = 1 .. min(KB, NB-1) (NB: the enclosing function's table size), fully unrolled in blocks of 8, each block under a wave-uniform guard:
-// indices into the per-lane table stay static, blocks beyond the cutoff are skipped by a scalar branch.
+// n = 1 .. KB rounded up to a whole block of 4 (< NB, the enclosing function's table size), fully unrolled, each block
+// under a wave-uniform guard: indices into the per-lane table stay static, blocks beyond the cutoff are skipped by a
+// scalar branch, and there is NO guard per n (a hundred loop-invariant lane masks would be hoisted out of the visit loops and
+// spilled).  The cutoffs are numerical (terms below e^-20 of the sum), so up to three extra terms are harmless; the one
+// bound that is part of the model, n <= max_abundance, is applied where a term's weight is formed (bl_rn_lgamma_k).
 #define BL_RN_LOOP_BEGIN(KB)                                                            \
-    _Pragma("unroll") for (int nb_ = 1; nb_ < NB; nb_ += 8)                             \
+    _Pragma("unroll") for (int nb_ = 1; nb_ < NB; nb_ += 4)                             \
         if (nb_ <= (KB)) {                                                              \
-            _Pragma("unroll") for (int n = nb_; n < nb_ + 8; n++)                       \
-                if (n < NB && n <= (KB)) {
+            _Pragma("unroll") for (int n = nb_; n < nb_ + 4; n++)                       \
+                if (n < NB) {
 #define BL_RN_LOOP_END }}
+// lgamma(n+1), or a huge value for n > max_abundance so that the term's weight underflows to exactly 0.  Kv holds
+// max_abundance in a VECTOR register on purpose: a scalar compare per n would again become a hoisted, spilled mask.
+// The empty asm makes Kv opaque at every use: left alone, the compiler builds the whole masked table up front, once
+// per evaluation (NB x compare + select + register copy), although only the terms up to the cutoff are ever used.
+#define bl_rn_lgamma_k(n) ([&]() -> float { asm volatile("" : "+v"(Kv)); return ((float)(n) <= Kv) ? BL_LGAMMA1P[n] : 3.0e38f; }())
 // Two instantiations (chosen by the host from max_abundance), both free of scratch spills:
-//   NB = 128, GC = 1: max_abundance <= 127;   NB = 112, GC = 2: max_abundance <= 111 (the reference default is 100) --
+//   NB = 128, GC = 1: max_abundance <= 127;   NB = 104, GC = 2: max_abundance <= 103 (the reference default is 100) --
 // the 16 table registers saved pay for a second gradient recursion running beside the first.
-#define BL_RN_NB_SMALL 112
+#define BL_RN_NB_SMALL 104
 #define BL_RN_GA 10 // visits whose b_n recursions run side by side in pass A1 (one log per group and n)
+#define BL_RN_G0 5  // visits evaluated side by side in pass A0
 
+#ifdef BL_STAMPS
+static __device__ long long bl_rn_dbg[16];
+#define BL_RN_T(i) { const long long now_ = (long long)clock64(); if (st_on) bl_rn_dbg[i] += now_ - st_prev; st_prev = now_; }
+#else
+#define BL_RN_T(i)
+#endif
 template <int KS, int KO, int CT, int NB, int BL_RN_GC>
 __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, int T, int J, int K,
                                                  const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
@@ -958,6 +964,10 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
     const float LOG_TINY = -87.33654475f;
     // Every lane of a wave stays active through the loop (the cutoffs below are wave-level
     // reductions): lanes beyond the slice evaluate the last site again and are masked out.
+#ifdef BL_STAMPS
+    const bool st_on = blockIdx.x == 0 && threadIdx.x == 64;
+    long long st_prev = (long long)clock64();
+#endif
     for (int i0 = 0; i0 < cnt; i0 += CT) {
         if (i0 + (ct & ~63) >= cnt) continue; // wave-uniform: this wave has no site in this round
         const int i = min(i0 + ct, cnt - 1);
@@ -973,72 +983,106 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
         float ll_s = 0.0f, ga_s[KO + 1];
 #pragma unroll
         for (int k = 0; k <= KO; k++) ga_s[k] = 0.0f;
-        // renormalised truncated-Poisson prior: max, sum and mean of exp(n eta - lgamma(n+1)), n <= K.
-        // Kl: loose wave-uniform bound (Stirling); one scan over n <= Kl finds the exact maximum mz and
-        // the last n whose term is within e^-25 of a lower bound of it -> Kz.
-        const int Kl = min(K, bl_wave_max_u(bl_rn_cutoff(eta, 0.0f)));
-        const float mz_lb = bl_rn_mode_lb(eta, (float)K);
-        float mz = 0.0f; // n = 0 term
-        int nz = 0;
-        BL_RN_LOOP_BEGIN(Kl)
-            const float pn = fmaf((float)n, eta, -BL_LGAMMA1P[n]);
-            mz = fmaxf(mz, pn);
-            nz = (pn >= mz_lb - 25.0f) ? n : nz;
-        BL_RN_LOOP_END
-        const int Kz = min(Kl, bl_wave_max_u(nz));
-        float sz = bl_exp_f(-mz), b1 = 0.0f;
-        BL_RN_LOOP_BEGIN(Kz)
-            const float e = bl_exp_f(fmaf((float)n, eta, -BL_LGAMMA1P[n]) - mz);
-            sz += e;
-            b1 = fmaf((float)n, e, b1);
-        BL_RN_LOOP_END
-        const float rsz = __builtin_amdgcn_rcpf(sz);
-        const float log_z = mz + BL_LN2 * __builtin_amdgcn_logf(sz);
-        const float en_prior = b1 * rsz;
+        // Truncated-Poisson prior, p_n = n eta - lgamma(n+1), n <= K.  Its sums ride in the one scan over n that each
+        // period needs anyway (below); here only the shift of those sums: an upper bound of max_n p_n that is tight
+        // to a few nats -- lambda = e^eta while lambda <= K (Stirling: p_n <= lambda - 0.9), else p_K (p_n still rising at K).
+        float Kv = (float)K;
+        asm volatile("v_mov_b32 %0, %0" : "+v"(Kv));
+        const float lam = bl_exp_f(fminf(eta, 80.0f));
+        const float mzs = lam <= (float)K ? lam : fmaf((float)K, eta, -BL_LGAMMA1P[K]);
+        const float mz_lb = fmaxf(bl_rn_mode_lb(eta, (float)K), 0.0f); // lower bound of max_n p_n (p_0 = 0)
         float deta = 0.0f;
+        BL_RN_T(0)
         for (int t = 0; t < T; t++) {
             const float *pv = rec + 2 * (XQ + t * pb);
             float cnon = 0.0f, clr = 0.0f, ndet = 0.0f;
+            float lqmin = 0.0f; // smallest log q over the non-detections
             float Rv[KO + 1];
 #pragma unroll
             for (int k = 0; k <= KO; k++) Rv[k] = 0.0f;
             // ---- A0: visits, no sum over n yet.  u = c nu;  log sigma(u) = log r (detection) or log q (non-detection) ----
-            for (int j = 0; j < J; j++) {
-                float w[KO + 1];
+            // BL_RN_G0 visits side by side and branch-free: one wave per SIMD has nothing else to hide the dependent
+            // latencies (LDS read -> dot product -> exp -> log / rcp) behind.  A visit past J re-reads the last one as masked.
+            for (int j0 = 0; j0 < J; j0 += BL_RN_G0) {
 #pragma unroll
-                for (int k = 0; k <= KO; k++) w[k] = pv[2 * (j * (KO + 1) + k)];
-                const float c = w[0];
-                float u = c * alpha[0];
+                for (int g = 0; g < BL_RN_G0; g++) {
+                    const int j = min(j0 + g, J - 1);
+                    float w[KO + 1];
 #pragma unroll
-                for (int k = 1; k <= KO; k++) u = fmaf(w[k], alpha[k], u);
-                const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E), op = 1.0f + e;
-                const float logsig = fminf(u, 0.0f) - BL_LN2 * __builtin_amdgcn_logf(op);
-                const float sm = (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(op); // sigma(-u)
-                if (c > 0.0f) {
-                    clr += logsig;
-                    ndet += 1.0f;
-                } else if (c < 0.0f) {
-                    cnon += logsig;
+                    for (int k = 0; k <= KO; k++) w[k] = pv[2 * (j * (KO + 1) + k)];
+                    const float c = (j0 + g < J) ? w[0] : 0.0f;
+                    float u = w[0] * alpha[0];
+#pragma unroll
+                    for (int k = 1; k <= KO; k++) u = fmaf(w[k], alpha[k], u);
+                    const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E), op = 1.0f + e;
+                    const float logsig = fminf(u, 0.0f) - BL_LN2 * __builtin_amdgcn_logf(op);
+                    const float ld = c > 0.0f ? logsig : 0.0f, ln = c < 0.0f ? logsig : 0.0f;
+                    const float sm = c < 0.0f ? (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(op) : 0.0f; // sigma(-u)
+                    clr += ld;
+                    ndet += c > 0.0f ? 1.0f : 0.0f;
+                    cnon += ln;
+                    lqmin = fminf(lqmin, ln);
                     // d/dnu of n log q is -n r: rank-1; dnu * (1, w) = r E[n] * (c, c w)
 #pragma unroll
                     for (int k = 0; k <= KO; k++) Rv[k] = fmaf(sm, w[k], Rv[k]);
                 }
             }
+            BL_RN_T(1)
             const float a = eta + cnon;
             const float term0 = ndet * LOG_TINY; // n = 0: detections impossible -> numpyro's clamp tiny
-            // Every term_n is bounded above by the Poisson part p_n = n eta - lgamma(n+1) (all other parts
-            // are <= 0), and the best term is at least m_lb = max(term_0, term_1, term at the mode of
-            // n a - lgamma(n+1), with log b >= 0): keep n up to the last p_n >= m_lb - 25.
+            // Every term_n is bounded above by the Poisson part p_n = n eta - lgamma(n+1) plus the non-detections' share
+            // (the detections' log r + log b_n = log(1 - q^n) is <= 0), and the non-detections' floored sum (see below)
+            // is n cnon up to n* = FL / lqmin, where the first visit floors, and at most n* cnon beyond.  The best term
+            // is at least m_lb = max(term_0, term_1, term at the mode of n a - lgamma(n+1), with log b >= 0): keep n up
+            // to the last  p_n + cnon min(n, n*) >= m_lb - 20  (what is dropped is below 2e-9 of the sum, per term).
             const float m_lb = fmaxf(fmaxf(term0, a + clr), bl_rn_mode_lb(a, (float)K) + clr);
+            //
+            // numpyro floors a non-detection's log(1 - P) = n log q at log(eps_f32) = -15.94 (Bernoulli probabilities are
+            // clamped to [tiny, 1 - eps]): the visit's term is max(n log q_j, FL).  The sums below carry the un-floored
+            // n log q_j (rank one in n: it rides in `a`) and add the difference only for visits where the floor can be
+            // reached by a term that still matters.  Visit j is floored for n > FL / log q_j; the first visit to floor does
+            // so at n* = FL / lqmin, and from there on the floored sum (non-increasing in n) is <= n* cnon.  With
+            // log b_n <= log n per detection and Stirling's lgamma(n+1) >= n ln n - n + ln(2 pi n)/2, every term beyond
+            // t0 = FL / log q_j is <= clr + n* cnon + x(t),  x(t) = t (eta + 1 - ln t) + (ndet - 1/2) ln t - ln(2 pi)/2,
+            // concave in t: if x is already falling at t0 its supremum over t >= t0 is x(t0), and the floor of visit j
+            // matters only if that is within e^-17 of m_lb (below half an ulp of the float32 sum over n).  Where x is
+            // still rising at t0 (the floor starts below the Poisson mode) the visit takes the floor unconditionally.
+            const float FL = -15.942385f; // log(finfo(float32).eps)
+            const float thr_f = lqmin < 0.0f ? m_lb - clr - 17.0f - FL * cnon * __builtin_amdgcn_rcpf(lqmin) : 3.0e38f;
+            auto floor_matters = [&](float lq) -> bool { // lq = log q_j <= 0 of a non-detection (0: not one)
+                const float t0 = fmaxf(FL * __builtin_amdgcn_rcpf(fminf(lq, -1.0e-30f)), 1.0f);
+                const float lt = BL_LN2 * __builtin_amdgcn_logf(t0);
+                const float rising = eta - lt + (ndet - 0.5f) * __builtin_amdgcn_rcpf(t0);
+                const float xt = fmaf(t0, eta + 1.0f - lt, fmaf(ndet - 0.5f, lt, -0.9189385f));
+                return lq < 0.0f && t0 < (float)K && (rising > 0.0f || xt >= thr_f);
+            };
+            const float nstar = lqmin < 0.0f ? FL * __builtin_amdgcn_rcpf(lqmin) : 0.0f; // cnon = 0 when there is none
+            // Loose cutoff Kl (wave-uniform): both the prior sum and the posterior sum can drop every n with
+            // p_n < thr = min(mz_lb, m_lb) - 20.  For n > lambda, p_n <= lambda - 0.9 - (n - lambda)^2 / (n + lambda)
+            // (Stirling, and ln x >= 2 (x - 1) / (x + 1) for x >= 1), which is below thr once
+            // n - lambda > (Tq + sqrt(Tq^2 + 8 lambda Tq)) / 2,  Tq = lambda - 0.9 - thr > 0.
+            const float Tq = lam - 0.9f - (fminf(mz_lb, m_lb) - 20.0f);
+            const float dmax = 0.5f * (Tq + __builtin_amdgcn_sqrtf(fmaf(Tq, Tq, 8.0f * lam * Tq)));
+            const int Kl = min(K, bl_wave_max_u((int)fminf(lam + dmax + 2.0f, 1.0e6f)));
+            // ---- one scan over n <= Kl: prior sums, the posterior cutoff nw, and the table's starting values ----
+            // LP[n] (log2 units) starts as the part of term_n that needs no recursion: p_n + n cnon + clr; pass A1 adds the
+            // detections' log2 b_n, A1b the floor corrections.  n > K: lgamma is replaced by 3e38 and LP[n] = -inf (weight 0).
+            float LP[NB];
+            float sz = bl_exp_f(-mzs), b1 = 0.0f; // n = 0
             int nw = 1;
             BL_RN_LOOP_BEGIN(Kl)
-                nw = (fmaf((float)n, eta, -BL_LGAMMA1P[n]) >= m_lb - 25.0f) ? n : nw;
+                const float pn = fmaf((float)n, eta, -bl_rn_lgamma_k(n));
+                const float e = bl_exp_f(pn - mzs);
+                sz += e;
+                b1 = fmaf((float)n, e, b1);
+                nw = (fmaf(cnon, fminf((float)n, nstar), pn) >= m_lb - 20.0f) ? n : nw;
+                LP[n] = (pn + fmaf((float)n, cnon, clr)) * BL_LOG2E;
             BL_RN_LOOP_END
+            const float log_z = mzs + BL_LN2 * __builtin_amdgcn_logf(sz);
+            const float en_prior = b1 * __builtin_amdgcn_rcpf(sz);
             const int Kw = min(Kl, bl_wave_max_u(nw));
-            // ---- A1: LP[n] = sum over detection visits of log2 b_n ----
-            float LP[NB];
-#pragma unroll
-            for (int n = 0; n < NB; n++) LP[n] = 0.0f;
+            BL_RN_T(2)
+            // ---- A1: LP[n] += sum over detection visits of log2 b_n ----
             // Visits are taken BL_RN_GA at a time with their b_n recursions side by side (independent chains keep the
             // VALU busy; one wave per SIMD has no other wave to hide latencies) and ONE log per n for the group:
             // sum_j log b_jn = log prod_j b_jn (b <= n <= 127, so ten factors stay far inside float32).  A
@@ -1061,40 +1105,80 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
                         }
                     }
                     if (!__any(det)) continue; // no lane of the wave has a detection in this group
-                    float b[BL_RN_GA];
+                    // visits in pairs (packed fma / mul), the product as a tree: five recursions, four multiplies and one
+                    // log per n instead of a chain of nine dependent multiplies behind the recursions
+                    static_assert(BL_RN_GA == 10, "the product tree below is written for five pairs");
+                    bl_f2 b2[5], q2[5];
 #pragma unroll
-                    for (int g = 0; g < BL_RN_GA; g++) b[g] = 0.0f;
+                    for (int g = 0; g < 5; g++) { b2[g] = bl2(0.0f); q2[g] = bl_f2{q[2 * g], q[2 * g + 1]}; }
                     BL_RN_LOOP_BEGIN(Kw)
-                        float prod = 1.0f;
 #pragma unroll
-                        for (int g = 0; g < BL_RN_GA; g++) {
-                            b[g] = fmaf(b[g], q[g], 1.0f);
-                            prod *= b[g];
-                        }
-                        LP[n] += __builtin_amdgcn_logf(prod);
+                        for (int g = 0; g < 5; g++) b2[g] = bl_fma2(b2[g], q2[g], bl2(1.0f));
+                        const bl_f2 pp = ((b2[0] * b2[1]) * (b2[2] * b2[3])) * b2[4];
+                        LP[n] += __builtin_amdgcn_logf(pp.x * pp.y);
                     BL_RN_LOOP_END
                 }
             }
+            BL_RN_T(3)
+            // ---- A1b: visits whose floor matters somewhere in the wave: LP[n] += max(0, FL - n log q_j)  (log2 units) ----
+            unsigned long long floored = 0ull; // wave-uniform: bit j = visit j took the correction (j < 64)
+            // floor_matters is monotone in log q (a smaller t0 only raises the bound): a wave in which no site's smallest
+            // log q matters -- about half of them at the posterior -- skips the visit loop altogether.
+            const int Jf = __any(floor_matters(lqmin)) ? J : 0;
+            for (int j = 0; j < Jf; j++) {
+                const float *wv = pv + 2 * (j * (KO + 1));
+                float u = wv[0] * alpha[0];
+#pragma unroll
+                for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
+                const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E);
+                const float lq2 = wv[0] < 0.0f ? fminf(u, 0.0f) * BL_LOG2E - __builtin_amdgcn_logf(1.0f + e) : 0.0f;
+                if (!__any(floor_matters(BL_LN2 * lq2))) continue;
+                floored |= 1ull << (j & 63);
+                BL_RN_LOOP_BEGIN(Kw)
+                    LP[n] += fmaxf(fmaf(-(float)n, lq2, -23.0f), 0.0f); // log2(eps_f32) = -23
+                BL_RN_LOOP_END
+            }
+            BL_RN_T(4)
             // ---- B: sum over n ----
-            float m = term0;
+            float m = term0 * BL_LOG2E; // log2 units, like LP
             BL_RN_LOOP_BEGIN(Kw)
-                LP[n] = fmaf((float)n, a, fmaf(BL_LN2, LP[n], clr - BL_LGAMMA1P[n])); // term_n (prior unnormalised)
                 m = fmaxf(m, LP[n]);
             BL_RN_LOOP_END
-            const float t0 = bl_exp_f(term0 - m);
+            const float t0 = __builtin_amdgcn_exp2f(fmaf(term0, BL_LOG2E, -m));
             float s = t0, a1 = 0.0f;
             BL_RN_LOOP_BEGIN(Kw)
-                const float wn = bl_exp_f(LP[n] - m);
+                const float wn = __builtin_amdgcn_exp2f(LP[n] - m);
                 LP[n] = wn; // unnormalised posterior weight of N = n
                 s += wn;
                 a1 = fmaf((float)n, wn, a1);
             BL_RN_LOOP_END
+            BL_RN_T(5)
             const float rs = __builtin_amdgcn_rcpf(s);
-            ll_s += m + BL_LN2 * __builtin_amdgcn_logf(s) - log_z;
+            ll_s += BL_LN2 * (m + __builtin_amdgcn_logf(s)) - log_z;
             const float en_post = a1 * rs;
             deta += en_post - en_prior;
 #pragma unroll
             for (int k = 0; k <= KO; k++) ga_s[k] = fmaf(en_post, Rv[k], ga_s[k]);
+            // floored visits: d/du max(n log sigma(u), FL) vanishes for the floored n -- take their n w_n back out
+            for (int j = 0; j < Jf; j++) {
+                if (!((floored >> (j & 63)) & 1ull)) continue;
+                const float *wv = pv + 2 * (j * (KO + 1));
+                float u = wv[0] * alpha[0];
+#pragma unroll
+                for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
+                const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E), op = 1.0f + e;
+                const bool non = wv[0] < 0.0f;
+                const float lq2 = non ? fminf(u, 0.0f) * BL_LOG2E - __builtin_amdgcn_logf(op) : 0.0f;
+                const float sm = non ? (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(op) : 0.0f; // sigma(-u)
+                float hf = 0.0f;
+                BL_RN_LOOP_BEGIN(Kw)
+                    hf += ((float)n * lq2 < -23.0f) ? (float)n * LP[n] : 0.0f;
+                BL_RN_LOOP_END
+                const float dnu = -sm * hf * rs;
+#pragma unroll
+                for (int k = 0; k <= KO; k++) ga_s[k] = fmaf(dnu, wv[2 * k], ga_s[k]);
+            }
+            BL_RN_T(6)
             // ---- C: detection visits' d/dnu = sum_n w_n (q - q r b'_n / b_n),  b'_n = b'_(n-1) q + b_(n-1) ----
             if (__any(ndet > 0.0f)) {
                 for (int j0 = 0; j0 < J; j0 += BL_RN_GC) {
@@ -1140,6 +1224,7 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
                 }
             }
         }
+        BL_RN_T(7)
         deta *= live;
         ll = fmaf(live, ll_s, ll);
 #pragma unroll
@@ -1150,7 +1235,7 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
     }
 }
 
-// MODEL 0 = occu (occu.py), MODEL 1 / 5 = occu_rn (occu_rn.py; LDS records only; table of 128 / 112 entries);
+// MODEL 0 = occu (occu.py), MODEL 1 / 5 = occu_rn (occu_rn.py; LDS records only; table of 128 / 104 entries);
 // MODEL 2 (occu with false positives) is dispatched by bl_phase_a below
 template <int KS, int KO, bool LDS, int MODEL, int CT>
 __device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ grows, int ld_or_stride, int cnt, int T, int J, int K,

@@ -1,6 +1,6 @@
 """Resource usage of the compiled gfx950 kernels (hipcc cross-compiles without a GPU).
 
-The persistent kernels are written to live in registers: the per-lane tables of occu_rn (112 / 128 entries), the
+The persistent kernels are written to live in registers: the per-lane tables of occu_rn (104 / 128 entries), the
 control wave's loop-carried state, and two site records per lane.  A change that tips one of them into scratch does
 not fail to build, it just gets slower -- or worse (occu_rn) -- so the budget is asserted here
 for the headline capacity pair and for the fullest one."""
