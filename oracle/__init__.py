@@ -18,6 +18,7 @@ from .oracle import (  # noqa: F401
     literal_log_joint_cop,
     literal_log_joint_fp,
     literal_log_joint_nmix,
+    literal_log_joint_re,
     literal_log_joint_rn,
     nuts_run,
     rng_streams,

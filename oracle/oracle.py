@@ -50,9 +50,11 @@ def lib():
             L.orc_data_set_fp.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_cop.argtypes = [C.c_void_p, dp, dp, C.c_int, C.c_double]
             L.orc_data_set_nmix.argtypes = [C.c_void_p, dp, C.c_int]
+            L.orc_data_set_re.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
             L.orc_potential_grad.restype = C.c_double
             L.orc_potential_grad.argtypes = [C.c_void_p, dp, dp]
             L.orc_rng_streams.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
+            L.orc_rng_streams_strided.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
             L.orc_rng_next.restype = C.c_uint32
             L.orc_rng_next.argtypes = [C.POINTER(C.c_uint32)]
             L.orc_rng_jump.argtypes = [C.POINTER(C.c_uint32)]
@@ -84,7 +86,8 @@ class OracleData:
     """Prepared dataset for ONE species: site_covs (N,Ks), obs_covs (N,T,J,Ko), obs (N,T,J)."""
 
     def __init__(self, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0), model="occu",
-                 max_abundance=100, fp_mode="constant", prior_fp=(2.0, 5.0), session_duration=None, prior_fp_rate=1.0):
+                 max_abundance=100, fp_mode="constant", prior_fp=(2.0, 5.0), session_duration=None, prior_fp_rate=1.0,
+                 site_random_effects=False, obs_random_effects=False, prior_site_re_sd=1.0, prior_obs_re_sd=1.0):
         X = _as_f32_f64(site_covs)
         W = _as_f32_f64(obs_covs)
         Y = _as_f32_f64(obs)
@@ -104,7 +107,7 @@ class OracleData:
         self.X, self.W, self.Y = X, W, Y
         self.prior_beta, self.prior_alpha = tuple(prior_beta), tuple(prior_alpha)
         self.model, self.max_abundance = model, int(max_abundance)
-        assert model in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture")
+        assert model in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture", "occu_re")
         lib().orc_data_set_model(self._h, 1 if model == "occu_rn" else 0, int(max_abundance))
         if model == "occu_fp":  # theta gains phi = logit(false-positive rate) as its last coordinate
             assert fp_mode in ("constant", "unoccupied")
@@ -121,6 +124,14 @@ class OracleData:
                                    float(prior_fp_rate))
             self.D += 1 if fp_mode else 0
         self.fp_mode, self.prior_fp, self.prior_fp_rate = fp_mode, tuple(prior_fp), float(prior_fp_rate)
+        if model == "occu_re":
+            # theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_occ[N], site_re_det[N]), (obs_re[N][T][J])]
+            assert site_random_effects or obs_random_effects
+            lib().orc_data_set_re(self._h, int(bool(site_random_effects)), int(bool(obs_random_effects)),
+                                  float(prior_site_re_sd), float(prior_obs_re_sd))
+            self.D = int(lib().orc_data_dim(self._h))
+        self.site_re, self.obs_re = bool(site_random_effects), bool(obs_random_effects)
+        self.prior_site_re_sd, self.prior_obs_re_sd = float(prior_site_re_sd), float(prior_obs_re_sd)
 
     def __del__(self):
         try:
@@ -257,6 +268,66 @@ def literal_log_joint(theta, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), pr
         return (-0.5 * ((v - loc) / scale) ** 2 - np.log(scale) - 0.5 * np.log(2 * np.pi)).sum()
 
     return ll + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
+
+
+def literal_log_joint_re(theta, site_covs, obs_covs, obs, site_random_effects=True, obs_random_effects=False,
+                         prior_site_re_sd=1.0, prior_obs_re_sd=1.0, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):
+    """log density of occu with random effects (biolith/models/occu.py:170-173, 191-196, 215-218) in NumPyro's
+    unconstrained space, z summed by brute force.  theta = [beta, alpha, (log site_re_sd), (log obs_re_sd),
+    (site_re_occ[N], site_re_det[N]), (obs_re[N][T][J])]; a HalfNormal site lives on the log scale (+ log-Jacobian)."""
+    X, W, Y = (_as_f32_f64(a) for a in (site_covs, obs_covs, obs))
+    if Y.ndim == 4:
+        Y = Y[0]
+    N, Ks = X.shape
+    _, T, J, Ko = W.shape
+    theta = np.asarray(theta, dtype=np.float64)
+    at = Ks + Ko + 2
+    beta, alpha = theta[: Ks + 1], theta[Ks + 1: at]
+    lp = 0.0
+
+    def half_normal_on_log_scale(phi, scale):      # dist.HalfNormal(scale).log_prob(sd) + log|d sd / d phi|
+        sd = np.exp(phi)
+        return 0.5 * np.log(2.0 / np.pi) - np.log(scale) - 0.5 * (sd / scale) ** 2 + phi
+
+    def normal_logpdf(v, loc, scale):
+        return (-0.5 * ((v - loc) / scale) ** 2 - np.log(scale) - 0.5 * np.log(2 * np.pi)).sum()
+
+    sd_site = sd_obs = None
+    if site_random_effects:
+        lp += half_normal_on_log_scale(theta[at], prior_site_re_sd)
+        sd_site = np.exp(theta[at]); at += 1
+    if obs_random_effects:
+        lp += half_normal_on_log_scale(theta[at], prior_obs_re_sd)
+        sd_obs = np.exp(theta[at]); at += 1
+    re_occ = re_det = np.zeros(N)
+    obs_re = np.zeros((N, T, J))
+    if site_random_effects:
+        re_occ, re_det = theta[at: at + N], theta[at + N: at + 2 * N]
+        at += 2 * N
+        lp += normal_logpdf(re_occ, 0.0, sd_site) + normal_logpdf(re_det, 0.0, sd_site)
+    if obs_random_effects:
+        obs_re = theta[at: at + N * T * J].reshape(N, T, J)
+        at += N * T * J
+        lp += normal_logpdf(obs_re, 0.0, sd_obs)
+    assert at == theta.size
+    obs_mask = np.isnan(W).any(-1) | np.isnan(X).any(-1)[:, None, None]       # occu.py:136-142
+    Y = np.where(obs_mask, np.nan, Y)
+    W, X = np.nan_to_num(W), np.nan_to_num(X)
+    occ_linear = beta[0] + X @ beta[1:] + re_occ                               # occu.py:198-202
+    psi = 1.0 / (1.0 + np.exp(-occ_linear))
+    det_linear = alpha[0] + np.tensordot(W, alpha[1:], axes=([3], [0])) + re_det[:, None, None] + obs_re   # occu.py:221-228
+    finite = np.isfinite(Y)
+    y0 = np.where(finite, Y, 0.0)
+    per_z = []
+    for z in (0.0, 1.0):
+        if z == 1.0:   # exact log-sigmoid in the z = 1 branch, as literal_log_joint(clamp_z1=False)
+            ly = y0 * (-np.logaddexp(0.0, -det_linear)) + (1.0 - y0) * (-np.logaddexp(0.0, det_linear))
+        else:
+            ly = _bernoulli_logpmf_clamped(np.zeros_like(det_linear), y0)
+        ly = np.where(finite, ly, 0.0).sum(axis=2)
+        per_z.append(_bernoulli_logpmf_clamped(psi, z)[:, None] + ly)
+    ll = np.logaddexp(per_z[0], per_z[1]).sum()
+    return ll + lp + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
 
 
 def literal_log_joint_fp(theta, site_covs, obs_covs, obs, fp_mode="constant", prior_fp=(2.0, 5.0),

@@ -1,0 +1,78 @@
+"""Random-effects occupancy model (biolith/models/occu.py:170-173, 191-196, 215-218) -- oracle side, no GPU:
+the C oracle's potential against the literal NumPy model statement and against finite differences for the
+three option combinations, and its NUTS (vectors on the heap, one RNG stream per coordinate) on a small case."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import load_golden
+
+
+@pytest.mark.parametrize("name,site,obs,scales", [("small_3x3", True, False, (1.0, 1.0)), ("small_3x3", False, True, (1.0, 0.5)),
+                                                  ("missing", True, True, (0.7, 2.0))])
+def test_re_potential_equals_literal_model_and_fd(name, site, obs, scales):
+    g = load_golden(name)
+    N, T, J = g["obs"].shape[-3:]
+    kw = dict(site_random_effects=site, obs_random_effects=obs, prior_site_re_sd=scales[0], prior_obs_re_sd=scales[1])
+    od = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], model="occu_re", **kw)
+    G0 = g["site_covs"].shape[1] + g["obs_covs"].shape[3] + 2
+    assert od.D == G0 + site + obs + (2 * N if site else 0) + (N * T * J if obs else 0)
+    rng = np.random.default_rng(5)
+    for _ in range(2):
+        th = rng.uniform(-1.2, 1.2, size=od.D)
+        U, G = od.potential_grad(th)
+        lit = oracle.literal_log_joint_re(th, g["site_covs"], g["obs_covs"], g["obs"], **kw)
+        assert U == pytest.approx(-lit, rel=1e-12, abs=1e-9)
+        h = 1e-6
+        for k in list(range(G0 + site + obs)) + list(rng.integers(G0, od.D, size=12)):   # all globals, a sample of the effects
+            e = np.zeros(od.D); e[k] = h
+            fd = (od.potential_grad(th + e)[0] - od.potential_grad(th - e)[0]) / (2 * h)
+            assert abs(fd - G[k]) <= 2e-6 * max(1.0, np.max(np.abs(G))), (k, fd, G[k])
+
+
+def test_re_effects_at_zero_reduce_to_the_plain_model():
+    g = load_golden("small_3x3")
+    N = g["obs"].shape[-3]
+    od0 = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"])
+    od = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], model="occu_re", site_random_effects=True)
+    th = np.random.default_rng(0).uniform(-1, 1, size=od0.D)
+    phi = 0.3
+    U, G = od.potential_grad(np.concatenate([th, [phi], np.zeros(2 * N)]))
+    U0, G0 = od0.potential_grad(th)
+    sd = np.exp(phi)
+    prior = 0.5 * np.log(2 / np.pi) - 0.5 * sd ** 2 + phi + 2 * N * (-phi - 0.5 * np.log(2 * np.pi))
+    assert U == pytest.approx(U0 - prior, rel=1e-12)
+    assert np.allclose(G[: od0.D], G0, rtol=1e-12, atol=1e-12)
+
+
+def test_re_streams_do_not_collide_across_chains():
+    """D + 2 streams per chain (one per coordinate, then the two scalar streams): chain c starts c * stride jumps into
+    the one sequence of jumped states, so chain 1's streams are exactly the continuation of chain 0's."""
+    import ctypes as C
+
+    L = oracle.oracle.lib()
+    stride = 2112
+    both = np.zeros((2 * stride, 4), dtype=np.uint32)
+    L.orc_rng_streams_strided(7, 0, stride, 2 * stride, both.ctypes.data_as(C.POINTER(C.c_uint32)))
+    second = np.zeros((stride, 4), dtype=np.uint32)
+    L.orc_rng_streams_strided(7, 1, stride, stride, second.ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert np.array_equal(both[stride:], second)
+    assert len({tuple(r) for r in both}) == 2 * stride
+    small = np.zeros((64, 4), dtype=np.uint32)   # the small models' layout is the stride-64 case
+    L.orc_rng_streams(7, 1, 64, small.ctypes.data_as(C.POINTER(C.c_uint32)))
+    strided = np.zeros((64, 4), dtype=np.uint32)
+    L.orc_rng_streams_strided(7, 1, 64, 64, strided.ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert np.array_equal(small, strided)
+
+
+def test_re_oracle_nuts_recovers_a_sensible_posterior():
+    g = load_golden("small_3x3")
+    od = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], model="occu_re", site_random_effects=True)
+    r = oracle.nuts_run(od, 300, 300, num_chains=2, seed=0)
+    G0 = od.Ks + od.Ko + 2
+    sd = np.exp(r["draws"][:, :, G0])
+    assert np.all(np.isfinite(r["draws"])) and r["diverging"].mean() < 0.1
+    assert 0.05 < sd.mean() < 3.0
+    # fixed effects stay in the neighbourhood of the plain model's posterior mean
+    o0 = oracle.nuts_run(oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"]), 300, 300, num_chains=2, seed=0)
+    assert np.max(np.abs(r["draws"][:, :, :G0].mean((0, 1)) - o0["draws"].mean((0, 1)))) < 1.0
