@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "logp_kernel.hpp"
+#include "re_kernel.hpp"
 #include "nuts_kernel.hpp"
 
 // ------------------------------------------------------------------ errors ----
@@ -129,6 +130,21 @@ static void rng_streams(uint64_t seed, int chain, int nstreams, uint32_t *out)
     }
 }
 
+// Streams of `nchains` consecutive chains at `stride` streams per chain (stream (c, s) = base advanced by c * stride + s
+// jumps, like rng_streams with its stride of 64): out[(c - first_chain) * stride + s].
+static void rng_streams_strided(uint64_t seed, int first_chain, int stride, int nchains, uint32_t *out)
+{
+    uint64_t sm = seed;
+    const uint64_t a = splitmix64(sm), b = splitmix64(sm);
+    uint32_t s[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+    if (!(s[0] | s[1] | s[2] | s[3])) s[0] = 1;
+    for (long long k = 0; k < (long long)first_chain * stride; k++) xo_jump(s);
+    for (long long k = 0; k < (long long)nchains * stride; k++) {
+        memcpy(out + 4 * k, s, sizeof s);
+        xo_jump(s);
+    }
+}
+
 static int adaptation_schedule(int num_steps, int32_t *starts, int32_t *ends, int cap)
 {
     // numpyro.infer.hmc_util.build_adaptation_schedule
@@ -159,7 +175,10 @@ static int adaptation_schedule(int num_steps, int32_t *starts, int32_t *ends, in
 // ----------------------------------------------------------------- handle ----
 struct bl_dataset {
     int device = 0;
-    int model = 0;          // 0 occu, 1 occu_rn, 2 occu with false positives, 3 occu_cop, 4 nmixture
+    int model = 0;          // 0 occu, 1 occu_rn, 2 occu with false positives, 3 occu_cop, 4 nmixture, 6 occu with random effects
+    BlReModel re{};         // model 6 (re_kernel.hpp); D is then the full coordinate count
+    float *d_restate = nullptr; // model 6: sampler state [C][RE_SLOTS][D]
+    size_t restate_bytes = 0;
     float *d_tab = nullptr; // nmixture: B[t][n][site] = sum_j m log C(n, y_j), -inf below the largest count
     int ko_layout = 0;      // KO the record layout helpers are called with (KO, or KO + 1 for occu_cop's wider visits)
     int max_abundance = 0;  // occu_rn only
@@ -245,7 +264,7 @@ struct BlPredRng {
 __global__ void bl_predict_kernel(const float *__restrict__ rows, const float *__restrict__ wraw, int n_stride, int N, int T, int J,
                                   int Ks, int Ko, int D, const float *__restrict__ draws, int n0, int n1,
                                   unsigned long long seed, int model, int max_abundance, int fp_mode,
-                                  unsigned char *__restrict__ latent, unsigned char *__restrict__ y)
+                                  unsigned char *__restrict__ latent, unsigned char *__restrict__ y, int o_u, int o_v, int o_e)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -256,6 +275,7 @@ __global__ void bl_predict_kernel(const float *__restrict__ rows, const float *_
         const float *al = th + Ks + 1;
         float eta = th[0];
         for (int k = 0; k < Ks; k++) eta = fmaf(x[k], th[k + 1], eta);
+        if (o_u >= 0) eta += th[o_u + i]; // random effects (model 6; offsets into a draw, -1 = absent): occu.py:198-202, 221-228
         // false-positive rate (model 2): acts on every site ("constant") or on unoccupied ones only
         const float fpr = model == 2 ? 1.0f / (1.0f + __expf(-th[D - 1])) : 0.0f;
         const float f_c = fp_mode == BL_FP_CONSTANT ? fpr : 0.0f, f_u = fp_mode == BL_FP_UNOCCUPIED ? fpr : 0.0f;
@@ -286,6 +306,8 @@ __global__ void bl_predict_kernel(const float *__restrict__ rows, const float *_
                 const int v = t * J + j;
                 float nu = al[0];
                 for (int k = 0; k < Ko; k++) nu = fmaf(wraw[((size_t)v * Ko + k) * n_stride + i], al[k + 1], nu);
+                if (o_v >= 0) nu += th[o_v + i];
+                if (o_e >= 0) nu += th[o_e + (size_t)i * T * J + v];
                 const float r = 1.0f / (1.0f + __expf(-nu));
                 float pd = model == 1 ? 1.0f - __powf(1.0f - r, (float)zn) : (float)zn * r;
                 if (model == 2) pd = 1.0f - (1.0f - pd) * (1.0f - f_c) * (1.0f - (zn ? 0.0f : f_u));
@@ -325,7 +347,8 @@ extern "C" int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint6
         const int n1 = (n0 + chunk < n_draws) ? n0 + chunk : n_draws;
         const dim3 grid((N + 255) / 256, (n1 - n0) < 1024 ? (n1 - n0) : 1024);
         hipLaunchKernelGGL(bl_predict_kernel, grid, block, 0, nullptr, ds->d_rows, ds->d_wraw, ds->n_stride, N, T, J, ds->Ks, ds->Ko, D,
-                           d_draws, n0, n1, (unsigned long long)seed, ds->model, ds->max_abundance, ds->fp_mode, d_lat, d_y);
+                           d_draws, n0, n1, (unsigned long long)seed, ds->model, ds->max_abundance, ds->fp_mode, d_lat, d_y,
+                           ds->model == 6 ? ds->re.o_u : -1, ds->model == 6 ? ds->re.o_v : -1, ds->model == 6 ? ds->re.o_e : -1);
         BL_HIP(hipGetLastError());
         if (latent) BL_HIP(hipMemcpy(latent + (size_t)n0 * T * N, d_lat, (size_t)(n1 - n0) * T * N, hipMemcpyDeviceToHost));
         if (y) BL_HIP(hipMemcpy(y + (size_t)n0 * J * T * N, d_y, (size_t)(n1 - n0) * J * T * N, hipMemcpyDeviceToHost));
@@ -734,6 +757,7 @@ extern "C" int bl_dataset_destroy(bl_dataset *ds)
     if (ds->d_dur) hipFree(ds->d_dur);
     if (ds->d_run) hipFree(ds->d_run);
     if (ds->d_xchg) hipFree(ds->d_xchg);
+    if (ds->d_restate) hipFree(ds->d_restate);
     if (ds->h_abort) hipHostFree(ds->h_abort);
     if (ds->ev0) hipEventDestroy(ds->ev0);
     if (ds->ev1) hipEventDestroy(ds->ev1);
@@ -830,12 +854,76 @@ __global__ void bl_logp_final_kernel(BlDevData dd, int k, const double *theta, c
     if (lane == D) U[b] = -acc + prior + dd.prior_const;
 }
 
+extern "C" int bl_dataset_create_re(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
+                                    int site_random_effects, int obs_random_effects, double prior_site_re_sd_scale,
+                                    double prior_obs_re_sd_scale, const bl_normal_prior *prior_beta,
+                                    const bl_normal_prior *prior_alpha, int device, bl_dataset **out)
+{
+    if (!site_random_effects && !obs_random_effects)
+        return bl_fail(BL_ERR_INVALID, "bl_dataset_create_re: neither random effect requested (use bl_dataset_create)");
+    if (dims && (dims->n_site_covs > BL_RE_MAXK || dims->n_obs_covs > BL_RE_MAXK))
+        return bl_fail(BL_ERR_UNSUPPORTED, "random-effects kernels are built for at most %d covariates per side (Ks=%d, Ko=%d)",
+                       BL_RE_MAXK, dims->n_site_covs, dims->n_obs_covs);
+    if ((site_random_effects && !(prior_site_re_sd_scale > 0.0)) || (obs_random_effects && !(prior_obs_re_sd_scale > 0.0)))
+        return bl_fail(BL_ERR_INVALID, "HalfNormal prior needs scale > 0");
+    // the rows of the plain model (mask, NaN -> 0, sign folding) are exactly what the random-effects site pass reads
+    int rc = dataset_create_impl(ModelOpts{}, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
+    if (rc) return rc;
+    bl_dataset *ds = *out;
+    const int N = dims->n_sites, T = dims->n_periods, J = dims->n_replicates, Ks = ds->Ks, Ko = ds->Ko;
+    const long long Dll = (long long)Ks + Ko + 2 + (site_random_effects ? 1 + 2LL * N : 0) + (obs_random_effects ? 1 + (long long)N * T * J : 0);
+    if (Dll > (1LL << 24)) { bl_dataset_destroy(ds); *out = nullptr; return bl_fail(BL_ERR_UNSUPPORTED, "%lld coordinates", Dll); }
+    BlReModel &m = ds->re;
+    m.rows = ds->dd.rows; m.n_sites = N; m.n_stride = ds->dd.n_stride; m.T = T; m.J = J; m.Ks = Ks; m.Ko = Ko; m.KS = ds->KS; m.KO = ds->KO;
+    m.site_re = site_random_effects ? 1 : 0; m.obs_re = obs_random_effects ? 1 : 0;
+    m.G0 = Ks + Ko + 2; m.G = m.G0 + m.site_re + m.obs_re; m.D = (int)Dll;
+    int at = m.G0;
+    m.o_phi_s = m.site_re ? at++ : -1;
+    m.o_phi_o = m.obs_re ? at++ : -1;
+    m.o_u = m.o_v = m.o_e = -1;
+    if (m.site_re) { m.o_u = at; m.o_v = at + N; at += 2 * N; }
+    if (m.obs_re) { m.o_e = at; at += N * T * J; }
+    m.loc_b = ds->dd.loc_b; m.isc2_b = ds->dd.isc2_b; m.loc_a = ds->dd.loc_a; m.isc2_a = ds->dd.isc2_a;
+    m.hn_is2_s = site_random_effects ? (float)(1.0 / (prior_site_re_sd_scale * prior_site_re_sd_scale)) : 0.0f;
+    m.hn_is2_o = obs_random_effects ? (float)(1.0 / (prior_obs_re_sd_scale * prior_obs_re_sd_scale)) : 0.0f;
+    const double HL2PI = 0.91893853320467274178, HN0 = 0.5 * std::log(2.0 / 3.14159265358979323846);
+    m.u_const = ds->dd.prior_const;
+    if (m.site_re) m.u_const += -HN0 + std::log(prior_site_re_sd_scale) + 2.0 * N * HL2PI;
+    if (m.obs_re) m.u_const += -HN0 + std::log(prior_obs_re_sd_scale) + (double)N * T * J * HL2PI;
+    int tps = 1;
+    while (tps < 64 && 2 * tps * N <= BL_RE_NT && 2 * tps <= J) tps *= 2; // spare threads share a site's visits
+    m.tps = tps;
+    ds->model = 6; ds->D = m.D;
+    return BL_OK;
+}
+
+static int re_logp_grad(bl_dataset *ds, int B, const double *theta, double *U, double *grad)
+{
+    const size_t D = ds->D;
+    std::vector<float> th32((size_t)B * D);
+    for (size_t i = 0; i < th32.size(); i++) th32[i] = (float)theta[i];
+    float *d_th = nullptr, *d_work = nullptr;
+    double *d_U = nullptr, *d_grad = nullptr;
+    DevScratch scratch;
+    BL_HIP(scratch.alloc((void **)&d_th, th32.size() * 4));
+    BL_HIP(scratch.alloc((void **)&d_work, (size_t)B * 2 * D * 4));
+    BL_HIP(scratch.alloc((void **)&d_U, (size_t)B * 8));
+    BL_HIP(scratch.alloc((void **)&d_grad, (size_t)B * D * 8));
+    BL_HIP(hipMemcpy(d_th, th32.data(), th32.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(bl_re_logp_kernel, dim3(B), dim3(BL_RE_NT), 0, nullptr, ds->re, B, d_th, d_work, d_U, d_grad);
+    BL_HIP(hipGetLastError());
+    BL_HIP(hipMemcpy(U, d_U, (size_t)B * 8, hipMemcpyDeviceToHost));
+    BL_HIP(hipMemcpy(grad, d_grad, (size_t)B * D * 8, hipMemcpyDeviceToHost));
+    return BL_OK;
+}
+
 extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *U, double *grad, int staged)
 {
     if (!ds || !theta || !U || !grad || B <= 0) return bl_fail(BL_ERR_INVALID, "bl_logp_grad: bad argument");
     if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
     int rc = set_device(ds);
     if (rc) return rc;
+    if (ds->model == 6) return re_logp_grad(ds, B, theta, U, grad);
     const int D = ds->D;
     int k, nloc, ld, lds_bytes, can_stage, ncw, wide;
     choose_geometry(ds, 1, 0, &k, &nloc, &ld, &lds_bytes, &can_stage, &ncw, &wide);
@@ -874,6 +962,78 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
 // ------------------------------------------------------------------- NUTS ----
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
+// Random-effects model: one workgroup per chain, sampler state in device memory (re_kernel.hpp).  Outputs land in the
+// same run-slab fields as the other models', so poll / wait / fetch are shared.
+static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t st, int max_depth)
+{
+    const int C = cfg->num_chains, S = cfg->num_samples, W = cfg->num_warmup;
+    const size_t D = ds->D, Sa = S > 0 ? S : 1;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
+    const size_t o_draws = carve((size_t)C * Sa * D * 4), o_div = carve((size_t)C * Sa), o_steps = carve((size_t)C * Sa * 4),
+                 o_acc = carve((size_t)C * Sa * 4), o_pot = carve((size_t)C * Sa * 4), o_eps = carve((size_t)C * 4),
+                 o_minv = carve((size_t)C * D * 4), o_nleap = carve((size_t)C * 16), o_status = carve(16),
+                 o_rng = carve((size_t)C * (D + 2) * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(32 * 8),
+                 o_run = carve(sizeof(BlReRun));
+    if (off > ds->run_bytes) {
+        if (ds->d_run) hipFree(ds->d_run);
+        ds->d_run = nullptr; ds->run_bytes = 0;
+        BL_HIP(hipMalloc(&ds->d_run, off));
+        ds->run_bytes = off;
+    }
+    const size_t state_bytes = (size_t)C * RE_SLOTS * D * 4;
+    if (state_bytes > ds->restate_bytes) {
+        if (ds->d_restate) hipFree(ds->d_restate);
+        ds->d_restate = nullptr; ds->restate_bytes = 0;
+        BL_HIP(hipMalloc((void **)&ds->d_restate, state_bytes));
+        ds->restate_bytes = state_bytes;
+    }
+    char *base = (char *)ds->d_run;
+    ds->d_draws = (float *)(base + o_draws); ds->d_div = (unsigned char *)(base + o_div); ds->d_steps = (int *)(base + o_steps);
+    ds->d_acc = (float *)(base + o_acc); ds->d_pot = (float *)(base + o_pot); ds->d_eps = (float *)(base + o_eps);
+    ds->d_minv = (float *)(base + o_minv); ds->d_nleap = (long long *)(base + o_nleap); ds->d_status = (int *)(base + o_status);
+    ds->d_rng = (uint32_t *)(base + o_rng); ds->d_init = (float *)(base + o_init); ds->d_dbg = (long long *)(base + o_dbg);
+    ds->d_loc = nullptr;
+
+    // one stream per coordinate, then the scalar and the direction stream; chains are D + 2 streams apart (>= 64)
+    const int stride = (int)D + 2;
+    std::vector<uint32_t> rs((size_t)C * stride * 4);
+    rng_streams_strided(cfg->seed, cfg->chain_offset, stride, C, rs.data());
+    BL_HIP(hipMemcpyAsync(ds->d_rng, rs.data(), rs.size() * 4, hipMemcpyHostToDevice, st));
+    std::vector<float> it32;
+    if (cfg->init_theta) {
+        it32.resize((size_t)C * D);
+        for (size_t i = 0; i < it32.size(); i++) it32[i] = (float)cfg->init_theta[i];
+        BL_HIP(hipMemcpyAsync(ds->d_init, it32.data(), it32.size() * 4, hipMemcpyHostToDevice, st));
+    }
+    BlReRun run{};
+    run.m = ds->re;
+    run.num_chains = C; run.num_warmup = W; run.num_samples = S; run.max_depth = max_depth;
+    run.target_accept = (float)(cfg->target_accept > 0.0 ? cfg->target_accept : 0.8);
+    int32_t ws[32], we[32];
+    run.nwin = adaptation_schedule(W, ws, we, 32);
+    if (run.nwin > 32) return bl_fail(BL_ERR_INVALID, "adaptation schedule too long");
+    for (int i = 0; i < 32; i++) run.win_end[i] = i < run.nwin ? we[i] : 0x7fffffff;
+    run.state = ds->d_restate; run.rng = ds->d_rng;
+    run.init_theta = cfg->init_theta ? ds->d_init : nullptr;
+    run.abort_flag = ds->d_abort;
+    run.draws = ds->d_draws; run.diverging = ds->d_div; run.num_steps = ds->d_steps; run.accept_prob = ds->d_acc;
+    run.potential = ds->d_pot; run.step_size = ds->d_eps; run.inv_mass = ds->d_minv; run.nleap = ds->d_nleap; run.status = ds->d_status;
+    BlReRun *d_runp = (BlReRun *)(base + o_run);
+    BL_HIP(hipMemcpyAsync(d_runp, &run, sizeof run, hipMemcpyHostToDevice, st));
+    BL_HIP(hipStreamSynchronize(st));
+    *ds->h_abort = 0;
+    BL_HIP(hipEventRecord(ds->ev0, st));
+    BL_HIP(hipMemsetAsync(ds->d_status, 0, 16, st));
+    BL_HIP(hipMemsetAsync(ds->d_dbg, 0, 256, st));
+    hipLaunchKernelGGL(bl_re_nuts_kernel, dim3(C), dim3(BL_RE_NT), 0, st, d_runp);
+    BL_HIP(hipGetLastError());
+    BL_HIP(hipEventRecord(ds->ev1, st));
+    ds->stream = st; ds->in_flight = true; ds->have_run = true;
+    ds->C = C; ds->S = S; ds->W = W; ds->k = 1; ds->nloc = ds->re.n_sites; ds->lds_ld = 0; ds->lds_bytes = 0; ds->staged = 0; ds->nvp = 0; ds->ncw = BL_RE_NW;
+    return BL_OK;
+}
+
 extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *stream)
 {
     if (!ds || !cfg) return bl_fail(BL_ERR_INVALID, "NULL argument");
@@ -886,6 +1046,8 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     if (cfg->chain_offset < 0) return bl_fail(BL_ERR_INVALID, "chain_offset < 0");
     int rc = set_device(ds);
     if (rc) return rc;
+
+    if (ds->model == 6) return re_nuts_launch(ds, cfg, (hipStream_t)stream, max_depth);
 
     int k, nloc, ld, lds_bytes, staged;
     int ncw, wide;
@@ -1092,12 +1254,12 @@ extern "C" int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads
     if (!ds) return bl_fail(BL_ERR_INVALID, "NULL argument");
     if (!ds->have_run) return bl_fail(BL_ERR_INVALID, "no NUTS launch on this handle");
     if (wgs_per_chain) *wgs_per_chain = ds->k;
-    if (threads_per_wg) *threads_per_wg = 64 * (ds->ncw + 1);
+    if (threads_per_wg) *threads_per_wg = ds->model == 6 ? BL_RE_NT : 64 * (ds->ncw + 1);
     if (lds_bytes) *lds_bytes = ds->lds_bytes;
     if (lds_staged) *lds_staged = ds->staged;
     if (chains_on_l2_local_exchange) {
         *chains_on_l2_local_exchange = 0;
-        if (!ds->in_flight) {
+        if (!ds->in_flight && ds->d_loc) {
             std::vector<int> loc(ds->C, 0);
             BL_HIP(hipMemcpy(loc.data(), ds->d_loc, (size_t)ds->C * 4, hipMemcpyDeviceToHost));
             for (int v : loc) *chains_on_l2_local_exchange += v;
@@ -1108,8 +1270,10 @@ extern "C" int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads
 
 // ------------------------------------------------- deterministic sites ----
 // psi[n][t][i] = sigmoid(beta0 + x_i . beta)      (occu.py:198-207; constant over t)
+// With random effects (model 6; offsets o_u / o_v / o_e into a draw, -1 = absent, external coordinate order) the site's
+// occupancy effect joins eta, its detection effect and the replicate's effect join nu (occu.py:198-202, 221-228).
 __global__ void bl_psi_kernel(const float *__restrict__ rows, int n_stride, int N, int T, int Ks, int D,
-                              const float *__restrict__ draws, int n0, int n1, float *__restrict__ psi, int model)
+                              const float *__restrict__ draws, int n0, int n1, float *__restrict__ psi, int model, int o_u)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -1119,6 +1283,7 @@ __global__ void bl_psi_kernel(const float *__restrict__ rows, int n_stride, int 
         const float *th = draws + (size_t)n * D;
         float eta = th[0];
         for (int k = 0; k < Ks; k++) eta = fmaf(x[k], th[k + 1], eta);
+        if (o_u >= 0) eta += th[o_u + i];
         // occu: psi = sigmoid(eta) (occu.py:207); occu_rn: abundance = exp(eta) (occu_rn.py:192)
         const float v = (model == 1 || model == 4) ? __expf(eta) : 1.0f / (1.0f + __expf(-eta));
         for (int t = 0; t < T; t++) psi[((size_t)(n - n0) * T + t) * N + i] = v;
@@ -1126,17 +1291,20 @@ __global__ void bl_psi_kernel(const float *__restrict__ rows, int n_stride, int 
 }
 // prob_detection[n][j][t][i] = sigmoid(alpha0 + w_itj . alpha)   (occu.py:221-228)
 __global__ void bl_pdet_kernel(const float *__restrict__ wraw, int n_stride, int N, int T, int J, int Ks, int Ko, int D,
-                               const float *__restrict__ draws, int n0, int n1, float *__restrict__ out, int model)
+                               const float *__restrict__ draws, int n0, int n1, float *__restrict__ out, int model, int o_v, int o_e)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     for (int n = n0 + blockIdx.y; n < n1; n += gridDim.y) {
         const float *al = draws + (size_t)n * D + Ks + 1;
+        const float *th = draws + (size_t)n * D;
         for (int t = 0; t < T; t++)
             for (int j = 0; j < J; j++) {
                 const int v = t * J + j;
                 float nu = al[0];
                 for (int k = 0; k < Ko; k++) nu = fmaf(wraw[((size_t)v * Ko + k) * n_stride + i], al[k + 1], nu);
+                if (o_v >= 0) nu += th[o_v + i];
+                if (o_e >= 0) nu += th[o_e + (size_t)i * T * J + v];
                 // occu / occu_rn: prob_detection = sigmoid(nu); occu_cop: rate_detection = exp(nu) (occu_cop.py:236-243)
                 out[(((size_t)(n - n0) * J + j) * T + t) * N + i] = model == 3 ? __expf(nu) : 1.0f / (1.0f + __expf(-nu));
             }
@@ -1169,12 +1337,13 @@ extern "C" int bl_deterministic(bl_dataset *ds, int n_draws, const float *draws,
         const int n1 = (n0 + chunk < n_draws) ? n0 + chunk : n_draws;
         const dim3 grid((N + 255) / 256, (n1 - n0) < 1024 ? (n1 - n0) : 1024);
         if (psi) {
-            hipLaunchKernelGGL(bl_psi_kernel, grid, block, 0, nullptr, ds->d_rows, ds->n_stride, N, T, ds->Ks, D, d_draws, n0, n1, d_out, ds->model);
+            hipLaunchKernelGGL(bl_psi_kernel, grid, block, 0, nullptr, ds->d_rows, ds->n_stride, N, T, ds->Ks, D, d_draws, n0, n1, d_out, ds->model, ds->model == 6 ? ds->re.o_u : -1);
             BL_HIP(hipGetLastError());
             BL_HIP(hipMemcpy(psi + (size_t)n0 * T * N, d_out, (size_t)(n1 - n0) * T * N * 4, hipMemcpyDeviceToHost));
         }
         if (prob_detection) {
-            hipLaunchKernelGGL(bl_pdet_kernel, grid, block, 0, nullptr, ds->d_wraw, ds->n_stride, N, T, J, ds->Ks, ds->Ko, D, d_draws, n0, n1, d_out, ds->model);
+            hipLaunchKernelGGL(bl_pdet_kernel, grid, block, 0, nullptr, ds->d_wraw, ds->n_stride, N, T, J, ds->Ks, ds->Ko, D, d_draws, n0, n1, d_out, ds->model,
+                               ds->model == 6 ? ds->re.o_v : -1, ds->model == 6 ? ds->re.o_e : -1);
             BL_HIP(hipGetLastError());
             BL_HIP(hipMemcpy(prob_detection + (size_t)n0 * J * T * N, d_out, (size_t)(n1 - n0) * J * T * N * 4, hipMemcpyDeviceToHost));
         }

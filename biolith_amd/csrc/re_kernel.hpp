@@ -1,0 +1,540 @@
+// re_kernel.hpp -- occupancy model with site / observation random effects (biolith/models/occu.py:170-173, 191-196,
+// 215-218): log-density + gradient, and NUTS over all D = Ks + Ko + 2 (+1 +1) + 2 N + N T J coordinates.
+//
+// Shape of the problem: D runs to thousands, so the lane-per-coordinate design of nuts_kernel.hpp does not apply.  Here a
+// chain is ONE workgroup; every vector of the sampler (position, momentum, gradient, tree edges, proposals, checkpoints,
+// mass matrix, Welford moments) is an array of length D in device memory (L2-resident: 40 D floats per chain), threads
+// own coordinates d = tid, tid + NT, ...; scalars of the sampler are kept redundantly by every thread (all threads see the
+// same reduced sums in LDS and take the same decisions), so nothing is broadcast.  Per leapfrog: two vector passes, one
+// site pass, two block reductions.  The arithmetic follows the oracle (oracle/occu_oracle.c: potential_grad_re,
+// orc_nuts_run) statement by statement; RNG: one xoshiro stream per coordinate (external order) + the two scalar streams.
+//
+// The site data are the sign-folded rows the plain occu kernels read (occu_device.hpp: bl_eval_sites_hbm): a visit's
+// record is (c, c w_1 .. c w_KO), c = +1 detection / -1 non-detection / 0 masked, so a random effect enters a visit's
+// u = c nu as c (v_i + e_itj).
+#pragma once
+#include "nuts_kernel.hpp"
+
+#define BL_RE_NT 256             // threads per chain
+#define BL_RE_NW (BL_RE_NT / 64)
+#define BL_RE_MAXK 4             // covariates per side (as the false-positive model)
+#define BL_RE_NRED 26            // widest block reduction
+
+struct BlReModel {
+    const float *rows;
+    int n_sites, n_stride, T, J, Ks, Ko, KS, KO;
+    int site_re, obs_re;
+    int G0, G, D;                         // fixed effects, + log sds, all coordinates
+    int o_phi_s, o_phi_o, o_u, o_v, o_e;  // offsets (internal order = external order except inside the obs_re block)
+    float loc_b, isc2_b, loc_a, isc2_a;   // Normal priors of beta / alpha
+    float hn_is2_s, hn_is2_o;             // 1 / scale^2 of the HalfNormal priors of site_re_sd / obs_re_sd
+    double u_const;                       // the constant part of the potential
+    int tps;                              // threads that share one site in the site pass (power of two, <= 64)
+};
+
+// slots of the per-chain state block, each D floats
+enum {
+    RE_CZ = 0, RE_CR, RE_CG,                       // leaf in flight: position, momentum (half step, then full), gradient
+    RE_TH, RE_GR,                                  // position / gradient the transition started from
+    RE_ZL, RE_RL, RE_GL, RE_ZR, RE_RR, RE_GRR,     // tree edges
+    RE_ZP, RE_GP, RE_SZP, RE_SGP,                  // proposals: tree, subtree
+    RE_RSUM, RE_SRSUM,                             // momentum sums: tree, subtree
+    RE_MINV, RE_WFMEAN, RE_WFM2,                   // diagonal mass matrix, Welford moments
+    RE_CKR,                                        // BL_MAX_DEPTH checkpoints of r, then BL_MAX_DEPTH of the running sum
+    RE_SLOTS = RE_CKR + 2 * BL_MAX_DEPTH
+};
+
+struct BlReRun {
+    BlReModel m;
+    int num_chains, num_warmup, num_samples, max_depth, nwin;
+    int win_end[32];
+    float target_accept;
+    float *state;               // [C][RE_SLOTS][D]
+    uint32_t *rng;              // [C][D + 2][4]: stream of external coordinate e at index e, then scalar, direction
+    const float *init_theta;    // [C][D] external order, or NULL
+    const int *abort_flag;
+    float *draws;               // [C][S][D] external order
+    unsigned char *diverging; int *num_steps; float *accept_prob, *potential, *step_size, *inv_mass;
+    long long *nleap; int *status;
+};
+
+// internal coordinate -> external (oracle / caller) coordinate: obs_re is kept site-fastest inside, replicate-fastest outside
+__device__ __forceinline__ int bl_re_ext(const BlReModel &m, int d)
+{
+    if (!m.obs_re || d < m.o_e) return d;
+    const int r = d - m.o_e, v = r / m.n_sites, i = r - v * m.n_sites;
+    return m.o_e + i * (m.T * m.J) + v;
+}
+
+// Sum NV per-thread values over the workgroup: DPP wave sums, then a fixed-order f64 sum of the wave partials.
+// out[] (LDS) is valid for every thread on return.
+template <int NV>
+__device__ __forceinline__ void bl_re_block_sum(float (&v)[NV], float *scr /*[NW][NRED]*/, double *out /*[NRED]*/)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const float s = bl_wave_sum(v[k]);
+        if (lane == 0) scr[wave * BL_RE_NRED + k] = s;
+    }
+    __syncthreads();
+    if (tid < NV) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < BL_RE_NW; w++) s += (double)scr[w * BL_RE_NRED + tid];
+        out[tid] = s;
+    }
+    __syncthreads();
+}
+
+// Site pass at position z: per-thread partials of the log-likelihood and of its gradient w.r.t. beta / alpha, and the
+// random effects' full potential gradient written to g (the effect's own likelihood term + its Normal(0, sd) prior).
+// part[0] = ll, part[1 .. 5] = d/d beta, part[6 .. 10] = d/d alpha.
+__device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float *__restrict__ z, float *__restrict__ g, float (&part)[11])
+{
+    const int tid = threadIdx.x, tps = m.tps, grp = tid / tps, sub = tid - grp * tps, ngrp = BL_RE_NT / tps;
+    const int N = m.n_sites, ns = m.n_stride, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 1;
+    const float *rows = m.rows;
+    float beta[BL_RE_MAXK + 1], alpha[BL_RE_MAXK + 1];
+#pragma unroll
+    for (int k = 0; k <= BL_RE_MAXK; k++) {
+        beta[k] = k <= Ks ? z[k] : 0.0f;
+        alpha[k] = k <= Ko ? z[Ks + 1 + k] : 0.0f;
+    }
+    const float isd2_s = m.site_re ? bl_exp(-2.0f * z[m.o_phi_s]) : 0.0f;
+    const float isd2_o = m.obs_re ? bl_exp(-2.0f * z[m.o_phi_o]) : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 11; k++) part[k] = 0.0f;
+    const int row_ka = m.KS + T * J * vw, row_kb = row_ka + T;
+    const int rounds = (N + ngrp - 1) / ngrp;
+    for (int rd = 0; rd < rounds; rd++) {
+        const int i_raw = rd * ngrp + grp;
+        const bool live = i_raw < N;
+        const int i = live ? i_raw : N - 1; // idle groups shadow the last site (their results are dropped)
+        float x[BL_RE_MAXK];
+        float eta = beta[0];
+#pragma unroll
+        for (int k = 0; k < BL_RE_MAXK; k++) {
+            x[k] = k < Ks ? rows[(size_t)k * ns + i] : 0.0f;
+            eta = fmaf(x[k], beta[k + 1], eta);
+        }
+        const float ui = m.site_re ? z[m.o_u + i] : 0.0f, vi = m.site_re ? z[m.o_v + i] : 0.0f;
+        eta += ui;
+        const float ee = bl_exp(-fabsf(eta)), lop = bl_log(1.0f + ee);
+        const float log_psi = fminf(eta, 0.0f) - lop, log_1mpsi = fminf(-eta, 0.0f) - lop;
+        const float psi = (eta > 0.0f ? 1.0f : ee) * bl_rcp(1.0f + ee);
+        float dl_deta = 0.0f, dl_dv = 0.0f;
+        for (int t = 0; t < T; t++) {
+            float a = 0.0f, ga[BL_RE_MAXK + 1];
+#pragma unroll
+            for (int k = 0; k <= BL_RE_MAXK; k++) ga[k] = 0.0f;
+            for (int j = sub; j < J; j += tps) {
+                const int v = t * J + j;
+                const size_t r0 = (size_t)(m.KS + v * vw) * ns + i;
+                const float c = rows[r0];
+                float w[BL_RE_MAXK + 1];
+                w[0] = c;
+                float u = c * alpha[0];
+#pragma unroll
+                for (int k = 1; k <= BL_RE_MAXK; k++) {
+                    w[k] = k <= Ko ? rows[r0 + (size_t)k * ns] : 0.0f;
+                    u = fmaf(w[k], alpha[k], u);
+                }
+                const float eo = m.obs_re ? z[m.o_e + v * N + i] : 0.0f;
+                u = fmaf(c, vi + eo, u);
+                const float e = bl_exp(-fabsf(u)), op = 1.0f + e;
+                a += fminf(u, 0.0f) - bl_log(op);
+                const float s = (u > 0.0f ? e : 1.0f) * bl_rcp(op); // sigma(-u): d log sigma(u) / du
+#pragma unroll
+                for (int k = 0; k <= BL_RE_MAXK; k++) ga[k] = fmaf(s, w[k], ga[k]);
+                if (m.obs_re && live) g[m.o_e + v * N + i] = s * c; // d a / d nu of this visit; scaled by q below
+            }
+            for (int msk = 1; msk < tps; msk <<= 1) { // the site's threads pool their visits
+                a += __shfl_xor(a, msk);
+#pragma unroll
+                for (int k = 0; k <= BL_RE_MAXK; k++) ga[k] += __shfl_xor(ga[k], msk);
+            }
+            const float ka = rows[(size_t)(row_ka + t) * ns + i], kb = rows[(size_t)(row_kb + t) * ns + i];
+            const float A = log_psi + a + ka, B = log_1mpsi + kb;
+            const float l = bl_logaddexp(A, B);
+            const float q = bl_exp(A - l);
+            if (live && sub == 0) {
+                part[0] += l;
+#pragma unroll
+                for (int k = 0; k <= BL_RE_MAXK; k++) part[6 + k] = fmaf(q, ga[k], part[6 + k]);
+            }
+            dl_deta += q - psi;
+            dl_dv = fmaf(q, ga[0], dl_dv);
+            if (m.obs_re && live) {
+                __threadfence_block(); // this thread's own stores above, read back here
+                for (int j = sub; j < J; j += tps) {
+                    const int d = m.o_e + (t * J + j) * N + i;
+                    g[d] = fmaf(z[d], isd2_o, -q * g[d]);
+                }
+            }
+        }
+        if (live && sub == 0) {
+            part[1] += dl_deta;
+#pragma unroll
+            for (int k = 0; k < BL_RE_MAXK; k++) part[2 + k] = fmaf(dl_deta, x[k], part[2 + k]);
+            if (m.site_re) {
+                g[m.o_u + i] = fmaf(ui, isd2_s, -dl_deta);
+                g[m.o_v + i] = fmaf(vi, isd2_s, -dl_dv);
+            }
+        }
+    }
+}
+
+// Potential gradient of a fixed effect / log sd coordinate d < G at position z, from the reduced sums of the site pass
+// (red[0..10]) and of the effects' squares (red[11] = sum u^2 + v^2, red[12] = sum e^2).
+__device__ __forceinline__ float bl_re_global_grad(const BlReModel &m, int d, float zd, const double *red)
+{
+    if (d < m.G0) {
+        const bool is_b = d <= m.Ks;
+        const float loc = is_b ? m.loc_b : m.loc_a, isc2 = is_b ? m.isc2_b : m.isc2_a;
+        const double gl = red[is_b ? 1 + d : 6 + (d - m.Ks - 1)];
+        return (float)(-gl) + (zd - loc) * isc2;
+    }
+    const bool site = m.site_re && d == m.o_phi_s;
+    const float isd2 = bl_exp(-2.0f * zd), sd2 = bl_exp(2.0f * zd);
+    const float cnt = site ? 2.0f * (float)m.n_sites : (float)m.n_sites * (float)(m.T * m.J);
+    const float ssq = (float)red[site ? 11 : 12];
+    // U = sd^2 / (2 s^2) - phi + sum_k (x_k^2 / (2 sd^2) + phi):   dU/dphi = sd^2 / s^2 - 1 - ssq / sd^2 + cnt
+    return sd2 * (site ? m.hn_is2_s : m.hn_is2_o) - 1.0f - ssq * isd2 + cnt;
+}
+
+// Potential at z from the reduced sums (f64): red[0] = log-lik, pe2 = sum over fixed effects of ((z - loc) / scale)^2
+__device__ __forceinline__ double bl_re_potential(const BlReModel &m, const float *z, const double *red, double pe2)
+{
+    double U = -red[0] + 0.5 * pe2 + m.u_const;
+    if (m.site_re) {
+        const float phi = z[m.o_phi_s];
+        U += 0.5 * (double)(bl_exp(2.0f * phi) * m.hn_is2_s) - (double)phi + 0.5 * red[11] * (double)bl_exp(-2.0f * phi) + 2.0 * m.n_sites * (double)phi;
+    }
+    if (m.obs_re) {
+        const float phi = z[m.o_phi_o];
+        U += 0.5 * (double)(bl_exp(2.0f * phi) * m.hn_is2_o) - (double)phi + 0.5 * red[12] * (double)bl_exp(-2.0f * phi)
+             + (double)m.n_sites * (m.T * m.J) * (double)phi;
+    }
+    return U;
+}
+
+// sum of squares of the random effects owned by this thread at position z -> ss[0] (site), ss[1] (obs)
+__device__ __forceinline__ void bl_re_effect_squares(const BlReModel &m, const float *z, float (&ss)[2])
+{
+    ss[0] = 0.0f; ss[1] = 0.0f;
+    for (int d = m.G + threadIdx.x; d < m.D; d += BL_RE_NT) {
+        const float x = z[d];
+        if (m.obs_re && d >= m.o_e) ss[1] = fmaf(x, x, ss[1]);
+        else ss[0] = fmaf(x, x, ss[0]);
+    }
+}
+
+// ---- parity hook: U and dU/dtheta for B positions (external order in, external order out), one workgroup each ----
+__global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel m, int B, const float *__restrict__ theta,
+                                                              float *__restrict__ work /*[B][2][D]*/, double *__restrict__ U, double *__restrict__ grad)
+{
+    __shared__ float scr[BL_RE_NW * BL_RE_NRED];
+    __shared__ double red[BL_RE_NRED];
+    const int b = blockIdx.x, tid = threadIdx.x, D = m.D;
+    if (b >= B) return;
+    float *z = work + (size_t)b * 2 * D, *g = z + D;
+    for (int d = tid; d < D; d += BL_RE_NT) z[d] = theta[(size_t)b * D + bl_re_ext(m, d)];
+    __syncthreads();
+    float v[13], part[11], ss[2];
+    bl_re_site_pass(m, z, g, part);
+    bl_re_effect_squares(m, z, ss);
+#pragma unroll
+    for (int k = 0; k < 11; k++) v[k] = part[k];
+    v[11] = ss[0]; v[12] = ss[1];
+    bl_re_block_sum<13>(v, scr, red);
+    float pe[1] = {0.0f};
+    for (int d = tid; d < m.G; d += BL_RE_NT) {
+        const float zd = z[d];
+        g[d] = bl_re_global_grad(m, d, zd, red);
+        if (d < m.G0) {
+            const bool is_b = d <= m.Ks;
+            const float t = zd - (is_b ? m.loc_b : m.loc_a);
+            pe[0] = fmaf(t * t, is_b ? m.isc2_b : m.isc2_a, pe[0]);
+        }
+    }
+    __shared__ float scr2[BL_RE_NW * BL_RE_NRED];
+    __shared__ double red2[BL_RE_NRED];
+    bl_re_block_sum<1>(pe, scr2, red2);
+    if (tid == 0) U[b] = bl_re_potential(m, z, red, red2[0]);
+    for (int d = tid; d < D; d += BL_RE_NT) grad[(size_t)b * D + bl_re_ext(m, d)] = (double)g[d];
+}
+
+// ------------------------------------------------------------------------------------------------ NUTS ----
+__global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__restrict__ rp)
+{
+    __shared__ float scr[BL_RE_NW * BL_RE_NRED];
+    __shared__ double red[BL_RE_NRED], red2[BL_RE_NRED];
+    const BlReRun &R = *rp;
+    const BlReModel m = R.m;
+    const int chain = blockIdx.x, tid = threadIdx.x, D = m.D, G = m.G;
+    if (chain >= R.num_chains) return;
+    float *sv = R.state + (size_t)chain * RE_SLOTS * D;
+    auto V = [&](int slot) -> float * { return sv + (size_t)slot * D; };
+    uint32_t *rng_base = R.rng + (size_t)chain * (D + 2) * 4;
+    const int S = R.num_samples, W = R.num_warmup, total = W + S;
+
+    BlRng rng_u, rng_dir; // every thread carries its own copy of the two scalar streams and advances it identically
+    {
+        const uint32_t *a = rng_base + (size_t)D * 4, *b = a + 4;
+        rng_u.s0 = a[0]; rng_u.s1 = a[1]; rng_u.s2 = a[2]; rng_u.s3 = a[3];
+        rng_dir.s0 = b[0]; rng_dir.s1 = b[1]; rng_dir.s2 = b[2]; rng_dir.s3 = b[3];
+    }
+    auto rng_load = [&](int d) { const uint32_t *s = rng_base + (size_t)bl_re_ext(m, d) * 4; BlRng r; r.s0 = s[0]; r.s1 = s[1]; r.s2 = s[2]; r.s3 = s[3]; return r; };
+    auto rng_store = [&](int d, const BlRng &r) { uint32_t *s = rng_base + (size_t)bl_re_ext(m, d) * 4; s[0] = r.s0; s[1] = r.s1; s[2] = r.s2; s[3] = r.s3; };
+
+    // sampler scalars (identical in every thread)
+    float eps = 1.0f, epsdir = 1.0f;
+    int depth = 0, snprop = 0, it = 0;
+    bool sturn = false, sdiv = false, going_right = false;
+    double E0 = 0.0, Ucur = 0.0, sUp = 0.0, Up = 0.0;
+    float swt = 0.f, ssumacc = 0.f, wt = 0.f, sumacc = 0.f;
+    int nprop = 0;
+    float da_prox = 2.302585093f, da_gavg = 0.f, da_xt = 0.f, da_xavg = 0.f; // log(10 * step_size0)
+    int da_t = 0, win_idx = 0, wf_n = 0;
+    long long nleap_w = 0, nleap_s = 0;
+    int flag = 0;
+
+    // evaluate the potential and its gradient at V(RE_CZ) into V(RE_CG); returns U (same value in every thread)
+    auto evaluate = [&]() -> double {
+        float v[13], part[11], ss[2];
+        const float *z = V(RE_CZ);
+        float *g = V(RE_CG);
+        bl_re_site_pass(m, z, g, part);
+        bl_re_effect_squares(m, z, ss);
+#pragma unroll
+        for (int k = 0; k < 11; k++) v[k] = part[k];
+        v[11] = ss[0]; v[12] = ss[1];
+        bl_re_block_sum<13>(v, scr, red);
+        float pe[1] = {0.0f};
+        for (int d = tid; d < G; d += BL_RE_NT) {
+            const float zd = z[d];
+            g[d] = bl_re_global_grad(m, d, zd, red);
+            if (d < m.G0) {
+                const bool is_b = d <= m.Ks;
+                const float t = zd - (is_b ? m.loc_b : m.loc_a);
+                pe[0] = fmaf(t * t, is_b ? m.isc2_b : m.isc2_a, pe[0]);
+            }
+        }
+        bl_re_block_sum<1>(pe, scr, red2); // (its barriers also publish g[d < G])
+        return bl_re_potential(m, z, red, red2[0]);
+    };
+
+    // momentum r ~ N(0, M), fresh tree, first doubling; leaves the first leaf's start in CZ / CR / CG
+    auto new_transition = [&]() {
+        float kin[1] = {0.0f};
+        for (int d = tid; d < D; d += BL_RE_NT) {
+            const float th = V(RE_TH)[d], gr = V(RE_GR)[d], mi = V(RE_MINV)[d];
+            BlRng r = rng_load(d);
+            const float z01 = bl_rng_normal(r);
+            rng_store(d, r);
+            const float r0 = z01 * __builtin_amdgcn_rsqf(mi);
+            kin[0] = fmaf(mi * r0, r0, kin[0]);
+            V(RE_ZL)[d] = th; V(RE_RL)[d] = r0; V(RE_GL)[d] = gr;
+            V(RE_ZR)[d] = th; V(RE_RR)[d] = r0; V(RE_GRR)[d] = gr;
+            V(RE_ZP)[d] = th; V(RE_GP)[d] = gr; V(RE_RSUM)[d] = r0;
+            V(RE_CZ)[d] = th; V(RE_CR)[d] = r0; V(RE_CG)[d] = gr;
+        }
+        bl_re_block_sum<1>(kin, scr, red2);
+        E0 = Ucur + 0.5 * red2[0];
+        Up = Ucur; wt = 0.f; sumacc = 0.f; nprop = 0; depth = 0;
+        going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
+        epsdir = going_right ? eps : -eps;
+        snprop = 0; sturn = false; sdiv = false;
+    };
+
+    // ---- initial position: init_to_uniform(radius = 2) from each coordinate's own stream (always consumed) ----
+    for (int d = tid; d < D; d += BL_RE_NT) {
+        BlRng r = rng_load(d);
+        const float u0 = bl_rng_uniform(r);
+        rng_store(d, r);
+        V(RE_CZ)[d] = R.init_theta ? R.init_theta[(size_t)chain * D + bl_re_ext(m, d)] : 4.0f * u0 - 2.0f;
+        V(RE_MINV)[d] = 1.0f; V(RE_WFMEAN)[d] = 0.0f; V(RE_WFM2)[d] = 0.0f;
+    }
+    __syncthreads();
+    Ucur = evaluate();
+    for (int d = tid; d < D; d += BL_RE_NT) { V(RE_TH)[d] = V(RE_CZ)[d]; V(RE_GR)[d] = V(RE_CG)[d]; }
+    __syncthreads();
+    if (total <= 0) flag = 1;
+    else new_transition();
+    __syncthreads();
+
+    while (flag == 0) {
+        // ---- leaf: half step of the momentum, full step of the position (hmc_util velocity Verlet) ----
+        for (int d = tid; d < D; d += BL_RE_NT) {
+            float rh, zn;
+            bl_next_leaf(V(RE_CZ)[d], V(RE_CR)[d], V(RE_CG)[d], epsdir, V(RE_MINV)[d], rh, zn);
+            V(RE_CZ)[d] = zn; V(RE_CR)[d] = rh;
+        }
+        __syncthreads();
+        const double Un = evaluate();
+        if (it < W) nleap_w++; else nleap_s++;
+        // ---- second half step; kinetic energy; subtree momentum sum; U-turn dot products for every checkpoint this
+        //      leaf closes (_leaf_idx_to_ckpt_idxs) and for the whole tree if the subtree ends here ----
+        const int leaf_idx = snprop;
+        const int idx_max = __popc((unsigned)leaf_idx >> 1);
+        const int idx_min = idx_max - (int)__builtin_ctz(~(unsigned)leaf_idx) + 1;
+        const bool odd = (leaf_idx & 1) != 0;
+        float acc[BL_RE_NRED];
+#pragma unroll
+        for (int k = 0; k < BL_RE_NRED; k++) acc[k] = 0.0f;
+        for (int d = tid; d < D; d += BL_RE_NT) {
+            const float mi = V(RE_MINV)[d];
+            const float cr = bl_leaf_momentum(V(RE_CR)[d], epsdir, V(RE_CG)[d]);
+            V(RE_CR)[d] = cr;
+            acc[0] = fmaf(mi * cr, cr, acc[0]);
+            const float srs = leaf_idx == 0 ? cr : V(RE_SRSUM)[d] + cr;
+            V(RE_SRSUM)[d] = srs;
+            if (!odd) {
+                V(RE_CKR + idx_max)[d] = cr;
+                V(RE_CKR + BL_MAX_DEPTH + idx_max)[d] = srs;
+            } else {
+#pragma unroll
+                for (int q = 0; q < BL_MAX_DEPTH; q++) {
+                    const int i = idx_min + q;
+                    if (i <= idx_max) {
+                        const float ck = V(RE_CKR + i)[d];
+                        const float s_i = srs - V(RE_CKR + BL_MAX_DEPTH + i)[d] + ck;
+                        const float rho = s_i - 0.5f * (ck + cr);
+                        acc[2 + 2 * q] = fmaf(mi * ck, rho, acc[2 + 2 * q]);
+                        acc[3 + 2 * q] = fmaf(mi * cr, rho, acc[3 + 2 * q]);
+                    }
+                }
+            }
+            const float r_other = going_right ? V(RE_RL)[d] : V(RE_RR)[d];
+            const float rl = going_right ? r_other : cr, rr = going_right ? cr : r_other;
+            const float rho_t = (V(RE_RSUM)[d] + srs) - 0.5f * (rl + rr);
+            acc[22] = fmaf(mi * rl, rho_t, acc[22]);
+            acc[23] = fmaf(mi * rr, rho_t, acc[23]);
+        }
+        bl_re_block_sum<BL_RE_NRED>(acc, scr, red2);
+        // ---- decisions (_build_basetree tail, _iterative_build_subtree, _combine_tree, _double_tree) ----
+        double dE = (Un + 0.5 * red2[0]) - E0;
+        if (dE != dE) dE = (double)INFINITY;
+        sdiv = dE > 1000.0;
+        snprop = leaf_idx + 1;
+        const float fdE = (float)dE;
+        const float lw = -fdE, lacc = fdE <= 0.0f ? 1.0f : bl_exp(-fdE);
+        bool take = true; // this leaf becomes the subtree's proposal
+        if (leaf_idx == 0) { swt = lw; ssumacc = lacc; }
+        else {
+            float pr, lse;
+            bl_merge_weights(swt, lw, lse, pr);
+            const float u = bl_rng_uniform(rng_u);
+            take = u < pr;
+            swt = lse; ssumacc += lacc;
+        }
+        if (take) sUp = Un;
+        if (odd) {
+#pragma unroll
+            for (int q = 0; q < BL_MAX_DEPTH; q++)
+                if (idx_min + q <= idx_max) sturn = sturn || red2[2 + 2 * q] <= 0.0 || red2[3 + 2 * q] <= 0.0;
+        }
+        const bool sub_done = !(snprop < (1 << depth) && !sturn && !sdiv);
+        bool take2 = false, cont = false, trans_end = false;
+        const bool was_right = going_right;
+        int nprop_out = 0; float accp = 0.f;
+        if (sub_done) {
+            const bool turning = sturn || red2[22] <= 0.0 || red2[23] <= 0.0;
+            float pr = fminf(1.0f, bl_exp(swt - wt));
+            if (sturn || sdiv) pr = 0.0f;
+            const float u = bl_rng_uniform(rng_u);
+            take2 = u < pr;
+            if (take2) Up = sUp;
+            wt = bl_logaddexp(wt, swt);
+            sumacc += ssumacc;
+            nprop += snprop;
+            depth++;
+            cont = depth < R.max_depth && !turning && !sdiv;
+            trans_end = !cont;
+            if (cont) {
+                going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
+                epsdir = going_right ? eps : -eps;
+                snprop = 0; sturn = false;
+            }
+        }
+        // ---- transition end: scalar part of the warmup adapter (hmc_util.warmup_adapter.update_fn) ----
+        bool wf_update = false, wf_close = false;
+        const int it_done = it;
+        const bool div_out = sdiv;
+        if (trans_end) {
+            nprop_out = nprop;
+            accp = sumacc * bl_rcp((float)nprop);
+            Ucur = Up;
+            if (it < W) {
+                const float gdiff = R.target_accept - accp;
+                da_t += 1;
+                const float tt = (float)da_t, rt10 = bl_rcp(tt + 10.0f);
+                da_gavg = (1.0f - rt10) * da_gavg + gdiff * rt10;
+                da_xt = da_prox - __builtin_amdgcn_sqrtf(tt) * 20.0f * da_gavg;
+                const float wgt = __builtin_amdgcn_exp2f(-0.75f * __builtin_amdgcn_logf(tt));
+                da_xavg = (1.0f - wgt) * da_xavg + wgt * da_xt;
+                eps = bl_exp((it == W - 1) ? da_xavg : da_xt);
+                eps = fminf(fmaxf(eps, 1.1754944e-38f), 3.4028235e+38f);
+                const bool middle = win_idx > 0 && win_idx < R.nwin - 1;
+                if (middle) { wf_n += 1; wf_update = true; }
+                const bool at_end = it == R.win_end[win_idx];
+                if (at_end) win_idx++;
+                wf_close = at_end && middle;
+            }
+            it++;
+            if (it >= total) flag = 1;
+            if (R.abort_flag && *(volatile const int *)R.abort_flag) flag = 5;
+        }
+        // ---- vector part of the same decisions ----
+        const float wfn = (float)wf_n;
+        for (int d = tid; d < D; d += BL_RE_NT) {
+            const float cz = V(RE_CZ)[d], cg = V(RE_CG)[d], cr = V(RE_CR)[d];
+            float szp = V(RE_SZP)[d], sgp = V(RE_SGP)[d];
+            if (take) { szp = cz; sgp = cg; V(RE_SZP)[d] = szp; V(RE_SGP)[d] = sgp; }
+            if (!sub_done) continue;
+            V(was_right ? RE_ZR : RE_ZL)[d] = cz; V(was_right ? RE_RR : RE_RL)[d] = cr; V(was_right ? RE_GRR : RE_GL)[d] = cg;
+            V(RE_RSUM)[d] += V(RE_SRSUM)[d];
+            if (take2) { V(RE_ZP)[d] = szp; V(RE_GP)[d] = sgp; }
+            if (cont) {
+                V(RE_CZ)[d] = V(going_right ? RE_ZR : RE_ZL)[d];
+                V(RE_CR)[d] = V(going_right ? RE_RR : RE_RL)[d];
+                V(RE_CG)[d] = V(going_right ? RE_GRR : RE_GL)[d];
+                continue;
+            }
+            const float th = V(RE_ZP)[d];
+            V(RE_TH)[d] = th; V(RE_GR)[d] = V(RE_GP)[d];
+            if (wf_update) {
+                const float mean0 = V(RE_WFMEAN)[d], dpre = th - mean0;
+                const float mean = mean0 + dpre * bl_rcp(wfn);
+                V(RE_WFMEAN)[d] = mean;
+                V(RE_WFM2)[d] += dpre * (th - mean);
+            }
+            if (wf_close) {
+                const float var = V(RE_WFM2)[d] * bl_rcp(wfn - 1.0f), rn5 = bl_rcp(wfn + 5.0f);
+                V(RE_MINV)[d] = wfn * rn5 * var + 1e-3f * 5.0f * rn5;
+                V(RE_WFMEAN)[d] = 0.0f; V(RE_WFM2)[d] = 0.0f;
+            }
+            if (it_done >= W) R.draws[((size_t)chain * S + (it_done - W)) * D + bl_re_ext(m, d)] = th;
+        }
+        if (trans_end) {
+            if (wf_close) {
+                wf_n = 0; da_xt = 0.f; da_xavg = 0.f; da_gavg = 0.f; da_t = 0;
+                da_prox = bl_log(10.0f * eps);
+            }
+            if (it_done >= W && tid == 0) {
+                const size_t s = (size_t)chain * S + (it_done - W);
+                R.num_steps[s] = nprop_out; R.accept_prob[s] = accp;
+                R.diverging[s] = div_out ? 1 : 0; R.potential[s] = (float)Ucur;
+            }
+        }
+        __syncthreads();
+        if (trans_end && flag == 0) { new_transition(); __syncthreads(); }
+    }
+    for (int d = tid; d < D; d += BL_RE_NT) R.inv_mass[(size_t)chain * D + bl_re_ext(m, d)] = V(RE_MINV)[d];
+    if (tid == 0) {
+        if (flag > 1) atomicMax(R.status, flag);
+        R.step_size[chain] = eps;
+        R.nleap[chain * 2 + 0] = nleap_w; R.nleap[chain * 2 + 1] = nleap_s;
+    }
+}

@@ -32,6 +32,21 @@ class Exponential:
     rate: float = 1.0
 
 
+def as_half_normal(prior, name: str = "prior") -> float:
+    """scale of a HalfNormal prior; duck-types numpyro's ``dist.HalfNormal`` (has .scale, no .loc)."""
+    if type(prior).__name__ != "HalfNormal" or not hasattr(prior, "scale"):
+        raise NotImplementedError(f"{name}: the HIP engine supports HalfNormal(scale) priors here, got {prior!r}")
+    import numpy as np
+
+    scale = np.asarray(prior.scale, dtype=float)
+    if scale.size != 1:
+        raise NotImplementedError(f"{name}: scalar scale only")
+    scale = float(scale.reshape(()))
+    if not scale > 0:
+        raise ValueError(f"{name}: scale must be positive")
+    return scale
+
+
 def as_exponential(prior, name: str = "prior") -> float:
     """rate of an Exponential prior; duck-types numpyro's ``dist.Exponential`` (has .rate)."""
     if type(prior).__name__ != "Exponential" or not hasattr(prior, "rate"):

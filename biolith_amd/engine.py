@@ -51,9 +51,10 @@ class OccuDataset:
 
     def __init__(self, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0), device: int = 0,
                  model: str = "occu", max_abundance: int = 100, fp_mode: Optional[str] = "constant", prior_fp=(2.0, 5.0),
-                 session_duration=None, prior_fp_rate: float = 1.0):
+                 session_duration=None, prior_fp_rate: float = 1.0, site_random_effects: bool = False,
+                 obs_random_effects: bool = False, prior_site_re_sd: float = 1.0, prior_obs_re_sd: float = 1.0):
         lib = _ffi.load()
-        if model not in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture"):
+        if model not in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture", "occu_re"):
             raise ValueError(f"unknown model {model!r}")
         if fp_mode not in ("constant", "unoccupied") and not (model == "occu_cop" and fp_mode is None):
             raise ValueError(f"unknown fp_mode {fp_mode!r}")
@@ -100,6 +101,16 @@ class OccuDataset:
             mode = {None: 0, "constant": _ffi.FP_CONSTANT, "unoccupied": _ffi.FP_UNOCCUPIED}[fp_mode]
             _ffi.check(lib.bl_dataset_create_cop(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), _fp(Dur), mode,
                                                  float(prior_fp_rate), C.byref(pb), C.byref(pa), device, C.byref(h)))
+        elif model == "occu_re":
+            # theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_occ[N], site_re_det[N]), (obs_re[N][T][J])]
+            if not (site_random_effects or obs_random_effects):
+                raise ValueError("occu_re needs site_random_effects and / or obs_random_effects")
+            _ffi.check(lib.bl_dataset_create_re(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), int(bool(site_random_effects)),
+                                                int(bool(obs_random_effects)), float(prior_site_re_sd), float(prior_obs_re_sd),
+                                                C.byref(pb), C.byref(pa), device, C.byref(h)))
+            d = C.c_int()
+            _ffi.check(lib.bl_dataset_param_dim(h, C.byref(d)))
+            self.D = int(d.value)
         elif model == "occu_fp":
             pf = _ffi.bl_beta_prior(*self.prior_fp)
             mode = _ffi.FP_CONSTANT if fp_mode == "constant" else _ffi.FP_UNOCCUPIED
@@ -110,6 +121,7 @@ class OccuDataset:
                                              device, C.byref(h)))
         self._h = h
         self._lib = lib
+        self.site_re, self.obs_re = bool(site_random_effects), bool(obs_random_effects)
 
     def close(self):
         if getattr(self, "_h", None):

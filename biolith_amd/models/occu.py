@@ -16,7 +16,7 @@ from typing import Any, Optional
 
 import numpy as np
 
-from ..distributions import Beta, HalfNormal, Normal, as_beta, as_normal
+from ..distributions import Beta, HalfNormal, Normal, as_beta, as_half_normal, as_normal
 from ..regression import AbstractRegression, LinearRegression
 from ._generators import Generator, expit, observed_mean, within
 
@@ -66,8 +66,10 @@ def occu(
     """Bernoulli occupancy model (MacKenzie et al. 2002), z marginalised, on the HIP engine.
 
     Same parameters as the reference (biolith/models/occu.py:19-40).  Supported here: the default
-    option path -- linear regressors on both sides, Normal priors, no spatial effect, no random
-    effects -- plus ``false_positives_constant`` / ``false_positives_unoccupied`` with a Beta prior on the
+    option path -- linear regressors on both sides, Normal priors, no spatial effect -- plus
+    ``site_random_effects`` / ``obs_random_effects`` with HalfNormal priors on their sds (occu.py:170-173, 191-196,
+    215-218; one species, at most 4 covariates per side, not together with false positives) and
+    ``false_positives_constant`` / ``false_positives_unoccupied`` with a Beta prior on the
     rate (occu.py:146-157, 229-241; one species, at most 4 covariates per side); several species are sampled species by species (their joint density
     factorises over the ``species`` plate, occu.py:182-186).  Anything else raises ``NotImplementedError`` (the
     engine has no silent fallback).  ``coords=None`` / any ``ell`` are accepted and ignored, as the
@@ -111,7 +113,13 @@ def occu(
         if site_covs.shape[1] > 4 or obs_covs.shape[3] > 4:
             unsupported.append("false positives with more than 4 covariates per side")
     if site_random_effects or obs_random_effects:
-        unsupported.append("random effects (occu.py:170-173)")
+        # site_re_sd / obs_re_sd are sampled outside the species plate (occu.py:170-173): several species share them
+        if n_species != 1:
+            unsupported.append("random effects with n_species > 1 (the sds are shared across species, occu.py:170-173)")
+        if fp_mode is not None:
+            unsupported.append("random effects together with false positives")
+        if site_covs.shape[1] > 4 or obs_covs.shape[3] > 4:
+            unsupported.append("random effects with more than 4 covariates per side")
     if regressor_occ is not LinearRegression or regressor_det is not LinearRegression:
         unsupported.append("non-linear regressors (occu.py:185-186)")
     if obs is None:
@@ -123,6 +131,11 @@ def occu(
         )
     spec = OccuSpec(site_covs, obs_covs, obs, n_species, as_normal(prior_beta, "prior_beta"),
                     as_normal(prior_alpha, "prior_alpha"))
+    if site_random_effects or obs_random_effects:
+        spec.model = "occu_re"
+        spec.extras.update(site_random_effects=bool(site_random_effects), obs_random_effects=bool(obs_random_effects),
+                           prior_site_re_sd=as_half_normal(prior_site_re_sd, "prior_site_re_sd"),
+                           prior_obs_re_sd=as_half_normal(prior_obs_re_sd, "prior_obs_re_sd"))
     if fp_mode is not None:
         prior = prior_prob_fp_constant if fp_mode == "constant" else prior_prob_fp_unoccupied
         spec.model = "occu_fp"

@@ -150,6 +150,8 @@ def engine_options(spec) -> dict:
     if spec.model == "occu_cop":
         opts.update(fp_mode=spec.extras["fp_mode"], session_duration=spec.extras["session_duration"],
                     prior_fp_rate=spec.extras.get("prior_fp_rate", 1.0))
+    if spec.model == "occu_re":
+        opts.update({k: spec.extras[k] for k in ("site_random_effects", "obs_random_effects", "prior_site_re_sd", "prior_obs_re_sd")})
     return opts
 
 
@@ -184,6 +186,24 @@ def _assemble(per_species, spec, num_warmup) -> HipMCMC:
     if spec.model == "occu_cop" and spec.extras["fp_mode"] is not None:
         # phi = log(rate); the model's site is the rate (occu_cop.py:158-170)
         latent[f"rate_fp_{spec.extras['fp_mode']}"] = np.exp(res0.draws[:, :, Ks + Ko + 2].astype(np.float64)).astype(np.float32)
+    if spec.model == "occu_re":
+        # theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_occ[N], site_re_det[N]), (obs_re[N][T][J])]; the
+        # model's sites are the sds themselves, the effects with the species plate last (occu.py:170-173, 191-196, 215-218)
+        N, T, J = ds0.N, ds0.T, ds0.J
+        at = Ks + Ko + 2
+        if spec.extras["site_random_effects"]:
+            latent["site_re_sd"] = np.exp(res0.draws[:, :, at].astype(np.float64)).astype(np.float32)
+            at += 1
+        if spec.extras["obs_random_effects"]:
+            latent["obs_re_sd"] = np.exp(res0.draws[:, :, at].astype(np.float64)).astype(np.float32)
+            at += 1
+        if spec.extras["site_random_effects"]:
+            latent["site_re_occ"] = res0.draws[:, :, at: at + N, None]
+            latent["site_re_det"] = res0.draws[:, :, at + N: at + 2 * N, None]
+            at += 2 * N
+        if spec.extras["obs_random_effects"]:
+            e = res0.draws[:, :, at: at + N * T * J].reshape(C, S, N, T, J)
+            latent["obs_re"] = np.ascontiguousarray(e.transpose(0, 1, 4, 3, 2))[..., None]     # (C, S, J, T, N, 1)
     if S:
         parts = [d.deterministic(r.draws.reshape(C * S, D), psi=True, prob_detection=False)[0] for d, r in per_species]
         # one species (the common case): a view, not a 160 MB copy at the headline size

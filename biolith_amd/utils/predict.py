@@ -93,12 +93,26 @@ def predict(
         rate = np.maximum(np.asarray(posterior[fp_site], dtype=np.float64).reshape(n), 1e-300)
         phi = np.log(rate).astype(np.float32)[:, None]                  # the engine's coordinate: log(rate)
 
+    re_block = None
+    if spec.model == "occu_re":   # rebuild the engine's coordinates from the model's sites (see fit._assemble)
+        cols = []
+        if spec.extras["site_random_effects"]:
+            cols.append(np.log(np.maximum(np.asarray(posterior["site_re_sd"], dtype=np.float64).reshape(n, 1), 1e-300)))
+        if spec.extras["obs_random_effects"]:
+            cols.append(np.log(np.maximum(np.asarray(posterior["obs_re_sd"], dtype=np.float64).reshape(n, 1), 1e-300)))
+        if spec.extras["site_random_effects"]:
+            cols += [np.asarray(posterior["site_re_occ"]).reshape(n, -1), np.asarray(posterior["site_re_det"]).reshape(n, -1)]
+        if spec.extras["obs_random_effects"]:   # (n, J, T, N, 1) -> [N][T][J]
+            cols.append(np.asarray(posterior["obs_re"])[..., 0].transpose(0, 3, 2, 1).reshape(n, -1))
+        re_block = np.concatenate(cols, axis=1).astype(np.float32)
+
     def run():
         handles, first, latent, y8 = [], [], [], []
         for sp in range(n_species):
             ds = OccuDataset(spec.site_covs, spec.obs_covs, spec.obs[sp:sp + 1], spec.prior_beta, spec.prior_alpha,
                              device=device, model=spec.model, **engine_options(spec))
-            draws = np.concatenate([beta[:, sp, :], alpha[:, sp, :]] + ([phi] if fp_site else []), axis=1)
+            draws = np.concatenate([beta[:, sp, :], alpha[:, sp, :]] + ([phi] if fp_site else [])
+                                   + ([re_block] if re_block is not None else []), axis=1)
             first.append(ds.deterministic(draws, psi=True, prob_detection=False)[0])
             lat, yy = ds.predictive(draws, seed=(int(random_seed) + (sp << 32)) & (2 ** 64 - 1))
             latent.append(lat)
@@ -124,7 +138,7 @@ def predict(
 
     # occu_cop's replicate-level deterministic site is the detection rate (occu_cop.py:236-243)
     out.set_lazy("rate_detection" if spec.model == "occu_cop" else "prob_detection", prob_detection)   # (n, J, T, N, S)
-    if spec.model in ("occu", "occu_fp"):
+    if spec.model in ("occu", "occu_fp", "occu_re"):
         def prob_detection_fp():  # occu.py:229-235
             z = np.stack(latent, axis=-1)[:, None].astype(np.float32)
             zp = prob_detection() * z

@@ -120,6 +120,20 @@ int bl_dataset_create_cop(const bl_dims *dims, const float *site_covs, const flo
 int bl_dataset_create_nmix(const bl_dims *dims, const float *site_covs, const float *obs_covs,
                            const float *obs, int max_abundance, const bl_normal_prior *prior_beta,
                            const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
+/*
+ * Same for biolith.models.occu with site_random_effects / obs_random_effects (models/occu.py:36-39, 170-173, 191-196,
+ * 215-218): site_re_sd, obs_re_sd ~ HalfNormal(scale) sampled before the plates; per site site_re_occ, site_re_det ~
+ * Normal(0, site_re_sd) join the occupancy and detection predictors; per replicate obs_re ~ Normal(0, obs_re_sd) joins
+ * the detection predictor (masked replicates keep their prior term).  One species.  Coordinates, in NumPyro's
+ * unconstrained space:  theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_occ[N], site_re_det[N]),
+ * (obs_re[N][T][J])], D = bl_dataset_param_dim().  bl_logp_grad / bl_nuts_* work as for the other models (the sampler
+ * runs one workgroup per chain with its vectors in device memory; RNG: one stream per coordinate, D + 2 per chain).
+ * At most 4 covariates per side.  bl_deterministic adds the effects to both predictors; bl_predict draws z and y from them.
+ */
+int bl_dataset_create_re(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
+                         int site_random_effects, int obs_random_effects, double prior_site_re_sd_scale,
+                         double prior_obs_re_sd_scale, const bl_normal_prior *prior_beta,
+                         const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
 int bl_dataset_destroy(bl_dataset *ds);
 /* D = Ks+1 + Ko+1; theta = [beta_0..beta_Ks, alpha_0..alpha_Ko] */
 int bl_dataset_param_dim(const bl_dataset *ds, int *D);

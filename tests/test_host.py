@@ -6,7 +6,7 @@ import pandas as pd
 import pytest
 
 import oracle
-from biolith_amd.distributions import Beta, Normal
+from biolith_amd.distributions import Beta, HalfNormal, Normal
 from biolith_amd.evaluation import diagnostics, effective_sample_size, split_gelman_rubin, summary
 from biolith_amd.models import occu
 from biolith_amd.regression import AbstractRegression, LinearRegression
@@ -68,10 +68,20 @@ def test_occu_validates_like_reference():
         occu(g["site_covs"][:10], g["obs_covs"], obs=g["obs"])
     with pytest.raises(AssertionError, match="cannot both be True"):
         occu(g["site_covs"], g["obs_covs"], obs=g["obs"], false_positives_constant=True, false_positives_unoccupied=True)
-    for kw in (dict(coords=np.zeros((64, 2))), dict(site_random_effects=True),
-               dict(obs_random_effects=True), dict(regressor_occ=AbstractRegression)):
+    for kw in (dict(coords=np.zeros((64, 2))), dict(regressor_occ=AbstractRegression)):
         with pytest.raises(NotImplementedError):
             occu(g["site_covs"], g["obs_covs"], obs=g["obs"], **kw)
+    # random effects (occu.py:170-173, 191-196, 215-218): one species, HalfNormal priors on the sds, not with false positives
+    re = occu(g["site_covs"], g["obs_covs"], obs=g["obs"], site_random_effects=True, prior_site_re_sd=HalfNormal(0.5))
+    assert re.model == "occu_re" and re.extras == dict(site_random_effects=True, obs_random_effects=False,
+                                                        prior_site_re_sd=0.5, prior_obs_re_sd=1.0)
+    assert occu(g["site_covs"], g["obs_covs"], obs=g["obs"], obs_random_effects=True).extras["obs_random_effects"]
+    with pytest.raises(NotImplementedError, match="HalfNormal"):
+        occu(g["site_covs"], g["obs_covs"], obs=g["obs"], obs_random_effects=True, prior_obs_re_sd=Normal())
+    with pytest.raises(NotImplementedError, match="shared across species"):
+        occu(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]), site_random_effects=True)
+    with pytest.raises(NotImplementedError, match="together with false positives"):
+        occu(g["site_covs"], g["obs_covs"], obs=g["obs"], site_random_effects=True, false_positives_constant=True)
     # false positives (occu.py:146-157): one species, Beta prior on the rate
     fp = occu(g["site_covs"], g["obs_covs"], obs=g["obs"], false_positives_constant=True)
     assert fp.model == "occu_fp" and fp.extras == dict(fp_mode="constant", prior_fp=(2.0, 5.0))
