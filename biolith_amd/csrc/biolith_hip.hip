@@ -893,6 +893,15 @@ extern "C" int bl_dataset_create_re(const bl_dims *dims, const float *site_covs,
     int tps = 1;
     while (tps < 64 && 2 * tps * N <= BL_RE_NT && 2 * tps <= J) tps *= 2; // spare threads share a site's visits
     m.tps = tps;
+    m.n_rows = ds->n_rows;
+    // a workgroup's own LDS copy of the rows when they fit beside the reduction scratch (160 KB per CU, one workgroup per CU)
+    const size_t row_bytes = (size_t)m.n_rows * N * 4;
+    m.lds_rows = row_bytes <= (size_t)144 * 1024 ? 1 : 0;
+    if (m.lds_rows) {
+        if (hipFuncSetAttribute((const void *)bl_re_nuts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void *)bl_re_logp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_bytes) != hipSuccess)
+            m.lds_rows = 0;
+    }
     ds->model = 6; ds->D = m.D;
     return BL_OK;
 }
@@ -910,7 +919,8 @@ static int re_logp_grad(bl_dataset *ds, int B, const double *theta, double *U, d
     BL_HIP(scratch.alloc((void **)&d_U, (size_t)B * 8));
     BL_HIP(scratch.alloc((void **)&d_grad, (size_t)B * D * 8));
     BL_HIP(hipMemcpy(d_th, th32.data(), th32.size() * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(bl_re_logp_kernel, dim3(B), dim3(BL_RE_NT), 0, nullptr, ds->re, B, d_th, d_work, d_U, d_grad);
+    const size_t lds = ds->re.lds_rows ? (size_t)ds->re.n_rows * ds->re.n_sites * 4 : 0;
+    hipLaunchKernelGGL(bl_re_logp_kernel, dim3(B), dim3(BL_RE_NT), lds, nullptr, ds->re, B, d_th, d_work, d_U, d_grad);
     BL_HIP(hipGetLastError());
     BL_HIP(hipMemcpy(U, d_U, (size_t)B * 8, hipMemcpyDeviceToHost));
     BL_HIP(hipMemcpy(grad, d_grad, (size_t)B * D * 8, hipMemcpyDeviceToHost));
@@ -1019,6 +1029,7 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     run.abort_flag = ds->d_abort;
     run.draws = ds->d_draws; run.diverging = ds->d_div; run.num_steps = ds->d_steps; run.accept_prob = ds->d_acc;
     run.potential = ds->d_pot; run.step_size = ds->d_eps; run.inv_mass = ds->d_minv; run.nleap = ds->d_nleap; run.status = ds->d_status;
+    run.dbg = ds->d_dbg;
     BlReRun *d_runp = (BlReRun *)(base + o_run);
     BL_HIP(hipMemcpyAsync(d_runp, &run, sizeof run, hipMemcpyHostToDevice, st));
     BL_HIP(hipStreamSynchronize(st));
@@ -1026,11 +1037,12 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     BL_HIP(hipEventRecord(ds->ev0, st));
     BL_HIP(hipMemsetAsync(ds->d_status, 0, 16, st));
     BL_HIP(hipMemsetAsync(ds->d_dbg, 0, 256, st));
-    hipLaunchKernelGGL(bl_re_nuts_kernel, dim3(C), dim3(BL_RE_NT), 0, st, d_runp);
+    const size_t lds = ds->re.lds_rows ? (size_t)ds->re.n_rows * ds->re.n_sites * 4 : 0;
+    hipLaunchKernelGGL(bl_re_nuts_kernel, dim3(C), dim3(BL_RE_NT), lds, st, d_runp);
     BL_HIP(hipGetLastError());
     BL_HIP(hipEventRecord(ds->ev1, st));
     ds->stream = st; ds->in_flight = true; ds->have_run = true;
-    ds->C = C; ds->S = S; ds->W = W; ds->k = 1; ds->nloc = ds->re.n_sites; ds->lds_ld = 0; ds->lds_bytes = 0; ds->staged = 0; ds->nvp = 0; ds->ncw = BL_RE_NW;
+    ds->C = C; ds->S = S; ds->W = W; ds->k = 1; ds->nloc = ds->re.n_sites; ds->lds_ld = 0; ds->lds_bytes = (int)lds; ds->staged = ds->re.lds_rows; ds->nvp = 0; ds->ncw = BL_RE_NW;
     return BL_OK;
 }
 

@@ -15,10 +15,11 @@
 #pragma once
 #include "nuts_kernel.hpp"
 
-#define BL_RE_NT 256             // threads per chain
+#define BL_RE_NT 1024            // threads per chain
 #define BL_RE_NW (BL_RE_NT / 64)
 #define BL_RE_MAXK 4             // covariates per side (as the false-positive model)
 #define BL_RE_NRED 26            // widest block reduction
+#define BL_RE_VB 4               // visits whose loads are issued together in the site pass
 
 struct BlReModel {
     const float *rows;
@@ -30,7 +31,21 @@ struct BlReModel {
     float hn_is2_s, hn_is2_o;             // 1 / scale^2 of the HalfNormal priors of site_re_sd / obs_re_sd
     double u_const;                       // the constant part of the potential
     int tps;                              // threads that share one site in the site pass (power of two, <= 64)
+    int n_rows;                           // rows of the dataset (KS + T J (KO + 1) + 2 T)
+    int lds_rows;                         // 1: every workgroup keeps its own copy of the rows in LDS (n_rows * n_sites floats)
 };
+
+// The dataset's rows for this workgroup: staged into dynamic LDS once when they fit, else read from device memory (L2).
+__device__ __forceinline__ const float *bl_re_rows(const BlReModel &m, float *lds, int &ns)
+{
+    if (!m.lds_rows) { ns = m.n_stride; return m.rows; }
+    const int N = m.n_sites;
+    for (int r = 0; r < m.n_rows; r++)
+        for (int i = threadIdx.x; i < N; i += BL_RE_NT) lds[r * N + i] = m.rows[(size_t)r * m.n_stride + i];
+    __syncthreads();
+    ns = N;
+    return lds;
+}
 
 // slots of the per-chain state block, each D floats
 enum {
@@ -56,7 +71,13 @@ struct BlReRun {
     float *draws;               // [C][S][D] external order
     unsigned char *diverging; int *num_steps; float *accept_prob, *potential, *step_size, *inv_mass;
     long long *nleap; int *status;
+    long long *dbg;             // [32] section cycle counters (BL_STAMPS diagnostic builds; chain 0, thread 0)
 };
+#ifdef BL_STAMPS
+#define BL_RE_T(i) { const long long now_ = (long long)clock64(); st_acc[i] += now_ - st_prev; st_prev = now_; }
+#else
+#define BL_RE_T(i)
+#endif
 
 // internal coordinate -> external (oracle / caller) coordinate: obs_re is kept site-fastest inside, replicate-fastest outside
 __device__ __forceinline__ int bl_re_ext(const BlReModel &m, int d)
@@ -69,16 +90,18 @@ __device__ __forceinline__ int bl_re_ext(const BlReModel &m, int d)
 // Sum NV per-thread values over the workgroup: DPP wave sums, then a fixed-order f64 sum of the wave partials.
 // out[] (LDS) is valid for every thread on return.
 template <int NV>
-__device__ __forceinline__ void bl_re_block_sum(float (&v)[NV], float *scr /*[NW][NRED]*/, double *out /*[NRED]*/)
+__device__ __forceinline__ void bl_re_block_sum(float (&v)[NV], float *scr /*[NW][NRED]*/, double *out /*[NRED]*/, int n_used = NV)
 {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
-        const float s = bl_wave_sum(v[k]);
-        if (lane == 0) scr[wave * BL_RE_NRED + k] = s;
+        if (k < n_used) { // workgroup-uniform
+            const float s = bl_wave_sum(v[k]);
+            if (lane == 0) scr[wave * BL_RE_NRED + k] = s;
+        }
     }
     __syncthreads();
-    if (tid < NV) {
+    if (tid < n_used) {
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < BL_RE_NW; w++) s += (double)scr[w * BL_RE_NRED + tid];
@@ -90,11 +113,12 @@ __device__ __forceinline__ void bl_re_block_sum(float (&v)[NV], float *scr /*[NW
 // Site pass at position z: per-thread partials of the log-likelihood and of its gradient w.r.t. beta / alpha, and the
 // random effects' full potential gradient written to g (the effect's own likelihood term + its Normal(0, sd) prior).
 // part[0] = ll, part[1 .. 5] = d/d beta, part[6 .. 10] = d/d alpha.
-__device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float *__restrict__ z, float *__restrict__ g, float (&part)[11])
+// rows / ns: the dataset's rows in device memory (stride n_stride), or the workgroup's LDS copy of them (stride n_sites).
+__device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float *__restrict__ rows, int ns, const float *__restrict__ z,
+                                                float *__restrict__ g, float (&part)[11])
 {
     const int tid = threadIdx.x, tps = m.tps, grp = tid / tps, sub = tid - grp * tps, ngrp = BL_RE_NT / tps;
-    const int N = m.n_sites, ns = m.n_stride, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 1;
-    const float *rows = m.rows;
+    const int N = m.n_sites, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 1;
     float beta[BL_RE_MAXK + 1], alpha[BL_RE_MAXK + 1];
 #pragma unroll
     for (int k = 0; k <= BL_RE_MAXK; k++) {
@@ -128,26 +152,31 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
             float a = 0.0f, ga[BL_RE_MAXK + 1];
 #pragma unroll
             for (int k = 0; k <= BL_RE_MAXK; k++) ga[k] = 0.0f;
-            for (int j = sub; j < J; j += tps) {
-                const int v = t * J + j;
-                const size_t r0 = (size_t)(m.KS + v * vw) * ns + i;
-                const float c = rows[r0];
-                float w[BL_RE_MAXK + 1];
-                w[0] = c;
-                float u = c * alpha[0];
+            // visits in batches of BL_RE_VB: all loads of a batch are issued before the first is used (a lone workgroup per
+            // CU has little else to hide memory latency behind); a visit past J re-reads the last one and is dropped
+            for (int jb = sub; jb < J; jb += tps * BL_RE_VB) {
+                float w[BL_RE_VB][BL_RE_MAXK + 1], eo[BL_RE_VB];
 #pragma unroll
-                for (int k = 1; k <= BL_RE_MAXK; k++) {
-                    w[k] = k <= Ko ? rows[r0 + (size_t)k * ns] : 0.0f;
-                    u = fmaf(w[k], alpha[k], u);
+                for (int b = 0; b < BL_RE_VB; b++) {
+                    const int jj = min(jb + b * tps, J - 1), v = t * J + jj;
+                    const size_t r0 = (size_t)(m.KS + v * vw) * ns + i;
+#pragma unroll
+                    for (int k = 0; k <= BL_RE_MAXK; k++) w[b][k] = k <= Ko ? rows[r0 + (size_t)k * ns] : 0.0f;
+                    eo[b] = m.obs_re ? z[m.o_e + v * N + i] : 0.0f;
                 }
-                const float eo = m.obs_re ? z[m.o_e + v * N + i] : 0.0f;
-                u = fmaf(c, vi + eo, u);
-                const float e = bl_exp(-fabsf(u)), op = 1.0f + e;
-                a += fminf(u, 0.0f) - bl_log(op);
-                const float s = (u > 0.0f ? e : 1.0f) * bl_rcp(op); // sigma(-u): d log sigma(u) / du
 #pragma unroll
-                for (int k = 0; k <= BL_RE_MAXK; k++) ga[k] = fmaf(s, w[k], ga[k]);
-                if (m.obs_re && live) g[m.o_e + v * N + i] = s * c; // d a / d nu of this visit; scaled by q below
+                for (int b = 0; b < BL_RE_VB; b++) {
+                    const float ok = jb + b * tps < J ? 1.0f : 0.0f;
+                    float u = w[b][0] * alpha[0];
+#pragma unroll
+                    for (int k = 1; k <= BL_RE_MAXK; k++) u = fmaf(w[b][k], alpha[k], u);
+                    u = fmaf(w[b][0], vi + eo[b], u);
+                    const float e = bl_exp(-fabsf(u)), op = 1.0f + e;
+                    a = fmaf(ok, fminf(u, 0.0f) - bl_log(op), a);
+                    const float s = ok * (u > 0.0f ? e : 1.0f) * bl_rcp(op); // sigma(-u): d log sigma(u) / du
+#pragma unroll
+                    for (int k = 0; k <= BL_RE_MAXK; k++) ga[k] = fmaf(s, w[b][k], ga[k]);
+                }
             }
             for (int msk = 1; msk < tps; msk <<= 1) { // the site's threads pool their visits
                 a += __shfl_xor(a, msk);
@@ -166,10 +195,29 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
             dl_deta += q - psi;
             dl_dv = fmaf(q, ga[0], dl_dv);
             if (m.obs_re && live) {
-                __threadfence_block(); // this thread's own stores above, read back here
-                for (int j = sub; j < J; j += tps) {
-                    const int d = m.o_e + (t * J + j) * N + i;
-                    g[d] = fmaf(z[d], isd2_o, -q * g[d]);
+                // each replicate's own effect: d U / d e = -q d a / d nu + e / sd^2 (d a / d nu recomputed: nothing was kept per visit)
+                for (int jb = sub; jb < J; jb += tps * BL_RE_VB) {
+                    float w[BL_RE_VB][BL_RE_MAXK + 1], eo[BL_RE_VB];
+#pragma unroll
+                    for (int b = 0; b < BL_RE_VB; b++) {
+                        const int jj = min(jb + b * tps, J - 1), v = t * J + jj;
+                        const size_t r0 = (size_t)(m.KS + v * vw) * ns + i;
+#pragma unroll
+                        for (int k = 0; k <= BL_RE_MAXK; k++) w[b][k] = k <= Ko ? rows[r0 + (size_t)k * ns] : 0.0f;
+                        eo[b] = z[m.o_e + v * N + i];
+                    }
+#pragma unroll
+                    for (int b = 0; b < BL_RE_VB; b++) {
+                        if (jb + b * tps < J) {
+                            float u = w[b][0] * alpha[0];
+#pragma unroll
+                            for (int k = 1; k <= BL_RE_MAXK; k++) u = fmaf(w[b][k], alpha[k], u);
+                            u = fmaf(w[b][0], vi + eo[b], u);
+                            const float e = bl_exp(-fabsf(u));
+                            const float s = (u > 0.0f ? e : 1.0f) * bl_rcp(1.0f + e);
+                            g[m.o_e + (t * J + jb + b * tps) * N + i] = fmaf(eo[b], isd2_o, -q * s * w[b][0]);
+                        }
+                    }
                 }
             }
         }
@@ -230,6 +278,18 @@ __device__ __forceinline__ void bl_re_effect_squares(const BlReModel &m, const f
     }
 }
 
+// this thread's share of sum over fixed effects of ((z - loc) / scale)^2
+__device__ __forceinline__ float bl_re_prior_quad(const BlReModel &m, const float *z)
+{
+    float pe = 0.0f;
+    for (int d = threadIdx.x; d < m.G0; d += BL_RE_NT) {
+        const bool is_b = d <= m.Ks;
+        const float t = z[d] - (is_b ? m.loc_b : m.loc_a);
+        pe = fmaf(t * t, is_b ? m.isc2_b : m.isc2_a, pe);
+    }
+    return pe;
+}
+
 // ---- parity hook: U and dU/dtheta for B positions (external order in, external order out), one workgroup each ----
 __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel m, int B, const float *__restrict__ theta,
                                                               float *__restrict__ work /*[B][2][D]*/, double *__restrict__ U, double *__restrict__ grad)
@@ -240,28 +300,20 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel m,
     if (b >= B) return;
     float *z = work + (size_t)b * 2 * D, *g = z + D;
     for (int d = tid; d < D; d += BL_RE_NT) z[d] = theta[(size_t)b * D + bl_re_ext(m, d)];
+    extern __shared__ float bl_re_lds[];
+    int ns;
+    const float *rows = bl_re_rows(m, bl_re_lds, ns);
     __syncthreads();
-    float v[13], part[11], ss[2];
-    bl_re_site_pass(m, z, g, part);
+    float v[14], part[11], ss[2];
+    bl_re_site_pass(m, rows, ns, z, g, part);
     bl_re_effect_squares(m, z, ss);
 #pragma unroll
     for (int k = 0; k < 11; k++) v[k] = part[k];
     v[11] = ss[0]; v[12] = ss[1];
-    bl_re_block_sum<13>(v, scr, red);
-    float pe[1] = {0.0f};
-    for (int d = tid; d < m.G; d += BL_RE_NT) {
-        const float zd = z[d];
-        g[d] = bl_re_global_grad(m, d, zd, red);
-        if (d < m.G0) {
-            const bool is_b = d <= m.Ks;
-            const float t = zd - (is_b ? m.loc_b : m.loc_a);
-            pe[0] = fmaf(t * t, is_b ? m.isc2_b : m.isc2_a, pe[0]);
-        }
-    }
-    __shared__ float scr2[BL_RE_NW * BL_RE_NRED];
-    __shared__ double red2[BL_RE_NRED];
-    bl_re_block_sum<1>(pe, scr2, red2);
-    if (tid == 0) U[b] = bl_re_potential(m, z, red, red2[0]);
+    v[13] = bl_re_prior_quad(m, z);
+    bl_re_block_sum<14>(v, scr, red);
+    for (int d = tid; d < m.G; d += BL_RE_NT) g[d] = bl_re_global_grad(m, d, z[d], red);
+    if (tid == 0) U[b] = bl_re_potential(m, z, red, red[13]);
     for (int d = tid; d < D; d += BL_RE_NT) grad[(size_t)b * D + bl_re_ext(m, d)] = (double)g[d];
 }
 
@@ -278,6 +330,9 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
     auto V = [&](int slot) -> float * { return sv + (size_t)slot * D; };
     uint32_t *rng_base = R.rng + (size_t)chain * (D + 2) * 4;
     const int S = R.num_samples, W = R.num_warmup, total = W + S;
+    extern __shared__ float bl_re_lds[];
+    int rows_ns;
+    const float *rows = bl_re_rows(m, bl_re_lds, rows_ns);
 
     BlRng rng_u, rng_dir; // every thread carries its own copy of the two scalar streams and advances it identically
     {
@@ -300,33 +355,34 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
     long long nleap_w = 0, nleap_s = 0;
     int flag = 0;
 
-    // evaluate the potential and its gradient at V(RE_CZ) into V(RE_CG); returns U (same value in every thread)
+    // evaluate the potential and its gradient at V(RE_CZ) into V(RE_CG); returns U (same value in every thread).
+    // The gradient of a fixed effect / log sd is written by the thread that owns the coordinate, after the reduction.
+#ifdef BL_STAMPS
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = (long long)clock64(), st_leaves = 0;
+#endif
     auto evaluate = [&]() -> double {
-        float v[13], part[11], ss[2];
+        float v[14], part[11], ss[2];
         const float *z = V(RE_CZ);
         float *g = V(RE_CG);
-        bl_re_site_pass(m, z, g, part);
+        BL_RE_T(7)
+        bl_re_site_pass(m, rows, rows_ns, z, g, part);
         bl_re_effect_squares(m, z, ss);
 #pragma unroll
         for (int k = 0; k < 11; k++) v[k] = part[k];
         v[11] = ss[0]; v[12] = ss[1];
-        bl_re_block_sum<13>(v, scr, red);
-        float pe[1] = {0.0f};
-        for (int d = tid; d < G; d += BL_RE_NT) {
-            const float zd = z[d];
-            g[d] = bl_re_global_grad(m, d, zd, red);
-            if (d < m.G0) {
-                const bool is_b = d <= m.Ks;
-                const float t = zd - (is_b ? m.loc_b : m.loc_a);
-                pe[0] = fmaf(t * t, is_b ? m.isc2_b : m.isc2_a, pe[0]);
-            }
-        }
-        bl_re_block_sum<1>(pe, scr, red2); // (its barriers also publish g[d < G])
-        return bl_re_potential(m, z, red, red2[0]);
+        v[13] = bl_re_prior_quad(m, z);
+        BL_RE_T(0)
+        bl_re_block_sum<14>(v, scr, red);
+        for (int d = tid; d < G; d += BL_RE_NT) g[d] = bl_re_global_grad(m, d, z[d], red);
+        const double U = bl_re_potential(m, z, red, red[13]);
+        BL_RE_T(1)
+        return U;
     };
 
-    // momentum r ~ N(0, M), fresh tree, first doubling; leaves the first leaf's start in CZ / CR / CG
+    // momentum r ~ N(0, M), fresh tree, first doubling, and the first leaf's half step (start in CZ / CR / CG)
     auto new_transition = [&]() {
+        going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
+        epsdir = going_right ? eps : -eps;
         float kin[1] = {0.0f};
         for (int d = tid; d < D; d += BL_RE_NT) {
             const float th = V(RE_TH)[d], gr = V(RE_GR)[d], mi = V(RE_MINV)[d];
@@ -338,13 +394,13 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
             V(RE_ZL)[d] = th; V(RE_RL)[d] = r0; V(RE_GL)[d] = gr;
             V(RE_ZR)[d] = th; V(RE_RR)[d] = r0; V(RE_GRR)[d] = gr;
             V(RE_ZP)[d] = th; V(RE_GP)[d] = gr; V(RE_RSUM)[d] = r0;
-            V(RE_CZ)[d] = th; V(RE_CR)[d] = r0; V(RE_CG)[d] = gr;
+            float rh, zn;
+            bl_next_leaf(th, r0, gr, epsdir, mi, rh, zn);
+            V(RE_CZ)[d] = zn; V(RE_CR)[d] = rh; V(RE_CG)[d] = gr;
         }
-        bl_re_block_sum<1>(kin, scr, red2);
+        bl_re_block_sum<1>(kin, scr, red2); // (its barriers also publish the leaf start)
         E0 = Ucur + 0.5 * red2[0];
         Up = Ucur; wt = 0.f; sumacc = 0.f; nprop = 0; depth = 0;
-        going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
-        epsdir = going_right ? eps : -eps;
         snprop = 0; sturn = false; sdiv = false;
     };
 
@@ -358,32 +414,27 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
     }
     __syncthreads();
     Ucur = evaluate();
+    __syncthreads(); // every coordinate's gradient is in place
     for (int d = tid; d < D; d += BL_RE_NT) { V(RE_TH)[d] = V(RE_CZ)[d]; V(RE_GR)[d] = V(RE_CG)[d]; }
-    __syncthreads();
     if (total <= 0) flag = 1;
     else new_transition();
-    __syncthreads();
 
     while (flag == 0) {
-        // ---- leaf: half step of the momentum, full step of the position (hmc_util velocity Verlet) ----
-        for (int d = tid; d < D; d += BL_RE_NT) {
-            float rh, zn;
-            bl_next_leaf(V(RE_CZ)[d], V(RE_CR)[d], V(RE_CG)[d], epsdir, V(RE_MINV)[d], rh, zn);
-            V(RE_CZ)[d] = zn; V(RE_CR)[d] = rh;
-        }
-        __syncthreads();
+        // ---- the leaf's position is in CZ, its half-step momentum in CR (hmc_util velocity Verlet) ----
         const double Un = evaluate();
         if (it < W) nleap_w++; else nleap_s++;
         // ---- second half step; kinetic energy; subtree momentum sum; U-turn dot products for every checkpoint this
-        //      leaf closes (_leaf_idx_to_ckpt_idxs) and for the whole tree if the subtree ends here ----
+        //      leaf closes (_leaf_idx_to_ckpt_idxs) and for the whole tree in case the subtree ends here ----
         const int leaf_idx = snprop;
         const int idx_max = __popc((unsigned)leaf_idx >> 1);
         const int idx_min = idx_max - (int)__builtin_ctz(~(unsigned)leaf_idx) + 1;
         const bool odd = (leaf_idx & 1) != 0;
-        float acc[BL_RE_NRED];
+        float acc[BL_RE_NRED]; // 0: kinetic; 1, 2: tree; 3 + 2 q, 4 + 2 q: checkpoint idx_min + q
 #pragma unroll
         for (int k = 0; k < BL_RE_NRED; k++) acc[k] = 0.0f;
+        const int nck = odd ? idx_max - idx_min + 1 : 0;
         for (int d = tid; d < D; d += BL_RE_NT) {
+            // (coordinates below G: this thread wrote their gradient in evaluate(); the others' were published by its barriers)
             const float mi = V(RE_MINV)[d];
             const float cr = bl_leaf_momentum(V(RE_CR)[d], epsdir, V(RE_CG)[d]);
             V(RE_CR)[d] = cr;
@@ -401,18 +452,20 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
                         const float ck = V(RE_CKR + i)[d];
                         const float s_i = srs - V(RE_CKR + BL_MAX_DEPTH + i)[d] + ck;
                         const float rho = s_i - 0.5f * (ck + cr);
-                        acc[2 + 2 * q] = fmaf(mi * ck, rho, acc[2 + 2 * q]);
-                        acc[3 + 2 * q] = fmaf(mi * cr, rho, acc[3 + 2 * q]);
+                        acc[3 + 2 * q] = fmaf(mi * ck, rho, acc[3 + 2 * q]);
+                        acc[4 + 2 * q] = fmaf(mi * cr, rho, acc[4 + 2 * q]);
                     }
                 }
             }
             const float r_other = going_right ? V(RE_RL)[d] : V(RE_RR)[d];
             const float rl = going_right ? r_other : cr, rr = going_right ? cr : r_other;
             const float rho_t = (V(RE_RSUM)[d] + srs) - 0.5f * (rl + rr);
-            acc[22] = fmaf(mi * rl, rho_t, acc[22]);
-            acc[23] = fmaf(mi * rr, rho_t, acc[23]);
+            acc[1] = fmaf(mi * rl, rho_t, acc[1]);
+            acc[2] = fmaf(mi * rr, rho_t, acc[2]);
         }
-        bl_re_block_sum<BL_RE_NRED>(acc, scr, red2);
+        BL_RE_T(2)
+        bl_re_block_sum<BL_RE_NRED>(acc, scr, red2, 3 + 2 * nck);
+        BL_RE_T(3)
         // ---- decisions (_build_basetree tail, _iterative_build_subtree, _combine_tree, _double_tree) ----
         double dE = (Un + 0.5 * red2[0]) - E0;
         if (dE != dE) dE = (double)INFINITY;
@@ -433,14 +486,14 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
         if (odd) {
 #pragma unroll
             for (int q = 0; q < BL_MAX_DEPTH; q++)
-                if (idx_min + q <= idx_max) sturn = sturn || red2[2 + 2 * q] <= 0.0 || red2[3 + 2 * q] <= 0.0;
+                if (idx_min + q <= idx_max) sturn = sturn || red2[3 + 2 * q] <= 0.0 || red2[4 + 2 * q] <= 0.0;
         }
         const bool sub_done = !(snprop < (1 << depth) && !sturn && !sdiv);
         bool take2 = false, cont = false, trans_end = false;
         const bool was_right = going_right;
         int nprop_out = 0; float accp = 0.f;
         if (sub_done) {
-            const bool turning = sturn || red2[22] <= 0.0 || red2[23] <= 0.0;
+            const bool turning = sturn || red2[1] <= 0.0 || red2[2] <= 0.0;
             float pr = fminf(1.0f, bl_exp(swt - wt));
             if (sturn || sdiv) pr = 0.0f;
             const float u = bl_rng_uniform(rng_u);
@@ -486,20 +539,26 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
             if (it >= total) flag = 1;
             if (R.abort_flag && *(volatile const int *)R.abort_flag) flag = 5;
         }
-        // ---- vector part of the same decisions ----
+        // ---- vector part of the same decisions, and -- unless the transition ends -- the next leaf's half step ----
+        BL_RE_T(4)
         const float wfn = (float)wf_n;
         for (int d = tid; d < D; d += BL_RE_NT) {
             const float cz = V(RE_CZ)[d], cg = V(RE_CG)[d], cr = V(RE_CR)[d];
-            float szp = V(RE_SZP)[d], sgp = V(RE_SGP)[d];
-            if (take) { szp = cz; sgp = cg; V(RE_SZP)[d] = szp; V(RE_SGP)[d] = sgp; }
-            if (!sub_done) continue;
+            if (take) { V(RE_SZP)[d] = cz; V(RE_SGP)[d] = cg; }
+            if (!sub_done) { // the subtree goes on from this leaf
+                float rh, zn;
+                bl_next_leaf(cz, cr, cg, epsdir, V(RE_MINV)[d], rh, zn);
+                V(RE_CZ)[d] = zn; V(RE_CR)[d] = rh;
+                continue;
+            }
             V(was_right ? RE_ZR : RE_ZL)[d] = cz; V(was_right ? RE_RR : RE_RL)[d] = cr; V(was_right ? RE_GRR : RE_GL)[d] = cg;
             V(RE_RSUM)[d] += V(RE_SRSUM)[d];
-            if (take2) { V(RE_ZP)[d] = szp; V(RE_GP)[d] = sgp; }
-            if (cont) {
-                V(RE_CZ)[d] = V(going_right ? RE_ZR : RE_ZL)[d];
-                V(RE_CR)[d] = V(going_right ? RE_RR : RE_RL)[d];
-                V(RE_CG)[d] = V(going_right ? RE_GRR : RE_GL)[d];
+            if (take2) { V(RE_ZP)[d] = take ? cz : V(RE_SZP)[d]; V(RE_GP)[d] = take ? cg : V(RE_SGP)[d]; }
+            if (cont) { // next doubling: its first leaf starts from the tree edge on the chosen side
+                const float ez = V(going_right ? RE_ZR : RE_ZL)[d], er = V(going_right ? RE_RR : RE_RL)[d], eg = V(going_right ? RE_GRR : RE_GL)[d];
+                float rh, zn;
+                bl_next_leaf(ez, er, eg, epsdir, V(RE_MINV)[d], rh, zn);
+                V(RE_CZ)[d] = zn; V(RE_CR)[d] = rh; V(RE_CG)[d] = eg;
                 continue;
             }
             const float th = V(RE_ZP)[d];
@@ -527,10 +586,22 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
                 R.num_steps[s] = nprop_out; R.accept_prob[s] = accp;
                 R.diverging[s] = div_out ? 1 : 0; R.potential[s] = (float)Ucur;
             }
+            BL_RE_T(5)
+            if (flag == 0) new_transition(); // (own coordinates only: TH / GR / MINV were written by this thread above)
+            BL_RE_T(6)
         }
-        __syncthreads();
-        if (trans_end && flag == 0) { new_transition(); __syncthreads(); }
+        BL_RE_T(5)
+        __syncthreads(); // the next leaf's position is visible to the site pass
+#ifdef BL_STAMPS
+        st_leaves++;
+#endif
     }
+#ifdef BL_STAMPS
+    if (R.dbg && chain == 0 && tid == 0) {
+        for (int i = 0; i < 8; i++) R.dbg[i] = st_acc[i];
+        R.dbg[8] = st_leaves;
+    }
+#endif
     for (int d = tid; d < D; d += BL_RE_NT) R.inv_mass[(size_t)chain * D + bl_re_ext(m, d)] = V(RE_MINV)[d];
     if (tid == 0) {
         if (flag > 1) atomicMax(R.status, flag);
