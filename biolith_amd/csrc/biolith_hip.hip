@@ -895,12 +895,18 @@ extern "C" int bl_dataset_create_re(const bl_dims *dims, const float *site_covs,
     m.tps = tps;
     m.n_rows = ds->n_rows;
     // a workgroup's own LDS copy of the rows when they fit beside the reduction scratch (160 KB per CU, one workgroup per CU)
-    const size_t row_bytes = (size_t)m.n_rows * N * 4;
-    m.lds_rows = row_bytes <= (size_t)144 * 1024 ? 1 : 0;
-    if (m.lds_rows) {
-        if (hipFuncSetAttribute((const void *)bl_re_nuts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_bytes) != hipSuccess ||
-            hipFuncSetAttribute((const void *)bl_re_logp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_bytes) != hipSuccess)
+    // and, in the sampler, of the five vectors every leapfrog touches (RE_HOT * D floats) -- the rows first, then those
+    const size_t row_bytes = (size_t)m.n_rows * N * 4, hot_bytes = (size_t)RE_HOT * m.D * 4, budget = (size_t)152 * 1024;
+    m.lds_rows = row_bytes <= budget ? 1 : 0;
+    m.lds_hot = (m.lds_rows ? row_bytes : 0) + hot_bytes <= budget ? 1 : 0;
+    const size_t nuts_lds = (m.lds_rows ? row_bytes : 0) + (m.lds_hot ? hot_bytes : 0);
+    if (nuts_lds && hipFuncSetAttribute((const void *)bl_re_nuts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nuts_lds) != hipSuccess) {
+        m.lds_hot = 0;
+        if (m.lds_rows && hipFuncSetAttribute((const void *)bl_re_nuts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_bytes) != hipSuccess)
             m.lds_rows = 0;
+    }
+    if (m.lds_rows && hipFuncSetAttribute((const void *)bl_re_logp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_bytes) != hipSuccess) {
+        m.lds_rows = 0; m.lds_hot = 0;
     }
     ds->model = 6; ds->D = m.D;
     return BL_OK;
@@ -1037,7 +1043,7 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     BL_HIP(hipEventRecord(ds->ev0, st));
     BL_HIP(hipMemsetAsync(ds->d_status, 0, 16, st));
     BL_HIP(hipMemsetAsync(ds->d_dbg, 0, 256, st));
-    const size_t lds = ds->re.lds_rows ? (size_t)ds->re.n_rows * ds->re.n_sites * 4 : 0;
+    const size_t lds = (ds->re.lds_rows ? (size_t)ds->re.n_rows * ds->re.n_sites * 4 : 0) + (ds->re.lds_hot ? (size_t)RE_HOT * D * 4 : 0);
     hipLaunchKernelGGL(bl_re_nuts_kernel, dim3(C), dim3(BL_RE_NT), lds, st, d_runp);
     BL_HIP(hipGetLastError());
     BL_HIP(hipEventRecord(ds->ev1, st));

@@ -33,6 +33,7 @@ struct BlReModel {
     int tps;                              // threads that share one site in the site pass (power of two, <= 64)
     int n_rows;                           // rows of the dataset (KS + T J (KO + 1) + 2 T)
     int lds_rows;                         // 1: every workgroup keeps its own copy of the rows in LDS (n_rows * n_sites floats)
+    int lds_hot;                          // 1: the RE_HOT vectors of the chain live in LDS (after the rows), not in device memory
 };
 
 // The dataset's rows for this workgroup: staged into dynamic LDS once when they fit, else read from device memory (L2).
@@ -49,12 +50,15 @@ __device__ __forceinline__ const float *bl_re_rows(const BlReModel &m, float *ld
 
 // slots of the per-chain state block, each D floats
 enum {
+    // the five vectors every leapfrog reads and writes: kept in the workgroup's LDS when they fit (BlReModel::lds_hot)
     RE_CZ = 0, RE_CR, RE_CG,                       // leaf in flight: position, momentum (half step, then full), gradient
-    RE_TH, RE_GR,                                  // position / gradient the transition started from
+    RE_MINV, RE_SRSUM,                             // diagonal mass matrix; the subtree's momentum sum
+    RE_HOT,
+    RE_TH = RE_HOT, RE_GR,                         // position / gradient the transition started from
     RE_ZL, RE_RL, RE_GL, RE_ZR, RE_RR, RE_GRR,     // tree edges
     RE_ZP, RE_GP, RE_SZP, RE_SGP,                  // proposals: tree, subtree
-    RE_RSUM, RE_SRSUM,                             // momentum sums: tree, subtree
-    RE_MINV, RE_WFMEAN, RE_WFM2,                   // diagonal mass matrix, Welford moments
+    RE_RSUM,                                       // the tree's momentum sum
+    RE_WFMEAN, RE_WFM2,                            // Welford moments
     RE_CKR,                                        // BL_MAX_DEPTH checkpoints of r, then BL_MAX_DEPTH of the running sum
     RE_SLOTS = RE_CKR + 2 * BL_MAX_DEPTH
 };
@@ -327,10 +331,11 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
     const int chain = blockIdx.x, tid = threadIdx.x, D = m.D, G = m.G;
     if (chain >= R.num_chains) return;
     float *sv = R.state + (size_t)chain * RE_SLOTS * D;
-    auto V = [&](int slot) -> float * { return sv + (size_t)slot * D; };
+    extern __shared__ float bl_re_lds[];
+    float *hot = m.lds_hot ? bl_re_lds + (m.lds_rows ? (size_t)m.n_rows * m.n_sites : 0) : sv; // (generic pointers: LDS or device memory)
+    auto V = [&](int slot) -> float * { return (slot < RE_HOT ? hot : sv) + (size_t)slot * D; };
     uint32_t *rng_base = R.rng + (size_t)chain * (D + 2) * 4;
     const int S = R.num_samples, W = R.num_warmup, total = W + S;
-    extern __shared__ float bl_re_lds[];
     int rows_ns;
     const float *rows = bl_re_rows(m, bl_re_lds, rows_ns);
 

@@ -76,3 +76,21 @@ def test_re_oracle_nuts_recovers_a_sensible_posterior():
     # fixed effects stay in the neighbourhood of the plain model's posterior mean
     o0 = oracle.nuts_run(oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"]), 300, 300, num_chains=2, seed=0)
     assert np.max(np.abs(r["draws"][:, :, :G0].mean((0, 1)) - o0["draws"].mean((0, 1)))) < 1.0
+
+
+def test_oracle_sampler_is_pinned_by_its_own_first_draws():
+    """The oracle's sampler output for fixed seeds, captured when the GPU kernels reproduced its trees transition by
+    transition: any change of stream layout, adaptation or tree logic in the restatement shows up here, on the CPU."""
+    import json
+    import os
+
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_first_draws.json")))
+    g = load_golden("small_3x3")
+    r = oracle.nuts_run(oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"]), 20, 3, num_chains=3, seed=3)
+    assert np.array_equal(r["num_steps"], np.array(ref["occu"]["num_steps"]))
+    assert np.allclose(r["draws"], np.array(ref["occu"]["draws"]), rtol=0, atol=1e-9)
+    assert np.allclose(r["step_size"], np.array(ref["occu"]["step_size"]), rtol=1e-10)
+    od = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], model="occu_re", site_random_effects=True)
+    r = oracle.nuts_run(od, 10, 2, num_chains=2, seed=3)
+    assert np.array_equal(r["num_steps"], np.array(ref["occu_re_site"]["num_steps"]))
+    assert np.allclose(r["draws"][:, :, :12], np.array(ref["occu_re_site"]["draws"]), rtol=0, atol=1e-9)
