@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -177,7 +178,7 @@ struct bl_dataset {
     int device = 0;
     int model = 0;          // 0 occu, 1 occu_rn, 2 occu with false positives, 3 occu_cop, 4 nmixture, 6 occu with random effects
     BlReModel re{};         // model 6 (re_kernel.hpp); D is then the full coordinate count
-    float *d_restate = nullptr; // model 6: sampler state [C][RE_SLOTS][D]
+    float *d_restate = nullptr; // model 6: sampler state [C][k][RE_SLOTS][dl_max]
     size_t restate_bytes = 0;
     float *d_tab = nullptr; // nmixture: B[t][n][site] = sum_j m log C(n, y_j), -inf below the largest count
     int ko_layout = 0;      // KO the record layout helpers are called with (KO, or KO + 1 for occu_cop's wider visits)
@@ -854,6 +855,21 @@ __global__ void bl_logp_final_kernel(BlDevData dd, int k, const double *theta, c
     if (lane == D) U[b] = -acc + prior + dd.prior_const;
 }
 
+// Geometry of the random-effects kernels for slices of `nloc` sites: threads sharing a site's visits, what lives in LDS.
+// with_hot: also the sampler's five hot vectors (NUTS only).  Returns the dynamic LDS bytes.
+static size_t re_geometry(BlReModel &m, int nloc, int with_hot, int dl_max)
+{
+    int tps = 1;
+    while (tps < 64 && 2 * tps * nloc <= BL_RE_NT && 2 * tps <= m.J) tps *= 2; // spare threads share a site's visits
+    m.tps = tps;
+    // a workgroup's own LDS copy of its rows, and of the five vectors every leapfrog touches, when they fit (160 KB per CU,
+    // one workgroup per CU; a few KB go to the reduction scratch)
+    const size_t row_bytes = (size_t)m.n_rows * nloc * 4, hot_bytes = with_hot ? (size_t)RE_HOT * dl_max * 4 : 0, budget = (size_t)150 * 1024;
+    m.lds_rows = row_bytes <= budget ? 1 : 0;
+    m.lds_hot = with_hot && (m.lds_rows ? row_bytes : 0) + hot_bytes <= budget ? 1 : 0;
+    return (m.lds_rows ? row_bytes : 0) + (m.lds_hot ? hot_bytes : 0);
+}
+
 extern "C" int bl_dataset_create_re(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
                                     int site_random_effects, int obs_random_effects, double prior_site_re_sd_scale,
                                     double prior_obs_re_sd_scale, const bl_normal_prior *prior_beta,
@@ -890,24 +906,9 @@ extern "C" int bl_dataset_create_re(const bl_dims *dims, const float *site_covs,
     m.u_const = ds->dd.prior_const;
     if (m.site_re) m.u_const += -HN0 + std::log(prior_site_re_sd_scale) + 2.0 * N * HL2PI;
     if (m.obs_re) m.u_const += -HN0 + std::log(prior_obs_re_sd_scale) + (double)N * T * J * HL2PI;
-    int tps = 1;
-    while (tps < 64 && 2 * tps * N <= BL_RE_NT && 2 * tps <= J) tps *= 2; // spare threads share a site's visits
-    m.tps = tps;
+    m.n_total = N; m.s0 = 0; m.x_u = m.o_u; m.x_v = m.o_v; m.x_e = m.o_e;
     m.n_rows = ds->n_rows;
-    // a workgroup's own LDS copy of the rows when they fit beside the reduction scratch (160 KB per CU, one workgroup per CU)
-    // and, in the sampler, of the five vectors every leapfrog touches (RE_HOT * D floats) -- the rows first, then those
-    const size_t row_bytes = (size_t)m.n_rows * N * 4, hot_bytes = (size_t)RE_HOT * m.D * 4, budget = (size_t)152 * 1024;
-    m.lds_rows = row_bytes <= budget ? 1 : 0;
-    m.lds_hot = (m.lds_rows ? row_bytes : 0) + hot_bytes <= budget ? 1 : 0;
-    const size_t nuts_lds = (m.lds_rows ? row_bytes : 0) + (m.lds_hot ? hot_bytes : 0);
-    if (nuts_lds && hipFuncSetAttribute((const void *)bl_re_nuts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)nuts_lds) != hipSuccess) {
-        m.lds_hot = 0;
-        if (m.lds_rows && hipFuncSetAttribute((const void *)bl_re_nuts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_bytes) != hipSuccess)
-            m.lds_rows = 0;
-    }
-    if (m.lds_rows && hipFuncSetAttribute((const void *)bl_re_logp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_bytes) != hipSuccess) {
-        m.lds_rows = 0; m.lds_hot = 0;
-    }
+    re_geometry(m, N, 0, 0); // one workgroup over all sites (bl_logp_grad); bl_nuts_launch picks its own slices
     ds->model = 6; ds->D = m.D;
     return BL_OK;
 }
@@ -925,8 +926,10 @@ static int re_logp_grad(bl_dataset *ds, int B, const double *theta, double *U, d
     BL_HIP(scratch.alloc((void **)&d_U, (size_t)B * 8));
     BL_HIP(scratch.alloc((void **)&d_grad, (size_t)B * D * 8));
     BL_HIP(hipMemcpy(d_th, th32.data(), th32.size() * 4, hipMemcpyHostToDevice));
-    const size_t lds = ds->re.lds_rows ? (size_t)ds->re.n_rows * ds->re.n_sites * 4 : 0;
-    hipLaunchKernelGGL(bl_re_logp_kernel, dim3(B), dim3(BL_RE_NT), lds, nullptr, ds->re, B, d_th, d_work, d_U, d_grad);
+    BlReModel m = ds->re;
+    const size_t lds = re_geometry(m, m.n_sites, 0, 0);
+    if (lds) BL_HIP(hipFuncSetAttribute((const void *)bl_re_logp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(bl_re_logp_kernel, dim3(B), dim3(BL_RE_NT), lds, nullptr, m, B, d_th, d_work, d_U, d_grad);
     BL_HIP(hipGetLastError());
     BL_HIP(hipMemcpy(U, d_U, (size_t)B * 8, hipMemcpyDeviceToHost));
     BL_HIP(hipMemcpy(grad, d_grad, (size_t)B * D * 8, hipMemcpyDeviceToHost));
@@ -978,26 +981,44 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
 // ------------------------------------------------------------------- NUTS ----
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
-// Random-effects model: one workgroup per chain, sampler state in device memory (re_kernel.hpp).  Outputs land in the
-// same run-slab fields as the other models', so poll / wait / fetch are shared.
+// Random-effects model: k workgroups per chain, each with a slice of the sites; sampler state in device memory / LDS
+// (re_kernel.hpp).  Outputs land in the same run-slab fields as the other models', so poll / wait / fetch are shared.
 static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t st, int max_depth)
 {
     const int C = cfg->num_chains, S = cfg->num_samples, W = cfg->num_warmup;
     const size_t D = ds->D, Sa = S > 0 ? S : 1;
+    const BlReModel &g = ds->re;
+    const int N = g.n_sites, V = g.T * g.J, per_site = (g.site_re ? 2 : 0) + (g.obs_re ? V : 0);
+    // workgroups per chain: about a thousand coordinates, or eight thousand visits, each; all C k of them must be resident
+    // at once (one per CU: they spin on each other's sums)
+    int k = cfg->wgs_per_chain;
+    if (k <= 0) {
+        const long long work = std::max<long long>((long long)D, (long long)N * V / 8);
+        k = (int)((2 * work + BL_RE_NT - 1) / BL_RE_NT);
+        if (const char *e = getenv("BIOLITH_HIP_RE_WGS")) k = atoi(e);
+    }
+    int ncu = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ds->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
+    k = std::max(1, std::min(std::min(k, 32), std::min(ncu / C, N)));
+    if (C * k > ncu) return bl_fail(BL_ERR_UNSUPPORTED, "num_chains=%d random-effects chains need %d resident workgroups (%d CUs)", C, C * k, ncu);
+    const int nloc = (N + k - 1) / k;
+    k = (N + nloc - 1) / nloc; // no empty slice
+    const int dl_max = g.G + nloc * per_site;
+
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
     const size_t o_draws = carve((size_t)C * Sa * D * 4), o_div = carve((size_t)C * Sa), o_steps = carve((size_t)C * Sa * 4),
                  o_acc = carve((size_t)C * Sa * 4), o_pot = carve((size_t)C * Sa * 4), o_eps = carve((size_t)C * 4),
                  o_minv = carve((size_t)C * D * 4), o_nleap = carve((size_t)C * 16), o_status = carve(16),
-                 o_rng = carve((size_t)C * (D + 2) * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(32 * 8),
-                 o_run = carve(sizeof(BlReRun));
+                 o_rng = carve((size_t)C * k * (dl_max + 2) * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(32 * 8),
+                 o_xchg = carve((size_t)C * 2 * k * BL_RE_NRED * 8), o_run = carve(sizeof(BlReRun));
     if (off > ds->run_bytes) {
         if (ds->d_run) hipFree(ds->d_run);
         ds->d_run = nullptr; ds->run_bytes = 0;
         BL_HIP(hipMalloc(&ds->d_run, off));
         ds->run_bytes = off;
     }
-    const size_t state_bytes = (size_t)C * RE_SLOTS * D * 4;
+    const size_t state_bytes = (size_t)C * k * RE_SLOTS * dl_max * 4;
     if (state_bytes > ds->restate_bytes) {
         if (ds->d_restate) hipFree(ds->d_restate);
         ds->d_restate = nullptr; ds->restate_bytes = 0;
@@ -1011,10 +1032,31 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     ds->d_rng = (uint32_t *)(base + o_rng); ds->d_init = (float *)(base + o_init); ds->d_dbg = (long long *)(base + o_dbg);
     ds->d_loc = nullptr;
 
-    // one stream per coordinate, then the scalar and the direction stream; chains are D + 2 streams apart (>= 64)
+    // RNG: one stream per coordinate (the model's order), then the scalar and the direction stream; chains are D + 2 streams
+    // apart (>= 64).  Each workgroup gets the streams of ITS coordinates in its own order; the fixed effects' and the two
+    // scalar streams are replicated (every workgroup advances its copy identically).
     const int stride = (int)D + 2;
-    std::vector<uint32_t> rs((size_t)C * stride * 4);
-    rng_streams_strided(cfg->seed, cfg->chain_offset, stride, C, rs.data());
+    std::vector<uint32_t> all((size_t)C * stride * 4), rs((size_t)C * k * (dl_max + 2) * 4, 0u);
+    rng_streams_strided(cfg->seed, cfg->chain_offset, stride, C, all.data());
+    for (int c = 0; c < C; c++)
+        for (int w = 0; w < k; w++) {
+            const int s0 = w * nloc, cnt = std::min(nloc, N - s0);
+            uint32_t *dst = rs.data() + ((size_t)c * k + w) * (dl_max + 2) * 4;
+            const uint32_t *src = all.data() + (size_t)c * stride * 4;
+            auto put = [&](int local, int ext) { memcpy(dst + (size_t)local * 4, src + (size_t)ext * 4, 16); };
+            int at = 0;
+            for (; at < g.G; at++) put(at, at);
+            if (g.site_re) {
+                for (int i = 0; i < cnt; i++) put(at + i, g.o_u + s0 + i);
+                for (int i = 0; i < cnt; i++) put(at + cnt + i, g.o_v + s0 + i);
+                at += 2 * cnt;
+            }
+            if (g.obs_re)
+                for (int v = 0; v < V; v++)
+                    for (int i = 0; i < cnt; i++) put(at + v * cnt + i, g.o_e + (s0 + i) * V + v);
+            put(dl_max, (int)D);         // scalar stream
+            put(dl_max + 1, (int)D + 1); // direction stream
+        }
     BL_HIP(hipMemcpyAsync(ds->d_rng, rs.data(), rs.size() * 4, hipMemcpyHostToDevice, st));
     std::vector<float> it32;
     if (cfg->init_theta) {
@@ -1023,8 +1065,12 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
         BL_HIP(hipMemcpyAsync(ds->d_init, it32.data(), it32.size() * 4, hipMemcpyHostToDevice, st));
     }
     BlReRun run{};
-    run.m = ds->re;
+    run.m = g;
+    const size_t lds = re_geometry(run.m, nloc, 1, dl_max);
+    if (lds) BL_HIP(hipFuncSetAttribute((const void *)bl_re_nuts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     run.num_chains = C; run.num_warmup = W; run.num_samples = S; run.max_depth = max_depth;
+    run.k = k; run.nloc = nloc; run.dl_max = dl_max;
+    run.xchg = (unsigned long long *)(base + o_xchg);
     run.target_accept = (float)(cfg->target_accept > 0.0 ? cfg->target_accept : 0.8);
     int32_t ws[32], we[32];
     run.nwin = adaptation_schedule(W, ws, we, 32);
@@ -1043,12 +1089,12 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     BL_HIP(hipEventRecord(ds->ev0, st));
     BL_HIP(hipMemsetAsync(ds->d_status, 0, 16, st));
     BL_HIP(hipMemsetAsync(ds->d_dbg, 0, 256, st));
-    const size_t lds = (ds->re.lds_rows ? (size_t)ds->re.n_rows * ds->re.n_sites * 4 : 0) + (ds->re.lds_hot ? (size_t)RE_HOT * D * 4 : 0);
-    hipLaunchKernelGGL(bl_re_nuts_kernel, dim3(C), dim3(BL_RE_NT), lds, st, d_runp);
+    BL_HIP(hipMemsetAsync(run.xchg, 0, (size_t)C * 2 * k * BL_RE_NRED * 8, st));
+    hipLaunchKernelGGL(bl_re_nuts_kernel, dim3(C * k), dim3(BL_RE_NT), lds, st, d_runp);
     BL_HIP(hipGetLastError());
     BL_HIP(hipEventRecord(ds->ev1, st));
     ds->stream = st; ds->in_flight = true; ds->have_run = true;
-    ds->C = C; ds->S = S; ds->W = W; ds->k = 1; ds->nloc = ds->re.n_sites; ds->lds_ld = 0; ds->lds_bytes = (int)lds; ds->staged = ds->re.lds_rows; ds->nvp = 0; ds->ncw = BL_RE_NW;
+    ds->C = C; ds->S = S; ds->W = W; ds->k = k; ds->nloc = nloc; ds->lds_ld = 0; ds->lds_bytes = (int)lds; ds->staged = run.m.lds_rows; ds->nvp = 0; ds->ncw = BL_RE_NW;
     return BL_OK;
 }
 

@@ -2,11 +2,13 @@
 // 215-218): log-density + gradient, and NUTS over all D = Ks + Ko + 2 (+1 +1) + 2 N + N T J coordinates.
 //
 // Shape of the problem: D runs to thousands, so the lane-per-coordinate design of nuts_kernel.hpp does not apply.  Here a
-// chain is ONE workgroup; every vector of the sampler (position, momentum, gradient, tree edges, proposals, checkpoints,
+// chain is k workgroups, each with a contiguous slice of the sites and those sites' effects; the fixed effects and log sds
+// are replicated in every workgroup (same inputs, same arithmetic, same values).  Inside a workgroup every vector of the sampler (position, momentum, gradient, tree edges, proposals, checkpoints,
 // mass matrix, Welford moments) is an array of length D in device memory (L2-resident: 40 D floats per chain), threads
 // own coordinates d = tid, tid + NT, ...; scalars of the sampler are kept redundantly by every thread (all threads see the
 // same reduced sums in LDS and take the same decisions), so nothing is broadcast.  Per leapfrog: two vector passes, one
-// site pass, two block reductions.  The arithmetic follows the oracle (oracle/occu_oracle.c: potential_grad_re,
+// site pass, two block reductions -- each followed, when k > 1, by an exchange of the workgroups' partial sums through
+// self-tagged 8-byte granules in device memory ({epoch, float}: the exchange of nuts_kernel.hpp, agent-scope atomics).  The arithmetic follows the oracle (oracle/occu_oracle.c: potential_grad_re,
 // orc_nuts_run) statement by statement; RNG: one xoshiro stream per coordinate (external order) + the two scalar streams.
 //
 // The site data are the sign-folded rows the plain occu kernels read (occu_device.hpp: bl_eval_sites_hbm): a visit's
@@ -15,7 +17,7 @@
 #pragma once
 #include "nuts_kernel.hpp"
 
-#define BL_RE_NT 1024            // threads per chain
+#define BL_RE_NT 512             // threads per workgroup (measured: 256 / 512 / 1024 -> 512 with 16-32 workgroups per chain)
 #define BL_RE_NW (BL_RE_NT / 64)
 #define BL_RE_MAXK 4             // covariates per side (as the false-positive model)
 #define BL_RE_NRED 26            // widest block reduction
@@ -31,6 +33,11 @@ struct BlReModel {
     float hn_is2_s, hn_is2_o;             // 1 / scale^2 of the HalfNormal priors of site_re_sd / obs_re_sd
     double u_const;                       // the constant part of the potential
     int tps;                              // threads that share one site in the site pass (power of two, <= 64)
+    // a workgroup works on a LOCAL copy of this struct: n_sites = its slice, rows advanced to its first site, D / o_* the
+    // local layout; what refers to the whole dataset stays in the fields below
+    int n_total;                          // sites of the dataset
+    int s0;                               // first site of the slice
+    int x_u, x_v, x_e;                    // external offsets of site_re_occ / site_re_det / obs_re in a draw
     int n_rows;                           // rows of the dataset (KS + T J (KO + 1) + 2 T)
     int lds_rows;                         // 1: every workgroup keeps its own copy of the rows in LDS (n_rows * n_sites floats)
     int lds_hot;                          // 1: the RE_HOT vectors of the chain live in LDS (after the rows), not in device memory
@@ -68,8 +75,10 @@ struct BlReRun {
     int num_chains, num_warmup, num_samples, max_depth, nwin;
     int win_end[32];
     float target_accept;
-    float *state;               // [C][RE_SLOTS][D]
-    uint32_t *rng;              // [C][D + 2][4]: stream of external coordinate e at index e, then scalar, direction
+    int k, nloc, dl_max;        // workgroups per chain, sites per workgroup, coordinates of the largest slice
+    unsigned long long *xchg;   // [C][2][k][BL_RE_NRED] exchange granules (k > 1)
+    float *state;               // [C][k][RE_SLOTS][dl_max]
+    uint32_t *rng;              // [C][k][dl_max + 2][4]: a workgroup's streams in ITS coordinate order, then scalar, direction
     const float *init_theta;    // [C][D] external order, or NULL
     const int *abort_flag;
     float *draws;               // [C][S][D] external order
@@ -83,12 +92,28 @@ struct BlReRun {
 #define BL_RE_T(i)
 #endif
 
-// internal coordinate -> external (oracle / caller) coordinate: obs_re is kept site-fastest inside, replicate-fastest outside
+// local coordinate of a workgroup -> external (oracle / caller) coordinate.  Local order: fixed effects and log sds, then
+// the slice's site_re_occ, site_re_det, then obs_re site-fastest; external order: the model's (obs_re replicate-fastest).
 __device__ __forceinline__ int bl_re_ext(const BlReModel &m, int d)
 {
-    if (!m.obs_re || d < m.o_e) return d;
-    const int r = d - m.o_e, v = r / m.n_sites, i = r - v * m.n_sites;
-    return m.o_e + i * (m.T * m.J) + v;
+    if (d < m.G) return d;
+    const int cnt = m.n_sites;
+    if (m.site_re && d < m.o_u + cnt) return m.x_u + m.s0 + (d - m.o_u);
+    if (m.site_re && d < m.o_v + cnt) return m.x_v + m.s0 + (d - m.o_v);
+    const int r = d - m.o_e, v = r / cnt, i = r - v * cnt;
+    return m.x_e + (m.s0 + i) * (m.T * m.J) + v;
+}
+
+// The slice [s0, s0 + cnt) of the dataset as a model of its own (see BlReModel).
+__device__ __forceinline__ BlReModel bl_re_slice(const BlReModel &g, int s0, int cnt)
+{
+    BlReModel m = g;
+    m.rows = g.rows + s0; m.n_sites = cnt; m.s0 = s0;
+    int at = g.G;
+    if (g.site_re) { m.o_u = at; m.o_v = at + cnt; at += 2 * cnt; }
+    if (g.obs_re) { m.o_e = at; at += cnt * g.T * g.J; }
+    m.D = at;
+    return m;
 }
 
 // Sum NV per-thread values over the workgroup: DPP wave sums, then a fixed-order f64 sum of the wave partials.
@@ -114,6 +139,46 @@ __device__ __forceinline__ void bl_re_block_sum(float (&v)[NV], float *scr /*[NW
     __syncthreads();
 }
 
+// Exchange between the k workgroups of a chain: each publishes its nv block sums as {epoch, float} granules, reads all
+// k x nv of them and forms the totals in fixed order (f64) -- every workgroup gets bit-identical totals in out[].  Two
+// parities of slots: a workgroup can be at most one exchange ahead of the slowest.  Returns false on the spin bound.
+struct BlReXchg {
+    unsigned long long *buf; // [C][2][k][BL_RE_NRED]
+    int k, wg, chain;
+    unsigned epoch, spin_limit;
+};
+__device__ __forceinline__ bool bl_re_exchange(BlReXchg &x, double *out, float *scr2 /*[k][NRED]*/, int *lds_flag, int nv)
+{
+    if (x.k == 1) return true;
+    const int tid = threadIdx.x;
+    x.epoch++;
+    unsigned long long *base = x.buf + (((size_t)x.chain * 2 + (x.epoch & 1u)) * x.k) * BL_RE_NRED;
+    if (tid < nv) {
+        const unsigned long long gr = ((unsigned long long)x.epoch << 32) | (unsigned long long)__float_as_uint((float)out[tid]);
+        __hip_atomic_store(base + (size_t)x.wg * BL_RE_NRED + tid, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int t = tid; t < x.k * nv; t += BL_RE_NT) {
+        const int w = t / nv, v = t - w * nv;
+        unsigned spins = 0;
+        unsigned long long gr;
+        while (true) {
+            gr = __hip_atomic_load(base + (size_t)w * BL_RE_NRED + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(gr >> 32) == x.epoch) break;
+            if (++spins > x.spin_limit) { *lds_flag = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        scr2[w * BL_RE_NRED + v] = __uint_as_float((unsigned)gr);
+    }
+    __syncthreads();
+    if (tid < nv) {
+        double t = 0.0;
+        for (int w = 0; w < x.k; w++) t += (double)scr2[w * BL_RE_NRED + tid];
+        out[tid] = t;
+    }
+    __syncthreads();
+    return *lds_flag == 0;
+}
+
 // Site pass at position z: per-thread partials of the log-likelihood and of its gradient w.r.t. beta / alpha, and the
 // random effects' full potential gradient written to g (the effect's own likelihood term + its Normal(0, sd) prior).
 // part[0] = ll, part[1 .. 5] = d/d beta, part[6 .. 10] = d/d alpha.
@@ -121,7 +186,10 @@ __device__ __forceinline__ void bl_re_block_sum(float (&v)[NV], float *scr /*[NW
 __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float *__restrict__ rows, int ns, const float *__restrict__ z,
                                                 float *__restrict__ g, float (&part)[11])
 {
-    const int tid = threadIdx.x, tps = m.tps, grp = tid / tps, sub = tid - grp * tps, ngrp = BL_RE_NT / tps;
+    // threads of a site sit S = 64 / tps lanes apart in one wave: for a given visit the S neighbouring lanes read S
+    // neighbouring sites (one segment of a row), and the visits are pooled by xor-shuffles over the upper lane bits
+    const int tid = threadIdx.x, tps = m.tps, S = 64 / tps, lane = tid & 63;
+    const int grp = (tid >> 6) * S + (lane & (S - 1)), sub = lane / S, ngrp = BL_RE_NT / tps;
     const int N = m.n_sites, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 1;
     float beta[BL_RE_MAXK + 1], alpha[BL_RE_MAXK + 1];
 #pragma unroll
@@ -182,7 +250,7 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
                     for (int k = 0; k <= BL_RE_MAXK; k++) ga[k] = fmaf(s, w[b][k], ga[k]);
                 }
             }
-            for (int msk = 1; msk < tps; msk <<= 1) { // the site's threads pool their visits
+            for (int msk = S; msk < 64; msk <<= 1) { // the site's threads pool their visits
                 a += __shfl_xor(a, msk);
 #pragma unroll
                 for (int k = 0; k <= BL_RE_MAXK; k++) ga[k] += __shfl_xor(ga[k], msk);
@@ -249,7 +317,7 @@ __device__ __forceinline__ float bl_re_global_grad(const BlReModel &m, int d, fl
     }
     const bool site = m.site_re && d == m.o_phi_s;
     const float isd2 = bl_exp(-2.0f * zd), sd2 = bl_exp(2.0f * zd);
-    const float cnt = site ? 2.0f * (float)m.n_sites : (float)m.n_sites * (float)(m.T * m.J);
+    const float cnt = site ? 2.0f * (float)m.n_total : (float)m.n_total * (float)(m.T * m.J);
     const float ssq = (float)red[site ? 11 : 12];
     // U = sd^2 / (2 s^2) - phi + sum_k (x_k^2 / (2 sd^2) + phi):   dU/dphi = sd^2 / s^2 - 1 - ssq / sd^2 + cnt
     return sd2 * (site ? m.hn_is2_s : m.hn_is2_o) - 1.0f - ssq * isd2 + cnt;
@@ -261,12 +329,12 @@ __device__ __forceinline__ double bl_re_potential(const BlReModel &m, const floa
     double U = -red[0] + 0.5 * pe2 + m.u_const;
     if (m.site_re) {
         const float phi = z[m.o_phi_s];
-        U += 0.5 * (double)(bl_exp(2.0f * phi) * m.hn_is2_s) - (double)phi + 0.5 * red[11] * (double)bl_exp(-2.0f * phi) + 2.0 * m.n_sites * (double)phi;
+        U += 0.5 * (double)(bl_exp(2.0f * phi) * m.hn_is2_s) - (double)phi + 0.5 * red[11] * (double)bl_exp(-2.0f * phi) + 2.0 * m.n_total * (double)phi;
     }
     if (m.obs_re) {
         const float phi = z[m.o_phi_o];
         U += 0.5 * (double)(bl_exp(2.0f * phi) * m.hn_is2_o) - (double)phi + 0.5 * red[12] * (double)bl_exp(-2.0f * phi)
-             + (double)m.n_sites * (m.T * m.J) * (double)phi;
+             + (double)m.n_total * (m.T * m.J) * (double)phi;
     }
     return U;
 }
@@ -326,27 +394,34 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
 {
     __shared__ float scr[BL_RE_NW * BL_RE_NRED];
     __shared__ double red[BL_RE_NRED], red2[BL_RE_NRED];
+    __shared__ float scr2[32 * BL_RE_NRED];
+    __shared__ int xflag;
     const BlReRun &R = *rp;
-    const BlReModel m = R.m;
-    const int chain = blockIdx.x, tid = threadIdx.x, D = m.D, G = m.G;
+    const int chain = blockIdx.x / R.k, wg = blockIdx.x - chain * R.k, tid = threadIdx.x;
     if (chain >= R.num_chains) return;
-    float *sv = R.state + (size_t)chain * RE_SLOTS * D;
+    const int s0 = wg * R.nloc;
+    const BlReModel m = bl_re_slice(R.m, s0, min(R.nloc, R.m.n_sites - s0)); // this workgroup's slice as a model of its own
+    const int D = m.D, G = m.G;
+    const bool lead = wg == 0; // the fixed effects / log sds are replicated; workgroup 0 accounts for them in every sum and output
+    float *sv = R.state + ((size_t)chain * R.k + wg) * RE_SLOTS * R.dl_max;
     extern __shared__ float bl_re_lds[];
-    float *hot = m.lds_hot ? bl_re_lds + (m.lds_rows ? (size_t)m.n_rows * m.n_sites : 0) : sv; // (generic pointers: LDS or device memory)
-    auto V = [&](int slot) -> float * { return (slot < RE_HOT ? hot : sv) + (size_t)slot * D; };
-    uint32_t *rng_base = R.rng + (size_t)chain * (D + 2) * 4;
+    float *hot = m.lds_hot ? bl_re_lds + (m.lds_rows ? (size_t)m.n_rows * R.nloc : 0) : sv; // (generic pointers: LDS or device memory)
+    auto V = [&](int slot) -> float * { return (slot < RE_HOT ? hot : sv) + (size_t)slot * R.dl_max; };
+    uint32_t *rng_base = R.rng + ((size_t)chain * R.k + wg) * (R.dl_max + 2) * 4;
+    BlReXchg xc{R.xchg, R.k, wg, chain, 0u, 1u << 22};
+    if (tid == 0) xflag = 0;
     const int S = R.num_samples, W = R.num_warmup, total = W + S;
     int rows_ns;
     const float *rows = bl_re_rows(m, bl_re_lds, rows_ns);
 
     BlRng rng_u, rng_dir; // every thread carries its own copy of the two scalar streams and advances it identically
     {
-        const uint32_t *a = rng_base + (size_t)D * 4, *b = a + 4;
+        const uint32_t *a = rng_base + (size_t)R.dl_max * 4, *b = a + 4;
         rng_u.s0 = a[0]; rng_u.s1 = a[1]; rng_u.s2 = a[2]; rng_u.s3 = a[3];
         rng_dir.s0 = b[0]; rng_dir.s1 = b[1]; rng_dir.s2 = b[2]; rng_dir.s3 = b[3];
     }
-    auto rng_load = [&](int d) { const uint32_t *s = rng_base + (size_t)bl_re_ext(m, d) * 4; BlRng r; r.s0 = s[0]; r.s1 = s[1]; r.s2 = s[2]; r.s3 = s[3]; return r; };
-    auto rng_store = [&](int d, const BlRng &r) { uint32_t *s = rng_base + (size_t)bl_re_ext(m, d) * 4; s[0] = r.s0; s[1] = r.s1; s[2] = r.s2; s[3] = r.s3; };
+    auto rng_load = [&](int d) { const uint32_t *s = rng_base + (size_t)d * 4; BlRng r; r.s0 = s[0]; r.s1 = s[1]; r.s2 = s[2]; r.s3 = s[3]; return r; };
+    auto rng_store = [&](int d, const BlRng &r) { uint32_t *s = rng_base + (size_t)d * 4; s[0] = r.s0; s[1] = r.s1; s[2] = r.s2; s[3] = r.s3; };
 
     // sampler scalars (identical in every thread)
     float eps = 1.0f, epsdir = 1.0f;
@@ -366,7 +441,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = (long long)clock64(), st_leaves = 0;
 #endif
     auto evaluate = [&]() -> double {
-        float v[14], part[11], ss[2];
+        float v[15], part[11], ss[2];
         const float *z = V(RE_CZ);
         float *g = V(RE_CG);
         BL_RE_T(7)
@@ -375,9 +450,13 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
 #pragma unroll
         for (int k = 0; k < 11; k++) v[k] = part[k];
         v[11] = ss[0]; v[12] = ss[1];
-        v[13] = bl_re_prior_quad(m, z);
+        v[13] = lead ? bl_re_prior_quad(m, z) : 0.0f;
+        // the host's abort request rides in the sums, so that every workgroup of the chain sees it at the same leapfrog
+        v[14] = (lead && tid == 0 && R.abort_flag && *(volatile const int *)R.abort_flag) ? 1.0f : 0.0f;
         BL_RE_T(0)
-        bl_re_block_sum<14>(v, scr, red);
+        bl_re_block_sum<15>(v, scr, red);
+        if (!bl_re_exchange(xc, red, scr2, &xflag, 15)) flag = 4;
+        if (red[14] > 0.0) flag = 5;
         for (int d = tid; d < G; d += BL_RE_NT) g[d] = bl_re_global_grad(m, d, z[d], red);
         const double U = bl_re_potential(m, z, red, red[13]);
         BL_RE_T(1)
@@ -395,7 +474,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
             const float z01 = bl_rng_normal(r);
             rng_store(d, r);
             const float r0 = z01 * __builtin_amdgcn_rsqf(mi);
-            kin[0] = fmaf(mi * r0, r0, kin[0]);
+            if (d >= G || lead) kin[0] = fmaf(mi * r0, r0, kin[0]);
             V(RE_ZL)[d] = th; V(RE_RL)[d] = r0; V(RE_GL)[d] = gr;
             V(RE_ZR)[d] = th; V(RE_RR)[d] = r0; V(RE_GRR)[d] = gr;
             V(RE_ZP)[d] = th; V(RE_GP)[d] = gr; V(RE_RSUM)[d] = r0;
@@ -404,6 +483,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
             V(RE_CZ)[d] = zn; V(RE_CR)[d] = rh; V(RE_CG)[d] = gr;
         }
         bl_re_block_sum<1>(kin, scr, red2); // (its barriers also publish the leaf start)
+        if (!bl_re_exchange(xc, red2, scr2, &xflag, 1)) flag = 4;
         E0 = Ucur + 0.5 * red2[0];
         Up = Ucur; wt = 0.f; sumacc = 0.f; nprop = 0; depth = 0;
         snprop = 0; sturn = false; sdiv = false;
@@ -414,7 +494,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
         BlRng r = rng_load(d);
         const float u0 = bl_rng_uniform(r);
         rng_store(d, r);
-        V(RE_CZ)[d] = R.init_theta ? R.init_theta[(size_t)chain * D + bl_re_ext(m, d)] : 4.0f * u0 - 2.0f;
+        V(RE_CZ)[d] = R.init_theta ? R.init_theta[(size_t)chain * R.m.D + bl_re_ext(m, d)] : 4.0f * u0 - 2.0f;
         V(RE_MINV)[d] = 1.0f; V(RE_WFMEAN)[d] = 0.0f; V(RE_WFM2)[d] = 0.0f;
     }
     __syncthreads();
@@ -441,9 +521,10 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
         for (int d = tid; d < D; d += BL_RE_NT) {
             // (coordinates below G: this thread wrote their gradient in evaluate(); the others' were published by its barriers)
             const float mi = V(RE_MINV)[d];
+            const float mc = (d >= G || lead) ? mi : 0.0f; // weight of this coordinate in the chain-wide sums
             const float cr = bl_leaf_momentum(V(RE_CR)[d], epsdir, V(RE_CG)[d]);
             V(RE_CR)[d] = cr;
-            acc[0] = fmaf(mi * cr, cr, acc[0]);
+            acc[0] = fmaf(mc * cr, cr, acc[0]);
             const float srs = leaf_idx == 0 ? cr : V(RE_SRSUM)[d] + cr;
             V(RE_SRSUM)[d] = srs;
             if (!odd) {
@@ -457,19 +538,20 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
                         const float ck = V(RE_CKR + i)[d];
                         const float s_i = srs - V(RE_CKR + BL_MAX_DEPTH + i)[d] + ck;
                         const float rho = s_i - 0.5f * (ck + cr);
-                        acc[3 + 2 * q] = fmaf(mi * ck, rho, acc[3 + 2 * q]);
-                        acc[4 + 2 * q] = fmaf(mi * cr, rho, acc[4 + 2 * q]);
+                        acc[3 + 2 * q] = fmaf(mc * ck, rho, acc[3 + 2 * q]);
+                        acc[4 + 2 * q] = fmaf(mc * cr, rho, acc[4 + 2 * q]);
                     }
                 }
             }
             const float r_other = going_right ? V(RE_RL)[d] : V(RE_RR)[d];
             const float rl = going_right ? r_other : cr, rr = going_right ? cr : r_other;
             const float rho_t = (V(RE_RSUM)[d] + srs) - 0.5f * (rl + rr);
-            acc[1] = fmaf(mi * rl, rho_t, acc[1]);
-            acc[2] = fmaf(mi * rr, rho_t, acc[2]);
+            acc[1] = fmaf(mc * rl, rho_t, acc[1]);
+            acc[2] = fmaf(mc * rr, rho_t, acc[2]);
         }
         BL_RE_T(2)
         bl_re_block_sum<BL_RE_NRED>(acc, scr, red2, 3 + 2 * nck);
+        if (!bl_re_exchange(xc, red2, scr2, &xflag, 3 + 2 * nck)) flag = 4;
         BL_RE_T(3)
         // ---- decisions (_build_basetree tail, _iterative_build_subtree, _combine_tree, _double_tree) ----
         double dE = (Un + 0.5 * red2[0]) - E0;
@@ -541,8 +623,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
                 wf_close = at_end && middle;
             }
             it++;
-            if (it >= total) flag = 1;
-            if (R.abort_flag && *(volatile const int *)R.abort_flag) flag = 5;
+            if (it >= total && flag == 0) flag = 1;
         }
         // ---- vector part of the same decisions, and -- unless the transition ends -- the next leaf's half step ----
         BL_RE_T(4)
@@ -579,14 +660,14 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
                 V(RE_MINV)[d] = wfn * rn5 * var + 1e-3f * 5.0f * rn5;
                 V(RE_WFMEAN)[d] = 0.0f; V(RE_WFM2)[d] = 0.0f;
             }
-            if (it_done >= W) R.draws[((size_t)chain * S + (it_done - W)) * D + bl_re_ext(m, d)] = th;
+            if (it_done >= W && (d >= G || lead)) R.draws[((size_t)chain * S + (it_done - W)) * R.m.D + bl_re_ext(m, d)] = th;
         }
         if (trans_end) {
             if (wf_close) {
                 wf_n = 0; da_xt = 0.f; da_xavg = 0.f; da_gavg = 0.f; da_t = 0;
                 da_prox = bl_log(10.0f * eps);
             }
-            if (it_done >= W && tid == 0) {
+            if (it_done >= W && tid == 0 && lead) {
                 const size_t s = (size_t)chain * S + (it_done - W);
                 R.num_steps[s] = nprop_out; R.accept_prob[s] = accp;
                 R.diverging[s] = div_out ? 1 : 0; R.potential[s] = (float)Ucur;
@@ -602,14 +683,15 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
 #endif
     }
 #ifdef BL_STAMPS
-    if (R.dbg && chain == 0 && tid == 0) {
+    if (R.dbg && chain == 0 && tid == 0 && lead) {
         for (int i = 0; i < 8; i++) R.dbg[i] = st_acc[i];
         R.dbg[8] = st_leaves;
     }
 #endif
-    for (int d = tid; d < D; d += BL_RE_NT) R.inv_mass[(size_t)chain * D + bl_re_ext(m, d)] = V(RE_MINV)[d];
-    if (tid == 0) {
-        if (flag > 1) atomicMax(R.status, flag);
+    for (int d = tid; d < D; d += BL_RE_NT)
+        if (d >= G || lead) R.inv_mass[(size_t)chain * R.m.D + bl_re_ext(m, d)] = V(RE_MINV)[d];
+    if (tid == 0 && flag > 1) atomicMax(R.status, flag);
+    if (tid == 0 && lead) {
         R.step_size[chain] = eps;
         R.nleap[chain * 2 + 0] = nleap_w; R.nleap[chain * 2 + 1] = nleap_s;
     }
