@@ -127,7 +127,8 @@ int bl_dataset_create_nmix(const bl_dims *dims, const float *site_covs, const fl
  * the detection predictor (masked replicates keep their prior term).  One species.  Coordinates, in NumPyro's
  * unconstrained space:  theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_occ[N], site_re_det[N]),
  * (obs_re[N][T][J])], D = bl_dataset_param_dim().  bl_logp_grad / bl_nuts_* work as for the other models (the sampler
- * runs one workgroup per chain with its vectors in device memory; RNG: one stream per coordinate, D + 2 per chain).
+ * runs k workgroups per chain -- site slices, partial sums exchanged through device memory; all num_chains x k must be
+ * resident, so num_chains x k <= compute units -- with its vectors in device memory / LDS; RNG: one stream per coordinate, D + 2 per chain).
  * At most 4 covariates per side.  bl_deterministic adds the effects to both predictors; bl_predict draws z and y from them.
  */
 int bl_dataset_create_re(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
