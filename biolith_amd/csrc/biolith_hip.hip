@@ -1011,7 +1011,7 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
                  o_acc = carve((size_t)C * Sa * 4), o_pot = carve((size_t)C * Sa * 4), o_eps = carve((size_t)C * 4),
                  o_minv = carve((size_t)C * D * 4), o_nleap = carve((size_t)C * 16), o_status = carve(16),
                  o_rng = carve((size_t)C * k * (dl_max + 2) * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(32 * 8),
-                 o_xchg = carve((size_t)C * 2 * k * BL_RE_NRED * 8), o_run = carve(sizeof(BlReRun));
+                 o_xchg = carve((size_t)C * 2 * k * BL_RE_NRED * 8), o_loc = carve((size_t)C * 4), o_run = carve(sizeof(BlReRun));
     if (off > ds->run_bytes) {
         if (ds->d_run) hipFree(ds->d_run);
         ds->d_run = nullptr; ds->run_bytes = 0;
@@ -1030,7 +1030,7 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     ds->d_acc = (float *)(base + o_acc); ds->d_pot = (float *)(base + o_pot); ds->d_eps = (float *)(base + o_eps);
     ds->d_minv = (float *)(base + o_minv); ds->d_nleap = (long long *)(base + o_nleap); ds->d_status = (int *)(base + o_status);
     ds->d_rng = (uint32_t *)(base + o_rng); ds->d_init = (float *)(base + o_init); ds->d_dbg = (long long *)(base + o_dbg);
-    ds->d_loc = nullptr;
+    ds->d_loc = (int *)(base + o_loc);
 
     // RNG: one stream per coordinate (the model's order), then the scalar and the direction stream; chains are D + 2 streams
     // apart (>= 64).  Each workgroup gets the streams of ITS coordinates in its own order; the fixed effects' and the two
@@ -1071,6 +1071,8 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     run.num_chains = C; run.num_warmup = W; run.num_samples = S; run.max_depth = max_depth;
     run.k = k; run.nloc = nloc; run.dl_max = dl_max;
     run.xchg = (unsigned long long *)(base + o_xchg);
+    { const char *e1 = getenv("BIOLITH_HIP_NO_LOCAL"); run.allow_local = (e1 && e1[0] == '1') ? 0 : 1; }
+    run.xcd_local = ds->d_loc;
     run.target_accept = (float)(cfg->target_accept > 0.0 ? cfg->target_accept : 0.8);
     int32_t ws[32], we[32];
     run.nwin = adaptation_schedule(W, ws, we, 32);
@@ -1090,7 +1092,9 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     BL_HIP(hipMemsetAsync(ds->d_status, 0, 16, st));
     BL_HIP(hipMemsetAsync(ds->d_dbg, 0, 256, st));
     BL_HIP(hipMemsetAsync(run.xchg, 0, (size_t)C * 2 * k * BL_RE_NRED * 8, st));
-    hipLaunchKernelGGL(bl_re_nuts_kernel, dim3(C * k), dim3(BL_RE_NT), lds, st, d_runp);
+    BL_HIP(hipMemsetAsync(ds->d_loc, 0, (size_t)C * 4, st));
+    // XCD-aware mapping in the kernel (surplus blocks exit at once)
+    hipLaunchKernelGGL(bl_re_nuts_kernel, dim3(8 * k * ((C + 7) / 8)), dim3(BL_RE_NT), lds, st, d_runp);
     BL_HIP(hipGetLastError());
     BL_HIP(hipEventRecord(ds->ev1, st));
     ds->stream = st; ds->in_flight = true; ds->have_run = true;

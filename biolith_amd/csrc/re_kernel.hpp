@@ -76,6 +76,8 @@ struct BlReRun {
     int win_end[32];
     float target_accept;
     int k, nloc, dl_max;        // workgroups per chain, sites per workgroup, coordinates of the largest slice
+    int allow_local;            // 0: always the placement-independent exchange
+    int *xcd_local;             // [C] 1 if the chain ran on the L2-local exchange
     unsigned long long *xchg;   // [C][2][k][BL_RE_NRED] exchange granules (k > 1)
     float *state;               // [C][k][RE_SLOTS][dl_max]
     uint32_t *rng;              // [C][k][dl_max + 2][4]: a workgroup's streams in ITS coordinate order, then scalar, direction
@@ -146,6 +148,7 @@ struct BlReXchg {
     unsigned long long *buf; // [C][2][k][BL_RE_NRED]
     int k, wg, chain;
     unsigned epoch, spin_limit;
+    bool local;              // all k workgroups proven to sit on one XCD: stores may stay in that XCD's L2 (nuts_kernel.hpp)
 };
 __device__ __forceinline__ bool bl_re_exchange(BlReXchg &x, double *out, float *scr2 /*[k][NRED]*/, int *lds_flag, int nv)
 {
@@ -155,7 +158,10 @@ __device__ __forceinline__ bool bl_re_exchange(BlReXchg &x, double *out, float *
     unsigned long long *base = x.buf + (((size_t)x.chain * 2 + (x.epoch & 1u)) * x.k) * BL_RE_NRED;
     if (tid < nv) {
         const unsigned long long gr = ((unsigned long long)x.epoch << 32) | (unsigned long long)__float_as_uint((float)out[tid]);
-        __hip_atomic_store(base + (size_t)x.wg * BL_RE_NRED + tid, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (x.local) // the line stays in this XCD's L2, where every consumer of this chain polls it
+            __hip_atomic_store(base + (size_t)x.wg * BL_RE_NRED + tid, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else         // write-through: visible to any XCD
+            __hip_atomic_store(base + (size_t)x.wg * BL_RE_NRED + tid, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int t = tid; t < x.k * nv; t += BL_RE_NT) {
         const int w = t / nv, v = t - w * nv;
@@ -165,7 +171,7 @@ __device__ __forceinline__ bool bl_re_exchange(BlReXchg &x, double *out, float *
             gr = __hip_atomic_load(base + (size_t)w * BL_RE_NRED + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned)(gr >> 32) == x.epoch) break;
             if (++spins > x.spin_limit) { *lds_flag = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
+            if (!x.local) __builtin_amdgcn_s_sleep(1);
         }
         scr2[w * BL_RE_NRED + v] = __uint_as_float((unsigned)gr);
     }
@@ -397,7 +403,10 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
     __shared__ float scr2[32 * BL_RE_NRED];
     __shared__ int xflag;
     const BlReRun &R = *rp;
-    const int chain = blockIdx.x / R.k, wg = blockIdx.x - chain * R.k, tid = threadIdx.x;
+    // XCD-aware mapping (speed only, as in nuts_kernel.hpp): blocks b and b + 8 share an XCD under the observed round-robin
+    // dealing, so chain c takes blocks with b % 8 == c % 8 and its k workgroups share one L2; the first exchange checks it
+    const int label = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int chain = label + 8 * (slot / R.k), wg = slot % R.k, tid = threadIdx.x;
     if (chain >= R.num_chains) return;
     const int s0 = wg * R.nloc;
     const BlReModel m = bl_re_slice(R.m, s0, min(R.nloc, R.m.n_sites - s0)); // this workgroup's slice as a model of its own
@@ -408,7 +417,8 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
     float *hot = m.lds_hot ? bl_re_lds + (m.lds_rows ? (size_t)m.n_rows * R.nloc : 0) : sv; // (generic pointers: LDS or device memory)
     auto V = [&](int slot) -> float * { return (slot < RE_HOT ? hot : sv) + (size_t)slot * R.dl_max; };
     uint32_t *rng_base = R.rng + ((size_t)chain * R.k + wg) * (R.dl_max + 2) * 4;
-    BlReXchg xc{R.xchg, R.k, wg, chain, 0u, 1u << 22};
+    BlReXchg xc{R.xchg, R.k, wg, chain, 0u, 1u << 22, false};
+    const float xcc = (float)bl_xcc_id();
     if (tid == 0) xflag = 0;
     const int S = R.num_samples, W = R.num_warmup, total = W + S;
     int rows_ns;
@@ -441,7 +451,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = (long long)clock64(), st_leaves = 0;
 #endif
     auto evaluate = [&]() -> double {
-        float v[15], part[11], ss[2];
+        float v[17], part[11], ss[2];
         const float *z = V(RE_CZ);
         float *g = V(RE_CG);
         BL_RE_T(7)
@@ -453,9 +463,14 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
         v[13] = lead ? bl_re_prior_quad(m, z) : 0.0f;
         // the host's abort request rides in the sums, so that every workgroup of the chain sees it at the same leapfrog
         v[14] = (lead && tid == 0 && R.abort_flag && *(volatile const int *)R.abort_flag) ? 1.0f : 0.0f;
+        // XCD census (first exchange): k sum(x^2) == (sum x)^2 iff every workgroup reports the same XCC id
+        v[15] = tid == 0 ? xcc : 0.0f; v[16] = tid == 0 ? xcc * xcc : 0.0f;
         BL_RE_T(0)
-        bl_re_block_sum<15>(v, scr, red);
-        if (!bl_re_exchange(xc, red, scr2, &xflag, 15)) flag = 4;
+        const bool first = xc.epoch == 0u;
+        const int nv = first ? 17 : 15;
+        bl_re_block_sum<17>(v, scr, red, nv);
+        if (!bl_re_exchange(xc, red, scr2, &xflag, nv)) flag = 4;
+        if (first && R.allow_local) xc.local = ((double)R.k * red[16] == red[15] * red[15]); // exact: small integers
         if (red[14] > 0.0) flag = 5;
         for (int d = tid; d < G; d += BL_RE_NT) g[d] = bl_re_global_grad(m, d, z[d], red);
         const double U = bl_re_potential(m, z, red, red[13]);
@@ -692,6 +707,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
         if (d >= G || lead) R.inv_mass[(size_t)chain * R.m.D + bl_re_ext(m, d)] = V(RE_MINV)[d];
     if (tid == 0 && flag > 1) atomicMax(R.status, flag);
     if (tid == 0 && lead) {
+        if (R.xcd_local) R.xcd_local[chain] = xc.local ? 1 : 0;
         R.step_size[chain] = eps;
         R.nleap[chain * 2 + 0] = nleap_w; R.nleap[chain * 2 + 1] = nleap_s;
     }

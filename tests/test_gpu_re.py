@@ -148,3 +148,18 @@ def test_combined_random_effects_like_reference():
     r = results.mcmc.result
     print("combined RE: D", r.draws.shape[-1], "kernel ms", r.kernel_ms, "leapfrogs", int(r.n_leapfrog.sum()),
           "us/leapfrog", 1e3 * r.kernel_ms / max(int(r.n_leapfrog.sum()), 1))
+
+
+def test_re_chains_sharded_over_devices_reproduce_the_single_launch():
+    """fit(devices=[0, 0]): two launches of two chains each (chain_offset 0 and 2) draw the same streams as one launch of
+    four -- the random-effects streams are D + 2 per chain, offset by the chain's global index."""
+    from biolith_amd.models import occu, simulate
+    from biolith_amd.utils import fit
+
+    data, _ = simulate(simulate_missing=True, n_sites=60, deployment_days_per_site=70)
+    kw = dict(site_random_effects=True, obs_random_effects=True, num_chains=4, num_samples=20, num_warmup=20, random_seed=4)
+    one = fit(occu, **data, **kw)
+    two = fit(occu, **data, **kw, devices=[0, 0])
+    for k in ("cov_state_0", "site_re_sd", "obs_re_sd"):
+        assert np.allclose(one.samples[k], two.samples[k], atol=1e-5), k
+    assert np.allclose(one.samples["obs_re"], two.samples["obs_re"], atol=1e-4)
