@@ -163,3 +163,29 @@ def test_re_chains_sharded_over_devices_reproduce_the_single_launch():
     for k in ("cov_state_0", "site_re_sd", "obs_re_sd"):
         assert np.allclose(one.samples[k], two.samples[k], atol=1e-5), k
     assert np.allclose(one.samples["obs_re"], two.samples["obs_re"], atol=1e-4)
+
+
+@pytest.mark.parametrize("ks,ko,periods", [(0, 0, 1), (4, 4, 2), (2, 1, 3)])
+def test_re_covariate_counts_and_periods(ks, ko, periods):
+    """Dimension extremes (no covariates at all, four per side) and several periods sharing one site effect: potential and
+    gradient against the oracle over every coordinate, identical first trees, on the one-workgroup and on a sliced chain."""
+    rng = np.random.default_rng(10 * ks + ko + periods)
+    N, J = 70, 6
+    X = rng.normal(size=(N, ks)).astype(np.float32)
+    W = rng.normal(size=(N, periods, J, ko)).astype(np.float32)
+    Y = (rng.uniform(size=(1, N, periods, J)) < 0.35).astype(np.float32)
+    Y[0, rng.integers(0, N, 25), rng.integers(0, periods, 25), rng.integers(0, J, 25)] = np.nan
+    if ko:
+        W[rng.integers(0, N, 5), 0, rng.integers(0, J, 5), 0] = np.nan
+    kw = dict(model="occu_re", site_random_effects=True, obs_random_effects=True, prior_site_re_sd=0.8, prior_obs_re_sd=1.3)
+    od, ds = oracle.OracleData(X, W, Y, **kw), OccuDataset(X, W, Y, **kw)
+    assert ds.D == od.D == ks + ko + 4 + 2 * N + N * periods * J
+    th = rng.uniform(-1.0, 1.0, size=(2, od.D)).astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= 2e-6 and np.max(np.abs(Gg - Go)) <= 2e-5 * np.max(np.abs(Go))
+    o = oracle.nuts_run(od, 0, 3, num_chains=2, seed=8)
+    for k in (1, 4):
+        r = ds.nuts(num_warmup=0, num_samples=3, num_chains=2, seed=8, wgs_per_chain=k)
+        assert np.array_equal(o["num_steps"][:, :2], r.num_steps[:, :2]), (k, o["num_steps"], r.num_steps)
+        assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=5e-3)
