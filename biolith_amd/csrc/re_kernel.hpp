@@ -120,17 +120,29 @@ __device__ __forceinline__ BlReModel bl_re_slice(const BlReModel &g, int s0, int
 
 // Sum NV per-thread values over the workgroup: DPP wave sums, then a fixed-order f64 sum of the wave partials.
 // out[] (LDS) is valid for every thread on return.
+template <int M, int NV>
+__device__ __forceinline__ void bl_re_wave_sums(const float (&v)[NV], float *dst, int n_used)
+{
+    float t[M];
+#pragma unroll
+    for (int k = 0; k < M; k++) t[k] = k < NV ? v[k < NV ? k : 0] : 0.0f;
+    bl_wave_sum_vec_l63<M>(t); // M interleaved DPP chains, totals in lane 63
+    if ((threadIdx.x & 63) == 63) {
+#pragma unroll
+        for (int k = 0; k < M; k++)
+            if (k < n_used) dst[k] = t[k];
+    }
+}
 template <int NV>
 __device__ __forceinline__ void bl_re_block_sum(float (&v)[NV], float *scr /*[NW][NRED]*/, double *out /*[NRED]*/, int n_used = NV)
 {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-    for (int k = 0; k < NV; k++) {
-        if (k < n_used) { // workgroup-uniform
-            const float s = bl_wave_sum(v[k]);
-            if (lane == 0) scr[wave * BL_RE_NRED + k] = s;
-        }
-    }
+    const int tid = threadIdx.x, wave = tid >> 6;
+    float *dst = scr + wave * BL_RE_NRED;
+    // (workgroup-uniform choice of the chain count: most leaves close few checkpoints)
+    if (NV <= 5 || n_used <= 5) bl_re_wave_sums<(NV < 5 ? (NV < 3 ? 3 : NV) : 5)>(v, dst, n_used);
+    else if (NV <= 9 || n_used <= 9) bl_re_wave_sums<(NV < 9 ? NV : 9)>(v, dst, n_used);
+    else if (NV <= 17 || n_used <= 17) bl_re_wave_sums<(NV < 17 ? NV : 17)>(v, dst, n_used);
+    else bl_re_wave_sums<NV>(v, dst, n_used);
     __syncthreads();
     if (tid < n_used) {
         double s = 0.0;
