@@ -189,3 +189,21 @@ def test_re_covariate_counts_and_periods(ks, ko, periods):
         r = ds.nuts(num_warmup=0, num_samples=3, num_chains=2, seed=8, wgs_per_chain=k)
         assert np.array_equal(o["num_steps"][:, :2], r.num_steps[:, :2]), (k, o["num_steps"], r.num_steps)
         assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=5e-3)
+
+
+def test_re_timeout_stops_every_workgroup_of_the_chain():
+    """fit(timeout=...) on the sliced sampler: the abort request travels inside the exchanged sums, so all workgroups of a
+    chain leave at the same leapfrog (none is left spinning on the others) and the handle is usable afterwards."""
+    import time
+
+    from biolith_amd.models import occu, simulate
+    from biolith_amd.utils import fit
+    from biolith_amd.utils.misc import TimeoutException
+
+    data, _ = simulate(simulate_missing=True)
+    t0 = time.time()
+    with pytest.raises(TimeoutException):
+        fit(occu, **data, obs_random_effects=True, num_chains=2, num_samples=10, num_warmup=10 ** 8, timeout=1)
+    assert time.time() - t0 < 30
+    res = fit(occu, **data, obs_random_effects=True, num_chains=2, num_samples=20, num_warmup=20)
+    assert np.all(np.isfinite(res.samples["obs_re_sd"]))
