@@ -192,6 +192,7 @@ struct bl_dataset {
     BlDevData dd{};
     const KernelEntry *kern = nullptr;
     bl_normal_prior pb{}, pa{};
+    int fam_b = 0, fam_a = 0; // BL_PRIOR_NORMAL / BL_PRIOR_LAPLACE (bl_dataset_set_prior_family)
     // raw nan_to_num'd obs covariates, site-fastest [V][Ko][n_stride], for prob_detection (lazy upload)
     std::vector<float> h_wraw;
     float *d_wraw = nullptr;
@@ -747,6 +748,32 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
     return BL_OK;
 }
 
+extern "C" int bl_dataset_set_prior_family(bl_dataset *ds, int family_beta, int family_alpha)
+{
+    if (!ds) return bl_fail(BL_ERR_INVALID, "NULL argument");
+    if ((family_beta != BL_PRIOR_NORMAL && family_beta != BL_PRIOR_LAPLACE) || (family_alpha != BL_PRIOR_NORMAL && family_alpha != BL_PRIOR_LAPLACE))
+        return bl_fail(BL_ERR_INVALID, "prior family must be BL_PRIOR_NORMAL or BL_PRIOR_LAPLACE");
+    if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
+    BlDevData &dd = ds->dd;
+    // constant of the potential: log(scale) + log(2 pi) / 2 per Normal coefficient, log(2 scale) per Laplace one
+    const double HL2PI = 0.91893853320467274178;
+    auto konst = [&](int fam, double scale) { return fam == BL_PRIOR_LAPLACE ? std::log(2.0 * scale) : std::log(scale) + HL2PI; };
+    const double before = (ds->Ks + 1) * konst(ds->fam_b, ds->pb.scale) + (ds->Ko + 1) * konst(ds->fam_a, ds->pa.scale);
+    const double after = (ds->Ks + 1) * konst(family_beta, ds->pb.scale) + (ds->Ko + 1) * konst(family_alpha, ds->pa.scale);
+    dd.prior_const += after - before;
+    ds->fam_b = family_beta; ds->fam_a = family_alpha;
+    dd.isc2_b = family_beta == BL_PRIOR_LAPLACE ? 0.0f : (float)(1.0 / (ds->pb.scale * ds->pb.scale));
+    dd.l1_b = family_beta == BL_PRIOR_LAPLACE ? (float)(1.0 / ds->pb.scale) : 0.0f;
+    dd.isc2_a = family_alpha == BL_PRIOR_LAPLACE ? 0.0f : (float)(1.0 / (ds->pa.scale * ds->pa.scale));
+    dd.l1_a = family_alpha == BL_PRIOR_LAPLACE ? (float)(1.0 / ds->pa.scale) : 0.0f;
+    if (ds->model == 6) {
+        BlReModel &m = ds->re;
+        m.u_const += after - before;
+        m.isc2_b = dd.isc2_b; m.l1_b = dd.l1_b; m.isc2_a = dd.isc2_a; m.l1_a = dd.l1_a;
+    }
+    return BL_OK;
+}
+
 extern "C" int bl_dataset_destroy(bl_dataset *ds)
 {
     if (!ds) return BL_OK;
@@ -846,10 +873,10 @@ __global__ void bl_logp_final_kernel(BlDevData dd, int k, const double *theta, c
         grad[(size_t)b * D + lane] = -acc + (dd.fp_a + dd.fp_b) * sig - dd.fp_a;
     } else if (lane < D) {
         const bool is_b = lane <= dd.Ks;
-        const double loc = is_b ? dd.loc_b : dd.loc_a, isc2 = is_b ? dd.isc2_b : dd.isc2_a;
+        const double loc = is_b ? dd.loc_b : dd.loc_a, isc2 = is_b ? dd.isc2_b : dd.isc2_a, l1 = is_b ? dd.l1_b : dd.l1_a;
         const double dth = theta[(size_t)b * D + lane] - loc;
-        pr = 0.5 * dth * dth * isc2;
-        grad[(size_t)b * D + lane] = -acc + dth * isc2;
+        pr = 0.5 * dth * dth * isc2 + fabs(dth) * l1; // Normal or Laplace (one of isc2, l1 is 0)
+        grad[(size_t)b * D + lane] = -acc + dth * isc2 + ((dth > 0.0) - (dth < 0.0)) * l1;
     }
     const double prior = bl_wave_sum_d(pr);
     if (lane == D) U[b] = -acc + prior + dd.prior_const;
@@ -900,6 +927,7 @@ extern "C" int bl_dataset_create_re(const bl_dims *dims, const float *site_covs,
     if (m.site_re) { m.o_u = at; m.o_v = at + N; at += 2 * N; }
     if (m.obs_re) { m.o_e = at; at += N * T * J; }
     m.loc_b = ds->dd.loc_b; m.isc2_b = ds->dd.isc2_b; m.loc_a = ds->dd.loc_a; m.isc2_a = ds->dd.isc2_a;
+    m.l1_b = 0.0f; m.l1_a = 0.0f;
     m.hn_is2_s = site_random_effects ? (float)(1.0 / (prior_site_re_sd_scale * prior_site_re_sd_scale)) : 0.0f;
     m.hn_is2_o = obs_random_effects ? (float)(1.0 / (prior_obs_re_sd_scale * prior_obs_re_sd_scale)) : 0.0f;
     const double HL2PI = 0.91893853320467274178, HN0 = 0.5 * std::log(2.0 / 3.14159265358979323846);
@@ -1172,6 +1200,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     if (cold.nwin > 32) return bl_fail(BL_ERR_INVALID, "adaptation schedule too long");
     for (int i = 0; i < 32; i++) cold.win_end[i] = i < cold.nwin ? we[i] : 0x7fffffff;
     cold.loc_b = ds->dd.loc_b; cold.isc2_b = ds->dd.isc2_b; cold.loc_a = ds->dd.loc_a; cold.isc2_a = ds->dd.isc2_a;
+    cold.l1_b = ds->dd.l1_b; cold.l1_a = ds->dd.l1_a;
     cold.prior_const = ds->dd.prior_const;
     cold.fp_a = (float)ds->fp_a; cold.fp_b = (float)ds->fp_b;
     cold.rng = ds->d_rng;

@@ -69,7 +69,8 @@ struct BlNutsCold {
     int num_warmup, num_samples, nwin;
     float target_accept;
     int win_end[32];               // numpyro adaptation windows (inclusive ends)
-    float loc_b, isc2_b, loc_a, isc2_a;  // Normal prior loc, 1/scale^2
+    float loc_b, isc2_b, loc_a, isc2_a;  // Normal prior loc, 1/scale^2 (0 for a Laplace prior)
+    float l1_b, l1_a;                    // Laplace prior: 1/scale (0 for a Normal prior)
     double prior_const;            // sum_k log(scale_k) + D/2 log(2 pi)  (+ log B(a,b) for MODEL 2)
     float fp_a, fp_b;              // MODEL 2: Beta(a, b) prior of the false-positive rate; MODEL 3: Exponential(rate = fp_a)
     const uint32_t *rng;           // [C][64][4] xoshiro states (host-jumped)
@@ -232,7 +233,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     int pend_snprop = 0;
     bool init_pending = true;           // evaluating the initial position
     bool local = false;                 // L2-local exchange proven safe for this chain
-    float prior_loc = 0.f, prior_isc2 = 0.f;
+    float prior_loc = 0.f, prior_isc2 = 0.f, prior_l1 = 0.f;
     double prior_const = 0.0;
     int S = 0, W = 0, total = 0;
     const float xcc = (float)bl_xcc_id();
@@ -260,7 +261,8 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         S = cold->num_samples; W = cold->num_warmup; total = W + S;
         prior_loc = (lane <= Ks) ? cold->loc_b : cold->loc_a;
         prior_isc2 = act ? ((lane <= Ks) ? cold->isc2_b : cold->isc2_a) : 0.0f;
-        if (is_phi) { prior_loc = cold->fp_a; prior_isc2 = cold->fp_b; }
+        prior_l1 = act ? ((lane <= Ks) ? cold->l1_b : cold->l1_a) : 0.0f;
+        if (is_phi) { prior_loc = cold->fp_a; prior_isc2 = cold->fp_b; prior_l1 = 0.0f; }
         prior_const = cold->prior_const;
         const uint32_t *rs = cold->rng + ((size_t)chain * BL_NSTREAM + lane) * 4;
         rng_d.s0 = rs[0]; rng_d.s1 = rs[1]; rng_d.s2 = rs[2]; rng_d.s3 = rs[3];
@@ -563,10 +565,12 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             // ------------------------------------------------ potential at cz (lane d) ----
             // prior of lane d: pe2 = 2 x its energy, pg = d energy / d theta_d
             //   Normal(loc, scale):            pe2 = (theta-loc)^2 / scale^2 ,  pg = (theta-loc) / scale^2
+            //   Laplace(loc, scale):           pe2 = 2 |theta-loc| / scale ,    pg = sign(theta-loc) / scale   (one of isc2, l1 is 0)
             //   phi = logit f, f ~ Beta(a,b):  energy = a softplus(-phi) + b softplus(phi)  (Jacobian included),
             //                                  pg = (a+b) sigmoid(phi) - a        (prior_loc = a, prior_isc2 = b)
             const float dth = cz - prior_loc;
-            float pe2 = dth * dth * prior_isc2, pg = dth * prior_isc2;
+            float pe2 = fmaf(dth * dth, prior_isc2, 2.0f * fabsf(dth) * prior_l1);
+            float pg = fmaf(dth, prior_isc2, dth > 0.0f ? prior_l1 : (dth < 0.0f ? -prior_l1 : 0.0f));
             if constexpr (MODEL == 2) {
                 if (is_phi) {
                     const float e = bl_exp(-fabsf(cz)), op = 1.0f + e, l = bl_log(op);

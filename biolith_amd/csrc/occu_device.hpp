@@ -62,7 +62,8 @@ struct BlDevData {
     int n_sites, n_stride, T, J;
     int Ks, Ko;     // actual covariate counts (theta layout)
     int KS, KO;     // padded counts the rows were packed for (= kernel template capacity)
-    float loc_b, isc2_b, loc_a, isc2_a;  // Normal prior loc, 1/scale^2
+    float loc_b, isc2_b, loc_a, isc2_a;  // Normal prior loc, 1/scale^2 (0 for a Laplace prior)
+    float l1_b, l1_a;                    // Laplace(loc, scale) prior: 1/scale (0 for a Normal prior); energy = dth^2 isc2 / 2 + |dth| l1
     double prior_const;                  // sum_k log(scale_k) + D/2 log(2 pi)  (+ log B(a,b) with has_fp)
     int has_fp;                          // 0, or the model id (2: logit rate, Beta prior; 3: log rate, Exponential prior)
                                          // whose false-positive coordinate phi is theta's last entry

@@ -29,7 +29,8 @@ struct BlReModel {
     int site_re, obs_re;
     int G0, G, D;                         // fixed effects, + log sds, all coordinates
     int o_phi_s, o_phi_o, o_u, o_v, o_e;  // offsets (internal order = external order except inside the obs_re block)
-    float loc_b, isc2_b, loc_a, isc2_a;   // Normal priors of beta / alpha
+    float loc_b, isc2_b, loc_a, isc2_a;   // Normal priors of beta / alpha (isc2 = 0 for a Laplace prior)
+    float l1_b, l1_a;                     // Laplace priors: 1 / scale (0 for a Normal prior)
     float hn_is2_s, hn_is2_o;             // 1 / scale^2 of the HalfNormal priors of site_re_sd / obs_re_sd
     double u_const;                       // the constant part of the potential
     int tps;                              // threads that share one site in the site pass (power of two, <= 64)
@@ -329,9 +330,10 @@ __device__ __forceinline__ float bl_re_global_grad(const BlReModel &m, int d, fl
 {
     if (d < m.G0) {
         const bool is_b = d <= m.Ks;
-        const float loc = is_b ? m.loc_b : m.loc_a, isc2 = is_b ? m.isc2_b : m.isc2_a;
+        const float loc = is_b ? m.loc_b : m.loc_a, isc2 = is_b ? m.isc2_b : m.isc2_a, l1 = is_b ? m.l1_b : m.l1_a;
         const double gl = red[is_b ? 1 + d : 6 + (d - m.Ks - 1)];
-        return (float)(-gl) + (zd - loc) * isc2;
+        const float dth = zd - loc;
+        return (float)(-gl) + fmaf(dth, isc2, dth > 0.0f ? l1 : (dth < 0.0f ? -l1 : 0.0f));
     }
     const bool site = m.site_re && d == m.o_phi_s;
     const float isd2 = bl_exp(-2.0f * zd), sd2 = bl_exp(2.0f * zd);
@@ -368,14 +370,14 @@ __device__ __forceinline__ void bl_re_effect_squares(const BlReModel &m, const f
     }
 }
 
-// this thread's share of sum over fixed effects of ((z - loc) / scale)^2
+// this thread's share of twice the fixed effects' prior energy: ((z - loc) / scale)^2 (Normal) or 2 |z - loc| / scale (Laplace)
 __device__ __forceinline__ float bl_re_prior_quad(const BlReModel &m, const float *z)
 {
     float pe = 0.0f;
     for (int d = threadIdx.x; d < m.G0; d += BL_RE_NT) {
         const bool is_b = d <= m.Ks;
         const float t = z[d] - (is_b ? m.loc_b : m.loc_a);
-        pe = fmaf(t * t, is_b ? m.isc2_b : m.isc2_a, pe);
+        pe = fmaf(t * t, is_b ? m.isc2_b : m.isc2_a, fmaf(2.0f * fabsf(t), is_b ? m.l1_b : m.l1_a, pe));
     }
     return pe;
 }

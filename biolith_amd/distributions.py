@@ -17,6 +17,25 @@ class Normal:
 
 
 @dataclass(frozen=True)
+class Laplace:
+    loc: float = 0.0
+    scale: float = 1.0
+
+
+class LocScale(tuple):
+    """``(loc, scale)`` of a coefficient prior; compares equal to the plain tuple and carries the family
+    (``"normal"`` or ``"laplace"``: the two ``grid_search_priors`` tries, biolith/utils/grid_search.py:366-371)."""
+
+    def __new__(cls, loc, scale, family="normal"):
+        self = super().__new__(cls, (loc, scale))
+        self.family = family
+        return self
+
+    def __reduce__(self):
+        return (LocScale, (self[0], self[1], self.family))
+
+
+@dataclass(frozen=True)
 class HalfNormal:
     scale: float = 1.0
 
@@ -63,10 +82,11 @@ def as_exponential(prior, name: str = "prior") -> float:
 
 
 def as_normal(prior, name: str = "prior") -> tuple:
-    """(loc, scale) of a Normal prior; duck-types numpyro's ``dist.Normal`` (has .loc/.scale)."""
+    """(loc, scale) of a Normal -- or Laplace -- coefficient prior as a :class:`LocScale`; duck-types numpyro's
+    ``dist.Normal`` / ``dist.Laplace`` (class name, .loc, .scale)."""
     cls = type(prior).__name__
-    if cls != "Normal" or not hasattr(prior, "loc") or not hasattr(prior, "scale"):
-        raise NotImplementedError(f"{name}: the HIP engine supports Normal(loc, scale) priors, got {prior!r}")
+    if cls not in ("Normal", "Laplace") or not hasattr(prior, "loc") or not hasattr(prior, "scale"):
+        raise NotImplementedError(f"{name}: the HIP engine supports Normal(loc, scale) and Laplace(loc, scale) priors, got {prior!r}")
     import numpy as np
 
     loc, scale = np.asarray(prior.loc, dtype=float), np.asarray(prior.scale, dtype=float)
@@ -75,7 +95,7 @@ def as_normal(prior, name: str = "prior") -> tuple:
     loc, scale = float(loc.reshape(())), float(scale.reshape(()))
     if not scale > 0:
         raise ValueError(f"{name}: scale must be positive")
-    return loc, scale
+    return LocScale(loc, scale, cls.lower())
 
 
 def as_beta(prior, name: str = "prior") -> tuple:

@@ -121,6 +121,12 @@ class OccuDataset:
                                              device, C.byref(h)))
         self._h = h
         self._lib = lib
+        # Laplace instead of Normal coefficient priors (distributions.LocScale.family; utils/grid_search.py:366-371)
+        fam = [getattr(p, "family", "normal") for p in (prior_beta, prior_alpha)]
+        if any(f not in ("normal", "laplace") for f in fam):
+            raise ValueError(f"unknown prior family {fam}")
+        if "laplace" in fam:
+            _ffi.check(lib.bl_dataset_set_prior_family(h, int(fam[0] == "laplace"), int(fam[1] == "laplace")))
         self.site_re, self.obs_re = bool(site_random_effects), bool(obs_random_effects)
 
     def close(self):

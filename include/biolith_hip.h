@@ -135,6 +135,14 @@ int bl_dataset_create_re(const bl_dims *dims, const float *site_covs, const floa
                          int site_random_effects, int obs_random_effects, double prior_site_re_sd_scale,
                          double prior_obs_re_sd_scale, const bl_normal_prior *prior_beta,
                          const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
+/*
+ * The other prior family biolith.utils.grid_search_priors tries for the regression coefficients
+ * (utils/grid_search.py:366-371): Laplace(loc, scale) instead of Normal(loc, scale), per side, with the (loc, scale) the
+ * dataset was created with.  Call between bl_dataset_create* and the first use; applies to every model.
+ */
+#define BL_PRIOR_NORMAL 0
+#define BL_PRIOR_LAPLACE 1
+int bl_dataset_set_prior_family(bl_dataset *ds, int family_beta, int family_alpha);
 int bl_dataset_destroy(bl_dataset *ds);
 /* D = Ks+1 + Ko+1; theta = [beta_0..beta_Ks, alpha_0..alpha_Ko] */
 int bl_dataset_param_dim(const bl_dataset *ds, int *D);

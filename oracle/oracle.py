@@ -51,6 +51,7 @@ def lib():
             L.orc_data_set_cop.argtypes = [C.c_void_p, dp, dp, C.c_int, C.c_double]
             L.orc_data_set_nmix.argtypes = [C.c_void_p, dp, C.c_int]
             L.orc_data_set_re.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
+            L.orc_data_set_prior_family.argtypes = [C.c_void_p, C.c_int, C.c_int]
             L.orc_potential_grad.restype = C.c_double
             L.orc_potential_grad.argtypes = [C.c_void_p, dp, dp]
             L.orc_rng_streams.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
@@ -87,7 +88,8 @@ class OracleData:
 
     def __init__(self, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0), model="occu",
                  max_abundance=100, fp_mode="constant", prior_fp=(2.0, 5.0), session_duration=None, prior_fp_rate=1.0,
-                 site_random_effects=False, obs_random_effects=False, prior_site_re_sd=1.0, prior_obs_re_sd=1.0):
+                 site_random_effects=False, obs_random_effects=False, prior_site_re_sd=1.0, prior_obs_re_sd=1.0,
+                 prior_family=("normal", "normal")):
         X = _as_f32_f64(site_covs)
         W = _as_f32_f64(obs_covs)
         Y = _as_f32_f64(obs)
@@ -130,6 +132,10 @@ class OracleData:
             lib().orc_data_set_re(self._h, int(bool(site_random_effects)), int(bool(obs_random_effects)),
                                   float(prior_site_re_sd), float(prior_obs_re_sd))
             self.D = int(lib().orc_data_dim(self._h))
+        # prior family of beta / alpha: "normal" (occu.py:28-29) or "laplace" (utils/grid_search.py:366-371), same (loc, scale)
+        assert all(f in ("normal", "laplace") for f in prior_family)
+        self.prior_family = tuple(prior_family)
+        lib().orc_data_set_prior_family(self._h, int(prior_family[0] == "laplace"), int(prior_family[1] == "laplace"))
         self.site_re, self.obs_re = bool(site_random_effects), bool(obs_random_effects)
         self.prior_site_re_sd, self.prior_obs_re_sd = float(prior_site_re_sd), float(prior_obs_re_sd)
 
@@ -227,7 +233,7 @@ def _bernoulli_logpmf_clamped(p, y):
 
 
 def literal_log_joint(theta, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0),
-                      clamp_z1=False, prob_fp_constant=0.0, prob_fp_unoccupied=0.0):
+                      clamp_z1=False, prob_fp_constant=0.0, prob_fp_unoccupied=0.0, prior_family=("normal", "normal")):
     """log p(theta, y) for one species; obs (N,T,J).  ``clamp_z1`` applies numpyro's prob clamp
     in the z=1 branch too (the C oracle does not; they differ only for |nu| > ~15.9).
     ``prob_fp_*``: the false-positive rates of occu.py:146-157 as given numbers (their own prior is
@@ -264,10 +270,12 @@ def literal_log_joint(theta, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), pr
         per_z.append(lz + ly)
     ll = np.logaddexp(per_z[0], per_z[1]).sum()
 
-    def normal_logpdf(v, loc, scale):
+    def prior_logpdf(v, loc, scale, family):   # dist.Normal / dist.Laplace .log_prob
+        if family == "laplace":
+            return (-np.abs(v - loc) / scale - np.log(2.0 * scale)).sum()
         return (-0.5 * ((v - loc) / scale) ** 2 - np.log(scale) - 0.5 * np.log(2 * np.pi)).sum()
 
-    return ll + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
+    return ll + prior_logpdf(beta, *prior_beta, prior_family[0]) + prior_logpdf(alpha, *prior_alpha, prior_family[1])
 
 
 def literal_log_joint_re(theta, site_covs, obs_covs, obs, site_random_effects=True, obs_random_effects=False,

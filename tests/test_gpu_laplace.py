@@ -1,0 +1,84 @@
+"""Laplace coefficient priors (the second family biolith/utils/grid_search.py:366-371 tries) on the kernels, and
+``grid_search_priors`` itself (grid_search.py:116-516, its own test :519-540)."""
+import warnings
+
+import numpy as np
+import pytest
+
+import oracle
+from biolith_amd.distributions import Laplace, LocScale
+from biolith_amd.engine import OccuDataset
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+PB, PA = LocScale(0.2, 0.7, "laplace"), LocScale(-0.1, 1.5, "laplace")
+
+
+@pytest.mark.parametrize("model,kw", [("occu", {}), ("occu_fp", dict(fp_mode="constant")), ("occu_re", dict(site_random_effects=True))])
+@pytest.mark.parametrize("families", [("laplace", "laplace"), ("normal", "laplace")])
+def test_laplace_prior_parity(model, kw, families):
+    g = load_golden("small_3x3")
+    pb, pa = LocScale(0.2, 0.7, families[0]), LocScale(-0.1, 1.5, families[1])
+    od = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], (0.2, 0.7), (-0.1, 1.5), model=model, prior_family=families, **kw)
+    ds = OccuDataset(g["site_covs"], g["obs_covs"], g["obs"], pb, pa, model=model, **kw)
+    th = np.random.default_rng(4).uniform(-1.2, 1.2, size=(3, od.D)).astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= 2e-6, (Ug, Uo)
+    assert np.max(np.abs(Gg - Go)) <= 2e-5 * np.max(np.abs(Go))
+    o = oracle.nuts_run(od, 0, 4, num_chains=2, seed=3)
+    r = ds.nuts(num_warmup=0, num_samples=4, num_chains=2, seed=3)
+    assert np.array_equal(o["num_steps"][:, :3], r.num_steps[:, :3]), (o["num_steps"], r.num_steps)
+    assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=5e-3)
+
+
+def test_laplace_posterior_matches_oracle():
+    g = load_golden("small_3x3")
+    od = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], (0.0, 0.25), (0.0, 0.25), prior_family=("laplace", "laplace"))
+    ds = OccuDataset(g["site_covs"], g["obs_covs"], g["obs"], LocScale(0.0, 0.25, "laplace"), LocScale(0.0, 0.25, "laplace"))
+    o = oracle.nuts_run(od, 300, 500, num_chains=4, seed=0)
+    r = ds.nuts(num_warmup=300, num_samples=500, num_chains=4, seed=50)
+    fg, fo = r.draws.reshape(-1, od.D).astype(np.float64), o["draws"].reshape(-1, od.D)
+    mcse = np.sqrt(fg.var(0) / oracle.effective_sample_size(r.draws.astype(np.float64)) + fo.var(0) / oracle.effective_sample_size(o["draws"]))
+    assert np.all(np.abs(fg.mean(0) - fo.mean(0)) <= 4 * mcse)
+    ratio = fg.std(0) / fo.std(0)
+    assert np.all((ratio > 0.85) & (ratio < 1.18)), ratio
+    # the tight Laplace prior pulls the coefficients towards 0 compared with the default Normal(0, 1) fit
+    r0 = OccuDataset(g["site_covs"], g["obs_covs"], g["obs"]).nuts(num_warmup=300, num_samples=500, num_chains=4, seed=50)
+    assert np.abs(fg.mean(0)).sum() < np.abs(r0.draws.reshape(-1, od.D).mean(0)).sum()
+
+
+def test_grid_search_like_reference():  # grid_search.py:519-540
+    from biolith_amd.models import occu, simulate
+    from biolith_amd.regression import LinearRegression
+    from biolith_amd.utils import grid_search_priors
+
+    data, _ = simulate(simulate_missing=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")   # no fold may fail
+        res = grid_search_priors(occu, **data, regressor_occ=LinearRegression, regressor_det=LinearRegression,
+                                 prior_types=["normal", "laplace"],
+                                 prior_params_occ={"normal": {"loc": [0.0], "scale": [1.0]}, "laplace": {"loc": [0.0], "scale": [1.0]}},
+                                 cv_folds=2, num_chains=1, num_warmup=30, num_samples=30, timeout=600)
+    assert len(res.cv_results) == 2 and {r["prior_type"] for r in res.cv_results} == {"normal", "laplace"}
+    assert all(r["n_successful_folds"] == 2 and np.isfinite(r["mean_val_lppd"]) for r in res.cv_results)
+    assert res.best_score == max(r["mean_val_lppd"] for r in res.cv_results)
+    assert res.best_params["prior_type"] in ("normal", "laplace") and res.best_params["occ_params"] == {"loc": 0.0, "scale": 1.0}
+    assert res.best_result.samples["psi"].shape == (30, 1, 100, 1)
+
+
+def test_grid_search_picks_the_informative_scale():
+    """With few sites, priors far too tight (scale 0.02) or the default must lose against each other in a definite order on
+    held-out LPPD; the search reports every combination and refits the winner."""
+    from biolith_amd.models import occu, simulate
+    from biolith_amd.regression import LinearRegression
+    from biolith_amd.utils import grid_search_priors
+
+    data, _ = simulate(n_sites=150, n_site_covs=2, n_obs_covs=2, deployment_days_per_site=70, random_seed=3)
+    res = grid_search_priors(occu, data["site_covs"], data["obs_covs"], data["obs"], LinearRegression, LinearRegression,
+                             prior_types=["normal"], prior_params_occ={"normal": {"loc": [0.0], "scale": [0.02, 1.0]}},
+                             prior_params_det=False, cv_folds=3, num_chains=2, num_warmup=150, num_samples=150)
+    by_scale = {r["occ_params"]["scale"]: r["mean_val_lppd"] for r in res.cv_results}
+    assert set(by_scale) == {0.02, 1.0} and by_scale[1.0] > by_scale[0.02]
+    assert res.best_params["occ_params"]["scale"] == 1.0 and res.best_params["det_params"] == {"loc": 0.0, "scale": 1.0}

@@ -6,7 +6,7 @@ import pandas as pd
 import pytest
 
 import oracle
-from biolith_amd.distributions import Beta, HalfNormal, Normal
+from biolith_amd.distributions import Beta, HalfNormal, Laplace, Normal
 from biolith_amd.evaluation import diagnostics, effective_sample_size, split_gelman_rubin, summary
 from biolith_amd.models import occu
 from biolith_amd.regression import AbstractRegression, LinearRegression
@@ -95,11 +95,14 @@ def test_occu_validates_like_reference():
     assert two.n_species == 2 and two.shape["S"] == 2  # the species plate is sampled species by species
     assert occu(g["site_covs"], g["obs_covs"], obs=g["obs"], prior_beta=Normal(0.5, 2.0)).prior_beta == (0.5, 2.0)
 
-    class Laplace:
+    class Cauchy:
         loc, scale = 0.0, 1.0
 
     with pytest.raises(NotImplementedError, match="Normal"):
-        occu(g["site_covs"], g["obs_covs"], obs=g["obs"], prior_alpha=Laplace())
+        occu(g["site_covs"], g["obs_covs"], obs=g["obs"], prior_alpha=Cauchy())
+    # Laplace coefficient priors (the other family grid_search_priors tries, utils/grid_search.py:366-371)
+    lap = occu(g["site_covs"], g["obs_covs"], obs=g["obs"], prior_beta=Laplace(0.0, 0.5))
+    assert lap.prior_beta == (0.0, 0.5) and lap.prior_beta.family == "laplace" and lap.prior_alpha.family == "normal"
     assert LinearRegression("beta", 2).n_covs == 2
 
 
