@@ -1027,7 +1027,7 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     }
     int ncu = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ds->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
-    k = std::max(1, std::min(std::min(k, 32), std::min(ncu / C, N)));
+    k = std::max(1, std::min(std::min(k, 32), std::min(ncu * 7 / 8 / C, N))); // (an eighth of the CUs spare: nobody may wait for a CU)
     if (C * k > ncu) return bl_fail(BL_ERR_UNSUPPORTED, "num_chains=%d random-effects chains need %d resident workgroups (%d CUs)", C, C * k, ncu);
     const int nloc = (N + k - 1) / k;
     k = (N + nloc - 1) / nloc; // no empty slice
