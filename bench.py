@@ -39,6 +39,16 @@ WORKLOADS = {
                     metric="effective samples/sec (abundance) for occu_rn NUTS, 5k sites x 10 visits",
                     text="biolith simulate_rn(n_sites=5000, n_site_covs=3, n_obs_covs=3, 10 visits, seed 0); "
                          "fit(occu_rn, max_abundance=100)"),
+    # SURVEY section 8 row f3 (no BASELINE config of its own): occu with site random effects, 20 009 coordinates.  (With
+    # observation effects as well the Bernoulli data leave obs_re_sd and the detection coefficients nearly unidentified: NUTS
+    # mixes in neither the reference's parameterisation nor here, R-hat > 2 -- not a throughput workload.)
+    "occu_re": dict(model="occu_re", cfg=dict(n_sites=10000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7,
+                                              site_random_effects=True, random_seed=0),
+                    num_warmup=1000, num_samples=1000, cpu_sample=(20, 20), site="psi",
+                    options=dict(site_random_effects=True),
+                    metric="effective samples/sec (psi) for occu NUTS with site random effects, 10k sites x 10 visits",
+                    text="biolith simulate(n_sites=10000, n_site_covs=3, n_obs_covs=3, 10 visits, site random effects, seed 0); "
+                         "fit(occu, site_random_effects=True)"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -48,11 +58,13 @@ def algorithmic_bytes_per_eval(N, T, J, Ks, Ko, S=1):
     return 4 * (N * Ks + N * T * J * Ko + S * N * T * J)
 
 
-def psi_draws(draws, X, site="psi"):
+def psi_draws(draws, X, site="psi", effects=None):
     """draws (C, S, D) -> psi (C, S, N) float32 = sigmoid(beta0 + X beta)  (occu.py:198-207), or
-    abundance = exp(beta0 + X beta) for occu_rn (occu_rn.py:192)."""
+    abundance = exp(beta0 + X beta) for occu_rn (occu_rn.py:192).  effects: (C, S, N) site_re_occ draws of these sites."""
     Ks = X.shape[1]
     eta = draws[..., :1] + draws[..., 1:Ks + 1] @ X.T
+    if effects is not None:
+        eta = eta + effects
     return (np.exp(eta) if site == "abundance" else 1.0 / (1.0 + np.exp(-eta))).astype(np.float32)
 
 
@@ -63,14 +75,15 @@ class _DevArray:
         self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr="<f4", data=(int(ptr), False), version=2)
 
 
-def ess_of_site_function(draws, X, site="psi", chunk=1000):
+def ess_of_site_function(draws, X, site="psi", chunk=1000, o_u=None):
     """Mean over sites of ESS(psi_i) (or abundance_i), computed over site chunks so that the (chains, draws, sites)
     array of the deterministic site never exists as a whole (8 GPUs x 4 chains x 1000 draws x 10 000 sites)."""
     from biolith_amd.evaluation import effective_sample_size
 
     total, n = 0.0, X.shape[0]
     for s0 in range(0, n, chunk):
-        total += float(effective_sample_size(psi_draws(draws, X[s0:s0 + chunk], site)).sum())
+        eff = None if o_u is None else draws[..., o_u + s0: o_u + min(s0 + chunk, n)]   # random effects: psi_i carries site_re_occ_i
+        total += float(effective_sample_size(psi_draws(draws, X[s0:s0 + chunk], site, eff)).sum())
     return total / n
 
 
@@ -79,13 +92,13 @@ def cpu_baseline(data, threads, wl):
     import oracle
     from biolith_amd.evaluation import effective_sample_size
 
-    od = oracle.OracleData(data["site_covs"], data["obs_covs"], data["obs"], model=wl["model"])
+    od = oracle.OracleData(data["site_covs"], data["obs_covs"], data["obs"], model=wl["model"], **wl.get("options", {}))
     w, s = wl["cpu_sample"]
     t0 = time.perf_counter()
     r = oracle.nuts_run(od, w, s, num_chains=CHAINS_PER_GPU, seed=0, threads=threads)
     wall = time.perf_counter() - t0
     X = np.asarray(data["site_covs"], dtype=np.float32).astype(np.float64)
-    ess = ess_of_site_function(r["draws"], X, wl["site"])
+    ess = ess_of_site_function(r["draws"], X, wl["site"], o_u=od.Ks + od.Ko + 3 if wl["model"] == "occu_re" else None)
     nleap = int(r["n_leapfrog"].sum())
     return dict(value=ess / wall, unit="ESS/s", cores=int(r["threads"]), kind="port",
                 sample=f"oracle NUTS (float64 C restatement), same data, {CHAINS_PER_GPU} chains x ({w} warmup + {s} draws) "
@@ -100,7 +113,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", action="store_true",
-                    help="occu_rn only: also time the oracle (about 9 minutes on 4 cores; off by default)")
+                    help="occu_rn / occu_re: also time the oracle (minutes on 4 cores; off by default)")
     ap.add_argument("--wgs-per-chain", type=int, default=0)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="occu")
     args = ap.parse_args()
@@ -137,7 +150,7 @@ def main():
         data, truth = (simulate_rn if wl["model"] == "occu_rn" else simulate)(**wl["cfg"])
     X = np.asarray(data["site_covs"], dtype=np.float32).astype(np.float64)
     ds = OccuDataset(data["site_covs"], data["obs_covs"], data["obs"], device=local_rank,
-                     model=wl["model"])  # resident in HBM from here on
+                     model=wl["model"], **wl.get("options", {}))  # resident in HBM from here on
     stream = torch.cuda.current_stream().cuda_stream
 
     def sync_all():
@@ -185,12 +198,16 @@ def main():
         # ---- metric numerator: ESS(psi), NumPyro estimator, mean over sites (diagnostics.py:28-32) ----
         ess_psi, ess_coef, rhat = [], [], []
         for _, d in steps:
-            ess_psi.append(ess_of_site_function(d.astype(np.float64), X, wl["site"]))
-            ess_coef.append(effective_sample_size(d).min())
-            rhat.append(float(split_gelman_rubin(d).max()))
+            G0 = ds.Ks + ds.Ko + 2
+            fixed = d[..., :G0] if wl["model"] == "occu_re" else d   # (with random effects: min ESS / R-hat over the fixed effects)
+            ess_psi.append(ess_of_site_function(d.astype(np.float64), X, wl["site"], o_u=G0 + 1 if wl["model"] == "occu_re" else None))
+            ess_coef.append(effective_sample_size(fixed).min())
+            rhat.append(float(split_gelman_rubin(fixed).max()))
         total_ess = float(np.sum(ess_psi))
         N, T, J, Ks, Ko = ds.N, ds.T, ds.J, ds.Ks, ds.Ko
         bytes_eval = algorithmic_bytes_per_eval(N, T, J, Ks, Ko)
+        if wl["model"] == "occu_re":   # + the sampler's own vectors: about 14 of them are read or written per leapfrog
+            bytes_eval += 56 * ds.D
         res0 = steps[0][0]
         achieved = leap_mean * bytes_eval / (kernel_ms_mean * 1e-3) / 1e9
         traffic = None
@@ -222,7 +239,8 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 # <KS, KO, LDS-staged, model id, compute waves>: occu = 0; occu_rn = 5 (112-entry table, max_abundance <= 111)
-                "kernel": f"bl_nuts_kernel<{ds.Ks}, {ds.Ko}, true, {5 if wl['model'] == 'occu_rn' else 0}, {res0.threads_per_wg // 64 - 1}>",
+                "kernel": "bl_re_nuts_kernel(BlReRun const*)" if wl["model"] == "occu_re" else
+                          f"bl_nuts_kernel<{ds.Ks}, {ds.Ko}, true, {5 if wl['model'] == 'occu_rn' else 0}, {res0.threads_per_wg // 64 - 1}>",
                 "kernel_ms": kernel_ms_mean,
                 "algorithmic_bytes_per_launch": leap_mean * bytes_eval, "bytes_per_gradient_evaluation": bytes_eval,
                 "gradient_evaluations_per_launch": leap_mean,
