@@ -135,7 +135,8 @@ __device__ __forceinline__ void bl_re_wave_sums(const float (&v)[NV], float *dst
     }
 }
 template <int NV>
-__device__ __forceinline__ void bl_re_block_sum(float (&v)[NV], float *scr /*[NW][NRED]*/, double *out /*[NRED]*/, int n_used = NV)
+__device__ __forceinline__ void bl_re_block_sum(float (&v)[NV], float *scr /*[NW][NRED]*/, double *out /*[NRED]*/, int n_used = NV,
+                                                bool last_barrier = true)
 {
     const int tid = threadIdx.x, wave = tid >> 6;
     float *dst = scr + wave * BL_RE_NRED;
@@ -151,7 +152,7 @@ __device__ __forceinline__ void bl_re_block_sum(float (&v)[NV], float *scr /*[NW
         for (int w = 0; w < BL_RE_NW; w++) s += (double)scr[w * BL_RE_NRED + tid];
         out[tid] = s;
     }
-    __syncthreads();
+    if (last_barrier) __syncthreads(); // (an exchange that follows only touches out[tid] from the thread that wrote it)
 }
 
 // Exchange between the k workgroups of a chain: each publishes its nv block sums as {epoch, float} granules, reads all
@@ -482,7 +483,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
         BL_RE_T(0)
         const bool first = xc.epoch == 0u;
         const int nv = first ? 17 : 15;
-        bl_re_block_sum<17>(v, scr, red, nv);
+        bl_re_block_sum<17>(v, scr, red, nv, xc.k == 1);
         if (!bl_re_exchange(xc, red, scr2, &xflag, nv)) flag = 4;
         if (first && R.allow_local) xc.local = ((double)R.k * red[16] == red[15] * red[15]); // exact: small integers
         if (red[14] > 0.0) flag = 5;
@@ -511,7 +512,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
             bl_next_leaf(th, r0, gr, epsdir, mi, rh, zn);
             V(RE_CZ)[d] = zn; V(RE_CR)[d] = rh; V(RE_CG)[d] = gr;
         }
-        bl_re_block_sum<1>(kin, scr, red2); // (its barriers also publish the leaf start)
+        bl_re_block_sum<1>(kin, scr, red2, 1, xc.k == 1); // (its barriers, or the exchange's, also publish the leaf start)
         if (!bl_re_exchange(xc, red2, scr2, &xflag, 1)) flag = 4;
         E0 = Ucur + 0.5 * red2[0];
         Up = Ucur; wt = 0.f; sumacc = 0.f; nprop = 0; depth = 0;
@@ -579,7 +580,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
             acc[2] = fmaf(mc * rr, rho_t, acc[2]);
         }
         BL_RE_T(2)
-        bl_re_block_sum<BL_RE_NRED>(acc, scr, red2, 3 + 2 * nck);
+        bl_re_block_sum<BL_RE_NRED>(acc, scr, red2, 3 + 2 * nck, xc.k == 1);
         if (!bl_re_exchange(xc, red2, scr2, &xflag, 3 + 2 * nck)) flag = 4;
         BL_RE_T(3)
         // ---- decisions (_build_basetree tail, _iterative_build_subtree, _combine_tree, _double_tree) ----
