@@ -206,7 +206,7 @@ def main():
         total_ess = float(np.sum(ess_psi))
         N, T, J, Ks, Ko = ds.N, ds.T, ds.J, ds.Ks, ds.Ko
         bytes_eval = algorithmic_bytes_per_eval(N, T, J, Ks, Ko)
-        if wl["model"] == "occu_re":   # + the sampler's own vectors: about 14 of them are read or written per leapfrog (DESIGN.md section 4)
+        if wl["model"] == "occu_re":   # + the sampler's own vectors: about 14 of them are read or written per leapfrog (DESIGN.md section 5)
             bytes_eval += 56 * ds.D
         res0 = steps[0][0]
         achieved = leap_mean * bytes_eval / (kernel_ms_mean * 1e-3) / 1e9
