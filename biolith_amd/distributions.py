@@ -47,6 +47,12 @@ class Beta:
 
 
 @dataclass(frozen=True)
+class Gamma:
+    concentration: float = 1.0
+    rate: float = 1.0
+
+
+@dataclass(frozen=True)
 class Exponential:
     rate: float = 1.0
 
@@ -64,6 +70,21 @@ def as_half_normal(prior, name: str = "prior") -> float:
     if not scale > 0:
         raise ValueError(f"{name}: scale must be positive")
     return scale
+
+
+def as_gamma(prior, name: str = "prior") -> tuple:
+    """(concentration, rate) of a Gamma prior; duck-types numpyro's ``dist.Gamma``."""
+    if type(prior).__name__ != "Gamma" or not hasattr(prior, "concentration") or not hasattr(prior, "rate"):
+        raise NotImplementedError(f"{name}: the HIP engine supports Gamma(concentration, rate) priors here, got {prior!r}")
+    import numpy as np
+
+    a, b = np.asarray(prior.concentration, dtype=float), np.asarray(prior.rate, dtype=float)
+    if a.size != 1 or b.size != 1:
+        raise NotImplementedError(f"{name}: scalar concentration / rate only")
+    a, b = float(a.reshape(())), float(b.reshape(()))
+    if not (a > 0 and b > 0):
+        raise ValueError(f"{name}: concentration and rate must be positive")
+    return a, b
 
 
 def as_exponential(prior, name: str = "prior") -> float:

@@ -156,6 +156,32 @@ def main_nmix():
         json.dump(index, f, indent=1, sort_keys=True)
 
 
+# continuous-score generator (biolith/models/occu_cs.py:222-361)
+CS_CASES = {
+    "cs_default": dict(kw=dict()),
+    "cs_missing": dict(kw=dict(simulate_missing=True)),                                   # occu_cs.py:364-365
+    "cs_small_2x2": dict(kw=dict(n_sites=70, n_site_covs=2, n_obs_covs=2, n_periods=2, deployment_days_per_site=42, random_seed=6)),
+}
+
+
+def main_cs():
+    simulate_cs = sys.modules["biolith.models.occu_cs"].simulate_cs
+    index = {}
+    for name, case in CS_CASES.items():
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            data, truth = simulate_cs(**case["kw"])
+        keys = ("site_covs", "obs_covs", "obs")
+        index[name] = dict(kwargs=case["kw"], stdout=buf.getvalue(), shapes={k: list(np.shape(data[k])) for k in keys},
+                           sha256={k: sha(data[k]) for k in keys}, coords=data["coords"], ell=float(data["ell"]),
+                           truth={k: float(truth[k]) for k in ("mu0", "sigma0", "mu1", "sigma1")}, mean_z=float(np.mean(truth["z"])))
+        np.savez_compressed(os.path.join(HERE, f"simulate_{name}.npz"), site_covs=data["site_covs"], obs_covs=data["obs_covs"],
+                            obs=data["obs"], z=truth["z"], beta=truth["beta"], alpha=truth["alpha"])
+        print(name, index[name]["shapes"], index[name]["sha256"]["obs"][:24])
+    with open(os.path.join(HERE, "simulate_cs_index.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+
+
 def main_rn():
     simulate_rn = load_reference_simulate_rn()
     index = {}
@@ -221,3 +247,4 @@ if __name__ == "__main__":
     main_rn()
     main_cop()
     main_nmix()
+    main_cs()
