@@ -52,6 +52,7 @@ def lib():
             L.orc_data_set_nmix.argtypes = [C.c_void_p, dp, C.c_int]
             L.orc_data_set_re.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_prior_family.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            L.orc_data_set_cs.argtypes = [C.c_void_p, dp, dp, dp]
             L.orc_potential_grad.restype = C.c_double
             L.orc_potential_grad.argtypes = [C.c_void_p, dp, dp]
             L.orc_rng_streams.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
@@ -89,7 +90,7 @@ class OracleData:
     def __init__(self, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0), model="occu",
                  max_abundance=100, fp_mode="constant", prior_fp=(2.0, 5.0), session_duration=None, prior_fp_rate=1.0,
                  site_random_effects=False, obs_random_effects=False, prior_site_re_sd=1.0, prior_obs_re_sd=1.0,
-                 prior_family=("normal", "normal")):
+                 prior_family=("normal", "normal"), prior_mu=((0.0, 10.0), (0.0, 10.0)), prior_sigma=((5.0, 1.0), (5.0, 1.0))):
         X = _as_f32_f64(site_covs)
         W = _as_f32_f64(obs_covs)
         Y = _as_f32_f64(obs)
@@ -109,7 +110,7 @@ class OracleData:
         self.X, self.W, self.Y = X, W, Y
         self.prior_beta, self.prior_alpha = tuple(prior_beta), tuple(prior_alpha)
         self.model, self.max_abundance = model, int(max_abundance)
-        assert model in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture", "occu_re")
+        assert model in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture", "occu_re", "occu_cs")
         lib().orc_data_set_model(self._h, 1 if model == "occu_rn" else 0, int(max_abundance))
         if model == "occu_fp":  # theta gains phi = logit(false-positive rate) as its last coordinate
             assert fp_mode in ("constant", "unoccupied")
@@ -126,6 +127,13 @@ class OracleData:
                                    float(prior_fp_rate))
             self.D += 1 if fp_mode else 0
         self.fp_mode, self.prior_fp, self.prior_fp_rate = fp_mode, tuple(prior_fp), float(prior_fp_rate)
+        if model == "occu_cs":
+            # theta = [beta, alpha, mu0, log(mu1 - mu0), log sigma0, log sigma1]; obs holds the scores
+            pm = np.ascontiguousarray(np.asarray(prior_mu, dtype=np.float64).reshape(4))
+            ps = np.ascontiguousarray(np.asarray(prior_sigma, dtype=np.float64).reshape(4))
+            lib().orc_data_set_cs(self._h, _dp(Y), _dp(pm), _dp(ps))
+            self.D += 4
+            self.prior_mu, self.prior_sigma = pm.reshape(2, 2), ps.reshape(2, 2)
         if model == "occu_re":
             # theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_occ[N], site_re_det[N]), (obs_re[N][T][J])]
             assert site_random_effects or obs_random_effects
@@ -335,6 +343,48 @@ def literal_log_joint_re(theta, site_covs, obs_covs, obs, site_random_effects=Tr
         ly = np.where(finite, ly, 0.0).sum(axis=2)
         per_z.append(_bernoulli_logpmf_clamped(psi, z)[:, None] + ly)
     ll = np.logaddexp(per_z[0], per_z[1]).sum()
+    return ll + lp + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
+
+
+def literal_log_joint_cs(theta, site_covs, obs_covs, scores, prior_mu=((0.0, 10.0), (0.0, 10.0)), prior_sigma=((5.0, 1.0), (5.0, 1.0)),
+                         prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):
+    """log density of the continuous-score model (biolith/models/occu_cs.py:120-232) in NumPyro's unconstrained space, z
+    and f summed by brute force over an explicit (z, f) axis.  theta = [beta, alpha, mu0, x1, log sigma0, log sigma1]."""
+    from scipy.special import erfc, gammaln, logsumexp
+
+    X, W, S = (_as_f32_f64(a) for a in (site_covs, obs_covs, scores))
+    if S.ndim == 4:
+        S = S[0]
+    Ks, Ko = X.shape[1], W.shape[-1]
+    theta = np.asarray(theta, dtype=np.float64)
+    beta, alpha = theta[: Ks + 1], theta[Ks + 1: Ks + Ko + 2]
+    mu0, x1, ls0, ls1 = theta[Ks + Ko + 2:]
+    mu1, sg = mu0 + np.exp(x1), np.exp([ls0, ls1])
+    mask = np.isnan(W).any(-1) | np.isnan(X).any(-1)[:, None, None]            # occu_cs.py:120-126
+    S = np.where(mask, np.nan, S)
+    W, X = np.nan_to_num(W), np.nan_to_num(X)
+    psi = 1.0 / (1.0 + np.exp(-(beta[0] + X @ beta[1:])))
+    p = 1.0 / (1.0 + np.exp(-(alpha[0] + np.tensordot(W, alpha[1:], axes=([3], [0])))))
+    finite = np.isfinite(S)
+    s0 = np.where(finite, S, 0.0)
+    mus = np.array([mu0, mu1])
+    lphi = -0.5 * ((s0[..., None] - mus) / sg) ** 2 - np.log(sg) - 0.5 * np.log(2 * np.pi)       # (N, T, J, f)
+    per_z = []
+    for z in (0.0, 1.0):
+        pf = np.stack([_bernoulli_logpmf_clamped(z * p, 0.0), _bernoulli_logpmf_clamped(z * p, 1.0)], axis=-1)   # log P(f | z)
+        lj = np.where(finite, logsumexp(pf + lphi, axis=-1), 0.0).sum(axis=2)                    # (N, T)
+        lz = -np.logaddexp(0.0, -(beta[0] + X @ beta[1:])) if z == 1.0 else -np.logaddexp(0.0, beta[0] + X @ beta[1:])
+        per_z.append(lz[:, None] + lj)
+    ll = np.logaddexp(per_z[0], per_z[1]).sum()
+
+    def normal_logpdf(v, loc, scale):
+        return (-0.5 * ((v - loc) / scale) ** 2 - np.log(scale) - 0.5 * np.log(2 * np.pi)).sum()
+
+    (l0, c0), (l1, c1) = prior_mu
+    lp = normal_logpdf(mu0, l0, c0)
+    lp += normal_logpdf(mu1, l1, c1) - np.log(0.5 * erfc((mu0 - l1) / c1 / np.sqrt(2.0))) + x1       # truncated below at mu0
+    for (a, b), ls in zip(prior_sigma, (ls0, ls1)):
+        lp += a * np.log(b) - gammaln(a) + (a - 1.0) * ls - b * np.exp(ls) + ls                      # Gamma + log-Jacobian
     return ll + lp + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
 
 
