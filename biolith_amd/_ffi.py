@@ -64,7 +64,7 @@ EXPORTS = (
     "bl_abi_version", "bl_last_error", "bl_device_count", "bl_dataset_create", "bl_dataset_create_rn", "bl_dataset_destroy",
     "bl_dataset_param_dim", "bl_logp_grad", "bl_nuts_run", "bl_nuts_launch", "bl_nuts_poll",
     "bl_nuts_abort", "bl_nuts_wait", "bl_nuts_fetch", "bl_nuts_elapsed_ms", "bl_nuts_device_draws",
-    "bl_nuts_geometry", "bl_nuts_debug_counters", "bl_deterministic", "bl_predict", "bl_predict_counts", "bl_dataset_create_fp", "bl_dataset_create_cop", "bl_dataset_create_nmix", "bl_dataset_create_re", "bl_dataset_set_prior_family", "bl_rng_streams", "bl_adaptation_schedule",
+    "bl_nuts_geometry", "bl_nuts_debug_counters", "bl_deterministic", "bl_predict", "bl_predict_counts", "bl_dataset_create_fp", "bl_dataset_create_cop", "bl_dataset_create_nmix", "bl_dataset_create_re", "bl_dataset_create_cs", "bl_dataset_set_prior_family", "bl_rng_streams", "bl_adaptation_schedule",
 )
 
 _lib = None
@@ -101,6 +101,8 @@ def load():
                                              C.POINTER(bl_normal_prior), C.c_int, C.POINTER(vp)]
         L.bl_dataset_create_re.argtypes = [C.POINTER(bl_dims), fp, fp, fp, C.c_int, C.c_int, C.c_double, C.c_double,
                                            C.POINTER(bl_normal_prior), C.POINTER(bl_normal_prior), C.c_int, C.POINTER(vp)]
+        L.bl_dataset_create_cs.argtypes = [C.POINTER(bl_dims), fp, fp, fp, dp, dp, C.POINTER(bl_normal_prior),
+                                           C.POINTER(bl_normal_prior), C.c_int, C.POINTER(vp)]
         L.bl_dataset_set_prior_family.argtypes = [vp, C.c_int, C.c_int]
         L.bl_dataset_destroy.argtypes = [vp]
         L.bl_dataset_param_dim.argtypes = [vp, ip]

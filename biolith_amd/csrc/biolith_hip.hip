@@ -212,6 +212,7 @@ struct bl_dataset {
     long long *d_nleap = nullptr, *d_dbg = nullptr;
     int *d_loc = nullptr;
     uint32_t *d_rng = nullptr;
+    float *d_scores = nullptr; // occu_cs: scores, site-fastest [T J][n_stride]
     unsigned long long *d_xchg = nullptr;
     size_t xchg_bytes = 0;
     int *h_abort = nullptr, *d_abort = nullptr;
@@ -786,6 +787,7 @@ extern "C" int bl_dataset_destroy(bl_dataset *ds)
     if (ds->d_run) hipFree(ds->d_run);
     if (ds->d_xchg) hipFree(ds->d_xchg);
     if (ds->d_restate) hipFree(ds->d_restate);
+    if (ds->d_scores) hipFree(ds->d_scores);
     if (ds->h_abort) hipHostFree(ds->h_abort);
     if (ds->ev0) hipEventDestroy(ds->ev0);
     if (ds->ev1) hipEventDestroy(ds->ev1);
@@ -937,6 +939,58 @@ extern "C" int bl_dataset_create_re(const bl_dims *dims, const float *site_covs,
     m.n_total = N; m.s0 = 0; m.x_u = m.o_u; m.x_v = m.o_v; m.x_e = m.o_e;
     m.n_rows = ds->n_rows;
     re_geometry(m, N, 0, 0); // one workgroup over all sites (bl_logp_grad); bl_nuts_launch picks its own slices
+    ds->model = 6; ds->D = m.D;
+    return BL_OK;
+}
+
+// occu_cs (biolith/models/occu_cs.py): the continuous-score model runs on the random-effects kernels' framework (a chain over
+// several workgroups, vectors in device memory) with four extra fixed coordinates and no effects.
+extern "C" int bl_dataset_create_cs(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *scores,
+                                    const double *prior_mu /*[4]: loc, scale of mu0; of mu1's base*/,
+                                    const double *prior_sigma /*[4]: concentration, rate of sigma0; of sigma1*/,
+                                    const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha, int device, bl_dataset **out)
+{
+    if (!dims || !scores || !prior_mu || !prior_sigma || !out) return bl_fail(BL_ERR_INVALID, "NULL argument");
+    if (dims->n_site_covs > BL_RE_MAXK || dims->n_obs_covs > BL_RE_MAXK)
+        return bl_fail(BL_ERR_UNSUPPORTED, "occu_cs kernels are built for at most %d covariates per side (Ks=%d, Ko=%d)", BL_RE_MAXK,
+                       dims->n_site_covs, dims->n_obs_covs);
+    if (!(prior_mu[1] > 0.0) || !(prior_mu[3] > 0.0) || !(prior_sigma[0] > 0.0) || !(prior_sigma[1] > 0.0) || !(prior_sigma[2] > 0.0) || !(prior_sigma[3] > 0.0))
+        return bl_fail(BL_ERR_INVALID, "occu_cs priors need positive scales / concentrations / rates");
+    const size_t n = (size_t)dims->n_species * dims->n_sites * dims->n_periods * dims->n_replicates;
+    // the plain model's rows with "has a score" as the observation: c = 1 for a scored replicate, 0 for a masked one
+    std::vector<float> has(n);
+    for (size_t i = 0; i < n; i++) has[i] = std::isfinite(scores[i]) ? 1.0f : NAN;
+    int rc = dataset_create_impl(ModelOpts{}, dims, site_covs, obs_covs, has.data(), prior_beta, prior_alpha, device, out);
+    if (rc) return rc;
+    bl_dataset *ds = *out;
+    const int N = dims->n_sites, V = dims->n_periods * dims->n_replicates, Ks = ds->Ks, Ko = ds->Ko;
+    std::vector<float> sc((size_t)V * ds->n_stride, 0.0f);
+    for (int i = 0; i < N; i++)
+        for (int v = 0; v < V; v++) {
+            const float x = scores[(size_t)i * V + v];
+            sc[(size_t)v * ds->n_stride + i] = std::isfinite(x) ? x : 0.0f;
+        }
+    if (hipMalloc((void **)&ds->d_scores, sc.size() * 4) != hipSuccess ||
+        hipMemcpy(ds->d_scores, sc.data(), sc.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        bl_dataset_destroy(ds); *out = nullptr;
+        return bl_fail(BL_ERR_NO_DEVICE, "occu_cs: score upload failed");
+    }
+    BlReModel &m = ds->re;
+    m.rows = ds->dd.rows; m.n_sites = N; m.n_stride = ds->dd.n_stride; m.T = dims->n_periods; m.J = dims->n_replicates;
+    m.Ks = Ks; m.Ko = Ko; m.KS = ds->KS; m.KO = ds->KO;
+    m.site_re = 0; m.obs_re = 0; m.kind = 1; m.scores = ds->d_scores;
+    m.G0 = Ks + Ko + 2; m.G = m.G0 + 4; m.D = m.G;
+    m.o_phi_s = m.o_phi_o = m.o_u = m.o_v = m.o_e = -1;
+    m.loc_b = ds->dd.loc_b; m.isc2_b = ds->dd.isc2_b; m.loc_a = ds->dd.loc_a; m.isc2_a = ds->dd.isc2_a; m.l1_b = 0.0f; m.l1_a = 0.0f;
+    m.hn_is2_s = m.hn_is2_o = 0.0f;
+    for (int k = 0; k < 4; k++) { m.cs_mu[k] = (float)prior_mu[k]; m.cs_sg[k] = (float)prior_sigma[k]; }
+    // constants of the potential: the coefficients' (dd.prior_const), the two Normal normalisers of mu0 / mu1, the Gammas'
+    const double HL2PI = 0.91893853320467274178;
+    m.u_const = ds->dd.prior_const + std::log(prior_mu[1]) + std::log(prior_mu[3]) + 2.0 * HL2PI;
+    for (int f = 0; f < 2; f++) m.u_const += -prior_sigma[2 * f] * std::log(prior_sigma[2 * f + 1]) + std::lgamma(prior_sigma[2 * f]);
+    m.n_total = N; m.s0 = 0; m.x_u = m.x_v = m.x_e = -1;
+    m.n_rows = ds->n_rows;
+    re_geometry(m, N, 0, 0);
     ds->model = 6; ds->D = m.D;
     return BL_OK;
 }

@@ -27,6 +27,9 @@ struct BlReModel {
     const float *rows;
     int n_sites, n_stride, T, J, Ks, Ko, KS, KO;
     int site_re, obs_re;
+    int kind;                             // 0: occu with random effects; 1: occu_cs (continuous scores, no effects: D = G = G0 + 4)
+    const float *scores;                  // kind 1: the replicates' scores, site-fastest [T J][n_stride] (0 where masked)
+    float cs_mu[4], cs_sg[4];             // kind 1: Normal(loc, scale) of mu0 and of mu1's base; Gamma(concentration, rate) of sigma0, sigma1
     int G0, G, D;                         // fixed effects, + log sds, all coordinates
     int o_phi_s, o_phi_o, o_u, o_v, o_e;  // offsets (internal order = external order except inside the obs_re block)
     float loc_b, isc2_b, loc_a, isc2_a;   // Normal priors of beta / alpha (isc2 = 0 for a Laplace prior)
@@ -112,6 +115,7 @@ __device__ __forceinline__ BlReModel bl_re_slice(const BlReModel &g, int s0, int
 {
     BlReModel m = g;
     m.rows = g.rows + s0; m.n_sites = cnt; m.s0 = s0;
+    if (g.kind == 1) m.scores = g.scores + s0;
     int at = g.G;
     if (g.site_re) { m.o_u = at; m.o_v = at + cnt; at += 2 * cnt; }
     if (g.obs_re) { m.o_e = at; at += cnt * g.T * g.J; }
@@ -325,6 +329,135 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
     }
 }
 
+// ---- occu_cs (biolith/models/occu_cs.py:120-232): s ~ Normal(mu_f, sigma_f), f ~ Bernoulli(z p), z ~ Bernoulli(psi); z and every
+// f summed out (the f of different replicates are independent given z).  Coordinates: [beta, alpha, mu0, x1 = log(mu1 - mu0),
+// log sigma0, log sigma1].  Site pass: part[0] = ll, [1..5] d/d beta, [6..10] d/d alpha, [11..14] d/d (mu0, mu1, log sigma0, log sigma1).
+__device__ __forceinline__ void bl_cs_site_pass(const BlReModel &m, const float *__restrict__ rows, int ns, const float *__restrict__ z,
+                                                float (&part)[15])
+{
+    const int tid = threadIdx.x, tps = m.tps, S = 64 / tps, lane = tid & 63;
+    const int grp = (tid >> 6) * S + (lane & (S - 1)), sub = lane / S, ngrp = BL_RE_NT / tps;
+    const int N = m.n_sites, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 1;
+    float beta[BL_RE_MAXK + 1], alpha[BL_RE_MAXK + 1];
+#pragma unroll
+    for (int k = 0; k <= BL_RE_MAXK; k++) {
+        beta[k] = k <= Ks ? z[k] : 0.0f;
+        alpha[k] = k <= Ko ? z[Ks + 1 + k] : 0.0f;
+    }
+    const float mu0 = z[m.G0], mu1 = mu0 + bl_exp(z[m.G0 + 1]), ls0 = z[m.G0 + 2], ls1 = z[m.G0 + 3];
+    const float is0 = bl_exp(-ls0), is1 = bl_exp(-ls1);
+    const float TINY = 1.1754944e-38f, PMAX = 1.0f - 1.1920929e-07f, HL2PI = 0.9189385f;
+    const float l_f1_z0 = -87.33654475f, l_f0_z0 = -1.1754944e-38f; // log(tiny), log1p(-tiny): numpyro clamps P(f = 1 | z = 0) = 0 to tiny
+#pragma unroll
+    for (int k = 0; k < 15; k++) part[k] = 0.0f;
+    const int rounds = (N + ngrp - 1) / ngrp;
+    for (int rd = 0; rd < rounds; rd++) {
+        const int i_raw = rd * ngrp + grp;
+        const bool live = i_raw < N;
+        const int i = live ? i_raw : N - 1;
+        float x[BL_RE_MAXK];
+        float eta = beta[0];
+#pragma unroll
+        for (int k = 0; k < BL_RE_MAXK; k++) {
+            x[k] = k < Ks ? rows[(size_t)k * ns + i] : 0.0f;
+            eta = fmaf(x[k], beta[k + 1], eta);
+        }
+        const float ee = bl_exp(-fabsf(eta)), lop = bl_log(1.0f + ee);
+        const float log_psi = fminf(eta, 0.0f) - lop, log_1mpsi = fminf(-eta, 0.0f) - lop;
+        const float psi = (eta > 0.0f ? 1.0f : ee) * bl_rcp(1.0f + ee);
+        float dl_deta = 0.0f;
+        for (int t = 0; t < T; t++) {
+            // r[0] = a1, r[1] = a0, r[2..6] = d a1 / d alpha, r[7..10] = d a1 / d (mu0, mu1, ls0, ls1), r[11..14] = the same of a0
+            float r[15];
+#pragma unroll
+            for (int k = 0; k < 15; k++) r[k] = 0.0f;
+            for (int j = sub; j < J; j += tps) {
+                const int v = t * J + j;
+                const size_t r0 = (size_t)(m.KS + v * vw) * ns + i;
+                float w[BL_RE_MAXK + 1];
+#pragma unroll
+                for (int k = 0; k <= BL_RE_MAXK; k++) w[k] = k <= Ko ? rows[r0 + (size_t)k * ns] : 0.0f;
+                const float c = w[0]; // 1: the replicate has a score, 0: masked
+                const float sc = m.scores[(size_t)v * m.n_stride + i];
+                float nu = c * alpha[0];
+#pragma unroll
+                for (int k = 1; k <= BL_RE_MAXK; k++) nu = fmaf(w[k], alpha[k], nu);
+                const float e0 = (sc - mu0) * is0, e1 = (sc - mu1) * is1;
+                const float lphi0 = fmaf(-0.5f * e0, e0, -ls0 - HL2PI), lphi1 = fmaf(-0.5f * e1, e1, -ls1 - HL2PI);
+                const float en = bl_exp(-fabsf(nu)), ron = bl_rcp(1.0f + en);
+                const float p = (nu > 0.0f ? 1.0f : en) * ron;
+                const bool inside = p > TINY && p < PMAX;
+                const float pc = fminf(fmaxf(p, TINY), PMAX);
+                // z = 1
+                const float t1 = bl_log(pc) + lphi1, t0 = bl_log(1.0f - pc) + lphi0;
+                const float L1 = bl_logaddexp(t0, t1), w1 = bl_exp(t1 - L1), w0 = bl_exp(t0 - L1);
+                const float dnu = inside ? fmaf(w1, 1.0f - p, -w0 * p) : 0.0f;
+                // z = 0
+                const float u1 = l_f1_z0 + lphi1, u0 = l_f0_z0 + lphi0;
+                const float L0 = bl_logaddexp(u0, u1), v1 = bl_exp(u1 - L0), v0 = bl_exp(u0 - L0);
+                r[0] = fmaf(c, L1, r[0]); r[1] = fmaf(c, L0, r[1]);
+#pragma unroll
+                for (int k = 0; k <= BL_RE_MAXK; k++) r[2 + k] = fmaf(dnu, w[k], r[2 + k]); // (w carries the mask)
+                r[7] = fmaf(c * w0, e0 * is0, r[7]); r[8] = fmaf(c * w1, e1 * is1, r[8]);
+                r[9] = fmaf(c * w0, fmaf(e0, e0, -1.0f), r[9]); r[10] = fmaf(c * w1, fmaf(e1, e1, -1.0f), r[10]);
+                r[11] = fmaf(c * v0, e0 * is0, r[11]); r[12] = fmaf(c * v1, e1 * is1, r[12]);
+                r[13] = fmaf(c * v0, fmaf(e0, e0, -1.0f), r[13]); r[14] = fmaf(c * v1, fmaf(e1, e1, -1.0f), r[14]);
+            }
+            for (int msk = S; msk < 64; msk <<= 1) {
+#pragma unroll
+                for (int k = 0; k < 15; k++) r[k] += __shfl_xor(r[k], msk);
+            }
+            const float A = log_psi + r[0], B = log_1mpsi + r[1];
+            const float l = bl_logaddexp(A, B);
+            const float q = bl_exp(A - l), q0 = 1.0f - q;
+            if (live && sub == 0) {
+                part[0] += l;
+#pragma unroll
+                for (int k = 0; k <= BL_RE_MAXK; k++) part[6 + k] = fmaf(q, r[2 + k], part[6 + k]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) part[11 + k] += fmaf(q, r[7 + k], q0 * r[11 + k]);
+            }
+            dl_deta += q - psi;
+        }
+        if (live && sub == 0) {
+            part[1] += dl_deta;
+#pragma unroll
+            for (int k = 0; k < BL_RE_MAXK; k++) part[2 + k] = fmaf(dl_deta, x[k], part[2 + k]);
+        }
+    }
+}
+
+// occu_cs: potential gradient of coordinate G0 + e (e = 0 mu0, 1 x1, 2 log sigma0, 3 log sigma1) from the reduced sums
+// (red[11], red[12], red[17], red[18] = d ll / d (mu0, mu1, log sigma0, log sigma1)) and the priors: mu0 ~ Normal(l0, s0);
+// mu1 ~ Normal(l1, s1) truncated below at mu0, in x1 = log(mu1 - mu0); sigma_f ~ Gamma(a, b) in log sigma_f.
+__device__ __forceinline__ float bl_cs_extra_grad(const BlReModel &m, int e, const float *z, const double *red)
+{
+    const float mu0 = z[m.G0], ex1 = bl_exp(z[m.G0 + 1]), mu1 = mu0 + ex1;
+    if (e >= 2) {
+        const float a = m.cs_sg[2 * (e - 2)], b = m.cs_sg[2 * (e - 2) + 1];
+        return -((float)red[15 + e] + a - b * bl_exp(z[m.G0 + e]));
+    }
+    const float l0 = m.cs_mu[0], s0 = m.cs_mu[1], l1 = m.cs_mu[2], s1 = m.cs_mu[3];
+    const float z1 = (mu1 - l1) / s1, dmu1 = (float)red[12] - z1 / s1;
+    if (e == 1) return -(dmu1 * ex1 + 1.0f);
+    const float z0 = (mu0 - l0) / s0, zl = (mu0 - l1) / s1;
+    const float hazard = bl_exp(-0.5f * zl * zl - 0.9189385f) / (0.5f * erfcf(zl * 0.70710678f)) / s1; // d/d mu0 of -log(1 - Phi(zl))
+    return -((float)red[11] - z0 / s0 + dmu1 + hazard);
+}
+// occu_cs: the four extra coordinates' share of the potential (their priors, Jacobians, the truncation's normaliser)
+__device__ __forceinline__ double bl_cs_extra_potential(const BlReModel &m, const float *z)
+{
+    const double mu0 = z[m.G0], x1 = z[m.G0 + 1], mu1 = mu0 + exp(x1);
+    const double l0 = m.cs_mu[0], s0 = m.cs_mu[1], l1 = m.cs_mu[2], s1 = m.cs_mu[3];
+    const double z0 = (mu0 - l0) / s0, z1 = (mu1 - l1) / s1, zl = (mu0 - l1) / s1;
+    double U = 0.5 * z0 * z0 + 0.5 * z1 * z1 + log(0.5 * erfc(zl * 0.70710678118654752)) - x1;
+    for (int f = 0; f < 2; f++) {
+        const double a = m.cs_sg[2 * f], b = m.cs_sg[2 * f + 1], ls = z[m.G0 + 2 + f];
+        U += -(a - 1.0) * ls + b * exp(ls) - ls;
+    }
+    return U; // (constants: m.u_const)
+}
+
 // Potential gradient of a fixed effect / log sd coordinate d < G at position z, from the reduced sums of the site pass
 // (red[0..10]) and of the effects' squares (red[11] = sum u^2 + v^2, red[12] = sum e^2).
 __device__ __forceinline__ float bl_re_global_grad(const BlReModel &m, int d, float zd, const double *red)
@@ -336,6 +469,7 @@ __device__ __forceinline__ float bl_re_global_grad(const BlReModel &m, int d, fl
         const float dth = zd - loc;
         return (float)(-gl) + fmaf(dth, isc2, dth > 0.0f ? l1 : (dth < 0.0f ? -l1 : 0.0f));
     }
+    if (m.kind == 1) return 0.0f; // (occu_cs: its four extra coordinates are handled by bl_cs_extra_grad)
     const bool site = m.site_re && d == m.o_phi_s;
     const float isd2 = bl_exp(-2.0f * zd), sd2 = bl_exp(2.0f * zd);
     const float cnt = site ? 2.0f * (float)m.n_total : (float)m.n_total * (float)(m.T * m.J);
@@ -397,16 +531,27 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel m,
     int ns;
     const float *rows = bl_re_rows(m, bl_re_lds, ns);
     __syncthreads();
-    float v[14], part[11], ss[2];
-    bl_re_site_pass(m, rows, ns, z, g, part);
-    bl_re_effect_squares(m, z, ss);
+    float v[19];
+    if (m.kind == 1) {
+        float part[15];
+        bl_cs_site_pass(m, rows, ns, z, part);
 #pragma unroll
-    for (int k = 0; k < 11; k++) v[k] = part[k];
-    v[11] = ss[0]; v[12] = ss[1];
+        for (int k = 0; k < 11; k++) v[k] = part[k];
+        v[11] = part[11]; v[12] = part[12]; v[17] = part[13]; v[18] = part[14];
+    } else {
+        float part[11], ss[2];
+        bl_re_site_pass(m, rows, ns, z, g, part);
+        bl_re_effect_squares(m, z, ss);
+#pragma unroll
+        for (int k = 0; k < 11; k++) v[k] = part[k];
+        v[11] = ss[0]; v[12] = ss[1]; v[17] = 0.0f; v[18] = 0.0f;
+    }
     v[13] = bl_re_prior_quad(m, z);
-    bl_re_block_sum<14>(v, scr, red);
-    for (int d = tid; d < m.G; d += BL_RE_NT) g[d] = bl_re_global_grad(m, d, z[d], red);
-    if (tid == 0) U[b] = bl_re_potential(m, z, red, red[13]);
+    v[14] = 0.0f; v[15] = 0.0f; v[16] = 0.0f;
+    bl_re_block_sum<19>(v, scr, red);
+    for (int d = tid; d < m.G; d += BL_RE_NT)
+        g[d] = (m.kind == 1 && d >= m.G0) ? bl_cs_extra_grad(m, d - m.G0, z, red) : bl_re_global_grad(m, d, z[d], red);
+    if (tid == 0) U[b] = bl_re_potential(m, z, red, red[13]) + (m.kind == 1 ? bl_cs_extra_potential(m, z) : 0.0);
     for (int d = tid; d < D; d += BL_RE_NT) grad[(size_t)b * D + bl_re_ext(m, d)] = (double)g[d];
 }
 
@@ -466,15 +611,24 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = (long long)clock64(), st_leaves = 0;
 #endif
     auto evaluate = [&]() -> double {
-        float v[17], part[11], ss[2];
+        float v[19];
         const float *z = V(RE_CZ);
         float *g = V(RE_CG);
         BL_RE_T(7)
-        bl_re_site_pass(m, rows, rows_ns, z, g, part);
-        bl_re_effect_squares(m, z, ss);
+        if (m.kind == 1) { // occu_cs: no effects; four more gradient sums
+            float part[15];
+            bl_cs_site_pass(m, rows, rows_ns, z, part);
 #pragma unroll
-        for (int k = 0; k < 11; k++) v[k] = part[k];
-        v[11] = ss[0]; v[12] = ss[1];
+            for (int k = 0; k < 11; k++) v[k] = part[k];
+            v[11] = part[11]; v[12] = part[12]; v[17] = part[13]; v[18] = part[14];
+        } else {
+            float part[11], ss[2];
+            bl_re_site_pass(m, rows, rows_ns, z, g, part);
+            bl_re_effect_squares(m, z, ss);
+#pragma unroll
+            for (int k = 0; k < 11; k++) v[k] = part[k];
+            v[11] = ss[0]; v[12] = ss[1]; v[17] = 0.0f; v[18] = 0.0f;
+        }
         v[13] = lead ? bl_re_prior_quad(m, z) : 0.0f;
         // the host's abort request rides in the sums, so that every workgroup of the chain sees it at the same leapfrog
         v[14] = (lead && tid == 0 && R.abort_flag && *(volatile const int *)R.abort_flag) ? 1.0f : 0.0f;
@@ -482,13 +636,15 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
         v[15] = tid == 0 ? xcc : 0.0f; v[16] = tid == 0 ? xcc * xcc : 0.0f;
         BL_RE_T(0)
         const bool first = xc.epoch == 0u;
-        const int nv = first ? 17 : 15;
-        bl_re_block_sum<17>(v, scr, red, nv, xc.k == 1);
+        const int nv = m.kind == 1 ? 19 : (first ? 17 : 15);
+        bl_re_block_sum<19>(v, scr, red, nv, xc.k == 1);
         if (!bl_re_exchange(xc, red, scr2, &xflag, nv)) flag = 4;
         if (first && R.allow_local) xc.local = ((double)R.k * red[16] == red[15] * red[15]); // exact: small integers
         if (red[14] > 0.0) flag = 5;
-        for (int d = tid; d < G; d += BL_RE_NT) g[d] = bl_re_global_grad(m, d, z[d], red);
-        const double U = bl_re_potential(m, z, red, red[13]);
+        for (int d = tid; d < G; d += BL_RE_NT)
+            g[d] = (m.kind == 1 && d >= m.G0) ? bl_cs_extra_grad(m, d - m.G0, z, red) : bl_re_global_grad(m, d, z[d], red);
+        double U = bl_re_potential(m, z, red, red[13]);
+        if (m.kind == 1) U += bl_cs_extra_potential(m, z);
         BL_RE_T(1)
         return U;
     };

@@ -52,9 +52,10 @@ class OccuDataset:
     def __init__(self, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0), device: int = 0,
                  model: str = "occu", max_abundance: int = 100, fp_mode: Optional[str] = "constant", prior_fp=(2.0, 5.0),
                  session_duration=None, prior_fp_rate: float = 1.0, site_random_effects: bool = False,
-                 obs_random_effects: bool = False, prior_site_re_sd: float = 1.0, prior_obs_re_sd: float = 1.0):
+                 obs_random_effects: bool = False, prior_site_re_sd: float = 1.0, prior_obs_re_sd: float = 1.0,
+                 prior_mu=((0.0, 10.0), (0.0, 10.0)), prior_sigma=((5.0, 1.0), (5.0, 1.0))):
         lib = _ffi.load()
-        if model not in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture", "occu_re"):
+        if model not in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture", "occu_re", "occu_cs"):
             raise ValueError(f"unknown model {model!r}")
         if fp_mode not in ("constant", "unoccupied") and not (model == "occu_cop" and fp_mode is None):
             raise ValueError(f"unknown fp_mode {fp_mode!r}")
@@ -101,6 +102,13 @@ class OccuDataset:
             mode = {None: 0, "constant": _ffi.FP_CONSTANT, "unoccupied": _ffi.FP_UNOCCUPIED}[fp_mode]
             _ffi.check(lib.bl_dataset_create_cop(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), _fp(Dur), mode,
                                                  float(prior_fp_rate), C.byref(pb), C.byref(pa), device, C.byref(h)))
+        elif model == "occu_cs":
+            # obs holds the scores; theta = [beta, alpha, mu0, log(mu1 - mu0), log sigma0, log sigma1]
+            pm = np.ascontiguousarray(np.asarray(prior_mu, dtype=np.float64).reshape(4))
+            ps = np.ascontiguousarray(np.asarray(prior_sigma, dtype=np.float64).reshape(4))
+            _ffi.check(lib.bl_dataset_create_cs(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), _dp(pm), _dp(ps),
+                                                C.byref(pb), C.byref(pa), device, C.byref(h)))
+            self.D = Ks + Ko + 6
         elif model == "occu_re":
             # theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_occ[N], site_re_det[N]), (obs_re[N][T][J])]
             if not (site_random_effects or obs_random_effects):

@@ -152,6 +152,8 @@ def engine_options(spec) -> dict:
                     prior_fp_rate=spec.extras.get("prior_fp_rate", 1.0))
     if spec.model == "occu_re":
         opts.update({k: spec.extras[k] for k in ("site_random_effects", "obs_random_effects", "prior_site_re_sd", "prior_obs_re_sd")})
+    if spec.model == "occu_cs":
+        opts.update(prior_mu=spec.extras["prior_mu"], prior_sigma=spec.extras["prior_sigma"])
     return opts
 
 
@@ -186,6 +188,12 @@ def _assemble(per_species, spec, num_warmup) -> HipMCMC:
     if spec.model == "occu_cop" and spec.extras["fp_mode"] is not None:
         # phi = log(rate); the model's site is the rate (occu_cop.py:158-170)
         latent[f"rate_fp_{spec.extras['fp_mode']}"] = np.exp(res0.draws[:, :, Ks + Ko + 2].astype(np.float64)).astype(np.float32)
+    if spec.model == "occu_cs":
+        # theta = [beta, alpha, mu0, log(mu1 - mu0), log sigma0, log sigma1]; the model's sites are mu0, mu1, sigma0, sigma1 (occu_cs.py:143-152)
+        e = res0.draws[:, :, Ks + Ko + 2:].astype(np.float64)
+        latent["mu0"] = e[..., 0].astype(np.float32)
+        latent["mu1"] = (e[..., 0] + np.exp(e[..., 1])).astype(np.float32)
+        latent["sigma0"], latent["sigma1"] = np.exp(e[..., 2]).astype(np.float32), np.exp(e[..., 3]).astype(np.float32)
     if spec.model == "occu_re":
         # theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_occ[N], site_re_det[N]), (obs_re[N][T][J])]; the
         # model's sites are the sds themselves, the effects with the species plate last (occu.py:170-173, 191-196, 215-218)

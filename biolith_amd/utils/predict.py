@@ -57,6 +57,8 @@ def predict(
     """
     if not callable(model_fn) or getattr(model_fn, "__biolith_amd_model__", None) is None:
         raise TypeError("predict(): model_fn must be a biolith_amd model (biolith_amd.models.occu / occu_rn)")
+    if getattr(model_fn, "__biolith_amd_model__", None) == "occu_cs":
+        raise NotImplementedError("predict() is not built for occu_cs (its observed site is a continuous score)")
     if infer_discrete:
         raise NotImplementedError("infer_discrete=True (predict.py:70) is not built on the HIP engine")
     device = int(kwargs.pop("device", 0))

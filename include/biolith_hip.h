@@ -136,6 +136,17 @@ int bl_dataset_create_re(const bl_dims *dims, const float *site_covs, const floa
                          double prior_obs_re_sd_scale, const bl_normal_prior *prior_beta,
                          const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
 /*
+ * The continuous-score occupancy model biolith.models.occu_cs (models/occu_cs.py:17-232; Rhinehart et al. 2022): `scores`
+ * [S=1][N][T][J] (NaN = missing) ~ Normal(mu_f, sigma_f) with f ~ Bernoulli(z p) and z ~ Bernoulli(psi) summed out.
+ * prior_mu = {loc, scale of mu0; loc, scale of the Normal that mu1 follows truncated below at mu0}; prior_sigma =
+ * {concentration, rate of sigma0's Gamma; of sigma1's}.  theta = [beta, alpha, mu0, log(mu1 - mu0), log sigma0, log sigma1]
+ * (NumPyro's unconstrained space), D = Ks + Ko + 6.  Runs on the random-effects kernels' framework (bl_dataset_create_re);
+ * bl_deterministic gives psi and prob_detection; bl_predict is not built for it.
+ */
+int bl_dataset_create_cs(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *scores,
+                         const double *prior_mu, const double *prior_sigma, const bl_normal_prior *prior_beta,
+                         const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
+/*
  * The other prior family biolith.utils.grid_search_priors tries for the regression coefficients
  * (utils/grid_search.py:366-371): Laplace(loc, scale) instead of Normal(loc, scale), per side, with the (loc, scale) the
  * dataset was created with.  Call between bl_dataset_create* and the first use; applies to every model.

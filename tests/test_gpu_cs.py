@@ -1,0 +1,81 @@
+"""Continuous-score occupancy model (biolith/models/occu_cs.py) through the C-ABI against the CPU oracle, and the
+reference's own fit(occu_cs) assertions (occu_cs.py:364-407)."""
+import numpy as np
+import pytest
+
+import oracle
+from biolith_amd.engine import OccuDataset
+from biolith_amd.evaluation import split_gelman_rubin
+from biolith_amd.models import occu_cs, simulate_cs
+from biolith_amd.utils import fit
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+PRI = dict(prior_mu=((0.5, 8.0), (1.0, 12.0)), prior_sigma=((5.0, 1.0), (3.0, 0.5)))
+
+
+def _theta(rng, D, n):
+    th = rng.uniform(-1, 1, size=(n, D))
+    th[:, -4:] = np.array([0.3, 1.8, 1.9, 1.2]) + rng.uniform(-0.3, 0.3, size=(n, 4))
+    return th.astype(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("name,pri", [("cs_small_2x2", PRI), ("cs_missing", {}), ("cs_default", PRI)])
+def test_cs_logp_grad_parity(name, pri):
+    g = load_golden(name)
+    od = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], model="occu_cs", **pri)
+    ds = OccuDataset(g["site_covs"], g["obs_covs"], g["obs"], model="occu_cs", **pri)
+    assert ds.D == od.D
+    th = _theta(np.random.default_rng(4), od.D, 3)
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.all(np.isfinite(Ug)) and np.all(np.isfinite(Gg))
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= 2e-6, (Ug, Uo)
+    assert np.max(np.abs(Gg - Go)) <= 5e-5 * np.max(np.abs(Go)), (Gg - Go, Go)
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_cs_first_transitions_match_oracle(k):
+    g = load_golden("cs_small_2x2")
+    od = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], model="occu_cs", **PRI)
+    ds = OccuDataset(g["site_covs"], g["obs_covs"], g["obs"], model="occu_cs", **PRI)
+    init = _theta(np.random.default_rng(2), od.D, 2)   # (uniform(-2, 2) starts put sigma at e^-2: start both sides in the bulk)
+    o = oracle.nuts_run(od, 0, 4, num_chains=2, seed=3, init=init)
+    r = ds.nuts(num_warmup=0, num_samples=4, num_chains=2, seed=3, init_theta=init, wgs_per_chain=k)
+    assert np.array_equal(o["num_steps"][:, :3], r.num_steps[:, :3]), (o["num_steps"], r.num_steps)
+    assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=5e-3)
+
+
+def test_cs_posterior_matches_oracle():
+    g = load_golden("cs_small_2x2")
+    od = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], model="occu_cs")
+    ds = OccuDataset(g["site_covs"], g["obs_covs"], g["obs"], model="occu_cs")
+    o = oracle.nuts_run(od, 400, 500, num_chains=4, seed=0)
+    r = ds.nuts(num_warmup=400, num_samples=500, num_chains=4, seed=50)
+    fg, fo = r.draws.reshape(-1, od.D).astype(np.float64), o["draws"].reshape(-1, od.D)
+    mcse = np.sqrt(fg.var(0) / oracle.effective_sample_size(r.draws.astype(np.float64)) + fo.var(0) / oracle.effective_sample_size(o["draws"]))
+    assert np.all(np.abs(fg.mean(0) - fo.mean(0)) <= 4 * mcse), (fg.mean(0) - fo.mean(0), mcse)
+    ratio = fg.std(0) / fo.std(0)
+    assert np.all((ratio > 0.85) & (ratio < 1.18)), ratio
+    assert split_gelman_rubin(r.draws).max() < 1.03
+
+
+def test_occu_cs_like_reference():  # occu_cs.py:364-395
+    data, true_params = simulate_cs(simulate_missing=True)
+    results = fit(occu_cs, **data, timeout=600)
+    assert np.allclose(results.samples["psi"].mean(), true_params["z"].mean(), atol=0.1)
+    assert np.allclose([results.samples[k].mean() for k in [f"cov_state_{i}" for i in range(true_params["beta"].shape[1])]],
+                       true_params["beta"].mean(axis=0), atol=0.5)
+    assert np.allclose([results.samples[k].mean() for k in [f"cov_det_{i}" for i in range(true_params["alpha"].shape[1])]],
+                       true_params["alpha"].mean(axis=0), atol=0.5)
+    for k in ("mu0", "mu1", "sigma0", "sigma1"):
+        assert results.samples[k].shape == (5000,)
+        assert np.allclose(results.samples[k].mean(), true_params[k], atol=1), k
+    assert np.all(results.samples["mu1"] > results.samples["mu0"])
+
+
+def test_occu_cs_multi_season():  # occu_cs.py:398-413
+    data, true_params = simulate_cs(simulate_missing=True, n_periods=3)
+    results = fit(occu_cs, **data, num_chains=1, num_samples=300, num_warmup=300, timeout=600)
+    assert np.allclose(results.samples["psi"].mean(), true_params["z"].mean(), atol=0.15)
