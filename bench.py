@@ -238,7 +238,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                # <KS, KO, LDS-staged, model id, compute waves>: occu = 0; occu_rn = 5 (112-entry table, max_abundance <= 111)
+                # <KS, KO, LDS-staged, model id, compute waves>: occu = 0; occu_rn = 5 (104-entry table, max_abundance <= 103)
                 "kernel": "bl_re_nuts_kernel(BlReRun const*)" if wl["model"] == "occu_re" else
                           f"bl_nuts_kernel<{ds.Ks}, {ds.Ko}, true, {5 if wl['model'] == 'occu_rn' else 0}, {res0.threads_per_wg // 64 - 1}>",
                 "kernel_ms": kernel_ms_mean,
