@@ -326,6 +326,8 @@ extern "C" int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint6
     if (!ds || !draws || n_draws <= 0 || (!latent && !y)) return bl_fail(BL_ERR_INVALID, "bl_predict: bad argument");
     if (ds->model == 3 || ds->model == 4)
         return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: the count models (occu_cop, nmixture) use bl_predict_counts");
+    if (ds->model == 6 && ds->re.kind == 1)
+        return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: not built for occu_cs (its observed site is a continuous score)");
     if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
     int rc = set_device(ds);
     if (rc) return rc;
