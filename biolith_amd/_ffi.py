@@ -64,7 +64,7 @@ EXPORTS = (
     "bl_abi_version", "bl_last_error", "bl_device_count", "bl_dataset_create", "bl_dataset_create_rn", "bl_dataset_destroy",
     "bl_dataset_param_dim", "bl_logp_grad", "bl_nuts_run", "bl_nuts_launch", "bl_nuts_poll",
     "bl_nuts_abort", "bl_nuts_wait", "bl_nuts_fetch", "bl_nuts_elapsed_ms", "bl_nuts_device_draws",
-    "bl_nuts_geometry", "bl_nuts_debug_counters", "bl_deterministic", "bl_predict", "bl_predict_counts", "bl_dataset_create_fp", "bl_dataset_create_cop", "bl_dataset_create_nmix", "bl_dataset_create_re", "bl_dataset_create_cs", "bl_dataset_set_prior_family", "bl_rng_streams", "bl_adaptation_schedule",
+    "bl_nuts_geometry", "bl_nuts_debug_counters", "bl_deterministic", "bl_predict", "bl_predict_counts", "bl_predict_scores", "bl_dataset_create_fp", "bl_dataset_create_cop", "bl_dataset_create_nmix", "bl_dataset_create_re", "bl_dataset_create_cs", "bl_dataset_set_prior_family", "bl_rng_streams", "bl_adaptation_schedule",
 )
 
 _lib = None
@@ -120,6 +120,7 @@ def load():
         L.bl_deterministic.argtypes = [vp, C.c_int, fp, fp, fp]
         L.bl_predict.argtypes = [vp, C.c_int, fp, C.c_uint64, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
         L.bl_predict_counts.argtypes = [vp, C.c_int, fp, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.bl_predict_scores.argtypes = [vp, C.c_int, fp, C.c_uint64, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), fp]
         L.bl_rng_streams.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
         L.bl_adaptation_schedule.argtypes = [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]
         for name in EXPORTS:

@@ -361,6 +361,80 @@ extern "C" int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint6
     return BL_OK;
 }
 
+// ---- predictive scores of the continuous-score model (occu_cs.py:196-232 with obs=None) ----
+// z ~ Bernoulli(psi);  f_j ~ Bernoulli(z p_j);  s_j ~ Normal(mu_f, sigma_f)   (draw = [beta, alpha, mu0, log(mu1 - mu0), log sigma0, log sigma1])
+__global__ void bl_predict_scores_kernel(const float *__restrict__ rows, const float *__restrict__ wraw, int n_stride, int N, int T, int J,
+                                         int Ks, int Ko, int D, const float *__restrict__ draws, int n0, int n1, unsigned long long seed,
+                                         unsigned char *__restrict__ latent, unsigned char *__restrict__ f_out, float *__restrict__ s_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float x[BL_MAX_COVS];
+    for (int k = 0; k < Ks; k++) x[k] = rows[(size_t)k * n_stride + i];
+    for (int n = n0 + blockIdx.y; n < n1; n += gridDim.y) {
+        const float *th = draws + (size_t)n * D, *al = th + Ks + 1, *ex = th + Ks + Ko + 2;
+        const float mu0 = ex[0], mu1 = ex[0] + __expf(ex[1]), sg0 = __expf(ex[2]), sg1 = __expf(ex[3]);
+        float eta = th[0];
+        for (int k = 0; k < Ks; k++) eta = fmaf(x[k], th[k + 1], eta);
+        const float psi = 1.0f / (1.0f + __expf(-eta));
+        for (int t = 0; t < T; t++) {
+            BlPredRng rng(seed, ((unsigned long long)n * T + t) * N + i);
+            const int zn = rng.uniform() < psi ? 1 : 0;
+            if (latent) latent[((size_t)(n - n0) * T + t) * N + i] = (unsigned char)zn;
+            for (int j = 0; j < J; j++) {
+                const int v = t * J + j;
+                float nu = al[0];
+                for (int k = 0; k < Ko; k++) nu = fmaf(wraw[((size_t)v * Ko + k) * n_stride + i], al[k + 1], nu);
+                const int fn = rng.uniform() < (float)zn / (1.0f + __expf(-nu)) ? 1 : 0;
+                // Box-Muller, one normal per replicate
+                const float u1 = fmaxf(rng.uniform(), 5.9604645e-08f), u2 = rng.uniform();
+                const float g = sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853f * u2);
+                const size_t o = (((size_t)(n - n0) * J + j) * T + t) * N + i;
+                if (f_out) f_out[o] = (unsigned char)fn;
+                if (s_out) s_out[o] = fn ? fmaf(sg1, g, mu1) : fmaf(sg0, g, mu0);
+            }
+        }
+    }
+}
+
+extern "C" int bl_predict_scores(bl_dataset *ds, int n_draws, const float *draws, uint64_t seed, uint8_t *latent, uint8_t *f, float *s)
+{
+    if (!ds || !draws || n_draws <= 0 || (!latent && !f && !s)) return bl_fail(BL_ERR_INVALID, "bl_predict_scores: bad argument");
+    if (!(ds->model == 6 && ds->re.kind == 1)) return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict_scores: an occu_cs dataset is required");
+    if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
+    int rc = set_device(ds);
+    if (rc) return rc;
+    const int N = ds->dims.n_sites, T = ds->dims.n_periods, J = ds->dims.n_replicates, D = ds->D;
+    float *d_draws = nullptr, *d_s = nullptr;
+    unsigned char *d_lat = nullptr, *d_f = nullptr;
+    DevScratch scratch;
+    BL_HIP(scratch.alloc((void **)&d_draws, (size_t)n_draws * D * 4));
+    BL_HIP(hipMemcpy(d_draws, draws, (size_t)n_draws * D * 4, hipMemcpyHostToDevice));
+    const size_t per_draw = (size_t)T * N * J * 4;
+    int chunk = (int)((256u << 20) / (per_draw ? per_draw : 1));
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_draws) chunk = n_draws;
+    if (latent) BL_HIP(scratch.alloc((void **)&d_lat, (size_t)chunk * T * N));
+    if (f) BL_HIP(scratch.alloc((void **)&d_f, (size_t)chunk * J * T * N));
+    if (s) BL_HIP(scratch.alloc((void **)&d_s, (size_t)chunk * J * T * N * 4));
+    if (!ds->d_wraw) {
+        BL_HIP(hipMalloc((void **)&ds->d_wraw, ds->h_wraw.size() * 4));
+        BL_HIP(hipMemcpy(ds->d_wraw, ds->h_wraw.data(), ds->h_wraw.size() * 4, hipMemcpyHostToDevice));
+    }
+    const dim3 block(256);
+    for (int n0 = 0; n0 < n_draws; n0 += chunk) {
+        const int n1 = (n0 + chunk < n_draws) ? n0 + chunk : n_draws;
+        const dim3 grid((N + 255) / 256, (n1 - n0) < 1024 ? (n1 - n0) : 1024);
+        hipLaunchKernelGGL(bl_predict_scores_kernel, grid, block, 0, nullptr, ds->d_rows, ds->d_wraw, ds->n_stride, N, T, J, ds->Ks, ds->Ko, D,
+                           d_draws, n0, n1, (unsigned long long)seed, d_lat, d_f, d_s);
+        BL_HIP(hipGetLastError());
+        if (latent) BL_HIP(hipMemcpy(latent + (size_t)n0 * T * N, d_lat, (size_t)(n1 - n0) * T * N, hipMemcpyDeviceToHost));
+        if (f) BL_HIP(hipMemcpy(f + (size_t)n0 * J * T * N, d_f, (size_t)(n1 - n0) * J * T * N, hipMemcpyDeviceToHost));
+        if (s) BL_HIP(hipMemcpy(s + (size_t)n0 * J * T * N, d_s, (size_t)(n1 - n0) * J * T * N * 4, hipMemcpyDeviceToHost));
+    }
+    return BL_OK;
+}
+
 // ---- predictive counts of the count models (occu_cop, nmixture) ----
 // Poisson(lam): inversion by sequential search for lam < 10, else Hoermann's PTRS transformed rejection
 // ("The transformed rejection method for generating Poisson random variables", 1993); both exact.

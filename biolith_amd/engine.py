@@ -287,6 +287,23 @@ class OccuDataset:
         return out_l, out_y
 
 
+def _predictive_scores(self, draws, seed: int = 0):
+    """occu_cs: posterior predictive ``z`` (n, T, N), ``f`` (n, J, T, N) as uint8 and the scores ``s`` (n, J, T, N) float32
+    (biolith/models/occu_cs.py:196-232 with obs withheld)."""
+    d = np.ascontiguousarray(draws, dtype=np.float32).reshape(-1, self.D)
+    n = d.shape[0]
+    z = np.empty((n, self.T, self.N), dtype=np.uint8)
+    f = np.empty((n, self.J, self.T, self.N), dtype=np.uint8)
+    s = np.empty((n, self.J, self.T, self.N), dtype=np.float32)
+    if n:
+        u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+        _ffi.check(self._lib.bl_predict_scores(self._h, n, _fp(d), C.c_uint64(int(seed) & (2 ** 64 - 1)), u8(z), u8(f), _fp(s)))
+    return z, f, s
+
+
+OccuDataset.predictive_scores = _predictive_scores
+
+
 def rng_streams(seed: int, chain: int, nstreams: int = _ffi.RNG_STREAMS_PER_CHAIN) -> np.ndarray:
     out = np.zeros((nstreams, 4), dtype=np.uint32)
     _ffi.check(_ffi.load().bl_rng_streams(int(seed), int(chain), int(nstreams),

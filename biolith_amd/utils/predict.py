@@ -57,8 +57,6 @@ def predict(
     """
     if not callable(model_fn) or getattr(model_fn, "__biolith_amd_model__", None) is None:
         raise TypeError("predict(): model_fn must be a biolith_amd model (biolith_amd.models.occu / occu_rn)")
-    if getattr(model_fn, "__biolith_amd_model__", None) == "occu_cs":
-        raise NotImplementedError("predict() is not built for occu_cs (its observed site is a continuous score)")
     if infer_discrete:
         raise NotImplementedError("infer_discrete=True (predict.py:70) is not built on the HIP engine")
     device = int(kwargs.pop("device", 0))
@@ -107,6 +105,33 @@ def predict(
         if spec.extras["obs_random_effects"]:   # (n, J, T, N, 1) -> [N][T][J]
             cols.append(np.asarray(posterior["obs_re"])[..., 0].transpose(0, 3, 2, 1).reshape(n, -1))
         re_block = np.concatenate(cols, axis=1).astype(np.float32)
+
+    if spec.model == "occu_cs":   # sites psi, z, f, s (occu_cs.py:196-232); mu / sigma travel in the engine's coordinates
+        from ..engine import OccuDataset
+        from .fit import engine_options
+
+        post = {k: np.asarray(posterior[k], dtype=np.float64).reshape(n) for k in ("mu0", "mu1", "sigma0", "sigma1")}
+        extra = np.stack([post["mu0"], np.log(np.maximum(post["mu1"] - post["mu0"], 1e-300)), np.log(post["sigma0"]),
+                          np.log(post["sigma1"])], axis=1).astype(np.float32)
+        ds = OccuDataset(spec.site_covs, spec.obs_covs, spec.obs, spec.prior_beta, spec.prior_alpha, device=device, model="occu_cs",
+                         **engine_options(spec))
+        draws = np.concatenate([beta[:, 0, :], alpha[:, 0, :], extra], axis=1)
+
+        def run_cs():
+            psi = ds.deterministic(draws, psi=True, prob_detection=False)[0]
+            return (psi,) + ds.predictive_scores(draws, seed=int(random_seed) & (2 ** 64 - 1))
+
+        if timeout is not None:
+            from .misc import time_limit
+
+            with time_limit(timeout):
+                psi, z, f, s = run_cs()
+        else:
+            psi, z, f, s = run_cs()
+        out = LazySamples()
+        out["psi"], out["z"] = psi[..., None], z[..., None].astype(np.int32)
+        out["f"], out["s"] = f[..., None].astype(np.int32), s[..., None]
+        return rename_samples(out, site_names, obs_names)
 
     def run():
         handles, first, latent, y8 = [], [], [], []

@@ -141,7 +141,7 @@ int bl_dataset_create_re(const bl_dims *dims, const float *site_covs, const floa
  * prior_mu = {loc, scale of mu0; loc, scale of the Normal that mu1 follows truncated below at mu0}; prior_sigma =
  * {concentration, rate of sigma0's Gamma; of sigma1's}.  theta = [beta, alpha, mu0, log(mu1 - mu0), log sigma0, log sigma1]
  * (NumPyro's unconstrained space), D = Ks + Ko + 6.  Runs on the random-effects kernels' framework (bl_dataset_create_re);
- * bl_deterministic gives psi and prob_detection; bl_predict is not built for it.
+ * bl_deterministic gives psi and prob_detection; predictive draws: bl_predict_scores.
  */
 int bl_dataset_create_cs(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *scores,
                          const double *prior_mu, const double *prior_sigma, const bl_normal_prior *prior_beta,
@@ -248,6 +248,9 @@ int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint64_t seed, u
  * int32 on the host, shapes as in bl_predict.  Poisson draws by inversion (rate < 10) or Hoermann's PTRS.
  */
 int bl_predict_counts(bl_dataset *ds, int n_draws, const float *draws, uint64_t seed, int32_t *latent, int32_t *y);
+/* Same for occu_cs (occu_cs.py:196-232 with obs withheld): z[n][T][N], f[n][J][T][N] (which score distribution a replicate
+ * drew from) as bytes, s[n][J][T][N] the scores; any of the three may be NULL. */
+int bl_predict_scores(bl_dataset *ds, int n_draws, const float *draws, uint64_t seed, uint8_t *latent, uint8_t *f, float *s);
 
 /* The engine's xoshiro128++ streams (host-side; no GPU needed): out[nstreams][4]. */
 int bl_rng_streams(uint64_t seed, int chain, int nstreams, uint32_t *out);
