@@ -62,6 +62,15 @@ def log_likelihood(model_fn: Callable, posterior_samples: Dict[str, np.ndarray],
     ps = {k: v for k, v in posterior_samples.items() if k not in observation_keys}
     obs = np.asarray(kwargs["obs"], dtype=np.float32)
     valid = _valid_obs(kwargs["site_covs"], kwargs["obs_covs"], obs).transpose((3, 2, 1, 0))  # (J, T, N, S)
+    if getattr(model_fn, "__biolith_amd_model__", None) == "occu_cs":
+        # the observed site is the score: Normal((1 - f) mu0 + f mu1, (1 - f) sigma0 + f sigma1).log_prob(obs)  (occu_cs.py:224-232)
+        f = np.asarray(ps["f"], dtype=np.float32)
+        shape = (-1,) + (1,) * 4
+        mu = np.where(f > 0, np.asarray(ps["mu1"], np.float32).reshape(shape), np.asarray(ps["mu0"], np.float32).reshape(shape))
+        sg = np.where(f > 0, np.asarray(ps["sigma1"], np.float32).reshape(shape), np.asarray(ps["sigma0"], np.float32).reshape(shape))
+        sc = np.where(valid, obs.transpose((3, 2, 1, 0)), np.float32(0.0))[None]
+        ll = -0.5 * ((sc - mu) / sg) ** 2 - np.log(sg) - np.float32(0.5 * np.log(2 * np.pi))
+        return {"s": np.where(valid[None], ll, np.float32(0.0)).astype(np.float32)}
     y = np.where(valid, obs.transpose((3, 2, 1, 0)), np.float32(0.0)).astype(np.float32)
     prob = np.clip(_detection_probability(model_fn, ps), _TINY, _ONE_MINUS_EPS)
     with np.errstate(divide="ignore"):
@@ -95,7 +104,7 @@ def _pointwise(ll_valid):
 
 def _model_ll(model_fn, posterior_samples, kwargs):
     valid = _valid_obs(kwargs["site_covs"], kwargs["obs_covs"], kwargs["obs"])
-    ll = log_likelihood(model_fn, posterior_samples, **kwargs)["y"].transpose((0, 4, 3, 2, 1))
+    ll = next(iter(log_likelihood(model_fn, posterior_samples, **kwargs).values())).transpose((0, 4, 3, 2, 1))
     return ll[:, valid].astype(np.float64)
 
 

@@ -131,6 +131,8 @@ def predict(
         out = LazySamples()
         out["psi"], out["z"] = psi[..., None], z[..., None].astype(np.int32)
         out["f"], out["s"] = f[..., None].astype(np.int32), s[..., None]
+        for k, v in post.items():   # (Predictive leaves the posterior's own sites out; log_likelihood needs them next to f)
+            out[k] = v.astype(np.float32)
         return rename_samples(out, site_names, obs_names)
 
     def run():

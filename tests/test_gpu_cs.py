@@ -103,3 +103,25 @@ def test_occu_cs_predict_draws_scores_from_the_two_distributions():
     again = predict(occu_cs, results.mcmc, **data, num_samples=800)
     other = predict(occu_cs, results.mcmc, **data, num_samples=800, random_seed=1)
     assert np.array_equal(again["s"], preds["s"]) and not np.array_equal(other["s"], preds["s"])
+
+
+def test_occu_cs_lppd_and_waic_from_the_predictive_sites():
+    from biolith_amd.evaluation import log_likelihood, lppd, waic
+    from biolith_amd.utils import predict
+
+    data, _ = simulate_cs(simulate_missing=True)
+    results = fit(occu_cs, **data, num_chains=2, num_samples=300, num_warmup=300)
+    preds = predict(occu_cs, results.mcmc, **data, num_samples=600)
+    ll = log_likelihood(occu_cs, preds, **data)["s"]
+    assert ll.shape == (600, 52, 1, 100, 1) and np.all(np.isfinite(ll))
+    obs = np.asarray(data["obs"])
+    valid = np.isfinite(obs) & np.isfinite(data["obs_covs"]).all(-1)[None] & np.isfinite(data["site_covs"]).all(-1)[None, :, None, None]
+    assert np.all(ll.transpose(0, 4, 3, 2, 1)[:, ~valid] == 0)
+    # one entry by hand: Normal(mu_f, sigma_f).log_prob(score)
+    q, j, i = 17, 3, np.argwhere(valid[0, :, 0, 3])[0, 0]
+    f = preds["f"][q, j, 0, i, 0]
+    mu, sg = (preds["mu1"][q], preds["sigma1"][q]) if f else (preds["mu0"][q], preds["sigma0"][q])
+    want = -0.5 * ((obs[0, i, 0, j] - mu) / sg) ** 2 - np.log(sg) - 0.5 * np.log(2 * np.pi)
+    assert ll[q, j, 0, i, 0] == pytest.approx(want, rel=1e-5)
+    l, w = lppd(occu_cs, preds, **data), waic(occu_cs, preds, **data)
+    assert np.isfinite(l) and w["lppd"] == pytest.approx(l) and w["p_waic"] > 0
