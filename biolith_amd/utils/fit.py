@@ -212,14 +212,27 @@ def _assemble(per_species, spec, num_warmup) -> HipMCMC:
         if spec.extras["obs_random_effects"]:
             e = res0.draws[:, :, at: at + N * T * J].reshape(C, S, N, T, J)
             latent["obs_re"] = np.ascontiguousarray(e.transpose(0, 1, 4, 3, 2))[..., None]     # (C, S, J, T, N, 1)
-    if S:
+    def memo(fn):   # a site is computed once, on its first access
+        box = []
+
+        def get():
+            if not box:
+                box.append(fn())
+            return box[0]
+        return get
+
+    @memo
+    def psi():
+        # (as the reference's samples stay on the device until they are looked at, so does this site: 160 MB over PCIe at the
+        # headline size would otherwise be a sixth of fit()'s wall time)
+        if not S:
+            return np.empty((C, 0, ds0.T, ds0.N, nsp), np.float32)
         parts = [d.deterministic(r.draws.reshape(C * S, D), psi=True, prob_detection=False)[0] for d, r in per_species]
         # one species (the common case): a view, not a 160 MB copy at the headline size
-        psi = parts[0][..., None] if nsp == 1 else np.stack(parts, axis=-1)
-    else:
-        psi = np.empty((0, ds0.T, ds0.N, nsp), np.float32)
-    psi = psi.reshape(C, S, ds0.T, ds0.N, nsp)
+        out = parts[0][..., None] if nsp == 1 else np.stack(parts, axis=-1)
+        return out.reshape(C, S, ds0.T, ds0.N, nsp)
 
+    @memo
     def prob_detection():
         parts = [d.deterministic(r.draws.reshape(C * S, D), psi=False, prob_detection=True)[1] for d, r in per_species]
         pd = parts[0][..., None] if nsp == 1 else np.stack(parts, axis=-1)
