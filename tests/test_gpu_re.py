@@ -207,3 +207,30 @@ def test_re_timeout_stops_every_workgroup_of_the_chain():
     assert time.time() - t0 < 30
     res = fit(occu, **data, obs_random_effects=True, num_chains=2, num_samples=20, num_warmup=20)
     assert np.all(np.isfinite(res.samples["obs_re_sd"]))
+
+
+@pytest.mark.parametrize("n_sites,site,obs", [(10000, True, False), (2000, True, True)])
+def test_re_large_sizes_against_the_oracle(n_sites, site, obs):
+    """The bench-sized datasets (20 009 / 24 010 coordinates; 32 workgroups per chain, rows too large for one workgroup's
+    LDS at 10 000 sites): potential and gradient over every coordinate, and the first trees, against the oracle."""
+    import contextlib
+    import io
+
+    from biolith_amd.models import simulate
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        d, _ = simulate(n_sites=n_sites, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7,
+                        site_random_effects=site, obs_random_effects=obs, random_seed=0)
+    kw = dict(model="occu_re", site_random_effects=site, obs_random_effects=obs)
+    od, ds = oracle.OracleData(d["site_covs"], d["obs_covs"], d["obs"], **kw), OccuDataset(d["site_covs"], d["obs_covs"], d["obs"], **kw)
+    assert ds.D == od.D == 8 + site + obs + (2 * n_sites if site else 0) + (n_sites * 10 if obs else 0)
+    th = np.random.default_rng(0).uniform(-1.0, 1.0, size=(2, od.D)).astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= 2e-6, (Ug, Uo)
+    assert np.max(np.abs(Gg - Go)) <= 2e-5 * np.max(np.abs(Go))
+    o = oracle.nuts_run(od, 0, 2, num_chains=2, seed=1)
+    r = ds.nuts(num_warmup=0, num_samples=2, num_chains=2, seed=1)
+    assert r.wgs_per_chain >= 16
+    assert np.array_equal(o["num_steps"], r.num_steps), (o["num_steps"], r.num_steps)
+    assert np.allclose(o["draws"], r.draws, atol=5e-3)
