@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 --pmc passes of tools/pmc_run.sh: per-launch means of every counter for
 the NUTS kernel, and the HBM byte figure bench.py reports as roofline.traffic.
-   python tools/pmc_summary.py gpurun_out/pmc profiles/r01/d_pmc_summary.json
+   python tools/pmc_summary.py gpurun_out/pmc profiles/r01/d_pmc_summary.json [kernel name substring, default bl_nuts_kernel]
 HBM bytes per launch = 2 x FETCH_SIZE KB (gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md,
 an upper bound for this kernel's narrow staging loads) + WRITE_SIZE KB."""
 import csv
@@ -14,13 +14,14 @@ from collections import defaultdict
 
 def main():
     src, dst = sys.argv[1], sys.argv[2]
+    which = sys.argv[3] if len(sys.argv) > 3 else "bl_nuts_kernel"
     sums, counts = defaultdict(float), defaultdict(int)
     kernel = None
     for path in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
         per_dispatch = defaultdict(float)
         with open(path) as f:
             for row in csv.DictReader(f):
-                if "bl_nuts_kernel" not in row["Kernel_Name"]:
+                if which not in row["Kernel_Name"]:
                     continue
                 kernel = row["Kernel_Name"]
                 per_dispatch[(row["Dispatch_Id"], row["Counter_Name"])] += float(row["Counter_Value"])
