@@ -10,18 +10,22 @@ on (its configs[1]): simulate(n_sites=10000, 3 site + 3 obs covariates, 5 visits
 GPU x (1000 warmup + 1000 draws) of NUTS, i.e. exactly what ``fit(occu, **data, num_chains=4)``
 runs behind the C-ABI.  The dataset is resident in HBM before the timed region.  With N > 1 GPUs
 every rank runs its own 4 chains (weak scaling; chains are the unit the path shards over, no
-data-path collective) and the draws are all-gathered over RCCL inside the timed region.
-ESS is computed afterwards with the NumPyro estimator (mean over sites of per-site ESS of psi).
+data-path collective) and the result blocks are all-gathered over RCCL (``bl_gather_draws``, on librccl
+behind the C-ABI) inside the timed region.  ESS is computed afterwards with the NumPyro estimator
+(mean over sites of per-site ESS of psi).
+
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment: this process is only a LAUNCHER.  It starts N
+fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one per GPU) before importing torch or
+touching HIP, relays rank 0's JSON line and exits non-zero if any rank fails (e.g. fewer than N GPUs).
 """
 import argparse
 import contextlib
 import io
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -32,7 +36,8 @@ CHAINS_PER_GPU = 4
 # --workload: "occu" is the headline (BASELINE.json configs[1], what the driver runs); "occu_rn" is the
 # secondary line for configs[3] (same JSON shape, metric on `abundance`), run by hand for profiles/.
 WORKLOADS = {
-    "occu": dict(model="occu", cfg=CFG2, num_warmup=1000, num_samples=1000, cpu_sample=(250, 250), site="psi",
+    # cpu_sample: the oracle leg runs the SAME 4 chains x (1000 + 1000) as the GPU (about 45 s on 4 cores of this class)
+    "occu": dict(model="occu", cfg=CFG2, num_warmup=1000, num_samples=1000, cpu_sample=(1000, 1000), site="psi",
                  metric="effective samples/sec (psi) for occu NUTS, 10k sites x 5 visits",
                  text="biolith simulate(n_sites=10000, n_site_covs=3, n_obs_covs=3, 5 visits, seed 0); fit(occu)"),
     "occu_rn": dict(model="occu_rn", cfg=CFG4, num_warmup=500, num_samples=500, cpu_sample=(40, 40), site="abundance",
@@ -51,8 +56,77 @@ WORKLOADS = {
                          "fit(occu, site_random_effects=True)"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# Transcendental (v_exp / v_log / v_rcp ...) issue rate: quarter rate, 16 lanes per SIMD per cycle, 4 SIMDs per CU, 2.4 GHz
+# (MI355X_MICROARCH.md) = 153.6 G per second per CU; 256 CUs.
+TRANS_PER_CU_PER_S = 16 * 4 * 2.4e9
+N_CUS = 256
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", action="store_true",
+                    help="occu_rn / occu_re: also time the oracle (minutes on 4 cores; off by default)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end fit() timing (fit_e2e_ms / value_e2e)")
+    ap.add_argument("--wgs-per-chain", type=int, default=0)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="occu")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------ launcher ----
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a torchrun environment: start N rank processes (fresh interpreters; nothing in THIS process has
+    imported torch or touched HIP), one per GPU, and relay rank 0's line.  Mirrors chain_method="parallel" (fit.py:109-113)."""
+    import socket
+
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_LAUNCHED_BY="bench.py", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out0 = None
+    failed = None
+    deadline = time.monotonic() + float(os.environ.get("BENCH_LAUNCH_TIMEOUT", "3000"))
+    pending = set(range(n))
+    while pending and failed is None:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if r == 0:
+                out0 = procs[0].stdout.read()
+            if rc != 0:
+                failed = (r, rc)
+                break
+        if time.monotonic() > deadline:
+            failed = (-1, 124)
+        if pending and failed is None:
+            time.sleep(0.05)
+    if failed is not None:
+        for p in procs:   # the exact processes started above, nothing else
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+        sys.stderr.write(f"bench.py: rank {failed[0]} of {n} failed (exit code {failed[1]}); no result line\n")
+        raise SystemExit(failed[1] if 0 < failed[1] < 256 else 1)
+    line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    if not line:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        raise SystemExit(1)
+    print(line[-1])
+
+
+# --------------------------------------------------------------------------------------------- helpers ----
 def algorithmic_bytes_per_eval(N, T, J, Ks, Ko, S=1):
     """float32 bytes one potential+gradient evaluation of one chain must read."""
     return 4 * (N * Ks + N * T * J * Ko + S * N * T * J)
@@ -61,18 +135,13 @@ def algorithmic_bytes_per_eval(N, T, J, Ks, Ko, S=1):
 def psi_draws(draws, X, site="psi", effects=None):
     """draws (C, S, D) -> psi (C, S, N) float32 = sigmoid(beta0 + X beta)  (occu.py:198-207), or
     abundance = exp(beta0 + X beta) for occu_rn (occu_rn.py:192).  effects: (C, S, N) site_re_occ draws of these sites."""
+    import numpy as np
+
     Ks = X.shape[1]
     eta = draws[..., :1] + draws[..., 1:Ks + 1] @ X.T
     if effects is not None:
         eta = eta + effects
     return (np.exp(eta) if site == "abundance" else 1.0 / (1.0 + np.exp(-eta))).astype(np.float32)
-
-
-class _DevArray:
-    """Expose an engine-owned device buffer to torch (for the RCCL gather) without a copy."""
-
-    def __init__(self, ptr, shape):
-        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr="<f4", data=(int(ptr), False), version=2)
 
 
 def ess_of_site_function(draws, X, site="psi", chunk=1000, o_u=None):
@@ -88,9 +157,13 @@ def ess_of_site_function(draws, X, site="psi", chunk=1000, o_u=None):
 
 
 def cpu_baseline(data, threads, wl):
-    """Oracle (port of the same algorithm, float64 C) on host cores, bounded sample of the workload."""
+    """Oracle (port of the same algorithm, float64 C) on host cores: the same chains x (warmup + draws) as the GPU for the
+    headline workload, a bounded sample for the heavier ones.  Built -O3 -march=native on THIS host (oracle/Makefile `native`)."""
+    import numpy as np
+
+    os.environ["OCCU_ORACLE_FLAVOR"] = "native"
     import oracle
-    from biolith_amd.evaluation import effective_sample_size
+    from biolith_amd.evaluation import effective_sample_size  # noqa: F401
 
     od = oracle.OracleData(data["site_covs"], data["obs_covs"], data["obs"], model=wl["model"], **wl.get("options", {}))
     w, s = wl["cpu_sample"]
@@ -100,48 +173,94 @@ def cpu_baseline(data, threads, wl):
     X = np.asarray(data["site_covs"], dtype=np.float32).astype(np.float64)
     ess = ess_of_site_function(r["draws"], X, wl["site"], o_u=od.Ks + od.Ko + 3 if wl["model"] == "occu_re" else None)
     nleap = int(r["n_leapfrog"].sum())
+    same = (w, s) == (wl["num_warmup"], wl["num_samples"])
     return dict(value=ess / wall, unit="ESS/s", cores=int(r["threads"]), kind="port",
-                sample=f"oracle NUTS (float64 C restatement), same data, {CHAINS_PER_GPU} chains x ({w} warmup + {s} draws) "
-                       f"on {int(r['threads'])} threads: {wall:.1f} s, {nleap} gradient evaluations, "
+                sample=f"oracle NUTS (float64 C restatement, gcc -O3 -march=native -fno-fast-math, one thread per chain), same data, "
+                       f"{CHAINS_PER_GPU} chains x ({w} warmup + {s} draws){' = the GPU workload' if same else ' (bounded sample)'} "
+                       f"on {int(r['threads'])} of {os.cpu_count()} host cores: {wall:.1f} s, {nleap} gradient evaluations, "
                        f"{1e3 * wall * int(r['threads']) / nleap:.2f} ms per evaluation per core, ESS({wl['site']}) {ess:.0f}")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", action="store_true",
-                    help="occu_rn / occu_re: also time the oracle (minutes on 4 cores; off by default)")
-    ap.add_argument("--wgs-per-chain", type=int, default=0)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="occu")
-    args = ap.parse_args()
+def fit_end_to_end(data, reps=3):
+    """What biolith's own benchmark times (benchmarks/occu_spoccupancy.py:104-113): the clock around the whole
+    ``fit(occu, **data, num_chains=4)`` -- host arrays in, upload, sampling, draws back -- plus the ``psi`` fetch that the
+    metric needs (the reference's samples are device arrays until looked at; here psi is computed on first access)."""
+    from biolith_amd.evaluation import effective_sample_size  # noqa: F401
+    from biolith_amd.models import occu
+    from biolith_amd.utils import fit
+
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        res = fit(occu, **data, num_chains=CHAINS_PER_GPU)
+        t1 = time.perf_counter()
+        psi = res.samples["psi"]
+        t2 = time.perf_counter()
+        rec = dict(fit_ms=1e3 * (t1 - t0), psi_fetch_ms=1e3 * (t2 - t1), total_ms=1e3 * (t2 - t0), kernel_ms=res.mcmc.result.kernel_ms,
+                   draws=res.mcmc.result.draws)
+        if best is None or rec["total_ms"] < best["total_ms"]:
+            best = rec
+        del psi, res
+    return best
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, argv)     # before torch / HIP are touched in this process
     wl = WORKLOADS[args.workload]
     NUM_WARMUP, NUM_SAMPLES = wl["num_warmup"], wl["num_samples"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    import numpy as np
+
+    selftest = os.environ.get("BENCH_SELFTEST") == "1"   # tests/: launcher + rendezvous on gloo, no GPU work, not a bench line
     import torch
 
+    if not selftest:
+        have = torch.cuda.device_count()     # (does not initialise HIP)
+        if have < world or local_rank >= have:
+            raise SystemExit(f"bench.py: --gpus {world} but only {have} GPU(s) visible on this node (rank {rank}); "
+                             "refusing to run fewer ranks than asked")
     dist = None
-    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":  # the env knob exercises the RCCL path on one GPU
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"  # the env knob exercises the RCCL path on one GPU
+    if use_dist:
         import torch.distributed as dist
 
         # NCCL_DEBUG=VERSION (set on the GPU boxes) makes RCCL print a five-line banner on STDOUT when the first
         # communicator is created; stdout is reserved for the one JSON line, so that banner is turned off
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
             del os.environ["NCCL_DEBUG"]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        if selftest:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    elif not selftest:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+    if selftest:
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"selftest": True, "n_gpus": world, "world": dist.get_world_size() if dist is not None else 1,
+                              "rank_sum": float(t.item()), "launcher": os.environ.get("BENCH_LAUNCHED_BY", "external")}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
-    from biolith_amd.distributed import gather_draws
+    from biolith_amd.distributed import comm_from_env, gather_draws, rccl_version
     from biolith_amd.engine import OccuDataset
     from biolith_amd.evaluation import effective_sample_size, split_gelman_rubin
     from biolith_amd.models import simulate, simulate_rn
@@ -152,6 +271,9 @@ def main():
     ds = OccuDataset(data["site_covs"], data["obs_covs"], data["obs"], device=local_rank,
                      model=wl["model"], **wl.get("options", {}))  # resident in HBM from here on
     stream = torch.cuda.current_stream().cuda_stream
+    # the data-path communicator: the engine's own (librccl behind the C-ABI); made before the timed region, cost reported
+    comm = comm_from_env(local_rank, rank, world) if use_dist else None
+    chains_per_rank = [CHAINS_PER_GPU] * world
 
     def sync_all():
         torch.cuda.synchronize()
@@ -163,14 +285,21 @@ def main():
         ds.launch(num_warmup=NUM_WARMUP, num_samples=NUM_SAMPLES, num_chains=CHAINS_PER_GPU, seed=step_seed,
                   chain_offset=rank * CHAINS_PER_GPU, wgs_per_chain=args.wgs_per_chain, stream=stream)
         ds.wait()
-        res = ds.fetch()
-        draws_all = res.draws
-        if dist is not None:
-            ptr, _ = ds.device_draws()
-            # clone: the collective then runs on torch-allocated memory, not on the engine's own hipMalloc block
-            local = torch.as_tensor(_DevArray(ptr, res.draws.shape), device=f"cuda:{local_rank}").clone()
-            draws_all = gather_draws(local).cpu().numpy()  # RCCL all-gather: the path's only collective
-        return res, draws_all
+        if comm is None:
+            res = ds.fetch()
+            return res, res.draws
+        # bl_gather_draws: ONE all-gather of every rank's result block over RCCL / xGMI, the path's only collective;
+        # only rank 0 copies the gathered blocks to the host
+        full = gather_draws([comm], [ds], chains_per_rank, want_result=(rank == 0))
+        local = ds.fetch() if rank != 0 else None
+        if rank == 0:
+            lo = rank * CHAINS_PER_GPU
+            import copy
+
+            local = copy.copy(full)
+            for name in ("draws", "diverging", "num_steps", "accept_prob", "potential_energy", "step_size", "inv_mass", "n_leapfrog"):
+                setattr(local, name, getattr(full, name)[lo: lo + CHAINS_PER_GPU])
+        return local, (full.draws if full is not None else None)
 
     for w in range(args.warmup):
         one_step(10_000 + w)
@@ -187,10 +316,14 @@ def main():
     # ---- per-rank kernel statistics (HIP events on the launch stream, recorded inside the timed region)
     kernel_ms = np.array([r.kernel_ms for r, _ in steps])
     leap = np.array([int(r.n_leapfrog.sum()) + CHAINS_PER_GPU for r, _ in steps])  # + the initial evaluation of each chain
+    kernel_ms_per_rank = [float(kernel_ms.mean())]
     if dist is not None:
         agg = torch.tensor([kernel_ms.mean(), leap.mean()], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        kernel_ms_mean, leap_mean = float(agg[0].item()) / world, float(agg[1].item()) / world
+        every = [torch.zeros_like(agg) for _ in range(world)]
+        dist.all_gather(every, agg)
+        kernel_ms_per_rank = [float(e[0].item()) for e in every]
+        kernel_ms_mean = float(np.mean(kernel_ms_per_rank))
+        leap_mean = float(np.mean([float(e[1].item()) for e in every]))
     else:
         kernel_ms_mean, leap_mean = float(kernel_ms.mean()), float(leap.mean())
 
@@ -210,11 +343,47 @@ def main():
             bytes_eval += 56 * ds.D
         res0 = steps[0][0]
         achieved = leap_mean * bytes_eval / (kernel_ms_mean * 1e-3) / 1e9
-        traffic = None
+        # roofline.traffic: HBM bytes per launch from the PMC passes (tools/pmc_run.sh, separate --pmc runs of this same
+        # command); a STATIC figure read from a committed file, not measured in this run
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and args.workload == "occu":  # the PMC passes were taken on the headline workload
+        if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                tj = json.load(f)
+            ent = tj.get(args.workload) or (tj if args.workload == "occu" and "hbm_bytes_per_launch" in tj else None)
+            if ent:
+                traffic = ent.get("hbm_bytes_per_launch")
+                traffic_source = f"profiles/pmc_traffic.json (static; from {ent.get('source')})"
+        kernel_name = ("bl_re_nuts_kernel(BlReRun const*)" if wl["model"] == "occu_re" else
+                       # <KS, KO, LDS-staged, model id, compute waves>: occu = 0; occu_rn = 5 (104-entry table, max_abundance <= 103)
+                       f"bl_nuts_kernel<{ds.Ks}, {ds.Ko}, true, {5 if wl['model'] == 'occu_rn' else 0}, {res0.threads_per_wg // 64 - 1}>")
+        us_leap = 1e3 * kernel_ms_mean / (leap_mean / CHAINS_PER_GPU)
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": kernel_name, "kernel_ms": kernel_ms_mean,
+            "algorithmic_bytes_per_launch": leap_mean * bytes_eval, "bytes_per_gradient_evaluation": bytes_eval,
+            "gradient_evaluations_per_launch": leap_mean,
+            "us_per_leapfrog_per_chain": us_leap,
+            "note": "data is LDS-resident after one HBM read, so this is an effective (algorithmic) bandwidth; "
+                    "the sequential-leapfrog latency (us_per_leapfrog_per_chain) is the real bound",
+        }
+        if wl["model"] == "occu_rn":
+            # config 4 is VALU-transcendental-bound (about 5 M enumerated (site, visit, n) terms per evaluation,
+            # one transcendental each), not HBM-bound.  Peak = quarter-rate transcendental issue of the CUs the launch occupies.
+            terms = N * T * J * 101
+            cus = CHAINS_PER_GPU * res0.wgs_per_chain
+            ach = leap_mean * terms / (kernel_ms_mean * 1e-3) / 1e9
+            roofline = {
+                "bound": "valu-transcendental", "achieved": ach, "peak": cus * TRANS_PER_CU_PER_S / 1e9, "unit": "Gtrans/s",
+                "frac": ach / (cus * TRANS_PER_CU_PER_S / 1e9), "frac_of_chip": ach / (N_CUS * TRANS_PER_CU_PER_S / 1e9),
+                "cus_used": cus, "transcendentals_per_gradient_evaluation": terms,
+                "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms": kernel_ms_mean,
+                "gradient_evaluations_per_launch": leap_mean, "us_per_leapfrog_per_chain": us_leap,
+                "hbm_effective_GBps": achieved, "bytes_per_gradient_evaluation": bytes_eval,
+                "note": "algorithmic transcendentals = N x T x J x (max_abundance + 1) enumerated terms (SURVEY.md section 8d); the kernel "
+                        "truncates the n-range where the terms die out, so it executes fewer; peak = 16 lanes x 4 SIMDs x 2.4 GHz per CU",
+            }
         out = {
             "metric": wl["metric"],
             "value": total_ess / elapsed,
@@ -228,26 +397,19 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "rccl_world": comm.world if comm is not None else 1,
+            "kernel_ms_per_rank": kernel_ms_per_rank,
             "config": {
                 "workload": f"{wl['text']}: NUTS {CHAINS_PER_GPU} chains per GPU x ({NUM_WARMUP} warmup + {NUM_SAMPLES} draws), "
                             "one step = one full fit",
                 "chains_per_gpu": CHAINS_PER_GPU, "total_chains": CHAINS_PER_GPU * world,
                 "num_warmup": NUM_WARMUP, "num_samples": NUM_SAMPLES, "parallelism": f"chains x{world} (1 process per GPU)",
                 "wgs_per_chain": res0.wgs_per_chain, "lds_bytes_per_wg": res0.lds_bytes, "lds_staged": res0.lds_staged,
+                "gather": (f"bl_gather_draws: one ncclAllGather of {world} result blocks (RCCL {rccl_version()}), communicator init "
+                           f"{comm.init_ms:.0f} ms outside the timed region") if comm is not None else "none (one rank)",
+                "torch_process_group": (dist.get_backend() + f" x{dist.get_world_size()} (barrier / max-over-ranks only)") if dist is not None else None,
             },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                # <KS, KO, LDS-staged, model id, compute waves>: occu = 0; occu_rn = 5 (104-entry table, max_abundance <= 103)
-                "kernel": "bl_re_nuts_kernel(BlReRun const*)" if wl["model"] == "occu_re" else
-                          f"bl_nuts_kernel<{ds.Ks}, {ds.Ko}, true, {5 if wl['model'] == 'occu_rn' else 0}, {res0.threads_per_wg // 64 - 1}>",
-                "kernel_ms": kernel_ms_mean,
-                "algorithmic_bytes_per_launch": leap_mean * bytes_eval, "bytes_per_gradient_evaluation": bytes_eval,
-                "gradient_evaluations_per_launch": leap_mean,
-                "us_per_leapfrog_per_chain": 1e3 * kernel_ms_mean / (leap_mean / CHAINS_PER_GPU),
-                "note": "data is LDS-resident after one HBM read, so this is an effective (algorithmic) bandwidth; "
-                        "the sequential-leapfrog latency is the real bound",
-            },
+            "roofline": roofline,
             "sampler": {  # rank 0's chains, last timed step (SURVEY.md section 8d "also report")
                 "mean_num_steps": float(steps[-1][0].num_steps.mean()), "divergences": int(steps[-1][0].diverging.sum()),
                 "step_size": [float(x) for x in steps[-1][0].step_size], "mean_accept_prob": float(steps[-1][0].accept_prob.mean()),
@@ -256,11 +418,24 @@ def main():
             "ess": {f"{wl['site']}_mean_over_sites_per_step": ess_psi, "min_coef_per_step": [float(x) for x in ess_coef],
                     "max_split_rhat": max(rhat), "draws_per_step": CHAINS_PER_GPU * world * NUM_SAMPLES},
         }
+        if world == 1 and args.workload == "occu" and not args.no_e2e:
+            # SURVEY section 8d's second clock: end-to-end fit() from host arrays, PCIe and the psi fetch included (never `value`)
+            e2e = fit_end_to_end(data)
+            ess_e2e = ess_of_site_function(e2e["draws"].astype(np.float64), X, "psi")
+            out["fit_e2e_ms"] = e2e["total_ms"]
+            out["value_e2e"] = ess_e2e / (e2e["total_ms"] * 1e-3)
+            out["fit_e2e"] = {"fit_call_ms": e2e["fit_ms"], "psi_fetch_ms": e2e["psi_fetch_ms"], "kernel_ms": e2e["kernel_ms"],
+                              "ess_psi": ess_e2e,
+                              "what": "best of 3: clock around fit(occu, **data, num_chains=4) from host NumPy arrays (upload, sampling, "
+                                      "draws back) + samples['psi'] (4000 x 10000 float32 computed on the device and copied over PCIe), "
+                                      "as biolith/benchmarks/occu_spoccupancy.py:104-113 times it; library already loaded"}
         want_cpu = not args.no_cpu_baseline and (args.workload == "occu" or args.cpu_baseline)
         if world == 1 and want_cpu:
             out["cpu_baseline"] = cpu_baseline(data, threads=min(CHAINS_PER_GPU, os.cpu_count() or 1), wl=wl)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -12,7 +12,8 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BIOLITH_HIP_LIB") or os.path.join(_HERE, "lib", "libbiolith_hip.so")
 
-BL_OK, BL_ERR_INVALID, BL_ERR_NO_DEVICE, BL_ERR_UNSUPPORTED, BL_ERR_TIMEOUT, BL_ERR_ABORTED, BL_ERR_BUSY = range(7)
+BL_OK, BL_ERR_INVALID, BL_ERR_NO_DEVICE, BL_ERR_UNSUPPORTED, BL_ERR_TIMEOUT, BL_ERR_ABORTED, BL_ERR_BUSY, BL_ERR_COMM = range(8)
+COMM_ID_BYTES = 128
 RNG_STREAMS_PER_CHAIN = 64
 MAX_COVS = 16
 
@@ -65,6 +66,8 @@ EXPORTS = (
     "bl_dataset_param_dim", "bl_logp_grad", "bl_nuts_run", "bl_nuts_launch", "bl_nuts_poll",
     "bl_nuts_abort", "bl_nuts_wait", "bl_nuts_fetch", "bl_nuts_elapsed_ms", "bl_nuts_device_draws",
     "bl_nuts_geometry", "bl_nuts_debug_counters", "bl_deterministic", "bl_predict", "bl_predict_counts", "bl_predict_scores", "bl_dataset_create_fp", "bl_dataset_create_cop", "bl_dataset_create_nmix", "bl_dataset_create_re", "bl_dataset_create_cs", "bl_dataset_set_prior_family", "bl_rng_streams", "bl_adaptation_schedule",
+    "bl_comm_rccl_version", "bl_comm_unique_id", "bl_comm_init_rank", "bl_comm_init_all", "bl_comm_info", "bl_comm_destroy",
+    "bl_gather_draws",
 )
 
 _lib = None
@@ -123,6 +126,14 @@ def load():
         L.bl_predict_scores.argtypes = [vp, C.c_int, fp, C.c_uint64, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), fp]
         L.bl_rng_streams.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
         L.bl_adaptation_schedule.argtypes = [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]
+        u8p = C.POINTER(C.c_uint8)
+        L.bl_comm_rccl_version.argtypes = [ip]
+        L.bl_comm_unique_id.argtypes = [u8p]
+        L.bl_comm_init_rank.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+        L.bl_comm_init_all.argtypes = [C.c_int, ip, C.POINTER(vp)]
+        L.bl_comm_info.argtypes = [vp, ip, ip, ip, dp]
+        L.bl_comm_destroy.argtypes = [vp]
+        L.bl_gather_draws.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int, C.POINTER(C.c_int32), C.POINTER(bl_nuts_output)]
         for name in EXPORTS:
             if name != "bl_last_error":
                 getattr(L, name).restype = C.c_int

@@ -1139,6 +1139,20 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
 // ------------------------------------------------------------------- NUTS ----
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
+// Head of the run slab = the RESULT BLOCK of a launch: everything bl_nuts_fetch returns, contiguous, so that the gather
+// over RCCL (comm_rccl.hpp) ships it as one buffer.  Offsets are a function of (chains, draws kept, D) only.
+struct RunLayout { size_t draws, div, steps, acc, pot, eps, minv, nleap, end; };
+static RunLayout result_layout(size_t C, size_t Sa, size_t D)
+{
+    RunLayout L{};
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
+    L.draws = carve(C * Sa * D * 4); L.div = carve(C * Sa); L.steps = carve(C * Sa * 4); L.acc = carve(C * Sa * 4);
+    L.pot = carve(C * Sa * 4); L.eps = carve(C * 4); L.minv = carve(C * D * 4); L.nleap = carve(C * 16);
+    L.end = off;
+    return L;
+}
+
 // Random-effects model: k workgroups per chain, each with a slice of the sites; sampler state in device memory / LDS
 // (re_kernel.hpp).  Outputs land in the same run-slab fields as the other models', so poll / wait / fetch are shared.
 static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t st, int max_depth)
@@ -1163,11 +1177,11 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     k = (N + nloc - 1) / nloc; // no empty slice
     const int dl_max = g.G + nloc * per_site;
 
-    size_t off = 0;
+    const RunLayout RL = result_layout((size_t)C, Sa, D);
+    size_t off = RL.end;
     auto carve = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
-    const size_t o_draws = carve((size_t)C * Sa * D * 4), o_div = carve((size_t)C * Sa), o_steps = carve((size_t)C * Sa * 4),
-                 o_acc = carve((size_t)C * Sa * 4), o_pot = carve((size_t)C * Sa * 4), o_eps = carve((size_t)C * 4),
-                 o_minv = carve((size_t)C * D * 4), o_nleap = carve((size_t)C * 16), o_status = carve(16),
+    const size_t o_draws = RL.draws, o_div = RL.div, o_steps = RL.steps, o_acc = RL.acc, o_pot = RL.pot, o_eps = RL.eps,
+                 o_minv = RL.minv, o_nleap = RL.nleap, o_status = carve(16),
                  o_rng = carve((size_t)C * k * (dl_max + 2) * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(32 * 8),
                  o_xchg = carve((size_t)C * 2 * k * BL_RE_NRED * 8), o_loc = carve((size_t)C * 4), o_run = carve(sizeof(BlReRun));
     if (off > ds->run_bytes) {
@@ -1281,12 +1295,12 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     const int nvp = (D + 4 <= 16) ? 16 : (D + 4 <= 32 ? 32 : 64);
 
     // ---- (re)allocate run slab ----
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
     const size_t Sa = S > 0 ? S : 1;
-    const size_t o_draws = carve((size_t)C * Sa * D * 4), o_div = carve((size_t)C * Sa), o_steps = carve((size_t)C * Sa * 4),
-                 o_acc = carve((size_t)C * Sa * 4), o_pot = carve((size_t)C * Sa * 4), o_eps = carve((size_t)C * 4),
-                 o_minv = carve((size_t)C * D * 4), o_nleap = carve((size_t)C * 16), o_status = carve(16),
+    const RunLayout RL = result_layout((size_t)C, Sa, (size_t)D);
+    size_t off = RL.end;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
+    const size_t o_draws = RL.draws, o_div = RL.div, o_steps = RL.steps, o_acc = RL.acc, o_pot = RL.pot, o_eps = RL.eps,
+                 o_minv = RL.minv, o_nleap = RL.nleap, o_status = carve(16),
                  o_rng = carve((size_t)C * BL_RNG_STREAMS_PER_CHAIN * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(32 * 8), o_loc = carve((size_t)C * 4),
                  o_cold = carve(sizeof(BlNutsCold));
     if (off > ds->run_bytes) {
@@ -1577,3 +1591,6 @@ extern "C" int bl_deterministic(bl_dataset *ds, int n_draws, const float *draws,
     }
     return BL_OK;
 }
+
+// ------------------------------------------------------- multi-GPU: the gather of the draws over RCCL ----
+#include "comm_rccl.hpp"

@@ -40,6 +40,7 @@ class NutsResult:
     lds_staged: bool
     chains_l2_local: int = 0      # chains that ran the verified same-XCD (L2-local) exchange
     threads_per_wg: int = 0       # 64 x (compute waves + 1 control wave)
+    comm_init_ms: float = 0.0     # fit(devices=[...]): wall time of ncclCommInitAll (outside the sampling clock)
 
 
 class OccuDataset:
@@ -214,26 +215,32 @@ class OccuDataset:
         _ffi.check(self._lib.bl_nuts_device_draws(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
-    def fetch(self) -> NutsResult:
-        Cn, S = self._shape
+    def _output(self, Cn: int, S: int):
+        """Host arrays for ``Cn`` chains x ``S`` draws and the ``bl_nuts_output`` that points at them."""
         D = self.D
-        draws = np.empty((Cn, S, D), dtype=np.float32)
-        div = np.empty((Cn, S), dtype=np.uint8)
-        steps = np.empty((Cn, S), dtype=np.int32)
-        acc = np.empty((Cn, S), dtype=np.float32)
-        pot = np.empty((Cn, S), dtype=np.float32)
-        eps = np.empty(Cn, dtype=np.float32)
-        minv = np.empty((Cn, D), dtype=np.float32)
-        nleap = np.empty((Cn, 2), dtype=np.int64)
+        a = dict(draws=np.empty((Cn, S, D), dtype=np.float32), diverging=np.empty((Cn, S), dtype=np.uint8),
+                 num_steps=np.empty((Cn, S), dtype=np.int32), accept_prob=np.empty((Cn, S), dtype=np.float32),
+                 potential_energy=np.empty((Cn, S), dtype=np.float32), step_size=np.empty(Cn, dtype=np.float32),
+                 inv_mass=np.empty((Cn, D), dtype=np.float32), n_leapfrog=np.empty((Cn, 2), dtype=np.int64))
         out = _ffi.bl_nuts_output(
-            _fp(draws), div.ctypes.data_as(C.POINTER(C.c_uint8)), steps.ctypes.data_as(C.POINTER(C.c_int32)),
-            _fp(acc), _fp(pot), _fp(eps), _fp(minv), nleap.ctypes.data_as(C.POINTER(C.c_int64)),
+            _fp(a["draws"]), a["diverging"].ctypes.data_as(C.POINTER(C.c_uint8)), a["num_steps"].ctypes.data_as(C.POINTER(C.c_int32)),
+            _fp(a["accept_prob"]), _fp(a["potential_energy"]), _fp(a["step_size"]), _fp(a["inv_mass"]),
+            a["n_leapfrog"].ctypes.data_as(C.POINTER(C.c_int64)),
         )
-        _ffi.check(self._lib.bl_nuts_fetch(self._h, C.byref(out)))
+        return a, out
+
+    def _result(self, a) -> NutsResult:
         k, thr, lds, staged, loc = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
         _ffi.check(self._lib.bl_nuts_geometry(self._h, C.byref(k), C.byref(thr), C.byref(lds), C.byref(staged), C.byref(loc)))
-        return NutsResult(draws, div.astype(bool), steps, acc, pot, eps, minv, nleap, self.elapsed_ms(),
+        return NutsResult(a["draws"], a["diverging"].astype(bool), a["num_steps"], a["accept_prob"], a["potential_energy"],
+                          a["step_size"], a["inv_mass"], a["n_leapfrog"], self.elapsed_ms(),
                           k.value, lds.value, bool(staged.value), loc.value, thr.value)
+
+    def fetch(self) -> NutsResult:
+        Cn, S = self._shape
+        a, out = self._output(Cn, S)
+        _ffi.check(self._lib.bl_nuts_fetch(self._h, C.byref(out)))
+        return self._result(a)
 
     def nuts(self, timeout: Optional[float] = None, **kw) -> NutsResult:
         """launch + wait + fetch.  With ``timeout`` (seconds) the kernel is aborted through its
@@ -258,10 +265,18 @@ class OccuDataset:
         return self.fetch()
 
     # ------------------------------------------------------------ deterministic sites ----
+    def _draw_matrix(self, draws):
+        """draws (..., D) -> contiguous float32 (n, D); a different trailing size (e.g. a random-effects posterior of
+        another number of sites) is rejected instead of being silently re-shaped."""
+        d = np.asarray(draws, dtype=np.float32)
+        if d.ndim == 0 or d.shape[-1] != self.D:
+            raise ValueError(f"draws must have {self.D} coordinates on the last axis for this dataset, got shape {d.shape}")
+        return np.ascontiguousarray(d).reshape(-1, self.D)
+
     def deterministic(self, draws, psi: bool = True, prob_detection: bool = False):
         """psi -- or, for occu_rn, abundance -- (n, T, N) and/or prob_detection (n, J, T, N) for draws (n, D)
         (occu.py:207,221-228; occu_rn.py:192,209-218)."""
-        d = np.ascontiguousarray(draws, dtype=np.float32).reshape(-1, self.D)
+        d = self._draw_matrix(draws)
         n = d.shape[0]
         out_psi = np.empty((n, self.T, self.N), dtype=np.float32) if psi else None
         out_pd = np.empty((n, self.J, self.T, self.N), dtype=np.float32) if prob_detection else None
@@ -274,7 +289,7 @@ class OccuDataset:
         (``z`` for occu / occu_cop, ``N_i`` for occu_rn / nmixture) as (n, T, N) and ``y`` as (n, J, T, N); uint8, or
         int32 for the count models
         (biolith/utils/predict.py:66-92; occu.py:208-241; occu_rn.py:194-221)."""
-        d = np.ascontiguousarray(draws, dtype=np.float32).reshape(-1, self.D)
+        d = self._draw_matrix(draws)
         n = d.shape[0]
         counts = self.model in ("occu_cop", "nmixture")  # their sampled sites are counts: int32 (bl_predict_counts)
         dt, ct = (np.int32, C.c_int32) if counts else (np.uint8, C.c_uint8)
@@ -290,7 +305,7 @@ class OccuDataset:
 def _predictive_scores(self, draws, seed: int = 0):
     """occu_cs: posterior predictive ``z`` (n, T, N), ``f`` (n, J, T, N) as uint8 and the scores ``s`` (n, J, T, N) float32
     (biolith/models/occu_cs.py:196-232 with obs withheld)."""
-    d = np.ascontiguousarray(draws, dtype=np.float32).reshape(-1, self.D)
+    d = self._draw_matrix(draws)
     n = d.shape[0]
     z = np.empty((n, self.T, self.N), dtype=np.uint8)
     f = np.empty((n, self.J, self.T, self.N), dtype=np.uint8)

@@ -72,6 +72,37 @@ def log_likelihood(model_fn: Callable, posterior_samples: Dict[str, np.ndarray],
         ll = -0.5 * ((sc - mu) / sg) ** 2 - np.log(sg) - np.float32(0.5 * np.log(2 * np.pi))
         return {"s": np.where(valid[None], ll, np.float32(0.0)).astype(np.float32)}
     y = np.where(valid, obs.transpose((3, 2, 1, 0)), np.float32(0.0)).astype(np.float32)
+    name = getattr(model_fn, "__biolith_amd_model__", None)
+    if name == "nmixture":
+        # y ~ Binomial(N_i, prob_detection)  (nmixture.py:206-220): numpyro's BinomialProbs.log_prob, -inf above N_i
+        from scipy.special import gammaln, xlog1py, xlogy
+
+        n_i = np.asarray(ps["N_i"], dtype=np.float64)[:, None]                      # (n, 1, T, N, S)
+        p = np.clip(np.asarray(ps["prob_detection"], dtype=np.float64), _TINY, _ONE_MINUS_EPS)
+        yy = y[None].astype(np.float64)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ll = (gammaln(n_i + 1.0) - gammaln(yy + 1.0) - gammaln(np.maximum(n_i - yy, 0.0) + 1.0)
+                  + xlogy(yy, p) + xlog1py(n_i - yy, -p))
+        ll = np.where(yy > n_i, -np.inf, ll)
+        return {"y": np.where(valid[None], ll, 0.0).astype(np.float32)}
+    if name == "occu_cop":
+        # y ~ Poisson(session_duration (z rate_detection + (1 - z) f_u + f_c))  (occu_cop.py:222-255)
+        from scipy.special import gammaln, xlogy
+
+        dur = np.asarray(kwargs["session_duration"], dtype=np.float64)
+        if dur.ndim == 3:
+            dur = dur[None]
+        dur = np.broadcast_to(dur, obs.shape).transpose((3, 2, 1, 0))[None]        # (1, J, T, N, S)
+        z = np.asarray(ps["z"], dtype=np.float64)[:, None]
+        lam = np.asarray(ps["rate_detection"], dtype=np.float64)
+        shape = (-1,) + (1,) * 4
+        f_c = np.asarray(ps["rate_fp_constant"], np.float64).reshape(shape) if "rate_fp_constant" in ps else 0.0
+        f_u = np.asarray(ps["rate_fp_unoccupied"], np.float64).reshape(shape) if "rate_fp_unoccupied" in ps else 0.0
+        mu = dur * (z * lam + (1.0 - z) * f_u + f_c)
+        yy = y[None].astype(np.float64)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ll = xlogy(yy, mu) - mu - gammaln(yy + 1.0)        # rate 0: 0 for a zero count, -inf otherwise
+        return {"y": np.where(valid[None], ll, 0.0).astype(np.float32)}
     prob = np.clip(_detection_probability(model_fn, ps), _TINY, _ONE_MINUS_EPS)
     with np.errstate(divide="ignore"):
         ll = y[None] * np.log(prob) + (np.float32(1.0) - y[None]) * np.log1p(-prob)

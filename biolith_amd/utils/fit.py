@@ -68,6 +68,7 @@ def fit(
         raise NotImplementedError("init_strategy: only the default init_to_uniform (fit.py:93) is built")
     device = int(kwargs.pop("device", 0))
     devices = kwargs.pop("devices", None)
+    explicit_devices = devices is not None
     devices = [device] if devices is None else [int(d) for d in devices]
     if not devices:
         raise ValueError("devices must name at least one GPU")
@@ -124,17 +125,44 @@ def fit(
                 except Exception:
                     pass
             raise
+        if use_rccl:
+            # the gather of fit.py:132, as ONE RCCL all-gather per species behind the C-ABI (bl_gather_draws): every
+            # device contributes the result block of its chains; the host reads all of them from the first device
+            out = {}
+            for sp in range(n_species):
+                mine = [(ds, kw["num_chains"]) for s, ds, kw in jobs if s == sp]
+                out[sp] = gather_draws(comms, [ds for ds, _ in mine], [c for _, c in mine])
+            return out
         return [ds.fetch() for _, ds, _ in jobs]
 
-    if timeout is not None:
-        from .misc import time_limit
+    # devices=[...] with distinct GPUs (one is enough): communicators from ncclCommInitAll (made before the clock of a
+    # timeout starts; their cost is reported in mcmc.result.comm_init_ms).  A device named twice (tests on a one-GPU box)
+    # cannot hold two RCCL ranks: the shards are then fetched one by one and concatenated on the host.
+    used = [dev for r, dev in enumerate(devices) if shard_chains(num_chains, world, r)[0] > 0]
+    use_rccl = explicit_devices and len(set(used)) == len(used)
+    comms = []
+    if use_rccl:
+        from ..distributed import comms_for_devices, gather_draws
 
-        with time_limit(timeout):
+        comms = comms_for_devices(used)
+    try:
+        if timeout is not None:
+            from .misc import time_limit
+
+            with time_limit(timeout):
+                results = run_all()
+        else:
             results = run_all()
-    else:
-        results = run_all()
+    finally:
+        for c in comms:
+            c.close()
     per_species = []
     for sp in range(n_species):
+        if use_rccl:
+            ds0 = next(ds for s, ds, _ in jobs if s == sp)
+            results[sp].comm_init_ms = comms[0].init_ms
+            per_species.append((ds0, results[sp]))
+            continue
         shard = [(ds, res) for (s, ds, _), res in zip(jobs, results) if s == sp]
         per_species.append((shard[0][0], _concat_chains([r for _, r in shard])))
     mcmc = _assemble(per_species, spec, num_warmup)

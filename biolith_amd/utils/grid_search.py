@@ -88,10 +88,12 @@ def grid_search_priors(
     cv = StratifiedKFold(n_splits=cv_folds, shuffle=True, random_state=random_seed)
     folds = list(cv.split(np.arange(site_covs.shape[0]), stratify))
     common = dict(regressor_occ=regressor_occ, regressor_det=regressor_det, **kwargs)
+    # kernel / init_strategy belong to fit() alone (grid_search.py:64-96): predict() and lppd() hand unknown keywords to the model
+    fit_only = {}
     if kernel is not None:
-        common["kernel"] = kernel
+        fit_only["kernel"] = kernel
     if init_strategy is not None:
-        common["init_strategy"] = init_strategy
+        fit_only["init_strategy"] = init_strategy
 
     best_score, best_params, best_priors, cv_results = float("-inf"), {}, None, []
     for prior_type in prior_types:
@@ -109,7 +111,7 @@ def grid_search_priors(
                 try:
                     trained = fit(model_fn, site_covs=site_covs[train], obs_covs=obs_covs[train], obs=obs[:, train],
                                   prior_beta=prior_occ, prior_alpha=prior_det, num_samples=num_samples, num_warmup=num_warmup,
-                                  num_chains=num_chains, random_seed=random_seed + fold_idx, timeout=timeout, **common)
+                                  num_chains=num_chains, random_seed=random_seed + fold_idx, timeout=timeout, **fit_only, **common)
                     held_out = dict(site_covs=site_covs[val], obs_covs=obs_covs[val], obs=obs[:, val],
                                     prior_beta=prior_occ, prior_alpha=prior_det, **common)
                     with warnings.catch_warnings():
@@ -139,5 +141,5 @@ def grid_search_priors(
     # one fit
     best_result = fit(model_fn, site_covs=site_covs, obs_covs=obs_covs, obs=obs, prior_beta=best_priors[0], prior_alpha=best_priors[1],
                       num_samples=num_samples, num_warmup=num_warmup, num_chains=num_chains, random_seed=random_seed, timeout=timeout,
-                      **common)
+                      **fit_only, **common)
     return GridSearchResult(best_result, best_params, best_score, cv_results)

@@ -7,58 +7,64 @@ reference's consumers read from it: ``get_samples(group_by_chain)``, ``get_extra
 """
 from __future__ import annotations
 
+from collections.abc import MutableMapping
 from types import SimpleNamespace
 
 import numpy as np
 
 
-class LazySamples(dict):
-    """dict of posterior samples whose large deterministic sites are materialised on first access.
+class LazySamples(MutableMapping):
+    """Mapping of posterior samples whose large deterministic sites are materialised on first access.
 
     ``prob_detection`` is (draws, J, T, N, S): 1 GB at 10k sites x 5 visits x 5000 draws
     (SURVEY.md section 3.1 iv).  The reference materialises it eagerly after sampling; here it is
     computed by the device on first ``samples["prob_detection"]`` and then cached.
+
+    A ``collections.abc.MutableMapping``, NOT a ``dict`` subclass: CPython's fast paths for real dicts
+    (``dict(s)``, ``{**s}``, ``f(**s)``) read the underlying table directly and would hand out the
+    placeholders; for a Mapping they go through ``keys()`` / ``__getitem__`` and get the arrays.
     """
 
     def __init__(self, *a, **kw):
-        super().__init__(*a, **kw)
+        self._data = dict(*a, **kw)
         self._lazy = {}
 
     def set_lazy(self, key, thunk):
         self._lazy[key] = thunk
-        super().__setitem__(key, None)
-
-    def _force(self, key):
-        if key in self._lazy:
-            super().__setitem__(key, self._lazy.pop(key)())
+        self._data[key] = None     # keeps the site's position in iteration order
 
     def __getitem__(self, key):
-        self._force(key)
-        return super().__getitem__(key)
+        if key in self._lazy:
+            self._data[key] = self._lazy.pop(key)()
+        return self._data[key]
 
-    def get(self, key, default=None):
-        if key in self:
-            return self[key]
-        return default
+    def __setitem__(self, key, value):
+        self._lazy.pop(key, None)
+        self._data[key] = value
 
-    def pop(self, key, *default):
-        self._force(key)
-        return super().pop(key, *default)
+    def __delitem__(self, key):
+        self._lazy.pop(key, None)
+        del self._data[key]
 
-    def items(self):
-        for k in list(self._lazy):
-            self._force(k)
-        return super().items()
+    def __iter__(self):
+        return iter(self._data)
 
-    def values(self):
-        for k in list(self._lazy):
-            self._force(k)
-        return super().values()
+    def __len__(self):
+        return len(self._data)
+
+    def __contains__(self, key):
+        return key in self._data
+
+    def __repr__(self):
+        parts = [f"{k!r}: <lazy>" if k in self._lazy else f"{k!r}: array{getattr(v, 'shape', '')}" for k, v in self._data.items()]
+        return "LazySamples({" + ", ".join(parts) + "})"
 
     def __copy__(self):
-        new = LazySamples(dict.items(self))
+        new = LazySamples(self._data)
         new._lazy = dict(self._lazy)
         return new
+
+    copy = __copy__
 
 
 class HipMCMC:

@@ -30,7 +30,8 @@ enum {
     BL_ERR_UNSUPPORTED = 3,  /* model option outside the built path                          */
     BL_ERR_TIMEOUT = 4,      /* in-kernel spin bound hit (a cooperating workgroup vanished)  */
     BL_ERR_ABORTED = 5,      /* bl_nuts_abort() was honoured                                 */
-    BL_ERR_BUSY = 6          /* a launch is still in flight on this handle                   */
+    BL_ERR_BUSY = 6,         /* a launch is still in flight on this handle                   */
+    BL_ERR_COMM = 7          /* RCCL could not be loaded, or a communicator call failed      */
 };
 
 #define BL_RNG_STREAMS_PER_CHAIN 64
@@ -251,6 +252,41 @@ int bl_predict_counts(bl_dataset *ds, int n_draws, const float *draws, uint64_t 
 /* Same for occu_cs (occu_cs.py:196-232 with obs withheld): z[n][T][N], f[n][J][T][N] (which score distribution a replicate
  * drew from) as bytes, s[n][J][T][N] the scores; any of the three may be NULL. */
 int bl_predict_scores(bl_dataset *ds, int n_draws, const float *draws, uint64_t seed, uint8_t *latent, uint8_t *f, float *s);
+
+/*
+ * Multi-GPU: chain-parallel sampling and the gather of the draws.
+ *
+ * The reference's only multi-device strategy is chain_method="parallel" (biolith/utils/fit.py:109-113: one chain per
+ * local device under pmap); its gather is the implicit device->host copy of mcmc.get_samples() (fit.py:132).  Here rank
+ * r runs its own chains (bl_nuts_config.chain_offset selects their RNG streams), nothing is exchanged while sampling, and
+ * ONE collective over RCCL / xGMI follows: every rank contributes the result block of its chains (draws, diverging,
+ * num_steps, accept_prob, potential_energy, step_size, inv_mass, n_leapfrog -- contiguous in device memory) and receives
+ * everybody's.  librccl is loaded on first use (BL_ERR_COMM if it cannot be).
+ *
+ * Two ways to make the communicators:
+ *   process per GPU   rank 0 calls bl_comm_unique_id and hands the 128 bytes to the other ranks by any side channel
+ *                     (a file, a socket, torch.distributed's store); every rank calls bl_comm_init_rank.
+ *   one process       bl_comm_init_all(ndev, devices, comms) -- the in-process fit(..., devices=[...]).
+ */
+#define BL_COMM_ID_BYTES 128
+typedef struct bl_comm bl_comm;
+int bl_comm_rccl_version(int *version);
+int bl_comm_unique_id(uint8_t *id /*[BL_COMM_ID_BYTES]*/);
+int bl_comm_init_rank(const uint8_t *id /*[BL_COMM_ID_BYTES]*/, int world, int rank, int device, bl_comm **out);
+int bl_comm_init_all(int ndev, const int *devices /*[ndev], distinct*/, bl_comm **out /*[ndev]*/);
+/* world size, this communicator's rank and device, wall time its creation took (reported, never inside a timed region) */
+int bl_comm_info(const bl_comm *comm, int *world, int *rank, int *device, double *init_ms);
+int bl_comm_destroy(bl_comm *comm);
+/*
+ * All-gather of the last finished launch of every local dataset (bl_nuts_wait first).  comms / datasets: the n_local
+ * ranks this process drives (1 for process-per-GPU; all of them after bl_comm_init_all), dataset i on communicator i's
+ * device.  chains_per_rank[world]: chains each rank ran -- every rank can compute it (chains are dealt in contiguous
+ * blocks), so block sizes are never negotiated.  Equal counts: one ncclAllGather; unequal: its "v" form, one grouped
+ * set of broadcasts.  out (host, caller-allocated for sum(chains_per_rank) chains, fields may be NULL; out itself may be
+ * NULL on ranks that do not want the result) receives the chains in rank order.
+ */
+int bl_gather_draws(bl_comm *const *comms, bl_dataset *const *datasets, int n_local, const int32_t *chains_per_rank,
+                    bl_nuts_output *out);
 
 /* The engine's xoshiro128++ streams (host-side; no GPU needed): out[nstreams][4]. */
 int bl_rng_streams(uint64_t seed, int chain, int nstreams, uint32_t *out);

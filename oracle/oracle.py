@@ -26,7 +26,14 @@ EPS_F32 = float(np.finfo(np.float32).eps)
 
 
 def build(force: bool = False) -> str:
-    """Compile ``liboccu_oracle.so`` with gcc (a few hundred ms)."""
+    """Compile ``liboccu_oracle.so`` with gcc (a few hundred ms).  ``OCCU_ORACLE_FLAVOR=native`` (set by bench.py's
+    cpu_baseline leg only) selects the -O3 -march=native build, rebuilt on the host that runs it."""
+    if os.environ.get("OCCU_ORACLE_FLAVOR") == "native":
+        subprocess.run(["make", "-C", _HERE, "-s", "-B", "native"], check=True)
+        return os.path.join(_HERE, "_native", "liboccu_oracle_native.so")
+    if os.environ.get("OCCU_ORACLE_FLAVOR") == "asan":   # tests/test_oracle_sanitize.py: ASan + UBSan build, child process only
+        subprocess.run(["make", "-C", _HERE, "-s", "-B", "liboccu_oracle_asan.so"], check=True)
+        return os.path.join(_HERE, "liboccu_oracle_asan.so")
     so = os.path.join(_HERE, "liboccu_oracle.so")
     src = os.path.join(_HERE, "occu_oracle.c")
     if force or not os.path.exists(so) or (

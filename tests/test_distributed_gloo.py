@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from biolith_amd.distributed import gather_draws, shard_chains
+from biolith_amd.distributed import gather_host_arrays, shard_chains
 from conftest import ROOT, load_golden
 
 
@@ -37,7 +37,7 @@ def _worker(rank, world, port, total_chains, q):
     count, offset = shard_chains(total_chains, world, rank)
     r = oracle.nuts_run(od, 30, 25, num_chains=count, seed=3, chain_offset=offset, threads=1)
     local = torch.from_numpy(r["draws"].astype(np.float32))
-    full = gather_draws(local)
+    full = gather_host_arrays(local)
     if rank == 0:
         q.put(full.numpy())
     dist.barrier()
@@ -70,4 +70,4 @@ def test_two_rank_gather_equals_single_process():
 
 def test_gather_is_identity_without_process_group():
     t = torch.arange(6.0).reshape(1, 2, 3)
-    assert gather_draws(t) is t
+    assert gather_host_arrays(t) is t

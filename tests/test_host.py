@@ -131,6 +131,25 @@ def test_lazy_samples():
     assert s["big"].sum() == 3 and calls == [1, 1] and s["big"] is s["big"]
 
 
+def test_lazy_samples_survive_dict_fast_paths(tmp_path):
+    """dict(s), {**s} and f(**s) must hand out the arrays, never a placeholder (the reference returns plain
+    dicts of arrays, fit.py:132-133; np.savez(path, **samples) is the common consumer)."""
+    def fresh():
+        s = LazySamples(a=np.zeros(2))
+        s.set_lazy("psi", lambda: np.ones(3))
+        return s
+
+    assert dict(fresh())["psi"] is not None and dict(fresh())["psi"].sum() == 3
+    assert {**fresh()}["psi"].sum() == 3
+    assert (lambda **kw: kw["psi"].sum())(**fresh()) == 3
+    assert [v is not None for v in fresh().values()] == [True, True]
+    assert dict(fresh().items())["psi"].sum() == 3
+    np.savez(tmp_path / "s.npz", **fresh())
+    assert np.load(tmp_path / "s.npz")["psi"].sum() == 3
+    s = fresh()
+    assert s.get("psi").sum() == 3 and s.get("nope", 7) == 7 and s.pop("psi").sum() == 3 and "psi" not in s and len(s) == 1
+
+
 class _Res:
     def __init__(self, C, S, D, rng):
         self.draws = rng.normal(size=(C, S, D)).astype(np.float32)
@@ -172,3 +191,34 @@ def test_ess_and_rhat_against_oracle_restatement():
     assert abs(effective_sample_size(x).mean() / (2000 * 0.3 / 1.7) - 1) < 0.25
     t = summary(dict(x=x))
     assert t["x"]["n_eff"].shape == (3, 2) and "5.0%" in t["x"] and "95.0%" in t["x"]
+
+
+def test_grid_search_hands_kernel_and_init_strategy_to_fit_only(monkeypatch):
+    """grid_search_priors(kernel='nuts') must not leak `kernel` into predict() / lppd(), whose unknown keywords
+    go to the model (reference: grid_search.py:64-96 passes kernel / init_strategy to fit() alone)."""
+    from biolith_amd.utils import grid_search as gs
+
+    seen = dict(fit=[], predict=[], lppd=[])
+
+    def fake_fit(model_fn, **kw):
+        seen["fit"].append(kw)
+        return gs.FitResult({}, object())
+
+    def fake_predict(model_fn, mcmc, **kw):
+        seen["predict"].append(kw)
+        return {}
+
+    def fake_lppd(model_fn, preds, **kw):
+        seen["lppd"].append(kw)
+        return -1.0
+
+    monkeypatch.setattr(gs, "fit", fake_fit)
+    monkeypatch.setattr(gs, "predict", fake_predict)
+    monkeypatch.setattr(gs, "lppd", fake_lppd)
+    g = load_golden("default")
+    res = gs.grid_search_priors(occu, g["site_covs"], g["obs_covs"], g["obs"], LinearRegression, LinearRegression,
+                                prior_types=["normal"], prior_params_occ={"normal": {"loc": [0.0], "scale": [1.0]}},
+                                prior_params_det=False, cv_folds=2, kernel="nuts", init_strategy=None, num_samples=5, num_warmup=5, num_chains=1)
+    assert res.best_score == -1.0 and len(seen["fit"]) == 3          # two folds + the refit
+    assert all(kw.get("kernel") == "nuts" for kw in seen["fit"])
+    assert all("kernel" not in kw and "init_strategy" not in kw for kw in seen["predict"] + seen["lppd"])

@@ -159,3 +159,39 @@ def test_deviance_residuals_and_ppc_on_hand_made_samples():  # deviance.py, resi
         posterior_predictive_check(sam, good, statistic="g-test")
     with pytest.raises(ValueError):
         posterior_predictive_check(sam, good, group_by="period")
+
+
+def test_log_likelihood_of_the_count_models():
+    """nmixture (Binomial(N_i, p), nmixture.py:206-220) and occu_cop (Poisson(dur (z rate + (1 - z) f_u + f_c)),
+    occu_cop.py:222-255) have their own pointwise likelihoods instead of an opaque KeyError."""
+    from scipy import stats
+
+    from biolith_amd.models import nmixture, occu_cop
+
+    rng = np.random.default_rng(3)
+    n, N, T, J = 7, 6, 2, 3
+    data = _data(rng, N, T, J)
+    data["obs"] = np.where(np.isnan(data["obs"]), np.nan, rng.integers(0, 5, size=data["obs"].shape)).astype(np.float32)
+    p = rng.uniform(0.1, 0.8, size=(n, J, T, N, 1)).astype(np.float32)
+    n_i = rng.integers(0, 9, size=(n, T, N, 1)).astype(np.int32)
+    ll = log_likelihood(nmixture, {"abundance": np.ones((n, T, N, 1), np.float32), "N_i": n_i, "prob_detection": p, "y": None}, **data)["y"]
+    assert ll.shape == (n, J, T, N, 1)
+    y = data["obs"].transpose((3, 2, 1, 0))
+    want = stats.binom.logpmf(np.nan_to_num(y)[None], n_i[:, None], p)
+    ok = np.isfinite(y) & np.isfinite(data["obs_covs"]).all(-1).transpose((2, 1, 0))[..., None] & np.isfinite(data["site_covs"]).all(-1)[None, None, :, None]
+    assert np.allclose(ll[:, ok], want[:, ok], rtol=2e-5, atol=2e-5) and np.all(ll[:, ~ok] == 0)
+    assert np.isneginf(ll[:, ok]).any()          # a count above N_i is impossible
+
+    dur = rng.uniform(0.5, 3.0, size=(N, T, J)).astype(np.float32)
+    z = rng.integers(0, 2, size=(n, T, N, 1)).astype(np.int32)
+    lam = rng.uniform(0.1, 2.0, size=(n, J, T, N, 1)).astype(np.float32)
+    f = rng.uniform(0.05, 0.3, size=n).astype(np.float32)
+    ll = log_likelihood(occu_cop, {"psi": None, "z": z, "rate_detection": lam, "rate_fp_unoccupied": f, "y": None},
+                        session_duration=dur, **data)["y"]
+    mu = dur.transpose((2, 1, 0))[None, ..., None] * (z[:, None] * lam + (1 - z[:, None]) * f.reshape(-1, 1, 1, 1, 1))
+    want = stats.poisson.logpmf(np.nan_to_num(y)[None], mu)
+    assert np.allclose(ll[:, ok], want[:, ok], rtol=2e-5, atol=2e-5) and np.all(ll[:, ~ok] == 0)
+    # without a false-positive rate an unoccupied site cannot produce a count
+    ll0 = log_likelihood(occu_cop, {"z": z, "rate_detection": lam, "y": None}, session_duration=dur, **data)["y"]
+    bad = (z[:, None] == 0) & (np.nan_to_num(y)[None] > 0) & ok[None]
+    assert np.all(np.isneginf(ll0[bad])) and np.all(ll0[(z[:, None] == 0) & (np.nan_to_num(y)[None] == 0) & ok[None]] == 0)
