@@ -96,6 +96,12 @@ def log_likelihood(model_fn: Callable, posterior_samples: Dict[str, np.ndarray],
         z = np.asarray(ps["z"], dtype=np.float64)[:, None]
         lam = np.asarray(ps["rate_detection"], dtype=np.float64)
         shape = (-1,) + (1,) * 4
+        # Predictive leaves the posterior's own sites out of predict()'s result (as numpyro's does), so a model with a
+        # false-positive rate needs that site merged in by the caller: {**predictions, "rate_fp_constant": fit.samples[...]}
+        for opt, site in (("false_positives_constant", "rate_fp_constant"), ("false_positives_unoccupied", "rate_fp_unoccupied")):
+            if kwargs.get(opt) and site not in ps:
+                raise ValueError(f"log_likelihood(occu_cop, {opt}=True): posterior_samples lacks the site {site!r} "
+                                 "(merge it in from fit().samples; predict() returns predictive sites only)")
         f_c = np.asarray(ps["rate_fp_constant"], np.float64).reshape(shape) if "rate_fp_constant" in ps else 0.0
         f_u = np.asarray(ps["rate_fp_unoccupied"], np.float64).reshape(shape) if "rate_fp_unoccupied" in ps else 0.0
         mu = dur * (z * lam + (1.0 - z) * f_u + f_c)

@@ -179,7 +179,4 @@ def predict(
 
         out.set_lazy("prob_detection_fp", prob_detection_fp)
     out.set_lazy("y", lambda: np.stack(y8, axis=-1).astype(np.int32))                 # (n, J, T, N, S)
-    if spec.model == "occu_cop" and fp_site is not None:
-        # (Predictive leaves the posterior's own sites out; the Poisson log-likelihood needs the rate next to z)
-        out[fp_site] = rate.astype(np.float32)
     return rename_samples(out, site_names, obs_names)

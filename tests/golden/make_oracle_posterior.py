@@ -4,7 +4,8 @@
 The oracle needs minutes at 10 000 sites, too slow for the test-suite, so its output is captured
 once here: MAP + Laplace sd (BFGS on the analytic gradient) and 4 chains x (1000 + 1000) of oracle
 NUTS.  GPU tests compare the HIP engine's full-size posterior with these numbers.
-Run:  python tests/golden/make_oracle_posterior.py     (about a minute on 4 cores)
+Run:  python tests/golden/make_oracle_posterior.py [cfg2|cfg5]     (about a minute on 4 cores)
+cfg5 = the stacked-period stand-in of BASELINE.json configs[4] (2000 sites x 8 periods x 4 visits), 4 chains x (500 + 500).
 """
 import json
 import os
@@ -21,22 +22,28 @@ import oracle  # noqa: E402
 from conftest import CFG2, quiet_simulate  # noqa: E402
 
 
-def main():
-    data, truth, _ = quiet_simulate(**CFG2)
+# BASELINE.json configs[4] ("dynamic occupancy") has NO reference model; its nearest reference
+# behaviour is stacked periods sharing psi (occu.py:198-210): the stand-in of SURVEY.md section 8d, "no reference counterpart"
+CFG5 = dict(n_sites=2000, n_periods=8, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=28, session_duration=7)
+
+
+def main(which="cfg2"):
+    cfg, W, S = (CFG2, 1000, 1000) if which == "cfg2" else (CFG5, 500, 500)
+    data, truth, _ = quiet_simulate(**cfg)
     od = oracle.OracleData(data["site_covs"], data["obs_covs"], data["obs"])
     res = minimize(lambda t: od.potential_grad(t), np.zeros(od.D), jac=True, method="BFGS", options=dict(gtol=1e-6))
     h = 1e-5
     H = np.array([(od.potential_grad(res.x + h * e)[1] - od.potential_grad(res.x - h * e)[1]) / (2 * h) for e in np.eye(od.D)])
     laplace_sd = np.sqrt(np.diag(np.linalg.inv(0.5 * (H + H.T))))
     t0 = time.time()
-    r = oracle.nuts_run(od, 1000, 1000, num_chains=4, seed=0)
+    r = oracle.nuts_run(od, W, S, num_chains=4, seed=0)
     wall = time.time() - t0
     draws = r["draws"]
     flat = draws.reshape(-1, od.D)
     X = data["site_covs"].astype(np.float32).astype(np.float64)
     psi_mean_per_draw = (1 / (1 + np.exp(-(flat[:, :1] + flat[:, 1:4] @ X.T)))).mean(axis=1)
     out = dict(
-        config=CFG2, seed=0, chains=4, num_warmup=1000, num_samples=1000,
+        config=cfg, seed=0, chains=4, num_warmup=W, num_samples=S,
         U_at_rng1=float(od.potential_grad(np.random.default_rng(1).uniform(-2, 2, od.D))[0]),
         map=res.x.tolist(), U_map=float(res.fun), laplace_sd=laplace_sd.tolist(),
         mean=flat.mean(0).tolist(), sd=flat.std(0, ddof=1).tolist(),
@@ -47,10 +54,10 @@ def main():
         diverging=int(r["diverging"].sum()), true_mean_z=float(truth["z"].mean()),
         oracle_wall_s=wall, oracle_threads=int(r["threads"]),
     )
-    with open(os.path.join(HERE, "oracle_posterior_cfg2.json"), "w") as f:
+    with open(os.path.join(HERE, f"oracle_posterior_{which}.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: out[k] for k in ("map", "mean", "sd", "ess", "psi_mean", "oracle_wall_s", "n_leapfrog")}, indent=1))
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else "cfg2")
