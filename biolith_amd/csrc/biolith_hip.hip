@@ -1408,7 +1408,11 @@ extern "C" int bl_nuts_poll(bl_dataset *ds, int *done)
     hipSetDevice(ds->device);
     hipError_t e = hipEventQuery(ds->ev1);
     if (e == hipSuccess) { *done = 1; return BL_OK; }
-    if (e == hipErrorNotReady) { *done = 0; return BL_OK; }
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError(); // "not ready" is an answer, not an error: do not leave it behind as this thread's last error
+        *done = 0;
+        return BL_OK;
+    }
     return bl_fail(BL_ERR_NO_DEVICE, "hipEventQuery: %s", hipGetErrorString(e));
 }
 

@@ -6,8 +6,8 @@
 // shards over, so there is exactly ONE exchange, after sampling: every rank contributes the result block of its
 // own chains (draws + per-draw extras + adaptation results, contiguous in the run slab) and receives everybody's.
 //
-// librccl is resolved at first use with dlopen (573 MB: not worth mapping for single-GPU fits, and a process that
-// already holds an RCCL -- torch's -- shares it through the common SONAME instead of loading a second copy).
+// librccl is resolved at first use with dlopen (573 MB: not worth mapping for single-GPU fits), from the directory of the
+// libamdhip64 this library is bound to (see rccl_api()).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -36,7 +36,17 @@ RcclApi *rccl_api()
     static bool tried = false;
     if (tried) return &api;
     tried = true;
-    const char *names[] = {getenv("BIOLITH_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    // The RCCL that belongs to the HIP runtime THIS library is bound to: a process may hold two ROCm stacks (the system's
+    // under /opt/rocm and the one a torch wheel bundles; which libamdhip64 this library got depends on load order), and an
+    // RCCL bound to the other runtime finds "no ROCm-capable device".  So: look next to our own libamdhip64 first.
+    std::string beside, beside1;
+    Dl_info info;
+    if (dladdr((void *)static_cast<hipError_t (*)(void **, size_t)>(&hipMalloc), &info) && info.dli_fname) {
+        const std::string hip = info.dli_fname;
+        const size_t slash = hip.rfind('/');
+        if (slash != std::string::npos) { beside1 = hip.substr(0, slash + 1) + "librccl.so.1"; beside = hip.substr(0, slash + 1) + "librccl.so"; }
+    }
+    const char *names[] = {getenv("BIOLITH_RCCL_LIB"), beside1.c_str(), beside.c_str(), "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
         if (!n || !*n) continue;
         api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -80,6 +90,9 @@ struct bl_comm {
 
 static int need_rccl(RcclApi **out)
 {
+    // RCCL checks hipGetLastError() after its own launches: a stale, harmless last-error of this thread (hipErrorNotReady
+    // from an event query, say) would make it report "unhandled cuda error"
+    (void)hipGetLastError();
     RcclApi *api = rccl_api();
     if (!api->handle) return bl_fail(BL_ERR_COMM, "librccl could not be loaded: %s", api->error.c_str());
     *out = api;
