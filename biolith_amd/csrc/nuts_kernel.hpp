@@ -505,9 +505,11 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         }
     };
 
-    while (true) {
-        bool redo = false; // the evaluation in flight is not the one the sampler needs next
-        if (wave > 0) {
+    // Two loops, one per role, meeting at the same two workgroup barriers per tick: the register allocator then sees the
+    // compute waves' evaluation and the control wave's sampler state as DISJOINT live ranges (one shared loop keeps every
+    // loop-carried register of either role alive through the other role's code: spills on both sides).
+    if (wave > 0) {
+        while (true) {
             // ------------------------------------- phase A: compute waves, site log-lik ----
 #ifdef BL_STAMPS
             const long long st_a0 = (long long)clock64();
@@ -516,7 +518,14 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #ifdef BL_STAMPS
             st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
 #endif
-        } else if (SPEC && have_pending) {
+            __syncthreads(); // partials are in LDS: the control wave's exchange
+            __syncthreads(); // the next position is in LDS
+            if (sh_flag[0] != 0) break;
+        }
+    } else
+    while (true) {
+        bool redo = false; // the evaluation in flight is not the one the sampler needs next
+        if (SPEC && have_pending) {
             decide();
             // was the position being evaluated right now the one just chosen?  (bit-equal or redo: correctness
             // never depends on the guess)
@@ -531,12 +540,12 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         __syncthreads();
         BL_STAMP(1)
 
-        if (wave == 0 && redo) {
+        if (redo) {
             // the decisions chose another position (transition end, U-turn, divergence, ...) or the run is over:
             // publish nothing, hand the compute waves the right position
             if (act) sh_coef[my_pos] = cz;
             if (lane == 0) sh_flag[0] = flag;
-        } else if (wave == 0) {
+        } else {
             epoch++;
             // ---------------------------------- workgroup partial (fixed wave order) ----
             const float *part = bl_lds_f(BL_OFF_PART) + my_pos;
