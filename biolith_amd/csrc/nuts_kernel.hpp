@@ -120,7 +120,7 @@ struct BlCtlScalars {
     int nprop, diverged, da_t, wf_n, win_idx, it;
     long long nleap_w, nleap_s;
 };
-enum { SV_TH = 0, SV_GR, SV_ZL, SV_RL, SV_GL, SV_ZR, SV_RR, SV_GRR, SV_ZP, SV_GP, SV_RSUM, SV_WFMEAN, SV_WFM2 };
+enum { SV_TH = 0, SV_GR, SV_ZL, SV_RL, SV_GL, SV_ZR, SV_RR, SV_GRR, SV_ZP, SV_GP, SV_RSUM, SV_WFMEAN, SV_WFM2, SV_MOMZ };
 
 __device__ __forceinline__ float bl_exp(float x) { return __builtin_amdgcn_exp2f(x * BL_LOG2E); }
 __device__ __forceinline__ float bl_log(float x) { return BL_LN2 * __builtin_amdgcn_logf(x); }
@@ -232,6 +232,15 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     double pend_U = 0.0;
     int pend_snprop = 0;
     bool init_pending = true;           // evaluating the initial position
+    // momentum of the NEXT transition, drawn one transition ahead (same order on the per-dimension streams), so that a
+    // transition's end finds it ready: z ~ N(0,1), r0 = z / sqrt(M^-1), kinetic energy sum(M^-1 r0^2) / 2
+    float mom_r0 = 0.f;                 // (its z is kept in LDS: only a closing adaptation window needs it again)
+    double mom_kin = 0.0;
+    // what a finished transition still owes (outputs, Welford moments, the fresh tree, the next momentum): written out beside
+    // the evaluation of the new transition's first leaf, which the decisions release first.  Everything it needs is still in
+    // the control wave's LDS block by then; only these bits travel in a register:
+    // 1 pending, 2 warmup transition, 4 add the draw to the Welford moments, 8 the adaptation window ended, 16 emit a draw
+    int end_kind = 0;
     bool local = false;                 // L2-local exchange proven safe for this chain
     float prior_loc = 0.f, prior_isc2 = 0.f, prior_l1 = 0.f;
     double prior_const = 0.0;
@@ -274,8 +283,12 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         const float *init = cold->init_theta;
         cz = act ? (init ? init[chain * D + lane] : 4.0f * u0 - 2.0f) : 0.0f;
         if (act) sh_coef[my_pos] = cz;
+        const float z_first = bl_rng_normal(rng_d);  // the first transition's momentum (M^-1 = 1)
+        mom_r0 = act ? z_first : 0.0f;
+        mom_kin = (double)(0.5f * bl_wave_sum(mom_r0 * mom_r0));
 #pragma unroll
         for (int s = 0; s < 16; s++) sv[s * 64] = 0.0f;
+        sv[SV_MOMZ * 64] = z_first;
         if (lane == 0) {
             sh_flag[0] = 0;
             BlCtlScalars z{};
@@ -284,6 +297,59 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         }
     }
     __syncthreads();
+
+    auto mom_refresh = [&]() { // (after M^-1 changed: the same z under the new metric)
+        mom_r0 = act ? sv[SV_MOMZ * 64] * __builtin_amdgcn_rsqf(minv) : 0.0f;
+        mom_kin = (double)(0.5f * bl_wave_sum(minv * mom_r0 * mom_r0));
+    };
+    // The rest of a transition's end (everything the next position did not need), see end_kind above.  The tree's proposal
+    // (SV_ZP, SV_GP, ss->Up), its counters (ss->nprop, ss->sumacc), ss->it and the started transition's momentum (mom_r0) are
+    // untouched since the decisions.
+    auto end_deferred = [&]() {
+        if (end_kind == 0) return;
+        const float th = sv[SV_ZP * 64], gr = sv[SV_GP * 64], r0 = mom_r0;
+        const double U = ss->Up;
+        const int nprop = ss->nprop, it = ss->it;
+        sv[SV_TH * 64] = th; sv[SV_GR * 64] = gr;
+        ss->U = U;
+        if (end_kind & 2) {
+            ss->nleap_w += nprop;
+            if (end_kind & 4) { // Welford moments of the draw (a window's last draw was added by the decisions themselves)
+                const int wf_n = ss->wf_n + 1;
+                const float wf_mean0 = sv[SV_WFMEAN * 64];
+                const float dpre = th - wf_mean0;
+                const float wf_mean = wf_mean0 + dpre * bl_rcp((float)wf_n);
+                sv[SV_WFMEAN * 64] = wf_mean;
+                sv[SV_WFM2 * 64] += dpre * (th - wf_mean);
+                ss->wf_n = wf_n;
+            }
+            if (end_kind & 8) ss->win_idx = ss->win_idx + 1;
+        } else if (end_kind & 16) {
+            ss->nleap_s += nprop;
+            if (member == 0) {
+                const size_t s = (size_t)chain * S + (it - W);
+                if (act) cold->draws[s * D + lane] = th;
+                if (lane == 0) {
+                    cold->num_steps[s] = nprop;
+                    cold->accept_prob[s] = ss->sumacc * bl_rcp((float)nprop);
+                    cold->diverging[s] = pend_sdiv ? 1 : 0;
+                    cold->potential[s] = (float)U;
+                }
+            }
+        }
+        if (end_kind & (2 | 16)) ss->it = it + 1;
+        end_kind = 0;
+        // the fresh tree of the transition that has already started
+        sv[SV_ZL * 64] = th; sv[SV_RL * 64] = r0; sv[SV_GL * 64] = gr;
+        sv[SV_ZR * 64] = th; sv[SV_RR * 64] = r0; sv[SV_GRR * 64] = gr;
+        sv[SV_RSUM * 64] = r0;
+        ss->wt = 0.f; ss->sumacc = 0.f; ss->nprop = 0;
+        // and the momentum of the one after it
+        const float z = bl_rng_normal(rng_d);
+        sv[SV_MOMZ * 64] = z;
+        mom_r0 = act ? z * __builtin_amdgcn_rsqf(minv) : 0.0f;
+        mom_kin = (double)(0.5f * bl_wave_sum(minv * mom_r0 * mom_r0));
+    };
 
     // Deferred bookkeeping of the last finished leaf (hmc_util._combine_tree: proposal + weights).
     // Nothing in here can change where the next leaf is evaluated.
@@ -349,10 +415,11 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 BL_SUB0
                 // initial evaluation done
                 const double Un = -ll_tot + (double)(0.5f * bl_wave_sum(pe2)) + prior_const;
-                sv[SV_TH * 64] = cz; sv[SV_GR * 64] = cg;
-                ss->U = Un;
                 init_pending = false;
                 new_transition = true;
+                // (no transition behind it: the deferred part only installs the start state and the first tree)
+                sv[SV_ZP * 64] = cz; sv[SV_GP * 64] = cg; ss->Up = Un;
+                end_kind = 1;
             } else {
                 // ------- CRITICAL: finish the leaf (_build_basetree), decide where the next one goes -------
                 const float cr = bl_leaf_momentum(rh, epsdir, cg);
@@ -389,9 +456,9 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                     // ---------- subtree complete: extend the tree edge, tree-level U-turn ----------
                     BL_STAMP_KIND(1)
                     pend_end = true; pend_sturn = sturn; pend_sdiv = sdiv; pend_snprop = snprop;
-                    const int e_out = going_right ? SV_ZR : SV_ZL;  // edge this subtree extends (z, r, g slots follow)
+                    const int e_ext = going_right ? SV_ZR : SV_ZL;  // edge this subtree extends (z, r, g slots follow)
                     const int e_in = going_right ? SV_ZL : SV_ZR;   // opposite edge
-                    sv[e_out * 64] = cz; sv[(e_out + 1) * 64] = cr; sv[(e_out + 2) * 64] = cg;
+                    sv[e_ext * 64] = cz; sv[(e_ext + 1) * 64] = cr; sv[(e_ext + 2) * 64] = cg;
                     const float r_other = sv[(e_in + 1) * 64];
                     const float rsum = sv[SV_RSUM * 64] + srsum;
                     sv[SV_RSUM * 64] = rsum;
@@ -407,21 +474,19 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                         const float ez = sv[e * 64], er = sv[(e + 1) * 64], eg = sv[(e + 2) * 64];
                         bl_next_leaf(ez, er, eg, epsdir, minv, rh, cz);
                     } else {
-                        // ---------------- transition complete (nothing left to overlap with) ----------------
+                        // ---------------- transition complete ----------------
+                        // Only what the next position needs is done here -- the proposal, and during warmup the new step
+                        // size (and metric, when a window closes); outputs, adaptation state, the fresh tree and the next
+                        // momentum follow beside the evaluation of that position (end_deferred).
                         BL_STAMP_KIND(2)
                         BL_SUB0
                         run_deferred();
                         BL_SUB(0)
-                        const int nprop = ss->nprop;
-                        const float accp = ss->sumacc * bl_rcp((float)nprop);
-                        const float th = sv[SV_ZP * 64];
-                        const double U = ss->Up;
-                        sv[SV_TH * 64] = th; sv[SV_GR * 64] = sv[SV_GP * 64];
-                        ss->U = U;
                         const int it = ss->it;
+                        end_kind = it < W ? (1 | 2) : (1 | 16);
                         if (it < W) {
-                            ss->nleap_w += nprop;
                             // warmup_adapter.update_fn: dual averaging (t0=10, kappa=.75, gamma=.05)
+                            const float accp = ss->sumacc * bl_rcp((float)ss->nprop);
                             const float g = cold->target_accept - accp;
                             const int da_t = ss->da_t + 1;
                             const float tt = (float)da_t;
@@ -433,41 +498,30 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                             eps = bl_exp((it == W - 1) ? da_xavg : da_xt);
                             eps = fminf(fmaxf(eps, 1.1754944e-38f), 3.4028235e+38f);
                             ss->da_t = da_t; ss->da_gavg = da_gavg; ss->da_xt = da_xt; ss->da_xavg = da_xavg;
-                            int win_idx = ss->win_idx;
+                            const int win_idx = ss->win_idx;
                             const bool middle = win_idx > 0 && win_idx < cold->nwin - 1;
-                            if (middle) {
+                            const bool at_end = it == cold->win_end[win_idx];
+                            if (middle) end_kind |= 4;
+                            if (at_end) end_kind |= 8;
+                            if (at_end && middle) {
+                                // a window closes: the new metric enters the very next leaf, so this draw's moments are
+                                // added here and now (a handful of times per run)
+                                const float th = sv[SV_ZP * 64];
                                 const int wf_n = ss->wf_n + 1;
                                 const float wf_mean0 = sv[SV_WFMEAN * 64];
                                 const float dpre = th - wf_mean0;
                                 const float wf_mean = wf_mean0 + dpre * bl_rcp((float)wf_n);
-                                sv[SV_WFMEAN * 64] = wf_mean;
-                                sv[SV_WFM2 * 64] += dpre * (th - wf_mean);
-                                ss->wf_n = wf_n;
-                            }
-                            const bool at_end = it == cold->win_end[win_idx];
-                            if (at_end) ss->win_idx = win_idx + 1;
-                            if (at_end && middle) {
-                                const float n = (float)ss->wf_n;
-                                const float var = sv[SV_WFM2 * 64] * bl_rcp(n - 1.0f), rn5 = bl_rcp(n + 5.0f);
+                                const float wf_m2 = sv[SV_WFM2 * 64] + dpre * (th - wf_mean);
+                                const float n = (float)wf_n;
+                                const float var = wf_m2 * bl_rcp(n - 1.0f), rn5 = bl_rcp(n + 5.0f);
                                 minv = act ? (n * rn5 * var + 1e-3f * 5.0f * rn5) : 0.0f;
                                 sv[SV_WFMEAN * 64] = 0.f; sv[SV_WFM2 * 64] = 0.f; ss->wf_n = 0;
+                                end_kind &= ~4; // (done)
                                 ss->da_xt = 0.f; ss->da_xavg = 0.f; ss->da_gavg = 0.f; ss->da_t = 0;
                                 ss->da_prox = bl_log(10.0f * eps);
-                            }
-                        } else {
-                            ss->nleap_s += nprop;
-                            if (member == 0) {
-                                const size_t s = (size_t)chain * S + (it - W);
-                                if (act) cold->draws[s * D + lane] = th;
-                                if (lane == 0) {
-                                    cold->num_steps[s] = nprop;
-                                    cold->accept_prob[s] = accp;
-                                    cold->diverging[s] = pend_sdiv ? 1 : 0;
-                                    cold->potential[s] = (float)U;
-                                }
+                                mom_refresh();
                             }
                         }
-                        ss->it = it + 1;
                         if (it + 1 >= total) flag = 1; // done
                         else new_transition = true;
                         BL_SUB(1)
@@ -475,16 +529,10 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 }
             }
             if (new_transition) {
-                // sample momentum r = N(0,1)/sqrt(M^-1); start a fresh tree and its first doubling
-                const float th = sv[SV_TH * 64], gr = sv[SV_GR * 64];
-                const double U = ss->U;
-                const float z01 = bl_rng_normal(rng_d);
-                const float r0 = act ? z01 * __builtin_amdgcn_rsqf(minv) : 0.0f;
-                E0 = U + (double)(0.5f * bl_wave_sum(minv * r0 * r0));
-                sv[SV_ZL * 64] = th; sv[SV_RL * 64] = r0; sv[SV_GL * 64] = gr;
-                sv[SV_ZR * 64] = th; sv[SV_RR * 64] = r0; sv[SV_GRR * 64] = gr;
-                sv[SV_ZP * 64] = th; sv[SV_GP * 64] = gr; sv[SV_RSUM * 64] = r0;
-                ss->Up = U; ss->wt = 0.f; ss->sumacc = 0.f; ss->nprop = 0;
+                // a fresh tree from the proposal (SV_ZP, SV_GP, ss->Up) with the momentum drawn ahead; its first doubling, first leaf
+                const float th = sv[SV_ZP * 64], gr = sv[SV_GP * 64];
+                const float r0 = mom_r0;
+                E0 = ss->Up + mom_kin;
                 depth = 0;
                 going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
                 epsdir = going_right ? eps : -eps;
@@ -493,6 +541,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 BL_SUB(2)
             }
         }
+        if (flag != 0) end_deferred();
         if (flag != 0 && member == 0) {
             if (flag > 1 && lane == 0) atomicMax(cold->status, flag);
             if (act) cold->inv_mass[chain * D + lane] = minv;
@@ -526,6 +575,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     while (true) {
         bool redo = false; // the evaluation in flight is not the one the sampler needs next
         if (SPEC && have_pending) {
+            end_deferred(); // (only if the guess at a transition's end happened to be right: otherwise done in the branch below)
             decide();
             // was the position being evaluated right now the one just chosen?  (bit-equal or redo: correctness
             // never depends on the guess)
@@ -534,7 +584,11 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             BL_STAMP_CRIT
             BL_STAMP(0)
         } else if (!SPEC) {
+            end_deferred();
             run_deferred(); // non-speculative form: only the bookkeeping overlaps the evaluation
+            BL_STAMP(0)
+        } else {
+            end_deferred(); // beside the evaluation of the new transition's first leaf
             BL_STAMP(0)
         }
         __syncthreads();
