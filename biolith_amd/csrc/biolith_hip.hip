@@ -595,9 +595,6 @@ extern "C" int bl_dataset_create_rn(const bl_dims *dims, const float *site_covs,
 {
     if (max_abundance < 1 || max_abundance >= BL_RN_NB)
         return bl_fail(BL_ERR_UNSUPPORTED, "max_abundance=%d outside 1..%d", max_abundance, BL_RN_NB - 1);
-    if (dims && (dims->n_site_covs > 4 || dims->n_obs_covs > 4))
-        return bl_fail(BL_ERR_UNSUPPORTED, "occu_rn kernels are built for at most 4 covariates per side (Ks=%d, Ko=%d)",
-                       dims->n_site_covs, dims->n_obs_covs);
     ModelOpts mo; mo.model = 1; mo.max_abundance = max_abundance;
     return dataset_create_impl(mo, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
 }
@@ -608,9 +605,6 @@ extern "C" int bl_dataset_create_fp(const bl_dims *dims, const float *site_covs,
 {
     if (fp_mode != BL_FP_CONSTANT && fp_mode != BL_FP_UNOCCUPIED)
         return bl_fail(BL_ERR_INVALID, "fp_mode must be BL_FP_CONSTANT or BL_FP_UNOCCUPIED");
-    if (dims && (dims->n_site_covs > 4 || dims->n_obs_covs > 4))
-        return bl_fail(BL_ERR_UNSUPPORTED, "false-positive kernels are built for at most 4 covariates per side (Ks=%d, Ko=%d)",
-                       dims->n_site_covs, dims->n_obs_covs);
     ModelOpts mo; mo.model = 2; mo.fp_mode = fp_mode;
     if (prior_fp) { mo.fp_a = prior_fp->a; mo.fp_b = prior_fp->b; }
     if (!(mo.fp_a > 0.0) || !(mo.fp_b > 0.0) || !std::isfinite(mo.fp_a) || !std::isfinite(mo.fp_b))
@@ -624,9 +618,6 @@ extern "C" int bl_dataset_create_nmix(const bl_dims *dims, const float *site_cov
 {
     if (max_abundance < 1 || max_abundance >= BL_RN_NB)
         return bl_fail(BL_ERR_UNSUPPORTED, "max_abundance=%d outside 1..%d", max_abundance, BL_RN_NB - 1);
-    if (dims && (dims->n_site_covs > 4 || dims->n_obs_covs > 4))
-        return bl_fail(BL_ERR_UNSUPPORTED, "nmixture kernels are built for at most 4 covariates per side (Ks=%d, Ko=%d)",
-                       dims->n_site_covs, dims->n_obs_covs);
     ModelOpts mo; mo.model = 4; mo.max_abundance = max_abundance;
     return dataset_create_impl(mo, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
 }
@@ -639,9 +630,6 @@ extern "C" int bl_dataset_create_cop(const bl_dims *dims, const float *site_covs
     if (fp_mode != 0 && fp_mode != BL_FP_CONSTANT && fp_mode != BL_FP_UNOCCUPIED)
         return bl_fail(BL_ERR_INVALID, "fp_mode must be 0, BL_FP_CONSTANT or BL_FP_UNOCCUPIED");
     if (!session_duration) return bl_fail(BL_ERR_INVALID, "session_duration is NULL");
-    if (dims && (dims->n_site_covs > 4 || dims->n_obs_covs > 4))
-        return bl_fail(BL_ERR_UNSUPPORTED, "occu_cop kernels are built for at most 4 covariates per side (Ks=%d, Ko=%d)",
-                       dims->n_site_covs, dims->n_obs_covs);
     ModelOpts mo; mo.model = 3; mo.fp_mode = fp_mode; mo.session_duration = session_duration;
     mo.fp_a = fp_mode ? prior_fp_rate : 1.0;
     if (!(mo.fp_a > 0.0) || !std::isfinite(mo.fp_a)) return bl_fail(BL_ERR_INVALID, "Exponential prior needs a finite rate > 0");
@@ -1086,8 +1074,14 @@ static int re_logp_grad(bl_dataset *ds, int B, const double *theta, double *U, d
     BL_HIP(hipMemcpy(d_th, th32.data(), th32.size() * 4, hipMemcpyHostToDevice));
     BlReModel m = ds->re;
     const size_t lds = re_geometry(m, m.n_sites, 0, 0);
-    if (lds) BL_HIP(hipFuncSetAttribute((const void *)bl_re_logp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(bl_re_logp_kernel, dim3(B), dim3(BL_RE_NT), lds, nullptr, m, B, d_th, d_work, d_U, d_grad);
+    // capacity 4 (the common case: short register arrays) or 16 covariates per side
+    if (m.Ks <= 4 && m.Ko <= 4) {
+        if (lds) BL_HIP(hipFuncSetAttribute((const void *)bl_re_logp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bl_re_logp_kernel<4>, dim3(B), dim3(BL_RE_NT), lds, nullptr, m, B, d_th, d_work, d_U, d_grad);
+    } else {
+        if (lds) BL_HIP(hipFuncSetAttribute((const void *)bl_re_logp_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(bl_re_logp_kernel<16>, dim3(B), dim3(BL_RE_NT), lds, nullptr, m, B, d_th, d_work, d_U, d_grad);
+    }
     BL_HIP(hipGetLastError());
     BL_HIP(hipMemcpy(U, d_U, (size_t)B * 8, hipMemcpyDeviceToHost));
     BL_HIP(hipMemcpy(grad, d_grad, (size_t)B * D * 8, hipMemcpyDeviceToHost));
@@ -1183,7 +1177,7 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     const size_t o_draws = RL.draws, o_div = RL.div, o_steps = RL.steps, o_acc = RL.acc, o_pot = RL.pot, o_eps = RL.eps,
                  o_minv = RL.minv, o_nleap = RL.nleap, o_status = carve(16),
                  o_rng = carve((size_t)C * k * (dl_max + 2) * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(32 * 8),
-                 o_xchg = carve((size_t)C * 2 * k * BL_RE_NRED * 8), o_loc = carve((size_t)C * 4), o_run = carve(sizeof(BlReRun));
+                 o_xchg = carve((size_t)C * 2 * k * BL_RE_NRED_MAX * 8), o_loc = carve((size_t)C * 4), o_run = carve(sizeof(BlReRun));
     if (off > ds->run_bytes) {
         if (ds->d_run) hipFree(ds->d_run);
         ds->d_run = nullptr; ds->run_bytes = 0;
@@ -1239,7 +1233,8 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     BlReRun run{};
     run.m = g;
     const size_t lds = re_geometry(run.m, nloc, 1, dl_max);
-    if (lds) BL_HIP(hipFuncSetAttribute((const void *)bl_re_nuts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const bool cap4 = g.Ks <= 4 && g.Ko <= 4;
+    if (lds) BL_HIP(hipFuncSetAttribute(cap4 ? (const void *)bl_re_nuts_kernel<4> : (const void *)bl_re_nuts_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     run.num_chains = C; run.num_warmup = W; run.num_samples = S; run.max_depth = max_depth;
     run.k = k; run.nloc = nloc; run.dl_max = dl_max;
     run.xchg = (unsigned long long *)(base + o_xchg);
@@ -1263,10 +1258,11 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     BL_HIP(hipEventRecord(ds->ev0, st));
     BL_HIP(hipMemsetAsync(ds->d_status, 0, 16, st));
     BL_HIP(hipMemsetAsync(ds->d_dbg, 0, 256, st));
-    BL_HIP(hipMemsetAsync(run.xchg, 0, (size_t)C * 2 * k * BL_RE_NRED * 8, st));
+    BL_HIP(hipMemsetAsync(run.xchg, 0, (size_t)C * 2 * k * BL_RE_NRED_MAX * 8, st));
     BL_HIP(hipMemsetAsync(ds->d_loc, 0, (size_t)C * 4, st));
     // XCD-aware mapping in the kernel (surplus blocks exit at once)
-    hipLaunchKernelGGL(bl_re_nuts_kernel, dim3(8 * k * ((C + 7) / 8)), dim3(BL_RE_NT), lds, st, d_runp);
+    if (cap4) hipLaunchKernelGGL(bl_re_nuts_kernel<4>, dim3(8 * k * ((C + 7) / 8)), dim3(BL_RE_NT), lds, st, d_runp);
+    else hipLaunchKernelGGL(bl_re_nuts_kernel<16>, dim3(8 * k * ((C + 7) / 8)), dim3(BL_RE_NT), lds, st, d_runp);
     BL_HIP(hipGetLastError());
     BL_HIP(hipEventRecord(ds->ev1, st));
     ds->stream = st; ds->in_flight = true; ds->have_run = true;

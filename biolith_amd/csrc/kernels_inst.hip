@@ -10,7 +10,7 @@
 #endif
 #define BL_CAT3(a, b, c) a##_##b##_##c
 #define BL_NAME(base, ks, ko) BL_CAT3(base, ks, ko)
-#if BL_KS <= 4 && BL_KO <= 4
+#if 1 // every model at every capacity pair (the count models and occu_rn were once limited to <= 4 covariates per side)
 #define BL_HAVE_RN 1
 #else
 #define BL_HAVE_RN 0

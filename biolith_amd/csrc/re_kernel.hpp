@@ -19,8 +19,14 @@
 
 #define BL_RE_NT 512             // threads per workgroup (measured: 256 / 512 / 1024 -> 512 with 16-32 workgroups per chain)
 #define BL_RE_NW (BL_RE_NT / 64)
-#define BL_RE_MAXK 4             // covariates per side (as the false-positive model)
-#define BL_RE_NRED 26            // widest block reduction
+#define BL_RE_MAXK 16            // covariates per side: the kernels are instantiated for capacities 4 and 16 (template parameter MK)
+// Layout of the first block reduction for capacity MK: [0] log-lik, [1 .. MK+1] d/d beta, [MK+2 .. 2MK+2] d/d alpha, then from
+// OX = 2MK+3: sum u^2+v^2 (occu_cs: d/d mu0), sum e^2 (d/d mu1), prior quadratic, abort request, XCC census (2), occu_cs d/d log sigma (2)
+#define BL_RE_OA(MK) ((MK) + 2)
+#define BL_RE_OX(MK) (2 * (MK) + 3)
+#define BL_RE_NV1(MK) (2 * (MK) + 11)
+#define BL_RE_NRED_OF(MK) (BL_RE_NV1(MK) > 26 ? BL_RE_NV1(MK) : 26) // widest block reduction (the second one: 3 + 2 x 10 checkpoints)
+#define BL_RE_NRED_MAX BL_RE_NRED_OF(BL_RE_MAXK)
 #define BL_RE_VB 4               // visits whose loads are issued together in the site pass
 
 struct BlReModel {
@@ -82,7 +88,7 @@ struct BlReRun {
     int k, nloc, dl_max;        // workgroups per chain, sites per workgroup, coordinates of the largest slice
     int allow_local;            // 0: always the placement-independent exchange
     int *xcd_local;             // [C] 1 if the chain ran on the L2-local exchange
-    unsigned long long *xchg;   // [C][2][k][BL_RE_NRED] exchange granules (k > 1)
+    unsigned long long *xchg;   // [C][2][k][NRED of the kernel's capacity] exchange granules (k > 1)
     float *state;               // [C][k][RE_SLOTS][dl_max]
     uint32_t *rng;              // [C][k][dl_max + 2][4]: a workgroup's streams in ITS coordinate order, then scalar, direction
     const float *init_theta;    // [C][D] external order, or NULL
@@ -138,22 +144,23 @@ __device__ __forceinline__ void bl_re_wave_sums(const float (&v)[NV], float *dst
             if (k < n_used) dst[k] = t[k];
     }
 }
-template <int NV>
+template <int NV, int NRED>
 __device__ __forceinline__ void bl_re_block_sum(float (&v)[NV], float *scr /*[NW][NRED]*/, double *out /*[NRED]*/, int n_used = NV,
                                                 bool last_barrier = true)
 {
     const int tid = threadIdx.x, wave = tid >> 6;
-    float *dst = scr + wave * BL_RE_NRED;
+    float *dst = scr + wave * NRED;
     // (workgroup-uniform choice of the chain count: most leaves close few checkpoints)
     if (NV <= 5 || n_used <= 5) bl_re_wave_sums<(NV < 5 ? (NV < 3 ? 3 : NV) : 5)>(v, dst, n_used);
     else if (NV <= 9 || n_used <= 9) bl_re_wave_sums<(NV < 9 ? NV : 9)>(v, dst, n_used);
     else if (NV <= 17 || n_used <= 17) bl_re_wave_sums<(NV < 17 ? NV : 17)>(v, dst, n_used);
+    else if (NV <= 26 || n_used <= 26) bl_re_wave_sums<(NV < 26 ? NV : 26)>(v, dst, n_used);
     else bl_re_wave_sums<NV>(v, dst, n_used);
     __syncthreads();
     if (tid < n_used) {
         double s = 0.0;
 #pragma unroll
-        for (int w = 0; w < BL_RE_NW; w++) s += (double)scr[w * BL_RE_NRED + tid];
+        for (int w = 0; w < BL_RE_NW; w++) s += (double)scr[w * NRED + tid];
         out[tid] = s;
     }
     if (last_barrier) __syncthreads(); // (an exchange that follows only touches out[tid] from the thread that wrote it)
@@ -163,40 +170,41 @@ __device__ __forceinline__ void bl_re_block_sum(float (&v)[NV], float *scr /*[NW
 // k x nv of them and forms the totals in fixed order (f64) -- every workgroup gets bit-identical totals in out[].  Two
 // parities of slots: a workgroup can be at most one exchange ahead of the slowest.  Returns false on the spin bound.
 struct BlReXchg {
-    unsigned long long *buf; // [C][2][k][BL_RE_NRED]
+    unsigned long long *buf; // [C][2][k][NRED]
     int k, wg, chain;
     unsigned epoch, spin_limit;
     bool local;              // all k workgroups proven to sit on one XCD: stores may stay in that XCD's L2 (nuts_kernel.hpp)
 };
+template <int NRED>
 __device__ __forceinline__ bool bl_re_exchange(BlReXchg &x, double *out, float *scr2 /*[k][NRED]*/, int *lds_flag, int nv)
 {
     if (x.k == 1) return true;
     const int tid = threadIdx.x;
     x.epoch++;
-    unsigned long long *base = x.buf + (((size_t)x.chain * 2 + (x.epoch & 1u)) * x.k) * BL_RE_NRED;
+    unsigned long long *base = x.buf + (((size_t)x.chain * 2 + (x.epoch & 1u)) * x.k) * NRED;
     if (tid < nv) {
         const unsigned long long gr = ((unsigned long long)x.epoch << 32) | (unsigned long long)__float_as_uint((float)out[tid]);
         if (x.local) // the line stays in this XCD's L2, where every consumer of this chain polls it
-            __hip_atomic_store(base + (size_t)x.wg * BL_RE_NRED + tid, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(base + (size_t)x.wg * NRED + tid, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else         // write-through: visible to any XCD
-            __hip_atomic_store(base + (size_t)x.wg * BL_RE_NRED + tid, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(base + (size_t)x.wg * NRED + tid, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int t = tid; t < x.k * nv; t += BL_RE_NT) {
         const int w = t / nv, v = t - w * nv;
         unsigned spins = 0;
         unsigned long long gr;
         while (true) {
-            gr = __hip_atomic_load(base + (size_t)w * BL_RE_NRED + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gr = __hip_atomic_load(base + (size_t)w * NRED + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned)(gr >> 32) == x.epoch) break;
             if (++spins > x.spin_limit) { *lds_flag = 1; break; }
             if (!x.local) __builtin_amdgcn_s_sleep(1);
         }
-        scr2[w * BL_RE_NRED + v] = __uint_as_float((unsigned)gr);
+        scr2[w * NRED + v] = __uint_as_float((unsigned)gr);
     }
     __syncthreads();
     if (tid < nv) {
         double t = 0.0;
-        for (int w = 0; w < x.k; w++) t += (double)scr2[w * BL_RE_NRED + tid];
+        for (int w = 0; w < x.k; w++) t += (double)scr2[w * NRED + tid];
         out[tid] = t;
     }
     __syncthreads();
@@ -207,34 +215,35 @@ __device__ __forceinline__ bool bl_re_exchange(BlReXchg &x, double *out, float *
 // random effects' full potential gradient written to g (the effect's own likelihood term + its Normal(0, sd) prior).
 // part[0] = ll, part[1 .. 5] = d/d beta, part[6 .. 10] = d/d alpha.
 // rows / ns: the dataset's rows in device memory (stride n_stride), or the workgroup's LDS copy of them (stride n_sites).
+template <int MK>
 __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float *__restrict__ rows, int ns, const float *__restrict__ z,
-                                                float *__restrict__ g, float (&part)[11])
+                                                float *__restrict__ g, float (&part)[2 * MK + 3])
 {
     // threads of a site sit S = 64 / tps lanes apart in one wave: for a given visit the S neighbouring lanes read S
     // neighbouring sites (one segment of a row), and the visits are pooled by xor-shuffles over the upper lane bits
     const int tid = threadIdx.x, tps = m.tps, S = 64 / tps, lane = tid & 63;
     const int grp = (tid >> 6) * S + (lane & (S - 1)), sub = lane / S, ngrp = BL_RE_NT / tps;
     const int N = m.n_sites, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 1;
-    float beta[BL_RE_MAXK + 1], alpha[BL_RE_MAXK + 1];
+    float beta[MK + 1], alpha[MK + 1];
 #pragma unroll
-    for (int k = 0; k <= BL_RE_MAXK; k++) {
+    for (int k = 0; k <= MK; k++) {
         beta[k] = k <= Ks ? z[k] : 0.0f;
         alpha[k] = k <= Ko ? z[Ks + 1 + k] : 0.0f;
     }
     const float isd2_s = m.site_re ? bl_exp(-2.0f * z[m.o_phi_s]) : 0.0f;
     const float isd2_o = m.obs_re ? bl_exp(-2.0f * z[m.o_phi_o]) : 0.0f;
 #pragma unroll
-    for (int k = 0; k < 11; k++) part[k] = 0.0f;
+    for (int k = 0; k < 2 * MK + 3; k++) part[k] = 0.0f;
     const int row_ka = m.KS + T * J * vw, row_kb = row_ka + T;
     const int rounds = (N + ngrp - 1) / ngrp;
     for (int rd = 0; rd < rounds; rd++) {
         const int i_raw = rd * ngrp + grp;
         const bool live = i_raw < N;
         const int i = live ? i_raw : N - 1; // idle groups shadow the last site (their results are dropped)
-        float x[BL_RE_MAXK];
+        float x[MK];
         float eta = beta[0];
 #pragma unroll
-        for (int k = 0; k < BL_RE_MAXK; k++) {
+        for (int k = 0; k < MK; k++) {
             x[k] = k < Ks ? rows[(size_t)k * ns + i] : 0.0f;
             eta = fmaf(x[k], beta[k + 1], eta);
         }
@@ -245,19 +254,19 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
         const float psi = (eta > 0.0f ? 1.0f : ee) * bl_rcp(1.0f + ee);
         float dl_deta = 0.0f, dl_dv = 0.0f;
         for (int t = 0; t < T; t++) {
-            float a = 0.0f, ga[BL_RE_MAXK + 1];
+            float a = 0.0f, ga[MK + 1];
 #pragma unroll
-            for (int k = 0; k <= BL_RE_MAXK; k++) ga[k] = 0.0f;
+            for (int k = 0; k <= MK; k++) ga[k] = 0.0f;
             // visits in batches of BL_RE_VB: all loads of a batch are issued before the first is used (a lone workgroup per
             // CU has little else to hide memory latency behind); a visit past J re-reads the last one and is dropped
             for (int jb = sub; jb < J; jb += tps * BL_RE_VB) {
-                float w[BL_RE_VB][BL_RE_MAXK + 1], eo[BL_RE_VB];
+                float w[BL_RE_VB][MK + 1], eo[BL_RE_VB];
 #pragma unroll
                 for (int b = 0; b < BL_RE_VB; b++) {
                     const int jj = min(jb + b * tps, J - 1), v = t * J + jj;
                     const size_t r0 = (size_t)(m.KS + v * vw) * ns + i;
 #pragma unroll
-                    for (int k = 0; k <= BL_RE_MAXK; k++) w[b][k] = k <= Ko ? rows[r0 + (size_t)k * ns] : 0.0f;
+                    for (int k = 0; k <= MK; k++) w[b][k] = k <= Ko ? rows[r0 + (size_t)k * ns] : 0.0f;
                     eo[b] = m.obs_re ? z[m.o_e + v * N + i] : 0.0f;
                 }
 #pragma unroll
@@ -265,19 +274,19 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
                     const float ok = jb + b * tps < J ? 1.0f : 0.0f;
                     float u = w[b][0] * alpha[0];
 #pragma unroll
-                    for (int k = 1; k <= BL_RE_MAXK; k++) u = fmaf(w[b][k], alpha[k], u);
+                    for (int k = 1; k <= MK; k++) u = fmaf(w[b][k], alpha[k], u);
                     u = fmaf(w[b][0], vi + eo[b], u);
                     const float e = bl_exp(-fabsf(u)), op = 1.0f + e;
                     a = fmaf(ok, fminf(u, 0.0f) - bl_log(op), a);
                     const float s = ok * (u > 0.0f ? e : 1.0f) * bl_rcp(op); // sigma(-u): d log sigma(u) / du
 #pragma unroll
-                    for (int k = 0; k <= BL_RE_MAXK; k++) ga[k] = fmaf(s, w[b][k], ga[k]);
+                    for (int k = 0; k <= MK; k++) ga[k] = fmaf(s, w[b][k], ga[k]);
                 }
             }
             for (int msk = S; msk < 64; msk <<= 1) { // the site's threads pool their visits
                 a += __shfl_xor(a, msk);
 #pragma unroll
-                for (int k = 0; k <= BL_RE_MAXK; k++) ga[k] += __shfl_xor(ga[k], msk);
+                for (int k = 0; k <= MK; k++) ga[k] += __shfl_xor(ga[k], msk);
             }
             const float ka = rows[(size_t)(row_ka + t) * ns + i], kb = rows[(size_t)(row_kb + t) * ns + i];
             const float A = log_psi + a + ka, B = log_1mpsi + kb;
@@ -286,20 +295,20 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
             if (live && sub == 0) {
                 part[0] += l;
 #pragma unroll
-                for (int k = 0; k <= BL_RE_MAXK; k++) part[6 + k] = fmaf(q, ga[k], part[6 + k]);
+                for (int k = 0; k <= MK; k++) part[MK + 2 + k] = fmaf(q, ga[k], part[MK + 2 + k]);
             }
             dl_deta += q - psi;
             dl_dv = fmaf(q, ga[0], dl_dv);
             if (m.obs_re && live) {
                 // each replicate's own effect: d U / d e = -q d a / d nu + e / sd^2 (d a / d nu recomputed: nothing was kept per visit)
                 for (int jb = sub; jb < J; jb += tps * BL_RE_VB) {
-                    float w[BL_RE_VB][BL_RE_MAXK + 1], eo[BL_RE_VB];
+                    float w[BL_RE_VB][MK + 1], eo[BL_RE_VB];
 #pragma unroll
                     for (int b = 0; b < BL_RE_VB; b++) {
                         const int jj = min(jb + b * tps, J - 1), v = t * J + jj;
                         const size_t r0 = (size_t)(m.KS + v * vw) * ns + i;
 #pragma unroll
-                        for (int k = 0; k <= BL_RE_MAXK; k++) w[b][k] = k <= Ko ? rows[r0 + (size_t)k * ns] : 0.0f;
+                        for (int k = 0; k <= MK; k++) w[b][k] = k <= Ko ? rows[r0 + (size_t)k * ns] : 0.0f;
                         eo[b] = z[m.o_e + v * N + i];
                     }
 #pragma unroll
@@ -307,7 +316,7 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
                         if (jb + b * tps < J) {
                             float u = w[b][0] * alpha[0];
 #pragma unroll
-                            for (int k = 1; k <= BL_RE_MAXK; k++) u = fmaf(w[b][k], alpha[k], u);
+                            for (int k = 1; k <= MK; k++) u = fmaf(w[b][k], alpha[k], u);
                             u = fmaf(w[b][0], vi + eo[b], u);
                             const float e = bl_exp(-fabsf(u));
                             const float s = (u > 0.0f ? e : 1.0f) * bl_rcp(1.0f + e);
@@ -320,7 +329,7 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
         if (live && sub == 0) {
             part[1] += dl_deta;
 #pragma unroll
-            for (int k = 0; k < BL_RE_MAXK; k++) part[2 + k] = fmaf(dl_deta, x[k], part[2 + k]);
+            for (int k = 0; k < MK; k++) part[2 + k] = fmaf(dl_deta, x[k], part[2 + k]);
             if (m.site_re) {
                 g[m.o_u + i] = fmaf(ui, isd2_s, -dl_deta);
                 g[m.o_v + i] = fmaf(vi, isd2_s, -dl_dv);
@@ -332,15 +341,16 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
 // ---- occu_cs (biolith/models/occu_cs.py:120-232): s ~ Normal(mu_f, sigma_f), f ~ Bernoulli(z p), z ~ Bernoulli(psi); z and every
 // f summed out (the f of different replicates are independent given z).  Coordinates: [beta, alpha, mu0, x1 = log(mu1 - mu0),
 // log sigma0, log sigma1].  Site pass: part[0] = ll, [1..5] d/d beta, [6..10] d/d alpha, [11..14] d/d (mu0, mu1, log sigma0, log sigma1).
+template <int MK>
 __device__ __forceinline__ void bl_cs_site_pass(const BlReModel &m, const float *__restrict__ rows, int ns, const float *__restrict__ z,
-                                                float (&part)[15])
+                                                float (&part)[2 * MK + 7])
 {
     const int tid = threadIdx.x, tps = m.tps, S = 64 / tps, lane = tid & 63;
     const int grp = (tid >> 6) * S + (lane & (S - 1)), sub = lane / S, ngrp = BL_RE_NT / tps;
     const int N = m.n_sites, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 1;
-    float beta[BL_RE_MAXK + 1], alpha[BL_RE_MAXK + 1];
+    float beta[MK + 1], alpha[MK + 1];
 #pragma unroll
-    for (int k = 0; k <= BL_RE_MAXK; k++) {
+    for (int k = 0; k <= MK; k++) {
         beta[k] = k <= Ks ? z[k] : 0.0f;
         alpha[k] = k <= Ko ? z[Ks + 1 + k] : 0.0f;
     }
@@ -349,16 +359,16 @@ __device__ __forceinline__ void bl_cs_site_pass(const BlReModel &m, const float 
     const float TINY = 1.1754944e-38f, PMAX = 1.0f - 1.1920929e-07f, HL2PI = 0.9189385f;
     const float l_f1_z0 = -87.33654475f, l_f0_z0 = -1.1754944e-38f; // log(tiny), log1p(-tiny): numpyro clamps P(f = 1 | z = 0) = 0 to tiny
 #pragma unroll
-    for (int k = 0; k < 15; k++) part[k] = 0.0f;
+    for (int k = 0; k < 2 * MK + 7; k++) part[k] = 0.0f;
     const int rounds = (N + ngrp - 1) / ngrp;
     for (int rd = 0; rd < rounds; rd++) {
         const int i_raw = rd * ngrp + grp;
         const bool live = i_raw < N;
         const int i = live ? i_raw : N - 1;
-        float x[BL_RE_MAXK];
+        float x[MK];
         float eta = beta[0];
 #pragma unroll
-        for (int k = 0; k < BL_RE_MAXK; k++) {
+        for (int k = 0; k < MK; k++) {
             x[k] = k < Ks ? rows[(size_t)k * ns + i] : 0.0f;
             eta = fmaf(x[k], beta[k + 1], eta);
         }
@@ -368,20 +378,21 @@ __device__ __forceinline__ void bl_cs_site_pass(const BlReModel &m, const float 
         float dl_deta = 0.0f;
         for (int t = 0; t < T; t++) {
             // r[0] = a1, r[1] = a0, r[2..6] = d a1 / d alpha, r[7..10] = d a1 / d (mu0, mu1, ls0, ls1), r[11..14] = the same of a0
-            float r[15];
+            constexpr int RB = MK + 3; // r[RB .. RB+3] = d a1 / d (mu0, mu1, ls0, ls1), r[RB+4 .. RB+7] = the same of a0
+            float r[MK + 11];
 #pragma unroll
-            for (int k = 0; k < 15; k++) r[k] = 0.0f;
+            for (int k = 0; k < MK + 11; k++) r[k] = 0.0f;
             for (int j = sub; j < J; j += tps) {
                 const int v = t * J + j;
                 const size_t r0 = (size_t)(m.KS + v * vw) * ns + i;
-                float w[BL_RE_MAXK + 1];
+                float w[MK + 1];
 #pragma unroll
-                for (int k = 0; k <= BL_RE_MAXK; k++) w[k] = k <= Ko ? rows[r0 + (size_t)k * ns] : 0.0f;
+                for (int k = 0; k <= MK; k++) w[k] = k <= Ko ? rows[r0 + (size_t)k * ns] : 0.0f;
                 const float c = w[0]; // 1: the replicate has a score, 0: masked
                 const float sc = m.scores[(size_t)v * m.n_stride + i];
                 float nu = c * alpha[0];
 #pragma unroll
-                for (int k = 1; k <= BL_RE_MAXK; k++) nu = fmaf(w[k], alpha[k], nu);
+                for (int k = 1; k <= MK; k++) nu = fmaf(w[k], alpha[k], nu);
                 const float e0 = (sc - mu0) * is0, e1 = (sc - mu1) * is1;
                 const float lphi0 = fmaf(-0.5f * e0, e0, -ls0 - HL2PI), lphi1 = fmaf(-0.5f * e1, e1, -ls1 - HL2PI);
                 const float en = bl_exp(-fabsf(nu)), ron = bl_rcp(1.0f + en);
@@ -397,15 +408,15 @@ __device__ __forceinline__ void bl_cs_site_pass(const BlReModel &m, const float 
                 const float L0 = bl_logaddexp(u0, u1), v1 = bl_exp(u1 - L0), v0 = bl_exp(u0 - L0);
                 r[0] = fmaf(c, L1, r[0]); r[1] = fmaf(c, L0, r[1]);
 #pragma unroll
-                for (int k = 0; k <= BL_RE_MAXK; k++) r[2 + k] = fmaf(dnu, w[k], r[2 + k]); // (w carries the mask)
-                r[7] = fmaf(c * w0, e0 * is0, r[7]); r[8] = fmaf(c * w1, e1 * is1, r[8]);
-                r[9] = fmaf(c * w0, fmaf(e0, e0, -1.0f), r[9]); r[10] = fmaf(c * w1, fmaf(e1, e1, -1.0f), r[10]);
-                r[11] = fmaf(c * v0, e0 * is0, r[11]); r[12] = fmaf(c * v1, e1 * is1, r[12]);
-                r[13] = fmaf(c * v0, fmaf(e0, e0, -1.0f), r[13]); r[14] = fmaf(c * v1, fmaf(e1, e1, -1.0f), r[14]);
+                for (int k = 0; k <= MK; k++) r[2 + k] = fmaf(dnu, w[k], r[2 + k]); // (w carries the mask)
+                r[RB] = fmaf(c * w0, e0 * is0, r[RB]); r[RB + 1] = fmaf(c * w1, e1 * is1, r[RB + 1]);
+                r[RB + 2] = fmaf(c * w0, fmaf(e0, e0, -1.0f), r[RB + 2]); r[RB + 3] = fmaf(c * w1, fmaf(e1, e1, -1.0f), r[RB + 3]);
+                r[RB + 4] = fmaf(c * v0, e0 * is0, r[RB + 4]); r[RB + 5] = fmaf(c * v1, e1 * is1, r[RB + 5]);
+                r[RB + 6] = fmaf(c * v0, fmaf(e0, e0, -1.0f), r[RB + 6]); r[RB + 7] = fmaf(c * v1, fmaf(e1, e1, -1.0f), r[RB + 7]);
             }
             for (int msk = S; msk < 64; msk <<= 1) {
 #pragma unroll
-                for (int k = 0; k < 15; k++) r[k] += __shfl_xor(r[k], msk);
+                for (int k = 0; k < MK + 11; k++) r[k] += __shfl_xor(r[k], msk);
             }
             const float A = log_psi + r[0], B = log_1mpsi + r[1];
             const float l = bl_logaddexp(A, B);
@@ -413,36 +424,38 @@ __device__ __forceinline__ void bl_cs_site_pass(const BlReModel &m, const float 
             if (live && sub == 0) {
                 part[0] += l;
 #pragma unroll
-                for (int k = 0; k <= BL_RE_MAXK; k++) part[6 + k] = fmaf(q, r[2 + k], part[6 + k]);
+                for (int k = 0; k <= MK; k++) part[MK + 2 + k] = fmaf(q, r[2 + k], part[MK + 2 + k]);
 #pragma unroll
-                for (int k = 0; k < 4; k++) part[11 + k] += fmaf(q, r[7 + k], q0 * r[11 + k]);
+                for (int k = 0; k < 4; k++) part[2 * MK + 3 + k] += fmaf(q, r[RB + k], q0 * r[RB + 4 + k]);
             }
             dl_deta += q - psi;
         }
         if (live && sub == 0) {
             part[1] += dl_deta;
 #pragma unroll
-            for (int k = 0; k < BL_RE_MAXK; k++) part[2 + k] = fmaf(dl_deta, x[k], part[2 + k]);
+            for (int k = 0; k < MK; k++) part[2 + k] = fmaf(dl_deta, x[k], part[2 + k]);
         }
     }
 }
 
 // occu_cs: potential gradient of coordinate G0 + e (e = 0 mu0, 1 x1, 2 log sigma0, 3 log sigma1) from the reduced sums
-// (red[11], red[12], red[17], red[18] = d ll / d (mu0, mu1, log sigma0, log sigma1)) and the priors: mu0 ~ Normal(l0, s0);
+// (red[OX], red[OX+1], red[OX+6], red[OX+7] = d ll / d (mu0, mu1, log sigma0, log sigma1)) and the priors: mu0 ~ Normal(l0, s0);
 // mu1 ~ Normal(l1, s1) truncated below at mu0, in x1 = log(mu1 - mu0); sigma_f ~ Gamma(a, b) in log sigma_f.
+template <int MK>
 __device__ __forceinline__ float bl_cs_extra_grad(const BlReModel &m, int e, const float *z, const double *red)
 {
+    constexpr int OX = BL_RE_OX(MK);
     const float mu0 = z[m.G0], ex1 = bl_exp(z[m.G0 + 1]), mu1 = mu0 + ex1;
     if (e >= 2) {
         const float a = m.cs_sg[2 * (e - 2)], b = m.cs_sg[2 * (e - 2) + 1];
-        return -((float)red[15 + e] + a - b * bl_exp(z[m.G0 + e]));
+        return -((float)red[OX + 4 + e] + a - b * bl_exp(z[m.G0 + e]));
     }
     const float l0 = m.cs_mu[0], s0 = m.cs_mu[1], l1 = m.cs_mu[2], s1 = m.cs_mu[3];
-    const float z1 = (mu1 - l1) / s1, dmu1 = (float)red[12] - z1 / s1;
+    const float z1 = (mu1 - l1) / s1, dmu1 = (float)red[OX + 1] - z1 / s1;
     if (e == 1) return -(dmu1 * ex1 + 1.0f);
     const float z0 = (mu0 - l0) / s0, zl = (mu0 - l1) / s1;
     const float hazard = bl_exp(-0.5f * zl * zl - 0.9189385f) / (0.5f * erfcf(zl * 0.70710678f)) / s1; // d/d mu0 of -log(1 - Phi(zl))
-    return -((float)red[11] - z0 / s0 + dmu1 + hazard);
+    return -((float)red[OX] - z0 / s0 + dmu1 + hazard);
 }
 // occu_cs: the four extra coordinates' share of the potential (their priors, Jacobians, the truncation's normaliser)
 __device__ __forceinline__ double bl_cs_extra_potential(const BlReModel &m, const float *z)
@@ -459,13 +472,15 @@ __device__ __forceinline__ double bl_cs_extra_potential(const BlReModel &m, cons
 }
 
 // Potential gradient of a fixed effect / log sd coordinate d < G at position z, from the reduced sums of the site pass
-// (red[0..10]) and of the effects' squares (red[11] = sum u^2 + v^2, red[12] = sum e^2).
+// (red[0 .. 2MK+2]) and of the effects' squares (red[OX] = sum u^2 + v^2, red[OX+1] = sum e^2).
+template <int MK>
 __device__ __forceinline__ float bl_re_global_grad(const BlReModel &m, int d, float zd, const double *red)
 {
+    constexpr int OA = BL_RE_OA(MK), OX = BL_RE_OX(MK);
     if (d < m.G0) {
         const bool is_b = d <= m.Ks;
         const float loc = is_b ? m.loc_b : m.loc_a, isc2 = is_b ? m.isc2_b : m.isc2_a, l1 = is_b ? m.l1_b : m.l1_a;
-        const double gl = red[is_b ? 1 + d : 6 + (d - m.Ks - 1)];
+        const double gl = red[is_b ? 1 + d : OA + (d - m.Ks - 1)];
         const float dth = zd - loc;
         return (float)(-gl) + fmaf(dth, isc2, dth > 0.0f ? l1 : (dth < 0.0f ? -l1 : 0.0f));
     }
@@ -473,22 +488,22 @@ __device__ __forceinline__ float bl_re_global_grad(const BlReModel &m, int d, fl
     const bool site = m.site_re && d == m.o_phi_s;
     const float isd2 = bl_exp(-2.0f * zd), sd2 = bl_exp(2.0f * zd);
     const float cnt = site ? 2.0f * (float)m.n_total : (float)m.n_total * (float)(m.T * m.J);
-    const float ssq = (float)red[site ? 11 : 12];
+    const float ssq = (float)red[site ? OX : OX + 1];
     // U = sd^2 / (2 s^2) - phi + sum_k (x_k^2 / (2 sd^2) + phi):   dU/dphi = sd^2 / s^2 - 1 - ssq / sd^2 + cnt
     return sd2 * (site ? m.hn_is2_s : m.hn_is2_o) - 1.0f - ssq * isd2 + cnt;
 }
 
 // Potential at z from the reduced sums (f64): red[0] = log-lik, pe2 = sum over fixed effects of ((z - loc) / scale)^2
-__device__ __forceinline__ double bl_re_potential(const BlReModel &m, const float *z, const double *red, double pe2)
+__device__ __forceinline__ double bl_re_potential(const BlReModel &m, const float *z, const double *red, double pe2, int OX)
 {
     double U = -red[0] + 0.5 * pe2 + m.u_const;
     if (m.site_re) {
         const float phi = z[m.o_phi_s];
-        U += 0.5 * (double)(bl_exp(2.0f * phi) * m.hn_is2_s) - (double)phi + 0.5 * red[11] * (double)bl_exp(-2.0f * phi) + 2.0 * m.n_total * (double)phi;
+        U += 0.5 * (double)(bl_exp(2.0f * phi) * m.hn_is2_s) - (double)phi + 0.5 * red[OX] * (double)bl_exp(-2.0f * phi) + 2.0 * m.n_total * (double)phi;
     }
     if (m.obs_re) {
         const float phi = z[m.o_phi_o];
-        U += 0.5 * (double)(bl_exp(2.0f * phi) * m.hn_is2_o) - (double)phi + 0.5 * red[12] * (double)bl_exp(-2.0f * phi)
+        U += 0.5 * (double)(bl_exp(2.0f * phi) * m.hn_is2_o) - (double)phi + 0.5 * red[OX + 1] * (double)bl_exp(-2.0f * phi)
              + (double)m.n_total * (m.T * m.J) * (double)phi;
     }
     return U;
@@ -518,11 +533,13 @@ __device__ __forceinline__ float bl_re_prior_quad(const BlReModel &m, const floa
 }
 
 // ---- parity hook: U and dU/dtheta for B positions (external order in, external order out), one workgroup each ----
+template <int MK>
 __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel m, int B, const float *__restrict__ theta,
                                                               float *__restrict__ work /*[B][2][D]*/, double *__restrict__ U, double *__restrict__ grad)
 {
-    __shared__ float scr[BL_RE_NW * BL_RE_NRED];
-    __shared__ double red[BL_RE_NRED];
+    constexpr int NRED = BL_RE_NRED_OF(MK), OX = BL_RE_OX(MK), NV1 = BL_RE_NV1(MK);
+    __shared__ float scr[BL_RE_NW * NRED];
+    __shared__ double red[NRED];
     const int b = blockIdx.x, tid = threadIdx.x, D = m.D;
     if (b >= B) return;
     float *z = work + (size_t)b * 2 * D, *g = z + D;
@@ -531,36 +548,38 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel m,
     int ns;
     const float *rows = bl_re_rows(m, bl_re_lds, ns);
     __syncthreads();
-    float v[19];
+    float v[NV1];
     if (m.kind == 1) {
-        float part[15];
-        bl_cs_site_pass(m, rows, ns, z, part);
+        float part[2 * MK + 7];
+        bl_cs_site_pass<MK>(m, rows, ns, z, part);
 #pragma unroll
-        for (int k = 0; k < 11; k++) v[k] = part[k];
-        v[11] = part[11]; v[12] = part[12]; v[17] = part[13]; v[18] = part[14];
+        for (int k = 0; k < OX; k++) v[k] = part[k];
+        v[OX] = part[OX]; v[OX + 1] = part[OX + 1]; v[OX + 6] = part[OX + 2]; v[OX + 7] = part[OX + 3];
     } else {
-        float part[11], ss[2];
-        bl_re_site_pass(m, rows, ns, z, g, part);
+        float part[2 * MK + 3], ss[2];
+        bl_re_site_pass<MK>(m, rows, ns, z, g, part);
         bl_re_effect_squares(m, z, ss);
 #pragma unroll
-        for (int k = 0; k < 11; k++) v[k] = part[k];
-        v[11] = ss[0]; v[12] = ss[1]; v[17] = 0.0f; v[18] = 0.0f;
+        for (int k = 0; k < OX; k++) v[k] = part[k];
+        v[OX] = ss[0]; v[OX + 1] = ss[1]; v[OX + 6] = 0.0f; v[OX + 7] = 0.0f;
     }
-    v[13] = bl_re_prior_quad(m, z);
-    v[14] = 0.0f; v[15] = 0.0f; v[16] = 0.0f;
-    bl_re_block_sum<19>(v, scr, red);
+    v[OX + 2] = bl_re_prior_quad(m, z);
+    v[OX + 3] = 0.0f; v[OX + 4] = 0.0f; v[OX + 5] = 0.0f;
+    bl_re_block_sum<NV1, NRED>(v, scr, red);
     for (int d = tid; d < m.G; d += BL_RE_NT)
-        g[d] = (m.kind == 1 && d >= m.G0) ? bl_cs_extra_grad(m, d - m.G0, z, red) : bl_re_global_grad(m, d, z[d], red);
-    if (tid == 0) U[b] = bl_re_potential(m, z, red, red[13]) + (m.kind == 1 ? bl_cs_extra_potential(m, z) : 0.0);
+        g[d] = (m.kind == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red) : bl_re_global_grad<MK>(m, d, z[d], red);
+    if (tid == 0) U[b] = bl_re_potential(m, z, red, red[OX + 2], OX) + (m.kind == 1 ? bl_cs_extra_potential(m, z) : 0.0);
     for (int d = tid; d < D; d += BL_RE_NT) grad[(size_t)b * D + bl_re_ext(m, d)] = (double)g[d];
 }
 
 // ------------------------------------------------------------------------------------------------ NUTS ----
+template <int MK>
 __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__restrict__ rp)
 {
-    __shared__ float scr[BL_RE_NW * BL_RE_NRED];
-    __shared__ double red[BL_RE_NRED], red2[BL_RE_NRED];
-    __shared__ float scr2[32 * BL_RE_NRED];
+    constexpr int NRED = BL_RE_NRED_OF(MK), OX = BL_RE_OX(MK), NV1 = BL_RE_NV1(MK);
+    __shared__ float scr[BL_RE_NW * NRED];
+    __shared__ double red[NRED], red2[NRED];
+    __shared__ float scr2[32 * NRED];
     __shared__ int xflag;
     const BlReRun &R = *rp;
     // XCD-aware mapping (speed only, as in nuts_kernel.hpp): blocks b and b + 8 share an XCD under the observed round-robin
@@ -611,39 +630,39 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = (long long)clock64(), st_leaves = 0;
 #endif
     auto evaluate = [&]() -> double {
-        float v[19];
+        float v[NV1];
         const float *z = V(RE_CZ);
         float *g = V(RE_CG);
         BL_RE_T(7)
         if (m.kind == 1) { // occu_cs: no effects; four more gradient sums
-            float part[15];
-            bl_cs_site_pass(m, rows, rows_ns, z, part);
+            float part[2 * MK + 7];
+            bl_cs_site_pass<MK>(m, rows, rows_ns, z, part);
 #pragma unroll
-            for (int k = 0; k < 11; k++) v[k] = part[k];
-            v[11] = part[11]; v[12] = part[12]; v[17] = part[13]; v[18] = part[14];
+            for (int k = 0; k < OX; k++) v[k] = part[k];
+            v[OX] = part[OX]; v[OX + 1] = part[OX + 1]; v[OX + 6] = part[OX + 2]; v[OX + 7] = part[OX + 3];
         } else {
-            float part[11], ss[2];
-            bl_re_site_pass(m, rows, rows_ns, z, g, part);
+            float part[2 * MK + 3], ss[2];
+            bl_re_site_pass<MK>(m, rows, rows_ns, z, g, part);
             bl_re_effect_squares(m, z, ss);
 #pragma unroll
-            for (int k = 0; k < 11; k++) v[k] = part[k];
-            v[11] = ss[0]; v[12] = ss[1]; v[17] = 0.0f; v[18] = 0.0f;
+            for (int k = 0; k < OX; k++) v[k] = part[k];
+            v[OX] = ss[0]; v[OX + 1] = ss[1]; v[OX + 6] = 0.0f; v[OX + 7] = 0.0f;
         }
-        v[13] = lead ? bl_re_prior_quad(m, z) : 0.0f;
+        v[OX + 2] = lead ? bl_re_prior_quad(m, z) : 0.0f;
         // the host's abort request rides in the sums, so that every workgroup of the chain sees it at the same leapfrog
-        v[14] = (lead && tid == 0 && R.abort_flag && *(volatile const int *)R.abort_flag) ? 1.0f : 0.0f;
+        v[OX + 3] = (lead && tid == 0 && R.abort_flag && *(volatile const int *)R.abort_flag) ? 1.0f : 0.0f;
         // XCD census (first exchange): k sum(x^2) == (sum x)^2 iff every workgroup reports the same XCC id
-        v[15] = tid == 0 ? xcc : 0.0f; v[16] = tid == 0 ? xcc * xcc : 0.0f;
+        v[OX + 4] = tid == 0 ? xcc : 0.0f; v[OX + 5] = tid == 0 ? xcc * xcc : 0.0f;
         BL_RE_T(0)
         const bool first = xc.epoch == 0u;
-        const int nv = m.kind == 1 ? 19 : (first ? 17 : 15);
-        bl_re_block_sum<19>(v, scr, red, nv, xc.k == 1);
-        if (!bl_re_exchange(xc, red, scr2, &xflag, nv)) flag = 4;
-        if (first && R.allow_local) xc.local = ((double)R.k * red[16] == red[15] * red[15]); // exact: small integers
-        if (red[14] > 0.0) flag = 5;
+        const int nv = m.kind == 1 ? NV1 : (first ? OX + 6 : OX + 4);
+        bl_re_block_sum<NV1, NRED>(v, scr, red, nv, xc.k == 1);
+        if (!bl_re_exchange<NRED>(xc, red, scr2, &xflag, nv)) flag = 4;
+        if (first && R.allow_local) xc.local = ((double)R.k * red[OX + 5] == red[OX + 4] * red[OX + 4]); // exact: small integers
+        if (red[OX + 3] > 0.0) flag = 5;
         for (int d = tid; d < G; d += BL_RE_NT)
-            g[d] = (m.kind == 1 && d >= m.G0) ? bl_cs_extra_grad(m, d - m.G0, z, red) : bl_re_global_grad(m, d, z[d], red);
-        double U = bl_re_potential(m, z, red, red[13]);
+            g[d] = (m.kind == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red) : bl_re_global_grad<MK>(m, d, z[d], red);
+        double U = bl_re_potential(m, z, red, red[OX + 2], OX);
         if (m.kind == 1) U += bl_cs_extra_potential(m, z);
         BL_RE_T(1)
         return U;
@@ -668,8 +687,8 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
             bl_next_leaf(th, r0, gr, epsdir, mi, rh, zn);
             V(RE_CZ)[d] = zn; V(RE_CR)[d] = rh; V(RE_CG)[d] = gr;
         }
-        bl_re_block_sum<1>(kin, scr, red2, 1, xc.k == 1); // (its barriers, or the exchange's, also publish the leaf start)
-        if (!bl_re_exchange(xc, red2, scr2, &xflag, 1)) flag = 4;
+        bl_re_block_sum<1, NRED>(kin, scr, red2, 1, xc.k == 1); // (its barriers, or the exchange's, also publish the leaf start)
+        if (!bl_re_exchange<NRED>(xc, red2, scr2, &xflag, 1)) flag = 4;
         E0 = Ucur + 0.5 * red2[0];
         Up = Ucur; wt = 0.f; sumacc = 0.f; nprop = 0; depth = 0;
         snprop = 0; sturn = false; sdiv = false;
@@ -700,9 +719,9 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
         const int idx_max = __popc((unsigned)leaf_idx >> 1);
         const int idx_min = idx_max - (int)__builtin_ctz(~(unsigned)leaf_idx) + 1;
         const bool odd = (leaf_idx & 1) != 0;
-        float acc[BL_RE_NRED]; // 0: kinetic; 1, 2: tree; 3 + 2 q, 4 + 2 q: checkpoint idx_min + q
+        float acc[26]; // 0: kinetic; 1, 2: tree; 3 + 2 q, 4 + 2 q: checkpoint idx_min + q
 #pragma unroll
-        for (int k = 0; k < BL_RE_NRED; k++) acc[k] = 0.0f;
+        for (int k = 0; k < 26; k++) acc[k] = 0.0f;
         const int nck = odd ? idx_max - idx_min + 1 : 0;
         for (int d = tid; d < D; d += BL_RE_NT) {
             // (coordinates below G: this thread wrote their gradient in evaluate(); the others' were published by its barriers)
@@ -736,8 +755,8 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
             acc[2] = fmaf(mc * rr, rho_t, acc[2]);
         }
         BL_RE_T(2)
-        bl_re_block_sum<BL_RE_NRED>(acc, scr, red2, 3 + 2 * nck, xc.k == 1);
-        if (!bl_re_exchange(xc, red2, scr2, &xflag, 3 + 2 * nck)) flag = 4;
+        bl_re_block_sum<26, NRED>(acc, scr, red2, 3 + 2 * nck, xc.k == 1);
+        if (!bl_re_exchange<NRED>(xc, red2, scr2, &xflag, 3 + 2 * nck)) flag = 4;
         BL_RE_T(3)
         // ---- decisions (_build_basetree tail, _iterative_build_subtree, _combine_tree, _double_tree) ----
         double dE = (Un + 0.5 * red2[0]) - E0;

@@ -18,7 +18,7 @@ from ._generators import Generator, expit, observed_mean, within
 from .occu import OccuSpec
 
 MAX_ABUNDANCE_LIMIT = 127  # the kernel's lgamma table over N
-MAX_NMIX_COVS = 4          # covariates per side the nmixture kernels are instantiated for
+MAX_NMIX_COVS = 16  # covariates per side (the engine's BL_MAX_COVS; every model is instantiated at every capacity)
 
 
 def nmixture(
@@ -42,8 +42,7 @@ def nmixture(
 ) -> OccuSpec:
     """N-mixture model on the HIP engine (parameters: nmixture.py:17-35).
 
-    Built: linear regressors, Normal priors, no spatial / random effects, ``max_abundance`` <= 127, at most 4
-    covariates per side; several species are sampled species by species.  Everything else raises
+    Built: linear regressors, Normal priors, no spatial / random effects, ``max_abundance`` <= 127; several species are sampled species by species.  Everything else raises
     ``NotImplementedError``.
 
     Examples

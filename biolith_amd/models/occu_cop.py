@@ -17,7 +17,7 @@ from ..regression import LinearRegression
 from ._generators import Generator, expit, observed_mean, within
 from .occu import OccuSpec
 
-MAX_COP_COVS = 4  # covariates per side the occu_cop kernels are instantiated for
+MAX_COP_COVS = 16  # covariates per side (the engine's BL_MAX_COVS; every model is instantiated at every capacity)
 
 
 def occu_cop(
@@ -47,7 +47,7 @@ def occu_cop(
 
     Built: linear regressors, Normal priors, ``false_positives_constant`` / ``false_positives_unoccupied`` with an
     Exponential prior on the rate, no spatial / random effects; one species when a false-positive rate is
-    sampled (it is shared across species, occu_cop.py:158-170), at most 4 covariates per side.  Everything else
+    sampled (it is shared across species, occu_cop.py:158-170).  Everything else
     raises ``NotImplementedError``.
 
     Examples

@@ -43,7 +43,7 @@ def occu_cs(
     Same parameters as the reference (biolith/models/occu_cs.py:17-36).  Built: the default option path -- linear regressors,
     Normal / Laplace coefficient priors, ``prior_mu`` Normal (one, or a pair for mu0 and for the base of mu1, which is
     truncated below at mu0, occu_cs.py:146-148), ``prior_sigma`` Gamma (one or a pair), one species (mu and sigma are
-    sampled outside the species plate), at most 4 covariates per side.  Anything else raises ``NotImplementedError``.
+    sampled outside the species plate).  Anything else raises ``NotImplementedError``.
     """
     site_covs = np.asarray(site_covs, dtype=np.float32)
     obs_covs = np.asarray(obs_covs, dtype=np.float32)
@@ -71,8 +71,8 @@ def occu_cs(
         unsupported.append("obs=None (prior predictive)")
     if n_species != 1:
         unsupported.append("n_species > 1 (mu0, mu1, sigma0, sigma1 are shared across species, occu_cs.py:143-152)")
-    if site_covs.shape[1] > 4 or obs_covs.shape[3] > 4:
-        unsupported.append("more than 4 covariates per side")
+    if site_covs.shape[1] > 16 or obs_covs.shape[3] > 16:
+        unsupported.append("more than 16 covariates per side")
     if unsupported:
         raise NotImplementedError("biolith_amd.occu_cs: not built: " + "; ".join(unsupported))
     mus = prior_mu if isinstance(prior_mu, tuple) else (prior_mu, prior_mu)

@@ -18,7 +18,7 @@ from ._generators import Generator, expit, observed_mean, within
 from .occu import OccuSpec
 
 MAX_ABUNDANCE_LIMIT = 127  # the kernel's per-lane table over N (BL_RN_NB - 1)
-MAX_RN_COVS = 4            # covariates per side the occu_rn kernels are instantiated for
+MAX_RN_COVS = 16  # covariates per side (the engine's BL_MAX_COVS; every model is instantiated at every capacity)
 
 
 def occu_rn(

@@ -50,7 +50,8 @@ def fit(
     -------
     FitResult
         ``samples``: dict ``cov_state_*`` / ``cov_det_*`` of shape (chains*draws, n_species),
-        ``psi`` (chains*draws, T, N, S), ``prob_detection`` (chains*draws, J, T, N, S; lazy);
+        ``psi`` (chains*draws, T, N, S), ``prob_detection`` (chains*draws, J, T, N, S; lazy), ``prob_detection_fp``
+        (chains*draws, 2, J, T, N, S; lazy; the leading 2 is the enumerated z, occu.py:229-235);
         ``mcmc``: :class:`HipMCMC`.
     """
     if not callable(model_fn) or getattr(model_fn, "__biolith_amd_model__", None) is None:
@@ -266,6 +267,23 @@ def _assemble(per_species, spec, num_warmup) -> HipMCMC:
         pd = parts[0][..., None] if nsp == 1 else np.stack(parts, axis=-1)
         return pd.reshape(C, S, ds0.J, ds0.T, ds0.N, nsp)
 
+    @memo
+    def prob_detection_fp():
+        # occu.py:229-235: 1 - (1 - z p)(1 - f_c)(1 - (1 - z) f_u) depends on the ENUMERATED z, so under numpyro's parallel
+        # enumeration (occu.py:208-210) the recorded value carries z's enumeration axis in front of the plates
+        # (first available dim = -5: [UPSTREAM] funsor's enum dims sit left of max_plate_nesting = 4; not verifiable in this
+        # image): (C, S, 2, J, T, N, species), index 0 = unoccupied, 1 = occupied.  Nothing in the reference reads it.
+        pd = prob_detection().astype(np.float32)                                  # (C, S, J, T, N, nsp)
+        if spec.model != "occu_fp":   # both rates 0:  1 - (1 - z p) = z p
+            return np.stack([np.zeros_like(pd), pd], axis=2)
+        f_c = f_u = np.float32(0.0)
+        if spec.model == "occu_fp":
+            rate = latent[f"prob_fp_{spec.extras['fp_mode']}"].astype(np.float32).reshape(C, S, 1, 1, 1, 1)
+            f_c, f_u = (rate, np.float32(0.0)) if spec.extras["fp_mode"] == "constant" else (np.float32(0.0), rate)
+        z0 = np.broadcast_to(1.0 - (1.0 - f_c) * (1.0 - f_u), pd.shape).astype(np.float32)
+        z1 = (1.0 - (1.0 - pd) * (1.0 - f_c)).astype(np.float32)
+        return np.stack([z0, z1], axis=2)
+
     # one result object for the mcmc shim: extras concatenated over species along the chain axis
     import copy
 
@@ -283,6 +301,9 @@ def _assemble(per_species, spec, num_warmup) -> HipMCMC:
     first = "abundance" if spec.model in ("occu_rn", "nmixture") else "psi"
     # occu_cop's replicate-level site is the detection RATE exp(linear predictor) (occu_cop.py:236-243)
     second = "rate_detection" if spec.model == "occu_cop" else "prob_detection"
+    sites = {first: psi, second: prob_detection}
+    if spec.model in ("occu", "occu_fp", "occu_re"):
+        sites["prob_detection_fp"] = prob_detection_fp
     return HipMCMC(res, latent=latent,
-                   deterministic={first: psi, second: prob_detection},
+                   deterministic=sites,
                    num_warmup=num_warmup, spec_shape=spec.shape)

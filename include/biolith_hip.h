@@ -75,7 +75,7 @@ int bl_dataset_create(const bl_dims *dims, const float *site_covs, const float *
  * Same for the Royle-Nichols model biolith.models.occu_rn (models/occu_rn.py:20-222): latent
  * abundance N ~ RightTruncatedPoisson(exp(beta0 + x beta), max_abundance) (utils/distributions.py:6-40)
  * summed out in the kernel, detection 1 - (1 - sigmoid(alpha0 + w alpha))^N.  Built for
- * max_abundance <= 127 and at most 4 covariates per side.  The handle then behaves exactly like an
+ * max_abundance <= 127 (covariates: up to BL_MAX_COVS per side, as for every model).  The handle then behaves exactly like an
  * occu handle (bl_logp_grad, bl_nuts_*); bl_deterministic's first output becomes
  * `abundance` = exp(beta0 + x beta) (occu_rn.py:192).
  */
@@ -90,7 +90,6 @@ int bl_dataset_create_rn(const bl_dims *dims, const float *site_covs, const floa
  * prior_fp is the Beta(a, b) prior of that rate (NULL = Beta(2, 5), the reference default).  The handle's
  * parameter vector gains one trailing coordinate phi = logit(rate) (NumPyro's unconstrained space for
  * a unit-interval site), so bl_dataset_param_dim = Ks + Ko + 3 and draws[..., D-1] is phi.
- * Built for at most 4 covariates per side.
  */
 typedef struct { double a, b; } bl_beta_prior;
 enum { BL_FP_CONSTANT = 1, BL_FP_UNOCCUPIED = 2 };
@@ -105,7 +104,7 @@ int bl_dataset_create_fp(const bl_dims *dims, const float *site_covs, const floa
  * false-positive rate; BL_FP_CONSTANT / BL_FP_UNOCCUPIED: sites "rate_fp_constant" / "rate_fp_unoccupied"
  * with an Exponential(prior_fp_rate) prior (occu_cop.py:31-32, 158-170) sampled as a trailing coordinate
  * phi = log(rate).  bl_deterministic's second output becomes `rate_detection` = exp(alpha0 + w alpha)
- * (occu_cop.py:236-243).  Built for at most 4 covariates per side; predictive draws: bl_predict_counts.
+ * (occu_cop.py:236-243).  Predictive draws: bl_predict_counts.
  */
 int bl_dataset_create_cop(const bl_dims *dims, const float *site_covs, const float *obs_covs,
                           const float *obs, const float *session_duration, int fp_mode,
@@ -116,7 +115,7 @@ int bl_dataset_create_cop(const bl_dims *dims, const float *site_covs, const flo
  * N ~ Poisson(exp(beta0 + x beta)) enumerated over 0..max_abundance (raw, un-renormalised weights: the model's
  * "N_i_trunc_norm" factor, nmixture.py:183-196; support cut below the largest count of each (site, period),
  * nmixture.py:150-155), y ~ Binomial(N, sigmoid(alpha0 + w alpha)).  bl_deterministic's outputs are `abundance`
- * and `prob_detection`.  Built for max_abundance <= 127 and at most 4 covariates per side; predictive draws: bl_predict_counts.
+ * and `prob_detection`.  Built for max_abundance <= 127; predictive draws: bl_predict_counts.
  */
 int bl_dataset_create_nmix(const bl_dims *dims, const float *site_covs, const float *obs_covs,
                            const float *obs, int max_abundance, const bl_normal_prior *prior_beta,

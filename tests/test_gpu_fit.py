@@ -35,6 +35,10 @@ def test_occu():  # occu.py:433-456
     assert s["psi"].shape == (5000, 1, 100, 1)
     assert s["prob_detection"].shape == (5000, 52, 1, 100, 1)
     assert "beta" not in s and "alpha" not in s
+    # occu.py:229-235 under enumeration: the z axis (0 = unoccupied, 1 = occupied) in front of the plates; lazy
+    pfp = s["prob_detection_fp"]
+    assert pfp.shape == (5000, 2, 52, 1, 100, 1)
+    assert np.all(pfp[:, 0] == 0.0) and np.array_equal(pfp[:, 1], s["prob_detection"])   # no false positives: z p
     d = diagnostics(results.mcmc)
     assert d["mean_r_hat"] < 1.01 and d["mean_frac_eff"] > 0.3 and d["frac_diverging"] < 0.01
     assert results.mcmc.num_chains == 5 and results.mcmc.num_samples == 1000

@@ -55,9 +55,11 @@ def test_fp_ragged_site_counts(n_sites):
 
 def test_fp_limits():
     g = load_golden("small_3x3")
-    X5 = np.zeros((300, 5), np.float32)
-    with pytest.raises((NotImplementedError, RuntimeError, ValueError)):   # capacities <= 4 per side
-        OccuDataset(X5, g["obs_covs"], g["obs"], model="occu_fp")
+    X17 = np.zeros((300, 17), np.float32)
+    with pytest.raises((NotImplementedError, RuntimeError, ValueError)):   # the engine's capacity: BL_MAX_COVS = 16 per side
+        OccuDataset(X17, g["obs_covs"], g["obs"], model="occu_fp")
+    ds5 = OccuDataset(np.zeros((300, 5), np.float32), g["obs_covs"], g["obs"], model="occu_fp")   # (round 1 stopped at 4)
+    assert ds5.D == 5 + g["obs_covs"].shape[-1] + 3
     with pytest.raises(ValueError):
         OccuDataset(g["site_covs"], g["obs_covs"], g["obs"], model="occu_fp", prior_fp=(0.0, 1.0))
 
@@ -124,3 +126,9 @@ def test_predict_with_false_positives():
     unocc = np.broadcast_to(z == 0, y.shape)
     assert y[unocc].any()                                       # false positives do appear at unoccupied sites
     assert abs(y[unocc].mean() - np.broadcast_to(f, y.shape)[unocc].mean()) < 0.01
+    # fit().samples carries the site with z's enumeration axis (occu.py:229-235 under occu.py:208-210): [:, z]
+    pfp = res.samples["prob_detection_fp"]
+    assert pfp.shape == (600, 2) + p.shape[1:]
+    pd = res.samples["prob_detection"]
+    np.testing.assert_allclose(pfp[:, 0], np.broadcast_to(f, pd.shape), rtol=1e-6)                  # unoccupied: the rate alone
+    np.testing.assert_allclose(pfp[:, 1], 1 - (1 - pd) * (1 - f), rtol=1e-5, atol=1e-6)             # occupied
