@@ -447,7 +447,9 @@ __device__ __forceinline__ float bl_cs_extra_grad(const BlReModel &m, int e, con
     constexpr int OX = BL_RE_OX(MK);
     const float mu0 = z[m.G0], ex1 = bl_exp(z[m.G0 + 1]), mu1 = mu0 + ex1;
     if (e >= 2) {
-        const float a = m.cs_sg[2 * (e - 2)], b = m.cs_sg[2 * (e - 2) + 1];
+        // (selects, not m.cs_sg[2 * (e - 2)]: a dynamically indexed member would put the whole model struct into scratch memory
+        // -- 224 bytes per lane, read back on every use of the model: 12-16 % of a leapfrog, measured)
+        const float a = e == 2 ? m.cs_sg[0] : m.cs_sg[2], b = e == 2 ? m.cs_sg[1] : m.cs_sg[3];
         return -((float)red[OX + 4 + e] + a - b * bl_exp(z[m.G0 + e]));
     }
     const float l0 = m.cs_mu[0], s0 = m.cs_mu[1], l1 = m.cs_mu[2], s1 = m.cs_mu[3];
