@@ -187,6 +187,7 @@ struct bl_dataset {
     double fp_a = 2.0, fp_b = 5.0;  // model 2: Beta prior of the false-positive rate
     bl_dims dims{};
     int Ks = 0, Ko = 0, KS = 0, KO = 0, D = 0;
+    int nsp = 1;            // species sampled jointly by this handle (models 0 and 2)
     int n_stride = 0, n_rows = 0;
     float *d_rows = nullptr;
     BlDevData dd{};
@@ -324,6 +325,7 @@ __global__ void bl_predict_kernel(const float *__restrict__ rows, const float *_
 extern "C" int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint64_t seed, uint8_t *latent, uint8_t *y)
 {
     if (!ds || !draws || n_draws <= 0 || (!latent && !y)) return bl_fail(BL_ERR_INVALID, "bl_predict: bad argument");
+    if (ds->nsp > 1) return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: a joint-species handle samples; predict from one handle per species");
     if (ds->model == 3 || ds->model == 4)
         return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: the count models (occu_cop, nmixture) use bl_predict_counts");
     if (ds->model == 6 && ds->re.kind == 1)
@@ -647,8 +649,12 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
     const int Ks = dims->n_site_covs, Ko = dims->n_obs_covs;
     // shape checks mirror the asserts at biolith/models/occu.py:103-133
     if (N <= 0 || T <= 0 || J <= 0 || Ks < 0 || Ko < 0) return bl_fail(BL_ERR_INVALID, "non-positive dimension");
-    if (S != 1)
-        return bl_fail(BL_ERR_UNSUPPORTED, "n_species=%d: this build samples one species per dataset (occu.py:182)", S);
+    // Several species in ONE handle = one chain over all species' coefficients (the species plate of occu.py:182-186 under one
+    // NUTS, with a false-positive rate shared across species, occu.py:146-157): the LDS-staged occu / false-positive forms only.
+    if (S < 1) return bl_fail(BL_ERR_INVALID, "n_species=%d", S);
+    if (S > 1 && model != 0 && model != 2)
+        return bl_fail(BL_ERR_UNSUPPORTED, "n_species=%d: joint sampling of several species is built for occu with or without false positives; "
+                       "this model takes one species per dataset", S);
     if (Ks > BL_MAX_COVS || Ko > BL_MAX_COVS)
         return bl_fail(BL_ERR_UNSUPPORTED, "more than %d covariates per side (Ks=%d, Ko=%d)", BL_MAX_COVS, Ks, Ko);
     if ((Ks > 0 && !site_covs) || (Ko > 0 && !obs_covs) || !obs) return bl_fail(BL_ERR_INVALID, "NULL data pointer");
@@ -663,7 +669,8 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
 
     bl_dataset *ds = new bl_dataset();
     const int has_extra = (model == 2 || (model == 3 && mo.fp_mode != 0)) ? 1 : 0; // trailing false-positive coordinate
-    ds->device = device; ds->dims = *dims; ds->Ks = Ks; ds->Ko = Ko; ds->D = Ks + Ko + 2 + has_extra;
+    ds->device = device; ds->dims = *dims; ds->Ks = Ks; ds->Ko = Ko; ds->D = S * (Ks + Ko + 2) + has_extra;
+    ds->nsp = S;
     ds->model = model; ds->max_abundance = max_abundance;
     ds->fp_mode = mo.fp_mode; ds->fp_a = mo.fp_a; ds->fp_b = mo.fp_b;
     ds->KS = pad_covs(Ks); ds->KO = pad_covs(Ko);
@@ -671,10 +678,15 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
     ds->pb = pb; ds->pa = pa;
     if (!ds->kern) { delete ds; return bl_fail(BL_ERR_UNSUPPORTED, "no kernel for capacity (%d,%d)", pad_covs(Ks), pad_covs(Ko)); }
     const int V = T * J, KS = ds->KS, KO = ds->KO;
+    if (S > 1 && (S * BL_SP_COEF(KS, KO) + 2 > 64 || S * BL_SP_PART(KS, KO) * BL_CWAVES_MAX > BL_PART_FLOATS || ds->D + 4 > 64)) {
+        delete ds;
+        return bl_fail(BL_ERR_UNSUPPORTED, "n_species=%d x (Ks=%d, Ko=%d): too many coordinates for one joint chain (sample the species one by one)", S, Ks, Ko);
+    }
     const int vw = KO + 1 + ((model == 3 || model == 4) ? 1 : 0); // floats per visit
     ds->ko_layout = vw - 1;
     const int n_stride = (N + 63) / 64 * 64;
-    const int n_rows = KS + V * vw + 2 * T;
+    const int sp_rows = V * vw + 2 * T;          // rows of one species' block (visits, ka, kb); the site covariates come once
+    const int n_rows = KS + S * sp_rows;
     ds->n_stride = n_stride; ds->n_rows = n_rows;
 
     // ---- pack: mask (occu.py:136-142, modeling.py:15-17), NaN->0, sign folding, site-fastest rows ----
@@ -756,7 +768,10 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
             rows[(size_t)(row_ka + t) * n_stride + i] = (float)ysum;
             rows[(size_t)(row_kb + t) * n_stride + i] = (float)dsum;
         }
-        for (int t = 0; t < T && model != 3 && model != 4; t++) {
+        for (int sp = 0; sp < S && model != 3 && model != 4; sp++)
+        for (int t = 0; t < T; t++) {
+            const size_t sp_off = (size_t)sp * sp_rows;     // this species' block of rows
+            const float *obs_sp = obs + (size_t)sp * N * T * J;
             int n_masked = 0, n_det = 0;
             for (int j = 0; j < J; j++) {
                 const int v = t * J + j;
@@ -769,17 +784,17 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
                     w[k] = x;
                     ds->h_wraw[((size_t)v * Ko + k) * n_stride + i] = x;
                 }
-                const float y = obs[o];
+                const float y = obs_sp[o];
                 float c = 0.0f;
                 if (cov_nan || !std::isfinite(y)) n_masked++;
                 else if (y != 0.0f) { c = 1.0f; n_det++; }
                 else c = -1.0f;
-                const size_t r0 = (size_t)(row_wc + v * (KO + 1));
+                const size_t r0 = sp_off + (size_t)(row_wc + v * (KO + 1));
                 rows[r0 * n_stride + i] = c;
                 for (int k = 0; k < Ko; k++) rows[(r0 + 1 + k) * n_stride + i] = c * w[k];
             }
-            rows[(size_t)(row_ka + t) * n_stride + i] = (float)(n_masked * LN2);
-            rows[(size_t)(row_kb + t) * n_stride + i] = (float)(n_det * LOG_TINY);
+            rows[(sp_off + (size_t)(row_ka + t)) * n_stride + i] = (float)(n_masked * LN2);
+            rows[(sp_off + (size_t)(row_kb + t)) * n_stride + i] = (float)(n_det * LOG_TINY);
         }
     }
     hipError_t e = hipSetDevice(device);
@@ -801,7 +816,8 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
     dd.Ks = Ks; dd.Ko = Ko; dd.KS = KS; dd.KO = KO;
     dd.loc_b = (float)pb.loc; dd.isc2_b = (float)(1.0 / (pb.scale * pb.scale));
     dd.loc_a = (float)pa.loc; dd.isc2_a = (float)(1.0 / (pa.scale * pa.scale));
-    dd.prior_const = (Ks + 1) * std::log(pb.scale) + (Ko + 1) * std::log(pa.scale) + (Ks + Ko + 2) * 0.91893853320467274178;
+    dd.prior_const = S * ((Ks + 1) * std::log(pb.scale) + (Ko + 1) * std::log(pa.scale) + (Ks + Ko + 2) * 0.91893853320467274178);
+    dd.n_species = S;
     dd.has_fp = has_extra ? model : 0; dd.fp_a = (float)mo.fp_a; dd.fp_b = (float)mo.fp_b;
     if (model == 3) {
         dd.prior_const -= cop_const;                        // the parameter-free part of the Poisson log-pmf
@@ -823,8 +839,8 @@ extern "C" int bl_dataset_set_prior_family(bl_dataset *ds, int family_beta, int 
     // constant of the potential: log(scale) + log(2 pi) / 2 per Normal coefficient, log(2 scale) per Laplace one
     const double HL2PI = 0.91893853320467274178;
     auto konst = [&](int fam, double scale) { return fam == BL_PRIOR_LAPLACE ? std::log(2.0 * scale) : std::log(scale) + HL2PI; };
-    const double before = (ds->Ks + 1) * konst(ds->fam_b, ds->pb.scale) + (ds->Ko + 1) * konst(ds->fam_a, ds->pa.scale);
-    const double after = (ds->Ks + 1) * konst(family_beta, ds->pb.scale) + (ds->Ko + 1) * konst(family_alpha, ds->pa.scale);
+    const double before = ds->nsp * ((ds->Ks + 1) * konst(ds->fam_b, ds->pb.scale) + (ds->Ko + 1) * konst(ds->fam_a, ds->pa.scale));
+    const double after = ds->nsp * ((ds->Ks + 1) * konst(family_beta, ds->pb.scale) + (ds->Ko + 1) * konst(family_alpha, ds->pa.scale));
     dd.prior_const += after - before;
     ds->fam_b = family_beta; ds->fam_a = family_alpha;
     dd.isc2_b = family_beta == BL_PRIOR_LAPLACE ? 0.0f : (float)(1.0 / (ds->pb.scale * ds->pb.scale));
@@ -892,9 +908,9 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     const int lds_cap = BL_LDS_TOTAL - BL_OFF_DATA;
     // LDS keeps one record of `stride` floats per PAIR of sites (occu_device.hpp)
     const int stride = bl_record_stride(ds->dims.n_periods, ds->dims.n_replicates, ds->KS, ds->ko_layout);
-    auto fits = [&](int kk, int *nloc) {
+    auto fits = [&](int kk, int *nloc) { // (every species has a record region of its own)
         *nloc = (N + kk - 1) / kk;
-        return (long long)((*nloc + 1) / 2) * stride * 4 <= lds_cap;
+        return (long long)((*nloc + 1) / 2) * stride * 4 * ds->nsp <= lds_cap;
     };
     int nloc;
     bool ok = fits(k, &nloc);
@@ -914,14 +930,16 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     if (!ok && ds->model == 0) ncw = 4; // HBM-row form is built for 4 compute waves only
     if (wide) ncw = ds->model == 1 ? BL_CWAVES_RN : 4; // full slices: all four SIMDs evaluate
     *k_out = k; *nloc_out = nloc; *ld_out = stride; *staged_out = ok ? 1 : 0; *ncw_out = ncw; *wide_out = wide;
-    *lds_bytes_out = ok ? BL_OFF_DATA + ((nloc + 1) / 2) * stride * 4 : BL_OFF_DATA;
+    *lds_bytes_out = ok ? BL_OFF_DATA + ((nloc + 1) / 2) * stride * 4 * ds->nsp : BL_OFF_DATA;
 }
 
 // ------------------------------------------------------------- K1 logp ----
 __global__ void bl_logp_final_kernel(BlDevData dd, int k, const double *theta, const double *partial, double *U, double *grad)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
-    const int D = dd.Ks + dd.Ko + 2 + (dd.has_fp ? 1 : 0);
+    const int Dsp = dd.Ks + dd.Ko + 2, nsp = dd.n_species > 0 ? dd.n_species : 1;
+    const int D = nsp * Dsp + (dd.has_fp ? 1 : 0);
+    const int lj = lane < nsp * Dsp ? lane % Dsp : lane; // index within the lane's species
     double acc = 0.0;
     if (lane <= D)
         for (int m = 0; m < k; m++) acc += partial[((size_t)b * k + m) * 64 + lane];
@@ -938,7 +956,7 @@ __global__ void bl_logp_final_kernel(BlDevData dd, int k, const double *theta, c
         pr = dd.fp_a * (fmax(-phi, 0.0) + l) + dd.fp_b * (fmax(phi, 0.0) + l);
         grad[(size_t)b * D + lane] = -acc + (dd.fp_a + dd.fp_b) * sig - dd.fp_a;
     } else if (lane < D) {
-        const bool is_b = lane <= dd.Ks;
+        const bool is_b = lj <= dd.Ks;
         const double loc = is_b ? dd.loc_b : dd.loc_a, isc2 = is_b ? dd.isc2_b : dd.isc2_a, l1 = is_b ? dd.l1_b : dd.l1_a;
         const double dth = theta[(size_t)b * D + lane] - loc;
         pr = 0.5 * dth * dth * isc2 + fabs(dth) * l1; // Normal or Laplace (one of isc2, l1 is 0)
@@ -1119,6 +1137,9 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
     p.fp_mode = ds->fp_mode;
     p.nmix_tab = ds->d_tab;
     p.ncw = ncw;
+    p.n_species = ds->nsp; p.sp_lds = ((nloc + 1) / 2) * ld;
+    if (ds->nsp > 1 && !use_staged)
+        return bl_fail(BL_ERR_UNSUPPORTED, "joint sampling of %d species needs the LDS-staged path (slice too large, or staged=0 requested)", ds->nsp);
     if (ds->model != 0 && !use_staged)
         return bl_fail(BL_ERR_UNSUPPORTED, "occu_rn / false-positive models need the LDS-staged path (slice too large, or staged=0 requested)");
     const int lrc = ds->kern->logp(&p, k, lds_bytes, use_staged, ds->model, nullptr);
@@ -1364,6 +1385,9 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.fp_mode = ds->fp_mode;
     p.nmix_tab = ds->d_tab;
     p.ncw = ncw;
+    p.n_species = ds->nsp; p.sp_lds = ((nloc + 1) / 2) * ld;
+    if (ds->nsp > 1 && !staged)
+        return bl_fail(BL_ERR_UNSUPPORTED, "joint sampling of %d species: the dataset slice does not fit the LDS-staged path", ds->nsp);
     p.wide = wide;
     p.xchg = ds->d_xchg;
     p.cold = d_cold;
@@ -1555,6 +1579,7 @@ __global__ void bl_pdet_kernel(const float *__restrict__ wraw, int n_stride, int
 extern "C" int bl_deterministic(bl_dataset *ds, int n_draws, const float *draws, float *psi, float *prob_detection)
 {
     if (!ds || !draws || n_draws <= 0) return bl_fail(BL_ERR_INVALID, "bl_deterministic: bad argument");
+    if (ds->nsp > 1) return bl_fail(BL_ERR_UNSUPPORTED, "bl_deterministic: a joint-species handle samples; take the sites from one handle per species");
     if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
     int rc = set_device(ds);
     if (rc) return rc;

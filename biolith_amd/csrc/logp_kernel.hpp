@@ -11,6 +11,7 @@ struct BlLogpParams {
     int fp_mode;         // false-positive coordinate (see BlNutsParams)
     const float *nmix_tab; // MODEL 4 (see BlNutsParams)
     int ncw;             // compute waves per workgroup: selects the CW instantiation (host side)
+    int n_species, sp_lds; // joint-species datasets (see BlNutsParams)
     int B;
     const float *theta;  // [B][D] float32 view of the caller's double theta
     double *partial;     // [B][k][64]: c < D grad of log-lik, c == D log-lik
@@ -21,14 +22,16 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_logp_kernel(const BlLogpPara
 {
     const int member = blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int Ks = p.dd.Ks, Ko = p.dd.Ko, D = bl_model_dim<MODEL>(Ks, Ko, p.fp_mode);
+    const int Ks = p.dd.Ks, Ko = p.dd.Ko, nsp = p.n_species, Dsp = Ks + Ko + 2;
+    const int D = bl_model_dim<MODEL>(Ks, Ko, p.fp_mode) + (nsp - 1) * Dsp;
     const int s0 = member * p.nloc;
     int cnt = p.dd.n_sites - s0;
     cnt = cnt < 0 ? 0 : (cnt > p.nloc ? p.nloc : cnt);
     const float *grows = nullptr;
     int ld = p.rec_stride;
     if constexpr (LDS) {
-        bl_stage_records(p.dd.rows, p.dd.n_stride, s0, cnt, p.dd.T, p.dd.J, KS, bl_layout_ko<MODEL>(KO), p.rec_stride, 64 * (CW + 1));
+        for (int sp = 0; sp < nsp; sp++)
+            bl_stage_records(p.dd.rows, p.dd.n_stride, s0, cnt, p.dd.T, p.dd.J, KS, bl_layout_ko<MODEL>(KO), p.rec_stride, 64 * (CW + 1), sp, sp * p.sp_lds);
     } else {
         grows = p.dd.rows + s0;
         ld = p.dd.n_stride;
@@ -36,19 +39,28 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_logp_kernel(const BlLogpPara
     float *sh_coef = bl_lds_f(BL_OFF_COEF);
     if (tid < 64) sh_coef[tid] = 0.0f;
     __syncthreads();
-    const int my_pos = lane < D ? bl_coef_pos(lane, Ks, Ko, KS, KO) : (lane == D ? KS + KO + 2 : 0);
+    // (same lane -> coefficient / partial mapping as the NUTS kernel's control wave)
+    const bool has_phi = D > nsp * Dsp;
+    const int lsp = lane < nsp * Dsp ? lane / Dsp : 0, lj = lane - lsp * Dsp;
+    const int my_pos = lane < nsp * Dsp ? lsp * BL_SP_COEF(KS, KO) + bl_coef_pos(lj, Ks, Ko, KS, KO) : nsp * BL_SP_COEF(KS, KO) + 1;
+    const int part_pos = lane < nsp * Dsp ? lsp * BL_SP_PART(KS, KO) + bl_coef_pos(lj, Ks, Ko, KS, KO)
+                                          : ((has_phi && lane == D - 1) ? KS + KO + 3 : KS + KO + 2);
+    const bool part_all = lane >= nsp * Dsp;
+    const int part_rs = nsp > 1 ? nsp * BL_SP_PART(KS, KO) : BL_PART_STRIDE;
     for (int b = 0; b < p.B; b++) {
         if (wave == 0 && lane < D) sh_coef[my_pos] = p.theta[(size_t)b * D + lane];
         __syncthreads();
         if (wave > 0) { // compute waves, exactly as in the NUTS kernel
-            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, p.dd.T, p.dd.J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, p.dd.n_stride);
+            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, p.dd.T, p.dd.J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, p.dd.n_stride, nsp, p.sp_lds);
         }
         __syncthreads();
         if (wave == 0) {
             const float *part = bl_lds_f(BL_OFF_PART);
             double acc = 0.0;
 #pragma unroll
-            for (int w = 0; w < CW; w++) acc += (double)part[w * BL_PART_STRIDE + my_pos];
+            for (int w = 0; w < CW; w++) acc += (double)part[w * part_rs + part_pos];
+            for (int sp = 1; sp < nsp; sp++)
+                for (int w = 0; w < CW; w++) acc += part_all ? (double)part[w * part_rs + part_pos + sp * BL_SP_PART(KS, KO)] : 0.0;
             double *out = p.partial + ((size_t)b * p.k + member) * 64;
             if (lane <= D) out[lane] = acc;
         }

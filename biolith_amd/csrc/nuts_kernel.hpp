@@ -107,6 +107,8 @@ struct BlNutsParams {
     int poll_sleep;                // s_sleep(1) repeats between re-polls (fabric form)
     int first_delay;               // s_sleep(1) repeats between publishing and the first poll
     int pitch;                     // granules between consecutive workgroup records (>= nvp)
+    int n_species;                 // > 1: ONE chain over all species' coefficients (occu.py:182-186); layouts in occu_device.hpp (BL_SP_*)
+    int sp_lds;                    // floats between two species' record regions in LDS
     unsigned spin_limit;
     unsigned long long *xchg;      // [C][2][k][nvp] granules, zeroed before every launch
     const BlNutsCold *cold;
@@ -185,7 +187,9 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     const int member = p.wide ? (int)blockIdx.x % p.k : slot % p.k;
     if (chain >= p.num_chains) return; // whole block leaves before any barrier or exchange
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int Ks = p.Ks, Ko = p.Ko, D = bl_model_dim<MODEL>(Ks, Ko, p.fp_mode);
+    const int Ks = p.Ks, Ko = p.Ko, nsp = p.n_species;
+    const int Dsp = Ks + Ko + 2;    // coordinates of one species
+    const int D = bl_model_dim<MODEL>(Ks, Ko, p.fp_mode) + (nsp - 1) * Dsp;
     const int T = p.T, J = p.J;
     const int s0 = member * p.nloc;
     int cnt = p.n_sites - s0;
@@ -193,7 +197,8 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     const float *grows = nullptr;
     int ld = p.rec_stride;
     if constexpr (LDS) {
-        bl_stage_records(p.rows, p.n_stride, s0, cnt, T, J, KS, bl_layout_ko<MODEL>(KO), p.rec_stride, 64 * (CW + 1));
+        for (int sp = 0; sp < nsp; sp++)
+            bl_stage_records(p.rows, p.n_stride, s0, cnt, T, J, KS, bl_layout_ko<MODEL>(KO), p.rec_stride, 64 * (CW + 1), sp, sp * p.sp_lds);
     } else {
         grows = p.rows + s0;
         ld = p.n_stride;
@@ -209,10 +214,16 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     // ------------------------------------------------ replicated chain state (control wave) ----
     const BlNutsCold *cold = p.cold;
     const bool act = lane < D;
-    // where lane d's coefficient / partial lives in the padded LDS layouts; lanes >= D read the log-lik
-    const int my_pos = act ? bl_coef_pos(lane, Ks, Ko, KS, KO) : KS + KO + 2;
     // the false-positive coordinate (logit rate, Beta prior: MODEL 2; log rate, Exponential prior: MODEL 3), not Normal
     const bool is_phi = (MODEL == 2 || (MODEL == 3 && p.fp_mode != 0)) && lane == D - 1;
+    // lane d = coordinate d of theta = [species 0: beta, alpha | species 1: ... | (phi)]: species and index within it
+    const int lsp = lane < nsp * Dsp ? lane / Dsp : 0, lj = lane - lsp * Dsp;
+    // where lane d's coefficient lives in the LDS coefficient block, and its partial in a wave's row of the partial table;
+    // the log-lik (lane D) and the shared phi are sums over the species' slots (part_all)
+    const int my_pos = lane < nsp * Dsp ? lsp * BL_SP_COEF(KS, KO) + bl_coef_pos(lj, Ks, Ko, KS, KO) : nsp * BL_SP_COEF(KS, KO) + 1;
+    const int part_pos = lane < nsp * Dsp ? lsp * BL_SP_PART(KS, KO) + bl_coef_pos(lj, Ks, Ko, KS, KO) : (is_phi ? KS + KO + 3 : KS + KO + 2);
+    const bool part_all = lane >= nsp * Dsp;
+    const int part_rs = nsp > 1 ? nsp * BL_SP_PART(KS, KO) : BL_PART_STRIDE;
     // ---- loop-carried registers: only what the per-leaf path touches ----
     BlRng rng_d, rng_u, rng_dir;        // per-dimension stream, transition uniforms, direction bits
     float minv = act ? 1.0f : 0.0f;     // diagonal inverse mass (0 in idle lanes keeps sums clean)
@@ -268,9 +279,9 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 
     if (wave == 0) {
         S = cold->num_samples; W = cold->num_warmup; total = W + S;
-        prior_loc = (lane <= Ks) ? cold->loc_b : cold->loc_a;
-        prior_isc2 = act ? ((lane <= Ks) ? cold->isc2_b : cold->isc2_a) : 0.0f;
-        prior_l1 = act ? ((lane <= Ks) ? cold->l1_b : cold->l1_a) : 0.0f;
+        prior_loc = (lj <= Ks) ? cold->loc_b : cold->loc_a;
+        prior_isc2 = act ? ((lj <= Ks) ? cold->isc2_b : cold->isc2_a) : 0.0f;
+        prior_l1 = act ? ((lj <= Ks) ? cold->l1_b : cold->l1_a) : 0.0f;
         if (is_phi) { prior_loc = cold->fp_a; prior_isc2 = cold->fp_b; prior_l1 = 0.0f; }
         prior_const = cold->prior_const;
         const uint32_t *rs = cold->rng + ((size_t)chain * BL_NSTREAM + lane) * 4;
@@ -563,7 +574,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #ifdef BL_STAMPS
             const long long st_a0 = (long long)clock64();
 #endif
-            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, p.n_stride);
+            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, p.n_stride, nsp, p.sp_lds);
 #ifdef BL_STAMPS
             st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
 #endif
@@ -602,10 +613,14 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         } else {
             epoch++;
             // ---------------------------------- workgroup partial (fixed wave order) ----
-            const float *part = bl_lds_f(BL_OFF_PART) + my_pos;
+            const float *part = bl_lds_f(BL_OFF_PART) + part_pos;
             float comp = 0.0f; // lanes < D: their gradient component; lane D: the log-lik
 #pragma unroll
-            for (int w = 0; w < CW; w++) comp += part[w * BL_PART_STRIDE];
+            for (int w = 0; w < CW; w++) comp += part[w * part_rs];
+            for (int sp = 1; sp < nsp; sp++) { // several species: the log-lik and the shared coordinate add the other species' slots
+#pragma unroll
+                for (int w = 0; w < CW; w++) comp += part_all ? part[w * part_rs + sp * BL_SP_PART(KS, KO)] : 0.0f;
+            }
             if (lane > D) comp = 0.0f;
             if (lane == D + 1 && member == 0 && (epoch & 255u) == 0u)
                 comp = (__hip_atomic_load(cold->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1.0f : 0.0f;

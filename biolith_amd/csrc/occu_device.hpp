@@ -65,6 +65,7 @@ struct BlDevData {
     float loc_b, isc2_b, loc_a, isc2_a;  // Normal prior loc, 1/scale^2 (0 for a Laplace prior)
     float l1_b, l1_a;                    // Laplace(loc, scale) prior: 1/scale (0 for a Normal prior); energy = dth^2 isc2 / 2 + |dth| l1
     double prior_const;                  // sum_k log(scale_k) + D/2 log(2 pi)  (+ log B(a,b) with has_fp)
+    int n_species;                       // species sampled jointly (theta = [species 0: beta, alpha | species 1: ... | (phi)]); 0 reads as 1
     int has_fp;                          // 0, or the model id (2: logit rate, Beta prior; 3: log rate, Exponential prior)
                                          // whose false-positive coordinate phi is theta's last entry
     float fp_a, fp_b;                    // its prior: Beta(a, b) / Exponential(rate = a)
@@ -357,12 +358,12 @@ __device__ __forceinline__ void bl_visit2(const bl_f2 (&w)[KO + 1], const float 
 template <int KS, int KO, int JC, int CT>
 __device__ __forceinline__ void bl_eval_sites_lds(int ct, int pstride, int cnt, int T, int J,
                                                   const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
-                                                  float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
+                                                  float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], int data_off = 0)
 {
     constexpr int XQ = (KS + 3) & ~3;
     const int Jn = JC > 0 ? JC : J;
     const int pb = bl_period_block(Jn, KO);
-    const float *data = bl_lds_f(BL_OFF_DATA);
+    const float *data = bl_lds_f(BL_OFF_DATA) + data_off; // (data_off: the records of one species of a joint-species dataset)
     const int npairs = (cnt + 1) >> 1;
     bl_f2 ll2 = bl2(0.0f), gb2[KS + 1], ga2[KO + 1];
 #pragma unroll
@@ -528,11 +529,11 @@ __device__ __forceinline__ BlFpScalars bl_fp_scalars(float phi, int fp_z1)
 template <int KS, int KO, int CT>
 __device__ __forceinline__ void bl_eval_sites_fp(int ct, int pstride, int cnt, int T, int J, const BlFpScalars fp,
                                                  const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
-                                                 float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], float &gphi)
+                                                 float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], float &gphi, int data_off = 0)
 {
     constexpr int XQ = (KS + 3) & ~3;
     const int pb = bl_period_block(J, KO);
-    const float *data = bl_lds_f(BL_OFF_DATA);
+    const float *data = bl_lds_f(BL_OFF_DATA) + data_off;
     const int npairs = (cnt + 1) >> 1;
     const float Jf = (float)J;
     bl_f2 ll2 = bl2(0.0f), gb2[KS + 1], ga2[KO + 1], gp2 = bl2(0.0f);
@@ -1241,7 +1242,7 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
 template <int KS, int KO, bool LDS, int MODEL, int CT>
 __device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ grows, int ld_or_stride, int cnt, int T, int J, int K,
                                               const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
-                                              float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
+                                              float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], int data_off = 0)
 {
     if constexpr (MODEL == 1) {
         if constexpr (LDS) bl_eval_sites_rn<KS, KO, CT, BL_RN_NB, 1>(ct, ld_or_stride, cnt, T, J, K, beta, alpha, ll, gb, ga);
@@ -1249,14 +1250,14 @@ __device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ 
         if constexpr (LDS) bl_eval_sites_rn<KS, KO, CT, BL_RN_NB_SMALL, 2>(ct, ld_or_stride, cnt, T, J, K, beta, alpha, ll, gb, ga);
     } else if constexpr (LDS) {
         switch (J) { // wave-uniform
-        case 1: bl_eval_sites_lds<KS, KO, 1, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 2: bl_eval_sites_lds<KS, KO, 2, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 3: bl_eval_sites_lds<KS, KO, 3, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 4: bl_eval_sites_lds<KS, KO, 4, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 5: bl_eval_sites_lds<KS, KO, 5, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 6: bl_eval_sites_lds<KS, KO, 6, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        case 8: bl_eval_sites_lds<KS, KO, 8, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
-        default: bl_eval_sites_lds<KS, KO, 0, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga); break;
+        case 1: bl_eval_sites_lds<KS, KO, 1, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off); break;
+        case 2: bl_eval_sites_lds<KS, KO, 2, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off); break;
+        case 3: bl_eval_sites_lds<KS, KO, 3, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off); break;
+        case 4: bl_eval_sites_lds<KS, KO, 4, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off); break;
+        case 5: bl_eval_sites_lds<KS, KO, 5, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off); break;
+        case 6: bl_eval_sites_lds<KS, KO, 6, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off); break;
+        case 8: bl_eval_sites_lds<KS, KO, 8, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off); break;
+        default: bl_eval_sites_lds<KS, KO, 0, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off); break;
         }
     } else {
         bl_eval_sites_hbm<KS, KO, CT>(ct, grows, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga);
@@ -1265,12 +1266,15 @@ __device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ 
 
 // Transpose this workgroup's site slice [s0, s0+cnt) of the HBM rows (coalesced reads along the
 // site axis) into LDS pair records: element `pos` of site i lands at pair (i/2), float 2*pos + (i&1).
+// Joint-species datasets (species > 0): the HBM rows hold the site covariates once and then one block of visit / ka / kb rows
+// per species; every species gets a full record region of its own in LDS (lds_off floats from the first).
 __device__ __forceinline__ void bl_stage_records(const float *__restrict__ rows, int n_stride, int s0, int cnt,
-                                                 int T, int J, int KS, int KO, int pstride, int nthreads)
+                                                 int T, int J, int KS, int KO, int pstride, int nthreads, int species = 0, int lds_off = 0)
 {
-    float *dst = bl_lds_f(BL_OFF_DATA);
+    float *dst = bl_lds_f(BL_OFF_DATA) + lds_off;
     const int xq = bl_round4(KS), pb = bl_period_block(J, KO), V = T * J, vw = KO + 1;
     const int n_rows = KS + V * vw + 2 * T;
+    const int species_rows = species * (V * vw + 2 * T);
     if (cnt & 1) { // dummy second site of the last pair: all zeros (its contributions are masked)
         float *last = dst + (size_t)(cnt >> 1) * pstride;
         for (int e = threadIdx.x; e < xq + T * pb; e += nthreads) last[2 * e + 1] = 0.0f;
@@ -1283,7 +1287,7 @@ __device__ __forceinline__ void bl_stage_records(const float *__restrict__ rows,
             pos = xq + t * pb + j * vw + k;
         } else if (r < KS + V * vw + T) pos = xq + (r - KS - V * vw) * pb + J * vw;
         else pos = xq + (r - KS - V * vw - T) * pb + J * vw + 1;
-        const float *src = rows + (size_t)r * n_stride + s0;
+        const float *src = rows + (size_t)(r < KS ? r : r + species_rows) * n_stride + s0;
         for (int i = threadIdx.x; i < cnt; i += nthreads) dst[(size_t)(i >> 1) * pstride + 2 * pos + (i & 1)] = src[i];
     }
 }
@@ -1305,9 +1309,9 @@ template <int MODEL> __device__ __forceinline__ int bl_model_dim(int Ks, int Ko,
 template <int MODEL> __device__ __forceinline__ constexpr int bl_layout_ko(int KO) { return KO + ((MODEL == 3 || MODEL == 4) ? 1 : 0); }
 
 template <int KS, int KO>
-__device__ __forceinline__ void bl_load_coefs(float (&beta)[KS + 1], float (&alpha)[KO + 1])
+__device__ __forceinline__ void bl_load_coefs(float (&beta)[KS + 1], float (&alpha)[KO + 1], int coef_off = 0)
 {
-    const float *c = bl_lds_f(BL_OFF_COEF); // unused (padded) slots were zeroed once at kernel start
+    const float *c = bl_lds_f(BL_OFF_COEF) + coef_off; // unused (padded) slots were zeroed once at kernel start
 #pragma unroll
     for (int k = 0; k <= KS; k++) beta[k] = c[k];
 #pragma unroll
@@ -1320,7 +1324,7 @@ __device__ __forceinline__ void bl_load_coefs(float (&beta)[KS + 1], float (&alp
 // lane 63 holds the totals and stores them.  Cross-wave / cross-workgroup sums are done in f64.
 template <int KS, int KO, bool EXTRA = false>
 __device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, const float (&gb)[KS + 1], const float (&ga)[KO + 1],
-                                                        float gextra = 0.0f)
+                                                        float gextra = 0.0f, int row_stride = BL_PART_STRIDE, int row_off = 0)
 {
     constexpr int NV = KS + KO + 3 + (EXTRA ? 1 : 0);
     const int wave = cwave, lane = threadIdx.x & 63;
@@ -1333,7 +1337,7 @@ __device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, con
     if constexpr (EXTRA) v[KS + KO + 3] = gextra;
     bl_wave_sum_vec_l63<NV>(v);
     if (lane == 63) {
-        float *part = bl_lds_f(BL_OFF_PART) + wave * BL_PART_STRIDE;
+        float *part = bl_lds_f(BL_OFF_PART) + wave * row_stride + row_off;
 #pragma unroll
         for (int k = 0; k < NV; k++) part[k] = v[k];
     }
@@ -1341,13 +1345,22 @@ __device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, con
 
 // Phase A of one evaluation for a compute thread `ct` of the workgroup: coefficients from LDS, the
 // workgroup's site slice, wave partials into the LDS table.  Shared by the NUTS and logp kernels.
+// Joint-species layouts (n_species > 1; LDS-staged occu and false-positive forms): species s keeps its coefficients at
+// s * BL_SP_COEF(KS, KO) of the coefficient block (the shared false-positive coordinate after the last species), its records at
+// s * sp_lds floats of the data region, and its partial sums at s * BL_SP_PART(KS, KO) of a wave's row (row stride
+// n_species * BL_SP_PART).  One species: the round-1 layout (row stride BL_PART_STRIDE), unchanged.
+#define BL_SP_COEF(KS, KO) ((KS) + (KO) + 2)
+#define BL_SP_PART(KS, KO) ((KS) + (KO) + 4)
+#define BL_PART_FLOATS 384 // floats between BL_OFF_PART and BL_OFF_CKR
 template <int KS, int KO, bool LDS, int MODEL, int CW>
 __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__restrict__ grows, int ld_or_stride, int cnt,
                                            int T, int J, int max_abundance, int fp_mode, const float *__restrict__ tab = nullptr,
-                                           int tab_ld = 0)
+                                           int tab_ld = 0, int n_species = 1, int sp_lds = 0)
 {
+    const int row_stride = n_species > 1 ? n_species * BL_SP_PART(KS, KO) : BL_PART_STRIDE;
+    for (int sp = 0; sp < n_species; sp++) {
     float beta[KS + 1], alpha[KO + 1];
-    bl_load_coefs<KS, KO>(beta, alpha);
+    bl_load_coefs<KS, KO>(beta, alpha, sp * BL_SP_COEF(KS, KO));
     float ll = 0.0f, gb[KS + 1], ga[KO + 1];
 #pragma unroll
     for (int k = 0; k <= KS; k++) gb[k] = 0.0f;
@@ -1356,9 +1369,9 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
     if constexpr (MODEL == 2) {
         static_assert(LDS, "false-positive model: LDS records only");
         float gphi = 0.0f;
-        const BlFpScalars fp = bl_fp_scalars(bl_lds_f(BL_OFF_COEF)[KS + KO + 3], fp_mode == 1);
-        bl_eval_sites_fp<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi);
-        bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi);
+        const BlFpScalars fp = bl_fp_scalars(bl_lds_f(BL_OFF_COEF)[n_species * BL_SP_COEF(KS, KO) + 1], fp_mode == 1);
+        bl_eval_sites_fp<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
+        bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi, row_stride, sp * BL_SP_PART(KS, KO));
     } else if constexpr (MODEL == 4) {
         static_assert(LDS, "N-mixture model: LDS records only");
         bl_eval_sites_nmix<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, max_abundance, tab, tab_ld, beta, alpha, ll, gb, ga);
@@ -1370,7 +1383,8 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         bl_eval_sites_cop<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi);
         bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi);
     } else {
-        bl_eval_sites<KS, KO, LDS, MODEL, CW * 64>(ct, grows, ld_or_stride, cnt, T, J, max_abundance, beta, alpha, ll, gb, ga);
-        bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga);
+        bl_eval_sites<KS, KO, LDS, MODEL, CW * 64>(ct, grows, ld_or_stride, cnt, T, J, max_abundance, beta, alpha, ll, gb, ga, sp * sp_lds);
+        bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga, 0.0f, row_stride, sp * BL_SP_PART(KS, KO));
+    }
     }
 }

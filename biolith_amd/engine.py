@@ -81,6 +81,12 @@ class OccuDataset:
         self.N, self.T, self.J, self.Ks, self.Ko, self.S = N, T, J, Ks, Ko, Y.shape[0]
         # occu_fp: trailing phi = logit(false-positive rate); occu_cop with a false-positive rate: phi = log(rate)
         self.D = Ks + Ko + 2 + (1 if model == "occu_fp" or (model == "occu_cop" and fp_mode is not None) else 0)
+        if self.S > 1:
+            # several species in one handle: ONE chain over theta = [species 0: beta, alpha | species 1: ... | (shared phi)]
+            # (the species plate of occu.py:182-186 under one NUTS); occu with or without false positives
+            if model not in ("occu", "occu_fp"):
+                raise NotImplementedError(f"{model}: one species per dataset (joint sampling is built for occu / occu_fp)")
+            self.D += (self.S - 1) * (Ks + Ko + 2)
         self.device = device
         pb = _ffi.bl_normal_prior(float(prior_beta[0]), float(prior_beta[1]))
         pa = _ffi.bl_normal_prior(float(prior_alpha[0]), float(prior_alpha[1]))

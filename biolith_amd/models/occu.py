@@ -106,10 +106,8 @@ def occu(
     if coords is not None:
         unsupported.append("coords (spatial HSGP effect, occu.py:159-165)")
     fp_mode = "constant" if false_positives_constant else ("unoccupied" if false_positives_unoccupied else None)
-    if fp_mode is not None:
-        # prob_fp_* is sampled outside the species plate (occu.py:146-157): with several species it couples them
-        if n_species != 1:
-            unsupported.append("false positives with n_species > 1 (the rate is shared across species, occu.py:146-157)")
+    # (prob_fp_* is sampled outside the species plate, occu.py:146-157: several species share it -- fit() then samples all
+    # species under one chain)
     if site_random_effects or obs_random_effects:
         # site_re_sd / obs_re_sd are sampled outside the species plate (occu.py:170-173): several species share them
         if n_species != 1:

@@ -74,6 +74,7 @@ def fit(
     if not devices:
         raise ValueError("devices must name at least one GPU")
     chain_offset = int(kwargs.pop("chain_offset", 0))
+    joint_species = bool(kwargs.pop("joint_species", True))
 
     site_covs, obs_covs, obs, session_duration, site_names, obs_names = prepare_data(
         site_covs, obs_covs, obs, session_duration
@@ -89,20 +90,38 @@ def fit(
     # so the joint posterior is a product over species: each species gets its own device dataset and
     # its own chains (distinct RNG streams); the draws are stacked on the trailing species axis.
     n_species = spec.obs.shape[0]
+    # Several species: the reference samples ONE chain over all species' coefficients (the species plate sits inside one NUTS,
+    # occu.py:182-186; a false-positive rate is shared across the plate, occu.py:146-157).  occu with or without false positives
+    # does the same here -- one device dataset holding all species, theta = [species 0: beta, alpha | species 1: ... | (phi)], one
+    # step size, one tree per transition -- as long as the joint vector fits the kernel's 60 lanes and the records fit LDS
+    # (``joint_species=False`` forces the species-by-species form, which has the same marginals but its own adaptation per species).
+    joint = n_species > 1 and spec.model in ("occu", "occu_fp") and joint_species
     # chain_method="parallel" (fit.py:109-113) deals chains over the local devices; here ``devices``
     # names the GPUs, chains go to them in contiguous blocks, every shard is an asynchronous launch and
     # the draws are concatenated on the chain axis afterwards (no exchange while sampling).
     world = len(devices)
-    jobs = []
-    for sp in range(n_species):
-        for r, dev in enumerate(devices):
-            count, first = shard_chains(num_chains, world, r)
-            if count == 0:
-                continue
-            ds = OccuDataset(spec.site_covs, spec.obs_covs, spec.obs[sp:sp + 1], spec.prior_beta, spec.prior_alpha,
-                             device=dev, model=spec.model, **engine_options(spec))
-            jobs.append((sp, ds, dict(num_warmup=num_warmup, num_samples=num_samples, num_chains=count,
-                                      seed=random_seed, chain_offset=chain_offset + sp * num_chains + first)))
+
+    def make_jobs(joint):
+        jobs = []
+        for sp in ([0] if joint else range(n_species)):
+            for r, dev in enumerate(devices):
+                count, first = shard_chains(num_chains, world, r)
+                if count == 0:
+                    continue
+                ds = OccuDataset(spec.site_covs, spec.obs_covs, spec.obs if joint else spec.obs[sp:sp + 1], spec.prior_beta, spec.prior_alpha,
+                                 device=dev, model=spec.model, **engine_options(spec))
+                jobs.append((sp, ds, dict(num_warmup=num_warmup, num_samples=num_samples, num_chains=count,
+                                          seed=random_seed, chain_offset=chain_offset + sp * num_chains + first)))
+        return jobs
+
+    try:
+        jobs = make_jobs(joint)
+    except NotImplementedError:
+        if not joint or spec.model == "occu_fp":   # (a shared false-positive rate cannot be sampled species by species)
+            raise
+        joint = False
+        jobs = make_jobs(False)
+    n_units = 1 if joint else n_species
 
     def run_all():
         t_end = None if timeout is None else time.monotonic() + float(timeout) + 1.0
@@ -130,7 +149,7 @@ def fit(
             # the gather of fit.py:132, as ONE RCCL all-gather per species behind the C-ABI (bl_gather_draws): every
             # device contributes the result block of its chains; the host reads all of them from the first device
             out = {}
-            for sp in range(n_species):
+            for sp in range(n_units):
                 mine = [(ds, kw["num_chains"]) for s, ds, kw in jobs if s == sp]
                 out[sp] = gather_draws(comms, [ds for ds, _ in mine], [c for _, c in mine])
             return out
@@ -158,7 +177,7 @@ def fit(
         for c in comms:
             c.close()
     per_species = []
-    for sp in range(n_species):
+    for sp in range(n_units):
         if use_rccl:
             ds0 = next(ds for s, ds, _ in jobs if s == sp)
             results[sp].comm_init_ms = comms[0].init_ms
@@ -166,7 +185,22 @@ def fit(
             continue
         shard = [(ds, res) for (s, ds, _), res in zip(jobs, results) if s == sp]
         per_species.append((shard[0][0], _concat_chains([r for _, r in shard])))
-    mcmc = _assemble(per_species, spec, num_warmup)
+    joint_result = None
+    if joint:
+        # one launch holds every species: cut its draws into the per-species blocks the site assembly works on (deterministic
+        # sites come from one plain handle per species; the shared false-positive coordinate rides along with every block)
+        import copy
+
+        ds_joint, joint_result = per_species[0]
+        Dsp = ds_joint.Ks + ds_joint.Ko + 2
+        per_species = []
+        for sp in range(n_species):
+            part = copy.copy(joint_result)
+            part.draws = np.ascontiguousarray(np.concatenate([joint_result.draws[:, :, sp * Dsp:(sp + 1) * Dsp],
+                                                              joint_result.draws[:, :, n_species * Dsp:]], axis=2))
+            per_species.append((OccuDataset(spec.site_covs, spec.obs_covs, spec.obs[sp:sp + 1], spec.prior_beta, spec.prior_alpha,
+                                            device=devices[0], model=spec.model, **engine_options(spec)), part))
+    mcmc = _assemble(per_species, spec, num_warmup, joint_result)
     samples = rename_samples(mcmc.get_samples(), site_names, obs_names)
     return FitResult(samples, mcmc)
 
@@ -200,7 +234,7 @@ def _concat_chains(parts):
     return res
 
 
-def _assemble(per_species, spec, num_warmup) -> HipMCMC:
+def _assemble(per_species, spec, num_warmup, joint_result=None) -> HipMCMC:
     """Draws (C, S, D) per species -> the sample sites the reference's model emits (occu.py:185-228)."""
     ds0, res0 = per_species[0]
     C, S, D = res0.draws.shape
@@ -288,7 +322,9 @@ def _assemble(per_species, spec, num_warmup) -> HipMCMC:
     import copy
 
     res = copy.copy(res0)
-    if nsp > 1:
+    if joint_result is not None:
+        res = copy.copy(joint_result)    # one chain over all species: its per-draw fields are the sampler's own
+    elif nsp > 1:
         res.diverging = np.logical_or.reduce([r.diverging for _, r in per_species])
         res.num_steps = np.sum([r.num_steps for _, r in per_species], axis=0)
         res.accept_prob = np.mean([r.accept_prob for _, r in per_species], axis=0)
@@ -296,7 +332,8 @@ def _assemble(per_species, spec, num_warmup) -> HipMCMC:
         res.n_leapfrog = np.sum([r.n_leapfrog for _, r in per_species], axis=0)
         res.kernel_ms = float(np.sum([r.kernel_ms for _, r in per_species]))
         res.inv_mass = np.concatenate([r.inv_mass for _, r in per_species], axis=1)
-    res.draws = np.concatenate([r.draws for _, r in per_species], axis=2) if nsp > 1 else res0.draws
+    if joint_result is None:
+        res.draws = np.concatenate([r.draws for _, r in per_species], axis=2) if nsp > 1 else res0.draws
     # occu emits "psi" (occu.py:207); occu_rn emits "abundance" = exp(linear predictor) (occu_rn.py:192)
     first = "abundance" if spec.model in ("occu_rn", "nmixture") else "psi"
     # occu_cop's replicate-level site is the detection RATE exp(linear predictor) (occu_cop.py:236-243)

@@ -60,6 +60,7 @@ def lib():
             L.orc_data_set_re.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_prior_family.argtypes = [C.c_void_p, C.c_int, C.c_int]
             L.orc_data_set_cs.argtypes = [C.c_void_p, dp, dp, dp]
+            L.orc_data_set_species.argtypes = [C.c_void_p, C.c_int, dp, C.POINTER(C.c_ubyte)]
             L.orc_potential_grad.restype = C.c_double
             L.orc_potential_grad.argtypes = [C.c_void_p, dp, dp]
             L.orc_rng_streams.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
@@ -101,8 +102,11 @@ class OracleData:
         X = _as_f32_f64(site_covs)
         W = _as_f32_f64(obs_covs)
         Y = _as_f32_f64(obs)
+        Y_all = None
         if Y.ndim == 4:
-            assert Y.shape[0] == 1, "oracle handles one species"
+            if Y.shape[0] > 1:   # several species under ONE chain (occu.py:182-186): occu with or without false positives
+                assert model in ("occu", "occu_fp"), "joint species: occu / occu_fp"
+                Y_all = np.ascontiguousarray(Y)
             Y = np.ascontiguousarray(Y[0])
         assert X.ndim == 2 and W.ndim == 4 and Y.ndim == 3
         N, Ks = X.shape
@@ -147,6 +151,16 @@ class OracleData:
             lib().orc_data_set_re(self._h, int(bool(site_random_effects)), int(bool(obs_random_effects)),
                                   float(prior_site_re_sd), float(prior_obs_re_sd))
             self.D = int(lib().orc_data_dim(self._h))
+        self.n_species = 1
+        if Y_all is not None:
+            # theta = [species 0: beta, alpha | species 1: ... | (phi)]
+            cov_nan = (np.isnan(np.asarray(obs_covs, dtype=np.float64)).any(-1)
+                       | np.isnan(np.asarray(site_covs, dtype=np.float64)).any(-1)[:, None, None]).astype(np.uint8)
+            cov_nan = np.ascontiguousarray(cov_nan)
+            lib().orc_data_set_species(self._h, int(Y_all.shape[0]), _dp(Y_all), cov_nan.ctypes.data_as(C.POINTER(C.c_ubyte)))
+            self.n_species = int(Y_all.shape[0])
+            self.D = int(lib().orc_data_dim(self._h))
+            self.Y_all = Y_all
         # prior family of beta / alpha: "normal" (occu.py:28-29) or "laplace" (utils/grid_search.py:366-371), same (loc, scale)
         assert all(f in ("normal", "laplace") for f in prior_family)
         self.prior_family = tuple(prior_family)

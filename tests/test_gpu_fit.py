@@ -58,11 +58,13 @@ def test_occu_multi_species():  # occu.py:478-492
     assert results.samples["psi"].shape[-1] == 2
     assert results.samples["psi"].shape == (100, 1, 30, 2)
     assert results.samples["cov_state_0"].shape == (100, 2) and results.samples["prob_detection"].shape == (100, 52, 1, 30, 2)
-    # species are independent given the shared covariates: species 0 alone gives the same draws
+    assert not np.allclose(results.samples["cov_det_0"][:, 0], results.samples["cov_det_0"][:, 1])
+    # the species-by-species form (joint_species=False): species are independent given the shared covariates, so species 0
+    # alone gives the same draws (the default is ONE chain over all species, as in the reference: tests/test_gpu_species.py)
+    sep = fit(occu, **data, num_chains=1, num_samples=100, num_warmup=100, joint_species=False)
     one = dict(data, obs=data["obs"][:1])
     r1 = fit(occu, **one, num_chains=1, num_samples=100, num_warmup=100)
-    assert np.array_equal(r1.samples["cov_state_0"][:, 0], results.samples["cov_state_0"][:, 0])
-    assert not np.allclose(results.samples["cov_det_0"][:, 0], results.samples["cov_det_0"][:, 1])
+    assert np.array_equal(r1.samples["cov_state_0"][:, 0], sep.samples["cov_state_0"][:, 0])
 
 
 def test_fit_is_seeded():

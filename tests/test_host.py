@@ -89,10 +89,11 @@ def test_occu_validates_like_reference():
     assert fu.extras == dict(fp_mode="unoccupied", prior_fp=(1.0, 9.0))
     with pytest.raises(NotImplementedError, match="Beta"):
         occu(g["site_covs"], g["obs_covs"], obs=g["obs"], false_positives_constant=True, prior_prob_fp_constant=Normal())
-    with pytest.raises(NotImplementedError, match="shared across species"):
-        occu(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]), false_positives_constant=True)
+    # several species share the rate (occu.py:146-157): accepted, fit() samples all species under one chain
+    fp2 = occu(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]), false_positives_constant=True)
+    assert fp2.model == "occu_fp" and fp2.n_species == 2
     two = occu(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]))
-    assert two.n_species == 2 and two.shape["S"] == 2  # the species plate is sampled species by species
+    assert two.n_species == 2 and two.shape["S"] == 2
     assert occu(g["site_covs"], g["obs_covs"], obs=g["obs"], prior_beta=Normal(0.5, 2.0)).prior_beta == (0.5, 2.0)
 
     class Cauchy:
