@@ -1391,7 +1391,8 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.wide = wide;
     p.xchg = ds->d_xchg;
     p.cold = d_cold;
-    p.spin_limit = 1u << 18;
+    p.spin_limit = 5000000u; // microseconds (BIOLITH_HIP_SPIN_US overrides: tests of the bound)
+    { const char *e = getenv("BIOLITH_HIP_SPIN_US"); if (e && atoi(e) > 0) p.spin_limit = (unsigned)atoi(e); }
     {   // developer knobs (A/B measurements): exchange form and poll spacing
         const char *e1 = getenv("BIOLITH_HIP_NO_LOCAL"), *e2 = getenv("BIOLITH_HIP_POLL_SLEEP");
         p.allow_local = (e1 && e1[0] == '1') ? 0 : 1;

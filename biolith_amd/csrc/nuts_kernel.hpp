@@ -109,7 +109,8 @@ struct BlNutsParams {
     int pitch;                     // granules between consecutive workgroup records (>= nvp)
     int n_species;                 // > 1: ONE chain over all species' coefficients (occu.py:182-186); layouts in occu_device.hpp (BL_SP_*)
     int sp_lds;                    // floats between two species' record regions in LDS
-    unsigned spin_limit;
+    unsigned spin_limit;           // bound of an exchange's wait in MICROSECONDS of wall time (a peer that is late -- late-resident,
+                                   // descheduled by a co-tenant or a profiler -- is not an error for a while; one that vanished is)
     unsigned long long *xchg;      // [C][2][k][nvp] granules, zeroed before every launch
     const BlNutsCold *cold;
 };
@@ -176,6 +177,20 @@ __device__ __forceinline__ unsigned long long bl_poll_load(const unsigned char *
 {
     return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(base + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+
+// Bounded wait of the exchange polls: the wall clock (100 MHz) is looked at every 256th unsuccessful round only
+struct BlSpinBound {
+    unsigned spins = 0;
+    long long deadline = 0;
+    __device__ __forceinline__ bool expired(unsigned limit_us)
+    {
+        if ((++spins & 255u) != 0u) return false;
+        const long long now = (long long)wall_clock64();
+        if (deadline == 0) { deadline = now + (long long)limit_us * 100; return false; }
+        return now > deadline;
+    }
+};
 
 template <int KS, int KO, bool LDS, int MODEL, int CW>
 __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsParams p)
@@ -695,7 +710,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             if (one_batch) {
                 // common shape: one round of <= 8 loads per lane covers all k records
                 unsigned long long v[8];
-                unsigned spins = 0;
+                BlSpinBound bound;
                 while (true) {
 #ifdef BL_STAMPS
                     const long long st_r0 = (long long)clock64();
@@ -718,17 +733,17 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                     st_sub[3] += (long long)clock64() - st_r0; // cycles in poll rounds (loads issued -> tags checked)
 #endif
                     if (all_in) break;
-                    if (++spins > p.spin_limit) { timed_out = true; break; }
+                    if (bound.expired(p.spin_limit)) { timed_out = true; break; }
                     if (!local)
                         for (int z = 0; z < p.poll_sleep; z++) __builtin_amdgcn_s_sleep(1);
                 }
-                BL_COUNT_SPINS(spins)
+                BL_COUNT_SPINS(bound.spins)
 #pragma unroll
                 for (int q = 0; q < 8; q++) acc += (double)(pval[q] * __uint_as_float((unsigned)v[q]));
             } else {
                 for (int p0 = 0; p0 < p.k && !timed_out; p0 += 8 * G) {
                     unsigned long long v[8];
-                    unsigned spins = 0;
+                    BlSpinBound bound;
                     while (true) {
                         unsigned bad = 0u;
 #pragma unroll
@@ -739,7 +754,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #pragma unroll
                         for (int q = 0; q < 8; q++) bad |= ((unsigned)(v[q] >> 32)) ^ epoch;
                         if (__all(bad == 0u)) break;
-                        if (++spins > p.spin_limit) { timed_out = true; break; }
+                        if (bound.expired(p.spin_limit)) { timed_out = true; break; }
                         if (!local)
                             for (int z = 0; z < p.poll_sleep; z++) __builtin_amdgcn_s_sleep(1);
                     }

@@ -191,12 +191,12 @@ __device__ __forceinline__ bool bl_re_exchange(BlReXchg &x, double *out, float *
     }
     for (int t = tid; t < x.k * nv; t += BL_RE_NT) {
         const int w = t / nv, v = t - w * nv;
-        unsigned spins = 0;
+        BlSpinBound bound;
         unsigned long long gr;
         while (true) {
             gr = __hip_atomic_load(base + (size_t)w * NRED + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned)(gr >> 32) == x.epoch) break;
-            if (++spins > x.spin_limit) { *lds_flag = 1; break; }
+            if (bound.expired(x.spin_limit)) { *lds_flag = 1; break; }
             if (!x.local) __builtin_amdgcn_s_sleep(1);
         }
         scr2[w * NRED + v] = __uint_as_float((unsigned)gr);
@@ -598,7 +598,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
     float *hot = m.lds_hot ? bl_re_lds + (m.lds_rows ? (size_t)m.n_rows * R.nloc : 0) : sv; // (generic pointers: LDS or device memory)
     auto V = [&](int slot) -> float * { return (slot < RE_HOT ? hot : sv) + (size_t)slot * R.dl_max; };
     uint32_t *rng_base = R.rng + ((size_t)chain * R.k + wg) * (R.dl_max + 2) * 4;
-    BlReXchg xc{R.xchg, R.k, wg, chain, 0u, 1u << 22, false};
+    BlReXchg xc{R.xchg, R.k, wg, chain, 0u, 5000000u /* microseconds */, false};
     const float xcc = (float)bl_xcc_id();
     if (tid == 0) xflag = 0;
     const int S = R.num_samples, W = R.num_warmup, total = W + S;
