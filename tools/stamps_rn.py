@@ -2,7 +2,7 @@ import contextlib, io, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["BIOLITH_HIP_LIB"] = os.path.join(ROOT, "biolith_amd", "lib", "libbiolith_hip_stamps.so")
+os.environ.setdefault("BIOLITH_HIP_LIB", os.path.join(ROOT, "biolith_amd", "lib", "libbiolith_hip_stamps.so"))
 from biolith_amd.engine import OccuDataset
 from biolith_amd.models import simulate_rn
 with contextlib.redirect_stdout(io.StringIO()):
