@@ -36,6 +36,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_logp_kernel(const BlLogpPara
         grows = p.dd.rows + s0;
         ld = p.dd.n_stride;
     }
+    if constexpr (BL_RN_QUAD && (MODEL == 1 || MODEL == 5)) bl_rn_fill_lgamma(p.max_abundance, 64 * (CW + 1)); // (the barrier below publishes it)
     float *sh_coef = bl_lds_f(BL_OFF_COEF);
     if (tid < 64) sh_coef[tid] = 0.0f;
     __syncthreads();

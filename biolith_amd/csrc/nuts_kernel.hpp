@@ -218,6 +218,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         grows = p.rows + s0;
         ld = p.n_stride;
     }
+    if constexpr (BL_RN_QUAD && (MODEL == 1 || MODEL == 5)) bl_rn_fill_lgamma(p.max_abundance, 64 * (CW + 1)); // (the barrier below publishes it)
     float *sh_coef = bl_lds_f(BL_OFF_COEF);
     int *sh_flag = bl_lds_i(BL_OFF_FLAG);
     float *sh_ckr = bl_lds_f(BL_OFF_CKR), *sh_ckrs = bl_lds_f(BL_OFF_CKRS);

@@ -7,6 +7,7 @@
 //
 // Written for wave64 / CDNA4 only.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -765,6 +766,9 @@ __device__ __forceinline__ void bl_eval_sites_cop(int ct, int pstride, int cnt, 
 
 // lgamma(n + 1) for n < 128 (occu_rn, nmixture)
 #define BL_RN_NB 128 // upper bound of the per-lane table over N (max_abundance <= 127)
+#ifndef BL_RN_QUAD
+#define BL_RN_QUAD 0 // occu_rn: 1 = four lanes per site (bl_eval_sites_rn_quad: parity-green, not yet faster -- see its header), 0 = one lane per site
+#endif
 __device__ constexpr float BL_LGAMMA1P[128] = {0.000000000e+00f, 0.000000000e+00f, 6.931471806e-01f, 1.791759469e+00f, 3.178053830e+00f, 4.787491743e+00f, 6.579251212e+00f, 8.525161361e+00f, 1.060460290e+01f, 1.280182748e+01f, 1.510441257e+01f, 1.750230785e+01f, 1.998721450e+01f, 2.255216385e+01f, 2.519122118e+01f, 2.789927138e+01f, 3.067186011e+01f, 3.350507345e+01f, 3.639544521e+01f, 3.933988419e+01f, 4.233561646e+01f, 4.538013890e+01f, 4.847118135e+01f, 5.160667557e+01f, 5.478472940e+01f, 5.800360522e+01f, 6.126170176e+01f, 6.455753863e+01f, 6.788974314e+01f, 7.125703897e+01f, 7.465823635e+01f, 7.809222355e+01f, 8.155795946e+01f, 8.505446702e+01f, 8.858082754e+01f, 9.213617560e+01f, 9.571969454e+01f, 9.933061245e+01f, 1.029681986e+02f, 1.066317603e+02f, 1.103206397e+02f, 1.140342118e+02f, 1.177718814e+02f, 1.215330815e+02f, 1.253172711e+02f, 1.291239336e+02f, 1.329525750e+02f, 1.368027226e+02f, 1.406739236e+02f, 1.445657439e+02f, 1.484777670e+02f, 1.524095926e+02f, 1.563608363e+02f, 1.603311282e+02f, 1.643201123e+02f, 1.683274454e+02f, 1.723527971e+02f, 1.763958484e+02f, 1.804562914e+02f, 1.845338289e+02f, 1.886281734e+02f, 1.927390473e+02f, 1.968661817e+02f, 2.010093164e+02f, 2.051681995e+02f, 2.093425868e+02f, 2.135322415e+02f, 2.177369341e+02f, 2.219564418e+02f, 2.261905483e+02f, 2.304390436e+02f, 2.347017234e+02f, 2.389783896e+02f, 2.432688490e+02f, 2.475729141e+02f, 2.518904022e+02f, 2.562211356e+02f, 2.605649410e+02f, 2.649216498e+02f, 2.692910977e+02f, 2.736731243e+02f, 2.780675734e+02f, 2.824742927e+02f, 2.868931333e+02f, 2.913239501e+02f, 2.957666014e+02f, 3.002209486e+02f, 3.046868568e+02f, 3.091641936e+02f, 3.136528299e+02f, 3.181526396e+02f, 3.226634991e+02f, 3.271852877e+02f, 3.317178872e+02f, 3.362611820e+02f, 3.408150589e+02f, 3.453794071e+02f, 3.499541180e+02f, 3.545390855e+02f, 3.591342054e+02f, 3.637393756e+02f, 3.683544961e+02f, 3.729794689e+02f, 3.776141979e+02f, 3.822585888e+02f, 3.869125491e+02f, 3.915759882e+02f, 3.962488171e+02f, 4.009309483e+02f, 4.056222962e+02f, 4.103227765e+02f, 4.150323067e+02f, 4.197508056e+02f, 4.244781934e+02f, 4.292143919e+02f, 4.339593240e+02f, 4.387129142e+02f, 4.434750881e+02f, 4.482457727e+02f, 4.530248962e+02f, 4.578123880e+02f, 4.626081785e+02f, 4.674121996e+02f, 4.722243839e+02f, 4.770446655e+02f, 4.818729792e+02f, 4.867092611e+02f, 4.915534482e+02f};
 
 // --------------------------------------------------------------- N-mixture (nmixture, MODEL 4) ----
@@ -1237,6 +1241,276 @@ __device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, i
     }
 }
 
+// ---- occu_rn, FOUR LANES PER SITE: lane sub = 0..3 of a quad owns the terms n = sub + 4 m of its site's sum over N ----
+// The lane-per-site form above runs every lane to the wave's largest n-cutoff -- about 20-35 at BASELINE.json's config 4, where a
+// site needs n <= 7 on average -- and the slowest of a chain's waves sets the tick.  Here a site's n-range is spread over the four
+// lanes of a quad, so the per-lane trip count is a quarter of the (16-site) wave's cutoff, a wave makes four passes whose cutoffs
+// average out, and the table is 32 registers per lane:
+//   * the recursions advance four steps at once: b_(n+4) = b_n q^4 + b_4, b'_(n+4) = b'_n q^4 + 4 q^3 b_n + b'_4 (b_4 = 1+q+q^2+q^3,
+//     b'_4 = 1+2q+3q^2), started at b_sub, b'_sub -- no transcendental to start them;
+//   * lgamma(n + 1) comes from a 128-entry LDS table (BL_OFF_LGT, filled at kernel start; 3e38 beyond max_abundance);
+//   * the per-site sums (prior normaliser, posterior maximum / sums, E[n], each visit's gradient sum) are folded over the quad by
+//     two DPP steps; all four lanes then hold the site's totals and lane sub = 0 adds them to the wave's accumulators;
+//   * numpyro's floor of a non-detection (max(n log q, log eps)) is applied to every non-detection visit and every n -- at a
+//     quarter of the terms per lane that is cheaper than deciding where it matters.
+// Arithmetic as in bl_eval_sites_rn (same bounds, cutoffs and log2 units); the n = 0 term (detections impossible: numpyro's clamp
+// tiny) lives in lane 0's slot 0.
+// STATE (round 2): passes every occu_rn parity test (`make variant NAME=rnq EXTRA=-DBL_RN_QUAD=1`), but runs 53.6 us per leapfrog at
+// config 4 against 19.9 for the lane-per-site form: with <= 8 terms per lane the per-visit work (u, exp, log, rcp: ~25 instructions)
+// that each of the four loops over the visits repeats in all four lanes dominates -- 1 600 visit evaluations per 64 sites against
+// 30.  Next: evaluate each visit ONCE per pass in the lane j & 3 that already does so in A0, keep (c, q, r, log2 q, sigma(-u)) there and
+// broadcast them with quad_perm DPP in the later loops (5 moves instead of 25 instructions + 3 transcendentals); then the
+// instruction count per 64 sites is about the old form's, and what remains is the gain in balance (tick = slowest wave).
+#define BL_RN_MQ 32       // table slots per lane (n = sub + 4 m < 128)
+#define BL_OFF_LGT 1296   // 128 floats inside the partial-sum region (occu_rn uses 3 x 48 floats of it)
+__device__ __forceinline__ float bl_quad_sum(float x) { x += bl_dpp<0xB1, 0xF>(x); x += bl_dpp<0x4E, 0xF>(x); return x; }
+__device__ __forceinline__ float bl_quad_max(float x) { x = fmaxf(x, bl_dpp<0xB1, 0xF>(x)); return fmaxf(x, bl_dpp<0x4E, 0xF>(x)); }
+__device__ __forceinline__ float bl_quad_min(float x) { x = fminf(x, bl_dpp<0xB1, 0xF>(x)); return fminf(x, bl_dpp<0x4E, 0xF>(x)); }
+// fill the lgamma table (every thread of the workgroup calls this once, before the first evaluation and a barrier)
+__device__ __forceinline__ void bl_rn_fill_lgamma(int K, int nthreads)
+{
+    float *lgt = bl_lds_f(BL_OFF_LGT);
+    for (int n = threadIdx.x; n < 128; n += nthreads) lgt[n] = n <= K ? BL_LGAMMA1P[n] : 3.0e38f;
+}
+// slots m = 0 .. (slots needed for n <= KB), fully unrolled in blocks of two under a wave-uniform guard
+#define BL_RNQ_LOOP_BEGIN(KB)                                                           \
+    _Pragma("unroll") for (int mb_ = 0; mb_ < MQ; mb_ += 2)                             \
+        if (4 * mb_ <= (KB)) {                                                          \
+            _Pragma("unroll") for (int m = mb_; m < mb_ + 2; m++) {                     \
+                float sb_ = subf;                                                       \
+                asm volatile("" : "+v"(sb_)); /* opaque: n is formed where it is used, not hoisted out of the visit loops (32 x per loop) */ \
+                const float fn = sb_ + (float)(4 * m);
+#define BL_RNQ_LOOP_END }}
+
+template <int KS, int KO, int CT>
+__device__ __forceinline__ void bl_eval_sites_rn_quad(int ct, int pstride, int cnt, int T, int J, int K,
+                                                      const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
+                                                      float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
+{
+    constexpr int XQ = (KS + 3) & ~3;
+    constexpr int SPR = CT / 4; // sites per round of the workgroup's compute threads
+    const int pb = bl_period_block(J, KO);
+    const float *data = bl_lds_f(BL_OFF_DATA);
+    const float *lgt = bl_lds_f(BL_OFF_LGT);
+    const float LOG_TINY = -87.33654475f, FL2 = -23.0f; // log(tiny_f32); log2(eps_f32)
+    const int sub = ct & 3, qi = ct >> 2;
+    const float subf = (float)sub;
+    const float *lgs = lgt + sub;
+    for (int i0 = 0; i0 < cnt; i0 += SPR) {
+        if (i0 + ((ct & ~63) >> 2) >= cnt) continue; // wave-uniform: this wave has no site in this round
+        const int i = min(i0 + qi, cnt - 1);
+        const float live = (i0 + qi < cnt && sub == 0) ? 1.0f : 0.0f; // (one lane of the quad carries the site's totals)
+        const bool real = i0 + qi < cnt;                                // quads beyond the slice shadow the last site
+        const float *rec = data + (size_t)(i >> 1) * pstride + (i & 1); // element e of this site: rec[2 e]
+        float x[KS > 0 ? KS : 1];
+        float eta = beta[0];
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            x[k] = rec[2 * k];
+            eta = fmaf(x[k], beta[k + 1], eta);
+        }
+        float ll_s = 0.0f, ga_s[KO + 1];
+#pragma unroll
+        for (int k = 0; k <= KO; k++) ga_s[k] = 0.0f;
+        const float lam = bl_exp_f(fminf(eta, 80.0f));
+        const float mzs = lam <= (float)K ? lam : fmaf((float)K, eta, -BL_LGAMMA1P[K]);
+        const float mz_lb = fmaxf(bl_rn_mode_lb(eta, (float)K), 0.0f); // lower bound of max_n p_n (p_0 = 0)
+        float deta = 0.0f;
+        for (int t = 0; t < T; t++) {
+            const float *pv = rec + 2 * (XQ + t * pb);
+            // ---- A0: the visits, dealt over the quad's lanes; u = c nu; log sigma(u) = log r (detection) / log q (non-detection) ----
+            float cnon = 0.0f, clr = 0.0f, ndet = 0.0f, lqmin = 0.0f;
+            for (int j = sub; j < J; j += 4) {
+                const float *wv = pv + 2 * (j * (KO + 1));
+                const float c = wv[0];
+                float u = c * alpha[0];
+#pragma unroll
+                for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
+                const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E);
+                const float logsig = fminf(u, 0.0f) - BL_LN2 * __builtin_amdgcn_logf(1.0f + e);
+                clr += c > 0.0f ? logsig : 0.0f;
+                ndet += c > 0.0f ? 1.0f : 0.0f;
+                const float ln = c < 0.0f ? logsig : 0.0f;
+                cnon += ln;
+                lqmin = fminf(lqmin, ln);
+            }
+            cnon = bl_quad_sum(cnon); clr = bl_quad_sum(clr); ndet = bl_quad_sum(ndet); lqmin = bl_quad_min(lqmin);
+            // ---- bounds and cutoffs (bl_eval_sites_rn's) ----
+            const float a = eta + cnon;
+            const float term0 = ndet * LOG_TINY;
+            const float m_lb = fmaxf(fmaxf(term0, a + clr), bl_rn_mode_lb(a, (float)K) + clr);
+            const float FL = -15.942385f;
+            const float nstar = lqmin < 0.0f ? FL * __builtin_amdgcn_rcpf(lqmin) : 0.0f;
+            const float Tq = lam - 0.9f - (fminf(mz_lb, m_lb) - 20.0f);
+            const float dmax = 0.5f * (Tq + __builtin_amdgcn_sqrtf(fmaf(Tq, Tq, 8.0f * lam * Tq)));
+            const int Kl = min(K, bl_wave_max_u(real ? (int)fminf(lam + dmax + 2.0f, 1.0e6f) : 0));
+            // The rest of the period for a table of MQ slots per lane (n < 4 MQ): the common short ranges run a compact, register-lean
+            // instantiation (8 slots: n < 32), longer ones 16 or 32 slots (one fully unrolled 32-slot body alone spills hundreds of
+            // registers, measured)
+            auto period_body = [&](auto mq_tag) {
+            constexpr int MQ = decltype(mq_tag)::value;
+            // ---- one scan over the lane's n <= Kl: prior sums, the posterior cutoff, the table's starting values ----
+            float LP[MQ];
+            float sz = 0.0f, b1 = 0.0f;
+            int nw = 0;
+            BL_RNQ_LOOP_BEGIN(Kl)
+                const float pn = fmaf(fn, eta, -lgs[4 * m]);
+                const float e = bl_exp_f(pn - mzs);
+                sz += e;
+                b1 = fmaf(fn, e, b1);
+                nw = (fmaf(cnon, fminf(fn, nstar), pn) >= m_lb - 20.0f) ? sub + 4 * m : nw;
+                LP[m] = (pn + fmaf(fn, cnon, clr)) * BL_LOG2E;
+            BL_RNQ_LOOP_END
+            sz = bl_quad_sum(sz); b1 = bl_quad_sum(b1);
+            const float log_z = mzs + BL_LN2 * __builtin_amdgcn_logf(sz);
+            const float en_prior = b1 * __builtin_amdgcn_rcpf(sz);
+            const int Kw = min(Kl, bl_wave_max_u(real ? nw : 0));
+            // ---- floors: numpyro's max(n log q, log eps) of every non-detection visit: LP += max(0, log2 eps - n log2 q) ----
+            // (every lane walks ALL visits from here on: it needs each visit's value at its own n)
+            for (int j = 0; j < J; j++) {
+                const float *wv = pv + 2 * (j * (KO + 1));
+                float u = wv[0] * alpha[0];
+#pragma unroll
+                for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
+                const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E);
+                const float lq2 = wv[0] < 0.0f ? fminf(u, 0.0f) * BL_LOG2E - __builtin_amdgcn_logf(1.0f + e) : 0.0f; // 0: no correction
+                if (!__any(lq2 * (float)Kw < FL2)) continue; // no lane's floor is reached inside the range
+                BL_RNQ_LOOP_BEGIN(Kw)
+                    LP[m] += fmaxf(fmaf(-fn, lq2, FL2), 0.0f);
+                BL_RNQ_LOOP_END
+            }
+            // ---- A1: LP[m] += sum over detection visits of log2 b_n, ten visits side by side, one log per n and group ----
+            for (int j0 = 0; j0 < J; j0 += BL_RN_GA) {
+                float q[BL_RN_GA];
+                bool det = false;
+#pragma unroll
+                for (int g = 0; g < BL_RN_GA; g++) {
+                    q[g] = 0.0f;
+                    if (j0 + g < J) { // wave-uniform
+                        const float *wv = pv + 2 * ((j0 + g) * (KO + 1));
+                        float u = wv[0] * alpha[0];
+#pragma unroll
+                        for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
+                        const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E);
+                        q[g] = wv[0] > 0.0f ? (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(1.0f + e) : 0.0f; // a non-detection: q = 0, b = 1
+                        det = det || wv[0] > 0.0f;
+                    }
+                }
+                if (!__any(det)) continue; // no lane of the wave has a detection in this group
+                static_assert(BL_RN_GA == 10, "the product tree below is written for five pairs");
+                bl_f2 b2[5], q4[5], b4[5];
+#pragma unroll
+                for (int g = 0; g < 5; g++) {
+                    const bl_f2 qq = bl_f2{q[2 * g], q[2 * g + 1]}, q2 = qq * qq, s1 = bl2(1.0f) + qq, s2 = s1 + q2; // 1+q, 1+q+q^2
+                    q4[g] = q2 * q2;
+                    b4[g] = bl_fma2(q2, qq, s2);                                                                    // 1+q+q^2+q^3
+                    // b_sub: 0, 1, 1+q, 1+q+q^2  (q = 0: 0, 1, 1, 1 -- the factor 1 of a visit that is no detection; slot 0 of lane 0
+                    // is overwritten below)
+                    b2[g] = sub == 0 ? bl2(0.0f) : (sub == 1 ? bl2(1.0f) : (sub == 2 ? s1 : s2));
+                }
+                BL_RNQ_LOOP_BEGIN(Kw)
+                    const bl_f2 pp = ((b2[0] * b2[1]) * (b2[2] * b2[3])) * b2[4];
+                    LP[m] += __builtin_amdgcn_logf(pp.x * pp.y);
+#pragma unroll
+                    for (int g = 0; g < 5; g++) b2[g] = bl_fma2(b2[g], q4[g], b4[g]);
+                BL_RNQ_LOOP_END
+            }
+            if (sub == 0) LP[0] = term0 * BL_LOG2E; // n = 0: detections impossible -> numpyro's clamp (no b, no floor)
+            // ---- B: the sum over n ----
+            float mx = -3.0e38f;
+            BL_RNQ_LOOP_BEGIN(Kw)
+                mx = fmaxf(mx, LP[m]);
+            BL_RNQ_LOOP_END
+            mx = bl_quad_max(mx);
+            float s = 0.0f, a1 = 0.0f, s1 = 0.0f;
+            BL_RNQ_LOOP_BEGIN(Kw)
+                const float wn = __builtin_amdgcn_exp2f(LP[m] - mx);
+                LP[m] = wn; // unnormalised posterior weight of N = n
+                s += wn;
+                a1 = fmaf(fn, wn, a1);
+            BL_RNQ_LOOP_END
+            s1 = s - (sub == 0 ? LP[0] : 0.0f); // the weights of n >= 1
+            s = bl_quad_sum(s); a1 = bl_quad_sum(a1); s1 = bl_quad_sum(s1);
+            const float rs = __builtin_amdgcn_rcpf(s);
+            ll_s += BL_LN2 * (mx + __builtin_amdgcn_logf(s)) - log_z;
+            const float en_post = a1 * rs;
+            deta += en_post - en_prior;
+            // ---- C: the visits' d/dnu.  Non-detection: sigma(-u) sum_n n w_n [n not floored] (the record's c w_k carries the sign) ----
+            for (int j = 0; j < J; j++) {
+                const float *wv = pv + 2 * (j * (KO + 1));
+                if (!__any(wv[0] < 0.0f)) continue;
+                float u = wv[0] * alpha[0];
+#pragma unroll
+                for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
+                const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E), op = 1.0f + e;
+                const float lq2 = fminf(u, 0.0f) * BL_LOG2E - __builtin_amdgcn_logf(op);
+                float hn = 0.0f;
+                BL_RNQ_LOOP_BEGIN(Kw)
+                    hn += (fn * lq2 >= FL2) ? fn * LP[m] : 0.0f;
+                BL_RNQ_LOOP_END
+                hn = bl_quad_sum(hn);
+                const float dnu = wv[0] < 0.0f ? hn * rs * (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(op) : 0.0f;
+#pragma unroll
+                for (int k = 0; k <= KO; k++) ga_s[k] = fmaf(dnu, wv[2 * k], ga_s[k]);
+            }
+            // Detection: sum_n w_n (q - q r b'_n / b_n), two visits side by side (packed)
+            for (int j0 = 0; j0 < J; j0 += 2) {
+                float q[2], r[2], hs[2];
+                bool any = false;
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    q[g] = 0.0f; r[g] = 0.0f; hs[g] = 0.0f;
+                    if (j0 + g < J) {
+                        const float *wv = pv + 2 * ((j0 + g) * (KO + 1));
+                        float u = wv[0] * alpha[0];
+#pragma unroll
+                        for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
+                        const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E), rop = __builtin_amdgcn_rcpf(1.0f + e);
+                        const bool d = wv[0] > 0.0f;
+                        q[g] = d ? (u > 0.0f ? e : 1.0f) * rop : 0.0f;
+                        r[g] = (u > 0.0f ? 1.0f : e) * rop;
+                        any = any || d;
+                    }
+                }
+                if (!__any(any)) continue;
+                const bl_f2 qq = bl_f2{q[0], q[1]}, q2 = qq * qq, q3 = q2 * qq, s1q = bl2(1.0f) + qq, s2q = s1q + q2;
+                const bl_f2 q4 = q2 * q2, b4 = s2q + q3, c3 = bl2(4.0f) * q3, bp4 = bl_fma2(bl2(3.0f), q2, bl_fma2(bl2(2.0f), qq, bl2(1.0f)));
+                // b_sub: 0, 1, 1+q, 1+q+q^2;  b'_sub: 0, 0, 1, 1+2q
+                bl_f2 b = sub == 0 ? bl2(0.0f) : (sub == 1 ? bl2(1.0f) : (sub == 2 ? s1q : s2q));
+                bl_f2 bp = sub <= 1 ? bl2(0.0f) : (sub == 2 ? bl2(1.0f) : bl_fma2(bl2(2.0f), qq, bl2(1.0f)));
+                bl_f2 h = bl2(0.0f);
+                BL_RNQ_LOOP_BEGIN(Kw)
+                    const bl_f2 bs = __builtin_elementwise_max(b, bl2(1.0e-30f)); // (n = 0: b = b' = 0, its ratio counts as 0)
+                    h = bl_fma2(bl2(LP[m]) * bp, bl_rcp_2(bs), h);
+                    bp = bl_fma2(bp, q4, bl_fma2(b, c3, bp4));
+                    b = bl_fma2(b, q4, b4);
+                BL_RNQ_LOOP_END
+                hs[0] = bl_quad_sum(h.x); hs[1] = bl_quad_sum(h.y);
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    if (j0 + g < J) {
+                        const float *wv = pv + 2 * ((j0 + g) * (KO + 1));
+                        const float dnu = q[g] * (s1 - r[g] * hs[g]) * rs; // q = 0 unless a detection
+#pragma unroll
+                        for (int k = 0; k <= KO; k++) ga_s[k] = fmaf(dnu, wv[2 * k], ga_s[k]);
+                    }
+                }
+            }
+            };
+            if (Kl < 32) period_body(std::integral_constant<int, 8>{});
+            else if (Kl < 64) period_body(std::integral_constant<int, 16>{});
+            else period_body(std::integral_constant<int, BL_RN_MQ>{});
+        }
+        deta *= live;
+        ll = fmaf(live, ll_s, ll);
+#pragma unroll
+        for (int k = 0; k <= KO; k++) ga[k] = fmaf(live, ga_s[k], ga[k]);
+        gb[0] += deta;
+#pragma unroll
+        for (int k = 0; k < KS; k++) gb[k + 1] = fmaf(deta, x[k], gb[k + 1]);
+    }
+}
+
 // MODEL 0 = occu (occu.py), MODEL 1 / 5 = occu_rn (occu_rn.py; LDS records only; table of 128 / 104 entries);
 // MODEL 2 (occu with false positives) is dispatched by bl_phase_a below
 template <int KS, int KO, bool LDS, int MODEL, int CT>
@@ -1245,9 +1519,17 @@ __device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ 
                                               float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], int data_off = 0)
 {
     if constexpr (MODEL == 1) {
+#if BL_RN_QUAD
+        if constexpr (LDS) bl_eval_sites_rn_quad<KS, KO, CT>(ct, ld_or_stride, cnt, T, J, K, beta, alpha, ll, gb, ga);
+#else
         if constexpr (LDS) bl_eval_sites_rn<KS, KO, CT, BL_RN_NB, 1>(ct, ld_or_stride, cnt, T, J, K, beta, alpha, ll, gb, ga);
+#endif
     } else if constexpr (MODEL == 5) {
+#if BL_RN_QUAD
+        if constexpr (LDS) bl_eval_sites_rn_quad<KS, KO, CT>(ct, ld_or_stride, cnt, T, J, K, beta, alpha, ll, gb, ga);
+#else
         if constexpr (LDS) bl_eval_sites_rn<KS, KO, CT, BL_RN_NB_SMALL, 2>(ct, ld_or_stride, cnt, T, J, K, beta, alpha, ll, gb, ga);
+#endif
     } else if constexpr (LDS) {
         switch (J) { // wave-uniform
         case 1: bl_eval_sites_lds<KS, KO, 1, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off); break;
