@@ -966,8 +966,35 @@ __global__ void bl_logp_final_kernel(BlDevData dd, int k, const double *theta, c
     if (lane == D) U[b] = -acc + prior + dd.prior_const;
 }
 
+// Launch of the random-effects / occu_cs NUTS kernel instantiated for this run's capacity, model kind and LDS residency.
+template <int MK, int KIND, bool LROWS, int LT>
+static hipError_t re_nuts_launch_inst(const BlReRun &run, int grid, size_t lds, hipStream_t st)
+{
+    if (lds) {
+        const hipError_t e = hipFuncSetAttribute((const void *)bl_re_nuts_kernel<MK, KIND, LROWS, LT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((bl_re_nuts_kernel<MK, KIND, LROWS, LT>), dim3(grid), dim3(BL_RE_NT), lds, st, run);
+    return hipGetLastError();
+}
+template <int MK, int KIND>
+static hipError_t re_nuts_dispatch_lds(const BlReRun &run, int grid, size_t lds, hipStream_t st)
+{
+    const int lt = run.m.lds_hot;
+    if (run.m.lds_rows)
+        return lt == 2 ? re_nuts_launch_inst<MK, KIND, true, 2>(run, grid, lds, st)
+                       : (lt == 1 ? re_nuts_launch_inst<MK, KIND, true, 1>(run, grid, lds, st) : re_nuts_launch_inst<MK, KIND, true, 0>(run, grid, lds, st));
+    return lt == 2 ? re_nuts_launch_inst<MK, KIND, false, 2>(run, grid, lds, st)
+                   : (lt == 1 ? re_nuts_launch_inst<MK, KIND, false, 1>(run, grid, lds, st) : re_nuts_launch_inst<MK, KIND, false, 0>(run, grid, lds, st));
+}
+static hipError_t re_nuts_dispatch(int mk, const BlReRun &run, int grid, size_t lds, hipStream_t st)
+{
+    if (mk == 4) return run.m.kind == 1 ? re_nuts_dispatch_lds<4, 1>(run, grid, lds, st) : re_nuts_dispatch_lds<4, 0>(run, grid, lds, st);
+    return run.m.kind == 1 ? re_nuts_dispatch_lds<16, 1>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 0>(run, grid, lds, st);
+}
+
 // Geometry of the random-effects kernels for slices of `nloc` sites: threads sharing a site's visits, what lives in LDS.
-// with_hot: also the sampler's five hot vectors (NUTS only).  Returns the dynamic LDS bytes.
+// with_hot: also the sampler's hot (or hot and warm) vectors (NUTS only).  Returns the dynamic LDS bytes.
 static size_t re_geometry(BlReModel &m, int nloc, int with_hot, int dl_max)
 {
     int tps = 1;
@@ -975,10 +1002,13 @@ static size_t re_geometry(BlReModel &m, int nloc, int with_hot, int dl_max)
     m.tps = tps;
     // a workgroup's own LDS copy of its rows, and of the five vectors every leapfrog touches, when they fit (160 KB per CU,
     // one workgroup per CU; a few KB go to the reduction scratch)
-    const size_t row_bytes = (size_t)m.n_rows * nloc * 4, hot_bytes = with_hot ? (size_t)RE_HOT * dl_max * 4 : 0, budget = (size_t)150 * 1024;
+    const size_t row_bytes = (size_t)m.n_rows * nloc * 4, budget = (size_t)150 * 1024;
+    const size_t hot_bytes = (size_t)RE_HOT * dl_max * 4, warm_bytes = (size_t)RE_WARM * dl_max * 4;
     m.lds_rows = row_bytes <= budget ? 1 : 0;
-    m.lds_hot = with_hot && (m.lds_rows ? row_bytes : 0) + hot_bytes <= budget ? 1 : 0;
-    return (m.lds_rows ? row_bytes : 0) + (m.lds_hot ? hot_bytes : 0);
+    const size_t used = m.lds_rows ? row_bytes : 0;
+    m.lds_hot = !with_hot ? 0 : (used + warm_bytes <= budget ? 2 : (used + hot_bytes <= budget ? 1 : 0));
+    if (const char *e = getenv("BIOLITH_HIP_RE_LDS_TIER")) m.lds_hot = std::min(m.lds_hot, atoi(e)); // (measurement)
+    return used + (m.lds_hot == 2 ? warm_bytes : (m.lds_hot == 1 ? hot_bytes : 0));
 }
 
 extern "C" int bl_dataset_create_re(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
@@ -1255,7 +1285,6 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     run.m = g;
     const size_t lds = re_geometry(run.m, nloc, 1, dl_max);
     const bool cap4 = g.Ks <= 4 && g.Ko <= 4;
-    if (lds) BL_HIP(hipFuncSetAttribute(cap4 ? (const void *)bl_re_nuts_kernel<4> : (const void *)bl_re_nuts_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     run.num_chains = C; run.num_warmup = W; run.num_samples = S; run.max_depth = max_depth;
     run.k = k; run.nloc = nloc; run.dl_max = dl_max;
     run.xchg = (unsigned long long *)(base + o_xchg);
@@ -1282,9 +1311,7 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     BL_HIP(hipMemsetAsync(run.xchg, 0, (size_t)C * 2 * k * BL_RE_NRED_MAX * 8, st));
     BL_HIP(hipMemsetAsync(ds->d_loc, 0, (size_t)C * 4, st));
     // XCD-aware mapping in the kernel (surplus blocks exit at once)
-    if (cap4) hipLaunchKernelGGL(bl_re_nuts_kernel<4>, dim3(8 * k * ((C + 7) / 8)), dim3(BL_RE_NT), lds, st, d_runp);
-    else hipLaunchKernelGGL(bl_re_nuts_kernel<16>, dim3(8 * k * ((C + 7) / 8)), dim3(BL_RE_NT), lds, st, d_runp);
-    BL_HIP(hipGetLastError());
+    BL_HIP(re_nuts_dispatch(cap4 ? 4 : 16, run, 8 * k * ((C + 7) / 8), lds, st));
     BL_HIP(hipEventRecord(ds->ev1, st));
     ds->stream = st; ds->in_flight = true; ds->have_run = true;
     ds->C = C; ds->S = S; ds->W = W; ds->k = k; ds->nloc = nloc; ds->lds_ld = 0; ds->lds_bytes = (int)lds; ds->staged = run.m.lds_rows; ds->nvp = 0; ds->ncw = BL_RE_NW;

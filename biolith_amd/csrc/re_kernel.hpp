@@ -50,7 +50,7 @@ struct BlReModel {
     int x_u, x_v, x_e;                    // external offsets of site_re_occ / site_re_det / obs_re in a draw
     int n_rows;                           // rows of the dataset (KS + T J (KO + 1) + 2 T)
     int lds_rows;                         // 1: every workgroup keeps its own copy of the rows in LDS (n_rows * n_sites floats)
-    int lds_hot;                          // 1: the RE_HOT vectors of the chain live in LDS (after the rows), not in device memory
+    int lds_hot;                          // 1 / 2: the first RE_HOT / RE_WARM vectors of the chain live in LDS (after the rows), not in device memory
 };
 
 // The dataset's rows for this workgroup: staged into dynamic LDS once when they fit, else read from device memory (L2).
@@ -65,19 +65,21 @@ __device__ __forceinline__ const float *bl_re_rows(const BlReModel &m, float *ld
     return lds;
 }
 
-// slots of the per-chain state block, each D floats
+// slots of the per-chain state block, each D floats, ordered by how often a leapfrog touches them: the first RE_HOT, or the
+// first RE_WARM, live in the workgroup's LDS when they fit (BlReModel::lds_hot = 1 / 2), the rest in device memory (L2)
 enum {
-    // the five vectors every leapfrog reads and writes: kept in the workgroup's LDS when they fit (BlReModel::lds_hot)
     RE_CZ = 0, RE_CR, RE_CG,                       // leaf in flight: position, momentum (half step, then full), gradient
     RE_MINV, RE_SRSUM,                             // diagonal mass matrix; the subtree's momentum sum
     RE_HOT,
-    RE_TH = RE_HOT, RE_GR,                         // position / gradient the transition started from
-    RE_ZL, RE_RL, RE_GL, RE_ZR, RE_RR, RE_GRR,     // tree edges
-    RE_ZP, RE_GP, RE_SZP, RE_SGP,                  // proposals: tree, subtree
-    RE_RSUM,                                       // the tree's momentum sum
-    RE_WFMEAN, RE_WFM2,                            // Welford moments
+    RE_RSUM = RE_HOT, RE_RL, RE_RR,                // the tree's momentum sum; the momenta at the tree's edges
+    RE_SZP, RE_SGP,                                // the subtree's proposal
     RE_CKR,                                        // BL_MAX_DEPTH checkpoints of r, then BL_MAX_DEPTH of the running sum
-    RE_SLOTS = RE_CKR + 2 * BL_MAX_DEPTH
+    RE_WARM = RE_CKR + 2 * BL_MAX_DEPTH,
+    RE_TH = RE_WARM, RE_GR,                        // position / gradient the transition started from
+    RE_ZL, RE_GL, RE_ZR, RE_GRR,                   // positions / gradients at the tree's edges
+    RE_ZP, RE_GP,                                  // the tree's proposal
+    RE_WFMEAN, RE_WFM2,                            // Welford moments
+    RE_SLOTS
 };
 
 struct BlReRun {
@@ -211,6 +213,17 @@ __device__ __forceinline__ bool bl_re_exchange(BlReXchg &x, double *out, float *
     return *lds_flag == 0;
 }
 
+// Calls f(integral_constant<KB>, args...) for the smallest compiled covariate count KB in {1, 2, 4, 8, 16} (<= MK) that holds Ko.
+template <int MK, class F, class... A>
+__device__ __forceinline__ void bl_re_tiered(int Ko, F &f, A... args)
+{
+    if (Ko <= 1) f(std::integral_constant<int, 1>{}, args...);
+    else if (Ko <= 2) f(std::integral_constant<int, 2>{}, args...);
+    else if (MK <= 4 || Ko <= 4) f(std::integral_constant<int, (MK < 4 ? MK : 4)>{}, args...);
+    else if (MK <= 8 || Ko <= 8) f(std::integral_constant<int, (MK < 8 ? MK : 8)>{}, args...);
+    else f(std::integral_constant<int, MK>{}, args...);
+}
+
 // Site pass at position z: per-thread partials of the log-likelihood and of its gradient w.r.t. beta / alpha, and the
 // random effects' full potential gradient written to g (the effect's own likelihood term + its Normal(0, sd) prior).
 // part[0] = ll, part[1 .. 5] = d/d beta, part[6 .. 10] = d/d alpha.
@@ -224,11 +237,15 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
     const int tid = threadIdx.x, tps = m.tps, S = 64 / tps, lane = tid & 63;
     const int grp = (tid >> 6) * S + (lane & (S - 1)), sub = lane / S, ngrp = BL_RE_NT / tps;
     const int N = m.n_sites, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 1;
+    // (every load of the pass is unconditional, its index clamped into the array, and the value selected afterwards: a load
+    // under a wave-uniform condition `k <= Ko` becomes a branch around it -- twenty basic blocks per batch of visits -- and
+    // the loads of a batch are no longer in flight together)
     float beta[MK + 1], alpha[MK + 1];
 #pragma unroll
     for (int k = 0; k <= MK; k++) {
-        beta[k] = k <= Ks ? z[k] : 0.0f;
-        alpha[k] = k <= Ko ? z[Ks + 1 + k] : 0.0f;
+        const float b = z[min(k, Ks)], a = z[Ks + 1 + min(k, Ko)];
+        beta[k] = k <= Ks ? b : 0.0f;
+        alpha[k] = k <= Ko ? a : 0.0f;
     }
     const float isd2_s = m.site_re ? bl_exp(-2.0f * z[m.o_phi_s]) : 0.0f;
     const float isd2_o = m.obs_re ? bl_exp(-2.0f * z[m.o_phi_o]) : 0.0f;
@@ -244,10 +261,12 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
         float eta = beta[0];
 #pragma unroll
         for (int k = 0; k < MK; k++) {
-            x[k] = k < Ks ? rows[(size_t)k * ns + i] : 0.0f;
+            const float xk = rows[min(k, Ks) * ns + i]; // (k == Ks: the first visit row, discarded)
+            x[k] = k < Ks ? xk : 0.0f;
             eta = fmaf(x[k], beta[k + 1], eta);
         }
-        const float ui = m.site_re ? z[m.o_u + i] : 0.0f, vi = m.site_re ? z[m.o_v + i] : 0.0f;
+        const float ui_ = z[m.site_re ? m.o_u + i : 0], vi_ = z[m.site_re ? m.o_v + i : 0];
+        const float ui = m.site_re ? ui_ : 0.0f, vi = m.site_re ? vi_ : 0.0f;
         eta += ui;
         const float ee = bl_exp(-fabsf(eta)), lop = bl_log(1.0f + ee);
         const float log_psi = fminf(eta, 0.0f) - lop, log_1mpsi = fminf(-eta, 0.0f) - lop;
@@ -258,37 +277,44 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
 #pragma unroll
             for (int k = 0; k <= MK; k++) ga[k] = 0.0f;
             // visits in batches of BL_RE_VB: all loads of a batch are issued before the first is used (a lone workgroup per
-            // CU has little else to hide memory latency behind); a visit past J re-reads the last one and is dropped
-            for (int jb = sub; jb < J; jb += tps * BL_RE_VB) {
-                float w[BL_RE_VB][MK + 1], eo[BL_RE_VB];
+            // CU has little else to hide memory latency behind); a visit past J re-reads the last one and is dropped.  The
+            // batch is compiled for a few covariate counts KB >= Ko (1, 2, 4, 8, 16 up to MK): one uniform branch per batch.
+            auto batch = [&](auto kb_, int jb) {
+                constexpr int KB = decltype(kb_)::value;
+                float w[BL_RE_VB][KB + 1], eo[BL_RE_VB];
 #pragma unroll
                 for (int b = 0; b < BL_RE_VB; b++) {
                     const int jj = min(jb + b * tps, J - 1), v = t * J + jj;
-                    const size_t r0 = (size_t)(m.KS + v * vw) * ns + i;
+                    const int r0 = (m.KS + v * vw) * ns + i;
 #pragma unroll
-                    for (int k = 0; k <= MK; k++) w[b][k] = k <= Ko ? rows[r0 + (size_t)k * ns] : 0.0f;
-                    eo[b] = m.obs_re ? z[m.o_e + v * N + i] : 0.0f;
+                    for (int k = 0; k <= KB; k++) {
+                        const float wk = rows[r0 + min(k, Ko) * ns];
+                        w[b][k] = k <= Ko ? wk : 0.0f;
+                    }
+                    const float ev = z[m.obs_re ? m.o_e + v * N + i : 0];
+                    eo[b] = m.obs_re ? ev : 0.0f;
                 }
 #pragma unroll
                 for (int b = 0; b < BL_RE_VB; b++) {
                     const float ok = jb + b * tps < J ? 1.0f : 0.0f;
                     float u = w[b][0] * alpha[0];
 #pragma unroll
-                    for (int k = 1; k <= MK; k++) u = fmaf(w[b][k], alpha[k], u);
+                    for (int k = 1; k <= KB; k++) u = fmaf(w[b][k], alpha[k], u);
                     u = fmaf(w[b][0], vi + eo[b], u);
                     const float e = bl_exp(-fabsf(u)), op = 1.0f + e;
                     a = fmaf(ok, fminf(u, 0.0f) - bl_log(op), a);
                     const float s = ok * (u > 0.0f ? e : 1.0f) * bl_rcp(op); // sigma(-u): d log sigma(u) / du
 #pragma unroll
-                    for (int k = 0; k <= MK; k++) ga[k] = fmaf(s, w[b][k], ga[k]);
+                    for (int k = 0; k <= KB; k++) ga[k] = fmaf(s, w[b][k], ga[k]);
                 }
-            }
+            };
+            for (int jb = sub; jb < J; jb += tps * BL_RE_VB) bl_re_tiered<MK>(Ko, batch, jb);
             for (int msk = S; msk < 64; msk <<= 1) { // the site's threads pool their visits
                 a += __shfl_xor(a, msk);
 #pragma unroll
                 for (int k = 0; k <= MK; k++) ga[k] += __shfl_xor(ga[k], msk);
             }
-            const float ka = rows[(size_t)(row_ka + t) * ns + i], kb = rows[(size_t)(row_kb + t) * ns + i];
+            const float ka = rows[(row_ka + t) * ns + i], kb = rows[(row_kb + t) * ns + i];
             const float A = log_psi + a + ka, B = log_1mpsi + kb;
             const float l = bl_logaddexp(A, B);
             const float q = bl_exp(A - l);
@@ -301,14 +327,18 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
             dl_dv = fmaf(q, ga[0], dl_dv);
             if (m.obs_re && live) {
                 // each replicate's own effect: d U / d e = -q d a / d nu + e / sd^2 (d a / d nu recomputed: nothing was kept per visit)
-                for (int jb = sub; jb < J; jb += tps * BL_RE_VB) {
-                    float w[BL_RE_VB][MK + 1], eo[BL_RE_VB];
+                auto batch_e = [&](auto kb_, int jb) {
+                    constexpr int KB = decltype(kb_)::value;
+                    float w[BL_RE_VB][KB + 1], eo[BL_RE_VB];
 #pragma unroll
                     for (int b = 0; b < BL_RE_VB; b++) {
                         const int jj = min(jb + b * tps, J - 1), v = t * J + jj;
-                        const size_t r0 = (size_t)(m.KS + v * vw) * ns + i;
+                        const int r0 = (m.KS + v * vw) * ns + i;
 #pragma unroll
-                        for (int k = 0; k <= MK; k++) w[b][k] = k <= Ko ? rows[r0 + (size_t)k * ns] : 0.0f;
+                        for (int k = 0; k <= KB; k++) {
+                            const float wk = rows[r0 + min(k, Ko) * ns];
+                            w[b][k] = k <= Ko ? wk : 0.0f;
+                        }
                         eo[b] = z[m.o_e + v * N + i];
                     }
 #pragma unroll
@@ -316,14 +346,15 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
                         if (jb + b * tps < J) {
                             float u = w[b][0] * alpha[0];
 #pragma unroll
-                            for (int k = 1; k <= MK; k++) u = fmaf(w[b][k], alpha[k], u);
+                            for (int k = 1; k <= KB; k++) u = fmaf(w[b][k], alpha[k], u);
                             u = fmaf(w[b][0], vi + eo[b], u);
                             const float e = bl_exp(-fabsf(u));
                             const float s = (u > 0.0f ? e : 1.0f) * bl_rcp(1.0f + e);
                             g[m.o_e + (t * J + jb + b * tps) * N + i] = fmaf(eo[b], isd2_o, -q * s * w[b][0]);
                         }
                     }
-                }
+                };
+                for (int jb = sub; jb < J; jb += tps * BL_RE_VB) bl_re_tiered<MK>(Ko, batch_e, jb);
             }
         }
         if (live && sub == 0) {
@@ -348,11 +379,15 @@ __device__ __forceinline__ void bl_cs_site_pass(const BlReModel &m, const float 
     const int tid = threadIdx.x, tps = m.tps, S = 64 / tps, lane = tid & 63;
     const int grp = (tid >> 6) * S + (lane & (S - 1)), sub = lane / S, ngrp = BL_RE_NT / tps;
     const int N = m.n_sites, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 1;
+    // (every load of the pass is unconditional, its index clamped into the array, and the value selected afterwards: a load
+    // under a wave-uniform condition `k <= Ko` becomes a branch around it -- twenty basic blocks per batch of visits -- and
+    // the loads of a batch are no longer in flight together)
     float beta[MK + 1], alpha[MK + 1];
 #pragma unroll
     for (int k = 0; k <= MK; k++) {
-        beta[k] = k <= Ks ? z[k] : 0.0f;
-        alpha[k] = k <= Ko ? z[Ks + 1 + k] : 0.0f;
+        const float b = z[min(k, Ks)], a = z[Ks + 1 + min(k, Ko)];
+        beta[k] = k <= Ks ? b : 0.0f;
+        alpha[k] = k <= Ko ? a : 0.0f;
     }
     const float mu0 = z[m.G0], mu1 = mu0 + bl_exp(z[m.G0 + 1]), ls0 = z[m.G0 + 2], ls1 = z[m.G0 + 3];
     const float is0 = bl_exp(-ls0), is1 = bl_exp(-ls1);
@@ -369,7 +404,8 @@ __device__ __forceinline__ void bl_cs_site_pass(const BlReModel &m, const float 
         float eta = beta[0];
 #pragma unroll
         for (int k = 0; k < MK; k++) {
-            x[k] = k < Ks ? rows[(size_t)k * ns + i] : 0.0f;
+            const float xk = rows[min(k, Ks) * ns + i]; // (k == Ks: the first visit row, discarded)
+            x[k] = k < Ks ? xk : 0.0f;
             eta = fmaf(x[k], beta[k + 1], eta);
         }
         const float ee = bl_exp(-fabsf(eta)), lop = bl_log(1.0f + ee);
@@ -384,10 +420,13 @@ __device__ __forceinline__ void bl_cs_site_pass(const BlReModel &m, const float 
             for (int k = 0; k < MK + 11; k++) r[k] = 0.0f;
             for (int j = sub; j < J; j += tps) {
                 const int v = t * J + j;
-                const size_t r0 = (size_t)(m.KS + v * vw) * ns + i;
+                const int r0 = (m.KS + v * vw) * ns + i;
                 float w[MK + 1];
 #pragma unroll
-                for (int k = 0; k <= MK; k++) w[k] = k <= Ko ? rows[r0 + (size_t)k * ns] : 0.0f;
+                for (int k = 0; k <= MK; k++) {
+                    const float wk = rows[r0 + min(k, Ko) * ns];
+                    w[k] = k <= Ko ? wk : 0.0f;
+                }
                 const float c = w[0]; // 1: the replicate has a score, 0: masked
                 const float sc = m.scores[(size_t)v * m.n_stride + i];
                 float nu = c * alpha[0];
@@ -575,15 +614,17 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel m,
 }
 
 // ------------------------------------------------------------------------------------------------ NUTS ----
-template <int MK>
-__global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__restrict__ rp)
+// KIND: BlReModel::kind; LROWS / LT: BlReModel::lds_rows / lds_hot as compile-time facts, so that every access to the rows and to
+// the sampler's vectors is a DS or a GLOBAL instruction (one generic pointer for both made all of them FLAT: 272 flat loads, 230 spilled
+// SGPRs of 64-bit bases)
+template <int MK, int KIND, bool LROWS, int LT>
+__global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
 {
     constexpr int NRED = BL_RE_NRED_OF(MK), OX = BL_RE_OX(MK), NV1 = BL_RE_NV1(MK);
     __shared__ float scr[BL_RE_NW * NRED];
     __shared__ double red[NRED], red2[NRED];
     __shared__ float scr2[32 * NRED];
     __shared__ int xflag;
-    const BlReRun &R = *rp;
     // XCD-aware mapping (speed only, as in nuts_kernel.hpp): blocks b and b + 8 share an XCD under the observed round-robin
     // dealing, so chain c takes blocks with b % 8 == c % 8 and its k workgroups share one L2; the first exchange checks it
     const int label = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -595,15 +636,25 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
     const bool lead = wg == 0; // the fixed effects / log sds are replicated; workgroup 0 accounts for them in every sum and output
     float *sv = R.state + ((size_t)chain * R.k + wg) * RE_SLOTS * R.dl_max;
     extern __shared__ float bl_re_lds[];
-    float *hot = m.lds_hot ? bl_re_lds + (m.lds_rows ? (size_t)m.n_rows * R.nloc : 0) : sv; // (generic pointers: LDS or device memory)
-    auto V = [&](int slot) -> float * { return (slot < RE_HOT ? hot : sv) + (size_t)slot * R.dl_max; };
+    float *const hot_lds = bl_re_lds + (LROWS ? m.n_rows * R.nloc : 0);
+    // the RE_HOT vectors (H), the warm ones up to RE_WARM (Wm), the others (V)
+    auto H = [&](int slot) -> float * { if constexpr (LT >= 1) return hot_lds + slot * R.dl_max; else return sv + (size_t)slot * R.dl_max; };
+    auto Wm = [&](int slot) -> float * { if constexpr (LT >= 2) return hot_lds + slot * R.dl_max; else return sv + (size_t)slot * R.dl_max; };
+    auto V = [&](int slot) -> float * { return sv + (size_t)slot * R.dl_max; };
     uint32_t *rng_base = R.rng + ((size_t)chain * R.k + wg) * (R.dl_max + 2) * 4;
     BlReXchg xc{R.xchg, R.k, wg, chain, 0u, 5000000u /* microseconds */, false};
     const float xcc = (float)bl_xcc_id();
     if (tid == 0) xflag = 0;
     const int S = R.num_samples, W = R.num_warmup, total = W + S;
-    int rows_ns;
-    const float *rows = bl_re_rows(m, bl_re_lds, rows_ns);
+    int rows_ns = m.n_stride;
+    const float *rows = m.rows;
+    if constexpr (LROWS) { // the workgroup's own copy of its rows
+        const int N = m.n_sites;
+        for (int r = 0; r < m.n_rows; r++)
+            for (int i = tid; i < N; i += BL_RE_NT) bl_re_lds[r * N + i] = m.rows[(size_t)r * m.n_stride + i];
+        __syncthreads();
+        rows = bl_re_lds; rows_ns = N;
+    }
 
     BlRng rng_u, rng_dir; // every thread carries its own copy of the two scalar streams and advances it identically
     {
@@ -625,18 +676,19 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
     int da_t = 0, win_idx = 0, wf_n = 0;
     long long nleap_w = 0, nleap_s = 0;
     int flag = 0;
+    float abort_req = 0.0f; // (non-zero only in thread 0 of workgroup 0)
 
-    // evaluate the potential and its gradient at V(RE_CZ) into V(RE_CG); returns U (same value in every thread).
+    // evaluate the potential and its gradient at H(RE_CZ) into H(RE_CG); returns U (same value in every thread).
     // The gradient of a fixed effect / log sd is written by the thread that owns the coordinate, after the reduction.
 #ifdef BL_STAMPS
-    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = (long long)clock64(), st_leaves = 0;
+    long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = (long long)clock64(), st_leaves = 0;
 #endif
     auto evaluate = [&]() -> double {
         float v[NV1];
-        const float *z = V(RE_CZ);
-        float *g = V(RE_CG);
+        const float *z = H(RE_CZ);
+        float *g = H(RE_CG);
         BL_RE_T(7)
-        if (m.kind == 1) { // occu_cs: no effects; four more gradient sums
+        if constexpr (KIND == 1) { // occu_cs: no effects; four more gradient sums
             float part[2 * MK + 7];
             bl_cs_site_pass<MK>(m, rows, rows_ns, z, part);
 #pragma unroll
@@ -645,6 +697,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
         } else {
             float part[2 * MK + 3], ss[2];
             bl_re_site_pass<MK>(m, rows, rows_ns, z, g, part);
+            BL_RE_T(8)
             bl_re_effect_squares(m, z, ss);
 #pragma unroll
             for (int k = 0; k < OX; k++) v[k] = part[k];
@@ -652,42 +705,47 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
         }
         v[OX + 2] = lead ? bl_re_prior_quad(m, z) : 0.0f;
         // the host's abort request rides in the sums, so that every workgroup of the chain sees it at the same leapfrog
-        v[OX + 3] = (lead && tid == 0 && R.abort_flag && *(volatile const int *)R.abort_flag) ? 1.0f : 0.0f;
+        v[OX + 3] = abort_req;
         // XCD census (first exchange): k sum(x^2) == (sum x)^2 iff every workgroup reports the same XCC id
         v[OX + 4] = tid == 0 ? xcc : 0.0f; v[OX + 5] = tid == 0 ? xcc * xcc : 0.0f;
         BL_RE_T(0)
         const bool first = xc.epoch == 0u;
-        const int nv = m.kind == 1 ? NV1 : (first ? OX + 6 : OX + 4);
+        const int nv = KIND == 1 ? NV1 : (first ? OX + 6 : OX + 4);
         bl_re_block_sum<NV1, NRED>(v, scr, red, nv, xc.k == 1);
+        BL_RE_T(9)
         if (!bl_re_exchange<NRED>(xc, red, scr2, &xflag, nv)) flag = 4;
+        BL_RE_T(10)
         if (first && R.allow_local) xc.local = ((double)R.k * red[OX + 5] == red[OX + 4] * red[OX + 4]); // exact: small integers
         if (red[OX + 3] > 0.0) flag = 5;
         for (int d = tid; d < G; d += BL_RE_NT)
-            g[d] = (m.kind == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red) : bl_re_global_grad<MK>(m, d, z[d], red);
+            g[d] = (KIND == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red) : bl_re_global_grad<MK>(m, d, z[d], red);
         double U = bl_re_potential(m, z, red, red[OX + 2], OX);
-        if (m.kind == 1) U += bl_cs_extra_potential(m, z);
+        if constexpr (KIND == 1) U += bl_cs_extra_potential(m, z);
         BL_RE_T(1)
         return U;
     };
 
     // momentum r ~ N(0, M), fresh tree, first doubling, and the first leaf's half step (start in CZ / CR / CG)
     auto new_transition = [&]() {
+        // the abort flag is host memory: one read is a PCIe round trip (3 500 - 3 900 cycles measured, a seventh of a leapfrog when
+        // it was read at every leaf), so it is sampled once per transition, by one thread, and consumed by the next leaf's sums
+        if (lead && tid == 0 && R.abort_flag) abort_req = *(volatile const int *)R.abort_flag ? 1.0f : 0.0f;
         going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
         epsdir = going_right ? eps : -eps;
         float kin[1] = {0.0f};
         for (int d = tid; d < D; d += BL_RE_NT) {
-            const float th = V(RE_TH)[d], gr = V(RE_GR)[d], mi = V(RE_MINV)[d];
+            const float th = V(RE_TH)[d], gr = V(RE_GR)[d], mi = H(RE_MINV)[d];
             BlRng r = rng_load(d);
             const float z01 = bl_rng_normal(r);
             rng_store(d, r);
             const float r0 = z01 * __builtin_amdgcn_rsqf(mi);
             if (d >= G || lead) kin[0] = fmaf(mi * r0, r0, kin[0]);
-            V(RE_ZL)[d] = th; V(RE_RL)[d] = r0; V(RE_GL)[d] = gr;
-            V(RE_ZR)[d] = th; V(RE_RR)[d] = r0; V(RE_GRR)[d] = gr;
-            V(RE_ZP)[d] = th; V(RE_GP)[d] = gr; V(RE_RSUM)[d] = r0;
+            V(RE_ZL)[d] = th; Wm(RE_RL)[d] = r0; V(RE_GL)[d] = gr;
+            V(RE_ZR)[d] = th; Wm(RE_RR)[d] = r0; V(RE_GRR)[d] = gr;
+            V(RE_ZP)[d] = th; V(RE_GP)[d] = gr; Wm(RE_RSUM)[d] = r0;
             float rh, zn;
             bl_next_leaf(th, r0, gr, epsdir, mi, rh, zn);
-            V(RE_CZ)[d] = zn; V(RE_CR)[d] = rh; V(RE_CG)[d] = gr;
+            H(RE_CZ)[d] = zn; H(RE_CR)[d] = rh; H(RE_CG)[d] = gr;
         }
         bl_re_block_sum<1, NRED>(kin, scr, red2, 1, xc.k == 1); // (its barriers, or the exchange's, also publish the leaf start)
         if (!bl_re_exchange<NRED>(xc, red2, scr2, &xflag, 1)) flag = 4;
@@ -701,13 +759,13 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
         BlRng r = rng_load(d);
         const float u0 = bl_rng_uniform(r);
         rng_store(d, r);
-        V(RE_CZ)[d] = R.init_theta ? R.init_theta[(size_t)chain * R.m.D + bl_re_ext(m, d)] : 4.0f * u0 - 2.0f;
-        V(RE_MINV)[d] = 1.0f; V(RE_WFMEAN)[d] = 0.0f; V(RE_WFM2)[d] = 0.0f;
+        H(RE_CZ)[d] = R.init_theta ? R.init_theta[(size_t)chain * R.m.D + bl_re_ext(m, d)] : 4.0f * u0 - 2.0f;
+        H(RE_MINV)[d] = 1.0f; V(RE_WFMEAN)[d] = 0.0f; V(RE_WFM2)[d] = 0.0f;
     }
     __syncthreads();
     Ucur = evaluate();
     __syncthreads(); // every coordinate's gradient is in place
-    for (int d = tid; d < D; d += BL_RE_NT) { V(RE_TH)[d] = V(RE_CZ)[d]; V(RE_GR)[d] = V(RE_CG)[d]; }
+    for (int d = tid; d < D; d += BL_RE_NT) { V(RE_TH)[d] = H(RE_CZ)[d]; V(RE_GR)[d] = H(RE_CG)[d]; }
     if (total <= 0) flag = 1;
     else new_transition();
 
@@ -727,37 +785,38 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
         const int nck = odd ? idx_max - idx_min + 1 : 0;
         for (int d = tid; d < D; d += BL_RE_NT) {
             // (coordinates below G: this thread wrote their gradient in evaluate(); the others' were published by its barriers)
-            const float mi = V(RE_MINV)[d];
+            const float mi = H(RE_MINV)[d];
             const float mc = (d >= G || lead) ? mi : 0.0f; // weight of this coordinate in the chain-wide sums
-            const float cr = bl_leaf_momentum(V(RE_CR)[d], epsdir, V(RE_CG)[d]);
-            V(RE_CR)[d] = cr;
+            const float cr = bl_leaf_momentum(H(RE_CR)[d], epsdir, H(RE_CG)[d]);
+            H(RE_CR)[d] = cr;
             acc[0] = fmaf(mc * cr, cr, acc[0]);
-            const float srs = leaf_idx == 0 ? cr : V(RE_SRSUM)[d] + cr;
-            V(RE_SRSUM)[d] = srs;
+            const float srs = leaf_idx == 0 ? cr : H(RE_SRSUM)[d] + cr;
+            H(RE_SRSUM)[d] = srs;
             if (!odd) {
-                V(RE_CKR + idx_max)[d] = cr;
-                V(RE_CKR + BL_MAX_DEPTH + idx_max)[d] = srs;
+                Wm(RE_CKR + idx_max)[d] = cr;
+                Wm(RE_CKR + BL_MAX_DEPTH + idx_max)[d] = srs;
             } else {
 #pragma unroll
                 for (int q = 0; q < BL_MAX_DEPTH; q++) {
                     const int i = idx_min + q;
                     if (i <= idx_max) {
-                        const float ck = V(RE_CKR + i)[d];
-                        const float s_i = srs - V(RE_CKR + BL_MAX_DEPTH + i)[d] + ck;
+                        const float ck = Wm(RE_CKR + i)[d];
+                        const float s_i = srs - Wm(RE_CKR + BL_MAX_DEPTH + i)[d] + ck;
                         const float rho = s_i - 0.5f * (ck + cr);
                         acc[3 + 2 * q] = fmaf(mc * ck, rho, acc[3 + 2 * q]);
                         acc[4 + 2 * q] = fmaf(mc * cr, rho, acc[4 + 2 * q]);
                     }
                 }
             }
-            const float r_other = going_right ? V(RE_RL)[d] : V(RE_RR)[d];
+            const float r_other = going_right ? Wm(RE_RL)[d] : Wm(RE_RR)[d];
             const float rl = going_right ? r_other : cr, rr = going_right ? cr : r_other;
-            const float rho_t = (V(RE_RSUM)[d] + srs) - 0.5f * (rl + rr);
+            const float rho_t = (Wm(RE_RSUM)[d] + srs) - 0.5f * (rl + rr);
             acc[1] = fmaf(mc * rl, rho_t, acc[1]);
             acc[2] = fmaf(mc * rr, rho_t, acc[2]);
         }
         BL_RE_T(2)
         bl_re_block_sum<26, NRED>(acc, scr, red2, 3 + 2 * nck, xc.k == 1);
+        BL_RE_T(11)
         if (!bl_re_exchange<NRED>(xc, red2, scr2, &xflag, 3 + 2 * nck)) flag = 4;
         BL_RE_T(3)
         // ---- decisions (_build_basetree tail, _iterative_build_subtree, _combine_tree, _double_tree) ----
@@ -836,22 +895,22 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
         BL_RE_T(4)
         const float wfn = (float)wf_n;
         for (int d = tid; d < D; d += BL_RE_NT) {
-            const float cz = V(RE_CZ)[d], cg = V(RE_CG)[d], cr = V(RE_CR)[d];
-            if (take) { V(RE_SZP)[d] = cz; V(RE_SGP)[d] = cg; }
+            const float cz = H(RE_CZ)[d], cg = H(RE_CG)[d], cr = H(RE_CR)[d];
+            if (take) { Wm(RE_SZP)[d] = cz; Wm(RE_SGP)[d] = cg; }
             if (!sub_done) { // the subtree goes on from this leaf
                 float rh, zn;
-                bl_next_leaf(cz, cr, cg, epsdir, V(RE_MINV)[d], rh, zn);
-                V(RE_CZ)[d] = zn; V(RE_CR)[d] = rh;
+                bl_next_leaf(cz, cr, cg, epsdir, H(RE_MINV)[d], rh, zn);
+                H(RE_CZ)[d] = zn; H(RE_CR)[d] = rh;
                 continue;
             }
-            V(was_right ? RE_ZR : RE_ZL)[d] = cz; V(was_right ? RE_RR : RE_RL)[d] = cr; V(was_right ? RE_GRR : RE_GL)[d] = cg;
-            V(RE_RSUM)[d] += V(RE_SRSUM)[d];
-            if (take2) { V(RE_ZP)[d] = take ? cz : V(RE_SZP)[d]; V(RE_GP)[d] = take ? cg : V(RE_SGP)[d]; }
+            V(was_right ? RE_ZR : RE_ZL)[d] = cz; Wm(was_right ? RE_RR : RE_RL)[d] = cr; V(was_right ? RE_GRR : RE_GL)[d] = cg;
+            Wm(RE_RSUM)[d] += H(RE_SRSUM)[d];
+            if (take2) { V(RE_ZP)[d] = take ? cz : Wm(RE_SZP)[d]; V(RE_GP)[d] = take ? cg : Wm(RE_SGP)[d]; }
             if (cont) { // next doubling: its first leaf starts from the tree edge on the chosen side
-                const float ez = V(going_right ? RE_ZR : RE_ZL)[d], er = V(going_right ? RE_RR : RE_RL)[d], eg = V(going_right ? RE_GRR : RE_GL)[d];
+                const float ez = V(going_right ? RE_ZR : RE_ZL)[d], er = Wm(going_right ? RE_RR : RE_RL)[d], eg = V(going_right ? RE_GRR : RE_GL)[d];
                 float rh, zn;
-                bl_next_leaf(ez, er, eg, epsdir, V(RE_MINV)[d], rh, zn);
-                V(RE_CZ)[d] = zn; V(RE_CR)[d] = rh; V(RE_CG)[d] = eg;
+                bl_next_leaf(ez, er, eg, epsdir, H(RE_MINV)[d], rh, zn);
+                H(RE_CZ)[d] = zn; H(RE_CR)[d] = rh; H(RE_CG)[d] = eg;
                 continue;
             }
             const float th = V(RE_ZP)[d];
@@ -864,7 +923,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
             }
             if (wf_close) {
                 const float var = V(RE_WFM2)[d] * bl_rcp(wfn - 1.0f), rn5 = bl_rcp(wfn + 5.0f);
-                V(RE_MINV)[d] = wfn * rn5 * var + 1e-3f * 5.0f * rn5;
+                H(RE_MINV)[d] = wfn * rn5 * var + 1e-3f * 5.0f * rn5;
                 V(RE_WFMEAN)[d] = 0.0f; V(RE_WFM2)[d] = 0.0f;
             }
             if (it_done >= W && (d >= G || lead)) R.draws[((size_t)chain * S + (it_done - W)) * R.m.D + bl_re_ext(m, d)] = th;
@@ -891,12 +950,12 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun *__r
     }
 #ifdef BL_STAMPS
     if (R.dbg && chain == 0 && tid == 0 && lead) {
-        for (int i = 0; i < 8; i++) R.dbg[i] = st_acc[i];
-        R.dbg[8] = st_leaves;
+        for (int i = 0; i < 16; i++) R.dbg[i] = st_acc[i];
+        R.dbg[16] = st_leaves;
     }
 #endif
     for (int d = tid; d < D; d += BL_RE_NT)
-        if (d >= G || lead) R.inv_mass[(size_t)chain * R.m.D + bl_re_ext(m, d)] = V(RE_MINV)[d];
+        if (d >= G || lead) R.inv_mass[(size_t)chain * R.m.D + bl_re_ext(m, d)] = H(RE_MINV)[d];
     if (tid == 0 && flag > 1) atomicMax(R.status, flag);
     if (tid == 0 && lead) {
         if (R.xcd_local) R.xcd_local[chain] = xc.local ? 1 : 0;
