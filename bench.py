@@ -354,7 +354,9 @@ def main(argv=None):
             if ent:
                 traffic = ent.get("hbm_bytes_per_launch")
                 traffic_source = f"profiles/pmc_traffic.json (static; from {ent.get('source')})"
-        kernel_name = ("bl_re_nuts_kernel(BlReRun const*)" if wl["model"] == "occu_re" else
+        # random effects: <covariate capacity, model kind, rows in LDS, sampler-vector tier in LDS>
+        kernel_name = (f"bl_re_nuts_kernel<{4 if max(ds.Ks, ds.Ko) <= 4 else 16}, 0, {'true' if res0.lds_staged else 'false'}, {res0.lds_vector_tier}>"
+                       if wl["model"] == "occu_re" else
                        # <KS, KO, LDS-staged, model id, compute waves>: occu = 0; occu_rn = 5 (104-entry table, max_abundance <= 103)
                        f"bl_nuts_kernel<{ds.Ks}, {ds.Ko}, true, {5 if wl['model'] == 'occu_rn' else 0}, {res0.threads_per_wg // 64 - 1}>")
         us_leap = 1e3 * kernel_ms_mean / (leap_mean / CHAINS_PER_GPU)

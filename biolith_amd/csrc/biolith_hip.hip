@@ -1000,6 +1000,19 @@ static size_t re_geometry(BlReModel &m, int nloc, int with_hot, int dl_max)
     int tps = 1;
     while (tps < 64 && 2 * tps * nloc <= BL_RE_NT && 2 * tps <= m.J) tps *= 2; // spare threads share a site's visits
     m.tps = tps;
+    // two classes of waves (re_kernel.hpp: BlReSiteMap): more than four waves' worth of sites in one round -> the first four waves
+    // full, the remaining sites on the other four waves with as many threads per site as fit
+    m.w_a = BL_RE_NW; m.n_a = nloc; m.tps_b = tps;
+    {
+        const int lanes = nloc * tps, half = BL_RE_NT / 2;
+        if (lanes > half && lanes <= BL_RE_NT) {
+            const int n_a = half / tps, rest = nloc - n_a;
+            int tb = tps;
+            while (tb < 64 && 2 * tb * rest <= half && 2 * tb <= m.J) tb *= 2;
+            const char *e = getenv("BIOLITH_HIP_RE_NO_SPLIT"); // (measurement)
+            if (tb > tps && !(e && e[0] == '1')) { m.w_a = BL_RE_NW / 2; m.n_a = n_a; m.tps_b = tb; }
+        }
+    }
     // a workgroup's own LDS copy of its rows, and of the five vectors every leapfrog touches, when they fit (160 KB per CU,
     // one workgroup per CU; a few KB go to the reduction scratch)
     const size_t row_bytes = (size_t)m.n_rows * nloc * 4, budget = (size_t)150 * 1024;
@@ -1314,7 +1327,7 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     BL_HIP(re_nuts_dispatch(cap4 ? 4 : 16, run, 8 * k * ((C + 7) / 8), lds, st));
     BL_HIP(hipEventRecord(ds->ev1, st));
     ds->stream = st; ds->in_flight = true; ds->have_run = true;
-    ds->C = C; ds->S = S; ds->W = W; ds->k = k; ds->nloc = nloc; ds->lds_ld = 0; ds->lds_bytes = (int)lds; ds->staged = run.m.lds_rows; ds->nvp = 0; ds->ncw = BL_RE_NW;
+    ds->C = C; ds->S = S; ds->W = W; ds->k = k; ds->nloc = nloc; ds->lds_ld = 0; ds->lds_bytes = (int)lds; ds->staged = run.m.lds_rows | (run.m.lds_hot << 1); ds->nvp = 0; ds->ncw = BL_RE_NW;
     return BL_OK;
 }
 

@@ -43,6 +43,9 @@ struct BlReModel {
     float hn_is2_s, hn_is2_o;             // 1 / scale^2 of the HalfNormal priors of site_re_sd / obs_re_sd
     double u_const;                       // the constant part of the potential
     int tps;                              // threads that share one site in the site pass (power of two, <= 64)
+    // two classes of waves in the site pass (BlReSiteMap): waves [0, w_a) take sites [0, n_a) with `tps` threads per site, waves
+    // [w_a, NW) take the rest with tps_b (w_a = NW: every wave in the first class)
+    int w_a, n_a, tps_b;
     // a workgroup works on a LOCAL copy of this struct: n_sites = its slice, rows advanced to its first site, D / o_* the
     // local layout; what refers to the whole dataset stays in the fields below
     int n_total;                          // sites of the dataset
@@ -177,10 +180,11 @@ struct BlReXchg {
     unsigned epoch, spin_limit;
     bool local;              // all k workgroups proven to sit on one XCD: stores may stay in that XCD's L2 (nuts_kernel.hpp)
 };
+// The two halves can be called apart: what a workgroup does between them overlaps the hand-off.
 template <int NRED>
-__device__ __forceinline__ bool bl_re_exchange(BlReXchg &x, double *out, float *scr2 /*[k][NRED]*/, int *lds_flag, int nv)
+__device__ __forceinline__ void bl_re_publish(BlReXchg &x, const double *out, int nv)
 {
-    if (x.k == 1) return true;
+    if (x.k == 1) return;
     const int tid = threadIdx.x;
     x.epoch++;
     unsigned long long *base = x.buf + (((size_t)x.chain * 2 + (x.epoch & 1u)) * x.k) * NRED;
@@ -191,6 +195,13 @@ __device__ __forceinline__ bool bl_re_exchange(BlReXchg &x, double *out, float *
         else         // write-through: visible to any XCD
             __hip_atomic_store(base + (size_t)x.wg * NRED + tid, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+template <int NRED>
+__device__ __forceinline__ bool bl_re_collect(BlReXchg &x, double *out, float *scr2 /*[k][NRED]*/, int *lds_flag, int nv)
+{
+    if (x.k == 1) return true;
+    const int tid = threadIdx.x;
+    unsigned long long *base = x.buf + (((size_t)x.chain * 2 + (x.epoch & 1u)) * x.k) * NRED;
     for (int t = tid; t < x.k * nv; t += BL_RE_NT) {
         const int w = t / nv, v = t - w * nv;
         BlSpinBound bound;
@@ -212,6 +223,12 @@ __device__ __forceinline__ bool bl_re_exchange(BlReXchg &x, double *out, float *
     __syncthreads();
     return *lds_flag == 0;
 }
+template <int NRED>
+__device__ __forceinline__ bool bl_re_exchange(BlReXchg &x, double *out, float *scr2 /*[k][NRED]*/, int *lds_flag, int nv)
+{
+    bl_re_publish<NRED>(x, out, nv);
+    return bl_re_collect<NRED>(x, out, scr2, lds_flag, nv);
+}
 
 // Calls f(integral_constant<KB>, args...) for the smallest compiled covariate count KB in {1, 2, 4, 8, 16} (<= MK) that holds Ko.
 template <int MK, class F, class... A>
@@ -224,6 +241,31 @@ __device__ __forceinline__ void bl_re_tiered(int Ko, F &f, A... args)
     else f(std::integral_constant<int, MK>{}, args...);
 }
 
+// Which sites a thread works on in the site pass.  Threads of a site sit S = 64 / tps lanes apart in one wave: for a given visit the
+// S neighbouring lanes read S neighbouring sites (one segment of a row), and the visits are pooled by xor-shuffles over the upper
+// lane bits.  The pass is bound by VALU issue and a SIMD runs two of the workgroup's waves, so when the sites fill more than four
+// waves but not eight, the first four waves take full loads and the remaining sites are spread over the other four with more
+// threads per site (a shorter instruction stream): 313 sites x 10 visits: 4 x 64 sites with one thread each + 57 sites with four.
+struct BlReSiteMap {
+    int tps, S, sub, first, cnt, grp, ngrp, rounds;
+};
+__device__ __forceinline__ BlReSiteMap bl_re_site_map(const BlReModel &m)
+{
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const bool second = wave >= m.w_a;
+    BlReSiteMap q;
+    q.tps = second ? m.tps_b : m.tps;
+    q.S = 64 / q.tps;
+    q.sub = lane / q.S;
+    q.first = second ? m.n_a : 0;
+    q.cnt = second ? m.n_sites - m.n_a : min(m.n_a, m.n_sites);
+    const int wv = second ? wave - m.w_a : wave, nw = second ? BL_RE_NW - m.w_a : m.w_a;
+    q.grp = wv * q.S + (lane & (q.S - 1));
+    q.ngrp = nw * q.S;
+    q.rounds = (q.cnt + q.ngrp - 1) / q.ngrp;
+    return q;
+}
+
 // Site pass at position z: per-thread partials of the log-likelihood and of its gradient w.r.t. beta / alpha, and the
 // random effects' full potential gradient written to g (the effect's own likelihood term + its Normal(0, sd) prior).
 // part[0] = ll, part[1 .. 5] = d/d beta, part[6 .. 10] = d/d alpha.
@@ -232,10 +274,8 @@ template <int MK>
 __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float *__restrict__ rows, int ns, const float *__restrict__ z,
                                                 float *__restrict__ g, float (&part)[2 * MK + 3])
 {
-    // threads of a site sit S = 64 / tps lanes apart in one wave: for a given visit the S neighbouring lanes read S
-    // neighbouring sites (one segment of a row), and the visits are pooled by xor-shuffles over the upper lane bits
-    const int tid = threadIdx.x, tps = m.tps, S = 64 / tps, lane = tid & 63;
-    const int grp = (tid >> 6) * S + (lane & (S - 1)), sub = lane / S, ngrp = BL_RE_NT / tps;
+    const BlReSiteMap sm = bl_re_site_map(m);
+    const int tps = sm.tps, S = sm.S, sub = sm.sub;
     const int N = m.n_sites, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 1;
     // (every load of the pass is unconditional, its index clamped into the array, and the value selected afterwards: a load
     // under a wave-uniform condition `k <= Ko` becomes a branch around it -- twenty basic blocks per batch of visits -- and
@@ -252,11 +292,10 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
 #pragma unroll
     for (int k = 0; k < 2 * MK + 3; k++) part[k] = 0.0f;
     const int row_ka = m.KS + T * J * vw, row_kb = row_ka + T;
-    const int rounds = (N + ngrp - 1) / ngrp;
-    for (int rd = 0; rd < rounds; rd++) {
-        const int i_raw = rd * ngrp + grp;
-        const bool live = i_raw < N;
-        const int i = live ? i_raw : N - 1; // idle groups shadow the last site (their results are dropped)
+    for (int rd = 0; rd < sm.rounds; rd++) {
+        const int i_raw = rd * sm.ngrp + sm.grp;
+        const bool live = i_raw < sm.cnt;
+        const int i = sm.first + (live ? i_raw : sm.cnt - 1); // idle groups shadow the class's last site (their results are dropped)
         float x[MK];
         float eta = beta[0];
 #pragma unroll
@@ -376,8 +415,8 @@ template <int MK>
 __device__ __forceinline__ void bl_cs_site_pass(const BlReModel &m, const float *__restrict__ rows, int ns, const float *__restrict__ z,
                                                 float (&part)[2 * MK + 7])
 {
-    const int tid = threadIdx.x, tps = m.tps, S = 64 / tps, lane = tid & 63;
-    const int grp = (tid >> 6) * S + (lane & (S - 1)), sub = lane / S, ngrp = BL_RE_NT / tps;
+    const BlReSiteMap sm = bl_re_site_map(m);
+    const int tps = sm.tps, S = sm.S, sub = sm.sub;
     const int N = m.n_sites, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 1;
     // (every load of the pass is unconditional, its index clamped into the array, and the value selected afterwards: a load
     // under a wave-uniform condition `k <= Ko` becomes a branch around it -- twenty basic blocks per batch of visits -- and
@@ -395,11 +434,10 @@ __device__ __forceinline__ void bl_cs_site_pass(const BlReModel &m, const float 
     const float l_f1_z0 = -87.33654475f, l_f0_z0 = -1.1754944e-38f; // log(tiny), log1p(-tiny): numpyro clamps P(f = 1 | z = 0) = 0 to tiny
 #pragma unroll
     for (int k = 0; k < 2 * MK + 7; k++) part[k] = 0.0f;
-    const int rounds = (N + ngrp - 1) / ngrp;
-    for (int rd = 0; rd < rounds; rd++) {
-        const int i_raw = rd * ngrp + grp;
-        const bool live = i_raw < N;
-        const int i = live ? i_raw : N - 1;
+    for (int rd = 0; rd < sm.rounds; rd++) {
+        const int i_raw = rd * sm.ngrp + sm.grp;
+        const bool live = i_raw < sm.cnt;
+        const int i = sm.first + (live ? i_raw : sm.cnt - 1); // idle groups shadow the class's last site (their results are dropped)
         float x[MK];
         float eta = beta[0];
 #pragma unroll
@@ -683,7 +721,12 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
 #ifdef BL_STAMPS
     long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = (long long)clock64(), st_leaves = 0;
 #endif
-    auto evaluate = [&]() -> double {
+    // evaluate_a: site pass at H(RE_CZ) -- the random effects' gradients are complete after it -- and the workgroup's sums published
+    // to the chain; evaluate_b: the chain's sums collected, the gradients of the fixed effects / log sds written by the threads
+    // that own those coordinates; returns U (same value in every thread).
+    bool ev_first = false;
+    int ev_nv = 0;
+    auto evaluate_a = [&]() {
         float v[NV1];
         const float *z = H(RE_CZ);
         float *g = H(RE_CG);
@@ -709,13 +752,18 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
         // XCD census (first exchange): k sum(x^2) == (sum x)^2 iff every workgroup reports the same XCC id
         v[OX + 4] = tid == 0 ? xcc : 0.0f; v[OX + 5] = tid == 0 ? xcc * xcc : 0.0f;
         BL_RE_T(0)
-        const bool first = xc.epoch == 0u;
-        const int nv = KIND == 1 ? NV1 : (first ? OX + 6 : OX + 4);
-        bl_re_block_sum<NV1, NRED>(v, scr, red, nv, xc.k == 1);
+        ev_first = xc.epoch == 0u;
+        ev_nv = KIND == 1 ? NV1 : (ev_first ? OX + 6 : OX + 4);
+        bl_re_block_sum<NV1, NRED>(v, scr, red, ev_nv, xc.k == 1);
         BL_RE_T(9)
-        if (!bl_re_exchange<NRED>(xc, red, scr2, &xflag, nv)) flag = 4;
+        bl_re_publish<NRED>(xc, red, ev_nv);
+    };
+    auto evaluate_b = [&]() -> double {
+        const float *z = H(RE_CZ);
+        float *g = H(RE_CG);
+        if (!bl_re_collect<NRED>(xc, red, scr2, &xflag, ev_nv)) flag = 4;
         BL_RE_T(10)
-        if (first && R.allow_local) xc.local = ((double)R.k * red[OX + 5] == red[OX + 4] * red[OX + 4]); // exact: small integers
+        if (ev_first && R.allow_local) xc.local = ((double)R.k * red[OX + 5] == red[OX + 4] * red[OX + 4]); // exact: small integers
         if (red[OX + 3] > 0.0) flag = 5;
         for (int d = tid; d < G; d += BL_RE_NT)
             g[d] = (KIND == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red) : bl_re_global_grad<MK>(m, d, z[d], red);
@@ -727,8 +775,8 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
 
     // momentum r ~ N(0, M), fresh tree, first doubling, and the first leaf's half step (start in CZ / CR / CG)
     auto new_transition = [&]() {
-        // the abort flag is host memory: one read is a PCIe round trip (3 500 - 3 900 cycles measured, a seventh of a leapfrog when
-        // it was read at every leaf), so it is sampled once per transition, by one thread, and consumed by the next leaf's sums
+        // the abort flag is host memory (a PCIe round trip per read): sampled once per transition, by one thread, and consumed by
+        // the next leaf's sums
         if (lead && tid == 0 && R.abort_flag) abort_req = *(volatile const int *)R.abort_flag ? 1.0f : 0.0f;
         going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
         epsdir = going_right ? eps : -eps;
@@ -763,7 +811,8 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
         H(RE_MINV)[d] = 1.0f; V(RE_WFMEAN)[d] = 0.0f; V(RE_WFM2)[d] = 0.0f;
     }
     __syncthreads();
-    Ucur = evaluate();
+    evaluate_a();
+    Ucur = evaluate_b();
     __syncthreads(); // every coordinate's gradient is in place
     for (int d = tid; d < D; d += BL_RE_NT) { V(RE_TH)[d] = H(RE_CZ)[d]; V(RE_GR)[d] = H(RE_CG)[d]; }
     if (total <= 0) flag = 1;
@@ -771,7 +820,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
 
     while (flag == 0) {
         // ---- the leaf's position is in CZ, its half-step momentum in CR (hmc_util velocity Verlet) ----
-        const double Un = evaluate();
+        evaluate_a();
         if (it < W) nleap_w++; else nleap_s++;
         // ---- second half step; kinetic energy; subtree momentum sum; U-turn dot products for every checkpoint this
         //      leaf closes (_leaf_idx_to_ckpt_idxs) and for the whole tree in case the subtree ends here ----
@@ -783,37 +832,56 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
 #pragma unroll
         for (int k = 0; k < 26; k++) acc[k] = 0.0f;
         const int nck = odd ? idx_max - idx_min + 1 : 0;
-        for (int d = tid; d < D; d += BL_RE_NT) {
-            // (coordinates below G: this thread wrote their gradient in evaluate(); the others' were published by its barriers)
-            const float mi = H(RE_MINV)[d];
-            const float mc = (d >= G || lead) ? mi : 0.0f; // weight of this coordinate in the chain-wide sums
-            const float cr = bl_leaf_momentum(H(RE_CR)[d], epsdir, H(RE_CG)[d]);
-            H(RE_CR)[d] = cr;
-            acc[0] = fmaf(mc * cr, cr, acc[0]);
-            const float srs = leaf_idx == 0 ? cr : H(RE_SRSUM)[d] + cr;
-            H(RE_SRSUM)[d] = srs;
-            if (!odd) {
-                Wm(RE_CKR + idx_max)[d] = cr;
-                Wm(RE_CKR + BL_MAX_DEPTH + idx_max)[d] = srs;
-            } else {
+        // One pass costs its dependent latency (~1.4 k cycles) whatever the coordinate count, so every load is issued before the
+        // first store (the compiler must assume the vectors alias and will not move a load above a store), and the checkpoint
+        // loop is compiled for QN = 0 (even leaf), 1, 2, 4 or all checkpoints, loaded unconditionally (index clamped, weight 0).
+        auto second_half = [&](auto qn_, int d) {
+            constexpr int QN = decltype(qn_)::value;
+            const float mi = H(RE_MINV)[d], cr0 = H(RE_CR)[d], cg = H(RE_CG)[d], srs0 = H(RE_SRSUM)[d];
+            const float r_other = Wm(going_right ? RE_RL : RE_RR)[d], rsum = Wm(RE_RSUM)[d];
+            float ck[QN > 0 ? QN : 1], cs[QN > 0 ? QN : 1];
 #pragma unroll
-                for (int q = 0; q < BL_MAX_DEPTH; q++) {
-                    const int i = idx_min + q;
-                    if (i <= idx_max) {
-                        const float ck = Wm(RE_CKR + i)[d];
-                        const float s_i = srs - Wm(RE_CKR + BL_MAX_DEPTH + i)[d] + ck;
-                        const float rho = s_i - 0.5f * (ck + cr);
-                        acc[3 + 2 * q] = fmaf(mc * ck, rho, acc[3 + 2 * q]);
-                        acc[4 + 2 * q] = fmaf(mc * cr, rho, acc[4 + 2 * q]);
-                    }
-                }
+            for (int q = 0; q < QN; q++) {
+                const int i = min(idx_min + q, idx_max);
+                ck[q] = Wm(RE_CKR + i)[d];
+                cs[q] = Wm(RE_CKR + BL_MAX_DEPTH + i)[d];
             }
-            const float r_other = going_right ? Wm(RE_RL)[d] : Wm(RE_RR)[d];
+            const float mc = (d >= G || lead) ? mi : 0.0f; // weight of this coordinate in the chain-wide sums
+            const float cr = bl_leaf_momentum(cr0, epsdir, cg);
+            acc[0] = fmaf(mc * cr, cr, acc[0]);
+            const float srs = leaf_idx == 0 ? cr : srs0 + cr;
+#pragma unroll
+            for (int q = 0; q < QN; q++) {
+                const float mq = idx_min + q <= idx_max ? mc : 0.0f;
+                const float s_i = srs - cs[q] + ck[q];
+                const float rho = s_i - 0.5f * (ck[q] + cr);
+                acc[3 + 2 * q] = fmaf(mq * ck[q], rho, acc[3 + 2 * q]);
+                acc[4 + 2 * q] = fmaf(mq * cr, rho, acc[4 + 2 * q]);
+            }
             const float rl = going_right ? r_other : cr, rr = going_right ? cr : r_other;
-            const float rho_t = (Wm(RE_RSUM)[d] + srs) - 0.5f * (rl + rr);
+            const float rho_t = (rsum + srs) - 0.5f * (rl + rr);
             acc[1] = fmaf(mc * rl, rho_t, acc[1]);
             acc[2] = fmaf(mc * rr, rho_t, acc[2]);
-        }
+            H(RE_CR)[d] = cr;
+            H(RE_SRSUM)[d] = srs;
+            if (QN == 0) { // even leaf: it opens checkpoint idx_max
+                Wm(RE_CKR + idx_max)[d] = cr;
+                Wm(RE_CKR + BL_MAX_DEPTH + idx_max)[d] = srs;
+            }
+        };
+        auto second_half_all = [&](auto qn_) {
+            for (int d = tid; d < D; d += BL_RE_NT) second_half(qn_, d);
+        };
+        // (Measured and dropped: running this loop for the random effects between evaluate_a and evaluate_b -- their gradients are
+        // complete after the site pass -- to overlap the exchange's hand-off.  7 % SLOWER: collecting granules that are already
+        // there still costs one L2 round trip + the sums (~2 k of the exchange's 2.4 k cycles), while the extra pass of this loop
+        // for the handful of fixed effects costs its full latency again, ~1.4 k.)
+        const double Un = evaluate_b();
+        if (!odd) second_half_all(std::integral_constant<int, 0>{});
+        else if (nck <= 1) second_half_all(std::integral_constant<int, 1>{});
+        else if (nck <= 2) second_half_all(std::integral_constant<int, 2>{});
+        else if (nck <= 4) second_half_all(std::integral_constant<int, 4>{});
+        else second_half_all(std::integral_constant<int, BL_MAX_DEPTH>{});
         BL_RE_T(2)
         bl_re_block_sum<26, NRED>(acc, scr, red2, 3 + 2 * nck, xc.k == 1);
         BL_RE_T(11)
@@ -895,11 +963,11 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
         BL_RE_T(4)
         const float wfn = (float)wf_n;
         for (int d = tid; d < D; d += BL_RE_NT) {
-            const float cz = H(RE_CZ)[d], cg = H(RE_CG)[d], cr = H(RE_CR)[d];
+            const float cz = H(RE_CZ)[d], cg = H(RE_CG)[d], cr = H(RE_CR)[d], mi = H(RE_MINV)[d]; // (loads before the first store)
             if (take) { Wm(RE_SZP)[d] = cz; Wm(RE_SGP)[d] = cg; }
             if (!sub_done) { // the subtree goes on from this leaf
                 float rh, zn;
-                bl_next_leaf(cz, cr, cg, epsdir, H(RE_MINV)[d], rh, zn);
+                bl_next_leaf(cz, cr, cg, epsdir, mi, rh, zn);
                 H(RE_CZ)[d] = zn; H(RE_CR)[d] = rh;
                 continue;
             }
@@ -909,7 +977,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
             if (cont) { // next doubling: its first leaf starts from the tree edge on the chosen side
                 const float ez = V(going_right ? RE_ZR : RE_ZL)[d], er = Wm(going_right ? RE_RR : RE_RL)[d], eg = V(going_right ? RE_GRR : RE_GL)[d];
                 float rh, zn;
-                bl_next_leaf(ez, er, eg, epsdir, H(RE_MINV)[d], rh, zn);
+                bl_next_leaf(ez, er, eg, epsdir, mi, rh, zn);
                 H(RE_CZ)[d] = zn; H(RE_CR)[d] = rh; H(RE_CG)[d] = eg;
                 continue;
             }

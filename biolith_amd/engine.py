@@ -40,6 +40,7 @@ class NutsResult:
     lds_staged: bool
     chains_l2_local: int = 0      # chains that ran the verified same-XCD (L2-local) exchange
     threads_per_wg: int = 0       # 64 x (compute waves + 1 control wave)
+    lds_vector_tier: int = 0      # random-effects / occu_cs kernels: sampler vectors kept in LDS (0 none, 1 the leaf in flight, 2 all a leapfrog touches)
     comm_init_ms: float = 0.0     # fit(devices=[...]): wall time of ncclCommInitAll (outside the sampling clock)
 
 
@@ -240,7 +241,7 @@ class OccuDataset:
         _ffi.check(self._lib.bl_nuts_geometry(self._h, C.byref(k), C.byref(thr), C.byref(lds), C.byref(staged), C.byref(loc)))
         return NutsResult(a["draws"], a["diverging"].astype(bool), a["num_steps"], a["accept_prob"], a["potential_energy"],
                           a["step_size"], a["inv_mass"], a["n_leapfrog"], self.elapsed_ms(),
-                          k.value, lds.value, bool(staged.value), loc.value, thr.value)
+                          k.value, lds.value, bool(staged.value & 1), loc.value, thr.value, staged.value >> 1)
 
     def fetch(self) -> NutsResult:
         Cn, S = self._shape

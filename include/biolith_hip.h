@@ -210,7 +210,9 @@ int bl_nuts_elapsed_ms(bl_dataset *ds, float *ms);
 /* Device address of the last launch's draws [C][S][D] float32 (for an RCCL gather). */
 int bl_nuts_device_draws(bl_dataset *ds, void **dev_ptr, size_t *bytes);
 /* Geometry the last launch used; the last field counts the chains whose workgroups were verified
- * (HW_REG_XCC_ID census) to share one XCD and therefore ran the L2-local exchange. */
+ * (HW_REG_XCC_ID census) to share one XCD and therefore ran the L2-local exchange.  lds_staged: bit 0 = the
+ * site data were staged in LDS; random-effects / occu_cs launches: bits 1-2 = how many of the sampler's
+ * vectors lived in LDS (0 none, 1 the five of the leaf in flight, 2 every vector a leapfrog touches). */
 int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads_per_wg, int *lds_bytes, int *lds_staged,
                      int *chains_on_l2_local_exchange);
 
