@@ -347,6 +347,7 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
                     for (int k = 0; k <= KB; k++) ga[k] = fmaf(s, w[b][k], ga[k]);
                 }
             };
+            // (measured equal: a shorter last batch -- lengths 1 .. 3 compiled beside BL_RE_VB -- instead of a full one with dropped visits)
             for (int jb = sub; jb < J; jb += tps * BL_RE_VB) bl_re_tiered<MK>(Ko, batch, jb);
             for (int msk = S; msk < 64; msk <<= 1) { // the site's threads pool their visits
                 a += __shfl_xor(a, msk);
@@ -869,6 +870,8 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
                 Wm(RE_CKR + BL_MAX_DEPTH + idx_max)[d] = srs;
             }
         };
+        // (Measured and dropped: two coordinates per thread and pass for slices of more than NT coordinates, both loaded before either
+        // is stored, here and in the vector loop after the decisions: 10 % slower at 634 and 764 coordinates per slice.)
         auto second_half_all = [&](auto qn_) {
             for (int d = tid; d < D; d += BL_RE_NT) second_half(qn_, d);
         };
