@@ -1018,6 +1018,7 @@ static size_t re_geometry(BlReModel &m, int nloc, int with_hot, int dl_max)
     const size_t row_bytes = (size_t)m.n_rows * nloc * 4, budget = (size_t)150 * 1024;
     const size_t hot_bytes = (size_t)RE_HOT * dl_max * 4, warm_bytes = (size_t)RE_WARM * dl_max * 4;
     m.lds_rows = row_bytes <= budget ? 1 : 0;
+    if (const char *e = getenv("BIOLITH_HIP_RE_LDS_ROWS")) m.lds_rows = std::min(m.lds_rows, atoi(e)); // (tests: every instantiation)
     const size_t used = m.lds_rows ? row_bytes : 0;
     m.lds_hot = !with_hot ? 0 : (used + warm_bytes <= budget ? 2 : (used + hot_bytes <= budget ? 1 : 0));
     if (const char *e = getenv("BIOLITH_HIP_RE_LDS_TIER")) m.lds_hot = std::min(m.lds_hot, atoi(e)); // (measurement)

@@ -234,3 +234,65 @@ def test_re_large_sizes_against_the_oracle(n_sites, site, obs):
     assert r.wgs_per_chain >= 16
     assert np.array_equal(o["num_steps"], r.num_steps), (o["num_steps"], r.num_steps)
     assert np.allclose(o["draws"], r.draws, atol=5e-3)
+
+
+def _with_env(env, fn):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("what", ["re_cap4", "re_cap16", "cs"])
+def test_re_kernel_instantiations_agree_bit_for_bit(what):
+    """bl_re_nuts_kernel<MK, KIND, LROWS, LT> is compiled for the covariate capacity, the model kind, rows in LDS or in device memory,
+    and none / five / thirty sampler vectors in LDS.  Where the data live changes no arithmetic: all six (rows, tier) forms of a
+    capacity and kind give bit-identical draws (the launch reports which form ran)."""
+    rng = np.random.default_rng(5)
+    if what == "cs":
+        g = load_golden("cs_small_2x2")
+        kw = dict(model="occu_cs", prior_mu=((0.5, 8.0), (1.0, 12.0)), prior_sigma=((5.0, 1.0), (3.0, 0.5)))
+        ds = OccuDataset(g["site_covs"], g["obs_covs"], g["obs"], **kw)
+        init = rng.uniform(-1, 1, size=(2, ds.D))
+        init[:, -4:] = np.array([0.3, 1.8, 1.9, 1.2])
+    else:
+        ks, ko = (3, 2) if what == "re_cap4" else (6, 9)
+        N, J = 90, 6
+        X = rng.normal(size=(N, ks)).astype(np.float32)
+        W = rng.normal(size=(N, 1, J, ko)).astype(np.float32)
+        Y = (rng.uniform(size=(1, N, 1, J)) < 0.4).astype(np.float32)
+        ds = OccuDataset(X, W, Y, model="occu_re", site_random_effects=True, obs_random_effects=True)
+        init = rng.uniform(-0.5, 0.5, size=(2, ds.D))
+    run = lambda: ds.nuts(num_warmup=30, num_samples=10, num_chains=2, seed=2, init_theta=init, wgs_per_chain=3)
+    ref = _with_env({}, run)
+    assert ref.lds_staged and ref.lds_vector_tier == 2 and np.all(np.isfinite(ref.draws))
+    for rows in (1, 0):
+        for tier in (2, 1, 0):
+            r = _with_env(dict(BIOLITH_HIP_RE_LDS_ROWS=rows, BIOLITH_HIP_RE_LDS_TIER=tier), run)
+            assert (r.lds_staged, r.lds_vector_tier) == (bool(rows), tier)
+            assert np.array_equal(r.draws, ref.draws) and np.array_equal(r.num_steps, ref.num_steps), (rows, tier)
+            assert np.array_equal(r.step_size, ref.step_size) and np.array_equal(r.inv_mass, ref.inv_mass)
+
+
+def test_re_site_pass_wave_classes_build_the_same_trees():
+    """300 sites in one workgroup fill 4.7 waves: four waves take a site per lane, the other four share the remaining 44 sites two
+    lanes per site (BlReSiteMap).  Same trees and draws (to float32 summation order) as with one class, and as the oracle."""
+    rng = np.random.default_rng(11)
+    N, J = 300, 8
+    X = rng.normal(size=(N, 2)).astype(np.float32)
+    W = rng.normal(size=(N, 1, J, 2)).astype(np.float32)
+    Y = (rng.uniform(size=(1, N, 1, J)) < 0.4).astype(np.float32)
+    kw = dict(model="occu_re", site_random_effects=True, obs_random_effects=True)
+    od, ds = oracle.OracleData(X, W, Y, **kw), OccuDataset(X, W, Y, **kw)
+    run = lambda: ds.nuts(num_warmup=0, num_samples=4, num_chains=2, seed=3, wgs_per_chain=1)
+    two, one = _with_env({}, run), _with_env(dict(BIOLITH_HIP_RE_NO_SPLIT=1), run)
+    o = oracle.nuts_run(od, 0, 4, num_chains=2, seed=3)
+    assert np.array_equal(o["num_steps"][:, :2], two.num_steps[:, :2]) and np.array_equal(one.num_steps[:, :2], two.num_steps[:, :2])
+    assert np.allclose(o["draws"][:, 0], two.draws[:, 0], atol=5e-3) and np.allclose(one.draws[:, :2], two.draws[:, :2], atol=2e-3)
