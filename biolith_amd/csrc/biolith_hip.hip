@@ -579,6 +579,7 @@ struct ModelOpts {
     int model = 0, max_abundance = 0, fp_mode = 0;
     double fp_a = 2.0, fp_b = 5.0;           // model 2: Beta(a, b); model 3: Exponential(rate = fp_a)
     const float *session_duration = nullptr; // model 3: [N][T][J]
+    bool vector_kernels = false;             // the rows feed re_kernel.hpp (random effects): no 64-lane limit on species x coefficients
 };
 static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const float *site_covs, const float *obs_covs,
                                const float *obs, const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha,
@@ -678,7 +679,7 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
     ds->pb = pb; ds->pa = pa;
     if (!ds->kern) { delete ds; return bl_fail(BL_ERR_UNSUPPORTED, "no kernel for capacity (%d,%d)", pad_covs(Ks), pad_covs(Ko)); }
     const int V = T * J, KS = ds->KS, KO = ds->KO;
-    if (S > 1 && (S * BL_SP_COEF(KS, KO) + 2 > 64 || S * BL_SP_PART(KS, KO) * BL_CWAVES_MAX > BL_PART_FLOATS || ds->D + 4 > 64)) {
+    if (S > 1 && !mo.vector_kernels && (S * BL_SP_COEF(KS, KO) + 2 > 64 || S * BL_SP_PART(KS, KO) * BL_CWAVES_MAX > BL_PART_FLOATS || ds->D + 4 > 64)) {
         delete ds;
         return bl_fail(BL_ERR_UNSUPPORTED, "n_species=%d x (Ks=%d, Ko=%d): too many coordinates for one joint chain (sample the species one by one)", S, Ks, Ko);
     }
@@ -1037,33 +1038,39 @@ extern "C" int bl_dataset_create_re(const bl_dims *dims, const float *site_covs,
                        BL_RE_MAXK, dims->n_site_covs, dims->n_obs_covs);
     if ((site_random_effects && !(prior_site_re_sd_scale > 0.0)) || (obs_random_effects && !(prior_obs_re_sd_scale > 0.0)))
         return bl_fail(BL_ERR_INVALID, "HalfNormal prior needs scale > 0");
-    // the rows of the plain model (mask, NaN -> 0, sign folding) are exactly what the random-effects site pass reads
-    int rc = dataset_create_impl(ModelOpts{}, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
+    if (dims && dims->n_species > BL_RE_SMAX)
+        return bl_fail(BL_ERR_UNSUPPORTED, "random effects: at most %d species under one chain (n_species=%d)", BL_RE_SMAX, dims->n_species);
+    // the rows of the plain model (mask, NaN -> 0, sign folding; one block of visit rows per species) are exactly what the
+    // random-effects site pass reads
+    ModelOpts mo; mo.vector_kernels = true;
+    int rc = dataset_create_impl(mo, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
     if (rc) return rc;
     bl_dataset *ds = *out;
-    const int N = dims->n_sites, T = dims->n_periods, J = dims->n_replicates, Ks = ds->Ks, Ko = ds->Ko;
-    const long long Dll = (long long)Ks + Ko + 2 + (site_random_effects ? 1 + 2LL * N : 0) + (obs_random_effects ? 1 + (long long)N * T * J : 0);
+    const int S = dims->n_species, N = dims->n_sites, T = dims->n_periods, J = dims->n_replicates, Ks = ds->Ks, Ko = ds->Ko;
+    // draws: [species 0: beta, alpha | species 1: ... | log site_re_sd | log obs_re_sd | site_re_occ [S][N] | site_re_det [S][N] | obs_re [S][N][T][J]]
+    const long long Dll = (long long)S * (Ks + Ko + 2) + (site_random_effects ? 1 + 2LL * S * N : 0) + (obs_random_effects ? 1 + (long long)S * N * T * J : 0);
     if (Dll > (1LL << 24)) { bl_dataset_destroy(ds); *out = nullptr; return bl_fail(BL_ERR_UNSUPPORTED, "%lld coordinates", Dll); }
     BlReModel &m = ds->re;
     m.rows = ds->dd.rows; m.n_sites = N; m.n_stride = ds->dd.n_stride; m.T = T; m.J = J; m.Ks = Ks; m.Ko = Ko; m.KS = ds->KS; m.KO = ds->KO;
     m.site_re = site_random_effects ? 1 : 0; m.obs_re = obs_random_effects ? 1 : 0;
-    m.G0 = Ks + Ko + 2; m.G = m.G0 + m.site_re + m.obs_re; m.D = (int)Dll;
+    m.n_species = S; m.G0s = Ks + Ko + 2; m.sp = 0; m.cb = 0; m.rv0 = ds->KS; m.sp_rows = T * J * (ds->KO + 1) + 2 * T;
+    m.G0 = S * m.G0s; m.G = m.G0 + m.site_re + m.obs_re; m.D = (int)Dll;
     int at = m.G0;
     m.o_phi_s = m.site_re ? at++ : -1;
     m.o_phi_o = m.obs_re ? at++ : -1;
     m.o_u = m.o_v = m.o_e = -1;
-    if (m.site_re) { m.o_u = at; m.o_v = at + N; at += 2 * N; }
-    if (m.obs_re) { m.o_e = at; at += N * T * J; }
+    if (m.site_re) { m.o_u = at; m.o_v = at + S * N; at += 2 * S * N; }
+    if (m.obs_re) { m.o_e = at; at += S * N * T * J; }
     m.loc_b = ds->dd.loc_b; m.isc2_b = ds->dd.isc2_b; m.loc_a = ds->dd.loc_a; m.isc2_a = ds->dd.isc2_a;
     m.l1_b = 0.0f; m.l1_a = 0.0f;
     m.hn_is2_s = site_random_effects ? (float)(1.0 / (prior_site_re_sd_scale * prior_site_re_sd_scale)) : 0.0f;
     m.hn_is2_o = obs_random_effects ? (float)(1.0 / (prior_obs_re_sd_scale * prior_obs_re_sd_scale)) : 0.0f;
     const double HL2PI = 0.91893853320467274178, HN0 = 0.5 * std::log(2.0 / 3.14159265358979323846);
     m.u_const = ds->dd.prior_const;
-    if (m.site_re) m.u_const += -HN0 + std::log(prior_site_re_sd_scale) + 2.0 * N * HL2PI;
-    if (m.obs_re) m.u_const += -HN0 + std::log(prior_obs_re_sd_scale) + (double)N * T * J * HL2PI;
+    if (m.site_re) m.u_const += -HN0 + std::log(prior_site_re_sd_scale) + 2.0 * S * N * HL2PI;
+    if (m.obs_re) m.u_const += -HN0 + std::log(prior_obs_re_sd_scale) + (double)S * N * T * J * HL2PI;
     m.n_total = N; m.s0 = 0; m.x_u = m.o_u; m.x_v = m.o_v; m.x_e = m.o_e;
-    m.n_rows = ds->n_rows;
+    m.n_rows = ds->KS + m.sp_rows; // what ONE workgroup stages: the site covariates and its species' block
     re_geometry(m, N, 0, 0); // one workgroup over all sites (bl_logp_grad); bl_nuts_launch picks its own slices
     ds->model = 6; ds->D = m.D;
     return BL_OK;
@@ -1106,6 +1113,7 @@ extern "C" int bl_dataset_create_cs(const bl_dims *dims, const float *site_covs,
     m.Ks = Ks; m.Ko = Ko; m.KS = ds->KS; m.KO = ds->KO;
     m.site_re = 0; m.obs_re = 0; m.kind = 1; m.scores = ds->d_scores;
     m.G0 = Ks + Ko + 2; m.G = m.G0 + 4; m.D = m.G;
+    m.n_species = 1; m.G0s = m.G0; m.sp = 0; m.cb = 0; m.rv0 = ds->KS; m.sp_rows = V * (ds->KO + 1) + 2 * dims->n_periods;
     m.o_phi_s = m.o_phi_o = m.o_u = m.o_v = m.o_e = -1;
     m.loc_b = ds->dd.loc_b; m.isc2_b = ds->dd.isc2_b; m.loc_a = ds->dd.loc_a; m.isc2_a = ds->dd.isc2_a; m.l1_b = 0.0f; m.l1_a = 0.0f;
     m.hn_is2_s = m.hn_is2_o = 0.0f;
@@ -1230,10 +1238,15 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     }
     int ncu = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ds->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
-    k = std::max(1, std::min(std::min(k, 32), std::min(ncu * 7 / 8 / C, N))); // (an eighth of the CUs spare: nobody may wait for a CU)
+    k = std::max(1, std::min(std::min(k, 32), std::min(ncu * 7 / 8 / C, N * g.n_species))); // (an eighth of the CUs spare: nobody may wait for a CU)
+    // several species: the chain's workgroups are n_species groups of kps, each group slicing the sites of its species
+    const int nsp = g.n_species;
+    int kps = std::max(1, k / nsp);
+    const int nloc = (N + kps - 1) / kps;
+    kps = (N + nloc - 1) / nloc; // no empty slice
+    k = nsp * kps;
+    if (k > 32) return bl_fail(BL_ERR_UNSUPPORTED, "n_species=%d needs %d workgroups per chain (at most 32)", nsp, k);
     if (C * k > ncu) return bl_fail(BL_ERR_UNSUPPORTED, "num_chains=%d random-effects chains need %d resident workgroups (%d CUs)", C, C * k, ncu);
-    const int nloc = (N + k - 1) / k;
-    k = (N + nloc - 1) / nloc; // no empty slice
     const int dl_max = g.G + nloc * per_site;
 
     const RunLayout RL = result_layout((size_t)C, Sa, D);
@@ -1271,20 +1284,20 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     rng_streams_strided(cfg->seed, cfg->chain_offset, stride, C, all.data());
     for (int c = 0; c < C; c++)
         for (int w = 0; w < k; w++) {
-            const int s0 = w * nloc, cnt = std::min(nloc, N - s0);
+            const int sp = w / kps, s0 = (w - sp * kps) * nloc, cnt = std::min(nloc, N - s0);
             uint32_t *dst = rs.data() + ((size_t)c * k + w) * (dl_max + 2) * 4;
             const uint32_t *src = all.data() + (size_t)c * stride * 4;
             auto put = [&](int local, int ext) { memcpy(dst + (size_t)local * 4, src + (size_t)ext * 4, 16); };
             int at = 0;
             for (; at < g.G; at++) put(at, at);
             if (g.site_re) {
-                for (int i = 0; i < cnt; i++) put(at + i, g.o_u + s0 + i);
-                for (int i = 0; i < cnt; i++) put(at + cnt + i, g.o_v + s0 + i);
+                for (int i = 0; i < cnt; i++) put(at + i, g.o_u + sp * N + s0 + i);
+                for (int i = 0; i < cnt; i++) put(at + cnt + i, g.o_v + sp * N + s0 + i);
                 at += 2 * cnt;
             }
             if (g.obs_re)
                 for (int v = 0; v < V; v++)
-                    for (int i = 0; i < cnt; i++) put(at + v * cnt + i, g.o_e + (s0 + i) * V + v);
+                    for (int i = 0; i < cnt; i++) put(at + v * cnt + i, g.o_e + (sp * N + s0 + i) * V + v);
             put(dl_max, (int)D);         // scalar stream
             put(dl_max + 1, (int)D + 1); // direction stream
         }

@@ -27,6 +27,7 @@
 #define BL_RE_NV1(MK) (2 * (MK) + 11)
 #define BL_RE_NRED_OF(MK) (BL_RE_NV1(MK) > 26 ? BL_RE_NV1(MK) : 26) // widest block reduction (the second one: 3 + 2 x 10 checkpoints)
 #define BL_RE_NRED_MAX BL_RE_NRED_OF(BL_RE_MAXK)
+#define BL_RE_SMAX 8             // species under one chain (each needs at least one of the chain's <= 32 workgroups)
 #define BL_RE_VB 4               // visits whose loads are issued together in the site pass
 
 struct BlReModel {
@@ -36,7 +37,10 @@ struct BlReModel {
     int kind;                             // 0: occu with random effects; 1: occu_cs (continuous scores, no effects: D = G = G0 + 4)
     const float *scores;                  // kind 1: the replicates' scores, site-fastest [T J][n_stride] (0 where masked)
     float cs_mu[4], cs_sg[4];             // kind 1: Normal(loc, scale) of mu0 and of mu1's base; Gamma(concentration, rate) of sigma0, sigma1
-    int G0, G, D;                         // fixed effects, + log sds, all coordinates
+    int G0, G, D;                         // fixed effects (of all species), + log sds, all coordinates
+    // several species under one chain (occu.py:182-196: beta, alpha and the effects inside the species plate; 170-173: the sds outside
+    // it, i.e. shared): a workgroup's slice belongs to ONE species -- its G0s coefficients start at cb, its visit rows at row rv0
+    int n_species, G0s, sp, cb, rv0, sp_rows;
     int o_phi_s, o_phi_o, o_u, o_v, o_e;  // offsets (internal order = external order except inside the obs_re block)
     float loc_b, isc2_b, loc_a, isc2_a;   // Normal priors of beta / alpha (isc2 = 0 for a Laplace prior)
     float l1_b, l1_a;                     // Laplace priors: 1 / scale (0 for a Normal prior)
@@ -121,15 +125,16 @@ __device__ __forceinline__ int bl_re_ext(const BlReModel &m, int d)
     return m.x_e + (m.s0 + i) * (m.T * m.J) + v;
 }
 
-// The slice [s0, s0 + cnt) of the dataset as a model of its own (see BlReModel).
-__device__ __forceinline__ BlReModel bl_re_slice(const BlReModel &g, int s0, int cnt)
+// The slice [s0, s0 + cnt) of species sp's sites as a model of its own (see BlReModel).
+__device__ __forceinline__ BlReModel bl_re_slice(const BlReModel &g, int sp, int s0, int cnt)
 {
     BlReModel m = g;
     m.rows = g.rows + s0; m.n_sites = cnt; m.s0 = s0;
+    m.sp = sp; m.cb = sp * g.G0s; m.rv0 = g.KS + sp * g.sp_rows;
     if (g.kind == 1) m.scores = g.scores + s0;
     int at = g.G;
-    if (g.site_re) { m.o_u = at; m.o_v = at + cnt; at += 2 * cnt; }
-    if (g.obs_re) { m.o_e = at; at += cnt * g.T * g.J; }
+    if (g.site_re) { m.o_u = at; m.o_v = at + cnt; at += 2 * cnt; m.x_u = g.x_u + sp * g.n_total; m.x_v = g.x_v + sp * g.n_total; }
+    if (g.obs_re) { m.o_e = at; at += cnt * g.T * g.J; m.x_e = g.x_e + sp * g.n_total * g.T * g.J; }
     m.D = at;
     return m;
 }
@@ -177,6 +182,7 @@ __device__ __forceinline__ void bl_re_block_sum(float (&v)[NV], float *scr /*[NW
 struct BlReXchg {
     unsigned long long *buf; // [C][2][k][NRED]
     int k, wg, chain;
+    int n_species;           // > 1: workgroups [s kps, (s + 1) kps) belong to species s, kps = k / n_species
     unsigned epoch, spin_limit;
     bool local;              // all k workgroups proven to sit on one XCD: stores may stay in that XCD's L2 (nuts_kernel.hpp)
 };
@@ -196,8 +202,9 @@ __device__ __forceinline__ void bl_re_publish(BlReXchg &x, const double *out, in
             __hip_atomic_store(base + (size_t)x.wg * NRED + tid, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+// out_sp (several species, first exchange of a leapfrog only): [n_species][NRED], each species' sums over ITS workgroups.
 template <int NRED>
-__device__ __forceinline__ bool bl_re_collect(BlReXchg &x, double *out, float *scr2 /*[k][NRED]*/, int *lds_flag, int nv)
+__device__ __forceinline__ bool bl_re_collect(BlReXchg &x, double *out, float *scr2 /*[k][NRED]*/, int *lds_flag, int nv, double *out_sp = nullptr)
 {
     if (x.k == 1) return true;
     const int tid = threadIdx.x;
@@ -219,6 +226,11 @@ __device__ __forceinline__ bool bl_re_collect(BlReXchg &x, double *out, float *s
         double t = 0.0;
         for (int w = 0; w < x.k; w++) t += (double)scr2[w * NRED + tid];
         out[tid] = t;
+    } else if (out_sp && tid < nv * (1 + x.n_species)) {
+        const int sp = tid / nv - 1, v = tid - (sp + 1) * nv, kps = x.k / x.n_species;
+        double t = 0.0;
+        for (int w = sp * kps; w < (sp + 1) * kps; w++) t += (double)scr2[w * NRED + v];
+        out_sp[sp * NRED + v] = t;
     }
     __syncthreads();
     return *lds_flag == 0;
@@ -271,8 +283,8 @@ __device__ __forceinline__ BlReSiteMap bl_re_site_map(const BlReModel &m)
 // part[0] = ll, part[1 .. 5] = d/d beta, part[6 .. 10] = d/d alpha.
 // rows / ns: the dataset's rows in device memory (stride n_stride), or the workgroup's LDS copy of them (stride n_sites).
 template <int MK>
-__device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float *__restrict__ rows, int ns, const float *__restrict__ z,
-                                                float *__restrict__ g, float (&part)[2 * MK + 3])
+__device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float *__restrict__ rows, int ns, int rv /* first visit row in rows */,
+                                                const float *__restrict__ z, float *__restrict__ g, float (&part)[2 * MK + 3])
 {
     const BlReSiteMap sm = bl_re_site_map(m);
     const int tps = sm.tps, S = sm.S, sub = sm.sub;
@@ -283,7 +295,7 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
     float beta[MK + 1], alpha[MK + 1];
 #pragma unroll
     for (int k = 0; k <= MK; k++) {
-        const float b = z[min(k, Ks)], a = z[Ks + 1 + min(k, Ko)];
+        const float b = z[m.cb + min(k, Ks)], a = z[m.cb + Ks + 1 + min(k, Ko)];
         beta[k] = k <= Ks ? b : 0.0f;
         alpha[k] = k <= Ko ? a : 0.0f;
     }
@@ -291,7 +303,7 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
     const float isd2_o = m.obs_re ? bl_exp(-2.0f * z[m.o_phi_o]) : 0.0f;
 #pragma unroll
     for (int k = 0; k < 2 * MK + 3; k++) part[k] = 0.0f;
-    const int row_ka = m.KS + T * J * vw, row_kb = row_ka + T;
+    const int row_ka = rv + T * J * vw, row_kb = row_ka + T;
     for (int rd = 0; rd < sm.rounds; rd++) {
         const int i_raw = rd * sm.ngrp + sm.grp;
         const bool live = i_raw < sm.cnt;
@@ -324,7 +336,7 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
 #pragma unroll
                 for (int b = 0; b < BL_RE_VB; b++) {
                     const int jj = min(jb + b * tps, J - 1), v = t * J + jj;
-                    const int r0 = (m.KS + v * vw) * ns + i;
+                    const int r0 = (rv + v * vw) * ns + i;
 #pragma unroll
                     for (int k = 0; k <= KB; k++) {
                         const float wk = rows[r0 + min(k, Ko) * ns];
@@ -373,7 +385,7 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
 #pragma unroll
                     for (int b = 0; b < BL_RE_VB; b++) {
                         const int jj = min(jb + b * tps, J - 1), v = t * J + jj;
-                        const int r0 = (m.KS + v * vw) * ns + i;
+                        const int r0 = (rv + v * vw) * ns + i;
 #pragma unroll
                         for (int k = 0; k <= KB; k++) {
                             const float wk = rows[r0 + min(k, Ko) * ns];
@@ -554,20 +566,23 @@ __device__ __forceinline__ double bl_cs_extra_potential(const BlReModel &m, cons
 // Potential gradient of a fixed effect / log sd coordinate d < G at position z, from the reduced sums of the site pass
 // (red[0 .. 2MK+2]) and of the effects' squares (red[OX] = sum u^2 + v^2, red[OX+1] = sum e^2).
 template <int MK>
-__device__ __forceinline__ float bl_re_global_grad(const BlReModel &m, int d, float zd, const double *red)
+__device__ __forceinline__ float bl_re_global_grad(const BlReModel &m, int d, float zd, const double *red, const double *red_sp = nullptr,
+                                                   int nred = 0)
 {
     constexpr int OA = BL_RE_OA(MK), OX = BL_RE_OX(MK);
     if (d < m.G0) {
-        const bool is_b = d <= m.Ks;
+        // (several species: red_sp holds each species' own gradient sums, NRED apart; one species: red itself)
+        const int sd = d / m.G0s, j = d - sd * m.G0s;
+        const bool is_b = j <= m.Ks;
         const float loc = is_b ? m.loc_b : m.loc_a, isc2 = is_b ? m.isc2_b : m.isc2_a, l1 = is_b ? m.l1_b : m.l1_a;
-        const double gl = red[is_b ? 1 + d : OA + (d - m.Ks - 1)];
+        const double gl = (m.n_species > 1 ? red_sp + sd * nred : red)[is_b ? 1 + j : OA + (j - m.Ks - 1)];
         const float dth = zd - loc;
         return (float)(-gl) + fmaf(dth, isc2, dth > 0.0f ? l1 : (dth < 0.0f ? -l1 : 0.0f));
     }
     if (m.kind == 1) return 0.0f; // (occu_cs: its four extra coordinates are handled by bl_cs_extra_grad)
     const bool site = m.site_re && d == m.o_phi_s;
     const float isd2 = bl_exp(-2.0f * zd), sd2 = bl_exp(2.0f * zd);
-    const float cnt = site ? 2.0f * (float)m.n_total : (float)m.n_total * (float)(m.T * m.J);
+    const float cnt = (float)m.n_species * (site ? 2.0f * (float)m.n_total : (float)m.n_total * (float)(m.T * m.J));
     const float ssq = (float)red[site ? OX : OX + 1];
     // U = sd^2 / (2 s^2) - phi + sum_k (x_k^2 / (2 sd^2) + phi):   dU/dphi = sd^2 / s^2 - 1 - ssq / sd^2 + cnt
     return sd2 * (site ? m.hn_is2_s : m.hn_is2_o) - 1.0f - ssq * isd2 + cnt;
@@ -579,12 +594,12 @@ __device__ __forceinline__ double bl_re_potential(const BlReModel &m, const floa
     double U = -red[0] + 0.5 * pe2 + m.u_const;
     if (m.site_re) {
         const float phi = z[m.o_phi_s];
-        U += 0.5 * (double)(bl_exp(2.0f * phi) * m.hn_is2_s) - (double)phi + 0.5 * red[OX] * (double)bl_exp(-2.0f * phi) + 2.0 * m.n_total * (double)phi;
+        U += 0.5 * (double)(bl_exp(2.0f * phi) * m.hn_is2_s) - (double)phi + 0.5 * red[OX] * (double)bl_exp(-2.0f * phi) + 2.0 * m.n_species * m.n_total * (double)phi;
     }
     if (m.obs_re) {
         const float phi = z[m.o_phi_o];
         U += 0.5 * (double)(bl_exp(2.0f * phi) * m.hn_is2_o) - (double)phi + 0.5 * red[OX + 1] * (double)bl_exp(-2.0f * phi)
-             + (double)m.n_total * (m.T * m.J) * (double)phi;
+             + (double)m.n_species * m.n_total * (m.T * m.J) * (double)phi;
     }
     return U;
 }
@@ -605,7 +620,7 @@ __device__ __forceinline__ float bl_re_prior_quad(const BlReModel &m, const floa
 {
     float pe = 0.0f;
     for (int d = threadIdx.x; d < m.G0; d += BL_RE_NT) {
-        const bool is_b = d <= m.Ks;
+        const bool is_b = d % m.G0s <= m.Ks;
         const float t = z[d] - (is_b ? m.loc_b : m.loc_a);
         pe = fmaf(t * t, is_b ? m.isc2_b : m.isc2_a, fmaf(2.0f * fabsf(t), is_b ? m.l1_b : m.l1_a, pe));
     }
@@ -613,43 +628,58 @@ __device__ __forceinline__ float bl_re_prior_quad(const BlReModel &m, const floa
 }
 
 // ---- parity hook: U and dU/dtheta for B positions (external order in, external order out), one workgroup each ----
+// Several species: the workgroup takes them one after the other (a species' slice = all sites, its own local vectors in `work`).
 template <int MK>
-__global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel m, int B, const float *__restrict__ theta,
-                                                              float *__restrict__ work /*[B][2][D]*/, double *__restrict__ U, double *__restrict__ grad)
+__global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel gm, int B, const float *__restrict__ theta,
+                                                              float *__restrict__ work /*[B][2][D of one species' slice]*/,
+                                                              double *__restrict__ U, double *__restrict__ grad)
 {
     constexpr int NRED = BL_RE_NRED_OF(MK), OX = BL_RE_OX(MK), NV1 = BL_RE_NV1(MK);
     __shared__ float scr[BL_RE_NW * NRED];
-    __shared__ double red[NRED];
-    const int b = blockIdx.x, tid = threadIdx.x, D = m.D;
+    __shared__ double red[NRED], red_tot[NRED], red_sp[BL_RE_SMAX * NRED];
+    const int b = blockIdx.x, tid = threadIdx.x, S = gm.n_species;
     if (b >= B) return;
-    float *z = work + (size_t)b * 2 * D, *g = z + D;
-    for (int d = tid; d < D; d += BL_RE_NT) z[d] = theta[(size_t)b * D + bl_re_ext(m, d)];
     extern __shared__ float bl_re_lds[];
-    int ns;
-    const float *rows = bl_re_rows(m, bl_re_lds, ns);
-    __syncthreads();
-    float v[NV1];
-    if (m.kind == 1) {
-        float part[2 * MK + 7];
-        bl_cs_site_pass<MK>(m, rows, ns, z, part);
+    const bool stage = gm.lds_rows && S == 1;
+    if (tid < NRED) red_tot[tid] = 0.0;
+    for (int sp = 0; sp < S; sp++) {
+        const BlReModel m = bl_re_slice(gm, sp, 0, gm.n_sites);
+        const int D = m.D;
+        float *z = work + (size_t)b * 2 * D, *g = z + D;
+        __syncthreads(); // (the previous species' vectors are done with)
+        for (int d = tid; d < D; d += BL_RE_NT) z[d] = theta[(size_t)b * gm.D + bl_re_ext(m, d)];
+        int ns = m.n_stride, rv = m.rv0;
+        const float *rows = m.rows;
+        if (stage) { rows = bl_re_rows(m, bl_re_lds, ns); rv = m.KS; }
+        __syncthreads();
+        float v[NV1];
+        if (m.kind == 1) {
+            float part[2 * MK + 7];
+            bl_cs_site_pass<MK>(m, rows, ns, z, part);
 #pragma unroll
-        for (int k = 0; k < OX; k++) v[k] = part[k];
-        v[OX] = part[OX]; v[OX + 1] = part[OX + 1]; v[OX + 6] = part[OX + 2]; v[OX + 7] = part[OX + 3];
-    } else {
-        float part[2 * MK + 3], ss[2];
-        bl_re_site_pass<MK>(m, rows, ns, z, g, part);
-        bl_re_effect_squares(m, z, ss);
+            for (int k = 0; k < OX; k++) v[k] = part[k];
+            v[OX] = part[OX]; v[OX + 1] = part[OX + 1]; v[OX + 6] = part[OX + 2]; v[OX + 7] = part[OX + 3];
+        } else {
+            float part[2 * MK + 3], ss[2];
+            bl_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
+            bl_re_effect_squares(m, z, ss);
 #pragma unroll
-        for (int k = 0; k < OX; k++) v[k] = part[k];
-        v[OX] = ss[0]; v[OX + 1] = ss[1]; v[OX + 6] = 0.0f; v[OX + 7] = 0.0f;
+            for (int k = 0; k < OX; k++) v[k] = part[k];
+            v[OX] = ss[0]; v[OX + 1] = ss[1]; v[OX + 6] = 0.0f; v[OX + 7] = 0.0f;
+        }
+        v[OX + 2] = sp == 0 ? bl_re_prior_quad(m, z) : 0.0f;
+        v[OX + 3] = 0.0f; v[OX + 4] = 0.0f; v[OX + 5] = 0.0f;
+        bl_re_block_sum<NV1, NRED>(v, scr, red);
+        if (tid < NV1) { red_sp[sp * NRED + tid] = red[tid]; red_tot[tid] += red[tid]; }
+        __syncthreads();
+        for (int d = m.G + tid; d < D; d += BL_RE_NT) grad[(size_t)b * gm.D + bl_re_ext(m, d)] = (double)g[d];
+        if (sp == S - 1) { // fixed effects of every species and the log sds, from the species' and the total sums
+            for (int d = tid; d < m.G; d += BL_RE_NT)
+                grad[(size_t)b * gm.D + d] = (double)((m.kind == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red_tot)
+                                                                                 : bl_re_global_grad<MK>(m, d, z[d], red_tot, red_sp, NRED));
+            if (tid == 0) U[b] = bl_re_potential(m, z, red_tot, red_tot[OX + 2], OX) + (m.kind == 1 ? bl_cs_extra_potential(m, z) : 0.0);
+        }
     }
-    v[OX + 2] = bl_re_prior_quad(m, z);
-    v[OX + 3] = 0.0f; v[OX + 4] = 0.0f; v[OX + 5] = 0.0f;
-    bl_re_block_sum<NV1, NRED>(v, scr, red);
-    for (int d = tid; d < m.G; d += BL_RE_NT)
-        g[d] = (m.kind == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red) : bl_re_global_grad<MK>(m, d, z[d], red);
-    if (tid == 0) U[b] = bl_re_potential(m, z, red, red[OX + 2], OX) + (m.kind == 1 ? bl_cs_extra_potential(m, z) : 0.0);
-    for (int d = tid; d < D; d += BL_RE_NT) grad[(size_t)b * D + bl_re_ext(m, d)] = (double)g[d];
 }
 
 // ------------------------------------------------------------------------------------------------ NUTS ----
@@ -661,7 +691,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
 {
     constexpr int NRED = BL_RE_NRED_OF(MK), OX = BL_RE_OX(MK), NV1 = BL_RE_NV1(MK);
     __shared__ float scr[BL_RE_NW * NRED];
-    __shared__ double red[NRED], red2[NRED];
+    __shared__ double red[NRED], red2[NRED], red_sp[BL_RE_SMAX * NRED];
     __shared__ float scr2[32 * NRED];
     __shared__ int xflag;
     // XCD-aware mapping (speed only, as in nuts_kernel.hpp): blocks b and b + 8 share an XCD under the observed round-robin
@@ -669,8 +699,9 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
     const int label = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int chain = label + 8 * (slot / R.k), wg = slot % R.k, tid = threadIdx.x;
     if (chain >= R.num_chains) return;
-    const int s0 = wg * R.nloc;
-    const BlReModel m = bl_re_slice(R.m, s0, min(R.nloc, R.m.n_sites - s0)); // this workgroup's slice as a model of its own
+    // several species: the chain's k workgroups are n_species groups of kps, each group slicing the sites of its species
+    const int kps = R.k / R.m.n_species, sp = wg / kps, s0 = (wg - sp * kps) * R.nloc;
+    const BlReModel m = bl_re_slice(R.m, sp, s0, min(R.nloc, R.m.n_sites - s0)); // this workgroup's slice as a model of its own
     const int D = m.D, G = m.G;
     const bool lead = wg == 0; // the fixed effects / log sds are replicated; workgroup 0 accounts for them in every sum and output
     float *sv = R.state + ((size_t)chain * R.k + wg) * RE_SLOTS * R.dl_max;
@@ -681,18 +712,20 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
     auto Wm = [&](int slot) -> float * { if constexpr (LT >= 2) return hot_lds + slot * R.dl_max; else return sv + (size_t)slot * R.dl_max; };
     auto V = [&](int slot) -> float * { return sv + (size_t)slot * R.dl_max; };
     uint32_t *rng_base = R.rng + ((size_t)chain * R.k + wg) * (R.dl_max + 2) * 4;
-    BlReXchg xc{R.xchg, R.k, wg, chain, 0u, 5000000u /* microseconds */, false};
+    BlReXchg xc{R.xchg, R.k, wg, chain, R.m.n_species, 0u, 5000000u /* microseconds */, false};
     const float xcc = (float)bl_xcc_id();
     if (tid == 0) xflag = 0;
     const int S = R.num_samples, W = R.num_warmup, total = W + S;
-    int rows_ns = m.n_stride;
+    int rows_ns = m.n_stride, rows_rv = m.rv0;
     const float *rows = m.rows;
-    if constexpr (LROWS) { // the workgroup's own copy of its rows
+    if constexpr (LROWS) { // the workgroup's own copy of its rows: the site covariates, then its species' block
         const int N = m.n_sites;
-        for (int r = 0; r < m.n_rows; r++)
-            for (int i = tid; i < N; i += BL_RE_NT) bl_re_lds[r * N + i] = m.rows[(size_t)r * m.n_stride + i];
+        for (int r = 0; r < m.n_rows; r++) {
+            const int rg = r < m.KS ? r : m.rv0 + (r - m.KS);
+            for (int i = tid; i < N; i += BL_RE_NT) bl_re_lds[r * N + i] = m.rows[(size_t)rg * m.n_stride + i];
+        }
         __syncthreads();
-        rows = bl_re_lds; rows_ns = N;
+        rows = bl_re_lds; rows_ns = N; rows_rv = m.KS;
     }
 
     BlRng rng_u, rng_dir; // every thread carries its own copy of the two scalar streams and advances it identically
@@ -740,7 +773,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
             v[OX] = part[OX]; v[OX + 1] = part[OX + 1]; v[OX + 6] = part[OX + 2]; v[OX + 7] = part[OX + 3];
         } else {
             float part[2 * MK + 3], ss[2];
-            bl_re_site_pass<MK>(m, rows, rows_ns, z, g, part);
+            bl_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
             BL_RE_T(8)
             bl_re_effect_squares(m, z, ss);
 #pragma unroll
@@ -762,12 +795,12 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
     auto evaluate_b = [&]() -> double {
         const float *z = H(RE_CZ);
         float *g = H(RE_CG);
-        if (!bl_re_collect<NRED>(xc, red, scr2, &xflag, ev_nv)) flag = 4;
+        if (!bl_re_collect<NRED>(xc, red, scr2, &xflag, ev_nv, m.n_species > 1 ? red_sp : nullptr)) flag = 4;
         BL_RE_T(10)
         if (ev_first && R.allow_local) xc.local = ((double)R.k * red[OX + 5] == red[OX + 4] * red[OX + 4]); // exact: small integers
         if (red[OX + 3] > 0.0) flag = 5;
         for (int d = tid; d < G; d += BL_RE_NT)
-            g[d] = (KIND == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red) : bl_re_global_grad<MK>(m, d, z[d], red);
+            g[d] = (KIND == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red) : bl_re_global_grad<MK>(m, d, z[d], red, red_sp, NRED);
         double U = bl_re_potential(m, z, red, red[OX + 2], OX);
         if constexpr (KIND == 1) U += bl_cs_extra_potential(m, z);
         BL_RE_T(1)

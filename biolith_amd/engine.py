@@ -84,9 +84,10 @@ class OccuDataset:
         self.D = Ks + Ko + 2 + (1 if model == "occu_fp" or (model == "occu_cop" and fp_mode is not None) else 0)
         if self.S > 1:
             # several species in one handle: ONE chain over theta = [species 0: beta, alpha | species 1: ... | (shared phi)]
-            # (the species plate of occu.py:182-186 under one NUTS); occu with or without false positives
-            if model not in ("occu", "occu_fp"):
-                raise NotImplementedError(f"{model}: one species per dataset (joint sampling is built for occu / occu_fp)")
+            # (the species plate of occu.py:182-186 under one NUTS); occu with or without false positives, or with random
+            # effects: theta = [... | log sds | site_re_occ [S][N] | site_re_det [S][N] | obs_re [S][N][T][J]], the sds shared
+            if model not in ("occu", "occu_fp", "occu_re"):
+                raise NotImplementedError(f"{model}: one species per dataset (joint sampling is built for occu / occu_fp / occu_re)")
             self.D += (self.S - 1) * (Ks + Ko + 2)
         self.device = device
         pb = _ffi.bl_normal_prior(float(prior_beta[0]), float(prior_beta[1]))

@@ -68,10 +68,10 @@ def occu(
     Same parameters as the reference (biolith/models/occu.py:19-40).  Supported here: the default
     option path -- linear regressors on both sides, Normal priors, no spatial effect -- plus
     ``site_random_effects`` / ``obs_random_effects`` with HalfNormal priors on their sds (occu.py:170-173, 191-196,
-    215-218; one species, not together with false positives) and
+    215-218; not together with false positives) and
     ``false_positives_constant`` / ``false_positives_unoccupied`` with a Beta prior on the
-    rate (occu.py:146-157, 229-241; one species); several species are sampled species by species (their joint density
-    factorises over the ``species`` plate, occu.py:182-186).  Anything else raises ``NotImplementedError`` (the
+    rate (occu.py:146-157, 229-241); several species are sampled under one chain as in the reference (the ``species`` plate,
+    occu.py:182-186, with the false-positive rate / the random effects' sds shared across it).  Anything else raises ``NotImplementedError`` (the
     engine has no silent fallback).  ``coords=None`` / any ``ell`` are accepted and ignored, as the
     reference does when ``coords`` is None (occu.py:159-167); ``simulate()`` returns both.
 
@@ -109,9 +109,8 @@ def occu(
     # (prob_fp_* is sampled outside the species plate, occu.py:146-157: several species share it -- fit() then samples all
     # species under one chain)
     if site_random_effects or obs_random_effects:
-        # site_re_sd / obs_re_sd are sampled outside the species plate (occu.py:170-173): several species share them
-        if n_species != 1:
-            unsupported.append("random effects with n_species > 1 (the sds are shared across species, occu.py:170-173)")
+        # site_re_sd / obs_re_sd are sampled outside the species plate (occu.py:170-173): several species share them -- fit()
+        # then samples all species under one chain (up to 8 species)
         if fp_mode is not None:
             unsupported.append("random effects together with false positives")
     if regressor_occ is not LinearRegression or regressor_det is not LinearRegression:

@@ -95,7 +95,10 @@ def fit(
     # does the same here -- one device dataset holding all species, theta = [species 0: beta, alpha | species 1: ... | (phi)], one
     # step size, one tree per transition -- as long as the joint vector fits the kernel's 60 lanes and the records fit LDS
     # (``joint_species=False`` forces the species-by-species form, which has the same marginals but its own adaptation per species).
-    joint = n_species > 1 and spec.model in ("occu", "occu_fp") and joint_species
+    # Random effects: their sds sit outside the species plate (occu.py:170-173), so several species are one chain by definition.
+    if n_species > 1 and spec.model == "occu_re" and not joint_species:
+        raise NotImplementedError("random effects share their sds across species (occu.py:170-173): joint_species=False does not apply")
+    joint = n_species > 1 and spec.model in ("occu", "occu_fp", "occu_re") and joint_species
     # chain_method="parallel" (fit.py:109-113) deals chains over the local devices; here ``devices``
     # names the GPUs, chains go to them in contiguous blocks, every shard is an asynchronous launch and
     # the draws are concatenated on the chain axis afterwards (no exchange while sampling).
@@ -117,7 +120,7 @@ def fit(
     try:
         jobs = make_jobs(joint)
     except NotImplementedError:
-        if not joint or spec.model == "occu_fp":   # (a shared false-positive rate cannot be sampled species by species)
+        if not joint or spec.model in ("occu_fp", "occu_re"):   # (a shared false-positive rate / shared sds cannot be sampled species by species)
             raise
         joint = False
         jobs = make_jobs(False)
@@ -194,10 +197,23 @@ def fit(
         ds_joint, joint_result = per_species[0]
         Dsp = ds_joint.Ks + ds_joint.Ko + 2
         per_species = []
+        jd = joint_result.draws
         for sp in range(n_species):
             part = copy.copy(joint_result)
-            part.draws = np.ascontiguousarray(np.concatenate([joint_result.draws[:, :, sp * Dsp:(sp + 1) * Dsp],
-                                                              joint_result.draws[:, :, n_species * Dsp:]], axis=2))
+            if spec.model == "occu_re":
+                # [species' beta, alpha | log sds | site_re_occ [S][N] | site_re_det [S][N] | obs_re [S][N][T][J]] -> the one-species layout
+                N, V = ds_joint.N, ds_joint.T * ds_joint.J
+                nsd = int(ds_joint.site_re) + int(ds_joint.obs_re)
+                at = n_species * Dsp + nsd
+                blocks = [jd[:, :, sp * Dsp:(sp + 1) * Dsp], jd[:, :, n_species * Dsp: at]]
+                if ds_joint.site_re:
+                    blocks += [jd[:, :, at + sp * N: at + (sp + 1) * N], jd[:, :, at + (n_species + sp) * N: at + (n_species + sp + 1) * N]]
+                    at += 2 * n_species * N
+                if ds_joint.obs_re:
+                    blocks.append(jd[:, :, at + sp * N * V: at + (sp + 1) * N * V])
+                part.draws = np.ascontiguousarray(np.concatenate(blocks, axis=2))
+            else:
+                part.draws = np.ascontiguousarray(np.concatenate([jd[:, :, sp * Dsp:(sp + 1) * Dsp], jd[:, :, n_species * Dsp:]], axis=2))
             per_species.append((OccuDataset(spec.site_covs, spec.obs_covs, spec.obs[sp:sp + 1], spec.prior_beta, spec.prior_alpha,
                                             device=devices[0], model=spec.model, **engine_options(spec)), part))
     mcmc = _assemble(per_species, spec, num_warmup, joint_result)
@@ -269,12 +285,12 @@ def _assemble(per_species, spec, num_warmup, joint_result=None) -> HipMCMC:
             latent["obs_re_sd"] = np.exp(res0.draws[:, :, at].astype(np.float64)).astype(np.float32)
             at += 1
         if spec.extras["site_random_effects"]:
-            latent["site_re_occ"] = res0.draws[:, :, at: at + N, None]
-            latent["site_re_det"] = res0.draws[:, :, at + N: at + 2 * N, None]
+            latent["site_re_occ"] = np.stack([r.draws[:, :, at: at + N] for _, r in per_species], axis=-1)          # (C, S, N, nsp)
+            latent["site_re_det"] = np.stack([r.draws[:, :, at + N: at + 2 * N] for _, r in per_species], axis=-1)
             at += 2 * N
         if spec.extras["obs_random_effects"]:
-            e = res0.draws[:, :, at: at + N * T * J].reshape(C, S, N, T, J)
-            latent["obs_re"] = np.ascontiguousarray(e.transpose(0, 1, 4, 3, 2))[..., None]     # (C, S, J, T, N, 1)
+            e = np.stack([r.draws[:, :, at: at + N * T * J].reshape(C, S, N, T, J) for _, r in per_species], axis=-1)
+            latent["obs_re"] = np.ascontiguousarray(e.transpose(0, 1, 4, 3, 2, 5))                                   # (C, S, J, T, N, nsp)
     def memo(fn):   # a site is computed once, on its first access
         box = []
 

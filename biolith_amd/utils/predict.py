@@ -93,18 +93,20 @@ def predict(
         rate = np.maximum(np.asarray(posterior[fp_site], dtype=np.float64).reshape(n), 1e-300)
         phi = np.log(rate).astype(np.float32)[:, None]                  # the engine's coordinate: log(rate)
 
-    re_block = None
-    if spec.model == "occu_re":   # rebuild the engine's coordinates from the model's sites (see fit._assemble)
+    def re_block(sp):
+        """The random-effects coordinates of species ``sp`` in the engine's one-species layout (see fit._assemble)."""
+        if spec.model != "occu_re":
+            return None
         cols = []
         if spec.extras["site_random_effects"]:
             cols.append(np.log(np.maximum(np.asarray(posterior["site_re_sd"], dtype=np.float64).reshape(n, 1), 1e-300)))
         if spec.extras["obs_random_effects"]:
             cols.append(np.log(np.maximum(np.asarray(posterior["obs_re_sd"], dtype=np.float64).reshape(n, 1), 1e-300)))
-        if spec.extras["site_random_effects"]:
-            cols += [np.asarray(posterior["site_re_occ"]).reshape(n, -1), np.asarray(posterior["site_re_det"]).reshape(n, -1)]
-        if spec.extras["obs_random_effects"]:   # (n, J, T, N, 1) -> [N][T][J]
-            cols.append(np.asarray(posterior["obs_re"])[..., 0].transpose(0, 3, 2, 1).reshape(n, -1))
-        re_block = np.concatenate(cols, axis=1).astype(np.float32)
+        if spec.extras["site_random_effects"]:   # (n, N, species)
+            cols += [np.asarray(posterior["site_re_occ"])[..., sp].reshape(n, -1), np.asarray(posterior["site_re_det"])[..., sp].reshape(n, -1)]
+        if spec.extras["obs_random_effects"]:   # (n, J, T, N, species) -> [N][T][J]
+            cols.append(np.asarray(posterior["obs_re"])[..., sp].transpose(0, 3, 2, 1).reshape(n, -1))
+        return np.concatenate(cols, axis=1).astype(np.float32)
 
     if spec.model == "occu_cs":   # sites psi, z, f, s (occu_cs.py:196-232); mu / sigma travel in the engine's coordinates
         from ..engine import OccuDataset
@@ -140,8 +142,8 @@ def predict(
         for sp in range(n_species):
             ds = OccuDataset(spec.site_covs, spec.obs_covs, spec.obs[sp:sp + 1], spec.prior_beta, spec.prior_alpha,
                              device=device, model=spec.model, **engine_options(spec))
-            draws = np.concatenate([beta[:, sp, :], alpha[:, sp, :]] + ([phi] if fp_site else [])
-                                   + ([re_block] if re_block is not None else []), axis=1)
+            rb = re_block(sp)
+            draws = np.concatenate([beta[:, sp, :], alpha[:, sp, :]] + ([phi] if fp_site else []) + ([rb] if rb is not None else []), axis=1)
             first.append(ds.deterministic(draws, psi=True, prob_detection=False)[0])
             lat, yy = ds.predictive(draws, seed=(int(random_seed) + (sp << 32)) & (2 ** 64 - 1))
             latent.append(lat)

@@ -124,12 +124,17 @@ int bl_dataset_create_nmix(const bl_dims *dims, const float *site_covs, const fl
  * Same for biolith.models.occu with site_random_effects / obs_random_effects (models/occu.py:36-39, 170-173, 191-196,
  * 215-218): site_re_sd, obs_re_sd ~ HalfNormal(scale) sampled before the plates; per site site_re_occ, site_re_det ~
  * Normal(0, site_re_sd) join the occupancy and detection predictors; per replicate obs_re ~ Normal(0, obs_re_sd) joins
- * the detection predictor (masked replicates keep their prior term).  One species.  Coordinates, in NumPyro's
+ * the detection predictor (masked replicates keep their prior term).  Coordinates, in NumPyro's
  * unconstrained space:  theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_occ[N], site_re_det[N]),
- * (obs_re[N][T][J])], D = bl_dataset_param_dim().  bl_logp_grad / bl_nuts_* work as for the other models (the sampler
+ * (obs_re[N][T][J])], D = bl_dataset_param_dim().  Several species (dims->n_species <= 8, obs [S][N][T][J]) are ONE chain, as in
+ * the reference: beta, alpha and the effects sit inside the species plate (occu.py:182-196), the two sds outside it
+ * (occu.py:170-173), i.e. shared:  theta = [species 0: beta, alpha | species 1: ... | (log site_re_sd) | (log obs_re_sd) |
+ * site_re_occ [S][N] | site_re_det [S][N] | obs_re [S][N][T][J]]; a chain then runs on a multiple of S workgroups, each
+ * slicing the sites of one species; bl_deterministic / bl_predict take one-species handles (cut the draws per species).
+ * bl_logp_grad / bl_nuts_* work as for the other models (the sampler
  * runs k workgroups per chain -- site slices, partial sums exchanged through device memory; all num_chains x k must be
  * resident, so num_chains x k <= compute units -- with its vectors in device memory / LDS; RNG: one stream per coordinate, D + 2 per chain).
- * At most 4 covariates per side.  bl_deterministic adds the effects to both predictors; bl_predict draws z and y from them.
+ * At most 16 covariates per side.  bl_deterministic adds the effects to both predictors; bl_predict draws z and y from them.
  */
 int bl_dataset_create_re(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
                          int site_random_effects, int obs_random_effects, double prior_site_re_sd_scale,

@@ -105,7 +105,7 @@ class OracleData:
         Y_all = None
         if Y.ndim == 4:
             if Y.shape[0] > 1:   # several species under ONE chain (occu.py:182-186): occu with or without false positives
-                assert model in ("occu", "occu_fp"), "joint species: occu / occu_fp"
+                assert model in ("occu", "occu_fp", "occu_re"), "joint species: occu / occu_fp / occu_re"
                 Y_all = np.ascontiguousarray(Y)
             Y = np.ascontiguousarray(Y[0])
         assert X.ndim == 2 and W.ndim == 4 and Y.ndim == 3
@@ -153,7 +153,8 @@ class OracleData:
             self.D = int(lib().orc_data_dim(self._h))
         self.n_species = 1
         if Y_all is not None:
-            # theta = [species 0: beta, alpha | species 1: ... | (phi)]
+            # theta = [species 0: beta, alpha | species 1: ... | (phi)]; with random effects (set before the species, so that the
+            # dimension counts them): [... | log sds | site_re_occ [S][N] | site_re_det [S][N] | obs_re [S][N][T][J]]
             cov_nan = (np.isnan(np.asarray(obs_covs, dtype=np.float64)).any(-1)
                        | np.isnan(np.asarray(site_covs, dtype=np.float64)).any(-1)[:, None, None]).astype(np.uint8)
             cov_nan = np.ascontiguousarray(cov_nan)

@@ -296,3 +296,69 @@ def test_re_site_pass_wave_classes_build_the_same_trees():
     o = oracle.nuts_run(od, 0, 4, num_chains=2, seed=3)
     assert np.array_equal(o["num_steps"][:, :2], two.num_steps[:, :2]) and np.array_equal(one.num_steps[:, :2], two.num_steps[:, :2])
     assert np.allclose(o["draws"][:, 0], two.draws[:, 0], atol=5e-3) and np.allclose(one.draws[:, :2], two.draws[:, :2], atol=2e-3)
+
+
+SPECIES_CASES = [(40, 2, 5, 2, 1, 3, True, True), (300, 1, 6, 3, 3, 2, True, False), (70, 1, 6, 6, 9, 2, False, True)]
+
+
+def _species_data(N, T, J, Ks, Ko, S, seed=0):
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(N, Ks)).astype(np.float32)
+    W = rng.normal(size=(N, T, J, Ko)).astype(np.float32)
+    Y = (rng.uniform(size=(S, N, T, J)) < 0.4).astype(np.float32)
+    Y[1, 3, 0, 1] = np.nan
+    W[5, 0, 2, 0] = np.nan
+    return rng, X, W, Y
+
+
+@pytest.mark.parametrize("N,T,J,Ks,Ko,S,site,obs", SPECIES_CASES)
+def test_re_several_species_share_the_sds(N, T, J, Ks, Ko, S, site, obs):
+    """Random effects inside the species plate, their sds outside it (occu.py:170-173, 182-196): ONE chain over
+    [species' beta, alpha | log sds | site_re_occ [S][N] | site_re_det [S][N] | obs_re [S][N][T][J]].  A chain's workgroups are S
+    groups, each slicing the sites of its species.  Potential and gradient over every coordinate against the oracle, and -- from a
+    start in the bulk -- the same step sizes after 8 adaptation steps and the same next tree and draw, on S, 2 S and up to 32 workgroups."""
+    rng, X, W, Y = _species_data(N, T, J, Ks, Ko, S)
+    kw = dict(model="occu_re", site_random_effects=site, obs_random_effects=obs, prior_site_re_sd=0.7, prior_obs_re_sd=1.3)
+    od, ds = oracle.OracleData(X, W, Y, **kw), OccuDataset(X, W, Y, **kw)
+    V = T * J
+    assert ds.D == od.D == S * (Ks + Ko + 2) + int(site) + int(obs) + S * ((2 * N if site else 0) + (N * V if obs else 0))
+    th = rng.uniform(-1, 1, size=(2, od.D)).astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= 2e-6 and np.max(np.abs(Gg - Go)) <= 2e-5 * np.max(np.abs(Go))
+    init = rng.uniform(-0.15, 0.15, size=(2, od.D)).astype(np.float32).astype(np.float64)
+    o = oracle.nuts_run(od, 8, 4, num_chains=2, seed=3, init=init)
+    assert o["num_steps"].max() > 7
+    for k in (S, 2 * S, 32):
+        r = ds.nuts(num_warmup=8, num_samples=4, num_chains=2, seed=3, wgs_per_chain=k, init_theta=init)
+        assert r.wgs_per_chain % S == 0 and r.wgs_per_chain <= 32
+        # (nine transitions in: the adapted step sizes and the first kept tree and draw; a float32 / float64 pair parts for good at the
+        # first very long tree -- here the 415-step one of transition 11)
+        assert np.array_equal(o["num_steps"][:, :1], r.num_steps[:, :1]), (k, o["num_steps"], r.num_steps)
+        assert np.allclose(o["step_size"], r.step_size, rtol=2e-3) and np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=5e-3)
+
+
+def test_re_several_species_through_fit_and_predict():
+    """fit(occu, site_random_effects=True, obs_random_effects=True) with three species: the reference's site shapes (species plate
+    last, occu.py:182), shared sds, finite deterministic sites; predict() draws from them; joint_species=False does not apply."""
+    from biolith_amd.models import occu, simulate
+    from biolith_amd.utils import fit, predict
+
+    data, _ = simulate(n_species=3, n_sites=60, deployment_days_per_site=56, site_random_effects=True, obs_random_effects=True, random_seed=3)
+    kw = dict(site_random_effects=True, obs_random_effects=True, num_chains=2, num_samples=30, num_warmup=30, random_seed=1)
+    res = fit(occu, **data, **kw)
+    s = res.samples
+    n, N, T, J = 60, 60, data["obs"].shape[2], data["obs"].shape[3]
+    assert s["site_re_sd"].shape == (n,) and s["obs_re_sd"].shape == (n,)
+    assert s["site_re_occ"].shape == s["site_re_det"].shape == (n, N, 3) and s["obs_re"].shape == (n, J, T, N, 3)
+    assert s["cov_state_0"].shape == (n, 3) and s["psi"].shape == (n, T, N, 3) and s["prob_detection"].shape == (n, J, T, N, 3)
+    assert all(np.all(np.isfinite(s[k])) for k in ("site_re_sd", "obs_re_sd", "site_re_occ", "obs_re", "psi", "prob_detection"))
+    assert np.all(s["site_re_sd"] > 0) and res.mcmc.result.draws.shape[2] == 3 * 4 + 2 + 3 * (2 * N + N * T * J)
+    # the species' effects are their own coordinates (not copies of one another)
+    assert not np.allclose(s["site_re_occ"][..., 0], s["site_re_occ"][..., 1])
+    pp = predict(occu, res.mcmc, **data, site_random_effects=True, obs_random_effects=True)
+    assert pp["psi"].shape == (n, T, N, 3) and pp["y"].shape[-1] == 3
+    # psi of species 1 from predict() = psi of the fit (same draws, same effects)
+    assert np.allclose(pp["psi"], s["psi"], atol=1e-5)
+    with pytest.raises(NotImplementedError):
+        fit(occu, **data, **kw, joint_species=False)

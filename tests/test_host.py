@@ -78,8 +78,9 @@ def test_occu_validates_like_reference():
     assert occu(g["site_covs"], g["obs_covs"], obs=g["obs"], obs_random_effects=True).extras["obs_random_effects"]
     with pytest.raises(NotImplementedError, match="HalfNormal"):
         occu(g["site_covs"], g["obs_covs"], obs=g["obs"], obs_random_effects=True, prior_obs_re_sd=Normal())
-    with pytest.raises(NotImplementedError, match="shared across species"):
-        occu(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]), site_random_effects=True)
+    # several species share the sds (occu.py:170-173): accepted, fit() samples them under one chain
+    two = occu(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]), site_random_effects=True)
+    assert two.model == "occu_re" and two.obs.shape[0] == 2
     with pytest.raises(NotImplementedError, match="together with false positives"):
         occu(g["site_covs"], g["obs_covs"], obs=g["obs"], site_random_effects=True, false_positives_constant=True)
     # false positives (occu.py:146-157): one species, Beta prior on the rate

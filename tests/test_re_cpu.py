@@ -94,3 +94,43 @@ def test_oracle_sampler_is_pinned_by_its_own_first_draws():
     r = oracle.nuts_run(od, 10, 2, num_chains=2, seed=3)
     assert np.array_equal(r["num_steps"], np.array(ref["occu_re_site"]["num_steps"]))
     assert np.allclose(r["draws"][:, :, :12], np.array(ref["occu_re_site"]["draws"]), rtol=0, atol=1e-9)
+
+
+def test_re_several_species_potential_is_the_sum_with_shared_sds():
+    """Random effects inside the species plate, their sds outside it (occu.py:170-173, 182-196): the joint potential over
+    [species' beta, alpha | log sds | site_re_occ [S][N] | site_re_det [S][N] | obs_re [S][N][T][J]] equals the sum of the species'
+    one-species potentials with the sds' own prior + Jacobian counted once; gradient against central differences."""
+    import math
+    rng = np.random.default_rng(0)
+    N, T, J, Ks, Ko, S = 12, 2, 3, 2, 1, 3
+    X = rng.normal(size=(N, Ks)).astype(np.float32)
+    W = rng.normal(size=(N, T, J, Ko)).astype(np.float32)
+    Y = (rng.uniform(size=(S, N, T, J)) < 0.4).astype(np.float32)
+    Y[1, 3, 0, 1] = np.nan
+    W[5, 1, 2, 0] = np.nan
+    kw = dict(model="occu_re", site_random_effects=True, obs_random_effects=True, prior_site_re_sd=0.7, prior_obs_re_sd=1.3)
+    od = oracle.OracleData(X, W, Y, **kw)
+    V, Dp = T * J, Ks + Ko + 2
+    assert od.D == S * Dp + 2 + S * (2 * N + N * V) and od.n_species == S
+    th = rng.uniform(-1, 1, size=(1, od.D))
+    U, G = od.potential_grad(th)
+    num = np.zeros(od.D)
+    for k in range(od.D):
+        a, b = th.copy(), th.copy()
+        a[0, k] += 1e-6
+        b[0, k] -= 1e-6
+        num[k] = (od.potential_grad(a)[0][0] - od.potential_grad(b)[0][0]) / 2e-6
+    assert np.max(np.abs(num - G[0])) <= 1e-6 * np.max(np.abs(G[0]))
+    o_sd = S * Dp
+    o_u, o_v, o_e = o_sd + 2, o_sd + 2 + S * N, o_sd + 2 + 2 * S * N
+    tot = 0.0
+    for s in range(S):
+        one = oracle.OracleData(X, W, Y[s], **kw)
+        t1 = np.concatenate([th[0, s * Dp:(s + 1) * Dp], th[0, o_sd:o_sd + 2], th[0, o_u + s * N:o_u + (s + 1) * N],
+                             th[0, o_v + s * N:o_v + (s + 1) * N], th[0, o_e + s * N * V:o_e + (s + 1) * N * V]])[None]
+        tot += one.potential_grad(t1)[0][0]
+    own = 0.0   # -log HalfNormal(sd; s0) - log |d sd / d phi| of the two sds
+    for phi, s0 in ((th[0, o_sd], 0.7), (th[0, o_sd + 1], 1.3)):
+        sd = math.exp(phi)
+        own += -(0.5 * math.log(2 / math.pi) - math.log(s0) - 0.5 * sd * sd / (s0 * s0) + phi)
+    assert U[0] == pytest.approx(tot - (S - 1) * own, rel=1e-12)
