@@ -1016,7 +1016,9 @@ static size_t re_geometry(BlReModel &m, int nloc, int with_hot, int dl_max)
     }
     // a workgroup's own LDS copy of its rows, and of the five vectors every leapfrog touches, when they fit (160 KB per CU,
     // one workgroup per CU; a few KB go to the reduction scratch)
-    const size_t row_bytes = (size_t)m.n_rows * nloc * 4, budget = (size_t)150 * 1024;
+    // (160 KB per workgroup; the kernels' static arrays -- reduction scratch, the exchange's [32][NRED] staging, per-species sums -- take up
+    // to 10.3 KB at capacity 16)
+    const size_t row_bytes = (size_t)m.n_rows * nloc * 4, budget = (size_t)148 * 1024;
     const size_t hot_bytes = (size_t)RE_HOT * dl_max * 4, warm_bytes = (size_t)RE_WARM * dl_max * 4;
     m.lds_rows = row_bytes <= budget ? 1 : 0;
     if (const char *e = getenv("BIOLITH_HIP_RE_LDS_ROWS")) m.lds_rows = std::min(m.lds_rows, atoi(e)); // (tests: every instantiation)

@@ -33,3 +33,28 @@ def test_kernels_stay_in_registers(tmp_path, ks, ko, max_scratch):
     assert len(kernels) >= 16 and len(scratch) >= len(kernels)
     assert max(scratch) <= max_scratch, sorted(scratch)[-3:]
     assert max(vgprs) <= 256
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_vector_kernels_leave_the_lds_budget(tmp_path):
+    """The random-effects / occu_cs kernels are launched with up to 148 KB of dynamic LDS (rows + sampler vectors, re_geometry in
+    biolith_hip.hip) next to their static arrays (reduction scratch, the exchange's staging, per-species sums): together they must
+    stay inside the 160 KB of a workgroup -- a launch that asks for more fails at run time, not at build time.  And the capacity-4
+    instantiations stay out of scratch memory."""
+    out = tmp_path / "main.s"
+    src = os.path.join(ROOT, "biolith_amd", "csrc", "biolith_hip.hip")
+    r = subprocess.run([HIPCC, *FLAGS, "-o", str(out), src], capture_output=True, text=True, cwd=os.path.join(ROOT, "biolith_amd", "csrc"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+    host = open(src).read()
+    budget_kb = int(re.search(r"budget = \(size_t\)(\d+) \* 1024", host).group(1))
+    seen = 0
+    for m in re.finditer(r"\.amdhsa_kernel (_Z\d+bl_re_(?:nuts|logp)_kernel\w+)\n(.*?)\.end_amdhsa_kernel", text, flags=re.S):
+        name, body = m.group(1), m.group(2)
+        static = int(re.search(r"\.amdhsa_group_segment_fixed_size (\d+)", body).group(1))
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+        assert static + budget_kb * 1024 <= 160 * 1024, (name, static)
+        if "ILi4E" in name:
+            assert scratch == 0, (name, scratch)
+        seen += 1
+    assert seen >= 26   # 2 capacities x 2 kinds x 2 x 3 LDS forms of the sampler + 2 parity kernels
