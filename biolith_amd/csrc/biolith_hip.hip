@@ -1389,7 +1389,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     ds->d_rng = (uint32_t *)(base + o_rng); ds->d_init = (float *)(base + o_init); ds->d_dbg = (long long *)(base + o_dbg); ds->d_loc = (int *)(base + o_loc);
     int pitch = nvp; // granules between workgroup records
     { const char *e = getenv("BIOLITH_HIP_PITCH"); if (e && atoi(e) >= nvp && atoi(e) <= 4096) pitch = atoi(e); }
-    const size_t xb = align256((size_t)C * 2 * k * pitch * 8);
+    const size_t xb = align256((size_t)C * BL_XCHG_SLOTS * k * pitch * 8);
     if (xb > ds->xchg_bytes) {
         if (ds->d_xchg) hipFree(ds->d_xchg);
         ds->d_xchg = nullptr; ds->xchg_bytes = 0;

@@ -111,7 +111,7 @@ struct BlNutsParams {
     int sp_lds;                    // floats between two species' record regions in LDS
     unsigned spin_limit;           // bound of an exchange's wait in MICROSECONDS of wall time (a peer that is late -- late-resident,
                                    // descheduled by a co-tenant or a profiler -- is not an error for a while; one that vanished is)
-    unsigned long long *xchg;      // [C][2][k][nvp] granules, zeroed before every launch
+    unsigned long long *xchg;      // [C][BL_XCHG_SLOTS][k][pitch] granules, zeroed before every launch
     const BlNutsCold *cold;
 };
 
@@ -192,6 +192,10 @@ struct BlSpinBound {
     }
 };
 
+// Slots of the exchange, by epoch: a workgroup whose decisions drop the evaluation in flight has already published it and goes on
+// to publish the corrected one without reading anybody's record in between, so it can be two epochs ahead of a peer that is still
+// reading -- four slots keep those apart (two sufficed while dropped evaluations were not published).
+#define BL_XCHG_SLOTS 4u
 template <int KS, int KO, bool LDS, int MODEL, int CW>
 __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsParams p)
 {
@@ -280,7 +284,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     const int nvp = p.nvp, G = 64 / nvp;
     const int c_idx = lane & (nvp - 1), sub = lane / nvp;
     const unsigned rec_bytes = (unsigned)(p.k * p.pitch * 8);
-    const unsigned char *xbase = reinterpret_cast<const unsigned char *>(p.xchg) + (size_t)chain * 2 * rec_bytes;
+    const unsigned char *xbase = reinterpret_cast<const unsigned char *>(p.xchg) + (size_t)chain * BL_XCHG_SLOTS * rec_bytes;
     const unsigned my_store_off = (unsigned)((member * p.pitch + (lane & (nvp - 1))) * 8);
     unsigned poff[8];
     float pval[8]; // 1 if that load is a real (unclamped) record of this lane
@@ -317,7 +321,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         for (int s = 0; s < 16; s++) sv[s * 64] = 0.0f;
         sv[SV_MOMZ * 64] = z_first;
         if (lane == 0) {
-            sh_flag[0] = 0;
+            sh_flag[0] = 0; sh_flag[1] = 0; sh_flag[2] = 0; // run status; L2-local exchange proven; compute waves arrived
             BlCtlScalars z{};
             z.eps = 1.0f; z.da_prox = 2.302585093f; // log(10 * step_size0)
             *ss = z;
@@ -585,6 +589,8 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     // compute waves' evaluation and the control wave's sampler state as DISJOINT live ranges (one shared loop keeps every
     // loop-carried register of either role alive through the other role's code: spills on both sides).
     if (wave > 0) {
+        unsigned epoch_c = 0;  // evaluations so far = the exchange epoch of the one in flight (the control wave counts the same)
+        bool local_c = false;
         while (true) {
             // ------------------------------------- phase A: compute waves, site log-lik ----
 #ifdef BL_STAMPS
@@ -594,9 +600,47 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #ifdef BL_STAMPS
             st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
 #endif
-            __syncthreads(); // partials are in LDS: the control wave's exchange
+            // ---- the LAST compute wave to finish publishes the workgroup's partial to the chain at once: the hand-off to the
+            // other workgroups then runs beside the control wave's decisions about the previous leaf (which outlast phase A on
+            // every doubling and transition-end tick) instead of after them.  Every evaluation is published, also one the
+            // decisions are about to drop (all workgroups drop the same ones and skip that epoch's poll).
+            epoch_c++;
+            int arrived = 0;
+            if (lane == 0) arrived = __hip_atomic_fetch_add(&sh_flag[2], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            arrived = __builtin_amdgcn_readfirstlane(arrived);
+            if (arrived == CW - 1) {
+                if (lane == 0) sh_flag[2] = 0; // (the next arrivals come after the two barriers below)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                // workgroup partial (fixed wave order): lanes < D their gradient component, lane D the log-lik
+                const float *part = bl_lds_f(BL_OFF_PART) + part_pos;
+                float comp = 0.0f;
+#pragma unroll
+                for (int w = 0; w < CW; w++) comp += part[w * part_rs];
+                for (int sp = 1; sp < nsp; sp++) { // several species: the log-lik and the shared coordinate add the other species' slots
+#pragma unroll
+                    for (int w = 0; w < CW; w++) comp += part_all ? part[w * part_rs + sp * BL_SP_PART(KS, KO)] : 0.0f;
+                }
+                if (lane > D) comp = 0.0f;
+                if (lane == D + 1 && member == 0 && (epoch_c & 255u) == 0u)
+                    comp = (__hip_atomic_load(cold->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1.0f : 0.0f;
+                if (epoch_c == 1u) { // placement census: all k XCC ids equal  <=>  k * sum(x^2) == (sum x)^2
+                    if (lane == D + 2) comp = xcc;
+                    if (lane == D + 3) comp = xcc * xcc;
+                }
+                const unsigned char *rbase = xbase + (epoch_c & (BL_XCHG_SLOTS - 1u)) * rec_bytes;
+                const unsigned long long granule = ((unsigned long long)epoch_c << 32) | __float_as_uint(comp);
+                if (lane < nvp) {
+                    unsigned long long *dst = reinterpret_cast<unsigned long long *>(const_cast<unsigned char *>(rbase) + my_store_off);
+                    if (local_c) // line stays in this XCD's L2, where every consumer of this chain polls it
+                        __hip_atomic_store(dst, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else         // write-through: visible to any XCD
+                        __hip_atomic_store(dst, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads(); // (the control wave's decisions are done)
             __syncthreads(); // the next position is in LDS
             if (sh_flag[0] != 0) break;
+            local_c = sh_flag[1] != 0;
         }
     } else
     while (true) {
@@ -621,40 +665,15 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         __syncthreads();
         BL_STAMP(1)
 
+        epoch++; // (the evaluation just finished was published by the compute waves under this epoch, wanted or not)
         if (redo) {
             // the decisions chose another position (transition end, U-turn, divergence, ...) or the run is over:
-            // publish nothing, hand the compute waves the right position
+            // that epoch is skipped by every workgroup alike; hand the compute waves the right position
             if (act) sh_coef[my_pos] = cz;
             if (lane == 0) sh_flag[0] = flag;
         } else {
-            epoch++;
-            // ---------------------------------- workgroup partial (fixed wave order) ----
-            const float *part = bl_lds_f(BL_OFF_PART) + part_pos;
-            float comp = 0.0f; // lanes < D: their gradient component; lane D: the log-lik
-#pragma unroll
-            for (int w = 0; w < CW; w++) comp += part[w * part_rs];
-            for (int sp = 1; sp < nsp; sp++) { // several species: the log-lik and the shared coordinate add the other species' slots
-#pragma unroll
-                for (int w = 0; w < CW; w++) comp += part_all ? part[w * part_rs + sp * BL_SP_PART(KS, KO)] : 0.0f;
-            }
-            if (lane > D) comp = 0.0f;
-            if (lane == D + 1 && member == 0 && (epoch & 255u) == 0u)
-                comp = (__hip_atomic_load(cold->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1.0f : 0.0f;
-            if (epoch == 1u) { // placement census: all k XCC ids equal  <=>  k * sum(x^2) == (sum x)^2
-                if (lane == D + 2) comp = xcc;
-                if (lane == D + 3) comp = xcc * xcc;
-            }
-
             // ------------------------------ all-gather of the k partials (G16 / R2) ----
-            const unsigned char *rbase = xbase + ((epoch & 1u) ? rec_bytes : 0u);
-            const unsigned long long granule = ((unsigned long long)epoch << 32) | __float_as_uint(comp);
-            if (lane < nvp) {
-                unsigned long long *dst = reinterpret_cast<unsigned long long *>(const_cast<unsigned char *>(rbase) + my_store_off);
-                if (local) // line stays in this XCD's L2, where every consumer of this chain polls it
-                    __hip_atomic_store(dst, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                else       // write-through: visible to any XCD
-                    __hip_atomic_store(dst, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            const unsigned char *rbase = xbase + (epoch & (BL_XCHG_SLOTS - 1u)) * rec_bytes;
             BL_STAMP(2)
             // ------------------------------------------------ potential at cz (lane d) ----
             // prior of lane d: pe2 = 2 x its energy, pg = d energy / d theta_d
@@ -774,6 +793,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             if (epoch == 1u && p.allow_local) {
                 const double sx = bl_readlane_d(acc, D + 2), sxx = bl_readlane_d(acc, D + 3);
                 local = ((double)p.k * sxx == sx * sx); // exact: small integers
+                if (lane == 0) sh_flag[1] = local ? 1 : 0; // (the compute waves' stores from the next evaluation on)
             }
             const float cg = act ? (-(float)acc + pg) : 0.0f;
             p_acc = acc; p_cg = cg; p_pe2 = pe2; p_timed_out = timed_out;
