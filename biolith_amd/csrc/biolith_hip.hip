@@ -1570,6 +1570,21 @@ extern "C" int bl_nuts_debug_counters(bl_dataset *ds, int64_t *out, int n)
     return BL_OK;
 }
 
+extern "C" int bl_host_alloc(size_t bytes, void **out)
+{
+    if (!out || bytes == 0) return bl_fail(BL_ERR_INVALID, "bl_host_alloc: NULL / empty");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return bl_fail(BL_ERR_NO_DEVICE, "no HIP device visible");
+    BL_HIP(hipHostMalloc(out, bytes, hipHostMallocPortable));
+    return BL_OK;
+}
+extern "C" int bl_host_free(void *ptr)
+{
+    if (ptr) BL_HIP(hipHostFree(ptr));
+    return BL_OK;
+}
+
 extern "C" int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads_per_wg, int *lds_bytes, int *lds_staged,
                                 int *chains_on_l2_local_exchange)
 {

@@ -221,6 +221,12 @@ int bl_nuts_device_draws(bl_dataset *ds, void **dev_ptr, size_t *bytes);
 int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads_per_wg, int *lds_bytes, int *lds_staged,
                      int *chains_on_l2_local_exchange);
 
+/* Page-locked host memory for large outputs (bl_deterministic / bl_predict write into caller memory; into page-locked memory the
+ * device copies at PCIe rate instead of staging through the runtime's bounce buffers).  The caller owns and frees it.  The
+ * reference's counterpart is jax.device_get() of a deterministic site (utils/fit.py:132). */
+int bl_host_alloc(size_t bytes, void **out);
+int bl_host_free(void *ptr);
+
 /* In-kernel phase cycle counters of the last launch; all zero unless the library is a diagnostic
  * BL_STAMPS build (make -C biolith_amd/csrc stamps).  Not part of the reference's interface. */
 int bl_nuts_debug_counters(bl_dataset *ds, int64_t *out /*[n<=32]*/, int n);

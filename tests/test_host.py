@@ -224,3 +224,64 @@ def test_grid_search_hands_kernel_and_init_strategy_to_fit_only(monkeypatch):
     assert res.best_score == -1.0 and len(seen["fit"]) == 3          # two folds + the refit
     assert all(kw.get("kernel") == "nuts" for kw in seen["fit"])
     assert all("kernel" not in kw and "init_strategy" not in kw for kw in seen["predict"] + seen["lppd"])
+
+
+def test_pinned_pool_hands_out_page_locked_buffers_from_the_second_request_on():
+    """engine._PinnedPool (outputs of bl_deterministic from 8 MB on): the first request of a size class gets ordinary pages and has a
+    buffer pinned in the background (after the copy: kick()); the next one takes it; it returns to the pool with its array."""
+    import ctypes as C
+    import gc
+    import threading
+    import time
+
+    from biolith_amd.engine import _PinnedPool
+
+    libc = C.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes, libc.free.argtypes = C.c_void_p, [C.c_size_t], [C.c_void_p]
+
+    class Lib:   # bl_host_alloc / bl_host_free on malloc
+        allocs, frees = [], []
+
+        def bl_host_alloc(self, size, out):
+            out._obj.value = libc.malloc(size)
+            self.allocs.append(out._obj.value)
+            return 0
+
+        def bl_host_free(self, p):
+            self.frees.append(p.value)
+            libc.free(p)
+            return 0
+
+    lib, pool = Lib(), _PinnedPool(cap=1 << 25)
+    shape = (3000, 1000)   # 12 MB -> the 16 MB class
+    a = pool.empty(lib, shape, np.float32)
+    assert a.shape == shape and not lib.allocs     # ordinary pages, nothing pinned yet
+    pool.kick(lib)
+    for _ in range(200):
+        if lib.allocs and not pool.pending:
+            break
+        time.sleep(0.01)
+    assert len(lib.allocs) == 1 and pool.held == 1 << 24
+    b = pool.empty(lib, shape, np.float32)
+    assert b.ctypes.data == lib.allocs[0] and pool.held == 0
+    b[:] = 2.0
+    view = b[5:7]
+    del b
+    gc.collect()
+    assert pool.held == 0 and float(view.sum()) == 4000.0   # a view keeps the buffer out of the pool
+    del view
+    gc.collect()
+    assert pool.held == 1 << 24 and not lib.frees
+    c = pool.empty(lib, shape, np.float32)
+    assert c.ctypes.data == lib.allocs[0]
+    # over the cap: a second class is asked for, pinned, and freed again when it comes back
+    d = pool.empty(lib, (6000, 1000), np.float32)   # 24 MB -> the 32 MB class: held 0 + 32 MB <= cap, so it is wanted
+    pool.kick(lib)
+    for _ in range(200):
+        if len(lib.allocs) == 2 and not pool.pending:
+            break
+        time.sleep(0.01)
+    del c
+    gc.collect()
+    assert len(lib.allocs) == 2 and len(lib.frees) == 1 and pool.held == 1 << 25   # 16 + 32 MB > cap: one of them was released
+    assert threading.active_count() >= 1 and d.shape == (6000, 1000)
