@@ -58,3 +58,21 @@ for name, key in (("true cutoff", cut), ("detections", det.sum(1)), ("eta at tru
     order = np.argsort(-np.asarray(key, dtype=np.float64), kind="stable")
     s, ideal, nr = slowest(order, waves)
     print(f"sorted by {name:22s}: slowest wave {s:6.1f} (balanced ideal {ideal:.1f}, {nr} rounds)")
+
+# ---- hybrid: per workgroup one QUAD wave (16 sites, four lanes each: n-loops a quarter as long) for the sites a static proxy ranks
+# heaviest, three ordinary waves for the rest; sites dealt round-robin over the workgroups in proxy order
+def hybrid(key, k=32, nq=16, fixed=8.0, fixed_q=12.0):
+    order = np.argsort(-np.asarray(key, dtype=np.float64), kind="stable")
+    worst = 0.0
+    for g in range(k):
+        mine = order[g::k]                       # this workgroup's sites, heaviest (by the proxy) first
+        cq, cn = cut[mine[:nq]], cut[mine[nq:]]
+        waves = [cq.max() / 4.0 + fixed_q] + [cn[i::3].max() + fixed for i in range(3)]
+        worst = max(worst, max(waves))
+    return worst
+
+print("hybrid (k = 32, 16 quad sites per workgroup), slowest wave:")
+for name, key in (("true cutoff (upper bound on what a proxy can do)", cut), ("detections", det.sum(1)),
+                  ("detections, then more non-detections first", det.sum(1) * 100 - non.sum(1)),
+                  ("log-odds proxy: detections / visits", det.sum(1) / np.maximum(det.sum(1) + non.sum(1), 1))):
+    print(f"  proxy {name:52s}: {hybrid(key):5.1f}   (32 quad sites: {hybrid(key, nq=32):5.1f})")
