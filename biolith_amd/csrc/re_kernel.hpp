@@ -957,6 +957,10 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
         // complete after the site pass -- to overlap the exchange's hand-off.  7 % SLOWER: collecting granules that are already
         // there still costs one L2 round trip + the sums (~2 k of the exchange's 2.4 k cycles), while the extra pass of this loop
         // for the handful of fixed effects costs its full latency again, ~1.4 k.)
+        // (Measured and dropped, round 2: TWO exchanges in flight -- the second exchange carrying the random effects' dot products only,
+        // published right behind the first, and the first wave adding the replicated coordinates' share, identical in every workgroup,
+        // after collecting both: one hand-off and one block sum less on the critical path, but the extra pass of the first wave over
+        // its replicated coordinates and its in-wave reduction cost more: 4-7 % slower, bench line 9.8 -> 10.3 us.)
         const double Un = evaluate_b();
         if (!odd) second_half_all(std::integral_constant<int, 0>{});
         else if (nck <= 1) second_half_all(std::integral_constant<int, 1>{});
