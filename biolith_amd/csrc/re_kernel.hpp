@@ -239,41 +239,59 @@ __device__ __forceinline__ bool bl_re_collect(BlReXchg &x, double *out, float *s
 // lane groups (nvp = 16, 32 or 64 value slots) each poll a share of the k workgroups' granules, up to eight loads in flight per
 // lane, add them in f64 and are folded across groups by v_permlane16_swap / v_permlane32_swap; one barrier hands the totals to
 // the other waves.  (The general form above stages k x nv floats in LDS between two barriers and adds them serially: 2.5-3.2 k
-// cycles per exchange against ~1.7 k.)  Same fixed order in every workgroup => bit-identical totals.
+// cycles per exchange against ~1.7 k; it remains for the per-species sums of more than three species.)  Same fixed order in every
+// workgroup => bit-identical totals.
+// (bl_re_wave_poll: the first wave's lanes < nv get the sums over workgroups [w_lo, w_lo + w_cnt); out_sp: several species, first
+// exchange of a leapfrog -- one poll per species' group of workgroups, the totals are their sums)
 template <int NRED>
-__device__ __forceinline__ bool bl_re_collect_wave(BlReXchg &x, double *out, int *lds_flag, int nv)
+__device__ __forceinline__ double bl_re_wave_poll(const BlReXchg &x, int nv, int w_lo, int w_cnt, bool &timed_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int nvp = nv <= 16 ? 16 : (nv <= 32 ? 32 : 64), G = 64 / nvp;
+    const int c = min(lane & (nvp - 1), nv - 1), sub = lane / nvp;
+    const unsigned long long *base = x.buf + (((size_t)x.chain * 2 + (x.epoch & 1u)) * x.k + w_lo) * NRED + c;
+    double acc = 0.0;
+    for (int p0 = 0; p0 < w_cnt && !timed_out; p0 += 8 * G) {
+        unsigned long long v[8];
+        BlSpinBound bound;
+        while (true) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int w = min(p0 + q * G + sub, w_cnt - 1); // (beyond the range: its last record again, dropped below)
+                v[q] = __hip_atomic_load(base + (size_t)w * NRED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            unsigned bad = 0u;
+#pragma unroll
+            for (int q = 0; q < 8; q++) bad |= (unsigned)(v[q] >> 32) ^ x.epoch;
+            if (__all(bad == 0u)) break;
+            if (bound.expired(x.spin_limit)) { timed_out = true; break; }
+            if (!x.local) __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc += (p0 + q * G + sub < w_cnt) ? (double)__uint_as_float((unsigned)v[q]) : 0.0;
+    }
+    if (nvp <= 16) acc = bl_fold_rows16_d(acc);
+    if (nvp <= 32) acc = bl_fold_halves32_d(acc);
+    return acc;
+}
+template <int NRED>
+__device__ __forceinline__ bool bl_re_collect_wave(BlReXchg &x, double *out, int *lds_flag, int nv, double *out_sp = nullptr)
 {
     if (x.k == 1) return true;
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
-        const int nvp = nv <= 16 ? 16 : (nv <= 32 ? 32 : 64), G = 64 / nvp;
-        const int c = min(lane & (nvp - 1), nv - 1), sub = lane / nvp;
-        const unsigned long long *base = x.buf + (((size_t)x.chain * 2 + (x.epoch & 1u)) * x.k) * NRED + c;
-        double acc = 0.0;
         bool timed_out = false;
-        for (int p0 = 0; p0 < x.k && !timed_out; p0 += 8 * G) {
-            unsigned long long v[8];
-            BlSpinBound bound;
-            while (true) {
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int w = min(p0 + q * G + sub, x.k - 1); // (beyond k: the last record again, dropped below)
-                    v[q] = __hip_atomic_load(base + (size_t)w * NRED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                unsigned bad = 0u;
-#pragma unroll
-                for (int q = 0; q < 8; q++) bad |= (unsigned)(v[q] >> 32) ^ x.epoch;
-                if (__all(bad == 0u)) break;
-                if (bound.expired(x.spin_limit)) { timed_out = true; break; }
-                if (!x.local) __builtin_amdgcn_s_sleep(1);
+        double tot = 0.0;
+        if (out_sp) {
+            const int kps = x.k / x.n_species;
+            for (int sp = 0; sp < x.n_species; sp++) {
+                const double t = bl_re_wave_poll<NRED>(x, nv, sp * kps, kps, timed_out);
+                if (lane < nv) out_sp[sp * NRED + lane] = t;
+                tot += t;
             }
-#pragma unroll
-            for (int q = 0; q < 8; q++) acc += (p0 + q * G + sub < x.k) ? (double)__uint_as_float((unsigned)v[q]) : 0.0;
-        }
-        if (nvp <= 16) acc = bl_fold_rows16_d(acc);
-        if (nvp <= 32) acc = bl_fold_halves32_d(acc);
+        } else tot = bl_re_wave_poll<NRED>(x, nv, 0, x.k, timed_out);
         if (timed_out && lane == 0) *lds_flag = 1;
-        if (lane < nv) out[lane] = acc;
+        if (lane < nv) out[lane] = tot;
     }
     __syncthreads();
     return *lds_flag == 0;
@@ -282,7 +300,7 @@ template <int NRED>
 __device__ __forceinline__ bool bl_re_exchange(BlReXchg &x, double *out, float *scr2 /*[k][NRED]*/, int *lds_flag, int nv)
 {
     bl_re_publish<NRED>(x, out, nv);
-    return x.n_species == 1 ? bl_re_collect_wave<NRED>(x, out, lds_flag, nv) : bl_re_collect<NRED>(x, out, scr2, lds_flag, nv);
+    return bl_re_collect_wave<NRED>(x, out, lds_flag, nv);
 }
 
 // Calls f(integral_constant<KB>, args...) for the smallest compiled covariate count KB in {1, 2, 4, 8, 16} (<= MK) that holds Ko.
@@ -840,7 +858,9 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
     auto evaluate_b = [&]() -> double {
         const float *z = H(RE_CZ);
         float *g = H(RE_CG);
-        if (!(m.n_species == 1 ? bl_re_collect_wave<NRED>(xc, red, &xflag, ev_nv) : bl_re_collect<NRED>(xc, red, scr2, &xflag, ev_nv, red_sp))) flag = 4;
+        // (several species: per-species sums by one poll per species up to three species, else the general form)
+        if (!(m.n_species <= 3 ? bl_re_collect_wave<NRED>(xc, red, &xflag, ev_nv, m.n_species > 1 ? red_sp : nullptr)
+                               : bl_re_collect<NRED>(xc, red, scr2, &xflag, ev_nv, red_sp))) flag = 4;
         BL_RE_T(10)
         if (ev_first && R.allow_local) xc.local = ((double)R.k * red[OX + 5] == red[OX + 4] * red[OX + 4]); // exact: small integers
         if (red[OX + 3] > 0.0) flag = 5;
