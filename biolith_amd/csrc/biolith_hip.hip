@@ -1456,8 +1456,8 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
         if (p.poll_sleep < 0 || p.poll_sleep > 127) p.poll_sleep = 3;
         const char *e3 = getenv("BIOLITH_HIP_FIRST_DELAY");
         p.pitch = pitch;
-        p.first_delay = e3 ? atoi(e3) : 2;
-        if (p.first_delay < 0 || p.first_delay > 127) p.first_delay = 2;
+        p.first_delay = e3 ? atoi(e3) : 0;
+        if (p.first_delay < 0 || p.first_delay > 127) p.first_delay = 0;
     }
 
     // timed region: state re-init (guide G16 "re-initialise every call") + the persistent kernel

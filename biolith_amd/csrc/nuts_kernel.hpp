@@ -662,6 +662,60 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             end_deferred(); // beside the evaluation of the new transition's first leaf
             BL_STAMP(0)
         }
+        // What the exchange of the evaluation in flight does not need is done BEFORE the barrier -- on a leaf tick the decisions
+        // are over before the site evaluation is, and this ran in the shadow of nothing: the first poll then goes out the moment the
+        // barrier opens (the prior at the position in flight, which kind of leaf comes next, the peeked direction, the other edge).
+        float pe2 = 0.0f, pg = 0.0f;
+        int spec_kind = 0;           // 0 none, 1 next leaf of the subtree, 2 / 3 next doubling from this leaf / from the other edge
+        float spec_ed = epsdir, spec_other = 0.0f;
+        if (!redo) {
+        // ------------------------------------------------ potential at cz (lane d) ----
+        // prior of lane d: pe2 = 2 x its energy, pg = d energy / d theta_d
+        //   Normal(loc, scale):            pe2 = (theta-loc)^2 / scale^2 ,  pg = (theta-loc) / scale^2
+        //   Laplace(loc, scale):           pe2 = 2 |theta-loc| / scale ,    pg = sign(theta-loc) / scale   (one of isc2, l1 is 0)
+        //   phi = logit f, f ~ Beta(a,b):  energy = a softplus(-phi) + b softplus(phi)  (Jacobian included),
+        //                                  pg = (a+b) sigmoid(phi) - a        (prior_loc = a, prior_isc2 = b)
+        const float dth = cz - prior_loc;
+        pe2 = fmaf(dth * dth, prior_isc2, 2.0f * fabsf(dth) * prior_l1);
+        pg = fmaf(dth, prior_isc2, dth > 0.0f ? prior_l1 : (dth < 0.0f ? -prior_l1 : 0.0f));
+        if constexpr (MODEL == 2) {
+            if (is_phi) {
+                const float e = bl_exp(-fabsf(cz)), op = 1.0f + e, l = bl_log(op);
+                const float sig = (cz > 0.0f ? 1.0f : e) * bl_rcp(op);
+                pe2 = 2.0f * (prior_loc * (fmaxf(-cz, 0.0f) + l) + prior_isc2 * (fmaxf(cz, 0.0f) + l));
+                pg = (prior_loc + prior_isc2) * sig - prior_loc;
+            }
+        }
+        if constexpr (MODEL == 3) {
+            //   phi = log f, f ~ Exponential(rate r):  energy = r e^phi - phi  (Jacobian included),  pg = r e^phi - 1
+            if (is_phi) {
+                const float rf = prior_loc * bl_exp(fminf(cz, 80.0f));
+                pe2 = 2.0f * (rf - cz);
+                pg = rf - 1.0f;
+            }
+        }
+        // Everything of the speculative position that does not need the gathered gradient is prepared here, in the
+        // shadow of the store -> poll latency: which kind of leaf comes next, the peeked direction bit, and -- when
+        // the next doubling starts from the tree's OTHER edge -- the whole position (it does not depend on this leaf).
+        spec_ed = epsdir;
+        if constexpr (SPEC) {
+            if (!init_pending) {
+                if (snprop + 1 < (1 << depth)) spec_kind = 1;
+                else if (depth + 1 < p.max_depth) {
+                    BlRng peek = rng_dir; // the real draw is made by the decisions
+                    const bool gr2 = (bl_rng_next(peek) >> 31) != 0u;
+                    spec_ed = gr2 ? eps : -eps;
+                    spec_kind = 2;
+                    if (gr2 != going_right) { // that edge is in LDS, untouched by the subtree in progress
+                        const int e = gr2 ? SV_ZR : SV_ZL;
+                        float rh2;
+                        bl_next_leaf(sv[e * 64], sv[(e + 1) * 64], sv[(e + 2) * 64], spec_ed, minv, rh2, spec_other);
+                        spec_kind = 3;
+                    }
+                }
+            }
+        }
+        }
         __syncthreads();
         BL_STAMP(1)
 
@@ -675,60 +729,15 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             // ------------------------------ all-gather of the k partials (G16 / R2) ----
             const unsigned char *rbase = xbase + (epoch & (BL_XCHG_SLOTS - 1u)) * rec_bytes;
             BL_STAMP(2)
-            // ------------------------------------------------ potential at cz (lane d) ----
-            // prior of lane d: pe2 = 2 x its energy, pg = d energy / d theta_d
-            //   Normal(loc, scale):            pe2 = (theta-loc)^2 / scale^2 ,  pg = (theta-loc) / scale^2
-            //   Laplace(loc, scale):           pe2 = 2 |theta-loc| / scale ,    pg = sign(theta-loc) / scale   (one of isc2, l1 is 0)
-            //   phi = logit f, f ~ Beta(a,b):  energy = a softplus(-phi) + b softplus(phi)  (Jacobian included),
-            //                                  pg = (a+b) sigmoid(phi) - a        (prior_loc = a, prior_isc2 = b)
-            const float dth = cz - prior_loc;
-            float pe2 = fmaf(dth * dth, prior_isc2, 2.0f * fabsf(dth) * prior_l1);
-            float pg = fmaf(dth, prior_isc2, dth > 0.0f ? prior_l1 : (dth < 0.0f ? -prior_l1 : 0.0f));
-            if constexpr (MODEL == 2) {
-                if (is_phi) {
-                    const float e = bl_exp(-fabsf(cz)), op = 1.0f + e, l = bl_log(op);
-                    const float sig = (cz > 0.0f ? 1.0f : e) * bl_rcp(op);
-                    pe2 = 2.0f * (prior_loc * (fmaxf(-cz, 0.0f) + l) + prior_isc2 * (fmaxf(cz, 0.0f) + l));
-                    pg = (prior_loc + prior_isc2) * sig - prior_loc;
-                }
-            }
-            if constexpr (MODEL == 3) {
-                //   phi = log f, f ~ Exponential(rate r):  energy = r e^phi - phi  (Jacobian included),  pg = r e^phi - 1
-                if (is_phi) {
-                    const float rf = prior_loc * bl_exp(fminf(cz, 80.0f));
-                    pe2 = 2.0f * (rf - cz);
-                    pg = rf - 1.0f;
-                }
-            }
-            // Everything of the speculative position that does not need the gathered gradient is prepared here, in the
-            // shadow of the store -> poll latency: which kind of leaf comes next, the peeked direction bit, and -- when
-            // the next doubling starts from the tree's OTHER edge -- the whole position (it does not depend on this leaf).
-            int spec_kind = 0;           // 0 none, 1 next leaf of the subtree, 2 / 3 next doubling from this leaf / from the other edge
-            float spec_ed = epsdir, spec_other = 0.0f;
-            if constexpr (SPEC) {
-                if (!init_pending) {
-                    if (snprop + 1 < (1 << depth)) spec_kind = 1;
-                    else if (depth + 1 < p.max_depth) {
-                        BlRng peek = rng_dir; // the real draw is made by the decisions
-                        const bool gr2 = (bl_rng_next(peek) >> 31) != 0u;
-                        spec_ed = gr2 ? eps : -eps;
-                        spec_kind = 2;
-                        if (gr2 != going_right) { // that edge is in LDS, untouched by the subtree in progress
-                            const int e = gr2 ? SV_ZR : SV_ZL;
-                            float rh2;
-                            bl_next_leaf(sv[e * 64], sv[(e + 1) * 64], sv[(e + 2) * 64], spec_ed, minv, rh2, spec_other);
-                            spec_kind = 3;
-                        }
-                    }
-                }
-            }
             // a first poll that misses costs a whole extra round trip: give the slowest peers' stores
             // a moment to land before looking
             for (int z = 0; z < p.first_delay; z++) __builtin_amdgcn_s_sleep(1);
             double acc = 0.0;
             bool timed_out = false;
             if (one_batch) {
-                // common shape: one round of <= 8 loads per lane covers all k records
+                // common shape: one round of <= 8 loads per lane covers all k records.  (Measured and dropped: two rounds in flight
+                // half a round trip apart, the first complete one taken -- 4-11 % slower: the waits on the second round's loads
+                // serialise behind the first's.)
                 unsigned long long v[8];
                 BlSpinBound bound;
                 while (true) {
