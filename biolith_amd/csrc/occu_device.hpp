@@ -1279,7 +1279,7 @@ __device__ __forceinline__ void bl_rn_fill_lgamma(int K, int nthreads)
             _Pragma("unroll") for (int m = mb_; m < mb_ + 2; m++) {                     \
                 float sb_ = subf;                                                       \
                 asm volatile("" : "+v"(sb_)); /* opaque: n is formed where it is used, not hoisted out of the visit loops (32 x per loop) */ \
-                const float fn = sb_ + (float)(4 * m);
+                const float fn = sb_ + (float)(4 * m); (void)fn;
 #define BL_RNQ_LOOP_END }}
 
 template <int KS, int KO, int CT>

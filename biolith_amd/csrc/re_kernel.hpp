@@ -493,7 +493,7 @@ __device__ __forceinline__ void bl_cs_site_pass(const BlReModel &m, const float 
 {
     const BlReSiteMap sm = bl_re_site_map(m);
     const int tps = sm.tps, S = sm.S, sub = sm.sub;
-    const int N = m.n_sites, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 1;
+    const int T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 1;
     // (every load of the pass is unconditional, its index clamped into the array, and the value selected afterwards: a load
     // under a wave-uniform condition `k <= Ko` becomes a branch around it -- twenty basic blocks per batch of visits -- and
     // the loads of a batch are no longer in flight together)
