@@ -637,6 +637,8 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                         __hip_atomic_store(dst, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            // (Measured and dropped: no barrier here -- the control wave polling straight after its decisions, a counter of coefficient
+            // reads guarding the one write that the barrier ordered: 2 % slower, the poll loop competes with the evaluation's tail.)
             __syncthreads(); // (the control wave's decisions are done)
             __syncthreads(); // the next position is in LDS
             if (sh_flag[0] != 0) break;
