@@ -11,6 +11,7 @@ from biolith_amd.engine import OccuDataset
 pytestmark = pytest.mark.gpu
 
 MODELS = ["occu", "occu_fp_c", "occu_fp_u", "occu_rn", "occu_cop", "occu_cop_fp", "nmixture", "occu_re_s", "occu_re_o", "occu_re_so", "occu_cs"]
+JOINT = ["occu", "occu_fp_c", "occu_fp_u", "occu_re_s", "occu_re_so"]   # several species under one chain
 
 
 def _draw(seed):
@@ -99,3 +100,35 @@ def test_random_shape_first_trees(seed):
         ok = np.logical_and.accumulate(~(np.asarray(o["diverging"][:, :2], bool) | np.asarray(r.diverging[:, :2], bool)), axis=1)
         assert np.array_equal(o["num_steps"][:, :2][ok], r.num_steps[:, :2][ok]), (model, k, o["num_steps"], r.num_steps)
         assert np.allclose(o["draws"][:, 0][ok[:, 0]], r.draws[:, 0][ok[:, 0]], atol=5e-3), (model, k)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_shape_several_species(seed):
+    """Two or three species under one chain (shared false-positive rate / shared sds): potential and gradient over all coordinates."""
+    rng = np.random.default_rng(5000 + seed)
+    model = JOINT[seed % len(JOINT)]
+    S, N, T, J = int(rng.choice([2, 3])), int(rng.choice([2, 40, 129, 300])), int(rng.choice([1, 2])), int(rng.choice([1, 4, 7]))
+    Ks, Ko = int(rng.choice([0, 1, 3, 4])), int(rng.choice([0, 2, 4]))
+    X = rng.normal(size=(N, Ks)).astype(np.float32) * 0.7
+    W = rng.normal(size=(N, T, J, Ko)).astype(np.float32) * 0.7
+    Y = (rng.uniform(size=(S, N, T, J)) < 0.35).astype(np.float32)
+    Y[rng.uniform(size=Y.shape) < 0.1] = np.nan
+    if Ko:
+        W[int(rng.integers(0, N)), 0, int(rng.integers(0, J)), 0] = np.nan
+    kw = {}
+    if model.startswith("occu_fp"):
+        kw = dict(model="occu_fp", fp_mode="constant" if model.endswith("c") else "unoccupied", prior_fp=(2.0, 6.0))
+    elif model.startswith("occu_re"):
+        kw = dict(model="occu_re", site_random_effects=True, obs_random_effects=model.endswith("so"), prior_site_re_sd=0.8, prior_obs_re_sd=1.2)
+    od, ds = oracle.OracleData(X, W, Y, **kw), OccuDataset(X, W, Y, **kw)
+    assert od.D == ds.D and od.n_species == S
+    th = rng.uniform(-1.0, 1.0, size=(2, od.D)).astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.max(np.abs(Ug - Uo) / np.maximum(np.abs(Uo), 1.0)) <= 3e-6, (model, S, X.shape, W.shape, Ug, Uo)
+    assert np.max(np.abs(Gg - Go)) <= 5e-5 * max(np.max(np.abs(Go)), 1.0), (model, S, X.shape, W.shape)
+    init = rng.uniform(-0.3, 0.3, size=(2, od.D)).astype(np.float32).astype(np.float64)
+    o = oracle.nuts_run(od, 0, 3, num_chains=2, seed=seed, init=init)
+    r = ds.nuts(num_warmup=0, num_samples=3, num_chains=2, seed=seed, init_theta=init)
+    ok = np.logical_and.accumulate(~(np.asarray(o["diverging"][:, :2], bool) | np.asarray(r.diverging[:, :2], bool)), axis=1)
+    assert np.array_equal(o["num_steps"][:, :2][ok], r.num_steps[:, :2][ok]), (model, o["num_steps"], r.num_steps)
