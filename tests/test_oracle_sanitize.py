@@ -3,7 +3,7 @@
 The 1.1 k-line ``oracle/occu_oracle.c`` is the ground truth of every GPU parity test; it carves a heap pool by hand and
 keeps stack arrays of ``ORC_MAX_D``.  Here its ASan + UBSan build (``make -C oracle liboccu_oracle_asan.so``) evaluates the
 potential + gradient and runs a short NUTS for EVERY model id (occu, occu_rn, false positives x2, occu_cop x2, nmixture,
-random effects x3, occu_cs; Normal and Laplace priors; missing data; several periods) in a fresh child process with libasan
+random effects x3, occu_cs, three species under one chain x3; Normal and Laplace priors; missing data; several periods) in a fresh child process with libasan
 preloaded.  Any report aborts the child (``halt_on_error``).  CPU only: GPU sanitizers are not available on this pool."""
 import os
 import subprocess
@@ -48,6 +48,13 @@ CHILD = textwrap.dedent("""
         ("occu_re both", oracle.OracleData(*base(occ), model="occu_re", site_random_effects=True, obs_random_effects=True)),
         ("occu_cs", oracle.OracleData(cs["site_covs"], cs["obs_covs"], cs["scores"] if "scores" in cs else cs["obs"], model="occu_cs")),
     ]
+    # several species under one chain (shared false-positive rate / shared random-effect sds)
+    sp = quiet(simulate, n_species=3, simulate_missing=True, **small)
+    cases += [
+        ("occu 3 species", oracle.OracleData(*base(sp))),
+        ("occu_fp 3 species", oracle.OracleData(*base(sp), model="occu_fp", fp_mode="constant")),
+        ("occu_re 3 species", oracle.OracleData(*base(sp), model="occu_re", site_random_effects=True, obs_random_effects=True)),
+    ]
     rng = np.random.default_rng(0)
     for name, od in cases:
         th = rng.uniform(-1.0, 1.0, size=(3, od.D))
@@ -75,4 +82,4 @@ def test_oracle_is_clean_under_asan_and_ubsan():
     assert r.returncode == 0, tail
     assert "SANITIZER RUN COMPLETE" in r.stdout, tail
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, tail
-    assert r.stdout.count("ok ") == 12
+    assert r.stdout.count("ok ") == 15
