@@ -362,3 +362,29 @@ def test_re_several_species_through_fit_and_predict():
     assert np.allclose(pp["psi"], s["psi"], atol=1e-5)
     with pytest.raises(NotImplementedError):
         fit(occu, **data, **kw, joint_species=False)
+
+
+def test_re_several_species_posterior_matches_oracle():
+    """Posterior of the fixed effects of two species and of the shared log site_re_sd, 4 x (400 + 400) on each side with independent
+    streams: means within 4 Monte-Carlo standard errors of the oracle's, spreads within a third."""
+    from biolith_amd.models import simulate
+    import contextlib
+    import io
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        d, _ = simulate(n_species=2, n_sites=120, n_site_covs=1, n_obs_covs=1, deployment_days_per_site=56, session_duration=7,
+                        site_random_effects=True, random_seed=5)
+    kw = dict(model="occu_re", site_random_effects=True, obs_random_effects=False)
+    od = oracle.OracleData(d["site_covs"], d["obs_covs"], d["obs"], **kw)
+    ds = OccuDataset(d["site_covs"], d["obs_covs"], d["obs"], **kw)
+    o = oracle.nuts_run(od, 400, 400, num_chains=4, seed=0)
+    r = ds.nuts(num_warmup=400, num_samples=400, num_chains=4, seed=50)
+    G = 2 * (od.Ks + od.Ko + 2) + 1
+    fg, fo = r.draws[:, :, :G].reshape(-1, G).astype(np.float64), o["draws"][:, :, :G].reshape(-1, G)
+    ess_g = np.array([oracle.effective_sample_size(r.draws[:, :, k:k + 1].astype(np.float64))[0] for k in range(G)])
+    ess_o = np.array([oracle.effective_sample_size(o["draws"][:, :, k:k + 1])[0] for k in range(G)])
+    mcse = np.sqrt(fg.var(0) / ess_g + fo.var(0) / ess_o)
+    assert np.all(np.abs(fg.mean(0) - fo.mean(0)) <= 4 * mcse), (fg.mean(0) - fo.mean(0), mcse)
+    ratio = (fg.std(0) / fo.std(0))[:G - 1]
+    assert np.all((ratio > 0.75) & (ratio < 1.33)), ratio
+    assert split_gelman_rubin(r.draws[:, :, :G - 1]).max() < 1.1 and r.diverging.mean() < 0.05
