@@ -980,7 +980,9 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
         // (Measured and dropped, round 2: TWO exchanges in flight -- the second exchange carrying the random effects' dot products only,
         // published right behind the first, and the first wave adding the replicated coordinates' share, identical in every workgroup,
         // after collecting both: one hand-off and one block sum less on the critical path, but the extra pass of the first wave over
-        // its replicated coordinates and its in-wave reduction cost more: 4-7 % slower, bench line 9.8 -> 10.3 us.)
+        // its replicated coordinates and its in-wave reduction cost more: 4-7 % slower, bench line 9.8 -> 10.3 us.  And its
+        // leaner form -- ONE block sum for both payloads, the two records published together and collected by the first two waves
+        // side by side, four barriers per leapfrog instead of five: -6 ... +3 % over the five shapes, -1 % on the bench line, i.e. even.)
         const double Un = evaluate_b();
         if (!odd) second_half_all(std::integral_constant<int, 0>{});
         else if (nck <= 1) second_half_all(std::integral_constant<int, 1>{});
