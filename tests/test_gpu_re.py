@@ -362,6 +362,10 @@ def test_re_several_species_through_fit_and_predict():
     assert np.allclose(pp["psi"], s["psi"], atol=1e-5)
     with pytest.raises(NotImplementedError):
         fit(occu, **data, **kw, joint_species=False)
+    # chains dealt over two shards (here the same GPU twice): the same draws as the single launch
+    two = fit(occu, **data, **kw, devices=[0, 0])
+    for k in ("cov_state_0", "site_re_sd", "obs_re_sd", "site_re_occ"):
+        assert np.allclose(res.samples[k], two.samples[k], atol=1e-5), k
 
 
 def test_re_several_species_posterior_matches_oracle():
