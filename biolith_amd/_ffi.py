@@ -67,7 +67,7 @@ EXPORTS = (
     "bl_nuts_abort", "bl_nuts_wait", "bl_nuts_fetch", "bl_nuts_elapsed_ms", "bl_nuts_device_draws",
     "bl_nuts_geometry", "bl_nuts_debug_counters", "bl_deterministic", "bl_predict", "bl_predict_counts", "bl_predict_scores", "bl_dataset_create_fp", "bl_dataset_create_cop", "bl_dataset_create_nmix", "bl_dataset_create_re", "bl_dataset_create_cs", "bl_dataset_set_prior_family", "bl_rng_streams", "bl_adaptation_schedule",
     "bl_comm_rccl_version", "bl_comm_unique_id", "bl_comm_init_rank", "bl_comm_init_all", "bl_comm_info", "bl_comm_destroy",
-    "bl_gather_draws", "bl_host_alloc", "bl_host_free",
+    "bl_gather_draws", "bl_result_block_layout", "bl_gather_unpack", "bl_host_alloc", "bl_host_free",
 )
 
 _lib = None
@@ -136,6 +136,8 @@ def load():
         L.bl_comm_info.argtypes = [vp, ip, ip, ip, dp]
         L.bl_comm_destroy.argtypes = [vp]
         L.bl_gather_draws.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int, C.POINTER(C.c_int32), C.POINTER(bl_nuts_output)]
+        L.bl_result_block_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+        L.bl_gather_unpack.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(bl_nuts_output)]
         for name in EXPORTS:
             if name != "bl_last_error":
                 getattr(L, name).restype = C.c_int

@@ -683,7 +683,9 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
         delete ds;
         return bl_fail(BL_ERR_UNSUPPORTED, "n_species=%d x (Ks=%d, Ko=%d): too many coordinates for one joint chain (sample the species one by one)", S, Ks, Ko);
     }
-    const int vw = KO + 1 + ((model == 3 || model == 4) ? 1 : 0); // floats per visit
+    // floats per visit: (c, c w_1 .. c w_KO), or (y, dur | m, w..) for the count models; occu_rn keeps one more, zero here, that its
+    // kernel rewrites at every evaluation (rn_device.hpp)
+    const int vw = KO + 1 + ((model == 1 || model == 3 || model == 4) ? 1 : 0);
     ds->ko_layout = vw - 1;
     const int n_stride = (N + 63) / 64 * 64;
     const int sp_rows = V * vw + 2 * T;          // rows of one species' block (visits, ka, kb); the site covariates come once
@@ -790,7 +792,7 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
                 if (cov_nan || !std::isfinite(y)) n_masked++;
                 else if (y != 0.0f) { c = 1.0f; n_det++; }
                 else c = -1.0f;
-                const size_t r0 = sp_off + (size_t)(row_wc + v * (KO + 1));
+                const size_t r0 = sp_off + (size_t)(row_wc + v * vw);
                 rows[r0 * n_stride + i] = c;
                 for (int k = 0; k < Ko; k++) rows[(r0 + 1 + k) * n_stride + i] = c * w[k];
             }
@@ -896,8 +898,9 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     // occu / false positives: a lane evaluates a PAIR of sites (packed f32 math); one pair per lane is the
     // latency optimum.  With 3 compute waves every wave, the control wave included, owns a SIMD; that is
     // used whenever one pair per lane still fits the chain's workgroup budget, else 4 compute waves.
-    // occu_rn: one site per lane on 3 compute waves.
-    int ncw = BL_CWAVES_RN, per_wg = BL_CWAVES_RN * 64;
+    // occu_rn (rn_device.hpp): 7 compute waves; its cost is per item of the sums over N, not per lane, so a chain takes
+    // all the workgroups its XCD offers once it has more than a wave of sites for each.
+    int ncw = BL_CWAVES_RN, per_wg = 64;
     if (ds->model != 1) {
         ncw = ((N + 2 * 3 * 64 - 1) / (2 * 3 * 64) <= kmax) ? 3 : 4;
         if (const char *e = getenv("BIOLITH_HIP_CWAVES")) { const int v = atoi(e); if (v == 3 || v == 4) ncw = v; } // A/B knob
@@ -906,7 +909,8 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     int k = want_k > 0 ? want_k : (N + per_wg - 1) / per_wg;
     if (k > kmax) k = kmax;
     if (k < 1) k = 1;
-    const int lds_cap = BL_LDS_TOTAL - BL_OFF_DATA;
+    const int rn_scratch = ds->model == 1 ? bl_rn_scratch_bytes(BL_CWAVES_RN) : 0; // behind the records
+    const int lds_cap = BL_LDS_TOTAL - BL_OFF_DATA - rn_scratch;
     // LDS keeps one record of `stride` floats per PAIR of sites (occu_device.hpp)
     const int stride = bl_record_stride(ds->dims.n_periods, ds->dims.n_replicates, ds->KS, ds->ko_layout);
     auto fits = [&](int kk, int *nloc) { // (every species has a record region of its own)
@@ -927,11 +931,18 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
         if (!(e && e[0] == '1'))
             for (int kk = kmax + 1; kk <= kwide && !ok; kk++) { ok = fits(kk, &nloc); if (ok) { k = kk; wide = 1; } }
     }
+    if (ok && !wide && ds->model == 1 && want_k <= 0) { // A/B knob: occu_rn over more workgroups than one XCD offers a chain
+        if (const char *e = getenv("BIOLITH_HIP_RN_K")) {
+            const int kk = atoi(e), kwide = 256 / (chains > 0 ? chains : 1);
+            int nl;
+            if (kk > kmax && kk <= kwide && fits(kk, &nl)) { k = kk; nloc = nl; wide = 1; }
+        }
+    }
     if (!ok) fits(k, &nloc);
     if (!ok && ds->model == 0) ncw = 4; // HBM-row form is built for 4 compute waves only
     if (wide) ncw = ds->model == 1 ? BL_CWAVES_RN : 4; // full slices: all four SIMDs evaluate
     *k_out = k; *nloc_out = nloc; *ld_out = stride; *staged_out = ok ? 1 : 0; *ncw_out = ncw; *wide_out = wide;
-    *lds_bytes_out = ok ? BL_OFF_DATA + ((nloc + 1) / 2) * stride * 4 * ds->nsp : BL_OFF_DATA;
+    *lds_bytes_out = ok ? BL_OFF_DATA + ((nloc + 1) / 2) * stride * 4 * ds->nsp + rn_scratch : BL_OFF_DATA;
 }
 
 // ------------------------------------------------------------- K1 logp ----
@@ -1188,6 +1199,7 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
     BlLogpParams p{};
     p.dd = ds->dd; p.k = k; p.nloc = nloc; p.rec_stride = ld; p.B = B; p.theta = d_th32; p.partial = d_partial;
     p.max_abundance = ds->max_abundance;
+    p.rn_off = BL_OFF_DATA + ((nloc + 1) / 2) * ld * 4; // (occu_rn: one species)
     p.fp_mode = ds->fp_mode;
     p.nmix_tab = ds->d_tab;
     p.ncw = ncw;
@@ -1438,6 +1450,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.k = k; p.nloc = nloc; p.rec_stride = ld; p.nvp = nvp;
     p.max_depth = max_depth;
     p.max_abundance = ds->max_abundance;
+    p.rn_off = BL_OFF_DATA + ((nloc + 1) / 2) * ld * 4; // (occu_rn: one species)
     p.fp_mode = ds->fp_mode;
     p.nmix_tab = ds->d_tab;
     p.ncw = ncw;

@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <chrono>
+#include <mutex>
 
 namespace {
 
@@ -30,12 +31,18 @@ struct RcclApi {
     std::string error;
 };
 
+static void rccl_load(RcclApi &api);
+
 RcclApi *rccl_api()
 {
     static RcclApi api;
-    static bool tried = false;
-    if (tried) return &api;
-    tried = true;
+    static std::once_flag once; // (two threads may create communicators at the same time)
+    std::call_once(once, [] { rccl_load(api); });
+    return &api;
+}
+
+static void rccl_load(RcclApi &api)
+{
     // The RCCL that belongs to the HIP runtime THIS library is bound to: a process may hold two ROCm stacks (the system's
     // under /opt/rocm and the one a torch wheel bundles; which libamdhip64 this library got depends on load order), and an
     // RCCL bound to the other runtime finds "no ROCm-capable device".  So: look next to our own libamdhip64 first.
@@ -53,7 +60,7 @@ RcclApi *rccl_api()
         if (api.handle) break;
         api.error = dlerror();
     }
-    if (!api.handle) return &api;
+    if (!api.handle) return;
     bool ok = true;
     auto sym = [&](const char *name) { void *p = dlsym(api.handle, name); if (!p) { ok = false; api.error = std::string("missing symbol ") + name; } return p; };
     api.GetVersion = (decltype(api.GetVersion))sym("ncclGetVersion");
@@ -67,7 +74,6 @@ RcclApi *rccl_api()
     api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
     api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
     if (!ok) { dlclose(api.handle); api.handle = nullptr; }
-    return &api;
 }
 
 } // namespace
@@ -202,6 +208,31 @@ extern "C" int bl_comm_destroy(bl_comm *c)
     return BL_OK;
 }
 
+// ---- host-only half of the gather: where every rank's block lies in the gathered buffer, and how a block unpacks ----
+// (exported so that the N > 1 arithmetic is testable on a machine without GPUs: tests/test_gather_layout.py)
+extern "C" int bl_result_block_layout(int chains, int num_samples, int D, uint64_t *offsets /*[9]*/)
+{
+    if (chains <= 0 || num_samples < 0 || D <= 0 || !offsets) return bl_fail(BL_ERR_INVALID, "bl_result_block_layout: bad argument");
+    const RunLayout L = result_layout((size_t)chains, num_samples > 0 ? (size_t)num_samples : 1, (size_t)D);
+    const size_t o[9] = {L.draws, L.div, L.steps, L.acc, L.pot, L.eps, L.minv, L.nleap, L.end};
+    for (int i = 0; i < 9; i++) offsets[i] = (uint64_t)o[i];
+    return BL_OK;
+}
+
+// byte offset of every rank's block in the gathered buffer (boff[world] = its size); *equal = all ranks ran the same chain count
+static int gather_block_offsets(int world, const int32_t *chains_per_rank, size_t S, size_t D, std::vector<size_t> &boff, bool *equal)
+{
+    const size_t Sa = S > 0 ? S : 1;
+    boff.assign((size_t)world + 1, 0);
+    *equal = true;
+    for (int r = 0; r < world; r++) {
+        if (chains_per_rank[r] <= 0) return bl_fail(BL_ERR_INVALID, "bl_gather_draws: rank %d has no chains", r);
+        boff[r + 1] = boff[r] + result_layout((size_t)chains_per_rank[r], Sa, D).end;
+        *equal = *equal && chains_per_rank[r] == chains_per_rank[0];
+    }
+    return BL_OK;
+}
+
 // Scatter one rank's result block (the run slab's head, laid out by result_layout) into the caller's arrays at chain `c0`.
 static void unpack_block(const char *blk, size_t Cr, size_t S, size_t D, size_t c0, bl_nuts_output *out)
 {
@@ -214,6 +245,16 @@ static void unpack_block(const char *blk, size_t Cr, size_t S, size_t D, size_t 
     if (out->step_size) memcpy(out->step_size + c0, blk + L.eps, Cr * 4);
     if (out->inv_mass) memcpy(out->inv_mass + c0 * D, blk + L.minv, Cr * D * 4);
     if (out->n_leapfrog) memcpy(out->n_leapfrog + c0 * 2, blk + L.nleap, Cr * 16);
+}
+
+static void unpack_gathered(const char *host, int world, const int32_t *chains_per_rank, const std::vector<size_t> &boff, size_t S, size_t D,
+                            bl_nuts_output *out)
+{
+    size_t c0 = 0;
+    for (int r = 0; r < world; r++) {
+        unpack_block(host + boff[r], (size_t)chains_per_rank[r], S, D, c0, out);
+        c0 += (size_t)chains_per_rank[r];
+    }
 }
 
 extern "C" int bl_gather_draws(bl_comm *const *comms, bl_dataset *const *dss, int n_local, const int32_t *chains_per_rank,
@@ -237,14 +278,9 @@ extern "C" int bl_gather_draws(bl_comm *const *comms, bl_dataset *const *dss, in
             return bl_fail(BL_ERR_INVALID, "bl_gather_draws: rank %d ran %d chains, chains_per_rank says %d", c->rank, ds->C, chains_per_rank[c->rank]);
     }
     // every rank's block size follows from its chain count (the same carve as the launch), so nothing is negotiated
-    const size_t Sa = S > 0 ? S : 1;
-    std::vector<size_t> boff(world + 1, 0);
+    std::vector<size_t> boff;
     bool equal = true;
-    for (int r = 0; r < world; r++) {
-        if (chains_per_rank[r] <= 0) return bl_fail(BL_ERR_INVALID, "bl_gather_draws: rank %d has no chains", r);
-        boff[r + 1] = boff[r] + result_layout((size_t)chains_per_rank[r], Sa, D).end;
-        equal = equal && chains_per_rank[r] == chains_per_rank[0];
-    }
+    if (int rc = gather_block_offsets(world, chains_per_rank, S, D, boff, &equal)) return rc;
     for (int i = 0; i < n_local; i++) {
         bl_comm *c = comms[i];
         BL_HIP(hipSetDevice(c->device));
@@ -258,18 +294,26 @@ extern "C" int bl_gather_draws(bl_comm *const *comms, bl_dataset *const *dss, in
     }
     // ONE collective: ncclAllGather of the blocks (equal chain counts: the usual case), or its "v" form as grouped
     // broadcasts when the chains do not divide evenly
+    // (an error inside the group must not leave this thread in RCCL's group mode: remember the first one, always close the group)
     BL_NCCL(api, api->GroupStart());
-    for (int i = 0; i < n_local; i++) {
+    ncclResult_t first_err = ncclSuccess;
+    const char *first_what = "";
+    for (int i = 0; i < n_local && first_err == ncclSuccess; i++) {
         bl_comm *c = comms[i];
         const char *send = (const char *)dss[i]->d_run;
         if (equal) {
-            BL_NCCL(api, api->AllGather(send, c->d_recv, boff[1], ncclChar, c->comm, c->stream));
+            first_err = api->AllGather(send, c->d_recv, boff[1], ncclChar, c->comm, c->stream);
+            first_what = "ncclAllGather";
         } else {
-            for (int r = 0; r < world; r++)
-                BL_NCCL(api, api->Broadcast(send, (char *)c->d_recv + boff[r], boff[r + 1] - boff[r], ncclChar, r, c->comm, c->stream));
+            for (int r = 0; r < world && first_err == ncclSuccess; r++) {
+                first_err = api->Broadcast(send, (char *)c->d_recv + boff[r], boff[r + 1] - boff[r], ncclChar, r, c->comm, c->stream);
+                first_what = "ncclBroadcast";
+            }
         }
     }
-    BL_NCCL(api, api->GroupEnd());
+    const ncclResult_t end_err = api->GroupEnd();
+    if (first_err != ncclSuccess) return bl_fail(BL_ERR_COMM, "%s failed: %s", first_what, api->GetErrorString(first_err));
+    if (end_err != ncclSuccess) return bl_fail(BL_ERR_COMM, "ncclGroupEnd failed: %s", api->GetErrorString(end_err));
     for (int i = 0; i < n_local; i++) {
         BL_HIP(hipSetDevice(comms[i]->device));
         BL_HIP(hipStreamSynchronize(comms[i]->stream));
@@ -280,11 +324,22 @@ extern "C" int bl_gather_draws(bl_comm *const *comms, bl_dataset *const *dss, in
         std::vector<char> host(boff[world]);
         BL_HIP(hipSetDevice(c->device));
         BL_HIP(hipMemcpy(host.data(), c->d_recv, boff[world], hipMemcpyDeviceToHost));
-        size_t c0 = 0;
-        for (int r = 0; r < world; r++) {
-            unpack_block(host.data() + boff[r], (size_t)chains_per_rank[r], S, D, c0, out);
-            c0 += (size_t)chains_per_rank[r];
-        }
+        unpack_gathered(host.data(), world, chains_per_rank, boff, S, D, out);
     }
+    return BL_OK;
+}
+
+// The unpacking of a gathered buffer alone (host memory in, host arrays out; no GPU, no RCCL): `gathered` holds the
+// world blocks back to back, as bl_gather_draws receives them.
+extern "C" int bl_gather_unpack(const void *gathered, uint64_t gathered_bytes, int world, const int32_t *chains_per_rank,
+                                int num_samples, int D, bl_nuts_output *out)
+{
+    if (!gathered || world <= 0 || !chains_per_rank || num_samples < 0 || D <= 0 || !out) return bl_fail(BL_ERR_INVALID, "bl_gather_unpack: bad argument");
+    std::vector<size_t> boff;
+    bool equal = true;
+    if (int rc = gather_block_offsets(world, chains_per_rank, (size_t)num_samples, (size_t)D, boff, &equal)) return rc;
+    if ((uint64_t)boff[world] != gathered_bytes)
+        return bl_fail(BL_ERR_INVALID, "bl_gather_unpack: %llu bytes given, the %d blocks take %llu", (unsigned long long)gathered_bytes, world, (unsigned long long)boff[world]);
+    unpack_gathered((const char *)gathered, world, chains_per_rank, boff, (size_t)num_samples, (size_t)D, out);
     return BL_OK;
 }

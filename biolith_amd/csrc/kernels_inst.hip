@@ -26,15 +26,14 @@ static int bl_launch(K kernel, const P *p, int grid, int threads, int lds_bytes,
 }
 
 // Instantiations (CW = compute waves per workgroup, chosen by the host's choose_geometry):
-//   occu, LDS-staged: CW 3 and 4;  occu, HBM rows: CW 4;  occu_rn: CW 3;  false positives, occu_cop, nmixture: CW 3 and 4.
+//   occu, LDS-staged: CW 3 and 4;  occu, HBM rows: CW 4;  occu_rn: CW 7 (BL_CWAVES_RN);  false positives, occu_cop, nmixture: CW 3 and 4.
 #define BL_PICK(KERNEL, P, LDS, MODEL, CW) bl_launch(KERNEL<BL_KS, BL_KO, LDS, MODEL, CW>, P, grid, 64 * (CW + 1), lds_bytes, stream)
 
 extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int grid, int lds_bytes, int staged, int model, hipStream_t stream)
 {
-    if (model == 1) { // occu_rn: the smaller per-lane table (model id 5) whenever max_abundance allows
+    if (model == 1) { // occu_rn
 #if BL_HAVE_RN
-        if (staged && p->ncw == 3 && p->max_abundance < BL_RN_NB_SMALL) return BL_PICK(bl_nuts_kernel, p, true, 5, 3);
-        if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 1, 3);
+        if (staged && p->ncw == BL_CWAVES_RN) return BL_PICK(bl_nuts_kernel, p, true, 1, BL_CWAVES_RN);
 #endif
         return (int)hipErrorNotSupported;
     }
@@ -69,8 +68,7 @@ extern "C" int BL_NAME(bl_launch_logp, BL_KS, BL_KO)(const BlLogpParams *p, int 
 {
     if (model == 1) {
 #if BL_HAVE_RN
-        if (staged && p->ncw == 3 && p->max_abundance < BL_RN_NB_SMALL) return BL_PICK(bl_logp_kernel, p, true, 5, 3);
-        if (staged && p->ncw == 3) return BL_PICK(bl_logp_kernel, p, true, 1, 3);
+        if (staged && p->ncw == BL_CWAVES_RN) return BL_PICK(bl_logp_kernel, p, true, 1, BL_CWAVES_RN);
 #endif
         return (int)hipErrorNotSupported;
     }

@@ -103,6 +103,7 @@ struct BlNutsParams {
     int fp_mode;                   // MODEL 2 / 3: 0 none, 1 = rate acts on every site ("constant"), 2 = on unoccupied sites only
     int max_depth;
     int max_abundance;             // occu_rn only (occu_rn.py:26)
+    int rn_off;                    // occu_rn only: byte offset in LDS of its scratch (lgamma table + wave-private tables), behind the records
     int allow_local;               // 0: always use the placement-independent exchange
     int poll_sleep;                // s_sleep(1) repeats between re-polls (fabric form)
     int first_delay;               // s_sleep(1) repeats between publishing and the first poll
@@ -222,7 +223,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         grows = p.rows + s0;
         ld = p.n_stride;
     }
-    if constexpr (BL_RN_QUAD && (MODEL == 1 || MODEL == 5)) bl_rn_fill_lgamma(p.max_abundance, 64 * (CW + 1)); // (the barrier below publishes it)
+    if constexpr (MODEL == 1) bl_rn_fill_lgamma(p.rn_off, p.max_abundance, 64 * (CW + 1)); // (the barrier below publishes it)
     float *sh_coef = bl_lds_f(BL_OFF_COEF);
     int *sh_flag = bl_lds_i(BL_OFF_FLAG);
     float *sh_ckr = bl_lds_f(BL_OFF_CKR), *sh_ckrs = bl_lds_f(BL_OFF_CKRS);
@@ -428,7 +429,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     // Speculative overlap pays while a dropped evaluation is cheap: the LDS-staged occu / false-positive / occu_cop
     // forms (<= ~3 site pairs per lane) and nmixture (measured: 8.0 -> 7.6 us).  occu_rn's evaluation (sums over N) dominates its tick and the HBM-row form serves huge
     // slices: there the decisions are taken right after the exchange and only the bookkeeping overlaps.
-    constexpr bool SPEC = LDS && MODEL != 1 && MODEL != 5;
+    constexpr bool SPEC = LDS && MODEL != 1;
     auto decide = [&]() {
         have_pending = false;
         const double acc = p_acc;
@@ -596,7 +597,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #ifdef BL_STAMPS
             const long long st_a0 = (long long)clock64();
 #endif
-            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, p.n_stride, nsp, p.sp_lds);
+            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, p.n_stride, nsp, p.sp_lds, p.rn_off);
 #ifdef BL_STAMPS
             st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
 #endif
@@ -853,7 +854,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     }
     if (cold->dbg && chain == 0 && member == 0 && tid == 64) { // first compute wave: site-evaluation passes and their cycles
         cold->dbg[20] = st_sub[4]; cold->dbg[21] = st_sub[5];
-        if constexpr (MODEL == 1 || MODEL == 5) for (int i = 0; i < 8; i++) cold->dbg[22 + i] = bl_rn_dbg[i];
+        if constexpr (MODEL == 1) for (int i = 0; i < 8; i++) cold->dbg[22 + i] = bl_rn_dbg[i];
     }
 #endif
 }

@@ -16,11 +16,10 @@
 // 3 -> every wave has a SIMD to itself, so the control wave's decisions, which overlap the site
 //      evaluation, do not steal issue slots from a compute wave, and one wave per SIMD may use the
 //      whole 512-entry register file (the latency optimum while one site pair per lane still fits:
-//      N <= 384 sites per workgroup); occu_rn always runs this form (128-entry per-lane table);
-// 4 -> all four SIMDs evaluate sites (larger slices, where the evaluation dominates the tick).
-#define BL_CWAVES_MAX 4
-#define BL_CWAVES_RN 3
-#define BL_THREADS_RN (BL_CWAVES_RN * 64 + 64)
+//      N <= 384 sites per workgroup);
+// 4 -> all four SIMDs evaluate sites (larger slices, where the evaluation dominates the tick);
+// BL_CWAVES_RN -> occu_rn (rn_device.hpp): several waves per SIMD hide each other's LDS / exp / log / rcp latencies.
+#define BL_CWAVES_MAX 4   // (of the kernels that sample several species jointly: sizes their partial table)
 #define BL_DIR_STREAM 62
 #define BL_MAX_DEPTH 10
 #define BL_NSTREAM 64
@@ -29,13 +28,13 @@
 // ---- dynamic LDS carve (bytes; every offset a multiple of 16: guide G17) ----
 #define BL_OFF_COEF 0       // 64 floats : coefficients being evaluated, PADDED layout (beta[0..KS], alpha[0..KO])
 #define BL_OFF_FLAG 256     // 4 ints    : loop control
-#define BL_OFF_PART 272     // <= 4 compute waves x BL_PART_STRIDE floats (room for 8) : per-wave partial sums (padded layout + log-lik)
+#define BL_OFF_PART 272     // <= 16 compute waves x BL_PART_STRIDE floats : per-wave partial sums (padded layout + log-lik)
 #define BL_PART_STRIDE 48
-#define BL_OFF_CKR 1808     // 10 x 64 floats: r checkpoints      (numpyro r_ckpts)
-#define BL_OFF_CKRS 4368    // 10 x 64 floats: r_sum checkpoints  (numpyro r_sum_ckpts)
-#define BL_OFF_SV 6928      // 16 x 64 floats: control wave's rarely-touched per-dimension state (tree edges, proposal, ...)
-#define BL_OFF_SS 11024     // 256 bytes     : control wave's rarely-touched scalars (BlCtlScalars)
-#define BL_OFF_DATA 11280   // staged site records start here
+#define BL_OFF_CKR 3344     // 10 x 64 floats: r checkpoints      (numpyro r_ckpts)
+#define BL_OFF_CKRS 5904    // 10 x 64 floats: r_sum checkpoints  (numpyro r_sum_ckpts)
+#define BL_OFF_SV 8464      // 16 x 64 floats: control wave's rarely-touched per-dimension state (tree edges, proposal, ...)
+#define BL_OFF_SS 12560     // 256 bytes     : control wave's rarely-touched scalars (BlCtlScalars)
+#define BL_OFF_DATA 12816   // staged site records start here
 #define BL_LDS_TOTAL 163840
 
 extern __shared__ __attribute__((aligned(16))) unsigned char bl_smem_raw[];
@@ -765,10 +764,7 @@ __device__ __forceinline__ void bl_eval_sites_cop(int ct, int pstride, int cnt, 
 
 
 // lgamma(n + 1) for n < 128 (occu_rn, nmixture)
-#define BL_RN_NB 128 // upper bound of the per-lane table over N (max_abundance <= 127)
-#ifndef BL_RN_QUAD
-#define BL_RN_QUAD 0 // occu_rn: 1 = four lanes per site (bl_eval_sites_rn_quad: parity-green, not yet faster -- see its header), 0 = one lane per site
-#endif
+#define BL_RN_NB 128 // entries of the table: max_abundance <= 127
 __device__ constexpr float BL_LGAMMA1P[128] = {0.000000000e+00f, 0.000000000e+00f, 6.931471806e-01f, 1.791759469e+00f, 3.178053830e+00f, 4.787491743e+00f, 6.579251212e+00f, 8.525161361e+00f, 1.060460290e+01f, 1.280182748e+01f, 1.510441257e+01f, 1.750230785e+01f, 1.998721450e+01f, 2.255216385e+01f, 2.519122118e+01f, 2.789927138e+01f, 3.067186011e+01f, 3.350507345e+01f, 3.639544521e+01f, 3.933988419e+01f, 4.233561646e+01f, 4.538013890e+01f, 4.847118135e+01f, 5.160667557e+01f, 5.478472940e+01f, 5.800360522e+01f, 6.126170176e+01f, 6.455753863e+01f, 6.788974314e+01f, 7.125703897e+01f, 7.465823635e+01f, 7.809222355e+01f, 8.155795946e+01f, 8.505446702e+01f, 8.858082754e+01f, 9.213617560e+01f, 9.571969454e+01f, 9.933061245e+01f, 1.029681986e+02f, 1.066317603e+02f, 1.103206397e+02f, 1.140342118e+02f, 1.177718814e+02f, 1.215330815e+02f, 1.253172711e+02f, 1.291239336e+02f, 1.329525750e+02f, 1.368027226e+02f, 1.406739236e+02f, 1.445657439e+02f, 1.484777670e+02f, 1.524095926e+02f, 1.563608363e+02f, 1.603311282e+02f, 1.643201123e+02f, 1.683274454e+02f, 1.723527971e+02f, 1.763958484e+02f, 1.804562914e+02f, 1.845338289e+02f, 1.886281734e+02f, 1.927390473e+02f, 1.968661817e+02f, 2.010093164e+02f, 2.051681995e+02f, 2.093425868e+02f, 2.135322415e+02f, 2.177369341e+02f, 2.219564418e+02f, 2.261905483e+02f, 2.304390436e+02f, 2.347017234e+02f, 2.389783896e+02f, 2.432688490e+02f, 2.475729141e+02f, 2.518904022e+02f, 2.562211356e+02f, 2.605649410e+02f, 2.649216498e+02f, 2.692910977e+02f, 2.736731243e+02f, 2.780675734e+02f, 2.824742927e+02f, 2.868931333e+02f, 2.913239501e+02f, 2.957666014e+02f, 3.002209486e+02f, 3.046868568e+02f, 3.091641936e+02f, 3.136528299e+02f, 3.181526396e+02f, 3.226634991e+02f, 3.271852877e+02f, 3.317178872e+02f, 3.362611820e+02f, 3.408150589e+02f, 3.453794071e+02f, 3.499541180e+02f, 3.545390855e+02f, 3.591342054e+02f, 3.637393756e+02f, 3.683544961e+02f, 3.729794689e+02f, 3.776141979e+02f, 3.822585888e+02f, 3.869125491e+02f, 3.915759882e+02f, 3.962488171e+02f, 4.009309483e+02f, 4.056222962e+02f, 4.103227765e+02f, 4.150323067e+02f, 4.197508056e+02f, 4.244781934e+02f, 4.292143919e+02f, 4.339593240e+02f, 4.387129142e+02f, 4.434750881e+02f, 4.482457727e+02f, 4.530248962e+02f, 4.578123880e+02f, 4.626081785e+02f, 4.674121996e+02f, 4.722243839e+02f, 4.770446655e+02f, 4.818729792e+02f, 4.867092611e+02f, 4.915534482e+02f};
 
 // --------------------------------------------------------------- N-mixture (nmixture, MODEL 4) ----
@@ -901,636 +897,17 @@ __device__ __forceinline__ void bl_eval_sites_nmix(int ct, int pstride, int cnt,
 }
 
 
-// ---------------------------------------------------------------- Royle-Nichols (occu_rn) ----
-// biolith/models/occu_rn.py:179-222 + utils/distributions.py:31-40 with N summed out:
-//   lambda = exp(eta);  pi_n = Poisson(lambda)(n) renormalised over n <= K   (K = max_abundance)
-//   P(y=1 | n) = 1 - q^n = r * b_n ,  q = 1 - r ,  b_n = 1 + q + ... + q^(n-1)  (b_n = b_(n-1) q + 1:
-//   no cancellation);  non-detections contribute n log q: rank-1 in n.
-//   l = logsumexp_n [ n (eta + sum_nondet log q) - lgamma(n+1) + sum_det (log r + log b_n) ] - log Z
-// One site per lane.  LP[n] = sum over detection visits of log2 b_n lives in registers: every
-// n-loop is fully unrolled so the array is indexed statically; lgamma(n+1) folds to literals.
-// The gradient w.r.t. nu_j of a detection visit, sum_n w_n (q - q r b'_n / b_n), reuses the
-// posterior weights W[n] (stored over LP) in a second pass per detection: no per-visit state.
+#include "rn_device.hpp" // occu_rn: work-proportional site evaluation (items of 8 terms of the sum over N)
 
-// wave-uniform maximum of a non-negative per-lane integer (inactive lanes count as 0)
-__device__ __forceinline__ int bl_wave_max_u(int x)
-{
-#define BL_MAXSTEP(ctrl, rm) x = max(x, __builtin_amdgcn_update_dpp(0, x, ctrl, rm, 0xF, false));
-    BL_MAXSTEP(0xB1, 0xF) BL_MAXSTEP(0x4E, 0xF) BL_MAXSTEP(0x141, 0xF) BL_MAXSTEP(0x140, 0xF)
-    BL_MAXSTEP(0x142, 0xA) BL_MAXSTEP(0x143, 0xC)
-#undef BL_MAXSTEP
-    return __builtin_amdgcn_readlane(x, 63);
-}
-
-// lower bound of max_n (n a - lgamma(n+1)) over 1 <= n <= K: evaluate at the Poisson mode with
-// lgamma(n+1) <= (n + 1/2) ln n - n + 1  (n >= 1)
-__device__ __forceinline__ float bl_rn_mode_lb(float a, float K)
-{
-    const float n1 = fminf(fmaxf(floorf(bl_exp_f(a)), 1.0f), K);
-    return fmaf(n1, a, -(fmaf(n1 + 0.5f, BL_LN2 * __builtin_amdgcn_logf(n1), 1.0f - n1)));
-}
-
-// n = 1 .. KB rounded up to a whole block of 4 (< NB, the enclosing function's table size), fully unrolled, each block
-// under a wave-uniform guard: indices into the per-lane table stay static, blocks beyond the cutoff are skipped by a
-// scalar branch, and there is NO guard per n (a hundred loop-invariant lane masks would be hoisted out of the visit loops and
-// spilled).  The cutoffs are numerical (terms below e^-20 of the sum), so up to three extra terms are harmless; the one
-// bound that is part of the model, n <= max_abundance, is applied where a term's weight is formed (bl_rn_lgamma_k).
-#define BL_RN_LOOP_BEGIN(KB)                                                            \
-    _Pragma("unroll") for (int nb_ = 1; nb_ < NB; nb_ += 4)                             \
-        if (nb_ <= (KB)) {                                                              \
-            _Pragma("unroll") for (int n = nb_; n < nb_ + 4; n++)                       \
-                if (n < NB) {
-#define BL_RN_LOOP_END }}
-// lgamma(n+1), or a huge value for n > max_abundance so that the term's weight underflows to exactly 0.  Kv holds
-// max_abundance in a VECTOR register on purpose: a scalar compare per n would again become a hoisted, spilled mask.
-// The empty asm makes Kv opaque at every use: left alone, the compiler builds the whole masked table up front, once
-// per evaluation (NB x compare + select + register copy), although only the terms up to the cutoff are ever used.
-#define bl_rn_lgamma_k(n) ([&]() -> float { asm volatile("" : "+v"(Kv)); return ((float)(n) <= Kv) ? BL_LGAMMA1P[n] : 3.0e38f; }())
-// Two instantiations (chosen by the host from max_abundance), both free of scratch spills:
-//   NB = 128, GC = 1: max_abundance <= 127;   NB = 104, GC = 2: max_abundance <= 103 (the reference default is 100) --
-// the 16 table registers saved pay for a second gradient recursion running beside the first.
-#define BL_RN_NB_SMALL 104
-#define BL_RN_GA 10 // visits whose b_n recursions run side by side in pass A1 (one log per group and n)
-#define BL_RN_G0 5  // visits evaluated side by side in pass A0
-
-#ifdef BL_STAMPS
-static __device__ long long bl_rn_dbg[16];
-#define BL_RN_T(i) { const long long now_ = (long long)clock64(); if (st_on) bl_rn_dbg[i] += now_ - st_prev; st_prev = now_; }
-#else
-#define BL_RN_T(i)
-#endif
-template <int KS, int KO, int CT, int NB, int BL_RN_GC>
-__device__ __forceinline__ void bl_eval_sites_rn(int ct, int pstride, int cnt, int T, int J, int K,
-                                                 const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
-                                                 float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
-{
-    constexpr int XQ = (KS + 3) & ~3;
-    const int pb = bl_period_block(J, KO);
-    const float *data = bl_lds_f(BL_OFF_DATA);
-    const float LOG_TINY = -87.33654475f;
-    // Every lane of a wave stays active through the loop (the cutoffs below are wave-level
-    // reductions): lanes beyond the slice evaluate the last site again and are masked out.
-#ifdef BL_STAMPS
-    const bool st_on = blockIdx.x == 0 && threadIdx.x == 64;
-    long long st_prev = (long long)clock64();
-#endif
-    for (int i0 = 0; i0 < cnt; i0 += CT) {
-        if (i0 + (ct & ~63) >= cnt) continue; // wave-uniform: this wave has no site in this round
-        const int i = min(i0 + ct, cnt - 1);
-        const float live = (i0 + ct < cnt) ? 1.0f : 0.0f;
-        const float *rec = data + (size_t)(i >> 1) * pstride + (i & 1); // element e of this site: rec[2 e]
-        float x[KS > 0 ? KS : 1];
-        float eta = beta[0];
-#pragma unroll
-        for (int k = 0; k < KS; k++) {
-            x[k] = rec[2 * k];
-            eta = fmaf(x[k], beta[k + 1], eta);
-        }
-        float ll_s = 0.0f, ga_s[KO + 1];
-#pragma unroll
-        for (int k = 0; k <= KO; k++) ga_s[k] = 0.0f;
-        // Truncated-Poisson prior, p_n = n eta - lgamma(n+1), n <= K.  Its sums ride in the one scan over n that each
-        // period needs anyway (below); here only the shift of those sums: an upper bound of max_n p_n that is tight
-        // to a few nats -- lambda = e^eta while lambda <= K (Stirling: p_n <= lambda - 0.9), else p_K (p_n still rising at K).
-        float Kv = (float)K;
-        asm volatile("v_mov_b32 %0, %0" : "+v"(Kv));
-        const float lam = bl_exp_f(fminf(eta, 80.0f));
-        const float mzs = lam <= (float)K ? lam : fmaf((float)K, eta, -BL_LGAMMA1P[K]);
-        const float mz_lb = fmaxf(bl_rn_mode_lb(eta, (float)K), 0.0f); // lower bound of max_n p_n (p_0 = 0)
-        float deta = 0.0f;
-        BL_RN_T(0)
-        for (int t = 0; t < T; t++) {
-            const float *pv = rec + 2 * (XQ + t * pb);
-            float cnon = 0.0f, clr = 0.0f, ndet = 0.0f;
-            float lqmin = 0.0f; // smallest log q over the non-detections
-            float Rv[KO + 1];
-#pragma unroll
-            for (int k = 0; k <= KO; k++) Rv[k] = 0.0f;
-            // ---- A0: visits, no sum over n yet.  u = c nu;  log sigma(u) = log r (detection) or log q (non-detection) ----
-            // BL_RN_G0 visits side by side and branch-free: one wave per SIMD has nothing else to hide the dependent
-            // latencies (LDS read -> dot product -> exp -> log / rcp) behind.  A visit past J re-reads the last one as masked.
-            for (int j0 = 0; j0 < J; j0 += BL_RN_G0) {
-#pragma unroll
-                for (int g = 0; g < BL_RN_G0; g++) {
-                    const int j = min(j0 + g, J - 1);
-                    float w[KO + 1];
-#pragma unroll
-                    for (int k = 0; k <= KO; k++) w[k] = pv[2 * (j * (KO + 1) + k)];
-                    const float c = (j0 + g < J) ? w[0] : 0.0f;
-                    float u = w[0] * alpha[0];
-#pragma unroll
-                    for (int k = 1; k <= KO; k++) u = fmaf(w[k], alpha[k], u);
-                    const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E), op = 1.0f + e;
-                    const float logsig = fminf(u, 0.0f) - BL_LN2 * __builtin_amdgcn_logf(op);
-                    const float ld = c > 0.0f ? logsig : 0.0f, ln = c < 0.0f ? logsig : 0.0f;
-                    const float sm = c < 0.0f ? (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(op) : 0.0f; // sigma(-u)
-                    clr += ld;
-                    ndet += c > 0.0f ? 1.0f : 0.0f;
-                    cnon += ln;
-                    lqmin = fminf(lqmin, ln);
-                    // d/dnu of n log q is -n r: rank-1; dnu * (1, w) = r E[n] * (c, c w)
-#pragma unroll
-                    for (int k = 0; k <= KO; k++) Rv[k] = fmaf(sm, w[k], Rv[k]);
-                }
-            }
-            BL_RN_T(1)
-            const float a = eta + cnon;
-            const float term0 = ndet * LOG_TINY; // n = 0: detections impossible -> numpyro's clamp tiny
-            // Every term_n is bounded above by the Poisson part p_n = n eta - lgamma(n+1) plus the non-detections' share
-            // (the detections' log r + log b_n = log(1 - q^n) is <= 0), and the non-detections' floored sum (see below)
-            // is n cnon up to n* = FL / lqmin, where the first visit floors, and at most n* cnon beyond.  The best term
-            // is at least m_lb = max(term_0, term_1, term at the mode of n a - lgamma(n+1), with log b >= 0): keep n up
-            // to the last  p_n + cnon min(n, n*) >= m_lb - 20  (what is dropped is below 2e-9 of the sum, per term).
-            const float m_lb = fmaxf(fmaxf(term0, a + clr), bl_rn_mode_lb(a, (float)K) + clr);
-            //
-            // numpyro floors a non-detection's log(1 - P) = n log q at log(eps_f32) = -15.94 (Bernoulli probabilities are
-            // clamped to [tiny, 1 - eps]): the visit's term is max(n log q_j, FL).  The sums below carry the un-floored
-            // n log q_j (rank one in n: it rides in `a`) and add the difference only for visits where the floor can be
-            // reached by a term that still matters.  Visit j is floored for n > FL / log q_j; the first visit to floor does
-            // so at n* = FL / lqmin, and from there on the floored sum (non-increasing in n) is <= n* cnon.  With
-            // log b_n <= log n per detection and Stirling's lgamma(n+1) >= n ln n - n + ln(2 pi n)/2, every term beyond
-            // t0 = FL / log q_j is <= clr + n* cnon + x(t),  x(t) = t (eta + 1 - ln t) + (ndet - 1/2) ln t - ln(2 pi)/2,
-            // concave in t: if x is already falling at t0 its supremum over t >= t0 is x(t0), and the floor of visit j
-            // matters only if that is within e^-17 of m_lb (below half an ulp of the float32 sum over n).  Where x is
-            // still rising at t0 (the floor starts below the Poisson mode) the visit takes the floor unconditionally.
-            const float FL = -15.942385f; // log(finfo(float32).eps)
-            const float thr_f = lqmin < 0.0f ? m_lb - clr - 17.0f - FL * cnon * __builtin_amdgcn_rcpf(lqmin) : 3.0e38f;
-            auto floor_matters = [&](float lq) -> bool { // lq = log q_j <= 0 of a non-detection (0: not one)
-                const float t0 = fmaxf(FL * __builtin_amdgcn_rcpf(fminf(lq, -1.0e-30f)), 1.0f);
-                const float lt = BL_LN2 * __builtin_amdgcn_logf(t0);
-                const float rising = eta - lt + (ndet - 0.5f) * __builtin_amdgcn_rcpf(t0);
-                const float xt = fmaf(t0, eta + 1.0f - lt, fmaf(ndet - 0.5f, lt, -0.9189385f));
-                return lq < 0.0f && t0 < (float)K && (rising > 0.0f || xt >= thr_f);
-            };
-            const float nstar = lqmin < 0.0f ? FL * __builtin_amdgcn_rcpf(lqmin) : 0.0f; // cnon = 0 when there is none
-            // Loose cutoff Kl (wave-uniform): both the prior sum and the posterior sum can drop every n with
-            // p_n < thr = min(mz_lb, m_lb) - 20.  For n > lambda, p_n <= lambda - 0.9 - (n - lambda)^2 / (n + lambda)
-            // (Stirling, and ln x >= 2 (x - 1) / (x + 1) for x >= 1), which is below thr once
-            // n - lambda > (Tq + sqrt(Tq^2 + 8 lambda Tq)) / 2,  Tq = lambda - 0.9 - thr > 0.
-            const float Tq = lam - 0.9f - (fminf(mz_lb, m_lb) - 20.0f);
-            const float dmax = 0.5f * (Tq + __builtin_amdgcn_sqrtf(fmaf(Tq, Tq, 8.0f * lam * Tq)));
-            const int Kl = min(K, bl_wave_max_u((int)fminf(lam + dmax + 2.0f, 1.0e6f)));
-            // ---- one scan over n <= Kl: prior sums, the posterior cutoff nw, and the table's starting values ----
-            // LP[n] (log2 units) starts as the part of term_n that needs no recursion: p_n + n cnon + clr; pass A1 adds the
-            // detections' log2 b_n, A1b the floor corrections.  n > K: lgamma is replaced by 3e38 and LP[n] = -inf (weight 0).
-            float LP[NB];
-            float sz = bl_exp_f(-mzs), b1 = 0.0f; // n = 0
-            int nw = 1;
-            BL_RN_LOOP_BEGIN(Kl)
-                const float pn = fmaf((float)n, eta, -bl_rn_lgamma_k(n));
-                const float e = bl_exp_f(pn - mzs);
-                sz += e;
-                b1 = fmaf((float)n, e, b1);
-                nw = (fmaf(cnon, fminf((float)n, nstar), pn) >= m_lb - 20.0f) ? n : nw;
-                LP[n] = (pn + fmaf((float)n, cnon, clr)) * BL_LOG2E;
-            BL_RN_LOOP_END
-            const float log_z = mzs + BL_LN2 * __builtin_amdgcn_logf(sz);
-            const float en_prior = b1 * __builtin_amdgcn_rcpf(sz);
-            const int Kw = min(Kl, bl_wave_max_u(nw));
-            BL_RN_T(2)
-            // ---- A1: LP[n] += sum over detection visits of log2 b_n ----
-            // Visits are taken BL_RN_GA at a time with their b_n recursions side by side (independent chains keep the
-            // VALU busy; one wave per SIMD has no other wave to hide latencies) and ONE log per n for the group:
-            // sum_j log b_jn = log prod_j b_jn (b <= n <= 127, so ten factors stay far inside float32).  A
-            // non-detection visit gets q = 0, hence b = 1: its factor is 1 and it needs no mask.
-            if (__any(ndet > 0.0f)) {
-                for (int j0 = 0; j0 < J; j0 += BL_RN_GA) {
-                    float q[BL_RN_GA];
-                    bool det = false;
-#pragma unroll
-                    for (int g = 0; g < BL_RN_GA; g++) {
-                        q[g] = 0.0f;
-                        if (j0 + g < J) { // wave-uniform
-                            const float *wv = pv + 2 * ((j0 + g) * (KO + 1));
-                            float u = wv[0] * alpha[0];
-#pragma unroll
-                            for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
-                            const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E);
-                            q[g] = wv[0] > 0.0f ? (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(1.0f + e) : 0.0f;
-                            det = det || wv[0] > 0.0f;
-                        }
-                    }
-                    if (!__any(det)) continue; // no lane of the wave has a detection in this group
-                    // visits in pairs (packed fma / mul), the product as a tree: five recursions, four multiplies and one
-                    // log per n instead of a chain of nine dependent multiplies behind the recursions
-                    static_assert(BL_RN_GA == 10, "the product tree below is written for five pairs");
-                    bl_f2 b2[5], q2[5];
-#pragma unroll
-                    for (int g = 0; g < 5; g++) { b2[g] = bl2(0.0f); q2[g] = bl_f2{q[2 * g], q[2 * g + 1]}; }
-                    BL_RN_LOOP_BEGIN(Kw)
-#pragma unroll
-                        for (int g = 0; g < 5; g++) b2[g] = bl_fma2(b2[g], q2[g], bl2(1.0f));
-                        const bl_f2 pp = ((b2[0] * b2[1]) * (b2[2] * b2[3])) * b2[4];
-                        LP[n] += __builtin_amdgcn_logf(pp.x * pp.y);
-                    BL_RN_LOOP_END
-                }
-            }
-            BL_RN_T(3)
-            // ---- A1b: visits whose floor matters somewhere in the wave: LP[n] += max(0, FL - n log q_j)  (log2 units) ----
-            unsigned long long floored = 0ull; // wave-uniform: bit j = visit j took the correction (j < 64)
-            // floor_matters is monotone in log q (a smaller t0 only raises the bound): a wave in which no site's smallest
-            // log q matters -- about half of them at the posterior -- skips the visit loop altogether.
-            const int Jf = __any(floor_matters(lqmin)) ? J : 0;
-            for (int j = 0; j < Jf; j++) {
-                const float *wv = pv + 2 * (j * (KO + 1));
-                float u = wv[0] * alpha[0];
-#pragma unroll
-                for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
-                const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E);
-                const float lq2 = wv[0] < 0.0f ? fminf(u, 0.0f) * BL_LOG2E - __builtin_amdgcn_logf(1.0f + e) : 0.0f;
-                if (!__any(floor_matters(BL_LN2 * lq2))) continue;
-                floored |= 1ull << (j & 63);
-                BL_RN_LOOP_BEGIN(Kw)
-                    LP[n] += fmaxf(fmaf(-(float)n, lq2, -23.0f), 0.0f); // log2(eps_f32) = -23
-                BL_RN_LOOP_END
-            }
-            BL_RN_T(4)
-            // ---- B: sum over n ----
-            float m = term0 * BL_LOG2E; // log2 units, like LP
-            BL_RN_LOOP_BEGIN(Kw)
-                m = fmaxf(m, LP[n]);
-            BL_RN_LOOP_END
-            const float t0 = __builtin_amdgcn_exp2f(fmaf(term0, BL_LOG2E, -m));
-            float s = t0, a1 = 0.0f;
-            BL_RN_LOOP_BEGIN(Kw)
-                const float wn = __builtin_amdgcn_exp2f(LP[n] - m);
-                LP[n] = wn; // unnormalised posterior weight of N = n
-                s += wn;
-                a1 = fmaf((float)n, wn, a1);
-            BL_RN_LOOP_END
-            BL_RN_T(5)
-            const float rs = __builtin_amdgcn_rcpf(s);
-            ll_s += BL_LN2 * (m + __builtin_amdgcn_logf(s)) - log_z;
-            const float en_post = a1 * rs;
-            deta += en_post - en_prior;
-#pragma unroll
-            for (int k = 0; k <= KO; k++) ga_s[k] = fmaf(en_post, Rv[k], ga_s[k]);
-            // floored visits: d/du max(n log sigma(u), FL) vanishes for the floored n -- take their n w_n back out
-            for (int j = 0; j < Jf; j++) {
-                if (!((floored >> (j & 63)) & 1ull)) continue;
-                const float *wv = pv + 2 * (j * (KO + 1));
-                float u = wv[0] * alpha[0];
-#pragma unroll
-                for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
-                const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E), op = 1.0f + e;
-                const bool non = wv[0] < 0.0f;
-                const float lq2 = non ? fminf(u, 0.0f) * BL_LOG2E - __builtin_amdgcn_logf(op) : 0.0f;
-                const float sm = non ? (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(op) : 0.0f; // sigma(-u)
-                float hf = 0.0f;
-                BL_RN_LOOP_BEGIN(Kw)
-                    hf += ((float)n * lq2 < -23.0f) ? (float)n * LP[n] : 0.0f;
-                BL_RN_LOOP_END
-                const float dnu = -sm * hf * rs;
-#pragma unroll
-                for (int k = 0; k <= KO; k++) ga_s[k] = fmaf(dnu, wv[2 * k], ga_s[k]);
-            }
-            BL_RN_T(6)
-            // ---- C: detection visits' d/dnu = sum_n w_n (q - q r b'_n / b_n),  b'_n = b'_(n-1) q + b_(n-1) ----
-            if (__any(ndet > 0.0f)) {
-                for (int j0 = 0; j0 < J; j0 += BL_RN_GC) {
-                    float q[BL_RN_GC], r[BL_RN_GC];
-                    bool det = false;
-#pragma unroll
-                    for (int g = 0; g < BL_RN_GC; g++) {
-                        q[g] = 0.0f; r[g] = 0.0f;
-                        if (j0 + g < J) {
-                            const float *wv = pv + 2 * ((j0 + g) * (KO + 1));
-                            float u = wv[0] * alpha[0];
-#pragma unroll
-                            for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
-                            const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E), rop = __builtin_amdgcn_rcpf(1.0f + e);
-                            const bool d = wv[0] > 0.0f;
-                            q[g] = d ? (u > 0.0f ? e : 1.0f) * rop : 0.0f;
-                            r[g] = (u > 0.0f ? 1.0f : e) * rop;
-                            det = det || d;
-                        }
-                    }
-                    if (!__any(det)) continue;
-                    float b[BL_RN_GC], bp[BL_RN_GC], h[BL_RN_GC];
-#pragma unroll
-                    for (int g = 0; g < BL_RN_GC; g++) { b[g] = 0.0f; bp[g] = 0.0f; h[g] = 0.0f; }
-                    BL_RN_LOOP_BEGIN(Kw)
-                        const float wn = LP[n];
-#pragma unroll
-                        for (int g = 0; g < BL_RN_GC; g++) {
-                            bp[g] = fmaf(bp[g], q[g], b[g]);
-                            b[g] = fmaf(b[g], q[g], 1.0f);
-                            h[g] = fmaf(wn * bp[g], __builtin_amdgcn_rcpf(b[g]), h[g]);
-                        }
-                    BL_RN_LOOP_END
-#pragma unroll
-                    for (int g = 0; g < BL_RN_GC; g++) {
-                        if (j0 + g < J) {
-                            const float *wv = pv + 2 * ((j0 + g) * (KO + 1));
-                            const float dnu = q[g] * ((s - t0) - r[g] * h[g]) * rs; // q = 0 for a non-detection: no term
-#pragma unroll
-                            for (int k = 0; k <= KO; k++) ga_s[k] = fmaf(dnu, wv[2 * k], ga_s[k]);
-                        }
-                    }
-                }
-            }
-        }
-        BL_RN_T(7)
-        deta *= live;
-        ll = fmaf(live, ll_s, ll);
-#pragma unroll
-        for (int k = 0; k <= KO; k++) ga[k] = fmaf(live, ga_s[k], ga[k]);
-        gb[0] += deta;
-#pragma unroll
-        for (int k = 0; k < KS; k++) gb[k + 1] = fmaf(deta, x[k], gb[k + 1]);
-    }
-}
-
-// ---- occu_rn, FOUR LANES PER SITE: lane sub = 0..3 of a quad owns the terms n = sub + 4 m of its site's sum over N ----
-// The lane-per-site form above runs every lane to the wave's largest n-cutoff -- about 20-35 at BASELINE.json's config 4, where a
-// site needs n <= 7 on average -- and the slowest of a chain's waves sets the tick.  Here a site's n-range is spread over the four
-// lanes of a quad, so the per-lane trip count is a quarter of the (16-site) wave's cutoff, a wave makes four passes whose cutoffs
-// average out, and the table is 32 registers per lane:
-//   * the recursions advance four steps at once: b_(n+4) = b_n q^4 + b_4, b'_(n+4) = b'_n q^4 + 4 q^3 b_n + b'_4 (b_4 = 1+q+q^2+q^3,
-//     b'_4 = 1+2q+3q^2), started at b_sub, b'_sub -- no transcendental to start them;
-//   * lgamma(n + 1) comes from a 128-entry LDS table (BL_OFF_LGT, filled at kernel start; 3e38 beyond max_abundance);
-//   * the per-site sums (prior normaliser, posterior maximum / sums, E[n], each visit's gradient sum) are folded over the quad by
-//     two DPP steps; all four lanes then hold the site's totals and lane sub = 0 adds them to the wave's accumulators;
-//   * numpyro's floor of a non-detection (max(n log q, log eps)) is applied to every non-detection visit and every n -- at a
-//     quarter of the terms per lane that is cheaper than deciding where it matters.
-// Arithmetic as in bl_eval_sites_rn (same bounds, cutoffs and log2 units); the n = 0 term (detections impossible: numpyro's clamp
-// tiny) lives in lane 0's slot 0.
-// STATE (round 2): passes every occu_rn parity test (`make variant NAME=rnq EXTRA=-DBL_RN_QUAD=1`), but runs 53.6 us per leapfrog at
-// config 4 against 19.9 for the lane-per-site form: with <= 8 terms per lane the per-visit work (u, exp, log, rcp: ~25 instructions)
-// that each of the four loops over the visits repeats in all four lanes dominates -- 1 600 visit evaluations per 64 sites against
-// 30.  Next: evaluate each visit ONCE per pass in the lane j & 3 that already does so in A0, keep (c, q, r, log2 q, sigma(-u)) there and
-// broadcast them with quad_perm DPP in the later loops (5 moves instead of 25 instructions + 3 transcendentals); then the
-// instruction count per 64 sites is about the old form's, and what remains is the gain in balance (tick = slowest wave).
-#define BL_RN_MQ 32       // table slots per lane (n = sub + 4 m < 128)
-#define BL_OFF_LGT 1296   // 128 floats inside the partial-sum region (occu_rn uses 3 x 48 floats of it)
-__device__ __forceinline__ float bl_quad_sum(float x) { x += bl_dpp<0xB1, 0xF>(x); x += bl_dpp<0x4E, 0xF>(x); return x; }
-__device__ __forceinline__ float bl_quad_max(float x) { x = fmaxf(x, bl_dpp<0xB1, 0xF>(x)); return fmaxf(x, bl_dpp<0x4E, 0xF>(x)); }
-__device__ __forceinline__ float bl_quad_min(float x) { x = fminf(x, bl_dpp<0xB1, 0xF>(x)); return fminf(x, bl_dpp<0x4E, 0xF>(x)); }
-// fill the lgamma table (every thread of the workgroup calls this once, before the first evaluation and a barrier)
-__device__ __forceinline__ void bl_rn_fill_lgamma(int K, int nthreads)
-{
-    float *lgt = bl_lds_f(BL_OFF_LGT);
-    for (int n = threadIdx.x; n < 128; n += nthreads) lgt[n] = n <= K ? BL_LGAMMA1P[n] : 3.0e38f;
-}
-// slots m = 0 .. (slots needed for n <= KB), fully unrolled in blocks of two under a wave-uniform guard
-#define BL_RNQ_LOOP_BEGIN(KB)                                                           \
-    _Pragma("unroll") for (int mb_ = 0; mb_ < MQ; mb_ += 2)                             \
-        if (4 * mb_ <= (KB)) {                                                          \
-            _Pragma("unroll") for (int m = mb_; m < mb_ + 2; m++) {                     \
-                float sb_ = subf;                                                       \
-                asm volatile("" : "+v"(sb_)); /* opaque: n is formed where it is used, not hoisted out of the visit loops (32 x per loop) */ \
-                const float fn = sb_ + (float)(4 * m); (void)fn;
-#define BL_RNQ_LOOP_END }}
-
-template <int KS, int KO, int CT>
-__device__ __forceinline__ void bl_eval_sites_rn_quad(int ct, int pstride, int cnt, int T, int J, int K,
-                                                      const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
-                                                      float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
-{
-    constexpr int XQ = (KS + 3) & ~3;
-    constexpr int SPR = CT / 4; // sites per round of the workgroup's compute threads
-    const int pb = bl_period_block(J, KO);
-    const float *data = bl_lds_f(BL_OFF_DATA);
-    const float *lgt = bl_lds_f(BL_OFF_LGT);
-    const float LOG_TINY = -87.33654475f, FL2 = -23.0f; // log(tiny_f32); log2(eps_f32)
-    const int sub = ct & 3, qi = ct >> 2;
-    const float subf = (float)sub;
-    const float *lgs = lgt + sub;
-    for (int i0 = 0; i0 < cnt; i0 += SPR) {
-        if (i0 + ((ct & ~63) >> 2) >= cnt) continue; // wave-uniform: this wave has no site in this round
-        const int i = min(i0 + qi, cnt - 1);
-        const float live = (i0 + qi < cnt && sub == 0) ? 1.0f : 0.0f; // (one lane of the quad carries the site's totals)
-        const bool real = i0 + qi < cnt;                                // quads beyond the slice shadow the last site
-        const float *rec = data + (size_t)(i >> 1) * pstride + (i & 1); // element e of this site: rec[2 e]
-        float x[KS > 0 ? KS : 1];
-        float eta = beta[0];
-#pragma unroll
-        for (int k = 0; k < KS; k++) {
-            x[k] = rec[2 * k];
-            eta = fmaf(x[k], beta[k + 1], eta);
-        }
-        float ll_s = 0.0f, ga_s[KO + 1];
-#pragma unroll
-        for (int k = 0; k <= KO; k++) ga_s[k] = 0.0f;
-        const float lam = bl_exp_f(fminf(eta, 80.0f));
-        const float mzs = lam <= (float)K ? lam : fmaf((float)K, eta, -BL_LGAMMA1P[K]);
-        const float mz_lb = fmaxf(bl_rn_mode_lb(eta, (float)K), 0.0f); // lower bound of max_n p_n (p_0 = 0)
-        float deta = 0.0f;
-        for (int t = 0; t < T; t++) {
-            const float *pv = rec + 2 * (XQ + t * pb);
-            // ---- A0: the visits, dealt over the quad's lanes; u = c nu; log sigma(u) = log r (detection) / log q (non-detection) ----
-            float cnon = 0.0f, clr = 0.0f, ndet = 0.0f, lqmin = 0.0f;
-            for (int j = sub; j < J; j += 4) {
-                const float *wv = pv + 2 * (j * (KO + 1));
-                const float c = wv[0];
-                float u = c * alpha[0];
-#pragma unroll
-                for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
-                const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E);
-                const float logsig = fminf(u, 0.0f) - BL_LN2 * __builtin_amdgcn_logf(1.0f + e);
-                clr += c > 0.0f ? logsig : 0.0f;
-                ndet += c > 0.0f ? 1.0f : 0.0f;
-                const float ln = c < 0.0f ? logsig : 0.0f;
-                cnon += ln;
-                lqmin = fminf(lqmin, ln);
-            }
-            cnon = bl_quad_sum(cnon); clr = bl_quad_sum(clr); ndet = bl_quad_sum(ndet); lqmin = bl_quad_min(lqmin);
-            // ---- bounds and cutoffs (bl_eval_sites_rn's) ----
-            const float a = eta + cnon;
-            const float term0 = ndet * LOG_TINY;
-            const float m_lb = fmaxf(fmaxf(term0, a + clr), bl_rn_mode_lb(a, (float)K) + clr);
-            const float FL = -15.942385f;
-            const float nstar = lqmin < 0.0f ? FL * __builtin_amdgcn_rcpf(lqmin) : 0.0f;
-            const float Tq = lam - 0.9f - (fminf(mz_lb, m_lb) - 20.0f);
-            const float dmax = 0.5f * (Tq + __builtin_amdgcn_sqrtf(fmaf(Tq, Tq, 8.0f * lam * Tq)));
-            const int Kl = min(K, bl_wave_max_u(real ? (int)fminf(lam + dmax + 2.0f, 1.0e6f) : 0));
-            // The rest of the period for a table of MQ slots per lane (n < 4 MQ): the common short ranges run a compact, register-lean
-            // instantiation (8 slots: n < 32), longer ones 16 or 32 slots (one fully unrolled 32-slot body alone spills hundreds of
-            // registers, measured)
-            auto period_body = [&](auto mq_tag) {
-            constexpr int MQ = decltype(mq_tag)::value;
-            // ---- one scan over the lane's n <= Kl: prior sums, the posterior cutoff, the table's starting values ----
-            float LP[MQ];
-            float sz = 0.0f, b1 = 0.0f;
-            int nw = 0;
-            BL_RNQ_LOOP_BEGIN(Kl)
-                const float pn = fmaf(fn, eta, -lgs[4 * m]);
-                const float e = bl_exp_f(pn - mzs);
-                sz += e;
-                b1 = fmaf(fn, e, b1);
-                nw = (fmaf(cnon, fminf(fn, nstar), pn) >= m_lb - 20.0f) ? sub + 4 * m : nw;
-                LP[m] = (pn + fmaf(fn, cnon, clr)) * BL_LOG2E;
-            BL_RNQ_LOOP_END
-            sz = bl_quad_sum(sz); b1 = bl_quad_sum(b1);
-            const float log_z = mzs + BL_LN2 * __builtin_amdgcn_logf(sz);
-            const float en_prior = b1 * __builtin_amdgcn_rcpf(sz);
-            const int Kw = min(Kl, bl_wave_max_u(real ? nw : 0));
-            // ---- floors: numpyro's max(n log q, log eps) of every non-detection visit: LP += max(0, log2 eps - n log2 q) ----
-            // (every lane walks ALL visits from here on: it needs each visit's value at its own n)
-            for (int j = 0; j < J; j++) {
-                const float *wv = pv + 2 * (j * (KO + 1));
-                float u = wv[0] * alpha[0];
-#pragma unroll
-                for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
-                const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E);
-                const float lq2 = wv[0] < 0.0f ? fminf(u, 0.0f) * BL_LOG2E - __builtin_amdgcn_logf(1.0f + e) : 0.0f; // 0: no correction
-                if (!__any(lq2 * (float)Kw < FL2)) continue; // no lane's floor is reached inside the range
-                BL_RNQ_LOOP_BEGIN(Kw)
-                    LP[m] += fmaxf(fmaf(-fn, lq2, FL2), 0.0f);
-                BL_RNQ_LOOP_END
-            }
-            // ---- A1: LP[m] += sum over detection visits of log2 b_n, ten visits side by side, one log per n and group ----
-            for (int j0 = 0; j0 < J; j0 += BL_RN_GA) {
-                float q[BL_RN_GA];
-                bool det = false;
-#pragma unroll
-                for (int g = 0; g < BL_RN_GA; g++) {
-                    q[g] = 0.0f;
-                    if (j0 + g < J) { // wave-uniform
-                        const float *wv = pv + 2 * ((j0 + g) * (KO + 1));
-                        float u = wv[0] * alpha[0];
-#pragma unroll
-                        for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
-                        const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E);
-                        q[g] = wv[0] > 0.0f ? (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(1.0f + e) : 0.0f; // a non-detection: q = 0, b = 1
-                        det = det || wv[0] > 0.0f;
-                    }
-                }
-                if (!__any(det)) continue; // no lane of the wave has a detection in this group
-                static_assert(BL_RN_GA == 10, "the product tree below is written for five pairs");
-                bl_f2 b2[5], q4[5], b4[5];
-#pragma unroll
-                for (int g = 0; g < 5; g++) {
-                    const bl_f2 qq = bl_f2{q[2 * g], q[2 * g + 1]}, q2 = qq * qq, s1 = bl2(1.0f) + qq, s2 = s1 + q2; // 1+q, 1+q+q^2
-                    q4[g] = q2 * q2;
-                    b4[g] = bl_fma2(q2, qq, s2);                                                                    // 1+q+q^2+q^3
-                    // b_sub: 0, 1, 1+q, 1+q+q^2  (q = 0: 0, 1, 1, 1 -- the factor 1 of a visit that is no detection; slot 0 of lane 0
-                    // is overwritten below)
-                    b2[g] = sub == 0 ? bl2(0.0f) : (sub == 1 ? bl2(1.0f) : (sub == 2 ? s1 : s2));
-                }
-                BL_RNQ_LOOP_BEGIN(Kw)
-                    const bl_f2 pp = ((b2[0] * b2[1]) * (b2[2] * b2[3])) * b2[4];
-                    LP[m] += __builtin_amdgcn_logf(pp.x * pp.y);
-#pragma unroll
-                    for (int g = 0; g < 5; g++) b2[g] = bl_fma2(b2[g], q4[g], b4[g]);
-                BL_RNQ_LOOP_END
-            }
-            if (sub == 0) LP[0] = term0 * BL_LOG2E; // n = 0: detections impossible -> numpyro's clamp (no b, no floor)
-            // ---- B: the sum over n ----
-            float mx = -3.0e38f;
-            BL_RNQ_LOOP_BEGIN(Kw)
-                mx = fmaxf(mx, LP[m]);
-            BL_RNQ_LOOP_END
-            mx = bl_quad_max(mx);
-            float s = 0.0f, a1 = 0.0f, s1 = 0.0f;
-            BL_RNQ_LOOP_BEGIN(Kw)
-                const float wn = __builtin_amdgcn_exp2f(LP[m] - mx);
-                LP[m] = wn; // unnormalised posterior weight of N = n
-                s += wn;
-                a1 = fmaf(fn, wn, a1);
-            BL_RNQ_LOOP_END
-            s1 = s - (sub == 0 ? LP[0] : 0.0f); // the weights of n >= 1
-            s = bl_quad_sum(s); a1 = bl_quad_sum(a1); s1 = bl_quad_sum(s1);
-            const float rs = __builtin_amdgcn_rcpf(s);
-            ll_s += BL_LN2 * (mx + __builtin_amdgcn_logf(s)) - log_z;
-            const float en_post = a1 * rs;
-            deta += en_post - en_prior;
-            // ---- C: the visits' d/dnu.  Non-detection: sigma(-u) sum_n n w_n [n not floored] (the record's c w_k carries the sign) ----
-            for (int j = 0; j < J; j++) {
-                const float *wv = pv + 2 * (j * (KO + 1));
-                if (!__any(wv[0] < 0.0f)) continue;
-                float u = wv[0] * alpha[0];
-#pragma unroll
-                for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
-                const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E), op = 1.0f + e;
-                const float lq2 = fminf(u, 0.0f) * BL_LOG2E - __builtin_amdgcn_logf(op);
-                float hn = 0.0f;
-                BL_RNQ_LOOP_BEGIN(Kw)
-                    hn += (fn * lq2 >= FL2) ? fn * LP[m] : 0.0f;
-                BL_RNQ_LOOP_END
-                hn = bl_quad_sum(hn);
-                const float dnu = wv[0] < 0.0f ? hn * rs * (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(op) : 0.0f;
-#pragma unroll
-                for (int k = 0; k <= KO; k++) ga_s[k] = fmaf(dnu, wv[2 * k], ga_s[k]);
-            }
-            // Detection: sum_n w_n (q - q r b'_n / b_n), two visits side by side (packed)
-            for (int j0 = 0; j0 < J; j0 += 2) {
-                float q[2], r[2], hs[2];
-                bool any = false;
-#pragma unroll
-                for (int g = 0; g < 2; g++) {
-                    q[g] = 0.0f; r[g] = 0.0f; hs[g] = 0.0f;
-                    if (j0 + g < J) {
-                        const float *wv = pv + 2 * ((j0 + g) * (KO + 1));
-                        float u = wv[0] * alpha[0];
-#pragma unroll
-                        for (int k = 1; k <= KO; k++) u = fmaf(wv[2 * k], alpha[k], u);
-                        const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E), rop = __builtin_amdgcn_rcpf(1.0f + e);
-                        const bool d = wv[0] > 0.0f;
-                        q[g] = d ? (u > 0.0f ? e : 1.0f) * rop : 0.0f;
-                        r[g] = (u > 0.0f ? 1.0f : e) * rop;
-                        any = any || d;
-                    }
-                }
-                if (!__any(any)) continue;
-                const bl_f2 qq = bl_f2{q[0], q[1]}, q2 = qq * qq, q3 = q2 * qq, s1q = bl2(1.0f) + qq, s2q = s1q + q2;
-                const bl_f2 q4 = q2 * q2, b4 = s2q + q3, c3 = bl2(4.0f) * q3, bp4 = bl_fma2(bl2(3.0f), q2, bl_fma2(bl2(2.0f), qq, bl2(1.0f)));
-                // b_sub: 0, 1, 1+q, 1+q+q^2;  b'_sub: 0, 0, 1, 1+2q
-                bl_f2 b = sub == 0 ? bl2(0.0f) : (sub == 1 ? bl2(1.0f) : (sub == 2 ? s1q : s2q));
-                bl_f2 bp = sub <= 1 ? bl2(0.0f) : (sub == 2 ? bl2(1.0f) : bl_fma2(bl2(2.0f), qq, bl2(1.0f)));
-                bl_f2 h = bl2(0.0f);
-                BL_RNQ_LOOP_BEGIN(Kw)
-                    const bl_f2 bs = __builtin_elementwise_max(b, bl2(1.0e-30f)); // (n = 0: b = b' = 0, its ratio counts as 0)
-                    h = bl_fma2(bl2(LP[m]) * bp, bl_rcp_2(bs), h);
-                    bp = bl_fma2(bp, q4, bl_fma2(b, c3, bp4));
-                    b = bl_fma2(b, q4, b4);
-                BL_RNQ_LOOP_END
-                hs[0] = bl_quad_sum(h.x); hs[1] = bl_quad_sum(h.y);
-#pragma unroll
-                for (int g = 0; g < 2; g++) {
-                    if (j0 + g < J) {
-                        const float *wv = pv + 2 * ((j0 + g) * (KO + 1));
-                        const float dnu = q[g] * (s1 - r[g] * hs[g]) * rs; // q = 0 unless a detection
-#pragma unroll
-                        for (int k = 0; k <= KO; k++) ga_s[k] = fmaf(dnu, wv[2 * k], ga_s[k]);
-                    }
-                }
-            }
-            };
-            if (Kl < 32) period_body(std::integral_constant<int, 8>{});
-            else if (Kl < 64) period_body(std::integral_constant<int, 16>{});
-            else period_body(std::integral_constant<int, BL_RN_MQ>{});
-        }
-        deta *= live;
-        ll = fmaf(live, ll_s, ll);
-#pragma unroll
-        for (int k = 0; k <= KO; k++) ga[k] = fmaf(live, ga_s[k], ga[k]);
-        gb[0] += deta;
-#pragma unroll
-        for (int k = 0; k < KS; k++) gb[k + 1] = fmaf(deta, x[k], gb[k + 1]);
-    }
-}
-
-// MODEL 0 = occu (occu.py), MODEL 1 / 5 = occu_rn (occu_rn.py; LDS records only; table of 128 / 104 entries);
-// MODEL 2 (occu with false positives) is dispatched by bl_phase_a below
+// MODEL 0 = occu (occu.py); MODEL 1 = occu_rn (occu_rn.py) has its own entry, bl_eval_sites_rn (rn_device.hpp), called by bl_phase_a;
+// MODEL 2 (occu with false positives), 3 (occu_cop), 4 (nmixture) are dispatched by bl_phase_a below
 template <int KS, int KO, bool LDS, int MODEL, int CT>
 __device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ grows, int ld_or_stride, int cnt, int T, int J, int K,
                                               const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                               float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], int data_off = 0)
 {
-    if constexpr (MODEL == 1) {
-#if BL_RN_QUAD
-        if constexpr (LDS) bl_eval_sites_rn_quad<KS, KO, CT>(ct, ld_or_stride, cnt, T, J, K, beta, alpha, ll, gb, ga);
-#else
-        if constexpr (LDS) bl_eval_sites_rn<KS, KO, CT, BL_RN_NB, 1>(ct, ld_or_stride, cnt, T, J, K, beta, alpha, ll, gb, ga);
-#endif
-    } else if constexpr (MODEL == 5) {
-#if BL_RN_QUAD
-        if constexpr (LDS) bl_eval_sites_rn_quad<KS, KO, CT>(ct, ld_or_stride, cnt, T, J, K, beta, alpha, ll, gb, ga);
-#else
-        if constexpr (LDS) bl_eval_sites_rn<KS, KO, CT, BL_RN_NB_SMALL, 2>(ct, ld_or_stride, cnt, T, J, K, beta, alpha, ll, gb, ga);
-#endif
-    } else if constexpr (LDS) {
+    static_assert(MODEL == 0, "bl_eval_sites: the plain occupancy model only");
+    if constexpr (LDS) {
         switch (J) { // wave-uniform
         case 1: bl_eval_sites_lds<KS, KO, 1, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off); break;
         case 2: bl_eval_sites_lds<KS, KO, 2, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off); break;
@@ -1588,7 +965,7 @@ template <int MODEL> __device__ __forceinline__ int bl_model_dim(int Ks, int Ko,
     return Ks + Ko + 2 + ((MODEL == 2 || (MODEL == 3 && fp_mode != 0)) ? 1 : 0);
 }
 // visit width of the records in floats minus one: the KO every layout helper is called with
-template <int MODEL> __device__ __forceinline__ constexpr int bl_layout_ko(int KO) { return KO + ((MODEL == 3 || MODEL == 4) ? 1 : 0); }
+template <int MODEL> __device__ __forceinline__ constexpr int bl_layout_ko(int KO) { return KO + ((MODEL == 1 || MODEL == 3 || MODEL == 4) ? 1 : 0); }
 
 template <int KS, int KO>
 __device__ __forceinline__ void bl_load_coefs(float (&beta)[KS + 1], float (&alpha)[KO + 1], int coef_off = 0)
@@ -1633,11 +1010,11 @@ __device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, con
 // n_species * BL_SP_PART).  One species: the round-1 layout (row stride BL_PART_STRIDE), unchanged.
 #define BL_SP_COEF(KS, KO) ((KS) + (KO) + 2)
 #define BL_SP_PART(KS, KO) ((KS) + (KO) + 4)
-#define BL_PART_FLOATS 384 // floats between BL_OFF_PART and BL_OFF_CKR
+#define BL_PART_FLOATS 768 // floats between BL_OFF_PART and BL_OFF_CKR
 template <int KS, int KO, bool LDS, int MODEL, int CW>
 __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__restrict__ grows, int ld_or_stride, int cnt,
                                            int T, int J, int max_abundance, int fp_mode, const float *__restrict__ tab = nullptr,
-                                           int tab_ld = 0, int n_species = 1, int sp_lds = 0)
+                                           int tab_ld = 0, int n_species = 1, int sp_lds = 0, int rn_off = 0)
 {
     const int row_stride = n_species > 1 ? n_species * BL_SP_PART(KS, KO) : BL_PART_STRIDE;
     for (int sp = 0; sp < n_species; sp++) {
@@ -1657,6 +1034,10 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
     } else if constexpr (MODEL == 4) {
         static_assert(LDS, "N-mixture model: LDS records only");
         bl_eval_sites_nmix<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, max_abundance, tab, tab_ld, beta, alpha, ll, gb, ga);
+        bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga);
+    } else if constexpr (MODEL == 1) {
+        static_assert(LDS, "Royle-Nichols model: LDS records only");
+        bl_eval_sites_rn<KS, KO, CW>(cwave, ld_or_stride, cnt, T, J, max_abundance, rn_off, beta, alpha, ll, gb, ga);
         bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga);
     } else if constexpr (MODEL == 3) {
         static_assert(LDS, "count occupancy model: LDS records only");

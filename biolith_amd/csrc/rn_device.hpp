@@ -1,0 +1,522 @@
+// rn_device.hpp -- Royle-Nichols (occu_rn) site evaluation for gfx950, WORK-PROPORTIONAL form.
+//
+// biolith/models/occu_rn.py:179-222 + utils/distributions.py:31-40 with N summed out:
+//   lambda = exp(eta);  pi_n = Poisson(lambda)(n) renormalised over n <= K   (K = max_abundance)
+//   P(y=1 | n) = 1 - q^n = r * b_n ,  q = 1 - r ,  b_n = 1 + q + ... + q^(n-1)  (b_n = b_(n-1) q + 1: no cancellation);
+//   non-detections contribute n log q: rank-1 in n.
+//   l = logsumexp_n [ n (eta + sum_nondet log q) - lgamma(n+1) + sum_det (log r + log b_n) ] - log Z
+//
+// Rounds 1-2 gave every site one lane that ran the sum over n up to its WAVE's largest cutoff (20-35 at BASELINE.json's
+// config 4, where a site needs n <= 7 on average) with a 128-entry per-lane table, one wave per SIMD.  Here the sum over n
+// of a (site, period) is cut into ITEMS of BL_RN_CH = 8 consecutive n and a wave evaluates its sites in two steps:
+//
+//   P1  one lane per site: the visits (log r, log q, the rank-1 gradient pieces; each visit's q or log2 q is left in a spare
+//       slot of the site's LDS record for the items), the truncated-Poisson normaliser (closed form e^lambda whenever the
+//       tail beyond K is below 3e-11, else a loop), and the site's item count from the two concave bounds of its terms;
+//       a record {a, clr, term0, thr, cnon, n*} per site goes to a wave-private LDS table.
+//   P2  one lane per ITEM (site, chunk c: n = 8c+1 .. 8c+8): a wave prefix sum of the sites' item counts deals the items
+//       to lanes, sites packed whole into rounds of <= 64 lanes.  The item's b_n / q^n recursions start from
+//       b_(8c) = b_8 (1 + q^8 + ... + q^(8(c-1))), q^(8c) (products of positives: no cancellation, no transcendental);
+//       the items of a site combine their maxima and sums through a wave-private LDS table; every item then adds its
+//       share of the detections' gradient straight into its lane's accumulators (they are summed over the wave at
+//       the end anyway), so no per-site reduction of gradients exists.  numpyro's floor of a non-detection is applied by
+//       the items that hold a term it can matter for (a bound per term, no per-site flags).
+//       The item for chunk 0 also carries the n = 0 term and hands (max, sum, sum n w) back to the site's lane.
+//
+// Work is then sum_sites ceil(cutoff / 8) items of 8 terms instead of 64 x (wave's largest cutoff) per wave, the per-lane
+// table is 8 registers, and a workgroup runs 7 compute waves (two per SIMD) that hide each other's exp / log / rcp latencies.
+#pragma once
+
+#ifndef BL_CWAVES_RN
+#define BL_CWAVES_RN 7                 // compute waves per workgroup of the occu_rn kernels
+#endif
+#define BL_RN_CH 8                     // n-terms per item
+#define BL_RN_LGT 144                  // floats of the shifted lgamma table: lgt[i] = lgamma(i + 2) = the entry of n = i + 1
+#define BL_RN_WAVE_FLOATS 1088         // wave-private scratch: site records 64 x 8, site results 64 x 4, item map 64, combine 64 x 4
+#define BL_RN_GA 10                    // visits whose b_n recursions run side by side in pass A1 (one log per group and n)
+#define BL_RN_G0 5                     // visits evaluated side by side in pass A0
+// bytes of LDS behind the staged records that the occu_rn kernels need (host: choose_geometry)
+__host__ __device__ inline int bl_rn_scratch_bytes(int cw) { return 4 * (BL_RN_LGT + cw * BL_RN_WAVE_FLOATS); }
+
+#ifdef BL_STAMPS
+static __device__ long long bl_rn_dbg[16];
+#define BL_RN_T(i) { const long long now_ = (long long)clock64(); if (st_on) bl_rn_dbg[i] += now_ - st_prev; st_prev = now_; }
+#else
+#define BL_RN_T(i)
+#endif
+
+// lgt[i] = lgamma(i + 2) for n = i + 1 <= K, a huge value beyond (that term's weight underflows to exactly 0: the model's
+// bound n <= max_abundance).  Every thread of the workgroup calls this once, before the first evaluation and a barrier.
+__device__ __forceinline__ void bl_rn_fill_lgamma(int lds_off, int K, int nthreads)
+{
+    float *lgt = bl_lds_f(lds_off);
+    for (int i = threadIdx.x; i < BL_RN_LGT; i += nthreads) lgt[i] = (i + 1 <= K && i + 1 < 128) ? BL_LGAMMA1P[i + 1] : 3.0e38f;
+}
+
+// wave-uniform maximum of a non-negative per-lane integer (inactive lanes count as 0)
+__device__ __forceinline__ int bl_wave_max_u(int x)
+{
+#define BL_MAXSTEP(ctrl, rm) x = max(x, __builtin_amdgcn_update_dpp(0, x, ctrl, rm, 0xF, false));
+    BL_MAXSTEP(0xB1, 0xF) BL_MAXSTEP(0x4E, 0xF) BL_MAXSTEP(0x141, 0xF) BL_MAXSTEP(0x140, 0xF)
+    BL_MAXSTEP(0x142, 0xA) BL_MAXSTEP(0x143, 0xC)
+#undef BL_MAXSTEP
+    return __builtin_amdgcn_readlane(x, 63);
+}
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8), then the rows' totals
+__device__ __forceinline__ int bl_wave_iscan(int x)
+{
+#define BL_SCANSTEP(ctrl, rm) x += __builtin_amdgcn_update_dpp(0, x, ctrl, rm, 0xF, false);
+    BL_SCANSTEP(0x111, 0xF) BL_SCANSTEP(0x112, 0xF) BL_SCANSTEP(0x114, 0xF) BL_SCANSTEP(0x118, 0xF)
+    BL_SCANSTEP(0x142, 0xA) BL_SCANSTEP(0x143, 0xC)
+#undef BL_SCANSTEP
+    return x;
+}
+// the compiler may not move LDS accesses across this point; a wave's LDS operations complete in order
+__device__ __forceinline__ void bl_wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// lower bound of max_n (n a - lgamma(n+1)) over 1 <= n <= K: evaluate at the Poisson mode with
+// lgamma(n+1) <= (n + 1/2) ln n - n + 1  (n >= 1)
+__device__ __forceinline__ float bl_rn_mode_lb(float a, float K)
+{
+    const float n1 = fminf(fmaxf(floorf(bl_exp_f(fminf(a, 80.0f))), 1.0f), K);
+    return fmaf(n1, a, -(fmaf(n1 + 0.5f, BL_LN2 * __builtin_amdgcn_logf(n1), 1.0f - n1)));
+}
+
+// Accumulates over this WAVE's share of the workgroup's sites (cwave of CW compute waves, contiguous shares):
+//   ll += sum_t l_it ,  gb[k] += d ll / d beta_k ,  ga[k] += d ll / d alpha_k        (per lane; the caller sums the wave)
+// LDS records: the plain model's, one float wider per visit (bl_layout_ko<1>: [c, c w_1 .. c w_KO, v]).  The last slot is DYNAMIC:
+// at every evaluation the site's lane leaves there what the item lanes need of the visit -- q_j > 0 (a detection), log2 q_j < 0
+// (a non-detection) or 0 (masked) -- so that the items read one float per visit instead of repeating the dot product and its exp / rcp.
+template <int KS, int KO, int CW>
+__device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt, int T, int J, int K, int rn_off,
+                                                 const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
+                                                 float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
+{
+    constexpr int XQ = (KS + 3) & ~3;
+    constexpr int VW = KO + 2;                 // floats per visit in the record
+    const int lane = threadIdx.x & 63;
+    const int pb = bl_period_block(J, KO + 1);
+    float *data = bl_lds_f(BL_OFF_DATA);
+    const float *lgt = bl_lds_f(rn_off);
+    float *wsc = bl_lds_f(rn_off) + BL_RN_LGT + cwave * BL_RN_WAVE_FLOATS;
+    float *srec = wsc;                                              // [64][8]  site lane -> item lanes
+    float *sres = wsc + 512;                                        // [64][4]  chunk-0 item lane -> site lane
+    unsigned *imap = reinterpret_cast<unsigned *>(wsc + 768);       // [64]     item -> site lane | chunk << 8 | first lane << 16 | chunks << 24
+    float *comb = wsc + 832;                                        // [64][4]  items of one site: max, sum, sum n w
+    const float LOG_TINY = -87.33654475f;
+    const float FL = -15.942385f; // log(finfo(float32).eps)
+    const float Kf = (float)K;
+    const int cK = (K - 1) / BL_RN_CH;         // last chunk that holds an n <= K
+#ifdef BL_STAMPS
+    const bool st_on = blockIdx.x == 0 && threadIdx.x == 64;
+    long long st_prev = (long long)clock64();
+#endif
+    const int spw = (cnt + CW - 1) / CW;
+    const int w0 = cwave * spw, w1 = min(cnt, w0 + spw);
+    for (int r0 = w0; r0 < w1; r0 += 64) {
+        const int ns = min(64, w1 - r0);           // sites of this round (wave-uniform), one per lane
+        // A round of <= 32 sites gives every site TWO lanes for its visits (l and l + 32 take half of them each and fold their
+        // sums): the visits are the longest stretch of P1 and half of the lanes would idle.  Everything else is the site lane's.
+        const bool two = ns <= 32;                 // wave-uniform
+        const int sl0 = two ? (lane & 31) : lane, half = two ? (lane >> 5) : 0;
+        const bool has = lane < ns;                // this lane is a site's lane
+        const int i = r0 + min(sl0, ns - 1);       // lanes beyond the round re-evaluate its last site and are masked out
+        const float live = has ? 1.0f : 0.0f;
+        float *rec = data + (size_t)(i >> 1) * pstride + (i & 1); // element e of this site: rec[2 e]
+        float x[KS > 0 ? KS : 1];
+        float eta = beta[0];
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            x[k] = rec[2 * k];
+            eta = fmaf(x[k], beta[k + 1], eta);
+        }
+        // ---- truncated-Poisson prior, p_n = n eta - lgamma(n+1), n <= K: log Z and E[n] ----
+        // Z = e^lambda (1 - tail), tail = P(Poisson(lambda) > K) <= 2 e^(p_(K+1) - lambda) while lambda <= (K+2)/2: below 3e-11
+        // the closed forms log Z = lambda, E[n] = lambda are exact in float32.  Otherwise (lambda near or beyond K) the sums.
+        const float lam = bl_exp_f(fminf(eta, 80.0f));
+        const float pK = fmaf(Kf, eta, -lgt[K - 1]);
+        const float pK1 = pK + eta - BL_LN2 * __builtin_amdgcn_logf(Kf + 1.0f);
+        const bool closed = (lam <= 0.5f * (Kf + 2.0f)) && (pK1 - lam <= -25.0f);
+        float log_z = lam, en_prior = lam;
+        if (__any(has && !closed)) {
+            // shift: an upper bound of max_n p_n tight to a few nats -- lambda while lambda <= K (Stirling: p_n <= lambda - 0.9
+            // for n >= 1, p_0 = 0), else p_K (p_n still rising at K)
+            const float mzs = lam <= Kf ? lam : pK;
+            const float mz_lb = fmaxf(bl_rn_mode_lb(eta, Kf), 0.0f);
+            // no term with p_n < mz_lb - 20 matters: for n > lambda, p_n <= lambda - 0.9 - (n - lambda)^2 / (n + lambda) (Stirling, and
+            // ln x >= 2 (x - 1) / (x + 1) for x >= 1), below that once n - lambda > (Tq + sqrt(Tq^2 + 8 lambda Tq)) / 2
+            const float Tq = lam - 0.9f - (mz_lb - 20.0f);
+            const float dmax = 0.5f * (Tq + __builtin_amdgcn_sqrtf(fmaf(Tq, Tq, 8.0f * lam * Tq)));
+            const int Klp = min(K, bl_wave_max_u((has && !closed) ? (int)fminf(lam + dmax + 2.0f, 1.0e6f) : 0));
+            float sz = bl_exp_f(-mzs), b1 = 0.0f; // n = 0
+            for (int n = 1; n <= Klp; n++) {
+                const float e = bl_exp_f(fmaf((float)n, eta, -lgt[n - 1]) - mzs);
+                sz += e;
+                b1 = fmaf((float)n, e, b1);
+            }
+            if (!closed) {
+                log_z = mzs + BL_LN2 * __builtin_amdgcn_logf(sz);
+                en_prior = b1 * __builtin_amdgcn_rcpf(sz);
+            }
+        }
+        float ll_s = 0.0f, deta = 0.0f;
+        BL_RN_T(0)
+        for (int t = 0; t < T; t++) {
+            float *pv = rec + 2 * (XQ + t * pb);
+            float cnon = 0.0f, clr = 0.0f, ndet = 0.0f;
+            float lqmin = 0.0f; // smallest log q over the non-detections
+            float Rv[KO + 1];
+#pragma unroll
+            for (int k = 0; k <= KO; k++) Rv[k] = 0.0f;
+            // ---- A0 (lane = site, or half a site): visits, no sum over n yet.  u = c nu;  log sigma(u) = log r (detection) or log q (non-detection) ----
+            // BL_RN_G0 visits side by side and branch-free.  A visit past the lane's share re-reads the last one as masked.
+            const int Jh = two ? (J + 1) >> 1 : J, jbeg = half * Jh;
+            for (int j0 = 0; j0 < Jh; j0 += BL_RN_G0) {
+#pragma unroll
+                for (int g = 0; g < BL_RN_G0; g++) {
+                    const bool valid = (j0 + g < Jh) && (jbeg + j0 + g < J) && sl0 < ns;
+                    const int j = min(jbeg + j0 + g, J - 1);
+                    float w[KO + 1];
+#pragma unroll
+                    for (int k = 0; k <= KO; k++) w[k] = pv[2 * (j * VW + k)];
+                    const float c = valid ? w[0] : 0.0f;
+                    float u = w[0] * alpha[0];
+#pragma unroll
+                    for (int k = 1; k <= KO; k++) u = fmaf(w[k], alpha[k], u);
+                    const float e = __builtin_amdgcn_exp2f(-fabsf(u) * BL_LOG2E), op = 1.0f + e;
+                    const float logsig = fminf(u, 0.0f) - BL_LN2 * __builtin_amdgcn_logf(op);
+                    const float sneg = (u > 0.0f ? e : 1.0f) * __builtin_amdgcn_rcpf(op); // sigma(-u): q of a detection, r of a non-detection
+                    const float ld = c > 0.0f ? logsig : 0.0f, ln = c < 0.0f ? logsig : 0.0f;
+                    const float sm = c < 0.0f ? sneg : 0.0f;
+                    clr += ld;
+                    ndet += c > 0.0f ? 1.0f : 0.0f;
+                    cnon += ln;
+                    lqmin = fminf(lqmin, ln);
+                    // d/dnu of n log q is -n r: rank-1; dnu * (1, w) = r E[n] * (c, c w)
+#pragma unroll
+                    for (int k = 0; k <= KO; k++) Rv[k] = fmaf(sm, w[k], Rv[k]);
+                    // the visit's dynamic slot: q (detection), log2 q (non-detection), 0 (masked)
+                    if (valid) pv[2 * (j * VW + KO + 1)] = c > 0.0f ? sneg : ln * BL_LOG2E;
+                }
+            }
+            if (two) { // fold the two halves of every site (v_permlane32_swap: x[l], x[l ^ 32] side by side in every lane)
+                auto both = [](float v, bool take_min) -> float {
+                    const unsigned b = __float_as_uint(v);
+                    const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+                    const float lo = __uint_as_float(r[0]), hi = __uint_as_float(r[1]);
+                    return take_min ? fminf(lo, hi) : lo + hi;
+                };
+                cnon = both(cnon, false); clr = both(clr, false); ndet = both(ndet, false); lqmin = both(lqmin, true);
+#pragma unroll
+                for (int k = 0; k <= KO; k++) Rv[k] = both(Rv[k], false);
+            }
+            BL_RN_T(1)
+            const float a = eta + cnon;
+            const float term0 = ndet * LOG_TINY; // n = 0: detections impossible -> numpyro's clamp tiny
+            // numpyro floors a non-detection's log(1 - P) = n log q at log(eps_f32) = -15.94 (Bernoulli probabilities are clamped to
+            // [tiny, 1 - eps]): the visit's term is max(n log q_j, FL).  The first visit to floor does so at n* = FL / lqmin; up to there
+            // the non-detections' sum is n cnon (rank one in n: it rides in `a`), beyond it is non-increasing, hence <= n* cnon.
+            // Every term_n is therefore bounded above by the Poisson part p_n = n eta - lgamma(n+1) plus that share (the detections'
+            // log r + log b_n = log(1 - q^n) is <= 0):
+            //     g(n) = max( n a - lgamma(n+1) ,  p_n + n* cnon ) ,     both branches concave in n,
+            // and the best term is at least m_lb = max(term_0, term_1, term at the mode of n a - lgamma(n+1), with log b >= 0).
+            // The site keeps n up to the last g(n) >= thr = m_lb - 20 (what is dropped is below 2e-9 of the sum, per term).
+            const float ea = bl_exp_f(fminf(a, 80.0f));
+            const float n1 = fminf(fmaxf(floorf(ea), 1.0f), Kf);
+            const float mode_lb = fmaf(n1, a, -(fmaf(n1 + 0.5f, BL_LN2 * __builtin_amdgcn_logf(n1), 1.0f - n1))); // (bl_rn_mode_lb)
+            const float thr = fmaxf(fmaxf(term0, a + clr), mode_lb + clr) - 20.0f;
+            const float nstar = lqmin < 0.0f ? FL * __builtin_amdgcn_rcpf(lqmin) : 0.0f; // cnon = 0 when there is none
+            const float shiftB = cnon * nstar;
+            // ---- the site's item count: chunk c (n = 8c+1 ..) is needed while some n >= 8c+1 has g(n) >= thr.  Per branch: its mode
+            // is at or beyond 8c+1 (floor(e^a), whose value is >= thr; floor(lambda), with p_n <= lambda - 0.9 as the test) or, past the
+            // mode where the branch falls, its value AT 8c+1 still reaches thr.  Monotone in c, so the chunks are counted until no
+            // site of the wave needs another (two or three steps at the posterior). ----
+            int nch = has ? 1 : 0;
+            {
+                const bool okB = lam - 0.9f + shiftB >= thr;
+                bool need = has;
+                for (int c = 1; c <= cK && __any(need); c++) {
+                    const float tn = (float)(c * BL_RN_CH + 1), lg = lgt[c * BL_RN_CH];
+                    need = need && ((ea >= tn) || (fmaf(tn, a, -lg) >= thr) || (okB && lam >= tn) || (fmaf(tn, eta, -lg) + shiftB >= thr));
+                    nch += need ? 1 : 0;
+                }
+            }
+            // record for the item lanes
+            *reinterpret_cast<float4 *>(srec + lane * 8) = make_float4(a, clr, term0, thr);
+            *reinterpret_cast<float2 *>(srec + lane * 8 + 4) = make_float2(cnon, nstar);
+            const int P = bl_wave_iscan(nch);
+            BL_RN_T(2)
+            // ---- P2: items.  Sites are packed whole into rounds of <= 64 lanes (a site has <= 16 items) ----
+            int first = 0, base = 0;
+            while (first < ns) {
+                const unsigned long long fit = __ballot(P - base <= 64);    // a prefix of the lanes (P is non-decreasing)
+                const int last = min(ns, (int)__popcll(fit));               // sites [first, last) go into this round
+                const int nitems = __builtin_amdgcn_readlane(P, last - 1) - base;
+                const bool mine = lane >= first && lane < last;
+                const int start = P - nch - base;
+                for (int c = 0; __any(mine && c < nch); c++)
+                    if (mine && c < nch) imap[start + c] = (unsigned)lane | ((unsigned)c << 8) | ((unsigned)start << 16) | ((unsigned)nch << 24);
+                bl_wave_lds_fence(); // (also: the sites' dynamic visit slots are written)
+                const bool item = lane < nitems;
+                const unsigned im = imap[item ? lane : 0];
+                const int sl = (int)(im & 0xFFu), ch = (int)((im >> 8) & 0xFFu), st = (int)((im >> 16) & 0xFFu), nc = (int)(im >> 24);
+                const int is = r0 + sl;
+                const float *ipv = data + (size_t)(is >> 1) * pstride + (is & 1) + 2 * (XQ + t * pb);
+                const float4 s0v = *reinterpret_cast<const float4 *>(srec + sl * 8);
+                const float i_a = s0v.x, i_clr = s0v.y, i_term0 = s0v.z, i_thr = s0v.w;
+                const bool deep = __any(ch > 0);                // some item is not a chunk 0: the recursions' starting values are needed
+                const bool multi = __any(nc > 1);               // some site has several items: combine through LDS
+                const float n0f = (float)(ch * BL_RN_CH);
+                BL_RN_T(3)
+                // LP[i] (log2 units): term of n = 8 ch + 1 + i;  starts as the part that needs no recursion, p_n + n cnon + clr
+                float LP[BL_RN_CH];
+                {
+                    const float4 l0 = *reinterpret_cast<const float4 *>(lgt + ch * BL_RN_CH);
+                    const float4 l1 = *reinterpret_cast<const float4 *>(lgt + ch * BL_RN_CH + 4);
+                    const float lg[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+#pragma unroll
+                    for (int q = 0; q < BL_RN_CH; q++) LP[q] = (fmaf(n0f + (float)(q + 1), i_a, -lg[q]) + i_clr) * BL_LOG2E;
+                }
+                // ---- A1: LP[n] += sum over detection visits of log2 b_n ----
+                // Visits are taken BL_RN_GA at a time, their b_n recursions side by side as five packed pairs, and ONE log per n for
+                // the group: sum_j log b_jn = log prod_j b_jn (b <= n <= 127, so ten factors stay far inside float32).  A
+                // non-detection visit gets q = 0, hence b = 1: its factor is 1 and it needs no mask.
+                // J <= 10 (one group): the reciprocals 1 / b_jn, which pass C needs, are formed here and kept (80 registers), the
+                // product runs over them, and C is left with ten dot products -- no second recursion.
+                static_assert(BL_RN_GA == 10, "the product tree below is written for five pairs");
+                const bool one_group = J <= BL_RN_GA; // wave-uniform
+                bl_f2 rb[BL_RN_CH][5], q2k[5];
+                if (one_group) {
+#pragma unroll
+                    for (int g = 0; g < BL_RN_GA; g++) {
+                        float qv = 0.0f;
+                        if (g < J) qv = fmaxf(ipv[2 * (g * VW + KO + 1)], 0.0f); // wave-uniform guard
+                        if (g & 1) q2k[g >> 1].y = qv; else q2k[g >> 1].x = qv;
+                    }
+                    bl_f2 b2[5];
+#pragma unroll
+                    for (int g = 0; g < 5; g++) b2[g] = bl2(0.0f);
+                    if (deep) { // b_(8 ch) = b_8 B,  b_8 = (1+q)(1+q^2)(1+q^4),  B = 1 + q^8 + ... + q^(8 (ch-1))  (0 for ch = 0)
+                        bl_f2 q8[5], B[5];
+#pragma unroll
+                        for (int g = 0; g < 5; g++) {
+                            const bl_f2 qq = q2k[g] * q2k[g], q4 = qq * qq;
+                            q8[g] = q4 * q4;
+                            b2[g] = ((q2k[g] + bl2(1.0f)) * (qq + bl2(1.0f))) * (q4 + bl2(1.0f));
+                            B[g] = bl2(0.0f);
+                        }
+                        for (int s = 0; __any(s < ch); s++) {
+                            const bool on = s < ch;
+#pragma unroll
+                            for (int g = 0; g < 5; g++) {
+                                const bl_f2 Bn = bl_fma2(B[g], q8[g], bl2(1.0f));
+                                B[g] = on ? Bn : B[g];
+                            }
+                        }
+#pragma unroll
+                        for (int g = 0; g < 5; g++) b2[g] = b2[g] * B[g];
+                    }
+#pragma unroll
+                    for (int n = 0; n < BL_RN_CH; n++) {
+#pragma unroll
+                        for (int g = 0; g < 5; g++) {
+                            b2[g] = bl_fma2(b2[g], q2k[g], bl2(1.0f));
+                            rb[n][g] = bl_rcp_2(b2[g]);
+                        }
+                        const bl_f2 pp = ((rb[n][0] * rb[n][1]) * (rb[n][2] * rb[n][3])) * rb[n][4];
+                        LP[n] -= __builtin_amdgcn_logf(pp.x * pp.y);
+                    }
+                } else
+                for (int j0 = 0; j0 < J; j0 += BL_RN_GA) {
+                    bl_f2 b2[5], q2[5];
+                    float qmax = 0.0f;
+#pragma unroll
+                    for (int g = 0; g < BL_RN_GA; g++) {
+                        float qv = 0.0f;
+                        if (j0 + g < J) qv = fmaxf(ipv[2 * ((j0 + g) * VW + KO + 1)], 0.0f); // wave-uniform guard
+                        if (g & 1) q2[g >> 1].y = qv; else q2[g >> 1].x = qv;
+                        qmax = fmaxf(qmax, qv);
+                    }
+                    if (!__any(qmax > 0.0f)) continue; // no lane of the wave has a detection in this group
+#pragma unroll
+                    for (int g = 0; g < 5; g++) b2[g] = bl2(0.0f);
+                    if (deep) {
+                        bl_f2 q8[5], B[5];
+#pragma unroll
+                        for (int g = 0; g < 5; g++) {
+                            const bl_f2 qq = q2[g] * q2[g], q4 = qq * qq;
+                            q8[g] = q4 * q4;
+                            b2[g] = ((q2[g] + bl2(1.0f)) * (qq + bl2(1.0f))) * (q4 + bl2(1.0f));
+                            B[g] = bl2(0.0f);
+                        }
+                        for (int s = 0; __any(s < ch); s++) {
+                            const bool on = s < ch;
+#pragma unroll
+                            for (int g = 0; g < 5; g++) {
+                                const bl_f2 Bn = bl_fma2(B[g], q8[g], bl2(1.0f));
+                                B[g] = on ? Bn : B[g];
+                            }
+                        }
+#pragma unroll
+                        for (int g = 0; g < 5; g++) b2[g] = b2[g] * B[g];
+                    }
+#pragma unroll
+                    for (int n = 0; n < BL_RN_CH; n++) {
+#pragma unroll
+                        for (int g = 0; g < 5; g++) b2[g] = bl_fma2(b2[g], q2[g], bl2(1.0f));
+                        const bl_f2 pp = ((b2[0] * b2[1]) * (b2[2] * b2[3])) * b2[4];
+                        LP[n] += __builtin_amdgcn_logf(pp.x * pp.y);
+                    }
+                }
+                BL_RN_T(4)
+                // ---- A1b: numpyro's floor.  Beyond n* the TRUE term is at most p_n + n* cnon + clr + sum log b = LP[n] + cnon (n* - n):
+                // only an item with such an n within 20 nats of m_lb needs the correction LP[n] += sum_j max(0, FL - n log q_j), and then
+                // only for the visits whose floor one of its n reaches (taking the floor where it does not matter is still the
+                // model, so a visit picked by any lane is corrected in all).  About one site in a hundred at the posterior. ----
+                unsigned long long floored = 0ull; // wave-uniform: visits (bit j & 63) that took the correction
+                {
+                    const float2 s1v = *reinterpret_cast<const float2 *>(srec + sl * 8 + 4);
+                    const float i_cnon = s1v.x, i_nstar = s1v.y;
+                    bool rel = false;
+#pragma unroll
+                    for (int n = 0; n < BL_RN_CH; n++) {
+                        const float nf = n0f + (float)(n + 1);
+                        rel = rel || (nf > i_nstar && fmaf(LP[n], BL_LN2, i_cnon * (i_nstar - nf)) >= i_thr);
+                    }
+                    rel = rel && item && i_nstar > 0.0f;
+                    if (__any(rel)) {
+                        const float nmax = n0f + (float)BL_RN_CH;
+                        for (int j = 0; j < J; j++) {
+                            const float lq2 = fminf(ipv[2 * (j * VW + KO + 1)], 0.0f); // log2 q of a non-detection, else 0
+                            if (!__any(rel && nmax * lq2 < -23.0f)) continue;          // log2(eps_f32) = -23
+                            floored |= 1ull << (j & 63);
+#pragma unroll
+                            for (int n = 0; n < BL_RN_CH; n++) LP[n] += fmaxf(fmaf(-(n0f + (float)(n + 1)), lq2, -23.0f), 0.0f);
+                        }
+                    }
+                }
+                // ---- B: the item's maximum and sums, then the site's over its items (one exchange through LDS) ----
+                float m_it = ch == 0 ? i_term0 * BL_LOG2E : -3.0e38f; // the n = 0 term rides with chunk 0
+#pragma unroll
+                for (int n = 0; n < BL_RN_CH; n++) m_it = fmaxf(m_it, LP[n]);
+                float S = ch == 0 ? __builtin_amdgcn_exp2f(fmaf(i_term0, BL_LOG2E, -m_it)) : 0.0f, a1 = 0.0f;
+#pragma unroll
+                for (int n = 0; n < BL_RN_CH; n++) {
+                    const float wn = __builtin_amdgcn_exp2f(LP[n] - m_it);
+                    const float nw = (n0f + (float)(n + 1)) * wn;
+                    LP[n] = nw; // n x the posterior weight of N = n, relative to the item's best term
+                    S += wn;
+                    a1 += nw;
+                }
+                const float a1_it = a1;
+                float m_s = m_it, f_it = 1.0f; // f_it: the item's weights relative to the site's best term
+                if (multi) {
+                    *reinterpret_cast<float4 *>(comb + lane * 4) = make_float4(m_it, S, a1, 0.0f);
+                    bl_wave_lds_fence();
+                    for (int s = 0; __any(s < nc); s++) m_s = fmaxf(m_s, comb[(st + min(s, nc - 1)) * 4]);
+                    f_it = __builtin_amdgcn_exp2f(m_it - m_s);
+                    S = 0.0f; a1 = 0.0f;
+                    for (int s = 0; __any(s < nc); s++) { // (fixed order: every item of a site forms the same sums)
+                        const float4 v = *reinterpret_cast<const float4 *>(comb + (st + min(s, nc - 1)) * 4);
+                        const float f = s < nc ? __builtin_amdgcn_exp2f(v.x - m_s) : 0.0f;
+                        S = fmaf(f, v.y, S);
+                        a1 = fmaf(f, v.z, a1);
+                    }
+                }
+                if (item && ch == 0) *reinterpret_cast<float4 *>(sres + sl * 4) = make_float4(m_s, S, a1, 0.0f);
+                const float rs = item ? f_it * __builtin_amdgcn_rcpf(S) : 0.0f;
+                BL_RN_T(5)
+                // floored visits: d/du max(n log sigma(u), FL) vanishes for the floored n -- take their n w_n back out of the rank-1 part
+                if (floored != 0ull) {
+                    for (int j = 0; j < J; j++) {
+                        if (!((floored >> (j & 63)) & 1ull)) continue;
+                        const float *wv = ipv + 2 * (j * VW);
+                        const float lq2 = fminf(wv[2 * (KO + 1)], 0.0f);
+                        const float sm = 1.0f - __builtin_amdgcn_exp2f(lq2); // r = sigma(-u) of a non-detection (a floor is reached where q <= 0.88)
+                        float hf = 0.0f;
+#pragma unroll
+                        for (int n = 0; n < BL_RN_CH; n++) hf += ((n0f + (float)(n + 1)) * lq2 < -23.0f) ? LP[n] : 0.0f;
+                        const float dnu = -sm * hf * rs;
+#pragma unroll
+                        for (int k = 0; k <= KO; k++) ga[k] = fmaf(dnu, wv[2 * k], ga[k]);
+                    }
+                }
+                // ---- C: detection visits' d/dnu = sum_n w_n n q^n / b_n   (d log(1 - q^n) / dnu = n r q^n / (1 - q^n)), and
+                // q^n / b_n = 1 / b_n - r  (1 - q^n = r b_n):  sum_n (n w_n) / b_jn - r_j sum_n n w_n  -- no q^n recursion ----
+                if (one_group) {
+                    bl_f2 h[5];
+#pragma unroll
+                    for (int g = 0; g < 5; g++) h[g] = bl2(0.0f);
+#pragma unroll
+                    for (int n = 0; n < BL_RN_CH; n++) {
+#pragma unroll
+                        for (int g = 0; g < 5; g++) h[g] = bl_fma2(bl2(LP[n]), rb[n][g], h[g]);
+                    }
+#pragma unroll
+                    for (int g = 0; g < BL_RN_GA; g++) {
+                        if (g < J) { // wave-uniform
+                            const float *wv = ipv + 2 * (g * VW);
+                            const float qv = (g & 1) ? q2k[g >> 1].y : q2k[g >> 1].x, hv = (g & 1) ? h[g >> 1].y : h[g >> 1].x;
+                            const float dnu = qv > 0.0f ? fmaf(qv - 1.0f, a1_it, hv) * rs : 0.0f;
+#pragma unroll
+                            for (int k = 0; k <= KO; k++) ga[k] = fmaf(dnu, wv[2 * k], ga[k]);
+                        }
+                    }
+                } else
+                for (int j0 = 0; j0 < J; j0 += 2) {
+                    const float *wv0 = ipv + 2 * (j0 * VW), *wv1 = ipv + 2 * (min(j0 + 1, J - 1) * VW);
+                    bl_f2 q2;
+                    q2.x = fmaxf(wv0[2 * (KO + 1)], 0.0f);
+                    q2.y = j0 + 1 < J ? fmaxf(wv1[2 * (KO + 1)], 0.0f) : 0.0f;
+                    if (!__any(fmaxf(q2.x, q2.y) > 0.0f)) continue;
+                    bl_f2 b = bl2(0.0f), h = bl2(0.0f);
+                    if (deep) {
+                        const bl_f2 qq = q2 * q2, q4 = qq * qq, q8 = q4 * q4;
+                        const bl_f2 b8 = ((q2 + bl2(1.0f)) * (qq + bl2(1.0f))) * (q4 + bl2(1.0f));
+                        bl_f2 B = bl2(0.0f);
+                        for (int s = 0; __any(s < ch); s++) {
+                            const bl_f2 Bn = bl_fma2(B, q8, bl2(1.0f));
+                            B = s < ch ? Bn : B;
+                        }
+                        b = b8 * B;
+                    }
+#pragma unroll
+                    for (int n = 0; n < BL_RN_CH; n++) {
+                        b = bl_fma2(b, q2, bl2(1.0f));
+                        h = bl_fma2(bl2(LP[n]), bl_rcp_2(b), h);
+                    }
+                    const float dnu0 = q2.x > 0.0f ? fmaf(q2.x - 1.0f, a1_it, h.x) * rs : 0.0f;
+                    const float dnu1 = q2.y > 0.0f ? fmaf(q2.y - 1.0f, a1_it, h.y) * rs : 0.0f;
+#pragma unroll
+                    for (int k = 0; k <= KO; k++) ga[k] = fmaf(dnu0, wv0[2 * k], ga[k]);
+#pragma unroll
+                    for (int k = 0; k <= KO; k++) ga[k] = fmaf(dnu1, wv1[2 * k], ga[k]);
+                }
+                BL_RN_T(6)
+                first = last;
+                base += nitems;
+                bl_wave_lds_fence(); // (the next round rewrites the item map and the combine table)
+            }
+            // ---- back in the site's lane: log-lik, E[n | y], the non-detections' rank-1 gradient ----
+            float4 res = *reinterpret_cast<const float4 *>(sres + lane * 4);
+            if (!has) res = make_float4(0.0f, 1.0f, 0.0f, 0.0f); // (no item wrote this lane's slot)
+            const float en_post = res.z * __builtin_amdgcn_rcpf(res.y);
+            ll_s += BL_LN2 * (res.x + __builtin_amdgcn_logf(res.y)) - log_z;
+            deta += en_post - en_prior;
+            const float enl = live * en_post;
+#pragma unroll
+            for (int k = 0; k <= KO; k++) ga[k] = fmaf(enl, Rv[k], ga[k]);
+            BL_RN_T(7)
+        }
+        deta *= live;
+        ll = fmaf(live, ll_s, ll);
+        gb[0] += deta;
+#pragma unroll
+        for (int k = 0; k < KS; k++) gb[k + 1] = fmaf(deta, x[k], gb[k + 1]);
+    }
+}

@@ -299,6 +299,16 @@ int bl_comm_destroy(bl_comm *comm);
  */
 int bl_gather_draws(bl_comm *const *comms, bl_dataset *const *datasets, int n_local, const int32_t *chains_per_rank,
                     bl_nuts_output *out);
+/*
+ * The host-only half of the gather (no GPU, no RCCL needed; what a machine without GPUs can test of the N > 1 path).
+ * bl_result_block_layout: byte offsets of {draws, diverging, num_steps, accept_prob, potential_energy, step_size, inv_mass,
+ * n_leapfrog, end} inside ONE rank's result block for `chains` chains of `num_samples` draws of D coordinates.
+ * bl_gather_unpack: scatters a gathered buffer -- the world blocks back to back in rank order, exactly what
+ * bl_gather_draws receives on the device -- into the caller's arrays, the chains in rank order.
+ */
+int bl_result_block_layout(int chains, int num_samples, int D, uint64_t *offsets /*[9]*/);
+int bl_gather_unpack(const void *gathered, uint64_t gathered_bytes, int world, const int32_t *chains_per_rank,
+                     int num_samples, int D, bl_nuts_output *out);
 
 /* The engine's xoshiro128++ streams (host-side; no GPU needed): out[nstreams][4]. */
 int bl_rng_streams(uint64_t seed, int chain, int nstreams, uint32_t *out);

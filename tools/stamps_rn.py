@@ -16,7 +16,7 @@ print(f"k={r.wgs_per_chain} kernel {r.kernel_ms:.1f} ms ticks {ticks} cycles/tic
 for n, v in zip(["decide", "wait compute", "wg partial+publish", "sweep(poll)", "spec", "barrier2"], c[:6]):
     print(f"    {n:30s} {v / max(ticks, 1):8.0f} cyc  {100.0 * v / tot:5.1f} %")
 print(f"    site evaluation (compute wave 1): {int(c[20])} passes, {c[21] / max(float(c[20]), 1.0):.0f} cyc each")
-names=["prior","A0","bounds+scan","A1","A1b floors","B","C rank1+floors","C det groups"]
+names=["x, eta, prior","A0 visits (lane = site)","bounds, cutoff bisection, records, scan","item map + record reads","LP init + A1","floors + B + combine","floor grads + C","site results"]
 n=max(int(c[20]),1)
 for i,nm in enumerate(names): print(f"      {nm:18s} {c[22+i]/n:8.0f} cyc")
 print("      sum", c[22:30].sum()/n)
