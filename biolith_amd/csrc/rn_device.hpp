@@ -239,10 +239,17 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
             int nch = has ? 1 : 0;
             {
                 const bool okB = lam - 0.9f + shiftB >= thr;
-                bool need = has;
-                for (int c = 1; c <= cK && __any(need); c++) {
+                auto need_chunk = [&](int c) -> bool {
                     const float tn = (float)(c * BL_RN_CH + 1), lg = lgt[c * BL_RN_CH];
-                    need = need && ((ea >= tn) || (fmaf(tn, a, -lg) >= thr) || (okB && lam >= tn) || (fmaf(tn, eta, -lg) + shiftB >= thr));
+                    return (ea >= tn) || (fmaf(tn, a, -lg) >= thr) || (okB && lam >= tn) || (fmaf(tn, eta, -lg) + shiftB >= thr);
+                };
+                // (chunks 1 and 2 are tested unconditionally -- their table reads and compares go out together -- the rest by the loop)
+                bool need = has && cK >= 1 && need_chunk(1);
+                nch += need ? 1 : 0;
+                need = need && cK >= 2 && need_chunk(2);
+                nch += need ? 1 : 0;
+                for (int c = 3; c <= cK && __any(need); c++) {
+                    need = need && need_chunk(c);
                     nch += need ? 1 : 0;
                 }
             }
@@ -311,11 +318,9 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                             B[g] = bl2(0.0f);
                         }
                         for (int s = 0; __any(s < ch); s++) {
-                            const bool on = s < ch;
+                            if (s < ch) { // (exec-masked: the lanes with fewer steps sit this one out)
 #pragma unroll
-                            for (int g = 0; g < 5; g++) {
-                                const bl_f2 Bn = bl_fma2(B[g], q8[g], bl2(1.0f));
-                                B[g] = on ? Bn : B[g];
+                                for (int g = 0; g < 5; g++) B[g] = bl_fma2(B[g], q8[g], bl2(1.0f));
                             }
                         }
 #pragma unroll
@@ -323,13 +328,14 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                     }
 #pragma unroll
                     for (int n = 0; n < BL_RN_CH; n++) {
+                        float rp[5]; // 1 / (b_x b_y) of every pair: ONE reciprocal serves both visits (1 / b_x = b_y rp), and prod_j 1 / b_j = prod rp
 #pragma unroll
                         for (int g = 0; g < 5; g++) {
                             b2[g] = bl_fma2(b2[g], q2k[g], bl2(1.0f));
-                            rb[n][g] = bl_rcp_2(b2[g]);
+                            rp[g] = __builtin_amdgcn_rcpf(b2[g].x * b2[g].y);
+                            rb[n][g] = bl_f2{b2[g].y, b2[g].x} * bl2(rp[g]);
                         }
-                        const bl_f2 pp = ((rb[n][0] * rb[n][1]) * (rb[n][2] * rb[n][3])) * rb[n][4];
-                        LP[n] -= __builtin_amdgcn_logf(pp.x * pp.y);
+                        LP[n] -= __builtin_amdgcn_logf(((rp[0] * rp[1]) * (rp[2] * rp[3])) * rp[4]);
                     }
                 } else
                 for (int j0 = 0; j0 < J; j0 += BL_RN_GA) {
@@ -355,11 +361,9 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                             B[g] = bl2(0.0f);
                         }
                         for (int s = 0; __any(s < ch); s++) {
-                            const bool on = s < ch;
+                            if (s < ch) { // (exec-masked: the lanes with fewer steps sit this one out)
 #pragma unroll
-                            for (int g = 0; g < 5; g++) {
-                                const bl_f2 Bn = bl_fma2(B[g], q8[g], bl2(1.0f));
-                                B[g] = on ? Bn : B[g];
+                                for (int g = 0; g < 5; g++) B[g] = bl_fma2(B[g], q8[g], bl2(1.0f));
                             }
                         }
 #pragma unroll
@@ -415,8 +419,19 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                 }
                 const float a1_it = a1;
                 float m_s = m_it, f_it = 1.0f; // f_it: the item's weights relative to the site's best term
+                if (multi) *reinterpret_cast<float4 *>(comb + lane * 4) = make_float4(m_it, S, a1, 0.0f);
+                // (pass C's dot products need the item's own weights only: they run here, in the shadow of that LDS round trip)
+                bl_f2 h[5];
+                if (one_group) {
+#pragma unroll
+                    for (int g = 0; g < 5; g++) h[g] = bl2(0.0f);
+#pragma unroll
+                    for (int n = 0; n < BL_RN_CH; n++) {
+#pragma unroll
+                        for (int g = 0; g < 5; g++) h[g] = bl_fma2(bl2(LP[n]), rb[n][g], h[g]);
+                    }
+                }
                 if (multi) {
-                    *reinterpret_cast<float4 *>(comb + lane * 4) = make_float4(m_it, S, a1, 0.0f);
                     bl_wave_lds_fence();
                     for (int s = 0; __any(s < nc); s++) m_s = fmaxf(m_s, comb[(st + min(s, nc - 1)) * 4]);
                     f_it = __builtin_amdgcn_exp2f(m_it - m_s);
@@ -449,14 +464,6 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                 // ---- C: detection visits' d/dnu = sum_n w_n n q^n / b_n   (d log(1 - q^n) / dnu = n r q^n / (1 - q^n)), and
                 // q^n / b_n = 1 / b_n - r  (1 - q^n = r b_n):  sum_n (n w_n) / b_jn - r_j sum_n n w_n  -- no q^n recursion ----
                 if (one_group) {
-                    bl_f2 h[5];
-#pragma unroll
-                    for (int g = 0; g < 5; g++) h[g] = bl2(0.0f);
-#pragma unroll
-                    for (int n = 0; n < BL_RN_CH; n++) {
-#pragma unroll
-                        for (int g = 0; g < 5; g++) h[g] = bl_fma2(bl2(LP[n]), rb[n][g], h[g]);
-                    }
 #pragma unroll
                     for (int g = 0; g < BL_RN_GA; g++) {
                         if (g < J) { // wave-uniform
@@ -479,10 +486,8 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                         const bl_f2 qq = q2 * q2, q4 = qq * qq, q8 = q4 * q4;
                         const bl_f2 b8 = ((q2 + bl2(1.0f)) * (qq + bl2(1.0f))) * (q4 + bl2(1.0f));
                         bl_f2 B = bl2(0.0f);
-                        for (int s = 0; __any(s < ch); s++) {
-                            const bl_f2 Bn = bl_fma2(B, q8, bl2(1.0f));
-                            B = s < ch ? Bn : B;
-                        }
+                        for (int s = 0; __any(s < ch); s++)
+                            if (s < ch) B = bl_fma2(B, q8, bl2(1.0f));
                         b = b8 * B;
                     }
 #pragma unroll

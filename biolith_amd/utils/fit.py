@@ -165,17 +165,44 @@ def fit(
     use_rccl = explicit_devices and len(set(used)) == len(used)
     comms = []
     if use_rccl:
+        from .._ffi import BL_ERR_COMM, EngineError
         from ..distributed import comms_for_devices, gather_draws
 
-        comms = comms_for_devices(used)
+        try:
+            comms = comms_for_devices(used)
+        except EngineError as exc:
+            # librccl missing or communicator creation refused: the gather is a convenience of the multi-GPU form, not a
+            # requirement of the fit -- every shard is then fetched by itself and the chains are concatenated on the host
+            if exc.code != BL_ERR_COMM:
+                raise
+            import warnings
+
+            warnings.warn(f"fit(devices={devices}): no RCCL communicator ({exc}); gathering the chains on the host instead", RuntimeWarning)
+            use_rccl = False
+
+    def run_with_fallback():
+        # Joint sampling of several species needs all species' records in LDS for the chain count asked for; that is decided by the
+        # launch (geometry depends on num_chains), which refuses with BL_ERR_UNSUPPORTED before anything runs.  Plain occu then
+        # falls back to one dataset and one sampler per species, as documented above (same marginals).
+        nonlocal jobs, joint, n_units
+        try:
+            return run_all()
+        except NotImplementedError:
+            if not joint or spec.model != "occu":
+                raise
+            joint = False
+            jobs = make_jobs(False)
+            n_units = n_species
+            return run_all()
+
     try:
         if timeout is not None:
             from .misc import time_limit
 
             with time_limit(timeout):
-                results = run_all()
+                results = run_with_fallback()
         else:
-            results = run_all()
+            results = run_with_fallback()
     finally:
         for c in comms:
             c.close()

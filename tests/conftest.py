@@ -55,3 +55,24 @@ CFG2 = dict(n_sites=10000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site
 def cfg2_data():
     data, truth, _ = quiet_simulate(**CFG2)
     return data, truth
+
+
+# ---- HIP NUTS vs CPU-oracle NUTS on independent streams, >= 4 chains x 1000 draws ----
+PARITY_W, PARITY_S = 500, 2000          # warmup / draws per chain of the posterior-parity tests (4 chains each side)
+
+
+def posterior_parity(draws_gpu, draws_orc, ess_gpu=None):
+    """|mean_gpu - mean_oracle| <= 4 MCSE, 0.9 <= sd ratio <= 1.1, split R-hat < 1.01 (both sides) -- the tolerances SURVEY.md
+    section 8c states; the runs are long enough (4 x 2000 draws) for them to hold with room."""
+    import oracle
+    from biolith_amd.evaluation import effective_sample_size, split_gelman_rubin
+
+    D = draws_gpu.shape[-1]
+    fg, fo = draws_gpu.reshape(-1, D).astype(np.float64), np.asarray(draws_orc).reshape(-1, D)
+    ess_g = effective_sample_size(draws_gpu) if ess_gpu is None else ess_gpu
+    mcse = np.sqrt(fg.var(0) / ess_g + fo.var(0) / oracle.effective_sample_size(draws_orc))
+    assert np.all(np.abs(fg.mean(0) - fo.mean(0)) <= 4 * mcse), (fg.mean(0) - fo.mean(0), mcse)
+    ratio = fg.std(0) / fo.std(0)
+    assert np.all((ratio > 0.9) & (ratio < 1.1)), ratio
+    assert split_gelman_rubin(draws_gpu).max() < 1.01, split_gelman_rubin(draws_gpu)
+    assert oracle.split_gelman_rubin(np.asarray(draws_orc)).max() < 1.01

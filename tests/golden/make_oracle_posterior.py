@@ -4,7 +4,8 @@
 The oracle needs minutes at 10 000 sites, too slow for the test-suite, so its output is captured
 once here: MAP + Laplace sd (BFGS on the analytic gradient) and 4 chains x (1000 + 1000) of oracle
 NUTS.  GPU tests compare the HIP engine's full-size posterior with these numbers.
-Run:  python tests/golden/make_oracle_posterior.py [cfg2|cfg5]     (about a minute on 4 cores)
+Run:  python tests/golden/make_oracle_posterior.py [cfg2|cfg4|cfg5]     (about a minute on 4 cores; cfg4: a quarter of an hour)
+cfg4 = BASELINE.json configs[3]: occu_rn, simulate_rn(5000 sites x 10 visits, 3 + 3 covariates), max_abundance 100, 4 chains x (500 + 500).
 cfg5 = the stacked-period stand-in of BASELINE.json configs[4] (2000 sites x 8 periods x 4 visits), 4 chains x (500 + 500).
 """
 import json
@@ -27,10 +28,23 @@ from conftest import CFG2, quiet_simulate  # noqa: E402
 CFG5 = dict(n_sites=2000, n_periods=8, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=28, session_duration=7)
 
 
+CFG4 = dict(n_sites=5000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7)
+
+
 def main(which="cfg2"):
-    cfg, W, S = (CFG2, 1000, 1000) if which == "cfg2" else (CFG5, 500, 500)
-    data, truth, _ = quiet_simulate(**cfg)
-    od = oracle.OracleData(data["site_covs"], data["obs_covs"], data["obs"])
+    cfg, W, S = {"cfg2": (CFG2, 1000, 1000), "cfg4": (CFG4, 500, 500), "cfg5": (CFG5, 500, 500)}[which]
+    if which == "cfg4":
+        import contextlib
+        import io
+
+        from biolith_amd.models import simulate_rn
+
+        with contextlib.redirect_stdout(io.StringIO()):
+            data, truth = simulate_rn(**cfg)
+        od = oracle.OracleData(data["site_covs"], data["obs_covs"], data["obs"], model="occu_rn")
+    else:
+        data, truth, _ = quiet_simulate(**cfg)
+        od = oracle.OracleData(data["site_covs"], data["obs_covs"], data["obs"])
     res = minimize(lambda t: od.potential_grad(t), np.zeros(od.D), jac=True, method="BFGS", options=dict(gtol=1e-6))
     h = 1e-5
     H = np.array([(od.potential_grad(res.x + h * e)[1] - od.potential_grad(res.x - h * e)[1]) / (2 * h) for e in np.eye(od.D)])
@@ -41,7 +55,8 @@ def main(which="cfg2"):
     draws = r["draws"]
     flat = draws.reshape(-1, od.D)
     X = data["site_covs"].astype(np.float32).astype(np.float64)
-    psi_mean_per_draw = (1 / (1 + np.exp(-(flat[:, :1] + flat[:, 1:4] @ X.T)))).mean(axis=1)
+    eta = flat[:, :1] + flat[:, 1:4] @ X.T
+    psi_mean_per_draw = (np.exp(eta) if which == "cfg4" else 1 / (1 + np.exp(-eta))).mean(axis=1)   # (cfg4: the mean abundance)
     out = dict(
         config=cfg, seed=0, chains=4, num_warmup=W, num_samples=S,
         U_at_rng1=float(od.potential_grad(np.random.default_rng(1).uniform(-2, 2, od.D))[0]),
@@ -51,7 +66,7 @@ def main(which="cfg2"):
         psi_mean=float(psi_mean_per_draw.mean()), psi_mean_sd=float(psi_mean_per_draw.std()),
         step_size=r["step_size"].tolist(), inv_mass=r["inv_mass"].tolist(),
         mean_num_steps=float(r["num_steps"].mean()), n_leapfrog=r["n_leapfrog"].tolist(),
-        diverging=int(r["diverging"].sum()), true_mean_z=float(truth["z"].mean()),
+        diverging=int(r["diverging"].sum()), true_mean_z=float(np.mean(truth["abundance"] if which == "cfg4" else truth["z"])),
         oracle_wall_s=wall, oracle_threads=int(r["threads"]),
     )
     with open(os.path.join(HERE, f"oracle_posterior_{which}.json"), "w") as f:

@@ -5,10 +5,9 @@ import pytest
 
 import oracle
 from biolith_amd.engine import OccuDataset
-from biolith_amd.evaluation import split_gelman_rubin
 from biolith_amd.models import occu_cs, simulate_cs
 from biolith_amd.utils import fit
-from conftest import load_golden
+from conftest import PARITY_S, PARITY_W, load_golden, posterior_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -51,14 +50,9 @@ def test_cs_posterior_matches_oracle():
     g = load_golden("cs_small_2x2")
     od = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], model="occu_cs")
     ds = OccuDataset(g["site_covs"], g["obs_covs"], g["obs"], model="occu_cs")
-    o = oracle.nuts_run(od, 400, 500, num_chains=4, seed=0)
-    r = ds.nuts(num_warmup=400, num_samples=500, num_chains=4, seed=50)
-    fg, fo = r.draws.reshape(-1, od.D).astype(np.float64), o["draws"].reshape(-1, od.D)
-    mcse = np.sqrt(fg.var(0) / oracle.effective_sample_size(r.draws.astype(np.float64)) + fo.var(0) / oracle.effective_sample_size(o["draws"]))
-    assert np.all(np.abs(fg.mean(0) - fo.mean(0)) <= 4 * mcse), (fg.mean(0) - fo.mean(0), mcse)
-    ratio = fg.std(0) / fo.std(0)
-    assert np.all((ratio > 0.85) & (ratio < 1.18)), ratio
-    assert split_gelman_rubin(r.draws).max() < 1.03
+    o = oracle.nuts_run(od, PARITY_W, PARITY_S, num_chains=4, seed=0)
+    r = ds.nuts(num_warmup=PARITY_W, num_samples=PARITY_S, num_chains=4, seed=50)
+    posterior_parity(r.draws, o["draws"], ess_gpu=oracle.effective_sample_size(r.draws.astype(np.float64)))
 
 
 def test_occu_cs_like_reference():  # occu_cs.py:364-395

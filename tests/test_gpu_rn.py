@@ -5,10 +5,10 @@ import pytest
 
 import oracle
 from biolith_amd.engine import OccuDataset
-from biolith_amd.evaluation import effective_sample_size, split_gelman_rubin
+from biolith_amd.evaluation import split_gelman_rubin
 from biolith_amd.models import occu_rn, simulate_rn
 from biolith_amd.utils import fit
-from conftest import load_golden
+from conftest import PARITY_S, PARITY_W, load_golden, posterior_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -58,14 +58,9 @@ def test_rn_first_transitions_match_oracle():
 
 def test_rn_posterior_matches_oracle():
     _, od, ds = _pair("rn_small_2x2")
-    o = oracle.nuts_run(od, 300, 400, num_chains=4, seed=0)
-    r = ds.nuts(num_warmup=300, num_samples=400, num_chains=4, seed=50)
-    fg, fo = r.draws.reshape(-1, od.D).astype(np.float64), o["draws"].reshape(-1, od.D)
-    mcse = np.sqrt(fg.var(0) / effective_sample_size(r.draws) + fo.var(0) / oracle.effective_sample_size(o["draws"]))
-    assert np.all(np.abs(fg.mean(0) - fo.mean(0)) <= 4 * mcse), (fg.mean(0) - fo.mean(0), mcse)
-    ratio = fg.std(0) / fo.std(0)
-    assert np.all((ratio > 0.8) & (ratio < 1.25)), ratio
-    assert split_gelman_rubin(r.draws).max() < 1.03
+    o = oracle.nuts_run(od, PARITY_W, PARITY_S, num_chains=4, seed=0)
+    r = ds.nuts(num_warmup=PARITY_W, num_samples=PARITY_S, num_chains=4, seed=50)
+    posterior_parity(r.draws, o["draws"])
 
 
 def test_occu_rn_like_reference():  # occu_rn.py:361-388 (simulate_rn default: 100 sites x 52 visits)
@@ -96,6 +91,66 @@ def test_rn_config4_runs_and_recovers_truth():
     assert split_gelman_rubin(res.mcmc.get_samples(group_by_chain=True)["beta"]).max() < 1.05
     print("cfg4 kernel ms", res.mcmc.result.kernel_ms, "leapfrogs", res.mcmc.result.n_leapfrog.sum(),
           "us/leapfrog/chain", res.mcmc.result.kernel_ms * 1e3 / (res.mcmc.result.n_leapfrog.sum() / 4))
+
+
+def _cfg4():
+    import contextlib
+    import io
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        return simulate_rn(n_sites=5000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7)
+
+
+def test_rn_config4_full_size_against_oracle():
+    """BASELINE config 4 at full size against the float64 oracle (one oracle evaluation costs about 50 ms here): K1 at the stated
+    1e-5 / 1e-4 near the generating parameters and over init_to_uniform's box, then the sampler on shared streams -- the step
+    sizes after ten adaptation steps from the generating parameters, the next trees and the first draw."""
+    data, truth = _cfg4()
+    od = oracle.OracleData(data["site_covs"], data["obs_covs"], data["obs"], model="occu_rn")
+    ds = OccuDataset(data["site_covs"], data["obs_covs"], data["obs"], model="occu_rn")
+    th0 = np.concatenate([truth["beta"][0], truth["alpha"][0]]).astype(np.float32).astype(np.float64)
+    th = np.concatenate([th0[None] + np.random.default_rng(0).normal(0, 0.1, size=(3, 8)), np.random.default_rng(1).uniform(-2, 2, size=(3, 8))])
+    th = th.astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= 1e-5, (Ug, Uo)
+    assert np.all(np.abs(Gg - Go).max(1) <= 1e-4 * np.abs(Go).max(1)), np.abs(Gg - Go).max(1) / np.abs(Go).max(1)
+    init = np.tile(th0, (2, 1))
+    o = oracle.nuts_run(od, 10, 3, num_chains=2, seed=3, init=init)
+    r = ds.nuts(num_warmup=10, num_samples=3, num_chains=2, seed=3, init_theta=init)
+    assert r.lds_staged and r.wgs_per_chain >= 16
+    assert np.allclose(o["step_size"], r.step_size, rtol=5e-3), (o["step_size"], r.step_size)
+    assert np.array_equal(o["num_steps"][:, :2], r.num_steps[:, :2]), (o["num_steps"], r.num_steps)
+    assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=5e-3)
+
+
+def test_rn_config4_posterior_against_oracle_fixture():
+    """4 chains x (500 + 500) at full size against the oracle's captured posterior (tests/golden/oracle_posterior_cfg4.json, made
+    by make_oracle_posterior.py cfg4: a quarter of an hour of CPU, so a fixture)."""
+    import json
+    import os
+
+    from conftest import GOLDEN
+
+    data, truth = _cfg4()
+    fx = json.load(open(os.path.join(GOLDEN, "oracle_posterior_cfg4.json")))
+    ds = OccuDataset(data["site_covs"], data["obs_covs"], data["obs"], model="occu_rn")
+    r = ds.nuts(num_warmup=fx["num_warmup"], num_samples=fx["num_samples"], num_chains=4, seed=0)
+    assert r.diverging.sum() == 0
+    flat = r.draws.reshape(-1, 8).astype(np.float64)
+    from biolith_amd.evaluation import effective_sample_size
+
+    mcse = np.sqrt(flat.var(0) / effective_sample_size(r.draws) + np.array(fx["sd"]) ** 2 / np.array(fx["ess"]))
+    assert np.all(np.abs(flat.mean(0) - fx["mean"]) <= 4 * mcse), (flat.mean(0) - fx["mean"], mcse)
+    assert np.all(np.abs(flat.std(0) / fx["sd"] - 1) < 0.1), flat.std(0) / fx["sd"]
+    assert np.all(np.abs(flat.mean(0) - fx["map"]) < 3 * np.array(fx["laplace_sd"]))  # SURVEY 8c(4)
+    assert split_gelman_rubin(r.draws).max() < 1.01
+    assert abs(r.num_steps.mean() / fx["mean_num_steps"] - 1) < 0.15
+    assert abs(np.log(r.step_size.mean() / np.mean(fx["step_size"]))) < 0.2
+    X = data["site_covs"].astype(np.float32).astype(np.float64)
+    lam_mean = np.exp(flat[::10, :1] + flat[::10, 1:4] @ X.T).mean()
+    assert abs(lam_mean - fx["psi_mean"]) < 4 * fx["psi_mean_sd"] / np.sqrt(100) + 2e-3    # (psi_mean: the mean abundance here)
+    assert np.allclose(lam_mean, truth["abundance"].mean(), rtol=0.1)  # occu_rn.py:368-372
 
 
 def test_rn_nondetection_clamp_regime():

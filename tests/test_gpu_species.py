@@ -79,6 +79,20 @@ def test_joint_chain_and_species_by_species_have_the_same_marginals():
     assert abs(float(a.samples["psi"].mean()) - truth["z"].mean()) < 0.1
 
 
+def test_joint_species_too_large_for_lds_falls_back_to_species_by_species():
+    """the joint form needs all species' records in LDS for the chain count asked for, which only the launch can
+    tell (16 chains leave a chain 16 workgroups: three species' 10 000-site records do not fit them).  fit() then samples the
+    species one by one -- the same result, bit for bit, as asking for that form -- instead of failing."""
+    data, truth = simulate(n_species=3, n_sites=10000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=35, session_duration=7, random_seed=2)
+    kw = dict(num_chains=16, num_samples=60, num_warmup=60)
+    a = fit(occu, **data, **kw)
+    b = fit(occu, **data, **kw, joint_species=False)
+    assert a.mcmc.result.draws.shape == (16, 60, 3 * 8)
+    assert np.array_equal(a.mcmc.result.draws, b.mcmc.result.draws)
+    few = fit(occu, **data, num_chains=2, num_samples=20, num_warmup=20)      # two chains: the joint form fits and is used
+    assert few.mcmc.result.step_size.shape == (2,)
+
+
 def test_false_positive_rate_shared_across_species():
     """occu.py:146-157: prob_fp_constant sits outside the species plate -- one rate for all species, sampled with them."""
     data, truth = simulate(n_species=2, n_sites=300, deployment_days_per_site=84, prob_fp_constant=0.1, random_seed=3)
