@@ -66,9 +66,17 @@ WORKLOADS = {
                          metric="effective samples/sec (psi) for occu NUTS, 2k sites x 8 stacked periods x 4 visits (configs[4] stand-in: "
                                 "no reference counterpart for the dynamic model)",
                          text="biolith simulate(n_sites=2000, n_periods=8, n_site_covs=3, n_obs_covs=3, 4 visits per period, seed 0); fit(occu)"),
+    # ... and the dynamic model itself, BUILDER-DEFINED (models/occu_dyn.py, csrc/dyn_device.hpp): initial occupancy, colonisation,
+    # extinction, the latent paths summed by the forward recursion in the kernel.  Parity against the builder's own oracle only.
+    "occu_dyn": dict(model="occu_dyn", cfg=dict(n_sites=2000, n_periods=8, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=28,
+                                                 session_duration=7, random_seed=0),
+                     num_warmup=1000, num_samples=1000, cpu_sample=(100, 100), site="psi",
+                     metric="effective samples/sec (initial psi) for dynamic-occupancy NUTS (colonisation / extinction, forward algorithm), "
+                            "2k sites x 8 seasons x 4 visits (configs[4] as worded: builder-defined model, no reference counterpart)",
+                     text="biolith_amd simulate_dyn(n_sites=2000, n_periods=8, n_site_covs=3, n_obs_covs=3, 4 visits per season, seed 0); fit(occu_dyn)"),
 }
 # (workload, timed steps, untimed steps) appended to the default run's line; each with a bounded cpu_baseline
-SECONDARY = (("occu_rn", 3, 1), ("occu_re", 2, 1), ("occu_stacked", 3, 1))
+SECONDARY = (("occu_rn", 3, 1), ("occu_re", 2, 1), ("occu_stacked", 3, 1), ("occu_dyn", 3, 1))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Transcendental (v_exp / v_log / v_rcp ...) issue rate: quarter rate, 16 lanes per SIMD per cycle, 4 SIMDs per CU, 2.4 GHz
 # (MI355X_MICROARCH.md) = 153.6 G per second per CU; 256 CUs.
@@ -340,7 +348,7 @@ def main(argv=None):
     from biolith_amd.distributed import comm_from_env, gather_draws, rccl_version
     from biolith_amd.engine import OccuDataset
     from biolith_amd.evaluation import effective_sample_size, split_gelman_rubin
-    from biolith_amd.models import simulate, simulate_rn
+    from biolith_amd.models import simulate, simulate_dyn, simulate_rn
 
     stream = torch.cuda.current_stream().cuda_stream
     # the data-path communicator: the engine's own (librccl behind the C-ABI); made before the timed region, cost reported
@@ -358,7 +366,7 @@ def main(argv=None):
         wl = WORKLOADS[name]
         NUM_WARMUP, NUM_SAMPLES = wl["num_warmup"], wl["num_samples"]
         with contextlib.redirect_stdout(io.StringIO()):
-            data, truth = (simulate_rn if wl["model"] == "occu_rn" else simulate)(**wl["cfg"])
+            data, truth = {"occu_rn": simulate_rn, "occu_dyn": simulate_dyn}.get(wl["model"], simulate)(**wl["cfg"])
         X = np.asarray(data["site_covs"], dtype=np.float32).astype(np.float64)
         ds = OccuDataset(data["site_covs"], data["obs_covs"], data["obs"], device=local_rank,
                          model=wl["model"], **wl.get("options", {}))  # resident in HBM from here on
@@ -440,8 +448,8 @@ def main(argv=None):
         # random effects: <covariate capacity, model kind, rows in LDS, sampler-vector tier in LDS>
         kernel_name = (f"bl_re_nuts_kernel<{4 if max(ds.Ks, ds.Ko) <= 4 else 16}, 0, {'true' if res0.lds_staged else 'false'}, {res0.lds_vector_tier}>"
                        if wl["model"] == "occu_re" else
-                       # <KS, KO, LDS-staged, model id, compute waves>: occu = 0; occu_rn = 1
-                       f"bl_nuts_kernel<{ds.Ks}, {ds.Ko}, true, {1 if wl['model'] == 'occu_rn' else 0}, {res0.threads_per_wg // 64 - 1}>")
+                       # <KS, KO, LDS-staged, model id, compute waves>: occu = 0; occu_rn = 1; dynamic occupancy = 8
+                       f"bl_nuts_kernel<{ds.Ks}, {ds.Ko}, true, {dict(occu_rn=1, occu_dyn=8).get(wl['model'], 0)}, {res0.threads_per_wg // 64 - 1}>")
         us_leap = 1e3 * kernel_ms_mean / (leap_mean / CHAINS_PER_GPU)
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -546,6 +554,8 @@ def main(argv=None):
                 entry = {"workload": name, "metric": o2["metric"], "value": o2["value"], "unit": o2["unit"], "steps": k_steps, "warmup": k_warm,
                          "ms_per_step": o2["ms_per_step"], "us_per_leapfrog_per_chain": o2["roofline"]["us_per_leapfrog_per_chain"],
                          "dtype": "f32", "config": o2["config"], "roofline": o2["roofline"], "sampler": o2["sampler"], "ess": o2["ess"]}
+                if name == "occu_dyn":
+                    entry["reference_counterpart"] = "none: builder-defined model (models/occu_dyn.py); parity against the builder's own oracle only"
                 if name == "occu_stacked":
                     entry["reference_counterpart"] = "none for BASELINE.json configs[4] as worded (dynamic colonisation / extinction); this is the stacked-period form of occu.py:198-210 at its size"
                 if not args.no_cpu_baseline:

@@ -62,7 +62,7 @@ class bl_nuts_output(C.Structure):
 
 # every symbol include/biolith_hip.h declares (tests check the library exports each one)
 EXPORTS = (
-    "bl_abi_version", "bl_last_error", "bl_device_count", "bl_dataset_create", "bl_dataset_create_rn", "bl_dataset_destroy",
+    "bl_abi_version", "bl_last_error", "bl_device_count", "bl_dataset_create", "bl_dataset_create_rn", "bl_dataset_create_dyn", "bl_dataset_destroy",
     "bl_dataset_param_dim", "bl_logp_grad", "bl_nuts_run", "bl_nuts_launch", "bl_nuts_poll",
     "bl_nuts_abort", "bl_nuts_wait", "bl_nuts_fetch", "bl_nuts_elapsed_ms", "bl_nuts_device_draws",
     "bl_nuts_geometry", "bl_nuts_debug_counters", "bl_deterministic", "bl_predict", "bl_predict_counts", "bl_predict_scores", "bl_dataset_create_fp", "bl_dataset_create_cop", "bl_dataset_create_nmix", "bl_dataset_create_re", "bl_dataset_create_cs", "bl_dataset_set_prior_family", "bl_rng_streams", "bl_adaptation_schedule",
@@ -96,6 +96,8 @@ def load():
                                         C.POINTER(bl_normal_prior), C.c_int, C.POINTER(vp)]
         L.bl_dataset_create_rn.argtypes = [C.POINTER(bl_dims), fp, fp, fp, C.c_int, C.POINTER(bl_normal_prior),
                                            C.POINTER(bl_normal_prior), C.c_int, C.POINTER(vp)]
+        L.bl_dataset_create_dyn.argtypes = [C.POINTER(bl_dims), fp, fp, fp, C.POINTER(bl_normal_prior),
+                                            C.POINTER(bl_normal_prior), C.c_int, C.POINTER(vp)]
         L.bl_dataset_create_fp.argtypes = [C.POINTER(bl_dims), fp, fp, fp, C.c_int, C.POINTER(bl_beta_prior),
                                            C.POINTER(bl_normal_prior), C.POINTER(bl_normal_prior), C.c_int, C.POINTER(vp)]
         L.bl_dataset_create_cop.argtypes = [C.POINTER(bl_dims), fp, fp, fp, fp, C.c_int, C.c_double,

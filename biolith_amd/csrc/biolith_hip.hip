@@ -326,6 +326,7 @@ extern "C" int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint6
 {
     if (!ds || !draws || n_draws <= 0 || (!latent && !y)) return bl_fail(BL_ERR_INVALID, "bl_predict: bad argument");
     if (ds->nsp > 1) return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: a joint-species handle samples; predict from one handle per species");
+    if (ds->model == 8) return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: not built for the dynamic occupancy model");
     if (ds->model == 3 || ds->model == 4)
         return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: the count models (occu_cop, nmixture) use bl_predict_counts");
     if (ds->model == 6 && ds->re.kind == 1)
@@ -602,6 +603,15 @@ extern "C" int bl_dataset_create_rn(const bl_dims *dims, const float *site_covs,
     return dataset_create_impl(mo, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
 }
 
+extern "C" int bl_dataset_create_dyn(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
+                                     const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha, int device, bl_dataset **out)
+{
+    if (dims && dims->n_site_covs > BL_DYN_MAX_KS)
+        return bl_fail(BL_ERR_UNSUPPORTED, "dynamic occupancy: at most %d site covariates (three coefficient blocks), got %d", BL_DYN_MAX_KS, dims->n_site_covs);
+    ModelOpts mo; mo.model = 8; // (6 names the random-effects / occu_cs handles)
+    return dataset_create_impl(mo, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
+}
+
 extern "C" int bl_dataset_create_fp(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
                                     int fp_mode, const bl_beta_prior *prior_fp, const bl_normal_prior *prior_beta,
                                     const bl_normal_prior *prior_alpha, int device, bl_dataset **out)
@@ -653,6 +663,7 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
     // Several species in ONE handle = one chain over all species' coefficients (the species plate of occu.py:182-186 under one
     // NUTS, with a false-positive rate shared across species, occu.py:146-157): the LDS-staged occu / false-positive forms only.
     if (S < 1) return bl_fail(BL_ERR_INVALID, "n_species=%d", S);
+    if (model == 8 && S != 1) return bl_fail(BL_ERR_UNSUPPORTED, "dynamic occupancy: one species per dataset");
     if (S > 1 && model != 0 && model != 2)
         return bl_fail(BL_ERR_UNSUPPORTED, "n_species=%d: joint sampling of several species is built for occu with or without false positives; "
                        "this model takes one species per dataset", S);
@@ -671,6 +682,7 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
     bl_dataset *ds = new bl_dataset();
     const int has_extra = (model == 2 || (model == 3 && mo.fp_mode != 0)) ? 1 : 0; // trailing false-positive coordinate
     ds->device = device; ds->dims = *dims; ds->Ks = Ks; ds->Ko = Ko; ds->D = S * (Ks + Ko + 2) + has_extra;
+    if (model == 8) ds->D = 3 * (Ks + 1) + Ko + 1; // dynamic occupancy: [b_psi | b_gamma | b_eps | alpha]
     ds->nsp = S;
     ds->model = model; ds->max_abundance = max_abundance;
     ds->fp_mode = mo.fp_mode; ds->fp_a = mo.fp_a; ds->fp_b = mo.fp_b;
@@ -821,6 +833,8 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
     dd.loc_a = (float)pa.loc; dd.isc2_a = (float)(1.0 / (pa.scale * pa.scale));
     dd.prior_const = S * ((Ks + 1) * std::log(pb.scale) + (Ko + 1) * std::log(pa.scale) + (Ks + Ko + 2) * 0.91893853320467274178);
     dd.n_species = S;
+    dd.dyn = model == 8 ? 1 : 0;
+    if (model == 8) dd.prior_const = 3 * (Ks + 1) * std::log(pb.scale) + (Ko + 1) * std::log(pa.scale) + ds->D * 0.91893853320467274178;
     dd.has_fp = has_extra ? model : 0; dd.fp_a = (float)mo.fp_a; dd.fp_b = (float)mo.fp_b;
     if (model == 3) {
         dd.prior_const -= cop_const;                        // the parameter-free part of the Poisson log-pmf
@@ -903,13 +917,14 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     int ncw = BL_CWAVES_RN, per_wg = 64;
     if (ds->model != 1) {
         ncw = ((N + 2 * 3 * 64 - 1) / (2 * 3 * 64) <= kmax) ? 3 : 4;
-        if (const char *e = getenv("BIOLITH_HIP_CWAVES")) { const int v = atoi(e); if (v == 3 || v == 4) ncw = v; } // A/B knob
+        if (const char *e = getenv("BIOLITH_HIP_CWAVES")) { const int v = atoi(e); if (v >= 3 && v <= 15) ncw = v; } // A/B knob (variant builds hold other counts)
         per_wg = 2 * ncw * 64;
     }
     int k = want_k > 0 ? want_k : (N + per_wg - 1) / per_wg;
     if (k > kmax) k = kmax;
     if (k < 1) k = 1;
-    const int rn_scratch = ds->model == 1 ? bl_rn_scratch_bytes(BL_CWAVES_RN) : 0; // behind the records
+    // behind the records: occu_rn's tables; the dynamic model's lane-private columns (sized for 4 compute waves: ncw is settled below)
+    const int rn_scratch = ds->model == 1 ? bl_rn_scratch_bytes(BL_CWAVES_RN) : (ds->model == 8 ? bl_dyn_scratch_bytes(ds->dims.n_periods, 4) : 0);
     const int lds_cap = BL_LDS_TOTAL - BL_OFF_DATA - rn_scratch;
     // LDS keeps one record of `stride` floats per PAIR of sites (occu_device.hpp)
     const int stride = bl_record_stride(ds->dims.n_periods, ds->dims.n_replicates, ds->KS, ds->ko_layout);
@@ -950,7 +965,7 @@ __global__ void bl_logp_final_kernel(BlDevData dd, int k, const double *theta, c
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int Dsp = dd.Ks + dd.Ko + 2, nsp = dd.n_species > 0 ? dd.n_species : 1;
-    const int D = nsp * Dsp + (dd.has_fp ? 1 : 0);
+    const int D = dd.dyn ? 3 * (dd.Ks + 1) + dd.Ko + 1 : nsp * Dsp + (dd.has_fp ? 1 : 0);
     const int lj = lane < nsp * Dsp ? lane % Dsp : lane; // index within the lane's species
     double acc = 0.0;
     if (lane <= D)
@@ -968,7 +983,7 @@ __global__ void bl_logp_final_kernel(BlDevData dd, int k, const double *theta, c
         pr = dd.fp_a * (fmax(-phi, 0.0) + l) + dd.fp_b * (fmax(phi, 0.0) + l);
         grad[(size_t)b * D + lane] = -acc + (dd.fp_a + dd.fp_b) * sig - dd.fp_a;
     } else if (lane < D) {
-        const bool is_b = lj <= dd.Ks;
+        const bool is_b = dd.dyn ? lane < 3 * (dd.Ks + 1) : lj <= dd.Ks;
         const double loc = is_b ? dd.loc_b : dd.loc_a, isc2 = is_b ? dd.isc2_b : dd.isc2_a, l1 = is_b ? dd.l1_b : dd.l1_a;
         const double dth = theta[(size_t)b * D + lane] - loc;
         pr = 0.5 * dth * dth * isc2 + fabs(dth) * l1; // Normal or Laplace (one of isc2, l1 is 0)
@@ -1665,6 +1680,7 @@ extern "C" int bl_deterministic(bl_dataset *ds, int n_draws, const float *draws,
 {
     if (!ds || !draws || n_draws <= 0) return bl_fail(BL_ERR_INVALID, "bl_deterministic: bad argument");
     if (ds->nsp > 1) return bl_fail(BL_ERR_UNSUPPORTED, "bl_deterministic: a joint-species handle samples; take the sites from one handle per species");
+    if (ds->model == 8) return bl_fail(BL_ERR_UNSUPPORTED, "bl_deterministic: the dynamic occupancy model's sites (psi, gamma, eps) are formed by the caller from the draws");
     if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
     int rc = set_device(ds);
     if (rc) return rc;

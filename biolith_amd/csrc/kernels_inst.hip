@@ -51,6 +51,13 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
 #endif
         return (int)hipErrorNotSupported;
     }
+    if (model == 8) { // dynamic occupancy (dyn_device.hpp): site-covariate capacities up to BL_DYN_MAX_KS
+#if BL_KS <= BL_DYN_MAX_KS
+        if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 8, 3);
+        if (staged && p->ncw == 4) return BL_PICK(bl_nuts_kernel, p, true, 8, 4);
+#endif
+        return (int)hipErrorNotSupported;
+    }
     if (model == 3) {
 #if BL_HAVE_RN
         if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 3, 3);
@@ -60,6 +67,9 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
     }
     if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 0, 3);
     if (staged && p->ncw == 4) return BL_PICK(bl_nuts_kernel, p, true, 0, 4);
+#ifdef BL_OCCU_CWX
+    if (staged && p->ncw == BL_OCCU_CWX) return BL_PICK(bl_nuts_kernel, p, true, 0, BL_OCCU_CWX);
+#endif
     if (!staged && p->ncw == 4) return BL_PICK(bl_nuts_kernel, p, false, 0, 4);
     return (int)hipErrorNotSupported;
 }
@@ -86,6 +96,13 @@ extern "C" int BL_NAME(bl_launch_logp, BL_KS, BL_KO)(const BlLogpParams *p, int 
 #endif
         return (int)hipErrorNotSupported;
     }
+    if (model == 8) {
+#if BL_KS <= BL_DYN_MAX_KS
+        if (staged && p->ncw == 3) return BL_PICK(bl_logp_kernel, p, true, 8, 3);
+        if (staged && p->ncw == 4) return BL_PICK(bl_logp_kernel, p, true, 8, 4);
+#endif
+        return (int)hipErrorNotSupported;
+    }
     if (model == 3) {
 #if BL_HAVE_RN
         if (staged && p->ncw == 3) return BL_PICK(bl_logp_kernel, p, true, 3, 3);
@@ -95,6 +112,9 @@ extern "C" int BL_NAME(bl_launch_logp, BL_KS, BL_KO)(const BlLogpParams *p, int 
     }
     if (staged && p->ncw == 3) return BL_PICK(bl_logp_kernel, p, true, 0, 3);
     if (staged && p->ncw == 4) return BL_PICK(bl_logp_kernel, p, true, 0, 4);
+#ifdef BL_OCCU_CWX
+    if (staged && p->ncw == BL_OCCU_CWX) return BL_PICK(bl_logp_kernel, p, true, 0, BL_OCCU_CWX);
+#endif
     if (!staged && p->ncw == 4) return BL_PICK(bl_logp_kernel, p, false, 0, 4);
     return (int)hipErrorNotSupported;
 }

@@ -42,12 +42,13 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_logp_kernel(const BlLogpPara
     if (tid < 64) sh_coef[tid] = 0.0f;
     __syncthreads();
     // (same lane -> coefficient / partial mapping as the NUTS kernel's control wave)
-    const bool has_phi = D > nsp * Dsp;
+    const bool has_phi = MODEL != 8 && D > nsp * Dsp;
     const int lsp = lane < nsp * Dsp ? lane / Dsp : 0, lj = lane - lsp * Dsp;
-    const int my_pos = lane < nsp * Dsp ? lsp * BL_SP_COEF(KS, KO) + bl_coef_pos(lj, Ks, Ko, KS, KO) : nsp * BL_SP_COEF(KS, KO) + 1;
-    const int part_pos = lane < nsp * Dsp ? lsp * BL_SP_PART(KS, KO) + bl_coef_pos(lj, Ks, Ko, KS, KO)
-                                          : ((has_phi && lane == D - 1) ? KS + KO + 3 : KS + KO + 2);
-    const bool part_all = lane >= nsp * Dsp;
+    int my_pos = lane < nsp * Dsp ? lsp * BL_SP_COEF(KS, KO) + bl_coef_pos(lj, Ks, Ko, KS, KO) : nsp * BL_SP_COEF(KS, KO) + 1;
+    int part_pos = lane < nsp * Dsp ? lsp * BL_SP_PART(KS, KO) + bl_coef_pos(lj, Ks, Ko, KS, KO)
+                                    : ((has_phi && lane == D - 1) ? KS + KO + 3 : KS + KO + 2);
+    if constexpr (MODEL == 8) my_pos = part_pos = bl_dyn_pos(lane < D ? lane : D, Ks, Ko, KS, KO); // dynamic occupancy (dyn_device.hpp)
+    const bool part_all = MODEL != 8 && lane >= nsp * Dsp;
     const int part_rs = nsp > 1 ? nsp * BL_SP_PART(KS, KO) : BL_PART_STRIDE;
     for (int b = 0; b < p.B; b++) {
         if (wave == 0 && lane < D) sh_coef[my_pos] = p.theta[(size_t)b * D + lane];

@@ -103,7 +103,8 @@ struct BlNutsParams {
     int fp_mode;                   // MODEL 2 / 3: 0 none, 1 = rate acts on every site ("constant"), 2 = on unoccupied sites only
     int max_depth;
     int max_abundance;             // occu_rn only (occu_rn.py:26)
-    int rn_off;                    // occu_rn only: byte offset in LDS of its scratch (lgamma table + wave-private tables), behind the records
+    int rn_off;                    // occu_rn: byte offset in LDS of its scratch (lgamma table + wave-private tables), behind the records;
+                                   // dynamic occupancy (MODEL 8): of its lane-private columns (dyn_device.hpp)
     int allow_local;               // 0: always use the placement-independent exchange
     int poll_sleep;                // s_sleep(1) repeats between re-polls (fabric form)
     int first_delay;               // s_sleep(1) repeats between publishing and the first poll
@@ -241,9 +242,14 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     const int lsp = lane < nsp * Dsp ? lane / Dsp : 0, lj = lane - lsp * Dsp;
     // where lane d's coefficient lives in the LDS coefficient block, and its partial in a wave's row of the partial table;
     // the log-lik (lane D) and the shared phi are sums over the species' slots (part_all)
-    const int my_pos = lane < nsp * Dsp ? lsp * BL_SP_COEF(KS, KO) + bl_coef_pos(lj, Ks, Ko, KS, KO) : nsp * BL_SP_COEF(KS, KO) + 1;
-    const int part_pos = lane < nsp * Dsp ? lsp * BL_SP_PART(KS, KO) + bl_coef_pos(lj, Ks, Ko, KS, KO) : (is_phi ? KS + KO + 3 : KS + KO + 2);
-    const bool part_all = lane >= nsp * Dsp;
+    int my_pos = lane < nsp * Dsp ? lsp * BL_SP_COEF(KS, KO) + bl_coef_pos(lj, Ks, Ko, KS, KO) : nsp * BL_SP_COEF(KS, KO) + 1;
+    int part_pos = lane < nsp * Dsp ? lsp * BL_SP_PART(KS, KO) + bl_coef_pos(lj, Ks, Ko, KS, KO) : (is_phi ? KS + KO + 3 : KS + KO + 2);
+    bool beta_lane = lj <= Ks;          // this coordinate takes beta's prior (else alpha's)
+    if constexpr (MODEL == 8) {         // dynamic occupancy: [b_psi | b_gamma | b_eps | alpha], its own layout (dyn_device.hpp)
+        my_pos = part_pos = bl_dyn_pos(lane < D ? lane : D, Ks, Ko, KS, KO);
+        beta_lane = lane < 3 * (Ks + 1);
+    }
+    const bool part_all = MODEL != 8 && lane >= nsp * Dsp;
     const int part_rs = nsp > 1 ? nsp * BL_SP_PART(KS, KO) : BL_PART_STRIDE;
     // ---- loop-carried registers: only what the per-leaf path touches ----
     BlRng rng_d, rng_u, rng_dir;        // per-dimension stream, transition uniforms, direction bits
@@ -300,9 +306,9 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 
     if (wave == 0) {
         S = cold->num_samples; W = cold->num_warmup; total = W + S;
-        prior_loc = (lj <= Ks) ? cold->loc_b : cold->loc_a;
-        prior_isc2 = act ? ((lj <= Ks) ? cold->isc2_b : cold->isc2_a) : 0.0f;
-        prior_l1 = act ? ((lj <= Ks) ? cold->l1_b : cold->l1_a) : 0.0f;
+        prior_loc = beta_lane ? cold->loc_b : cold->loc_a;
+        prior_isc2 = act ? (beta_lane ? cold->isc2_b : cold->isc2_a) : 0.0f;
+        prior_l1 = act ? (beta_lane ? cold->l1_b : cold->l1_a) : 0.0f;
         if (is_phi) { prior_loc = cold->fp_a; prior_isc2 = cold->fp_b; prior_l1 = 0.0f; }
         prior_const = cold->prior_const;
         const uint32_t *rs = cold->rng + ((size_t)chain * BL_NSTREAM + lane) * 4;

@@ -66,6 +66,7 @@ struct BlDevData {
     float l1_b, l1_a;                    // Laplace(loc, scale) prior: 1/scale (0 for a Normal prior); energy = dth^2 isc2 / 2 + |dth| l1
     double prior_const;                  // sum_k log(scale_k) + D/2 log(2 pi)  (+ log B(a,b) with has_fp)
     int n_species;                       // species sampled jointly (theta = [species 0: beta, alpha | species 1: ... | (phi)]); 0 reads as 1
+    int dyn;                             // 1: the dynamic occupancy model (theta = [b_psi | b_gamma | b_eps | alpha], dyn_device.hpp)
     int has_fp;                          // 0, or the model id (2: logit rate, Beta prior; 3: log rate, Exponential prior)
                                          // whose false-positive coordinate phi is theta's last entry
     float fp_a, fp_b;                    // its prior: Beta(a, b) / Exponential(rate = a)
@@ -898,6 +899,8 @@ __device__ __forceinline__ void bl_eval_sites_nmix(int ct, int pstride, int cnt,
 
 
 #include "rn_device.hpp" // occu_rn: work-proportional site evaluation (items of 8 terms of the sum over N)
+#include "dyn_device.hpp" // dynamic occupancy (builder-defined, BASELINE.json configs[4]): forward / backward recursions over the seasons
+#define BL_DYN_MAX_KS 8   // MODEL 8 is instantiated for site-covariate capacities up to 8 (three coefficient blocks share the 64-float coefficient block)
 
 // MODEL 0 = occu (occu.py); MODEL 1 = occu_rn (occu_rn.py) has its own entry, bl_eval_sites_rn (rn_device.hpp), called by bl_phase_a;
 // MODEL 2 (occu with false positives), 3 (occu_cop), 4 (nmixture) are dispatched by bl_phase_a below
@@ -962,7 +965,17 @@ __device__ __forceinline__ int bl_coef_pos(int d, int Ks, int Ko, int KS, int KO
 // theta dimension of a model: MODEL 2 always carries the false-positive coordinate, MODEL 3 when fp_mode != 0
 template <int MODEL> __device__ __forceinline__ int bl_model_dim(int Ks, int Ko, int fp_mode)
 {
+    if constexpr (MODEL == 8) return 3 * (Ks + 1) + Ko + 1; // [b_psi | b_gamma | b_eps | alpha]
     return Ks + Ko + 2 + ((MODEL == 2 || (MODEL == 3 && fp_mode != 0)) ? 1 : 0);
+}
+// MODEL 8: where coordinate d of theta lives in the coefficient block / a partial row (padded capacities KS, KO), and
+// whether it takes beta's prior; d == D names the log-likelihood's slot
+__device__ __forceinline__ int bl_dyn_pos(int d, int Ks, int Ko, int KS, int KO)
+{
+    const int B = Ks + 1;
+    if (d < 3 * B) { const int blk = d / B; return blk * (KS + 1) + (d - blk * B); }
+    if (d < 3 * B + Ko + 1) return BL_DYN_OA(KS) + (d - 3 * B);
+    return BL_DYN_LL(KS, KO);
 }
 // visit width of the records in floats minus one: the KO every layout helper is called with
 template <int MODEL> __device__ __forceinline__ constexpr int bl_layout_ko(int KO) { return KO + ((MODEL == 1 || MODEL == 3 || MODEL == 4) ? 1 : 0); }
@@ -1035,6 +1048,20 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         static_assert(LDS, "N-mixture model: LDS records only");
         bl_eval_sites_nmix<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, max_abundance, tab, tab_ld, beta, alpha, ll, gb, ga);
         bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga);
+    } else if constexpr (MODEL == 8) {
+        static_assert(LDS, "dynamic occupancy model: LDS records only");
+        if constexpr (KS <= BL_DYN_MAX_KS) {
+            const float *c = bl_lds_f(BL_OFF_COEF);
+            float bq[3][KS + 1], gq[3][KS + 1];
+#pragma unroll
+            for (int b = 0; b < 3; b++)
+#pragma unroll
+                for (int k = 0; k <= KS; k++) { bq[b][k] = c[b * (KS + 1) + k]; gq[b][k] = 0.0f; }
+#pragma unroll
+            for (int k = 0; k <= KO; k++) alpha[k] = c[BL_DYN_OA(KS) + k];
+            bl_eval_sites_dyn<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
+            bl_wave_partials_dyn<KS, KO>(cwave, ll, gq, ga);
+        }
     } else if constexpr (MODEL == 1) {
         static_assert(LDS, "Royle-Nichols model: LDS records only");
         bl_eval_sites_rn<KS, KO, CW>(cwave, ld_or_stride, cnt, T, J, max_abundance, rn_off, beta, alpha, ll, gb, ga);

@@ -118,7 +118,7 @@ class OccuDataset:
                  obs_random_effects: bool = False, prior_site_re_sd: float = 1.0, prior_obs_re_sd: float = 1.0,
                  prior_mu=((0.0, 10.0), (0.0, 10.0)), prior_sigma=((5.0, 1.0), (5.0, 1.0))):
         lib = _ffi.load()
-        if model not in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture", "occu_re", "occu_cs"):
+        if model not in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture", "occu_re", "occu_cs", "occu_dyn"):
             raise ValueError(f"unknown model {model!r}")
         if fp_mode not in ("constant", "unoccupied") and not (model == "occu_cop" and fp_mode is None):
             raise ValueError(f"unknown fp_mode {fp_mode!r}")
@@ -154,7 +154,13 @@ class OccuDataset:
         pb = _ffi.bl_normal_prior(float(prior_beta[0]), float(prior_beta[1]))
         pa = _ffi.bl_normal_prior(float(prior_alpha[0]), float(prior_alpha[1]))
         h = C.c_void_p()
-        if model == "occu_rn":
+        if model == "occu_dyn":
+            # builder-defined dynamic occupancy (no reference counterpart): theta = [b_psi | b_gamma | b_eps (Ks+1 each) | alpha (Ko+1)]
+            if self.S != 1:
+                raise NotImplementedError("occu_dyn: one species per dataset")
+            _ffi.check(lib.bl_dataset_create_dyn(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), C.byref(pb), C.byref(pa), device, C.byref(h)))
+            self.D = 3 * (Ks + 1) + Ko + 1
+        elif model == "occu_rn":
             _ffi.check(lib.bl_dataset_create_rn(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), int(max_abundance),
                                                 C.byref(pb), C.byref(pa), device, C.byref(h)))
         elif model == "nmixture":

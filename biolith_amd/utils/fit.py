@@ -243,6 +243,14 @@ def fit(
                 part.draws = np.ascontiguousarray(np.concatenate([jd[:, :, sp * Dsp:(sp + 1) * Dsp], jd[:, :, n_species * Dsp:]], axis=2))
             per_species.append((OccuDataset(spec.site_covs, spec.obs_covs, spec.obs[sp:sp + 1], spec.prior_beta, spec.prior_alpha,
                                             device=devices[0], model=spec.model, **engine_options(spec)), part))
+    if spec.model == "occu_dyn":
+        mcmc = _assemble_dyn(per_species[0], spec, num_warmup)
+        samples = rename_samples(mcmc.get_samples(), site_names, obs_names)
+        for prefix, base in (("cov_col_", "beta_col"), ("cov_ext_", "beta_ext")):   # the two extra predictors share the site covariates' names
+            block = samples.pop(base)
+            for i, name in enumerate(site_names):
+                samples[f"{prefix}{name}"] = block[..., i]
+        return FitResult(samples, mcmc)
     mcmc = _assemble(per_species, spec, num_warmup, joint_result)
     samples = rename_samples(mcmc.get_samples(), site_names, obs_names)
     return FitResult(samples, mcmc)
@@ -275,6 +283,27 @@ def _concat_chains(parts):
     res.kernel_ms = float(max(r.kernel_ms for r in parts))   # shards on different devices overlap
     res.chains_l2_local = int(sum(r.chains_l2_local for r in parts))
     return res
+
+
+def _assemble_dyn(ds_res, spec, num_warmup) -> HipMCMC:
+    """Dynamic occupancy (builder-defined, models/occu_dyn.py): theta = [b_psi | b_col | b_ext | alpha] -> sample sites, with the
+    species plate last as everywhere (one species); psi / gamma / epsilon per site are formed lazily on the host."""
+    ds0, res = ds_res
+    C, S, D = res.draws.shape
+    Ks, Ko, B = ds0.Ks, ds0.Ko, ds0.Ks + 1
+    blocks = [res.draws[:, :, b * B:(b + 1) * B][:, :, None, :] for b in range(3)]
+    latent = dict(beta=blocks[0], beta_col=blocks[1], beta_ext=blocks[2], alpha=res.draws[:, :, 3 * B:][:, :, None, :])
+    X = np.nan_to_num(np.asarray(spec.site_covs, dtype=np.float32))
+
+    def site(block):
+        def get():
+            b = block[:, :, 0, :].astype(np.float32)
+            eta = b[..., :1] + b[..., 1:] @ X.T
+            return (1.0 / (1.0 + np.exp(-eta)))[..., None].astype(np.float32)      # (C, S, N, species)
+        return get
+
+    return HipMCMC(res, latent=latent, deterministic=dict(psi=site(blocks[0]), gamma=site(blocks[1]), epsilon=site(blocks[2])),
+                   num_warmup=num_warmup, spec_shape=spec.shape)
 
 
 def _assemble(per_species, spec, num_warmup, joint_result=None) -> HipMCMC:

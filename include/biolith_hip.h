@@ -39,7 +39,9 @@ enum {
 
 /* Shapes as the reference names them (biolith/models/occu.py:116-133). */
 typedef struct bl_dims {
-    int32_t n_species;    /* S : must be 1 in this build (occu.py:182 plate "species")      */
+    int32_t n_species;    /* S : the "species" plate (occu.py:182).  S > 1 = ONE chain over all species' coefficients:
+                           *     bl_dataset_create / _fp (S (Ks + Ko + 2) (+ 1) <= 60 coordinates) and _re (S <= 8); the other
+                           *     models take one species per handle                                                       */
     int32_t n_sites;      /* N                                                               */
     int32_t n_periods;    /* T : stacked periods sharing psi (occu.py:198-210)               */
     int32_t n_replicates; /* J : visits per period                                           */
@@ -82,6 +84,17 @@ int bl_dataset_create(const bl_dims *dims, const float *site_covs, const float *
 int bl_dataset_create_rn(const bl_dims *dims, const float *site_covs, const float *obs_covs,
                          const float *obs, int max_abundance, const bl_normal_prior *prior_beta,
                          const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
+/*
+ * Dynamic (multi-season) occupancy -- BUILDER-DEFINED, NO REFERENCE COUNTERPART: BASELINE.json configs[4] names a model
+ * timmh/biolith does not have (its periods share one psi, models/occu.py:198-210).  Initial occupancy psi, colonisation gamma and
+ * extinction eps, each logit-linear in the site covariates; detection as in occu; the latent paths summed out by the forward
+ * recursion in the kernel (csrc/dyn_device.hpp).  theta = [b_psi | b_gamma | b_eps (n_site_covs + 1 each) | alpha (n_obs_covs + 1)],
+ * every coefficient under the Normal priors given (prior_beta for the three site-side blocks).  n_site_covs <= 8; one species.
+ * The handle serves bl_logp_grad and bl_nuts_*; deterministic sites are formed by the caller from the draws.
+ */
+int bl_dataset_create_dyn(const bl_dims *dims, const float *site_covs, const float *obs_covs,
+                          const float *obs, const bl_normal_prior *prior_beta,
+                          const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
 /*
  * Same for occu with a false-positive rate (models/occu.py:146-157, 229-241):
  *   P(y=1 | z) = 1 - (1 - z p)(1 - f_c)(1 - (1 - z) f_u),  exactly one of f_c / f_u sampled:
@@ -160,7 +173,10 @@ int bl_dataset_create_cs(const bl_dims *dims, const float *site_covs, const floa
 #define BL_PRIOR_LAPLACE 1
 int bl_dataset_set_prior_family(bl_dataset *ds, int family_beta, int family_alpha);
 int bl_dataset_destroy(bl_dataset *ds);
-/* D = Ks+1 + Ko+1; theta = [beta_0..beta_Ks, alpha_0..alpha_Ko] */
+/* Coordinates of theta.  occu / occu_rn / nmixture / occu_cop without a rate: D = Ks+1 + Ko+1, theta = [beta_0..beta_Ks,
+ * alpha_0..alpha_Ko]; with a false-positive coordinate (bl_dataset_create_fp, occu_cop with a rate): + 1 (trailing phi);
+ * S species under one chain: S (Ks + Ko + 2) (+ 1); dynamic occupancy: 3 (Ks + 1) + Ko + 1; occu_cs: Ks + Ko + 6; random
+ * effects: Ks + Ko + 2 + the log sds + 2 N (site effects) + N T J (observation effects), per species where S > 1. */
 int bl_dataset_param_dim(const bl_dataset *ds, int *D);
 
 /*

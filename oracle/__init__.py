@@ -17,6 +17,7 @@ from .oracle import (  # noqa: F401
     literal_log_joint,
     literal_log_joint_cop,
     literal_log_joint_cs,
+    literal_log_joint_dyn,
     literal_log_joint_fp,
     literal_log_joint_nmix,
     literal_log_joint_re,

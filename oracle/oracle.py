@@ -60,6 +60,7 @@ def lib():
             L.orc_data_set_re.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_prior_family.argtypes = [C.c_void_p, C.c_int, C.c_int]
             L.orc_data_set_cs.argtypes = [C.c_void_p, dp, dp, dp]
+            L.orc_data_set_dyn.argtypes = [C.c_void_p]
             L.orc_data_set_species.argtypes = [C.c_void_p, C.c_int, dp, C.POINTER(C.c_ubyte)]
             L.orc_potential_grad.restype = C.c_double
             L.orc_potential_grad.argtypes = [C.c_void_p, dp, dp]
@@ -121,7 +122,7 @@ class OracleData:
         self.X, self.W, self.Y = X, W, Y
         self.prior_beta, self.prior_alpha = tuple(prior_beta), tuple(prior_alpha)
         self.model, self.max_abundance = model, int(max_abundance)
-        assert model in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture", "occu_re", "occu_cs")
+        assert model in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture", "occu_re", "occu_cs", "occu_dyn")
         lib().orc_data_set_model(self._h, 1 if model == "occu_rn" else 0, int(max_abundance))
         if model == "occu_fp":  # theta gains phi = logit(false-positive rate) as its last coordinate
             assert fp_mode in ("constant", "unoccupied")
@@ -151,6 +152,10 @@ class OracleData:
             lib().orc_data_set_re(self._h, int(bool(site_random_effects)), int(bool(obs_random_effects)),
                                   float(prior_site_re_sd), float(prior_obs_re_sd))
             self.D = int(lib().orc_data_dim(self._h))
+        if model == "occu_dyn":
+            # builder-defined dynamic occupancy (no reference counterpart): theta = [b_psi | b_gamma | b_eps (Ks+1 each) | alpha (Ko+1)]
+            lib().orc_data_set_dyn(self._h)
+            self.D = 3 * (Ks + 1) + Ko + 1
         self.n_species = 1
         if Y_all is not None:
             # theta = [species 0: beta, alpha | species 1: ... | (phi)]; with random effects (set before the species, so that the
@@ -507,6 +512,50 @@ def literal_log_joint_nmix(theta, site_covs, obs_covs, obs, max_abundance=100, p
         return (-0.5 * ((v - loc) / scale) ** 2 - np.log(scale) - 0.5 * np.log(2 * np.pi)).sum()
 
     return ll + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
+
+
+def literal_log_joint_dyn(theta, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):
+    """The dynamic occupancy model (builder-defined: occu_oracle.c, potential_grad_dyn) stated literally: the log joint density of
+    theta and y with every latent path z_i1..z_iT summed by BRUTE FORCE over the 2^T paths (small T only).  Returns log p(theta, y)."""
+    import itertools
+
+    X, W, Y = _as_f32_f64(site_covs), _as_f32_f64(obs_covs), _as_f32_f64(obs)
+    if Y.ndim == 4:
+        Y = Y[0]
+    N, Ks = X.shape
+    _, T, J, Ko = W.shape
+    B = Ks + 1
+    th = np.asarray(theta, dtype=np.float64)
+    bp, bg, be, al = th[:B], th[B:2 * B], th[2 * B:3 * B], th[3 * B:]
+    mask = np.isfinite(Y) & ~np.isnan(W).any(-1) & ~np.isnan(X).any(-1)[:, None, None]
+    Xc, Wc = np.nan_to_num(X), np.nan_to_num(W)
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))  # noqa: E731
+    psi, gam, eps = sig(bp[0] + Xc @ bp[1:]), sig(bg[0] + Xc @ bg[1:]), sig(be[0] + Xc @ be[1:])
+    p = sig(al[0] + Wc @ al[1:])                                              # (N, T, J)
+    tiny = float(np.finfo(np.float32).tiny)
+    total = 0.0
+    for i in range(N):
+        terms = []
+        for z in itertools.product((0, 1), repeat=T):
+            lp = np.log(psi[i] if z[0] else 1.0 - psi[i])
+            for t in range(1, T):
+                pr1 = (1.0 - eps[i]) if z[t - 1] else gam[i]
+                lp += np.log(pr1 if z[t] else 1.0 - pr1)
+            for t in range(T):
+                for j in range(J):
+                    if not mask[i, t, j]:
+                        continue
+                    pd = p[i, t, j] if z[t] else tiny                         # P(y = 1 | z): numpyro's clamp at z = 0, as in occu
+                    lp += np.log(pd) if Y[i, t, j] != 0 else np.log1p(-pd)
+            terms.append(lp)
+        terms = np.array(terms)
+        total += terms.max() + np.log(np.exp(terms - terms.max()).sum())
+
+    def normal_logpdf(v, loc, scale):
+        return -0.5 * ((v - loc) / scale) ** 2 - np.log(scale) - 0.5 * np.log(2 * np.pi)
+
+    total += normal_logpdf(th[:3 * B], *prior_beta).sum() + normal_logpdf(al, *prior_alpha).sum()
+    return float(total)
 
 
 def literal_log_joint_rn(theta, site_covs, obs_covs, obs, max_abundance=100, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):
