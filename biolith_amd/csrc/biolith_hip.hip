@@ -901,6 +901,20 @@ extern "C" int bl_dataset_param_dim(const bl_dataset *ds, int *D)
 
 // Workgroups per chain / LDS staging decision.  One site per thread is the latency optimum
 // (DESIGN.md "geometry"); fall back to several sites per thread, then to un-staged HBM rows.
+// Dynamic occupancy: lanes that share one site pair (dyn_device.hpp) -- as many (a power of two, <= 8, <= the seasons) as the lanes of
+// the workgroups one XCD offers a chain allow at one pair per lane group.
+static int dyn_lanes_per_pair(const bl_dataset *ds, int chains)
+{
+    const int per_xcd = ((chains > 0 ? chains : 1) + 7) / 8;
+    const int kmax = std::max(1, 32 / per_xcd);
+    const long long npairs = (ds->dims.n_sites + 1) / 2;
+    int G = 1;
+    while (2 * G <= 8 && 2 * G <= ds->dims.n_periods) G *= 2;
+    while (G > 1 && npairs * G > (long long)kmax * 3 * 64) G >>= 1;
+    if (const char *e = getenv("BIOLITH_HIP_DYN_G")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) G = v; } // A/B knob
+    return G;
+}
+
 static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k_out, int *nloc_out, int *ld_out,
                             int *lds_bytes_out, int *staged_out, int *ncw_out, int *wide_out)
 {
@@ -919,6 +933,7 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
         ncw = ((N + 2 * 3 * 64 - 1) / (2 * 3 * 64) <= kmax) ? 3 : 4;
         if (const char *e = getenv("BIOLITH_HIP_CWAVES")) { const int v = atoi(e); if (v >= 3 && v <= 15) ncw = v; } // A/B knob (variant builds hold other counts)
         per_wg = 2 * ncw * 64;
+        if (ds->model == 8) { ncw = 3; per_wg = 2 * 3 * 64 / dyn_lanes_per_pair(ds, chains); } // one site pair per lane group
     }
     int k = want_k > 0 ? want_k : (N + per_wg - 1) / per_wg;
     if (k > kmax) k = kmax;
@@ -1016,6 +1031,7 @@ static hipError_t re_nuts_dispatch_lds(const BlReRun &run, int grid, size_t lds,
 }
 static hipError_t re_nuts_dispatch(int mk, const BlReRun &run, int grid, size_t lds, hipStream_t st)
 {
+    if (run.m.kind == 2) return mk == 4 ? re_nuts_dispatch_lds<4, 2>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 2>(run, grid, lds, st);
     if (mk == 4) return run.m.kind == 1 ? re_nuts_dispatch_lds<4, 1>(run, grid, lds, st) : re_nuts_dispatch_lds<4, 0>(run, grid, lds, st);
     return run.m.kind == 1 ? re_nuts_dispatch_lds<16, 1>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 0>(run, grid, lds, st);
 }
@@ -1054,10 +1070,41 @@ static size_t re_geometry(BlReModel &m, int nloc, int with_hot, int dl_max)
     return used + (m.lds_hot == 2 ? warm_bytes : (m.lds_hot == 1 ? hot_bytes : 0));
 }
 
+static int create_re_impl(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
+                          int site_random_effects, int obs_random_effects, double prior_site_re_sd_scale,
+                          double prior_obs_re_sd_scale, int fp_mode, double fp_a, double fp_b, const bl_normal_prior *prior_beta,
+                          const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
+
 extern "C" int bl_dataset_create_re(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
                                     int site_random_effects, int obs_random_effects, double prior_site_re_sd_scale,
                                     double prior_obs_re_sd_scale, const bl_normal_prior *prior_beta,
                                     const bl_normal_prior *prior_alpha, int device, bl_dataset **out)
+{
+    return create_re_impl(dims, site_covs, obs_covs, obs, site_random_effects, obs_random_effects, prior_site_re_sd_scale,
+                          prior_obs_re_sd_scale, 0, 0.0, 0.0, prior_beta, prior_alpha, device, out);
+}
+
+// occu(site_random_effects / obs_random_effects = True, false_positives_constant / _unoccupied = True): occu.py:146-157 with
+// :170-173, 191-196.  theta = [beta, alpha, phi = logit(rate), (log sds), (effects)]; one species.
+extern "C" int bl_dataset_create_re_fp(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
+                                       int site_random_effects, int obs_random_effects, double prior_site_re_sd_scale,
+                                       double prior_obs_re_sd_scale, int fp_mode, const bl_beta_prior *prior_fp,
+                                       const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha, int device, bl_dataset **out)
+{
+    if (fp_mode != BL_FP_CONSTANT && fp_mode != BL_FP_UNOCCUPIED)
+        return bl_fail(BL_ERR_INVALID, "fp_mode must be BL_FP_CONSTANT or BL_FP_UNOCCUPIED");
+    const double a = prior_fp ? prior_fp->a : 2.0, b = prior_fp ? prior_fp->b : 5.0;
+    if (!(a > 0.0) || !(b > 0.0) || !std::isfinite(a) || !std::isfinite(b)) return bl_fail(BL_ERR_INVALID, "Beta prior needs finite a, b > 0");
+    if (dims && dims->n_species != 1)
+        return bl_fail(BL_ERR_UNSUPPORTED, "random effects with a false-positive rate: one species per dataset (n_species=%d)", dims->n_species);
+    return create_re_impl(dims, site_covs, obs_covs, obs, site_random_effects, obs_random_effects, prior_site_re_sd_scale,
+                          prior_obs_re_sd_scale, fp_mode, a, b, prior_beta, prior_alpha, device, out);
+}
+
+static int create_re_impl(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
+                          int site_random_effects, int obs_random_effects, double prior_site_re_sd_scale,
+                          double prior_obs_re_sd_scale, int fp_mode, double fp_a, double fp_b, const bl_normal_prior *prior_beta,
+                          const bl_normal_prior *prior_alpha, int device, bl_dataset **out)
 {
     if (!site_random_effects && !obs_random_effects)
         return bl_fail(BL_ERR_INVALID, "bl_dataset_create_re: neither random effect requested (use bl_dataset_create)");
@@ -1076,14 +1123,16 @@ extern "C" int bl_dataset_create_re(const bl_dims *dims, const float *site_covs,
     bl_dataset *ds = *out;
     const int S = dims->n_species, N = dims->n_sites, T = dims->n_periods, J = dims->n_replicates, Ks = ds->Ks, Ko = ds->Ko;
     // draws: [species 0: beta, alpha | species 1: ... | log site_re_sd | log obs_re_sd | site_re_occ [S][N] | site_re_det [S][N] | obs_re [S][N][T][J]]
-    const long long Dll = (long long)S * (Ks + Ko + 2) + (site_random_effects ? 1 + 2LL * S * N : 0) + (obs_random_effects ? 1 + (long long)S * N * T * J : 0);
+    const long long Dll = (long long)S * (Ks + Ko + 2) + (fp_mode ? 1 : 0) + (site_random_effects ? 1 + 2LL * S * N : 0) + (obs_random_effects ? 1 + (long long)S * N * T * J : 0);
     if (Dll > (1LL << 24)) { bl_dataset_destroy(ds); *out = nullptr; return bl_fail(BL_ERR_UNSUPPORTED, "%lld coordinates", Dll); }
     BlReModel &m = ds->re;
     m.rows = ds->dd.rows; m.n_sites = N; m.n_stride = ds->dd.n_stride; m.T = T; m.J = J; m.Ks = Ks; m.Ko = Ko; m.KS = ds->KS; m.KO = ds->KO;
     m.site_re = site_random_effects ? 1 : 0; m.obs_re = obs_random_effects ? 1 : 0;
     m.n_species = S; m.G0s = Ks + Ko + 2; m.sp = 0; m.cb = 0; m.rv0 = ds->KS; m.sp_rows = T * J * (ds->KO + 1) + 2 * T;
-    m.G0 = S * m.G0s; m.G = m.G0 + m.site_re + m.obs_re; m.D = (int)Dll;
+    m.G0 = S * m.G0s; m.G = m.G0 + (fp_mode ? 1 : 0) + m.site_re + m.obs_re; m.D = (int)Dll;
     int at = m.G0;
+    m.kind = fp_mode ? 2 : 0; m.fp_mode = fp_mode; m.fp_a = (float)fp_a; m.fp_b = (float)fp_b;
+    m.o_fp = fp_mode ? at++ : -1;       // phi = logit(false-positive rate): right behind the regression coefficients
     m.o_phi_s = m.site_re ? at++ : -1;
     m.o_phi_o = m.obs_re ? at++ : -1;
     m.o_u = m.o_v = m.o_e = -1;
@@ -1095,6 +1144,7 @@ extern "C" int bl_dataset_create_re(const bl_dims *dims, const float *site_covs,
     m.hn_is2_o = obs_random_effects ? (float)(1.0 / (prior_obs_re_sd_scale * prior_obs_re_sd_scale)) : 0.0f;
     const double HL2PI = 0.91893853320467274178, HN0 = 0.5 * std::log(2.0 / 3.14159265358979323846);
     m.u_const = ds->dd.prior_const;
+    if (fp_mode) m.u_const += std::lgamma(fp_a) + std::lgamma(fp_b) - std::lgamma(fp_a + fp_b); // + log B(a, b)
     if (m.site_re) m.u_const += -HN0 + std::log(prior_site_re_sd_scale) + 2.0 * S * N * HL2PI;
     if (m.obs_re) m.u_const += -HN0 + std::log(prior_obs_re_sd_scale) + (double)S * N * T * J * HL2PI;
     m.n_total = N; m.s0 = 0; m.x_u = m.o_u; m.x_v = m.o_v; m.x_e = m.o_e;
@@ -1215,6 +1265,7 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
     p.dd = ds->dd; p.k = k; p.nloc = nloc; p.rec_stride = ld; p.B = B; p.theta = d_th32; p.partial = d_partial;
     p.max_abundance = ds->max_abundance;
     p.rn_off = BL_OFF_DATA + ((nloc + 1) / 2) * ld * 4; // (occu_rn: one species)
+    p.dyn_g = ds->model == 8 ? dyn_lanes_per_pair(ds, 1) : 1;
     p.fp_mode = ds->fp_mode;
     p.nmix_tab = ds->d_tab;
     p.ncw = ncw;
@@ -1466,6 +1517,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.max_depth = max_depth;
     p.max_abundance = ds->max_abundance;
     p.rn_off = BL_OFF_DATA + ((nloc + 1) / 2) * ld * 4; // (occu_rn: one species)
+    p.dyn_g = ds->model == 8 ? dyn_lanes_per_pair(ds, C) : 1;
     p.fp_mode = ds->fp_mode;
     p.nmix_tab = ds->d_tab;
     p.ncw = ncw;

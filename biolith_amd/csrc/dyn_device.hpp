@@ -22,10 +22,14 @@
 //            d/d eta_psi = rho_1 - psi;  rho_t -> LDS;
 //   pass 2   per period and visit: d/d alpha += rho_t sigma(-u_j) (c, c w)_j   (the visits are evaluated a second time: keeping
 //            T (Ko + 1) sums per site would not fit registers for general T).
+// A site pair is worked on by a GROUP of G = 1, 2, 4 or 8 neighbouring lanes (host: as many as the chain's lanes allow, <= T): lane g
+// of the group takes the periods t = g, g + G, ... in both visit passes -- they are nine tenths of the transcendentals -- and the
+// recursions between them, which need every period in order, are run by all G lanes alike on the visit sums exchanged through LDS.
 #pragma once
 
-// bytes of LDS behind the staged records: two float2 per period and compute lane (host: choose_geometry)
-__host__ __device__ inline int bl_dyn_scratch_bytes(int T, int cw) { return T * 2 * 8 * cw * 64; }
+// bytes of LDS behind the staged records: two float2 per period and compute lane (the lane's forward / smoothed columns), and one
+// more per period and lane GROUP for the periods' visit sums that the lanes of a group hand each other (host: choose_geometry)
+__host__ __device__ inline int bl_dyn_scratch_bytes(int T, int cw) { return T * 3 * 8 * cw * 64; }
 // coefficient / partial-sum layout of MODEL 8 (LDS coefficient block and a wave's row of the partial table alike):
 // block b in {psi 0, gamma 1, eps 2}: coefficient k at b (KS + 1) + k;  alpha_k at 3 (KS + 1) + k;  the log-lik at 3 (KS + 1) + KO + 1
 #define BL_DYN_OA(KS) (3 * ((KS) + 1))
@@ -39,7 +43,7 @@ __device__ __forceinline__ bl_f2 bl_sigmoid2(bl_f2 x)
 
 // Accumulates over this thread's site PAIRS m = ct, ct + CT, ...: ll, gb[b][k] = d ll / d (block b's coefficient k), ga[k] = d ll / d alpha_k
 template <int KS, int KO, int CT>
-__device__ __forceinline__ void bl_eval_sites_dyn(int ct, int pstride, int cnt, int T, int J, int scratch_off,
+__device__ __forceinline__ void bl_eval_sites_dyn(int ct, int pstride, int cnt, int T, int J, int G, int scratch_off,
                                                   const float (&bpsi)[KS + 1], const float (&bgam)[KS + 1], const float (&beps)[KS + 1],
                                                   const float (&alpha)[KO + 1],
                                                   float &ll, float (&gb)[3][KS + 1], float (&ga)[KO + 1])
@@ -48,7 +52,11 @@ __device__ __forceinline__ void bl_eval_sites_dyn(int ct, int pstride, int cnt, 
     const int pb = bl_period_block(J, KO);
     const float *data = bl_lds_f(BL_OFF_DATA);
     float2 *col = reinterpret_cast<float2 *>(bl_smem_raw + scratch_off) + ct; // element (t, which) of this lane: col[(2 t + which) * CT]
+    const int sub = ct & (G - 1), slot = ct / G, nslots = CT / G;              // lane `sub` of group `slot`
+    float2 *acol = reinterpret_cast<float2 *>(bl_smem_raw + scratch_off) + 2 * T * CT + slot; // period t's visit sum of this group: acol[t * nslots]
+    const float first = sub == 0 ? 1.0f : 0.0f;                               // (per-site sums are counted by the group's first lane)
     const int npairs = (cnt + 1) >> 1;
+    const int rounds = (npairs + nslots - 1) / nslots;
     bl_f2 ll2 = bl2(0.0f), gb2[3][KS + 1], ga2[KO + 1];
 #pragma unroll
     for (int b = 0; b < 3; b++)
@@ -56,9 +64,14 @@ __device__ __forceinline__ void bl_eval_sites_dyn(int ct, int pstride, int cnt, 
         for (int k = 0; k <= KS; k++) gb2[b][k] = bl2(0.0f);
 #pragma unroll
     for (int k = 0; k <= KO; k++) ga2[k] = bl2(0.0f);
-    for (int m = ct; m < npairs; m += CT) {
+    for (int rd = 0; rd < rounds; rd++) {
+        // (every lane of a wave stays in the loop -- the groups exchange through LDS between wave-level fences; a group without a
+        // pair in the last round re-evaluates the slice's last pair and is masked out)
+        const int m_raw = rd * nslots + slot;
+        const int m = min(m_raw, npairs - 1);
+        const float live = m_raw < npairs ? 1.0f : 0.0f;
         const float2 *rec = reinterpret_cast<const float2 *>(data + (size_t)m * pstride);
-        const bl_f2 vmask = bl_f2{1.0f, (2 * m + 1 < cnt) ? 1.0f : 0.0f}; // odd slice: the last pair's second site is a dummy
+        const bl_f2 vmask = bl_f2{live * first, (2 * m + 1 < cnt) ? live * first : 0.0f}; // odd slice: the last pair's second site is a dummy
         bl_f2 x[KS > 0 ? KS : 1];
         bl_f2 e_psi = bl2(bpsi[0]), e_gam = bl2(bgam[0]), e_eps = bl2(beps[0]);
 #pragma unroll
@@ -78,12 +91,11 @@ __device__ __forceinline__ void bl_eval_sites_dyn(int ct, int pstride, int cnt, 
         bl_f2 l1m = __builtin_elementwise_min(-e_psi, bl2(0.0f)) - lop;          // log(1 - pi_1)
         const bl_f2 stay = bl2(1.0f) - eps - gam;                                // pi_t+1 = gamma + phi_t (1 - eps - gamma)
         bl_f2 lsite = bl2(0.0f), phi = bl2(0.0f);
-        // ---- pass 1: the periods' visit sums and the forward recursion ----
-        for (int t = 0; t < T; t++) {
+        // ---- pass 1: the periods' visit sums (this lane's share of the periods), handed to the group through LDS ----
+        for (int t = sub; t < T; t += G) {
             const float2 *pp = rec + XQ + t * pb;
-            const float2 a_ = pp[J * (KO + 1)], kb_ = pp[J * (KO + 1) + 1];
+            const float2 a_ = pp[J * (KO + 1)];
             bl_f2 a = bl_f2{a_.x, a_.y};                       // ka: cancels the log sigma(0) of the masked visits
-            const bl_f2 kb = bl_f2{kb_.x, kb_.y};
 #pragma unroll 2
             for (int j = 0; j < J; j++) {
                 const float2 v0 = pp[j * (KO + 1)];
@@ -95,6 +107,13 @@ __device__ __forceinline__ void bl_eval_sites_dyn(int ct, int pstride, int cnt, 
                 }
                 a = bl_fma2(bl_log2_2(bl_expneg_2(u) + bl2(1.0f)), bl2(-BL_LN2), a); // log sigma(u) = -log(1 + e^-u)
             }
+            acol[t * nslots] = make_float2(a.x, a.y);
+        }
+        if (G > 1) bl_wave_lds_fence();
+        // ---- the forward recursion (every lane of the group, all periods) ----
+        for (int t = 0; t < T; t++) {
+            const float2 a_ = acol[t * nslots], kb_ = (rec + XQ + t * pb)[J * (KO + 1) + 1];
+            const bl_f2 a = bl_f2{a_.x, a_.y}, kb = bl_f2{kb_.x, kb_.y};
             const bl_f2 A = lpi + a, B = l1m + kb;
             const bl_f2 d = A - B;
             const bl_f2 e_d = bl_exp2_2(__builtin_elementwise_abs(d) * bl2(-BL_LOG2E)), op_d = e_d + bl2(1.0f);
@@ -123,11 +142,12 @@ __device__ __forceinline__ void bl_eval_sites_dyn(int ct, int pstride, int cnt, 
             col[(2 * (t + 1)) * CT] = make_float2(rho.x, rho.y);
             rho = xi11 + xi10;
         }
-        // ---- pass 2: d/d alpha = sum_t rho_t sum_j sigma(-u_j) (c, c w)_j ----
-        for (int t = 0; t < T; t++) {
+        // ---- pass 2: d/d alpha = sum_t rho_t sum_j sigma(-u_j) (c, c w)_j   (this lane's share of the periods) ----
+        for (int t = sub; t < T; t += G) {
             const float2 *pp = rec + XQ + t * pb;
             bl_f2 rt = rho;                                     // t = 0: still in registers
             if (t > 0) { const float2 r_ = col[(2 * t) * CT]; rt = bl_f2{r_.x, r_.y}; }
+            rt *= bl2(live);
 #pragma unroll 2
             for (int j = 0; j < J; j++) {
                 bl_f2 w[KO + 1];
@@ -145,6 +165,7 @@ __device__ __forceinline__ void bl_eval_sites_dyn(int ct, int pstride, int cnt, 
                 for (int k = 0; k <= KO; k++) ga2[k] = bl_fma2(s, w[k], ga2[k]);
             }
         }
+        if (G > 1) bl_wave_lds_fence(); // (the next round's visit sums overwrite this round's)
         ll2 = bl_fma2(lsite, vmask, ll2);
         const bl_f2 dv[3] = {(rho - psi) * vmask, d_gam * vmask, d_eps * vmask};
 #pragma unroll

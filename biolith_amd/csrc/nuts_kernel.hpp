@@ -105,6 +105,7 @@ struct BlNutsParams {
     int max_abundance;             // occu_rn only (occu_rn.py:26)
     int rn_off;                    // occu_rn: byte offset in LDS of its scratch (lgamma table + wave-private tables), behind the records;
                                    // dynamic occupancy (MODEL 8): of its lane-private columns (dyn_device.hpp)
+    int dyn_g;                     // dynamic occupancy: lanes that share one site pair (1, 2, 4, 8; dyn_device.hpp)
     int allow_local;               // 0: always use the placement-independent exchange
     int poll_sleep;                // s_sleep(1) repeats between re-polls (fabric form)
     int first_delay;               // s_sleep(1) repeats between publishing and the first poll
@@ -283,7 +284,6 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     float prior_loc = 0.f, prior_isc2 = 0.f, prior_l1 = 0.f;
     double prior_const = 0.0;
     int S = 0, W = 0, total = 0;
-    const float xcc = (float)bl_xcc_id();
 
     // exchange addressing (per lane, fixed for the whole launch): byte offsets of the <= 8 granules this
     // lane polls per round; record indices beyond k are clamped to k-1 (duplicates carry valid
@@ -292,7 +292,6 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     const int c_idx = lane & (nvp - 1), sub = lane / nvp;
     const unsigned rec_bytes = (unsigned)(p.k * p.pitch * 8);
     const unsigned char *xbase = reinterpret_cast<const unsigned char *>(p.xchg) + (size_t)chain * BL_XCHG_SLOTS * rec_bytes;
-    const unsigned my_store_off = (unsigned)((member * p.pitch + (lane & (nvp - 1))) * 8);
     unsigned poff[8];
     float pval[8]; // 1 if that load is a real (unclamped) record of this lane
 #pragma unroll
@@ -603,7 +602,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #ifdef BL_STAMPS
             const long long st_a0 = (long long)clock64();
 #endif
-            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, p.n_stride, nsp, p.sp_lds, p.rn_off);
+            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, p.n_stride, nsp, p.sp_lds, p.rn_off, p.dyn_g);
 #ifdef BL_STAMPS
             st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
 #endif
@@ -631,13 +630,19 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 if (lane == D + 1 && member == 0 && (epoch_c & 255u) == 0u)
                     comp = (__hip_atomic_load(cold->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1.0f : 0.0f;
                 if (epoch_c == 1u) { // placement census: all k XCC ids equal  <=>  k * sum(x^2) == (sum x)^2
+                    const float xcc = (float)bl_xcc_id(); // (read here, once: as a loop-carried value it was spilled to scratch and reloaded on every publish)
                     if (lane == D + 2) comp = xcc;
                     if (lane == D + 3) comp = xcc * xcc;
                 }
                 const unsigned char *rbase = xbase + (epoch_c & (BL_XCHG_SLOTS - 1u)) * rec_bytes;
                 const unsigned long long granule = ((unsigned long long)epoch_c << 32) | __float_as_uint(comp);
                 if (lane < nvp) {
-                    unsigned long long *dst = reinterpret_cast<unsigned long long *>(const_cast<unsigned char *>(rbase) + my_store_off);
+                    // (the granule's offset is formed HERE, from an opaque copy of the lane id: hoisted out of the loop, the 64-bit
+                    // address was spilled to scratch by the fullest instantiations and reloaded on every publish)
+                    int lane_o = lane;
+                    asm volatile("" : "+v"(lane_o));
+                    const unsigned store_off = (unsigned)((member * p.pitch + (lane_o & (nvp - 1))) * 8);
+                    unsigned long long *dst = reinterpret_cast<unsigned long long *>(const_cast<unsigned char *>(rbase) + store_off);
                     if (local_c) // line stays in this XCD's L2, where every consumer of this chain polls it
                         __hip_atomic_store(dst, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else         // write-through: visible to any XCD

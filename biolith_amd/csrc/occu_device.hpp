@@ -1027,7 +1027,7 @@ __device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, con
 template <int KS, int KO, bool LDS, int MODEL, int CW>
 __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__restrict__ grows, int ld_or_stride, int cnt,
                                            int T, int J, int max_abundance, int fp_mode, const float *__restrict__ tab = nullptr,
-                                           int tab_ld = 0, int n_species = 1, int sp_lds = 0, int rn_off = 0)
+                                           int tab_ld = 0, int n_species = 1, int sp_lds = 0, int rn_off = 0, int dyn_g = 1)
 {
     const int row_stride = n_species > 1 ? n_species * BL_SP_PART(KS, KO) : BL_PART_STRIDE;
     for (int sp = 0; sp < n_species; sp++) {
@@ -1059,7 +1059,7 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
                 for (int k = 0; k <= KS; k++) { bq[b][k] = c[b * (KS + 1) + k]; gq[b][k] = 0.0f; }
 #pragma unroll
             for (int k = 0; k <= KO; k++) alpha[k] = c[BL_DYN_OA(KS) + k];
-            bl_eval_sites_dyn<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
+            bl_eval_sites_dyn<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, dyn_g, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
             bl_wave_partials_dyn<KS, KO>(cwave, ll, gq, ga);
         }
     } else if constexpr (MODEL == 1) {

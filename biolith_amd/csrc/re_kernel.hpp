@@ -34,7 +34,10 @@ struct BlReModel {
     const float *rows;
     int n_sites, n_stride, T, J, Ks, Ko, KS, KO;
     int site_re, obs_re;
-    int kind;                             // 0: occu with random effects; 1: occu_cs (continuous scores, no effects: D = G = G0 + 4)
+    int kind;                             // 0: occu with random effects; 1: occu_cs (continuous scores, no effects: D = G = G0 + 4);
+                                          // 2: occu with random effects AND a false-positive rate (occu.py:146-157 with :170-173, 191-196)
+    int fp_mode, o_fp;                    // kind 2: 1 = the rate acts on every site ("constant"), 2 = on unoccupied sites; phi = logit(rate) at o_fp = G0
+    float fp_a, fp_b;                     // kind 2: Beta(a, b) prior of the rate
     const float *scores;                  // kind 1: the replicates' scores, site-fastest [T J][n_stride] (0 where masked)
     float cs_mu[4], cs_sg[4];             // kind 1: Normal(loc, scale) of mu0 and of mu1's base; Gamma(concentration, rate) of sigma0, sigma1
     int G0, G, D;                         // fixed effects (of all species), + log sds, all coordinates
@@ -343,10 +346,17 @@ __device__ __forceinline__ BlReSiteMap bl_re_site_map(const BlReModel &m)
 // random effects' full potential gradient written to g (the effect's own likelihood term + its Normal(0, sd) prior).
 // part[0] = ll, part[1 .. 5] = d/d beta, part[6 .. 10] = d/d alpha.
 // rows / ns: the dataset's rows in device memory (stride n_stride), or the workgroup's LDS copy of them (stride n_sites).
-template <int MK>
+// FP (kind 2): the visits' terms gain the false-positive rate as in bl_eval_sites_fp (occu_device.hpp) -- a detection costs
+// log sigma(u) + log(1 + f1 e^-u), a non-detection log sigma(u) + log(1 - f1), the z = 0 branch n_det log f + n_nondet log(1 - f) --
+// and gphi accumulates d ll / d phi (chain rule through f = sigmoid(phi) included).
+template <int MK, bool FP = false>
 __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float *__restrict__ rows, int ns, int rv /* first visit row in rows */,
-                                                const float *__restrict__ z, float *__restrict__ g, float (&part)[2 * MK + 3])
+                                                const float *__restrict__ z, float *__restrict__ g, float (&part)[2 * MK + 3], float *gphi = nullptr)
 {
+    BlFpScalars fp{};
+    if constexpr (FP) fp = bl_fp_scalars(z[m.o_fp], m.fp_mode == 1);
+    float gp = 0.0f;
+    const float Jf = (float)m.J;
     const BlReSiteMap sm = bl_re_site_map(m);
     const int tps = sm.tps, S = sm.S, sub = sm.sub;
     const int N = m.n_sites, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 1;
@@ -385,7 +395,7 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
         const float psi = (eta > 0.0f ? 1.0f : ee) * bl_rcp(1.0f + ee);
         float dl_deta = 0.0f, dl_dv = 0.0f;
         for (int t = 0; t < T; t++) {
-            float a = 0.0f, ga[MK + 1];
+            float a = 0.0f, ga[MK + 1], gf = 0.0f;
 #pragma unroll
             for (int k = 0; k <= MK; k++) ga[k] = 0.0f;
             // visits in batches of BL_RE_VB: all loads of a batch are issued before the first is used (a lone workgroup per
@@ -415,7 +425,17 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
                     u = fmaf(w[b][0], vi + eo[b], u);
                     const float e = bl_exp(-fabsf(u)), op = 1.0f + e;
                     a = fmaf(ok, fminf(u, 0.0f) - bl_log(op), a);
-                    const float s = ok * (u > 0.0f ? e : 1.0f) * bl_rcp(op); // sigma(-u): d log sigma(u) / du
+                    float s = ok * (u > 0.0f ? e : 1.0f) * bl_rcp(op); // sigma(-u): d log sigma(u) / du
+                    if constexpr (FP) {
+                        // a detection where the rate acts on occupied sites: + log(1 + f1 e^-u), d/du -= f1 e^-u / (1 + f1 e^-u)
+                        const float det = (w[b][0] > 0.0f ? ok : 0.0f) * fp.z1;
+                        const float td = bl_exp(-fmaxf(u, -87.0f)) * det;
+                        const float opf = fmaf(td, fp.f1, 1.0f);
+                        a += bl_log(opf);
+                        const float tr = td * bl_rcp(opf);
+                        gf += tr;
+                        s = fmaf(tr, -fp.f1, s);
+                    }
 #pragma unroll
                     for (int k = 0; k <= KB; k++) ga[k] = fmaf(s, w[b][k], ga[k]);
                 }
@@ -426,13 +446,28 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
             for (int jb = sub; jb < J; jb += tps * BL_RE_VB) bl_re_tiered<MK>(Ko, batch, jb);
             for (int msk = S; msk < 64; msk <<= 1) { // the site's threads pool their visits
                 a += __shfl_xor(a, msk);
+                if constexpr (FP) gf += __shfl_xor(gf, msk);
 #pragma unroll
                 for (int k = 0; k <= MK; k++) ga[k] += __shfl_xor(ga[k], msk);
             }
-            const float ka = rows[(row_ka + t) * ns + i], kb = rows[(row_kb + t) * ns + i];
+            const float ka = rows[(row_ka + t) * ns + i];
+            float kb = rows[(row_kb + t) * ns + i];
+            float nnon = 0.0f, ndet = 0.0f;
+            if constexpr (FP) { // counts of this (site, period) from the rows' ka = n_masked ln2 and kb = n_det log(tiny)
+                ndet = __builtin_rintf(kb * (1.0f / -87.33654475f));
+                nnon = Jf - ndet - __builtin_rintf(ka * (1.0f / BL_LN2));
+                a = fmaf(nnon, fp.l1f1, a);
+                kb = fmaf(ndet, fp.lf, nnon * fp.l1f);
+            }
             const float A = log_psi + a + ka, B = log_1mpsi + kb;
             const float l = bl_logaddexp(A, B);
             const float q = bl_exp(A - l);
+            if constexpr (FP) {
+                if (live && sub == 0) { // d/dphi: the z = 1 branch (only when the rate acts there) and the z = 0 branch, each times f (1 - f)
+                    const float d1 = fmaf(gf, fp.ff1, nnon * (-fp.f * fp.z1)), d0 = fmaf(ndet, 1.0f - fp.f, nnon * -fp.f);
+                    gp += fmaf(q, d1 - d0, d0);
+                }
+            }
             if (live && sub == 0) {
                 part[0] += l;
 #pragma unroll
@@ -464,7 +499,11 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
                             for (int k = 1; k <= KB; k++) u = fmaf(w[b][k], alpha[k], u);
                             u = fmaf(w[b][0], vi + eo[b], u);
                             const float e = bl_exp(-fabsf(u));
-                            const float s = (u > 0.0f ? e : 1.0f) * bl_rcp(1.0f + e);
+                            float s = (u > 0.0f ? e : 1.0f) * bl_rcp(1.0f + e);
+                            if constexpr (FP) {
+                                const float td = w[b][0] > 0.0f ? bl_exp(-fmaxf(u, -87.0f)) * fp.z1 : 0.0f;
+                                s = fmaf(td * bl_rcp(fmaf(td, fp.f1, 1.0f)), -fp.f1, s);
+                            }
                             g[m.o_e + (t * J + jb + b * tps) * N + i] = fmaf(eo[b], isd2_o, -q * s * w[b][0]);
                         }
                     }
@@ -482,6 +521,7 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
             }
         }
     }
+    if constexpr (FP) *gphi = gp;
 }
 
 // ---- occu_cs (biolith/models/occu_cs.py:120-232): s ~ Normal(mu_f, sigma_f), f ~ Bernoulli(z p), z ~ Bernoulli(psi); z and every
@@ -643,6 +683,11 @@ __device__ __forceinline__ float bl_re_global_grad(const BlReModel &m, int d, fl
         return (float)(-gl) + fmaf(dth, isc2, dth > 0.0f ? l1 : (dth < 0.0f ? -l1 : 0.0f));
     }
     if (m.kind == 1) return 0.0f; // (occu_cs: its four extra coordinates are handled by bl_cs_extra_grad)
+    if (m.kind == 2 && d == m.o_fp) {
+        // phi = logit f, f ~ Beta(a, b), Jacobian included: energy a softplus(-phi) + b softplus(phi); red[OX + 6] = d ll / d phi
+        const float e = bl_exp(-fabsf(zd)), sig = (zd > 0.0f ? 1.0f : e) * bl_rcp(1.0f + e);
+        return (float)(-red[OX + 6]) + (m.fp_a + m.fp_b) * sig - m.fp_a;
+    }
     const bool site = m.site_re && d == m.o_phi_s;
     const float isd2 = bl_exp(-2.0f * zd), sd2 = bl_exp(2.0f * zd);
     const float cnt = (float)m.n_species * (site ? 2.0f * (float)m.n_total : (float)m.n_total * (float)(m.T * m.J));
@@ -655,6 +700,10 @@ __device__ __forceinline__ float bl_re_global_grad(const BlReModel &m, int d, fl
 __device__ __forceinline__ double bl_re_potential(const BlReModel &m, const float *z, const double *red, double pe2, int OX)
 {
     double U = -red[0] + 0.5 * pe2 + m.u_const;
+    if (m.kind == 2) {
+        const double phi = z[m.o_fp], l = log1p(exp(-fabs(phi)));
+        U += m.fp_a * (fmax(-phi, 0.0) + l) + m.fp_b * (fmax(phi, 0.0) + l);
+    }
     if (m.site_re) {
         const float phi = z[m.o_phi_s];
         U += 0.5 * (double)(bl_exp(2.0f * phi) * m.hn_is2_s) - (double)phi + 0.5 * red[OX] * (double)bl_exp(-2.0f * phi) + 2.0 * m.n_species * m.n_total * (double)phi;
@@ -723,12 +772,13 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel gm
             for (int k = 0; k < OX; k++) v[k] = part[k];
             v[OX] = part[OX]; v[OX + 1] = part[OX + 1]; v[OX + 6] = part[OX + 2]; v[OX + 7] = part[OX + 3];
         } else {
-            float part[2 * MK + 3], ss[2];
-            bl_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
+            float part[2 * MK + 3], ss[2], gphi = 0.0f;
+            if (m.kind == 2) bl_re_site_pass<MK, true>(m, rows, ns, rv, z, g, part, &gphi);
+            else bl_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
             bl_re_effect_squares(m, z, ss);
 #pragma unroll
             for (int k = 0; k < OX; k++) v[k] = part[k];
-            v[OX] = ss[0]; v[OX + 1] = ss[1]; v[OX + 6] = 0.0f; v[OX + 7] = 0.0f;
+            v[OX] = ss[0]; v[OX + 1] = ss[1]; v[OX + 6] = gphi; v[OX + 7] = 0.0f;
         }
         v[OX + 2] = sp == 0 ? bl_re_prior_quad(m, z) : 0.0f;
         v[OX + 3] = 0.0f; v[OX + 4] = 0.0f; v[OX + 5] = 0.0f;
@@ -835,13 +885,13 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
             for (int k = 0; k < OX; k++) v[k] = part[k];
             v[OX] = part[OX]; v[OX + 1] = part[OX + 1]; v[OX + 6] = part[OX + 2]; v[OX + 7] = part[OX + 3];
         } else {
-            float part[2 * MK + 3], ss[2];
-            bl_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
+            float part[2 * MK + 3], ss[2], gphi = 0.0f;
+            bl_re_site_pass<MK, KIND == 2>(m, rows, rows_ns, rows_rv, z, g, part, &gphi);
             BL_RE_T(8)
             bl_re_effect_squares(m, z, ss);
 #pragma unroll
             for (int k = 0; k < OX; k++) v[k] = part[k];
-            v[OX] = ss[0]; v[OX + 1] = ss[1]; v[OX + 6] = 0.0f; v[OX + 7] = 0.0f;
+            v[OX] = ss[0]; v[OX + 1] = ss[1]; v[OX + 6] = gphi; v[OX + 7] = 0.0f;
         }
         v[OX + 2] = lead ? bl_re_prior_quad(m, z) : 0.0f;
         // the host's abort request rides in the sums, so that every workgroup of the chain sees it at the same leapfrog
@@ -850,7 +900,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
         v[OX + 4] = tid == 0 ? xcc : 0.0f; v[OX + 5] = tid == 0 ? xcc * xcc : 0.0f;
         BL_RE_T(0)
         ev_first = xc.epoch == 0u;
-        ev_nv = KIND == 1 ? NV1 : (ev_first ? OX + 6 : OX + 4);
+        ev_nv = KIND == 1 ? NV1 : (KIND == 2 ? OX + 7 : (ev_first ? OX + 6 : OX + 4));
         bl_re_block_sum<NV1, NRED>(v, scr, red, ev_nv, xc.k == 1);
         BL_RE_T(9)
         bl_re_publish<NRED>(xc, red, ev_nv);

@@ -24,11 +24,14 @@
 //       The item for chunk 0 also carries the n = 0 term and hands (max, sum, sum n w) back to the site's lane.
 //
 // Work is then sum_sites ceil(cutoff / 8) items of 8 terms instead of 64 x (wave's largest cutoff) per wave, the per-lane
-// table is 8 registers, and a workgroup runs 7 compute waves (two per SIMD) that hide each other's exp / log / rcp latencies.
+// table is 8 registers, and a workgroup runs 5 compute waves + the control wave (six waves on four SIMDs): a wave's instruction
+// stream is the same however few of its lanes are busy, so the count is the one that fills the lanes (31 sites, 46 items per wave at
+// BASELINE.json's config 4) while a SIMD still has a second wave to hide the exp / log / rcp and LDS latencies behind.
 #pragma once
 
 #ifndef BL_CWAVES_RN
-#define BL_CWAVES_RN 7                 // compute waves per workgroup of the occu_rn kernels
+#define BL_CWAVES_RN 5                 // compute waves per workgroup of the occu_rn kernels (measured at config 4, k = 32: 3 -> 15.5, 4 -> 12.9,
+                                       // 5 -> 9.5, 6 -> 10.0, 7 -> 9.9, 11 -> 13.5, 15 -> 16.0 us per leapfrog)
 #endif
 #define BL_RN_CH 8                     // n-terms per item
 #define BL_RN_LGT 144                  // floats of the shifted lgamma table: lgt[i] = lgamma(i + 2) = the entry of n = i + 1
@@ -128,13 +131,9 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
         const int i = r0 + min(sl0, ns - 1);       // lanes beyond the round re-evaluate its last site and are masked out
         const float live = has ? 1.0f : 0.0f;
         float *rec = data + (size_t)(i >> 1) * pstride + (i & 1); // element e of this site: rec[2 e]
-        float x[KS > 0 ? KS : 1];
         float eta = beta[0];
 #pragma unroll
-        for (int k = 0; k < KS; k++) {
-            x[k] = rec[2 * k];
-            eta = fmaf(x[k], beta[k + 1], eta);
-        }
+        for (int k = 0; k < KS; k++) eta = fmaf(rec[2 * k], beta[k + 1], eta); // (x is read again for the gradient: not kept across P2)
         // ---- truncated-Poisson prior, p_n = n eta - lgamma(n+1), n <= K: log Z and E[n] ----
         // Z = e^lambda (1 - tail), tail = P(Poisson(lambda) > K) <= 2 e^(p_(K+1) - lambda) while lambda <= (K+2)/2: below 3e-11
         // the closed forms log Z = lambda, E[n] = lambda are exact in float32.  Otherwise (lambda near or beyond K) the sums.
@@ -255,7 +254,7 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
             }
             // record for the item lanes
             *reinterpret_cast<float4 *>(srec + lane * 8) = make_float4(a, clr, term0, thr);
-            *reinterpret_cast<float2 *>(srec + lane * 8 + 4) = make_float2(cnon, nstar);
+            *reinterpret_cast<float4 *>(srec + lane * 8 + 4) = make_float4(cnon, nstar, log_z, en_prior); // (the last two: parked for this lane itself)
             const int P = bl_wave_iscan(nch);
             BL_RN_T(2)
             // ---- P2: items.  Sites are packed whole into rounds of <= 64 lanes (a site has <= 16 items) ----
@@ -468,7 +467,8 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                     for (int g = 0; g < BL_RN_GA; g++) {
                         if (g < J) { // wave-uniform
                             const float *wv = ipv + 2 * (g * VW);
-                            const float qv = (g & 1) ? q2k[g >> 1].y : q2k[g >> 1].x, hv = (g & 1) ? h[g >> 1].y : h[g >> 1].x;
+                            // (q_j is read again rather than kept: ten registers less across the combine -- the kernel sits at its 256-register budget)
+                            const float qv = fmaxf(wv[2 * (KO + 1)], 0.0f), hv = (g & 1) ? h[g >> 1].y : h[g >> 1].x;
                             const float dnu = qv > 0.0f ? fmaf(qv - 1.0f, a1_it, hv) * rs : 0.0f;
 #pragma unroll
                             for (int k = 0; k <= KO; k++) ga[k] = fmaf(dnu, wv[2 * k], ga[k]);
@@ -511,8 +511,9 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
             float4 res = *reinterpret_cast<const float4 *>(sres + lane * 4);
             if (!has) res = make_float4(0.0f, 1.0f, 0.0f, 0.0f); // (no item wrote this lane's slot)
             const float en_post = res.z * __builtin_amdgcn_rcpf(res.y);
-            ll_s += BL_LN2 * (res.x + __builtin_amdgcn_logf(res.y)) - log_z;
-            deta += en_post - en_prior;
+            const float2 parked = *reinterpret_cast<const float2 *>(srec + lane * 8 + 6);   // log Z, E[n] of the prior
+            ll_s += BL_LN2 * (res.x + __builtin_amdgcn_logf(res.y)) - parked.x;
+            deta += en_post - parked.y;
             const float enl = live * en_post;
 #pragma unroll
             for (int k = 0; k <= KO; k++) ga[k] = fmaf(enl, Rv[k], ga[k]);
@@ -522,6 +523,6 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
         ll = fmaf(live, ll_s, ll);
         gb[0] += deta;
 #pragma unroll
-        for (int k = 0; k < KS; k++) gb[k + 1] = fmaf(deta, x[k], gb[k + 1]);
+        for (int k = 0; k < KS; k++) gb[k + 1] = fmaf(deta, rec[2 * k], gb[k + 1]);
     }
 }

@@ -116,7 +116,7 @@ class OccuDataset:
                  model: str = "occu", max_abundance: int = 100, fp_mode: Optional[str] = "constant", prior_fp=(2.0, 5.0),
                  session_duration=None, prior_fp_rate: float = 1.0, site_random_effects: bool = False,
                  obs_random_effects: bool = False, prior_site_re_sd: float = 1.0, prior_obs_re_sd: float = 1.0,
-                 prior_mu=((0.0, 10.0), (0.0, 10.0)), prior_sigma=((5.0, 1.0), (5.0, 1.0))):
+                 prior_mu=((0.0, 10.0), (0.0, 10.0)), prior_sigma=((5.0, 1.0), (5.0, 1.0)), re_fp_mode: Optional[str] = None):
         lib = _ffi.load()
         if model not in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture", "occu_re", "occu_cs", "occu_dyn"):
             raise ValueError(f"unknown model {model!r}")
@@ -189,9 +189,19 @@ class OccuDataset:
             # theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_occ[N], site_re_det[N]), (obs_re[N][T][J])]
             if not (site_random_effects or obs_random_effects):
                 raise ValueError("occu_re needs site_random_effects and / or obs_random_effects")
-            _ffi.check(lib.bl_dataset_create_re(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), int(bool(site_random_effects)),
-                                                int(bool(obs_random_effects)), float(prior_site_re_sd), float(prior_obs_re_sd),
-                                                C.byref(pb), C.byref(pa), device, C.byref(h)))
+            if re_fp_mode is not None:
+                # ... together with a false-positive rate (occu.py:146-157): theta = [beta, alpha, phi = logit(rate), log sds, effects]
+                if re_fp_mode not in ("constant", "unoccupied"):
+                    raise ValueError(f"unknown re_fp_mode {re_fp_mode!r}")
+                pf = _ffi.bl_beta_prior(*self.prior_fp)
+                _ffi.check(lib.bl_dataset_create_re_fp(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), int(bool(site_random_effects)),
+                                                       int(bool(obs_random_effects)), float(prior_site_re_sd), float(prior_obs_re_sd),
+                                                       _ffi.FP_CONSTANT if re_fp_mode == "constant" else _ffi.FP_UNOCCUPIED, C.byref(pf),
+                                                       C.byref(pb), C.byref(pa), device, C.byref(h)))
+            else:
+                _ffi.check(lib.bl_dataset_create_re(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), int(bool(site_random_effects)),
+                                                    int(bool(obs_random_effects)), float(prior_site_re_sd), float(prior_obs_re_sd),
+                                                    C.byref(pb), C.byref(pa), device, C.byref(h)))
             d = C.c_int()
             _ffi.check(lib.bl_dataset_param_dim(h, C.byref(d)))
             self.D = int(d.value)
@@ -212,6 +222,7 @@ class OccuDataset:
         if "laplace" in fam:
             _ffi.check(lib.bl_dataset_set_prior_family(h, int(fam[0] == "laplace"), int(fam[1] == "laplace")))
         self.site_re, self.obs_re = bool(site_random_effects), bool(obs_random_effects)
+        self.re_fp_mode = re_fp_mode if model == "occu_re" else None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -272,6 +283,12 @@ class OccuDataset:
 
     def wait(self):
         _ffi.check(self._lib.bl_nuts_wait(self._h))
+
+    def wgs_per_chain(self) -> int:
+        """Workgroups per chain of the last launch (bl_nuts_geometry)."""
+        k, thr, lds, staged, loc = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _ffi.check(self._lib.bl_nuts_geometry(self._h, C.byref(k), C.byref(thr), C.byref(lds), C.byref(staged), C.byref(loc)))
+        return int(k.value)
 
     def elapsed_ms(self) -> float:
         ms = C.c_float(0)

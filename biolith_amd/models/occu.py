@@ -111,8 +111,8 @@ def occu(
     if site_random_effects or obs_random_effects:
         # site_re_sd / obs_re_sd are sampled outside the species plate (occu.py:170-173): several species share them -- fit()
         # then samples all species under one chain (up to 8 species)
-        if fp_mode is not None:
-            unsupported.append("random effects together with false positives")
+        if fp_mode is not None and n_species != 1:
+            unsupported.append("random effects together with false positives for several species")
     if regressor_occ is not LinearRegression or regressor_det is not LinearRegression:
         unsupported.append("non-linear regressors (occu.py:185-186)")
     if obs is None:
@@ -131,8 +131,11 @@ def occu(
                            prior_obs_re_sd=as_half_normal(prior_obs_re_sd, "prior_obs_re_sd"))
     if fp_mode is not None:
         prior = prior_prob_fp_constant if fp_mode == "constant" else prior_prob_fp_unoccupied
-        spec.model = "occu_fp"
-        spec.extras.update(fp_mode=fp_mode, prior_fp=as_beta(prior, f"prior_prob_fp_{fp_mode}"))
+        if spec.model == "occu_re":   # both: the random-effects kernels with the rate as one more replicated coordinate
+            spec.extras.update(re_fp_mode=fp_mode, prior_fp=as_beta(prior, f"prior_prob_fp_{fp_mode}"))
+        else:
+            spec.model = "occu_fp"
+            spec.extras.update(fp_mode=fp_mode, prior_fp=as_beta(prior, f"prior_prob_fp_{fp_mode}"))
     return spec
 
 

@@ -126,12 +126,12 @@ def fit(
         jobs = make_jobs(False)
     n_units = 1 if joint else n_species
 
-    def run_all():
+    def run_all(wgs_per_chain=0):
         t_end = None if timeout is None else time.monotonic() + float(timeout) + 1.0
         launched = []
         try:
             for _, ds, kw in jobs:   # launches on one device queue behind each other, devices overlap
-                ds.launch(**kw)
+                ds.launch(**kw, wgs_per_chain=wgs_per_chain)
                 launched.append(ds)
             for ds in launched:
                 while t_end is not None and not ds.done():
@@ -194,6 +194,19 @@ def fit(
             jobs = make_jobs(False)
             n_units = n_species
             return run_all()
+        except TimeoutError as exc:
+            # BL_ERR_TIMEOUT from the ENGINE (not the caller's time limit, which says "Timed out"): a chain's workgroups spin on each
+            # other's partial sums and must all be resident; on a shared or profiled device they may not be.  One fresh launch on half
+            # the workgroups per chain (nothing of the failed launch is reused) before giving up.
+            if not str(exc).startswith("biolith_hip:"):
+                raise
+            k = jobs[0][1].wgs_per_chain()
+            if k <= 1:
+                raise
+            import warnings
+
+            warnings.warn(f"fit(): the engine's exchange timed out with {k} workgroups per chain ({exc}); retrying once with {k // 2}", RuntimeWarning)
+            return run_all(wgs_per_chain=max(1, k // 2))
 
     try:
         if timeout is not None:
@@ -266,6 +279,8 @@ def engine_options(spec) -> dict:
                     prior_fp_rate=spec.extras.get("prior_fp_rate", 1.0))
     if spec.model == "occu_re":
         opts.update({k: spec.extras[k] for k in ("site_random_effects", "obs_random_effects", "prior_site_re_sd", "prior_obs_re_sd")})
+        if spec.extras.get("re_fp_mode") is not None:
+            opts.update(re_fp_mode=spec.extras["re_fp_mode"], prior_fp=spec.extras["prior_fp"])
     if spec.model == "occu_cs":
         opts.update(prior_mu=spec.extras["prior_mu"], prior_sigma=spec.extras["prior_sigma"])
     return opts
@@ -334,6 +349,10 @@ def _assemble(per_species, spec, num_warmup, joint_result=None) -> HipMCMC:
         # model's sites are the sds themselves, the effects with the species plate last (occu.py:170-173, 191-196, 215-218)
         N, T, J = ds0.N, ds0.T, ds0.J
         at = Ks + Ko + 2
+        if spec.extras.get("re_fp_mode") is not None:   # [beta, alpha, phi = logit(rate), log sds, effects]
+            phi = res0.draws[:, :, at].astype(np.float64)
+            latent[f"prob_fp_{spec.extras['re_fp_mode']}"] = (1.0 / (1.0 + np.exp(-phi))).astype(np.float32)
+            at += 1
         if spec.extras["site_random_effects"]:
             latent["site_re_sd"] = np.exp(res0.draws[:, :, at].astype(np.float64)).astype(np.float32)
             at += 1
@@ -380,12 +399,11 @@ def _assemble(per_species, spec, num_warmup, joint_result=None) -> HipMCMC:
         # (first available dim = -5: [UPSTREAM] funsor's enum dims sit left of max_plate_nesting = 4; not verifiable in this
         # image): (C, S, 2, J, T, N, species), index 0 = unoccupied, 1 = occupied.  Nothing in the reference reads it.
         pd = prob_detection().astype(np.float32)                                  # (C, S, J, T, N, nsp)
-        if spec.model != "occu_fp":   # both rates 0:  1 - (1 - z p) = z p
+        mode = spec.extras.get("fp_mode") if spec.model == "occu_fp" else spec.extras.get("re_fp_mode")
+        if mode is None:   # both rates 0:  1 - (1 - z p) = z p
             return np.stack([np.zeros_like(pd), pd], axis=2)
-        f_c = f_u = np.float32(0.0)
-        if spec.model == "occu_fp":
-            rate = latent[f"prob_fp_{spec.extras['fp_mode']}"].astype(np.float32).reshape(C, S, 1, 1, 1, 1)
-            f_c, f_u = (rate, np.float32(0.0)) if spec.extras["fp_mode"] == "constant" else (np.float32(0.0), rate)
+        rate = latent[f"prob_fp_{mode}"].astype(np.float32).reshape(C, S, 1, 1, 1, 1)
+        f_c, f_u = (rate, np.float32(0.0)) if mode == "constant" else (np.float32(0.0), rate)
         z0 = np.broadcast_to(1.0 - (1.0 - f_c) * (1.0 - f_u), pd.shape).astype(np.float32)
         z1 = (1.0 - (1.0 - pd) * (1.0 - f_c)).astype(np.float32)
         return np.stack([z0, z1], axis=2)

@@ -36,7 +36,14 @@ def predict(
     ``FitResult.mcmc`` that :func:`biolith_amd.utils.fit` returned; ``obs`` is accepted and ignored, as
     the reference drops it before calling the model (predict.py:78-80).  As with ``Predictive``, one
     predictive draw is made per posterior draw, so ``num_samples`` only triggers NumPyro's warning when
-    it differs from the number of posterior draws.  ``infer_discrete=True`` is not built.
+    it differs from the number of posterior draws.
+
+    ``infer_discrete=True`` (predict.py:18, 71): NumPyro's ``Predictive`` then draws the discrete sites from their posterior
+    given the OBSERVED sites of the model call -- but the reference withholds ``obs`` from that call (predict.py:78-80), so
+    ``y`` is itself an unobserved discrete site and the pair (``z``, ``y``) is drawn from its joint distribution given the
+    posterior draw of the continuous sites: the same distribution the default path samples ancestrally.  [UPSTREAM: numpyro's
+    ``_predictive`` / ``_sample_posterior``; not executable in this image.]  Both settings therefore run the same kernels here;
+    draw-level equality with NumPyro is impossible either way (threefry keys are not reproduced).
 
     Returns
     -------
@@ -57,8 +64,7 @@ def predict(
     """
     if not callable(model_fn) or getattr(model_fn, "__biolith_amd_model__", None) is None:
         raise TypeError("predict(): model_fn must be a biolith_amd model (biolith_amd.models.occu / occu_rn)")
-    if infer_discrete:
-        raise NotImplementedError("infer_discrete=True (predict.py:70) is not built on the HIP engine")
+    infer_discrete = bool(infer_discrete)   # (same sites, same distribution: see the docstring)
     device = int(kwargs.pop("device", 0))
 
     site_covs, obs_covs, obs, session_duration, site_names, obs_names = prepare_data(
@@ -84,6 +90,8 @@ def predict(
     from ..engine import OccuDataset
     from .fit import engine_options
 
+    if spec.model == "occu_re" and spec.extras.get("re_fp_mode") is not None:
+        raise NotImplementedError("predict(): random effects together with false positives are fitted, not yet predicted, on the HIP engine")
     fp_site = f"prob_fp_{spec.extras['fp_mode']}" if spec.model == "occu_fp" else None
     if fp_site is not None:
         rate = np.clip(np.asarray(posterior[fp_site], dtype=np.float64).reshape(n), 1e-300, 1 - 1e-16)

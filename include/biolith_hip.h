@@ -153,6 +153,12 @@ int bl_dataset_create_re(const bl_dims *dims, const float *site_covs, const floa
                          int site_random_effects, int obs_random_effects, double prior_site_re_sd_scale,
                          double prior_obs_re_sd_scale, const bl_normal_prior *prior_beta,
                          const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
+/* The same with a false-positive rate on top (occu.py:146-157 together with :170-173, 191-196; fp_mode / prior_fp as for
+ * bl_dataset_create_fp): theta = [beta, alpha, phi = logit(rate), (log sds), (effects)].  One species per dataset. */
+int bl_dataset_create_re_fp(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
+                            int site_random_effects, int obs_random_effects, double prior_site_re_sd_scale,
+                            double prior_obs_re_sd_scale, int fp_mode, const bl_beta_prior *prior_fp,
+                            const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
 /*
  * The continuous-score occupancy model biolith.models.occu_cs (models/occu_cs.py:17-232; Rhinehart et al. 2022): `scores`
  * [S=1][N][T][J] (NaN = missing) ~ Normal(mu_f, sigma_f) with f ~ Bernoulli(z p) and z ~ Bernoulli(psi) summed out.

@@ -58,6 +58,7 @@ def lib():
             L.orc_data_set_cop.argtypes = [C.c_void_p, dp, dp, C.c_int, C.c_double]
             L.orc_data_set_nmix.argtypes = [C.c_void_p, dp, C.c_int]
             L.orc_data_set_re.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
+            L.orc_data_set_re_fp.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_prior_family.argtypes = [C.c_void_p, C.c_int, C.c_int]
             L.orc_data_set_cs.argtypes = [C.c_void_p, dp, dp, dp]
             L.orc_data_set_dyn.argtypes = [C.c_void_p]
@@ -99,7 +100,8 @@ class OracleData:
     def __init__(self, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0), model="occu",
                  max_abundance=100, fp_mode="constant", prior_fp=(2.0, 5.0), session_duration=None, prior_fp_rate=1.0,
                  site_random_effects=False, obs_random_effects=False, prior_site_re_sd=1.0, prior_obs_re_sd=1.0,
-                 prior_family=("normal", "normal"), prior_mu=((0.0, 10.0), (0.0, 10.0)), prior_sigma=((5.0, 1.0), (5.0, 1.0))):
+                 prior_family=("normal", "normal"), prior_mu=((0.0, 10.0), (0.0, 10.0)), prior_sigma=((5.0, 1.0), (5.0, 1.0)),
+                 re_fp_mode=None):
         X = _as_f32_f64(site_covs)
         W = _as_f32_f64(obs_covs)
         Y = _as_f32_f64(obs)
@@ -151,6 +153,9 @@ class OracleData:
             assert site_random_effects or obs_random_effects
             lib().orc_data_set_re(self._h, int(bool(site_random_effects)), int(bool(obs_random_effects)),
                                   float(prior_site_re_sd), float(prior_obs_re_sd))
+            if re_fp_mode is not None:   # random effects together with a false-positive rate: theta = [beta, alpha, phi, log sds, effects]
+                assert re_fp_mode in ("constant", "unoccupied") and Y_all is None
+                lib().orc_data_set_re_fp(self._h, 1 if re_fp_mode == "constant" else 2, float(prior_fp[0]), float(prior_fp[1]))
             self.D = int(lib().orc_data_dim(self._h))
         if model == "occu_dyn":
             # builder-defined dynamic occupancy (no reference counterpart): theta = [b_psi | b_gamma | b_eps (Ks+1 each) | alpha (Ko+1)]
@@ -314,7 +319,8 @@ def literal_log_joint(theta, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), pr
 
 
 def literal_log_joint_re(theta, site_covs, obs_covs, obs, site_random_effects=True, obs_random_effects=False,
-                         prior_site_re_sd=1.0, prior_obs_re_sd=1.0, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):
+                         prior_site_re_sd=1.0, prior_obs_re_sd=1.0, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0),
+                         re_fp_mode=None, prior_fp=(2.0, 5.0)):
     """log density of occu with random effects (biolith/models/occu.py:170-173, 191-196, 215-218) in NumPyro's
     unconstrained space, z summed by brute force.  theta = [beta, alpha, (log site_re_sd), (log obs_re_sd),
     (site_re_occ[N], site_re_det[N]), (obs_re[N][T][J])]; a HalfNormal site lives on the log scale (+ log-Jacobian)."""
@@ -327,6 +333,14 @@ def literal_log_joint_re(theta, site_covs, obs_covs, obs, site_random_effects=Tr
     at = Ks + Ko + 2
     beta, alpha = theta[: Ks + 1], theta[Ks + 1: at]
     lp = 0.0
+    f_c = f_u = 0.0
+    if re_fp_mode is not None:   # with a false-positive rate (occu.py:146-157): theta = [beta, alpha, phi = logit(rate), ...]
+        from scipy.special import betaln
+
+        f = 1.0 / (1.0 + np.exp(-theta[at]))
+        at += 1
+        f_c, f_u = (f, 0.0) if re_fp_mode == "constant" else (0.0, f)
+        lp += (prior_fp[0] - 1.0) * np.log(f) + (prior_fp[1] - 1.0) * np.log1p(-f) - betaln(*prior_fp) + np.log(f) + np.log1p(-f)
 
     def half_normal_on_log_scale(phi, scale):      # dist.HalfNormal(scale).log_prob(sd) + log|d sd / d phi|
         sd = np.exp(phi)
@@ -363,7 +377,10 @@ def literal_log_joint_re(theta, site_covs, obs_covs, obs, site_random_effects=Tr
     y0 = np.where(finite, Y, 0.0)
     per_z = []
     for z in (0.0, 1.0):
-        if z == 1.0:   # exact log-sigmoid in the z = 1 branch, as literal_log_joint(clamp_z1=False)
+        if re_fp_mode is not None:   # occu.py:229-241: 1 - (1 - z p)(1 - f_c)(1 - (1 - z) f_u), numpyro's clamp in both branches
+            pdet = 1.0 / (1.0 + np.exp(-det_linear))
+            ly = _bernoulli_logpmf_clamped(1.0 - (1.0 - z * pdet) * (1.0 - f_c) * (1.0 - (1.0 - z) * f_u), y0)
+        elif z == 1.0:   # exact log-sigmoid in the z = 1 branch, as literal_log_joint(clamp_z1=False)
             ly = y0 * (-np.logaddexp(0.0, -det_linear)) + (1.0 - y0) * (-np.logaddexp(0.0, det_linear))
         else:
             ly = _bernoulli_logpmf_clamped(np.zeros_like(det_linear), y0)

@@ -81,8 +81,11 @@ def test_occu_validates_like_reference():
     # several species share the sds (occu.py:170-173): accepted, fit() samples them under one chain
     two = occu(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]), site_random_effects=True)
     assert two.model == "occu_re" and two.obs.shape[0] == 2
-    with pytest.raises(NotImplementedError, match="together with false positives"):
-        occu(g["site_covs"], g["obs_covs"], obs=g["obs"], site_random_effects=True, false_positives_constant=True)
+    # random effects together with false positives (occu.py:146-157 with :170-173): one species
+    both = occu(g["site_covs"], g["obs_covs"], obs=g["obs"], site_random_effects=True, false_positives_constant=True)
+    assert both.model == "occu_re" and both.extras["re_fp_mode"] == "constant" and both.extras["prior_fp"] == (2.0, 5.0)
+    with pytest.raises(NotImplementedError, match="together with false positives for several species"):
+        occu(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]), site_random_effects=True, false_positives_constant=True)
     # false positives (occu.py:146-157): one species, Beta prior on the rate
     fp = occu(g["site_covs"], g["obs_covs"], obs=g["obs"], false_positives_constant=True)
     assert fp.model == "occu_fp" and fp.extras == dict(fp_mode="constant", prior_fp=(2.0, 5.0))

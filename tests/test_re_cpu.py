@@ -134,3 +134,27 @@ def test_re_several_species_potential_is_the_sum_with_shared_sds():
         sd = math.exp(phi)
         own += -(0.5 * math.log(2 / math.pi) - math.log(s0) - 0.5 * sd * sd / (s0 * s0) + phi)
     assert U[0] == pytest.approx(tot - (S - 1) * own, rel=1e-12)
+
+
+@pytest.mark.parametrize("mode", ["constant", "unoccupied"])
+@pytest.mark.parametrize("site,obs", [(True, False), (False, True), (True, True)])
+def test_re_with_false_positives_equals_literal_model_and_finite_differences(mode, site, obs):
+    """occu(site_random_effects / obs_random_effects, false_positives_* ) together (occu.py:146-157 with :170-173, 191-196):
+    theta = [beta, alpha, phi = logit(rate), (log sds), (effects)]; the C closed form against the literal statement (z summed by
+    brute force, numpyro's clamps) and its analytic gradient against central differences."""
+    rng = np.random.default_rng(7)
+    N, T, J, Ks, Ko = 9, 2, 4, 2, 2
+    X, W = rng.normal(size=(N, Ks)), rng.normal(size=(N, T, J, Ko))
+    Y = (rng.uniform(size=(N, T, J)) < 0.4) * 1.0
+    Y[1, 1, 1] = np.nan
+    W[3, 1, 0, 1] = np.nan
+    od = oracle.OracleData(X, W, Y, model="occu_re", site_random_effects=site, obs_random_effects=obs, prior_site_re_sd=0.7,
+                           prior_obs_re_sd=1.3, re_fp_mode=mode, prior_fp=(2.0, 6.0))
+    assert od.D == Ks + Ko + 2 + 1 + site + obs + (2 * N if site else 0) + (N * T * J if obs else 0)
+    th = rng.uniform(-1, 1, size=od.D)
+    U, G = od.potential_grad(th)
+    lit = oracle.literal_log_joint_re(th, X, W, Y, site, obs, 0.7, 1.3, re_fp_mode=mode, prior_fp=(2.0, 6.0))
+    assert abs(U + lit) < 1e-10 * max(1.0, abs(U))
+    h = 1e-6
+    fd = np.array([(od.potential_grad(th + h * e)[0] - od.potential_grad(th - h * e)[0]) / (2 * h) for e in np.eye(od.D)])
+    assert np.max(np.abs(fd - G)) < 1e-6 * max(1.0, np.max(np.abs(G)))

@@ -26,7 +26,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     for s in range(3):
         r = ds.nuts(num_warmup=1000, num_samples=1000, num_chains=4, seed=s)
         per_chain = r.n_leapfrog.sum(axis=1)
-        print(f"  cfg4 seed {s}: kernel {r.kernel_ms:8.2f} ms  {1e3 * r.kernel_ms / per_chain.max():6.2f} us/leapfrog (slowest chain {int(per_chain.max())} of {int(per_chain.sum())})"
+        print(f"  cfg4 seed {s}: kernel {r.kernel_ms:8.2f} ms  {1e3 * r.kernel_ms / per_chain.max():6.2f} us/leapfrog (slowest chain {int(per_chain.max())} of {int(per_chain.sum())}; {1e3 * r.kernel_ms / per_chain.mean():6.2f} by the chains' mean, the bench line's figure)"
               f"  k={r.wgs_per_chain} div {int(r.diverging.sum())} l2local {r.chains_l2_local} means {r.draws.reshape(-1, 8).mean(0).round(3).tolist()}")
 else:
     libs = sys.argv[1:] or [os.path.join("biolith_amd", "lib", "libbiolith_hip.so")]
