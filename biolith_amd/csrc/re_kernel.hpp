@@ -36,8 +36,6 @@ struct BlReModel {
     int site_re, obs_re;
     int kind;                             // 0: occu with random effects; 1: occu_cs (continuous scores, no effects: D = G = G0 + 4);
                                           // 2: occu with random effects AND a false-positive rate (occu.py:146-157 with :170-173, 191-196)
-    int fp_mode, o_fp;                    // kind 2: 1 = the rate acts on every site ("constant"), 2 = on unoccupied sites; phi = logit(rate) at o_fp = G0
-    float fp_a, fp_b;                     // kind 2: Beta(a, b) prior of the rate
     const float *scores;                  // kind 1: the replicates' scores, site-fastest [T J][n_stride] (0 where masked)
     float cs_mu[4], cs_sg[4];             // kind 1: Normal(loc, scale) of mu0 and of mu1's base; Gamma(concentration, rate) of sigma0, sigma1
     int G0, G, D;                         // fixed effects (of all species), + log sds, all coordinates
@@ -61,6 +59,9 @@ struct BlReModel {
     int n_rows;                           // rows of the dataset (KS + T J (KO + 1) + 2 T)
     int lds_rows;                         // 1: every workgroup keeps its own copy of the rows in LDS (n_rows * n_sites floats)
     int lds_hot;                          // 1 / 2: the first RE_HOT / RE_WARM vectors of the chain live in LDS (after the rows), not in device memory
+    // kind 2 only (kept at the end: the other kinds' kernels never load them)
+    int fp_mode, o_fp;                    // 1 = the rate acts on every site ("constant"), 2 = on unoccupied sites; phi = logit(rate) at o_fp = G0
+    float fp_a, fp_b;                     // Beta(a, b) prior of the rate
 };
 
 // The dataset's rows for this workgroup: staged into dynamic LDS once when they fit, else read from device memory (L2).
@@ -668,7 +669,7 @@ __device__ __forceinline__ double bl_cs_extra_potential(const BlReModel &m, cons
 
 // Potential gradient of a fixed effect / log sd coordinate d < G at position z, from the reduced sums of the site pass
 // (red[0 .. 2MK+2]) and of the effects' squares (red[OX] = sum u^2 + v^2, red[OX+1] = sum e^2).
-template <int MK>
+template <int MK, bool FP = false>
 __device__ __forceinline__ float bl_re_global_grad(const BlReModel &m, int d, float zd, const double *red, const double *red_sp = nullptr,
                                                    int nred = 0)
 {
@@ -683,7 +684,7 @@ __device__ __forceinline__ float bl_re_global_grad(const BlReModel &m, int d, fl
         return (float)(-gl) + fmaf(dth, isc2, dth > 0.0f ? l1 : (dth < 0.0f ? -l1 : 0.0f));
     }
     if (m.kind == 1) return 0.0f; // (occu_cs: its four extra coordinates are handled by bl_cs_extra_grad)
-    if (m.kind == 2 && d == m.o_fp) {
+    if (FP && d == m.o_fp) {
         // phi = logit f, f ~ Beta(a, b), Jacobian included: energy a softplus(-phi) + b softplus(phi); red[OX + 6] = d ll / d phi
         const float e = bl_exp(-fabsf(zd)), sig = (zd > 0.0f ? 1.0f : e) * bl_rcp(1.0f + e);
         return (float)(-red[OX + 6]) + (m.fp_a + m.fp_b) * sig - m.fp_a;
@@ -697,10 +698,11 @@ __device__ __forceinline__ float bl_re_global_grad(const BlReModel &m, int d, fl
 }
 
 // Potential at z from the reduced sums (f64): red[0] = log-lik, pe2 = sum over fixed effects of ((z - loc) / scale)^2
+template <bool FP = false>
 __device__ __forceinline__ double bl_re_potential(const BlReModel &m, const float *z, const double *red, double pe2, int OX)
 {
     double U = -red[0] + 0.5 * pe2 + m.u_const;
-    if (m.kind == 2) {
+    if constexpr (FP) {
         const double phi = z[m.o_fp], l = log1p(exp(-fabs(phi)));
         U += m.fp_a * (fmax(-phi, 0.0) + l) + m.fp_b * (fmax(phi, 0.0) + l);
     }
@@ -789,8 +791,10 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel gm
         if (sp == S - 1) { // fixed effects of every species and the log sds, from the species' and the total sums
             for (int d = tid; d < m.G; d += BL_RE_NT)
                 grad[(size_t)b * gm.D + d] = (double)((m.kind == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red_tot)
-                                                                                 : bl_re_global_grad<MK>(m, d, z[d], red_tot, red_sp, NRED));
-            if (tid == 0) U[b] = bl_re_potential(m, z, red_tot, red_tot[OX + 2], OX) + (m.kind == 1 ? bl_cs_extra_potential(m, z) : 0.0);
+                                                      : (m.kind == 2 ? bl_re_global_grad<MK, true>(m, d, z[d], red_tot, red_sp, NRED)
+                                                                     : bl_re_global_grad<MK>(m, d, z[d], red_tot, red_sp, NRED)));
+            if (tid == 0) U[b] = (m.kind == 2 ? bl_re_potential<true>(m, z, red_tot, red_tot[OX + 2], OX) : bl_re_potential(m, z, red_tot, red_tot[OX + 2], OX))
+                                 + (m.kind == 1 ? bl_cs_extra_potential(m, z) : 0.0);
         }
     }
 }
@@ -886,7 +890,8 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
             v[OX] = part[OX]; v[OX + 1] = part[OX + 1]; v[OX + 6] = part[OX + 2]; v[OX + 7] = part[OX + 3];
         } else {
             float part[2 * MK + 3], ss[2], gphi = 0.0f;
-            bl_re_site_pass<MK, KIND == 2>(m, rows, rows_ns, rows_rv, z, g, part, &gphi);
+            if constexpr (KIND == 2) bl_re_site_pass<MK, true>(m, rows, rows_ns, rows_rv, z, g, part, &gphi);
+            else bl_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
             BL_RE_T(8)
             bl_re_effect_squares(m, z, ss);
 #pragma unroll
@@ -915,8 +920,8 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
         if (ev_first && R.allow_local) xc.local = ((double)R.k * red[OX + 5] == red[OX + 4] * red[OX + 4]); // exact: small integers
         if (red[OX + 3] > 0.0) flag = 5;
         for (int d = tid; d < G; d += BL_RE_NT)
-            g[d] = (KIND == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red) : bl_re_global_grad<MK>(m, d, z[d], red, red_sp, NRED);
-        double U = bl_re_potential(m, z, red, red[OX + 2], OX);
+            g[d] = (KIND == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red) : bl_re_global_grad<MK, KIND == 2>(m, d, z[d], red, red_sp, NRED);
+        double U = bl_re_potential<KIND == 2>(m, z, red, red[OX + 2], OX);
         if constexpr (KIND == 1) U += bl_cs_extra_potential(m, z);
         BL_RE_T(1)
         return U;
