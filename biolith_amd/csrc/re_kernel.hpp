@@ -62,6 +62,10 @@ struct BlReModel {
     // kind 2 only (kept at the end: the other kinds' kernels never load them)
     int fp_mode, o_fp;                    // 1 = the rate acts on every site ("constant"), 2 = on unoccupied sites; phi = logit(rate) at o_fp = G0
     float fp_a, fp_b;                     // Beta(a, b) prior of the rate
+    // kind 3 only: N-mixture with random effects (nmixture.py:139-141, 166-172, 199-214) -- the count model's rows
+    // (visit = (m y, m, w..)) and its data-only table tab[t][n][site] = sum_j m log C(n, y_j) (-inf below the largest count)
+    const float *tab;
+    int tab_ld, max_abundance;
 };
 
 // The dataset's rows for this workgroup: staged into dynamic LDS once when they fit, else read from device memory (L2).
@@ -134,6 +138,7 @@ __device__ __forceinline__ BlReModel bl_re_slice(const BlReModel &g, int sp, int
 {
     BlReModel m = g;
     m.rows = g.rows + s0; m.n_sites = cnt; m.s0 = s0;
+    if (g.kind == 3) m.tab = g.tab + s0;
     m.sp = sp; m.cb = sp * g.G0s; m.rv0 = g.KS + sp * g.sp_rows;
     if (g.kind == 1) m.scores = g.scores + s0;
     int at = g.G;
@@ -525,6 +530,114 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
     if constexpr (FP) *gphi = gp;
 }
 
+// ---- N-mixture with random effects (kind 3; biolith/models/nmixture.py:139-141, 166-172, 199-214) ----
+// site_re_abu_i joins the abundance predictor, site_re_det_i and obs_re_itj the detection predictor; the layout of the coordinates,
+// the sds and the effects' priors are the occupancy model's (kind 0), so only this site pass differs.  With nu = logit p:
+//   l = sum_j m y_j nu_j - lambda + logsumexp_n [ n (eta + c) - lgamma(n+1) + B_n ],   c = sum_j m log(1 - p_j),
+//   d l / d eta = E[n] - lambda,   d l / d nu_j = m (y_j - E[n] p_j)          (bl_eval_sites_nmix, occu_device.hpp).
+// One thread per site (this model's sums over n are cheap -- no per-visit recursion); rows: the count model's, visit = (m y, m, w..).
+template <int MK>
+__device__ __forceinline__ void bl_nmix_re_site_pass(const BlReModel &m, const float *__restrict__ rows, int ns, int rv,
+                                                     const float *__restrict__ z, float *__restrict__ g, float (&part)[2 * MK + 3])
+{
+    const int N = m.n_sites, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 2, K = m.max_abundance;
+    float beta[MK + 1], alpha[MK + 1];
+#pragma unroll
+    for (int k = 0; k <= MK; k++) {
+        const float b = z[m.cb + min(k, Ks)], a = z[m.cb + Ks + 1 + min(k, Ko)];
+        beta[k] = k <= Ks ? b : 0.0f;
+        alpha[k] = k <= Ko ? a : 0.0f;
+    }
+    const float isd2_s = m.site_re ? bl_exp(-2.0f * z[m.o_phi_s]) : 0.0f;
+    const float isd2_o = m.obs_re ? bl_exp(-2.0f * z[m.o_phi_o]) : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2 * MK + 3; k++) part[k] = 0.0f;
+    for (int i = threadIdx.x; i < N; i += BL_RE_NT) {
+        float x[MK];
+        float eta = beta[0];
+#pragma unroll
+        for (int k = 0; k < MK; k++) {
+            const float xk = rows[min(k, Ks) * ns + i];
+            x[k] = k < Ks ? xk : 0.0f;
+            eta = fmaf(x[k], beta[k + 1], eta);
+        }
+        const float ui = m.site_re ? z[m.o_u + i] : 0.0f, vi = m.site_re ? z[m.o_v + i] : 0.0f;
+        eta += ui;
+        const float lam = bl_exp(fminf(eta, 80.0f));
+        float dl_deta = 0.0f, dl_dv = 0.0f;
+        for (int t = 0; t < T; t++) {
+            float a = 0.0f, c = 0.0f, gy[MK + 1], gp[MK + 1];
+#pragma unroll
+            for (int k = 0; k <= MK; k++) { gy[k] = 0.0f; gp[k] = 0.0f; }
+            for (int j = 0; j < J; j++) {
+                const int v = t * J + j, r0 = (rv + v * vw) * ns + i;
+                const float ym = rows[r0], mk = rows[r0 + ns];
+                float w[MK];
+                float nu = alpha[0] + vi + (m.obs_re ? z[m.o_e + v * N + i] : 0.0f);
+#pragma unroll
+                for (int k = 0; k < MK; k++) {
+                    const float wk = rows[r0 + (2 + min(k, max(Ko, 1) - 1)) * ns];
+                    w[k] = k < Ko ? wk : 0.0f;
+                    nu = fmaf(w[k], alpha[k + 1], nu);
+                }
+                const float e = bl_exp(-fabsf(nu)), op = 1.0f + e;
+                const float sp = fmaxf(nu, 0.0f) + bl_log(op);              // softplus(nu)
+                const float p = (nu > 0.0f ? 1.0f : e) * bl_rcp(op) * mk;   // m sigmoid(nu)
+                a = fmaf(ym, nu, a);
+                c = fmaf(mk, -sp, c);
+                gy[0] += ym; gp[0] += p;
+#pragma unroll
+                for (int k = 0; k < MK; k++) { gy[k + 1] = fmaf(ym, w[k], gy[k + 1]); gp[k + 1] = fmaf(p, w[k], gp[k + 1]); }
+            }
+            // logsumexp over n of  n (eta + c) - lgamma(n+1) + B_n:  the maximum and the last term within 25 nats of the running
+            // maximum (the terms are concave in n above the largest count), then the sums up to there
+            const float slope = eta + c;
+            const float *b = m.tab + (size_t)t * (K + 1) * m.tab_ld + i;
+            float mx = -INFINITY;
+            int hi = 0;
+            for (int n = 0; n <= K; n++) {
+                const float tn = fmaf((float)n, slope, b[(size_t)n * m.tab_ld] - BL_LGAMMA1P[n]);
+                mx = fmaxf(mx, tn);
+                hi = tn >= mx - 25.0f ? n : hi;
+            }
+            float S = 0.0f, S1 = 0.0f;
+            for (int n = 0; n <= hi; n++) {
+                const float en = bl_exp(fmaf((float)n, slope, b[(size_t)n * m.tab_ld] - BL_LGAMMA1P[n]) - mx);
+                S += en;
+                S1 = fmaf((float)n, en, S1);
+            }
+            const float En = S1 * bl_rcp(S);
+            part[0] += a - lam + mx + bl_log(S);
+            dl_deta += En - lam;
+#pragma unroll
+            for (int k = 0; k <= MK; k++) part[MK + 2 + k] += gy[k] - En * gp[k];
+            dl_dv += gy[0] - En * gp[0];
+            if (m.obs_re) { // each replicate's own effect: d U / d e = -(m y - E[n] m p) + e / sd^2 (p recomputed: nothing was kept per visit)
+                for (int j = 0; j < J; j++) {
+                    const int v = t * J + j, r0 = (rv + v * vw) * ns + i;
+                    const float ym = rows[r0], mk = rows[r0 + ns], ev = z[m.o_e + v * N + i];
+                    float nu = alpha[0] + vi + ev;
+#pragma unroll
+                    for (int k = 0; k < MK; k++) {
+                        const float wk = rows[r0 + (2 + min(k, max(Ko, 1) - 1)) * ns];
+                        nu = fmaf(k < Ko ? wk : 0.0f, alpha[k + 1], nu);
+                    }
+                    const float e = bl_exp(-fabsf(nu));
+                    const float p = (nu > 0.0f ? 1.0f : e) * bl_rcp(1.0f + e) * mk;
+                    g[m.o_e + v * N + i] = fmaf(ev, isd2_o, -(ym - En * p));
+                }
+            }
+        }
+        part[1] += dl_deta;
+#pragma unroll
+        for (int k = 0; k < MK; k++) part[2 + k] = fmaf(dl_deta, x[k], part[2 + k]);
+        if (m.site_re) {
+            g[m.o_u + i] = fmaf(ui, isd2_s, -dl_deta);
+            g[m.o_v + i] = fmaf(vi, isd2_s, -dl_dv);
+        }
+    }
+}
+
 // ---- occu_cs (biolith/models/occu_cs.py:120-232): s ~ Normal(mu_f, sigma_f), f ~ Bernoulli(z p), z ~ Bernoulli(psi); z and every
 // f summed out (the f of different replicates are independent given z).  Coordinates: [beta, alpha, mu0, x1 = log(mu1 - mu0),
 // log sigma0, log sigma1].  Site pass: part[0] = ll, [1..5] d/d beta, [6..10] d/d alpha, [11..14] d/d (mu0, mu1, log sigma0, log sigma1).
@@ -776,6 +889,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel gm
         } else {
             float part[2 * MK + 3], ss[2], gphi = 0.0f;
             if (m.kind == 2) bl_re_site_pass<MK, true>(m, rows, ns, rv, z, g, part, &gphi);
+            else if (m.kind == 3) bl_nmix_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
             else bl_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
             bl_re_effect_squares(m, z, ss);
 #pragma unroll
@@ -891,6 +1005,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
         } else {
             float part[2 * MK + 3], ss[2], gphi = 0.0f;
             if constexpr (KIND == 2) bl_re_site_pass<MK, true>(m, rows, rows_ns, rows_rv, z, g, part, &gphi);
+            else if constexpr (KIND == 3) bl_nmix_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
             else bl_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
             BL_RE_T(8)
             bl_re_effect_squares(m, z, ss);

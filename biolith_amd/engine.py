@@ -167,8 +167,18 @@ class OccuDataset:
             with np.errstate(invalid="ignore"):
                 if np.isfinite(Y).any() and np.nanmax(Y) > max_abundance:
                     raise ValueError(f"max_abundance={max_abundance} is below the largest count {np.nanmax(Y):g}")
-            _ffi.check(lib.bl_dataset_create_nmix(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), int(max_abundance),
-                                                  C.byref(pb), C.byref(pa), device, C.byref(h)))
+            if site_random_effects or obs_random_effects:
+                # theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_abu[N], site_re_det[N]), (obs_re[N][T][J])]
+                _ffi.check(lib.bl_dataset_create_nmix_re(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), int(max_abundance),
+                                                         int(bool(site_random_effects)), int(bool(obs_random_effects)),
+                                                         float(prior_site_re_sd), float(prior_obs_re_sd), C.byref(pb), C.byref(pa),
+                                                         device, C.byref(h)))
+                d = C.c_int()
+                _ffi.check(lib.bl_dataset_param_dim(h, C.byref(d)))
+                self.D = int(d.value)
+            else:
+                _ffi.check(lib.bl_dataset_create_nmix(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), int(max_abundance),
+                                                      C.byref(pb), C.byref(pa), device, C.byref(h)))
         elif model == "occu_cop":
             if session_duration is None:
                 raise ValueError("occu_cop needs session_duration (n_sites, n_periods, n_replicates)")

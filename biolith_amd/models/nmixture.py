@@ -12,7 +12,7 @@ from typing import Any
 
 import numpy as np
 
-from ..distributions import HalfNormal, Normal, as_normal
+from ..distributions import HalfNormal, Normal, as_half_normal, as_normal
 from ..regression import LinearRegression
 from ._generators import Generator, expit, observed_mean, within
 from .occu import OccuSpec
@@ -42,8 +42,10 @@ def nmixture(
 ) -> OccuSpec:
     """N-mixture model on the HIP engine (parameters: nmixture.py:17-35).
 
-    Built: linear regressors, Normal priors, no spatial / random effects, ``max_abundance`` <= 127; several species are sampled species by species.  Everything else raises
-    ``NotImplementedError``.
+    Built: linear regressors, Normal priors, no spatial effect, ``max_abundance`` <= 127; several species are sampled species by
+    species.  ``site_random_effects`` / ``obs_random_effects`` with HalfNormal priors on their sds (nmixture.py:139-141, 166-172,
+    199-214) run on the random-effects kernels, one species per fit (the sds are sampled outside the species plate, so several
+    species would share them under one chain -- not built for the count model).  Everything else raises ``NotImplementedError``.
 
     Examples
     --------
@@ -72,8 +74,8 @@ def nmixture(
     unsupported = []
     if coords is not None:
         unsupported.append("coords (spatial HSGP effect, nmixture.py:125-133)")
-    if site_random_effects or obs_random_effects:
-        unsupported.append("random effects (nmixture.py:136-139)")
+    if (site_random_effects or obs_random_effects) and obs is not None and n_species > 1:
+        unsupported.append("random effects with several species (the sds are shared across the species plate, nmixture.py:139-141)")
     if regressor_abu is not LinearRegression or regressor_det is not LinearRegression:
         unsupported.append("non-linear regressors (nmixture.py:160-161)")
     if obs is None:
@@ -87,6 +89,10 @@ def nmixture(
     spec = OccuSpec(site_covs, obs_covs, obs, n_species, as_normal(prior_beta, "prior_beta"),
                     as_normal(prior_alpha, "prior_alpha"), model="nmixture")
     spec.extras["max_abundance"] = int(max_abundance)
+    if site_random_effects or obs_random_effects:
+        spec.extras.update(site_random_effects=bool(site_random_effects), obs_random_effects=bool(obs_random_effects),
+                           prior_site_re_sd=as_half_normal(prior_site_re_sd, "prior_site_re_sd"),
+                           prior_obs_re_sd=as_half_normal(prior_obs_re_sd, "prior_obs_re_sd"))
     return spec
 
 
@@ -116,7 +122,7 @@ def simulate_nmixture(
     obs_re_sd: float = 0.3,
 ):
     """Generator of :func:`nmixture` data, bit-identical to the reference's (nmixture.py:223-369) for
-    ``spatial=False`` and no random effects: same NumPy PCG64 stream, draw order and rejection loop.
+    ``spatial=False`` (random effects included: nmixture.py:285-310): same NumPy PCG64 stream, draw order and rejection loop.
 
     Examples
     --------
@@ -125,8 +131,8 @@ def simulate_nmixture(
     >>> sorted(data.keys())
     ['coords', 'ell', 'obs', 'obs_covs', 'site_covs']
     """
-    if spatial or site_random_effects or obs_random_effects:
-        raise NotImplementedError("simulate_nmixture: spatial and random effects are not built")
+    if spatial:
+        raise NotImplementedError("simulate_nmixture(spatial=True) is outside the built path (utils/spatial.py:52-76)")
 
     def latent(rng, abu_linear):  # nmixture.py:295-296
         return rng.poisson(np.exp(abu_linear)[:, None, :], size=(n_species, n_periods, n_sites))
@@ -140,9 +146,14 @@ def simulate_nmixture(
 
     n_replicates = round(deployment_days_per_site / session_duration)
     d = Generator(n_species, n_sites, n_periods, n_replicates, n_site_covs, n_obs_covs, latent, observe, accept,
+                  site_re_sd=site_re_sd if site_random_effects else None, obs_re_sd=obs_re_sd if obs_random_effects else None,
                   simulate_missing=simulate_missing).run(random_seed)
     print(f"True abundance: {np.mean(d.latent):.4f}")
     print(f"Mean count: {np.mean(d.obs[np.isfinite(d.obs)]):.4f}")
     true_params = dict(N_i=d.latent, abundance=np.exp(d.site_linear), beta=d.beta, alpha=d.alpha, w=d.extra["w"],
                        gp_sd=gp_sd, gp_l=gp_l)
+    if site_random_effects:   # nmixture.py:348-356
+        true_params.update(site_re_abu=d.extra["site_re_a"], site_re_det=d.extra["site_re_b"], site_re_sd=site_re_sd)
+    if obs_random_effects:    # nmixture.py:357-363
+        true_params.update(obs_re=d.extra["obs_re"], obs_re_sd=obs_re_sd)
     return dict(site_covs=d.site_covs, obs_covs=d.obs_covs, obs=d.obs, coords=None, ell=0.0), true_params

@@ -92,6 +92,8 @@ def predict(
 
     if spec.model == "occu_re" and spec.extras.get("re_fp_mode") is not None:
         raise NotImplementedError("predict(): random effects together with false positives are fitted, not yet predicted, on the HIP engine")
+    if spec.model == "nmixture" and "site_random_effects" in spec.extras:
+        raise NotImplementedError("predict(): the N-mixture model with random effects is fitted, not yet predicted, on the HIP engine")
     fp_site = f"prob_fp_{spec.extras['fp_mode']}" if spec.model == "occu_fp" else None
     if fp_site is not None:
         rate = np.clip(np.asarray(posterior[fp_site], dtype=np.float64).reshape(n), 1e-300, 1 - 1e-16)

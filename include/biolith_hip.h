@@ -159,6 +159,15 @@ int bl_dataset_create_re_fp(const bl_dims *dims, const float *site_covs, const f
                             int site_random_effects, int obs_random_effects, double prior_site_re_sd_scale,
                             double prior_obs_re_sd_scale, int fp_mode, const bl_beta_prior *prior_fp,
                             const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
+/* The N-mixture model with the same random effects (biolith/models/nmixture.py:139-141, 166-172, 199-214: site_re_abu joins the
+ * abundance predictor, site_re_det and obs_re the detection predictor): `counts` / max_abundance as for bl_dataset_create_nmix,
+ * theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_abu[N], site_re_det[N]), (obs_re[N][T][J])].  One species
+ * per dataset.  bl_logp_grad / bl_nuts_* as above; bl_deterministic returns abundance = exp(eta + site_re_abu) and the
+ * detection probability with its effects; bl_predict / bl_predict_counts are not built for it. */
+int bl_dataset_create_nmix_re(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *counts,
+                              int max_abundance, int site_random_effects, int obs_random_effects,
+                              double prior_site_re_sd_scale, double prior_obs_re_sd_scale, const bl_normal_prior *prior_beta,
+                              const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
 /*
  * The continuous-score occupancy model biolith.models.occu_cs (models/occu_cs.py:17-232; Rhinehart et al. 2022): `scores`
  * [S=1][N][T][J] (NaN = missing) ~ Normal(mu_f, sigma_f) with f ~ Bernoulli(z p) and z ~ Bernoulli(psi) summed out.

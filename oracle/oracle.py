@@ -59,6 +59,7 @@ def lib():
             L.orc_data_set_nmix.argtypes = [C.c_void_p, dp, C.c_int]
             L.orc_data_set_re.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_re_fp.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+            L.orc_data_set_nmix_re.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_prior_family.argtypes = [C.c_void_p, C.c_int, C.c_int]
             L.orc_data_set_cs.argtypes = [C.c_void_p, dp, dp, dp]
             L.orc_data_set_dyn.argtypes = [C.c_void_p]
@@ -132,6 +133,10 @@ class OracleData:
             self.D += 1
         if model == "nmixture":  # counts, N enumerated over 0..max_abundance with raw (un-renormalised) Poisson weights
             lib().orc_data_set_nmix(self._h, _dp(Y), int(max_abundance))
+            if site_random_effects or obs_random_effects:   # nmixture.py:139-141, 166, 199: the layout of occu's random effects
+                lib().orc_data_set_nmix_re(self._h, int(bool(site_random_effects)), int(bool(obs_random_effects)),
+                                           float(prior_site_re_sd), float(prior_obs_re_sd))
+                self.D = int(lib().orc_data_dim(self._h))
         if model == "occu_cop":  # counts + exposure; optional false-positive rate as trailing phi = log(rate)
             assert fp_mode in (None, "constant", "unoccupied")
             Dur = _as_f32_f64(session_duration)
@@ -488,7 +493,8 @@ def literal_log_joint_cop(theta, site_covs, obs_covs, obs, session_duration, fp_
     return out
 
 
-def literal_log_joint_nmix(theta, site_covs, obs_covs, obs, max_abundance=100, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):
+def literal_log_joint_nmix(theta, site_covs, obs_covs, obs, max_abundance=100, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0),
+                           site_random_effects=False, obs_random_effects=False, prior_site_re_sd=1.0, prior_obs_re_sd=1.0):
     """log density of the N-mixture model (biolith/models/nmixture.py:150-220), N summed by brute force with the
     model's own ingredients: Poisson logits masked below the largest count, the ``N_i_trunc_norm`` factor and the
     (normalising) Categorical, Binomial log-pmf as numpyro states it."""
@@ -499,21 +505,46 @@ def literal_log_joint_nmix(theta, site_covs, obs_covs, obs, max_abundance=100, p
         Y = Y[0]
     Ks, Ko = X.shape[1], W.shape[-1]
     theta = np.asarray(theta, dtype=np.float64)
-    beta, alpha = theta[: Ks + 1], theta[Ks + 1:]
+    beta, alpha = theta[: Ks + 1], theta[Ks + 1: Ks + Ko + 2]
+    # random effects (nmixture.py:139-141, 166-172, 199-214): theta = [beta, alpha, (log site_re_sd), (log obs_re_sd),
+    # (site_re_abu[N], site_re_det[N]), (obs_re[N][T][J])]; a HalfNormal site lives on the log scale (+ log-Jacobian)
+    N_, T_, J_ = Y.shape
+    at, lp_re = Ks + Ko + 2, 0.0
+    re_abu = re_det = np.zeros(N_)
+    obs_re = np.zeros((N_, T_, J_))
+
+    def half_normal_on_log_scale(phi, scale):
+        return 0.5 * np.log(2.0 / np.pi) - np.log(scale) - 0.5 * (np.exp(phi) / scale) ** 2 + phi
+
+    def normal0(v, sd):
+        return (-0.5 * (v / sd) ** 2 - np.log(sd) - 0.5 * np.log(2 * np.pi)).sum()
+
+    sd_s = sd_o = None
+    if site_random_effects:
+        lp_re += half_normal_on_log_scale(theta[at], prior_site_re_sd); sd_s = np.exp(theta[at]); at += 1
+    if obs_random_effects:
+        lp_re += half_normal_on_log_scale(theta[at], prior_obs_re_sd); sd_o = np.exp(theta[at]); at += 1
+    if site_random_effects:
+        re_abu, re_det = theta[at: at + N_], theta[at + N_: at + 2 * N_]; at += 2 * N_
+        lp_re += normal0(re_abu, sd_s) + normal0(re_det, sd_s)
+    if obs_random_effects:
+        obs_re = theta[at: at + N_ * T_ * J_].reshape(N_, T_, J_); at += N_ * T_ * J_
+        lp_re += normal0(obs_re, sd_o)
+    assert at == theta.size
     obs_mask = np.isnan(W).any(-1) | np.isnan(X).any(-1)[:, None, None]     # nmixture.py:117-123
     Y = np.where(obs_mask, np.nan, Y)
     W, X = np.nan_to_num(W), np.nan_to_num(X)
     with np.errstate(invalid="ignore"):
         obs_max = np.max(np.where(np.isnan(Y), -np.inf, Y), axis=2)          # nmixture.py:150-155 (over replicates)
     min_counts = np.where(np.isfinite(obs_max), obs_max, 0).astype(int)     # (N, T)
-    abundance = np.exp(beta[0] + X @ beta[1:])                              # (N,)
+    abundance = np.exp(beta[0] + X @ beta[1:] + re_abu)                     # (N,)
     support = np.arange(max_abundance + 1)
     logits = xlogy(support[None, :], abundance[:, None]) - gammaln(support + 1.0)[None, :] - abundance[:, None]   # Poisson.log_prob
     logits = np.broadcast_to(logits[:, None, :], min_counts.shape + (max_abundance + 1,)).copy()
     logits[support[None, None, :] < min_counts[..., None]] = -np.inf        # nmixture.py:186-190
     trunc_norm = logsumexp(logits, axis=-1)                                 # factor "N_i_trunc_norm"
     log_cat = logits - trunc_norm[..., None]                                # Categorical(logits).log_prob
-    p = 1.0 / (1.0 + np.exp(-(alpha[0] + np.tensordot(W, alpha[1:], axes=([3], [0])))))   # (N, T, J)
+    p = 1.0 / (1.0 + np.exp(-(alpha[0] + np.tensordot(W, alpha[1:], axes=([3], [0])) + re_det[:, None, None] + obs_re)))   # (N, T, J)
     finite = np.isfinite(Y)
     y0 = np.where(finite, Y, 0.0)
     n = support[None, None, None, :].astype(np.float64)                     # (1,1,1,K+1)
@@ -528,7 +559,7 @@ def literal_log_joint_nmix(theta, site_covs, obs_covs, obs, max_abundance=100, p
     def normal_logpdf(v, loc, scale):
         return (-0.5 * ((v - loc) / scale) ** 2 - np.log(scale) - 0.5 * np.log(2 * np.pi)).sum()
 
-    return ll + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
+    return ll + lp_re + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
 
 
 def literal_log_joint_dyn(theta, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):

@@ -130,6 +130,10 @@ NMIX_CASES = {
     "nmix_ref_test": dict(kw=NMIX_REF_TEST),
     "nmix_ref_test_3periods": dict(kw=dict(NMIX_REF_TEST, n_periods=3)),           # nmixture.py:423-431
     "nmix_small_2x2": dict(kw=dict(n_sites=60, n_site_covs=2, n_obs_covs=2, deployment_days_per_site=42, random_seed=4)),
+    # random effects (nmixture.py:285-310; the reference's own tests :516-600)
+    "nmix_site_re": dict(kw=dict(NMIX_REF_TEST, site_random_effects=True, obs_random_effects=False, deployment_days_per_site=140)),
+    "nmix_both_re": dict(kw=dict(n_sites=40, n_site_covs=2, n_obs_covs=1, deployment_days_per_site=42, site_random_effects=True,
+                                 obs_random_effects=True, site_re_sd=0.4, obs_re_sd=0.6, random_seed=3)),
 }
 
 
@@ -149,8 +153,9 @@ def main_nmix():
             mean_N=float(np.mean(truth["N_i"])), sha256_N=sha(truth["N_i"]), mean_obs=float(np.nanmean(data["obs"])),
             max_obs=float(np.nanmax(data["obs"])),
         )
+        extra = {k: np.asarray(truth[k]) for k in ("site_re_abu", "site_re_det", "obs_re") if k in truth}
         np.savez_compressed(os.path.join(HERE, f"simulate_{name}.npz"), site_covs=data["site_covs"], obs_covs=data["obs_covs"],
-                            obs=data["obs"], N_i=truth["N_i"], abundance=truth["abundance"], beta=truth["beta"], alpha=truth["alpha"])
+                            obs=data["obs"], N_i=truth["N_i"], abundance=truth["abundance"], beta=truth["beta"], alpha=truth["alpha"], **extra)
         print(name, index[name]["shapes"], index[name]["sha256"]["obs"][:24])
     with open(os.path.join(HERE, "simulate_nmix_index.json"), "w") as f:
         json.dump(index, f, indent=1, sort_keys=True)

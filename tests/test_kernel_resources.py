@@ -62,4 +62,4 @@ def test_vector_kernels_leave_the_lds_budget(tmp_path):
             if "Lb1ELi2EE" in name and "ILi4ELi2E" not in name:   # the form the bench sizes run: rows and every per-leapfrog vector in LDS
                 assert scratch == 0, (name, scratch)
         seen += 1
-    assert seen >= 38   # 2 capacities x 3 kinds x 2 x 3 LDS forms of the sampler + 2 parity kernels
+    assert seen >= 50   # 2 capacities x 4 kinds x 2 x 3 LDS forms of the sampler + 2 parity kernels
