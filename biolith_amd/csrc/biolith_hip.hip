@@ -357,7 +357,8 @@ extern "C" int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint6
         const int n1 = (n0 + chunk < n_draws) ? n0 + chunk : n_draws;
         const dim3 grid((N + 255) / 256, (n1 - n0) < 1024 ? (n1 - n0) : 1024);
         hipLaunchKernelGGL(bl_predict_kernel, grid, block, 0, nullptr, ds->d_rows, ds->d_wraw, ds->n_stride, N, T, J, ds->Ks, ds->Ko, D,
-                           d_draws, n0, n1, (unsigned long long)seed, ds->model, ds->max_abundance, ds->fp_mode, d_lat, d_y,
+                           d_draws, n0, n1, (unsigned long long)seed, ds->model == 6 && ds->re.kind == 4 ? 1 : ds->model /* Royle-Nichols with effects */,
+                           ds->max_abundance, ds->fp_mode, d_lat, d_y,
                            ds->model == 6 ? ds->re.o_u : -1, ds->model == 6 ? ds->re.o_v : -1, ds->model == 6 ? ds->re.o_e : -1);
         BL_HIP(hipGetLastError());
         if (latent) BL_HIP(hipMemcpy(latent + (size_t)n0 * T * N, d_lat, (size_t)(n1 - n0) * T * N, hipMemcpyDeviceToHost));
@@ -1035,6 +1036,7 @@ static hipError_t re_nuts_dispatch(int mk, const BlReRun &run, int grid, size_t 
 {
     if (run.m.kind == 2) return mk == 4 ? re_nuts_dispatch_lds<4, 2>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 2>(run, grid, lds, st);
     if (run.m.kind == 3) return mk == 4 ? re_nuts_dispatch_lds<4, 3>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 3>(run, grid, lds, st);
+    if (run.m.kind == 4) return mk == 4 ? re_nuts_dispatch_lds<4, 4>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 4>(run, grid, lds, st);
     if (mk == 4) return run.m.kind == 1 ? re_nuts_dispatch_lds<4, 1>(run, grid, lds, st) : re_nuts_dispatch_lds<4, 0>(run, grid, lds, st);
     return run.m.kind == 1 ? re_nuts_dispatch_lds<16, 1>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 0>(run, grid, lds, st);
 }
@@ -1075,7 +1077,7 @@ static size_t re_geometry(BlReModel &m, int nloc, int with_hot, int dl_max)
 
 static int create_re_impl(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
                           int site_random_effects, int obs_random_effects, double prior_site_re_sd_scale,
-                          double prior_obs_re_sd_scale, int fp_mode, double fp_a, double fp_b, int nmix_K, const bl_normal_prior *prior_beta,
+                          double prior_obs_re_sd_scale, int fp_mode, double fp_a, double fp_b, int count_model, int count_K, const bl_normal_prior *prior_beta,
                           const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
 
 extern "C" int bl_dataset_create_re(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
@@ -1084,7 +1086,7 @@ extern "C" int bl_dataset_create_re(const bl_dims *dims, const float *site_covs,
                                     const bl_normal_prior *prior_alpha, int device, bl_dataset **out)
 {
     return create_re_impl(dims, site_covs, obs_covs, obs, site_random_effects, obs_random_effects, prior_site_re_sd_scale,
-                          prior_obs_re_sd_scale, 0, 0.0, 0.0, 0, prior_beta, prior_alpha, device, out);
+                          prior_obs_re_sd_scale, 0, 0.0, 0.0, 0, 0, prior_beta, prior_alpha, device, out);
 }
 
 // occu(site_random_effects / obs_random_effects = True, false_positives_constant / _unoccupied = True): occu.py:146-157 with
@@ -1101,7 +1103,7 @@ extern "C" int bl_dataset_create_re_fp(const bl_dims *dims, const float *site_co
     if (dims && dims->n_species != 1)
         return bl_fail(BL_ERR_UNSUPPORTED, "random effects with a false-positive rate: one species per dataset (n_species=%d)", dims->n_species);
     return create_re_impl(dims, site_covs, obs_covs, obs, site_random_effects, obs_random_effects, prior_site_re_sd_scale,
-                          prior_obs_re_sd_scale, fp_mode, a, b, 0, prior_beta, prior_alpha, device, out);
+                          prior_obs_re_sd_scale, fp_mode, a, b, 0, 0, prior_beta, prior_alpha, device, out);
 }
 
 // nmixture(site_random_effects / obs_random_effects = True): nmixture.py:139-141, 166-172, 199-214.  theta = [beta, alpha, (log sds),
@@ -1116,12 +1118,27 @@ extern "C" int bl_dataset_create_nmix_re(const bl_dims *dims, const float *site_
     if (dims && dims->n_species != 1)
         return bl_fail(BL_ERR_UNSUPPORTED, "N-mixture with random effects: one species per dataset (n_species=%d)", dims->n_species);
     return create_re_impl(dims, site_covs, obs_covs, counts, site_random_effects, obs_random_effects, prior_site_re_sd_scale,
-                          prior_obs_re_sd_scale, 0, 0.0, 0.0, max_abundance, prior_beta, prior_alpha, device, out);
+                          prior_obs_re_sd_scale, 0, 0.0, 0.0, 4, max_abundance, prior_beta, prior_alpha, device, out);
+}
+
+// occu_rn(site_random_effects / obs_random_effects = True): occu_rn.py:151-154, 172-184, 199-212.  theta = [beta, alpha, (log sds),
+// site_re_abu [N], site_re_det [N], obs_re [N][T][J]]; one species.
+extern "C" int bl_dataset_create_rn_re(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
+                                       int max_abundance, int site_random_effects, int obs_random_effects,
+                                       double prior_site_re_sd_scale, double prior_obs_re_sd_scale, const bl_normal_prior *prior_beta,
+                                       const bl_normal_prior *prior_alpha, int device, bl_dataset **out)
+{
+    if (max_abundance < 1 || max_abundance >= BL_RN_NB)
+        return bl_fail(BL_ERR_UNSUPPORTED, "max_abundance=%d outside 1..%d", max_abundance, BL_RN_NB - 1);
+    if (dims && dims->n_species != 1)
+        return bl_fail(BL_ERR_UNSUPPORTED, "Royle-Nichols with random effects: one species per dataset (n_species=%d)", dims->n_species);
+    return create_re_impl(dims, site_covs, obs_covs, obs, site_random_effects, obs_random_effects, prior_site_re_sd_scale,
+                          prior_obs_re_sd_scale, 0, 0.0, 0.0, 1, max_abundance, prior_beta, prior_alpha, device, out);
 }
 
 static int create_re_impl(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
                           int site_random_effects, int obs_random_effects, double prior_site_re_sd_scale,
-                          double prior_obs_re_sd_scale, int fp_mode, double fp_a, double fp_b, int nmix_K, const bl_normal_prior *prior_beta,
+                          double prior_obs_re_sd_scale, int fp_mode, double fp_a, double fp_b, int count_model, int count_K, const bl_normal_prior *prior_beta,
                           const bl_normal_prior *prior_alpha, int device, bl_dataset **out)
 {
     if (!site_random_effects && !obs_random_effects)
@@ -1137,7 +1154,7 @@ static int create_re_impl(const bl_dims *dims, const float *site_covs, const flo
     // random-effects site pass reads
     // (N-mixture: the count model's rows -- visit = (m y, m, w..) -- and its table of log-binomial sums)
     ModelOpts mo; mo.vector_kernels = true;
-    if (nmix_K) { mo.model = 4; mo.max_abundance = nmix_K; }
+    if (count_model) { mo.model = count_model; mo.max_abundance = count_K; } // 4: N-mixture, 1: Royle-Nichols
     int rc = dataset_create_impl(mo, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
     if (rc) return rc;
     bl_dataset *ds = *out;
@@ -1148,11 +1165,11 @@ static int create_re_impl(const bl_dims *dims, const float *site_covs, const flo
     BlReModel &m = ds->re;
     m.rows = ds->dd.rows; m.n_sites = N; m.n_stride = ds->dd.n_stride; m.T = T; m.J = J; m.Ks = Ks; m.Ko = Ko; m.KS = ds->KS; m.KO = ds->KO;
     m.site_re = site_random_effects ? 1 : 0; m.obs_re = obs_random_effects ? 1 : 0;
-    m.n_species = S; m.G0s = Ks + Ko + 2; m.sp = 0; m.cb = 0; m.rv0 = ds->KS; m.sp_rows = T * J * (ds->KO + 1 + (nmix_K ? 1 : 0)) + 2 * T;
+    m.n_species = S; m.G0s = Ks + Ko + 2; m.sp = 0; m.cb = 0; m.rv0 = ds->KS; m.sp_rows = T * J * (ds->KO + 1 + (count_model ? 1 : 0)) + 2 * T;
     m.G0 = S * m.G0s; m.G = m.G0 + (fp_mode ? 1 : 0) + m.site_re + m.obs_re; m.D = (int)Dll;
     int at = m.G0;
-    m.kind = nmix_K ? 3 : (fp_mode ? 2 : 0); m.fp_mode = fp_mode; m.fp_a = (float)fp_a; m.fp_b = (float)fp_b;
-    m.tab = ds->d_tab; m.tab_ld = ds->n_stride; m.max_abundance = nmix_K;
+    m.kind = count_model == 4 ? 3 : (count_model == 1 ? 4 : (fp_mode ? 2 : 0)); m.fp_mode = fp_mode; m.fp_a = (float)fp_a; m.fp_b = (float)fp_b;
+    m.tab = ds->d_tab; m.tab_ld = ds->n_stride; m.max_abundance = count_K;
     m.o_fp = fp_mode ? at++ : -1;       // phi = logit(false-positive rate): right behind the regression coefficients
     m.o_phi_s = m.site_re ? at++ : -1;
     m.o_phi_o = m.obs_re ? at++ : -1;
@@ -1778,7 +1795,7 @@ extern "C" int bl_deterministic(bl_dataset *ds, int n_draws, const float *draws,
         const dim3 grid((N + 255) / 256, (n1 - n0) < 1024 ? (n1 - n0) : 1024);
         if (psi) {
             hipLaunchKernelGGL(bl_psi_kernel, grid, block, 0, nullptr, ds->d_rows, ds->n_stride, N, T, ds->Ks, D, d_draws, n0, n1, d_out,
-                               ds->model == 6 && ds->re.kind == 3 ? 4 : ds->model /* N-mixture with effects: abundance = exp(eta + u) */, ds->model == 6 ? ds->re.o_u : -1);
+                               ds->model == 6 && ds->re.kind >= 3 ? 4 : ds->model /* N-mixture / Royle-Nichols with effects: abundance = exp(eta + u) */, ds->model == 6 ? ds->re.o_u : -1);
             BL_HIP(hipGetLastError());
             BL_HIP(hipMemcpy(psi + (size_t)n0 * T * N, d_out, (size_t)(n1 - n0) * T * N * 4, hipMemcpyDeviceToHost));
         }

@@ -62,7 +62,7 @@ struct BlReModel {
     // kind 2 only (kept at the end: the other kinds' kernels never load them)
     int fp_mode, o_fp;                    // 1 = the rate acts on every site ("constant"), 2 = on unoccupied sites; phi = logit(rate) at o_fp = G0
     float fp_a, fp_b;                     // Beta(a, b) prior of the rate
-    // kind 3 only: N-mixture with random effects (nmixture.py:139-141, 166-172, 199-214) -- the count model's rows
+    // kinds 3 and 4 (max_abundance; the table is kind 3's): N-mixture / Royle-Nichols with random effects (nmixture.py:139-141, 166-172, 199-214) -- the count model's rows
     // (visit = (m y, m, w..)) and its data-only table tab[t][n][site] = sum_j m log C(n, y_j) (-inf below the largest count)
     const float *tab;
     int tab_ld, max_abundance;
@@ -638,6 +638,141 @@ __device__ __forceinline__ void bl_nmix_re_site_pass(const BlReModel &m, const f
     }
 }
 
+// ---- Royle-Nichols with random effects (kind 4; biolith/models/occu_rn.py:151-154, 172-184, 199-212) ----
+// site_re_abu_i joins the abundance predictor, site_re_det_i and obs_re_itj the detection predictor.  Per (site, period)
+//   l = logsumexp_n [ log pi_n + sum_j m_j log P(y_j | n) ],  pi_n = the Poisson weights renormalised over 0..K,
+//   P(y = 1 | n) = 1 - q^n = r b_n  (b_n = b_{n-1} q + 1, no cancellation),  both Bernoulli branches clamped as numpyro clamps them
+//   (log P(1 | 0) = log tiny; log P(0 | n) = max(n log q, log eps); a clamped factor has no gradient) -- rn_device.hpp's arithmetic,
+// one thread per site with the K + 1 terms of a (site, period) in a private column: the effects make every site's predictors its own,
+// and this form serves the reference's sizes (its tests: 100 sites) -- the work-proportional kernel of the plain model is not reused.
+// rows: the plain model's (visit = (c, c w_1..w_KO, spare), c = +1 detection, -1 none, 0 masked).
+template <int MK>
+__device__ __forceinline__ void bl_rn_re_site_pass(const BlReModel &m, const float *__restrict__ rows, int ns, int rv,
+                                                   const float *__restrict__ z, float *__restrict__ g, float (&part)[2 * MK + 3])
+{
+    const int N = m.n_sites, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 2, K = m.max_abundance;
+    constexpr float LOG_EPS = -15.9423847f, LOG_TINY = -87.3365448f, ONE_M_EPS = 0.99999988f, TINY = 1.17549435e-38f;
+    float beta[MK + 1], alpha[MK + 1];
+#pragma unroll
+    for (int k = 0; k <= MK; k++) {
+        const float b = z[m.cb + min(k, Ks)], a = z[m.cb + Ks + 1 + min(k, Ko)];
+        beta[k] = k <= Ks ? b : 0.0f;
+        alpha[k] = k <= Ko ? a : 0.0f;
+    }
+    const float isd2_s = m.site_re ? bl_exp(-2.0f * z[m.o_phi_s]) : 0.0f;
+    const float isd2_o = m.obs_re ? bl_exp(-2.0f * z[m.o_phi_o]) : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2 * MK + 3; k++) part[k] = 0.0f;
+    float term[BL_RN_NB];
+    for (int i = threadIdx.x; i < N; i += BL_RE_NT) {
+        float x[MK];
+        float eta = beta[0];
+#pragma unroll
+        for (int k = 0; k < MK; k++) {
+            const float xk = rows[min(k, Ks) * ns + i];
+            x[k] = k < Ks ? xk : 0.0f;
+            eta = fmaf(x[k], beta[k + 1], eta);
+        }
+        const float ui = m.site_re ? z[m.o_u + i] : 0.0f, vi = m.site_re ? z[m.o_v + i] : 0.0f;
+        eta += ui;
+        // the renormalised weights: log pi_n = n eta - lgamma(n + 1) - log Z,  d log Z / d eta = E_pi[n]
+        float m0 = -INFINITY;
+        for (int n = 0; n <= K; n++) m0 = fmaxf(m0, fmaf((float)n, eta, -BL_LGAMMA1P[n]));
+        float sz = 0.0f, s1 = 0.0f;
+        for (int n = 0; n <= K; n++) {
+            const float e = bl_exp(fmaf((float)n, eta, -BL_LGAMMA1P[n]) - m0);
+            sz += e;
+            s1 = fmaf((float)n, e, s1);
+        }
+        const float logz = m0 + bl_log(sz), en_prior = s1 * bl_rcp(sz);
+        float dl_deta = 0.0f, dl_dv = 0.0f;
+        for (int t = 0; t < T; t++) {
+            for (int n = 0; n <= K; n++) term[n] = fmaf((float)n, eta, -BL_LGAMMA1P[n]) - logz;
+            for (int j = 0; j < J; j++) {
+                const int v = t * J + j, r0 = (rv + v * vw) * ns + i;
+                const float c = rows[r0];
+                if (c == 0.0f) continue;
+                float sc = alpha[0] * c;
+#pragma unroll
+                for (int k = 0; k < MK; k++) {
+                    const float wk = rows[r0 + (1 + min(k, max(Ko, 1) - 1)) * ns];
+                    sc = fmaf(k < Ko ? wk : 0.0f, alpha[k + 1], sc);
+                }
+                const float nu = fmaf(c, sc, vi + (m.obs_re ? z[m.o_e + v * N + i] : 0.0f));
+                const float e = bl_exp(-fabsf(nu)), op = 1.0f + e, iop = bl_rcp(op);
+                const float r = (nu > 0.0f ? 1.0f : e) * iop, q = (nu > 0.0f ? e : 1.0f) * iop;
+                const float lq = -(fmaxf(nu, 0.0f) + bl_log(op)); // log(1 - r)
+                if (c < 0.0f) {
+                    for (int n = 1; n <= K; n++) term[n] += fmaxf((float)n * lq, LOG_EPS);
+                } else {
+                    term[0] += LOG_TINY;
+                    float b = 1.0f;
+                    for (int n = 1; n <= K; n++) {
+                        term[n] += bl_log(fmaxf(fminf(r * b, ONE_M_EPS), TINY));
+                        b = fmaf(b, q, 1.0f);
+                    }
+                }
+            }
+            float mx = -INFINITY;
+            for (int n = 0; n <= K; n++) mx = fmaxf(mx, term[n]);
+            float S = 0.0f, S1 = 0.0f;
+            for (int n = 0; n <= K; n++) {
+                const float e = bl_exp(term[n] - mx);
+                term[n] = e; // (unnormalised posterior weight of n)
+                S += e;
+                S1 = fmaf((float)n, e, S1);
+            }
+            const float inv = bl_rcp(S);
+            part[0] += mx + bl_log(S);
+            dl_deta += S1 * inv - en_prior;
+            for (int j = 0; j < J; j++) {
+                const int v = t * J + j, r0 = (rv + v * vw) * ns + i;
+                const float c = rows[r0], ev = m.obs_re ? z[m.o_e + v * N + i] : 0.0f;
+                float w[MK];
+                float sc = alpha[0] * c;
+#pragma unroll
+                for (int k = 0; k < MK; k++) {
+                    const float wk = rows[r0 + (1 + min(k, max(Ko, 1) - 1)) * ns];
+                    w[k] = k < Ko ? wk : 0.0f; // (c w_k)
+                    sc = fmaf(w[k], alpha[k + 1], sc);
+                }
+                float dnu = 0.0f;
+                if (c != 0.0f) {
+                    const float nu = fmaf(c, sc, vi + ev);
+                    const float e = bl_exp(-fabsf(nu)), op = 1.0f + e, iop = bl_rcp(op);
+                    const float r = (nu > 0.0f ? 1.0f : e) * iop, q = (nu > 0.0f ? e : 1.0f) * iop;
+                    if (c < 0.0f) { // d (n log q) / d nu = -n r, where the floor does not hold
+                        const float lq = -(fmaxf(nu, 0.0f) + bl_log(op));
+                        float acc = 0.0f;
+                        for (int n = 1; n <= K; n++) acc = fmaf((float)n * lq > LOG_EPS ? (float)n : 0.0f, term[n], acc);
+                        dnu = -r * acc * inv;
+                    } else {        // d log(1 - q^n) / d nu = n q^n / b_n = n (1 / b_n - r), where neither clamp holds
+                        float b = 1.0f, acc = 0.0f;
+                        for (int n = 1; n <= K; n++) {
+                            const float p = r * b;
+                            acc = fmaf((p <= ONE_M_EPS && p >= TINY) ? (float)n * (bl_rcp(b) - r) : 0.0f, term[n], acc);
+                            b = fmaf(b, q, 1.0f);
+                        }
+                        dnu = acc * inv;
+                    }
+                }
+                part[MK + 2] += dnu;
+#pragma unroll
+                for (int k = 0; k < MK; k++) part[MK + 3 + k] = fmaf(dnu * c, w[k], part[MK + 3 + k]); // w_k = c (c w_k)
+                dl_dv += dnu;
+                if (m.obs_re) g[m.o_e + v * N + i] = fmaf(ev, isd2_o, -dnu);
+            }
+        }
+        part[1] += dl_deta;
+#pragma unroll
+        for (int k = 0; k < MK; k++) part[2 + k] = fmaf(dl_deta, x[k], part[2 + k]);
+        if (m.site_re) {
+            g[m.o_u + i] = fmaf(ui, isd2_s, -dl_deta);
+            g[m.o_v + i] = fmaf(vi, isd2_s, -dl_dv);
+        }
+    }
+}
+
 // ---- occu_cs (biolith/models/occu_cs.py:120-232): s ~ Normal(mu_f, sigma_f), f ~ Bernoulli(z p), z ~ Bernoulli(psi); z and every
 // f summed out (the f of different replicates are independent given z).  Coordinates: [beta, alpha, mu0, x1 = log(mu1 - mu0),
 // log sigma0, log sigma1].  Site pass: part[0] = ll, [1..5] d/d beta, [6..10] d/d alpha, [11..14] d/d (mu0, mu1, log sigma0, log sigma1).
@@ -890,6 +1025,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel gm
             float part[2 * MK + 3], ss[2], gphi = 0.0f;
             if (m.kind == 2) bl_re_site_pass<MK, true>(m, rows, ns, rv, z, g, part, &gphi);
             else if (m.kind == 3) bl_nmix_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
+            else if (m.kind == 4) bl_rn_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
             else bl_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
             bl_re_effect_squares(m, z, ss);
 #pragma unroll
@@ -1006,6 +1142,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
             float part[2 * MK + 3], ss[2], gphi = 0.0f;
             if constexpr (KIND == 2) bl_re_site_pass<MK, true>(m, rows, rows_ns, rows_rv, z, g, part, &gphi);
             else if constexpr (KIND == 3) bl_nmix_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
+            else if constexpr (KIND == 4) bl_rn_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
             else bl_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
             BL_RE_T(8)
             bl_re_effect_squares(m, z, ss);

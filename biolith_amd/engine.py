@@ -160,6 +160,15 @@ class OccuDataset:
                 raise NotImplementedError("occu_dyn: one species per dataset")
             _ffi.check(lib.bl_dataset_create_dyn(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), C.byref(pb), C.byref(pa), device, C.byref(h)))
             self.D = 3 * (Ks + 1) + Ko + 1
+        elif model == "occu_rn" and (site_random_effects or obs_random_effects):
+            # theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_abu[N], site_re_det[N]), (obs_re[N][T][J])]
+            _ffi.check(lib.bl_dataset_create_rn_re(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), int(max_abundance),
+                                                   int(bool(site_random_effects)), int(bool(obs_random_effects)),
+                                                   float(prior_site_re_sd), float(prior_obs_re_sd), C.byref(pb), C.byref(pa),
+                                                   device, C.byref(h)))
+            d = C.c_int()
+            _ffi.check(lib.bl_dataset_param_dim(h, C.byref(d)))
+            self.D = int(d.value)
         elif model == "occu_rn":
             _ffi.check(lib.bl_dataset_create_rn(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), int(max_abundance),
                                                 C.byref(pb), C.byref(pa), device, C.byref(h)))

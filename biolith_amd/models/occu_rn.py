@@ -12,7 +12,7 @@ from typing import Any
 
 import numpy as np
 
-from ..distributions import Beta, HalfNormal, Normal, as_normal
+from ..distributions import Beta, HalfNormal, Normal, as_half_normal, as_normal
 from ..regression import LinearRegression
 from ._generators import Generator, expit, observed_mean, within
 from .occu import OccuSpec
@@ -44,8 +44,9 @@ def occu_rn(
 ) -> OccuSpec:
     """Royle-Nichols abundance-occupancy model on the HIP engine (parameters: occu_rn.py:20-40).
 
-    Built: the default option path (linear regressors, Normal priors, no false positives, no
-    spatial / random effects, one species).  Everything else raises ``NotImplementedError``.
+    Built: linear regressors, Normal priors, no false positives, no spatial effect; ``site_random_effects`` /
+    ``obs_random_effects`` with HalfNormal priors on their sds (occu_rn.py:151-154, 172-184, 199-212) run on the random-effects
+    kernels, one species per fit (the sds are sampled outside the species plate).  Everything else raises ``NotImplementedError``.
 
     Examples
     --------
@@ -69,8 +70,8 @@ def occu_rn(
         unsupported.append("coords (spatial effect, occu_rn.py:140-148)")
     if false_positives_constant:
         unsupported.append("false positives (occu_rn.py:133-138)")
-    if site_random_effects or obs_random_effects:
-        unsupported.append("random effects (occu_rn.py:151-154)")
+    if (site_random_effects or obs_random_effects) and obs is not None and n_species > 1:
+        unsupported.append("random effects with several species (the sds are shared across the species plate, occu_rn.py:151-154)")
     if regressor_abu is not LinearRegression or regressor_det is not LinearRegression:
         unsupported.append("non-linear regressors (occu_rn.py:166-167)")
     if obs is None:
@@ -86,9 +87,14 @@ def occu_rn(
         )
     if obs.shape[1:] != obs_covs.shape[:3] or site_covs.shape[0] != obs_covs.shape[0]:
         raise ValueError("site_covs, obs_covs and obs disagree on (n_sites, n_periods, n_replicates)")
-    return OccuSpec(site_covs, obs_covs, obs, n_species, as_normal(prior_beta, "prior_beta"),
+    spec = OccuSpec(site_covs, obs_covs, obs, n_species, as_normal(prior_beta, "prior_beta"),
                     as_normal(prior_alpha, "prior_alpha"), model="occu_rn",
                     extras=dict(max_abundance=int(max_abundance)))
+    if site_random_effects or obs_random_effects:
+        spec.extras.update(site_random_effects=bool(site_random_effects), obs_random_effects=bool(obs_random_effects),
+                           prior_site_re_sd=as_half_normal(prior_site_re_sd, "prior_site_re_sd"),
+                           prior_obs_re_sd=as_half_normal(prior_obs_re_sd, "prior_obs_re_sd"))
+    return spec
 
 
 occu_rn.__biolith_amd_model__ = "occu_rn"

@@ -281,7 +281,7 @@ def engine_options(spec) -> dict:
         opts.update({k: spec.extras[k] for k in ("site_random_effects", "obs_random_effects", "prior_site_re_sd", "prior_obs_re_sd")})
         if spec.extras.get("re_fp_mode") is not None:
             opts.update(re_fp_mode=spec.extras["re_fp_mode"], prior_fp=spec.extras["prior_fp"])
-    if spec.model == "nmixture" and "site_random_effects" in spec.extras:
+    if spec.model in ("nmixture", "occu_rn") and "site_random_effects" in spec.extras:
         opts.update({k: spec.extras[k] for k in ("site_random_effects", "obs_random_effects", "prior_site_re_sd", "prior_obs_re_sd")})
     if spec.model == "occu_cs":
         opts.update(prior_mu=spec.extras["prior_mu"], prior_sigma=spec.extras["prior_sigma"])
@@ -346,7 +346,7 @@ def _assemble(per_species, spec, num_warmup, joint_result=None) -> HipMCMC:
         latent["mu0"] = e[..., 0].astype(np.float32)
         latent["mu1"] = (e[..., 0] + np.exp(e[..., 1])).astype(np.float32)
         latent["sigma0"], latent["sigma1"] = np.exp(e[..., 2]).astype(np.float32), np.exp(e[..., 3]).astype(np.float32)
-    if spec.model == "occu_re" or (spec.model == "nmixture" and "site_random_effects" in spec.extras):
+    if spec.model == "occu_re" or (spec.model in ("nmixture", "occu_rn") and "site_random_effects" in spec.extras):
         # theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_occ[N], site_re_det[N]), (obs_re[N][T][J])]; the
         # model's sites are the sds themselves, the effects with the species plate last (occu.py:170-173, 191-196, 215-218)
         N, T, J = ds0.N, ds0.T, ds0.J
@@ -362,8 +362,8 @@ def _assemble(per_species, spec, num_warmup, joint_result=None) -> HipMCMC:
             latent["obs_re_sd"] = np.exp(res0.draws[:, :, at].astype(np.float64)).astype(np.float32)
             at += 1
         if spec.extras["site_random_effects"]:
-            # (the N-mixture model names the first one after its predictor: nmixture.py:166-169)
-            latent["site_re_abu" if spec.model == "nmixture" else "site_re_occ"] = np.stack([r.draws[:, :, at: at + N] for _, r in per_species], axis=-1)   # (C, S, N, nsp)
+            # (the abundance models name the first one after their predictor: nmixture.py:166-169, occu_rn.py:172-176)
+            latent["site_re_abu" if spec.model in ("nmixture", "occu_rn") else "site_re_occ"] = np.stack([r.draws[:, :, at: at + N] for _, r in per_species], axis=-1)   # (C, S, N, nsp)
             latent["site_re_det"] = np.stack([r.draws[:, :, at + N: at + 2 * N] for _, r in per_species], axis=-1)
             at += 2 * N
         if spec.extras["obs_random_effects"]:

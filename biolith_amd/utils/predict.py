@@ -105,7 +105,7 @@ def predict(
 
     def re_block(sp):
         """The random-effects coordinates of species ``sp`` in the engine's one-species layout (see fit._assemble)."""
-        if spec.model != "occu_re":
+        if spec.model != "occu_re" and not (spec.model == "occu_rn" and "site_random_effects" in spec.extras):
             return None
         cols = []
         if spec.extras["site_random_effects"]:
@@ -113,7 +113,8 @@ def predict(
         if spec.extras["obs_random_effects"]:
             cols.append(np.log(np.maximum(np.asarray(posterior["obs_re_sd"], dtype=np.float64).reshape(n, 1), 1e-300)))
         if spec.extras["site_random_effects"]:   # (n, N, species)
-            cols += [np.asarray(posterior["site_re_occ"])[..., sp].reshape(n, -1), np.asarray(posterior["site_re_det"])[..., sp].reshape(n, -1)]
+            first = "site_re_abu" if spec.model == "occu_rn" else "site_re_occ"   # (occu_rn.py:172-176)
+            cols += [np.asarray(posterior[first])[..., sp].reshape(n, -1), np.asarray(posterior["site_re_det"])[..., sp].reshape(n, -1)]
         if spec.extras["obs_random_effects"]:   # (n, J, T, N, species) -> [N][T][J]
             cols.append(np.asarray(posterior["obs_re"])[..., sp].transpose(0, 3, 2, 1).reshape(n, -1))
         return np.concatenate(cols, axis=1).astype(np.float32)

@@ -168,6 +168,13 @@ int bl_dataset_create_nmix_re(const bl_dims *dims, const float *site_covs, const
                               int max_abundance, int site_random_effects, int obs_random_effects,
                               double prior_site_re_sd_scale, double prior_obs_re_sd_scale, const bl_normal_prior *prior_beta,
                               const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
+/* The Royle-Nichols model with the same random effects (biolith/models/occu_rn.py:151-154, 172-184, 199-212): `obs` / max_abundance
+ * as for bl_dataset_create_rn, theta laid out as for bl_dataset_create_nmix_re.  One species per dataset.  bl_deterministic returns
+ * abundance = exp(eta + site_re_abu) and the detection probability with its effects; bl_predict draws N and y from them. */
+int bl_dataset_create_rn_re(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
+                            int max_abundance, int site_random_effects, int obs_random_effects,
+                            double prior_site_re_sd_scale, double prior_obs_re_sd_scale, const bl_normal_prior *prior_beta,
+                            const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
 /*
  * The continuous-score occupancy model biolith.models.occu_cs (models/occu_cs.py:17-232; Rhinehart et al. 2022): `scores`
  * [S=1][N][T][J] (NaN = missing) ~ Normal(mu_f, sigma_f) with f ~ Bernoulli(z p) and z ~ Bernoulli(psi) summed out.

@@ -60,6 +60,7 @@ def lib():
             L.orc_data_set_re.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_re_fp.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_nmix_re.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
+            L.orc_data_set_rn_re.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_prior_family.argtypes = [C.c_void_p, C.c_int, C.c_int]
             L.orc_data_set_cs.argtypes = [C.c_void_p, dp, dp, dp]
             L.orc_data_set_dyn.argtypes = [C.c_void_p]
@@ -127,6 +128,10 @@ class OracleData:
         self.model, self.max_abundance = model, int(max_abundance)
         assert model in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture", "occu_re", "occu_cs", "occu_dyn")
         lib().orc_data_set_model(self._h, 1 if model == "occu_rn" else 0, int(max_abundance))
+        if model == "occu_rn" and (site_random_effects or obs_random_effects):   # occu_rn.py:151-154, 172-184, 199-212
+            lib().orc_data_set_rn_re(self._h, int(bool(site_random_effects)), int(bool(obs_random_effects)),
+                                     float(prior_site_re_sd), float(prior_obs_re_sd))
+            self.D = int(lib().orc_data_dim(self._h))
         if model == "occu_fp":  # theta gains phi = logit(false-positive rate) as its last coordinate
             assert fp_mode in ("constant", "unoccupied")
             lib().orc_data_set_fp(self._h, 1 if fp_mode == "constant" else 2, float(prior_fp[0]), float(prior_fp[1]))
@@ -606,7 +611,8 @@ def literal_log_joint_dyn(theta, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0)
     return float(total)
 
 
-def literal_log_joint_rn(theta, site_covs, obs_covs, obs, max_abundance=100, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):
+def literal_log_joint_rn(theta, site_covs, obs_covs, obs, max_abundance=100, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0),
+                         site_random_effects=False, obs_random_effects=False, prior_site_re_sd=1.0, prior_obs_re_sd=1.0):
     """log p(theta, y) of the Royle-Nichols model, stated literally (biolith/models/occu_rn.py:123-222):
     N enumerated over 0..max_abundance under Categorical(logits=Poisson(lambda).log_prob(support))
     (utils/distributions.py:31-40; Categorical renormalises), Bernoulli(1-(1-r)^N) with clamp_probs."""
@@ -617,18 +623,43 @@ def literal_log_joint_rn(theta, site_covs, obs_covs, obs, max_abundance=100, pri
     Y = _as_f32_f64(obs)
     if Y.ndim == 4:
         Y = Y[0]
-    Ks = X.shape[1]
+    Ks, Ko = X.shape[1], W.shape[-1]
     theta = np.asarray(theta, dtype=np.float64)
-    beta, alpha = theta[: Ks + 1], theta[Ks + 1:]
+    beta, alpha = theta[: Ks + 1], theta[Ks + 1: Ks + Ko + 2]
+    # random effects (occu_rn.py:151-154, 172-184, 199-212): theta = [beta, alpha, (log site_re_sd), (log obs_re_sd),
+    # (site_re_abu[N], site_re_det[N]), (obs_re[N][T][J])]; a HalfNormal site lives on the log scale (+ log-Jacobian)
+    N_, T_, J_ = Y.shape
+    at, lp_re = Ks + Ko + 2, 0.0
+    re_abu = re_det = np.zeros(N_)
+    obs_re = np.zeros((N_, T_, J_))
+
+    def half_normal_on_log_scale(phi, scale):
+        return 0.5 * np.log(2.0 / np.pi) - np.log(scale) - 0.5 * (np.exp(phi) / scale) ** 2 + phi
+
+    def normal0(v, sd):
+        return (-0.5 * (v / sd) ** 2 - np.log(sd) - 0.5 * np.log(2 * np.pi)).sum()
+
+    sd_s = sd_o = None
+    if site_random_effects:
+        lp_re += half_normal_on_log_scale(theta[at], prior_site_re_sd); sd_s = np.exp(theta[at]); at += 1
+    if obs_random_effects:
+        lp_re += half_normal_on_log_scale(theta[at], prior_obs_re_sd); sd_o = np.exp(theta[at]); at += 1
+    if site_random_effects:
+        re_abu, re_det = theta[at: at + N_], theta[at + N_: at + 2 * N_]; at += 2 * N_
+        lp_re += normal0(re_abu, sd_s) + normal0(re_det, sd_s)
+    if obs_random_effects:
+        obs_re = theta[at: at + N_ * T_ * J_].reshape(N_, T_, J_); at += N_ * T_ * J_
+        lp_re += normal0(obs_re, sd_o)
+    assert at == theta.size
     obs_mask = np.isnan(W).any(-1) | np.isnan(X).any(-1)[:, None, None]       # occu_rn.py:124-130
     Y = np.where(obs_mask, np.nan, Y)
     W = np.nan_to_num(W)
     X = np.nan_to_num(X)
-    abundance = np.exp(beta[0] + X @ beta[1:])                                  # occu_rn.py:179-192
+    abundance = np.exp(beta[0] + X @ beta[1:] + re_abu)                         # occu_rn.py:179-192
     support = np.arange(max_abundance + 1)
     logits = np.log(abundance)[:, None] * support - gammaln(support + 1) - abundance[:, None]   # Poisson.log_prob
     log_prior = logits - logsumexp(logits, axis=1, keepdims=True)              # (N, K+1)
-    r = 1.0 / (1.0 + np.exp(-(alpha[0] + np.tensordot(W, alpha[1:], axes=([3], [0])))))   # (N,T,J)  occu_rn.py:209-218
+    r = 1.0 / (1.0 + np.exp(-(alpha[0] + np.tensordot(W, alpha[1:], axes=([3], [0])) + re_det[:, None, None] + obs_re)))   # (N,T,J)  occu_rn.py:209-218
     finite = np.isfinite(Y)
     y0 = np.where(finite, Y, 0.0)
     p = 1.0 - (1.0 - r[..., None]) ** support                                   # (N,T,J,K+1)  occu_rn.py:219
@@ -639,7 +670,7 @@ def literal_log_joint_rn(theta, site_covs, obs_covs, obs, max_abundance=100, pri
     def normal_logpdf(v, loc, scale):
         return (-0.5 * ((v - loc) / scale) ** 2 - np.log(scale) - 0.5 * np.log(2 * np.pi)).sum()
 
-    return ll + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
+    return ll + lp_re + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
 
 
 # --------------------------------------------------------------------------------------------

@@ -1,0 +1,151 @@
+"""Royle-Nichols model with random effects (biolith/models/occu_rn.py:151-154, 172-184, 199-212): site_re_abu joins the abundance
+predictor, site_re_det and obs_re the detection predictor.  theta = [beta, alpha, (log sds), (effects)].  The kernels
+(re_kernel.hpp, kind 4) through the C-ABI (bl_dataset_create_rn_re) against the float64 oracle: potential + gradient over every
+coordinate (also where numpyro's clamps decide it), the first trees on shared streams (one and several workgroups per chain), the
+posterior, predict, and the reference's own three fit tests (occu_rn.py:440-510)."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+import oracle
+from biolith_amd.engine import OccuDataset
+from biolith_amd.models import occu_rn, simulate_rn
+from biolith_amd.utils import fit, predict
+from conftest import load_golden, posterior_parity
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("rn_small_2x2", 15, True, False), ("rn_small_2x2", 40, False, True), ("rn_missing", 25, True, True),
+         ("rn_default", 100, True, False), ("rn_default", 127, True, True)]
+
+
+def _pair(name, K, site, obs, **kw):
+    g = load_golden(name)
+    kw = dict(model="occu_rn", max_abundance=K, site_random_effects=site, obs_random_effects=obs, prior_site_re_sd=0.8, prior_obs_re_sd=1.2, **kw)
+    return (g, oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], **kw), OccuDataset(g["site_covs"], g["obs_covs"], g["obs"], **kw))
+
+
+@pytest.mark.parametrize("name,K,site,obs", CASES)
+def test_rn_re_logp_grad_parity(name, K, site, obs):
+    """float32 kernel vs float64 oracle over every coordinate (the plain Royle-Nichols kernel's tolerances: 1e-5 / 1e-4)."""
+    _, od, ds = _pair(name, K, site, obs)
+    assert ds.D == od.D
+    th = np.random.default_rng(4).uniform(-0.8, 0.8, size=(3, od.D)).astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.all(np.isfinite(Ug)) and np.all(np.isfinite(Gg))
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= 1e-5, (Ug, Uo)
+    assert np.max(np.abs(Gg - Go)) <= 1e-4 * np.max(np.abs(Go)), np.max(np.abs(Gg - Go)) / np.max(np.abs(Go))
+
+
+def test_rn_re_clamp_regime():
+    """Parameters that force N ~ 50 onto sites with non-detections: numpyro's floor log(eps_f32) on a non-detection's n log(1 - r)
+    decides several per cent of the potential (test_gpu_rn.py::test_rn_nondetection_clamp_regime); the kernel carries it per visit."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        data, _ = simulate_rn(n_sites=200, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7, random_seed=1)
+    kw = dict(model="occu_rn", site_random_effects=True, obs_random_effects=True)
+    od, ds = oracle.OracleData(data["site_covs"], data["obs_covs"], data["obs"], **kw), OccuDataset(data["site_covs"], data["obs_covs"], data["obs"], **kw)
+    th = np.random.default_rng(2).uniform(-0.5, 0.5, size=(2, od.D)).astype(np.float32).astype(np.float64)
+    th[0, :8] = [1.5, 1.2, -1.0, 0.9, 1.8, 0.5, -0.4, 0.3]
+    th[1, :8] = [2.0, -2.0, 2.0, -2.0, 2.0, 2.0, -2.0, 2.0]
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.all(np.isfinite(Ug))
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= 2e-5, (Ug, Uo)
+    assert np.max(np.abs(Gg - Go)) <= 1e-3 * np.max(np.abs(Go)), np.max(np.abs(Gg - Go)) / np.max(np.abs(Go))
+
+
+@pytest.mark.parametrize("n_sites", [1, 2, 65, 513])
+def test_rn_re_ragged_site_counts(n_sites):
+    rng = np.random.default_rng(n_sites)
+    X = rng.normal(size=(n_sites, 2)) * 0.5; W = rng.normal(size=(n_sites, 2, 3, 2)) * 0.5
+    Y = (rng.uniform(size=(1, n_sites, 2, 3)) < 0.4).astype(float)
+    Y[rng.uniform(size=Y.shape) < 0.1] = np.nan
+    kw = dict(model="occu_rn", max_abundance=25, site_random_effects=True, obs_random_effects=True)
+    od, ds = oracle.OracleData(X, W, Y, **kw), OccuDataset(X, W, Y, **kw)
+    th = rng.uniform(-0.8, 0.8, size=(2, od.D)).astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    for staged in (True, False):   # rows in LDS / read from device memory
+        Ug, Gg = ds.logp_grad(th, staged=staged)
+        assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= 1e-5
+        assert np.max(np.abs(Gg - Go)) <= 1e-4 * np.max(np.abs(Go))
+
+
+@pytest.mark.parametrize("k", [1, 3, 16])
+@pytest.mark.parametrize("name,K,site,obs", CASES[:3])
+def test_rn_re_first_transitions_match_oracle(name, K, site, obs, k):
+    _, od, ds = _pair(name, K, site, obs)
+    o = oracle.nuts_run(od, 0, 4, num_chains=2, seed=3)
+    r = ds.nuts(num_warmup=0, num_samples=4, num_chains=2, seed=3, wgs_per_chain=k)
+    assert np.array_equal(o["num_steps"][:, :2], r.num_steps[:, :2]), (o["num_steps"], r.num_steps)
+    assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=5e-3)
+
+
+def test_rn_re_adaptation_and_next_tree_match_oracle():
+    _, od, ds = _pair("rn_small_2x2", 15, True, False)
+    o = oracle.nuts_run(od, 8, 3, num_chains=2, seed=5)
+    r = ds.nuts(num_warmup=8, num_samples=3, num_chains=2, seed=5)
+    assert np.allclose(o["step_size"], r.step_size, rtol=2e-3)
+    assert np.array_equal(o["num_steps"][:, :1], r.num_steps[:, :1])
+
+
+def test_rn_re_posterior_matches_oracle():
+    _, od, ds = _pair("rn_small_2x2", 15, True, False)
+    G = od.Ks + od.Ko + 2
+    o = oracle.nuts_run(od, 500, 1000, num_chains=4, seed=0)
+    r = ds.nuts(num_warmup=500, num_samples=1000, num_chains=4, seed=50)
+    # the fixed effects at SURVEY 8c's tolerances; log site_re_sd (the centred parameterisation's funnel: test_gpu_re.py) in mean
+    posterior_parity(r.draws[:, :, :G], o["draws"][:, :, :G])
+    sg, so = r.draws[:, :, G:G + 1].astype(np.float64), o["draws"][:, :, G:G + 1]
+    mcse = np.sqrt(sg.var() / oracle.effective_sample_size(sg)[0] + so.var() / oracle.effective_sample_size(so)[0])
+    assert abs(sg.mean() - so.mean()) <= 4 * mcse, (sg.mean(), so.mean(), mcse)
+
+
+def _data():
+    with contextlib.redirect_stdout(io.StringIO()):
+        return simulate_rn(simulate_missing=True)
+
+
+def test_reference_rn_site_random_effects():
+    """occu_rn.py:440-463; predict() draws N_i and y with the effects in both predictors."""
+    data, truth = _data()
+    res = fit(occu_rn, **data, site_random_effects=True, num_chains=1, num_samples=500, timeout=600)
+    s = res.samples
+    assert "site_re_sd" in s and "site_re_abu" in s and "site_re_det" in s
+    assert s["site_re_sd"].mean() > 0
+    assert s["site_re_abu"].shape == (500, 100, 1) and s["abundance"].shape == (500, 1, 100, 1)
+    assert np.allclose(s["abundance"].mean(), truth["abundance"].mean(), rtol=0.2)
+    pred = predict(occu_rn, res.mcmc, **data, site_random_effects=True, num_samples=500)
+    assert pred["N_i"].shape == (500, 1, 100, 1) and pred["y"].shape == (500, 52, 1, 100, 1)
+    assert np.allclose(pred["abundance"], s["abundance"], rtol=1e-5)
+    assert abs(pred["N_i"].mean() - s["abundance"].mean()) < 0.15 * s["abundance"].mean()   # E[N | lambda] = lambda (cutoff 100 far away)
+    seen = np.isfinite(data["obs"][0])
+    assert abs(pred["y"].mean(0)[..., 0].transpose(2, 1, 0)[seen].mean() - np.nanmean(data["obs"])) < 0.05
+
+
+def test_reference_rn_obs_random_effects():
+    """occu_rn.py:466-487."""
+    data, truth = _data()
+    res = fit(occu_rn, **data, obs_random_effects=True, num_chains=1, num_samples=500, timeout=600)
+    s = res.samples
+    assert "obs_re_sd" in s and "obs_re" in s
+    assert s["obs_re_sd"].mean() > 0
+    assert s["obs_re"].shape == (500, 52, 1, 100, 1)
+    assert np.allclose(s["abundance"].mean(), truth["abundance"].mean(), rtol=0.2)
+
+
+def test_reference_rn_combined_random_effects():
+    """occu_rn.py:490-510."""
+    data, _ = _data()
+    res = fit(occu_rn, **data, site_random_effects=True, obs_random_effects=True, num_chains=1, num_warmup=10, num_samples=10, timeout=600)
+    for k in ("site_re_sd", "site_re_abu", "site_re_det", "obs_re_sd", "obs_re"):
+        assert k in res.samples
+
+
+def test_rn_re_rejects_several_species():
+    with contextlib.redirect_stdout(io.StringIO()):
+        data, _ = simulate_rn(n_species=2, n_sites=30, random_seed=1)
+    with pytest.raises(NotImplementedError):
+        fit(occu_rn, **data, site_random_effects=True, num_chains=1, num_samples=5, num_warmup=5)

@@ -60,6 +60,27 @@ def test_rn_closed_form_equals_literal_model(name):
         assert np.max(np.abs(fd - grad)) <= 1e-5 * max(1.0, np.max(np.abs(grad)))
 
 
+@pytest.mark.parametrize("name,site,obs", [("rn_small_2x2", True, False), ("rn_small_2x2", False, True), ("rn_missing", True, True)])
+def test_rn_re_closed_form_equals_literal_model(name, site, obs):
+    """Random effects (occu_rn.py:151-154, 172-184, 199-212): the oracle against the literal model and central differences."""
+    g = load_golden(name)
+    kw = dict(site_random_effects=site, obs_random_effects=obs, prior_site_re_sd=0.8, prior_obs_re_sd=1.2)
+    od = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], (0.2, 1.5), (-0.1, 0.7), model="occu_rn", max_abundance=15, **kw)
+    N, T, J = g["obs"].shape[1:]
+    G = od.Ks + od.Ko + 2
+    assert od.D == G + site * (1 + 2 * N) + obs * (1 + N * T * J)
+    rng = np.random.default_rng(5)
+    th = rng.uniform(-0.8, 0.8, size=od.D)
+    U, grad = od.potential_grad(th)
+    lit = oracle.literal_log_joint_rn(th, g["site_covs"], g["obs_covs"], g["obs"][0], max_abundance=15, prior_beta=(0.2, 1.5),
+                                      prior_alpha=(-0.1, 0.7), **kw)
+    assert abs(U + lit) <= 1e-10 * abs(U)
+    h = 1e-6
+    idx = np.unique(np.concatenate([np.arange(min(G + 2, od.D)), rng.integers(0, od.D, size=12)]))
+    fd = np.array([(od.potential_grad(th + h * e)[0] - od.potential_grad(th - h * e)[0]) / (2 * h) for e in np.eye(od.D)[idx]])
+    assert np.max(np.abs(fd - grad[idx])) <= 1e-5 * max(1.0, np.max(np.abs(grad)))
+
+
 def test_rn_max_abundance_renormalises_the_prior():
     """Categorical(logits) renormalises the truncated Poisson (utils/distributions.py:31-40): with all
     data masked the marginal likelihood is exactly 1 whatever the cutoff."""
@@ -76,9 +97,12 @@ def test_occu_rn_validation():
     g = load_golden("rn_small_2x2")
     spec = occu_rn(g["site_covs"], g["obs_covs"], obs=g["obs"], coords=None, ell=0.0)
     assert spec.model == "occu_rn" and spec.extras["max_abundance"] == 100
-    for kw in (dict(false_positives_constant=True), dict(site_random_effects=True), dict(coords=np.zeros((60, 2))),
-               dict(max_abundance=500)):
+    for kw in (dict(false_positives_constant=True), dict(coords=np.zeros((60, 2))), dict(max_abundance=500)):
         with pytest.raises(NotImplementedError):
             occu_rn(g["site_covs"], g["obs_covs"], obs=g["obs"], **kw)
+    re = occu_rn(g["site_covs"], g["obs_covs"], obs=g["obs"], site_random_effects=True)   # occu_rn.py:151-154
+    assert re.model == "occu_rn" and re.extras["site_random_effects"] and not re.extras["obs_random_effects"]
+    with pytest.raises(NotImplementedError, match="several species"):
+        occu_rn(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]), obs_random_effects=True)
     with pytest.raises(AssertionError):
         occu_rn(g["site_covs"], g["obs_covs"], obs=g["obs"][0])
