@@ -95,6 +95,9 @@ def parse_args(argv=None):
                          "bounded, scaled sample of its evaluations")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end fit() timing (fit_e2e_ms / value_e2e)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads of the default run")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="roofline.traffic from profiles/pmc_traffic.json instead of the two rocprofv3 --pmc passes this run makes over a child process")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the child those passes profile: launches only
     ap.add_argument("--wgs-per-chain", type=int, default=0)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="occu")
     return ap.parse_args(argv)
@@ -293,9 +296,71 @@ def fit_end_to_end(data, reps=3):
     return runs
 
 
+PMC_CHILD_LAUNCHES = 2
+
+
+def pmc_child(args):
+    """What the live PMC passes profile: the workload's own launches (same geometry as the timed steps), nothing else.  No torch."""
+    from biolith_amd.engine import OccuDataset
+    from biolith_amd.models import simulate, simulate_dyn, simulate_rn
+
+    wl = WORKLOADS[args.workload]
+    with contextlib.redirect_stdout(io.StringIO()):
+        data, _ = {"occu_rn": simulate_rn, "occu_dyn": simulate_dyn}.get(wl["model"], simulate)(**wl["cfg"])
+    ds = OccuDataset(data["site_covs"], data["obs_covs"], data["obs"], model=wl["model"], **wl.get("options", {}))
+    for s in range(1 + PMC_CHILD_LAUNCHES):
+        ds.launch(num_warmup=wl["num_warmup"], num_samples=wl["num_samples"], num_chains=CHAINS_PER_GPU, seed=s, wgs_per_chain=args.wgs_per_chain)
+        ds.wait()
+
+
+def live_hbm_traffic(name, kernel_substr, wgs_per_chain=0, timeout_s=240):
+    """HBM bytes per launch of the workload's sampler kernel measured in THIS run: one rocprofv3 --pmc pass per counter (FETCH_SIZE and
+    WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md) over a child process that only launches (`--pmc-child`), the counters summed
+    over each dispatch's rows, the mean over its dispatches taken, FETCH_SIZE doubled (that guide's gfx950 correction) -- what
+    tools/pmc_run.sh + tools/pmc_summary.py do for the committed profiles.  Returns (bytes or None, how it was obtained / why not)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    from collections import defaultdict
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTX")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is itself running under a profiler"
+    kb = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(td, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-child", "--workload", name, "--wgs-per-chain", str(wgs_per_chain)]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter} pass timed out"
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr.strip()[-200:]}"
+            per_dispatch = defaultdict(float)
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            per_dispatch[row["Dispatch_Id"]] += float(row["Counter_Value"])
+            if not per_dispatch:
+                return None, f"no {counter} rows for {kernel_substr} in the pass's output"
+            kb[counter] = sum(per_dispatch.values()) / len(per_dispatch)
+    return (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0, (
+        "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE, over a child process making "
+        f"{1 + PMC_CHILD_LAUNCHES} launches of this workload; per-launch mean (FETCH_SIZE {kb['FETCH_SIZE']:.1f} KB doubled per "
+        f"MI355X_MICROARCH.md + WRITE_SIZE {kb['WRITE_SIZE']:.1f} KB)")
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    if args.pmc_child:
+        return pmc_child(args)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -446,6 +511,20 @@ def main(argv=None):
             if ent:
                 traffic = ent.get("hbm_bytes_per_launch")
                 traffic_source = f"profiles/pmc_traffic.json (static; from {ent.get('source')})"
+        if world == 1 and not args.no_live_pmc:
+            # measured NOW (two --pmc passes over a child process, after this workload's timed region; a few seconds each); the
+            # committed figure stays as the fallback and is quoted beside it
+            try:
+                live, how = live_hbm_traffic(name, "bl_re_nuts_kernel" if wl["model"] == "occu_re" else "bl_nuts_kernel", args.wgs_per_chain)
+            except Exception as e:  # noqa: BLE001 -- a profiler hiccup must not cost the line
+                live, how = None, f"live PMC passes failed: {e!r}"
+            if live is not None:
+                traffic_static, traffic, traffic_source = traffic, live, how
+            else:
+                traffic_static = None
+                traffic_source = f"{traffic_source}; live passes: {how}"
+        else:
+            traffic_static = None
         # random effects: <covariate capacity, model kind, rows in LDS, sampler-vector tier in LDS>
         kernel_name = (f"bl_re_nuts_kernel<{4 if max(ds.Ks, ds.Ko) <= 4 else 16}, 0, {'true' if res0.lds_staged else 'false'}, {res0.lds_vector_tier}>"
                        if wl["model"] == "occu_re" else
@@ -454,7 +533,7 @@ def main(argv=None):
         us_leap = 1e3 * kernel_ms_mean / (leap_mean / CHAINS_PER_GPU)
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": traffic_source,
+            "traffic": traffic, "traffic_source": traffic_source, **({"traffic_committed": traffic_static} if traffic_static is not None else {}),
             "kernel": kernel_name, "kernel_ms": kernel_ms_mean,
             "algorithmic_bytes_per_launch": leap_mean * bytes_eval, "bytes_per_gradient_evaluation": bytes_eval,
             "gradient_evaluations_per_launch": leap_mean,

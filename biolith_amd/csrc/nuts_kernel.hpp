@@ -665,7 +665,10 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             // was the position being evaluated right now the one just chosen?  (bit-equal or redo: correctness
             // never depends on the guess)
             redo = flag != 0 || __any(act && !(cz == cz_spec));
-            if (flag == 0) run_deferred(); // this leaf's proposal / weight bookkeeping, still under phase A
+            // this leaf's proposal / weight bookkeeping, still under phase A.  (Measured and dropped, round 3: the same call in the shadow of
+            // the first poll round -- every tick: 3 % slower, doubling ticks only: 2 % slower, the round's check waits for it -- and lagging
+            // one tick, at the head of the next tick's decisions: no change, what a doubling tick sheds its successor picks up.)
+            if (flag == 0) run_deferred();
             BL_STAMP_CRIT
             BL_STAMP(0)
         } else if (!SPEC) {

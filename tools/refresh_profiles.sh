@@ -15,7 +15,7 @@ python tools/time_fit_e2e.py > "$OUT/time_fit_e2e.txt" 2>&1
 python tools/time_rn.py > "$OUT/time_rn.txt" 2>&1
 cd /tmp && export TMPDIR=/tmp
 for wl in occu occu_rn occu_re occu_stacked occu_dyn; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_$wl" -- python3 "$ROOT/bench.py" --workload $wl --steps 3 --no-cpu-baseline --no-e2e --no-secondary > "$ROOT/$OUT/bench_${wl}_under_rocprof.json" 2> "$ROOT/$OUT/stats_$wl.err"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_$wl" -- python3 "$ROOT/bench.py" --workload $wl --steps 3 --no-cpu-baseline --no-e2e --no-secondary --no-live-pmc > "$ROOT/$OUT/bench_${wl}_under_rocprof.json" 2> "$ROOT/$OUT/stats_$wl.err"
   echo "stats $wl rc=$?"
 done
 cd "$ROOT"
