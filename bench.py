@@ -418,8 +418,49 @@ def main(argv=None):
 
     stream = torch.cuda.current_stream().cuda_stream
     # the data-path communicator: the engine's own (librccl behind the C-ABI); made before the timed region, cost reported
-    comm = comm_from_env(local_rank, rank, world) if use_dist else None
+    comm, gather_fallback = None, None
+    if use_dist:
+        try:
+            if os.environ.get("BENCH_FORCE_GATHER_FALLBACK") == "1":   # (exercises the fallback below on a one-GPU box)
+                raise RuntimeError("BENCH_FORCE_GATHER_FALLBACK=1")
+            comm = comm_from_env(local_rank, rank, world)
+        except Exception as exc:  # noqa: BLE001 -- the scaling line must not be lost to the engine's own communicator
+            gather_fallback = f"bl_comm_init_rank failed on rank {rank}: {type(exc).__name__}: {exc}"
     chains_per_rank = [CHAINS_PER_GPU] * world
+    GATHERED = ("draws", "diverging", "num_steps", "accept_prob", "potential_energy", "step_size", "inv_mass", "n_leapfrog")
+
+    def agree_on_gather():
+        """Every rank takes the same gather: the engine's (bl_gather_draws on librccl) unless ANY rank failed with it, then
+        torch.distributed's all-gather (backend nccl = the same RCCL) for the rest of the run -- said so in the line."""
+        nonlocal comm, gather_fallback
+        if dist is None:
+            return
+        bad = torch.tensor([0.0 if gather_fallback is None else 1.0], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if bad.item() != 0.0:
+            reasons = [None] * world
+            dist.all_gather_object(reasons, gather_fallback)
+            gather_fallback = "; ".join(r for r in reasons if r) or "a peer failed"
+            if comm is not None:
+                with contextlib.suppress(Exception):
+                    comm.close()
+                comm = None
+
+    def torch_gather(res):
+        """The fallback gather: every per-chain array of the local result through torch.distributed (RCCL), rank order."""
+        import copy
+
+        from biolith_amd.distributed import gather_host_arrays
+
+        full = copy.copy(res)
+        for nm in GATHERED:
+            a = np.ascontiguousarray(getattr(res, nm))
+            t = torch.from_numpy(a.astype(np.uint8) if a.dtype == np.bool_ else a).to(f"cuda:{local_rank}")
+            g = gather_host_arrays(t).cpu().numpy()
+            setattr(full, nm, g.astype(np.bool_) if a.dtype == np.bool_ else g)
+        return full
+
+    agree_on_gather()
 
     def sync_all():
         torch.cuda.synchronize()
@@ -427,8 +468,11 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
+    in_warmup, nonlocal_fail = [False], [None]
+
     def bench_workload(name, n_steps, n_warmup):
         """W untimed + exactly K timed steps of one workload; rank 0 gets the line (a dict), the others None."""
+        nonlocal comm
         wl = WORKLOADS[name]
         NUM_WARMUP, NUM_SAMPLES = wl["num_warmup"], wl["num_samples"]
         with contextlib.redirect_stdout(io.StringIO()):
@@ -443,10 +487,20 @@ def main(argv=None):
             ds.wait()
             if comm is None:
                 res = ds.fetch()
+                if gather_fallback is not None:   # (the engine's communicator failed somewhere: agree_on_gather)
+                    full = torch_gather(res)
+                    return res, (full.draws if rank == 0 else None)
                 return res, res.draws
             # bl_gather_draws: ONE all-gather of every rank's result block over RCCL / xGMI, the path's only collective;
             # only rank 0 copies the gathered blocks to the host
-            full = gather_draws([comm], [ds], chains_per_rank, want_result=(rank == 0))
+            try:
+                full = gather_draws([comm], [ds], chains_per_rank, want_result=(rank == 0))
+            except Exception as exc:  # noqa: BLE001 -- only recoverable during the untimed steps (see below); else it ends the run
+                if not in_warmup[0]:
+                    raise
+                nonlocal_fail[0] = f"bl_gather_draws failed on rank {rank}: {type(exc).__name__}: {exc}"
+                res = ds.fetch()
+                return res, None
             local = ds.fetch() if rank != 0 else None
             if rank == 0:
                 lo = rank * CHAINS_PER_GPU
@@ -458,7 +512,13 @@ def main(argv=None):
             return local, (full.draws if full is not None else None)
 
         for w in range(n_warmup):
+            in_warmup[0] = True
             one_step(10_000 + w)
+            in_warmup[0] = False
+            if comm is not None and world > 1 and w == 0:   # the first gather of the run, untimed: did it work on every rank?
+                nonlocal gather_fallback
+                gather_fallback = nonlocal_fail[0]
+                agree_on_gather()
         sync_all()
         t0 = time.perf_counter()
         steps = [one_step(s) for s in range(n_steps)]
@@ -580,7 +640,10 @@ def main(argv=None):
                 "num_warmup": NUM_WARMUP, "num_samples": NUM_SAMPLES, "parallelism": f"chains x{world} (1 process per GPU)",
                 "wgs_per_chain": res0.wgs_per_chain, "lds_bytes_per_wg": res0.lds_bytes, "lds_staged": res0.lds_staged,
                 "gather": (f"bl_gather_draws: one ncclAllGather of {world} result blocks (RCCL {rccl_version()}), communicator init "
-                           f"{comm.init_ms:.0f} ms outside the timed region") if comm is not None else "none (one rank)",
+                           f"{comm.init_ms:.0f} ms outside the timed region") if comm is not None else
+                          ("none (one rank)" if gather_fallback is None else
+                           f"FALLBACK torch.distributed all_gather (backend nccl = RCCL) of the per-chain arrays -- the engine's own gather was "
+                           f"given up: {gather_fallback}"),
                 "torch_process_group": (dist.get_backend() + f" x{dist.get_world_size()} (barrier / max-over-ranks only)") if dist is not None else None,
             },
             "roofline": roofline,
