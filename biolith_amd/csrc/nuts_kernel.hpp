@@ -327,7 +327,8 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         for (int s = 0; s < 16; s++) sv[s * 64] = 0.0f;
         sv[SV_MOMZ * 64] = z_first;
         if (lane == 0) {
-            sh_flag[0] = 0; sh_flag[1] = 0; sh_flag[2] = 0; // run status; L2-local exchange proven; compute waves arrived
+            sh_flag[0] = 0; sh_flag[1] = 0; sh_flag[2] = 0; // run status; L2-local exchange proven; (spare)
+            for (int w = 0; w < 16; w++) bl_lds_i(BL_OFF_TAG)[w] = 0; // no row of the partial table belongs to an evaluation yet
             BlCtlScalars z{};
             z.eps = 1.0f; z.da_prox = 2.302585093f; // log(10 * step_size0)
             *ss = z;
@@ -504,11 +505,13 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                     depth++;
                     if (depth < p.max_depth && !turning && !sdiv) {
                         // next doubling
+                        const bool was_right = going_right;
                         going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
                         epsdir = going_right ? eps : -eps;
                         snprop = 0; sturn = false; sdiv = false;
-                        const int e = going_right ? SV_ZR : SV_ZL;
-                        const float ez = sv[e * 64], er = sv[(e + 1) * 64], eg = sv[(e + 2) * 64];
+                        // the edge the next doubling starts from: the one just extended (this leaf, in registers) or the other one
+                        float ez = cz, er = cr, eg = cg;
+                        if (going_right != was_right) { ez = sv[e_in * 64]; er = sv[(e_in + 1) * 64]; eg = sv[(e_in + 2) * 64]; }
                         bl_next_leaf(ez, er, eg, epsdir, minv, rh, cz);
                     } else {
                         // ---------------- transition complete ----------------
@@ -596,8 +599,12 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     // loop-carried register of either role alive through the other role's code: spills on both sides).
     if (wave > 0) {
         unsigned epoch_c = 0;  // evaluations so far = the exchange epoch of the one in flight (the control wave counts the same)
-        bool local_c = false;
         while (true) {
+            // The loop control of this tick (run status, "the exchange is L2-local") is read in ONE ds_read_b64 that is issued here
+            // and looked at after the evaluation: read and tested first -- two dependent LDS round trips, as it was until round 3 --
+            // it stood in front of every evaluation.  The price: one evaluation nobody needs when the run ends.
+            typedef int BlInt2 __attribute__((ext_vector_type(2)));
+            const BlInt2 ctl = *(__attribute__((address_space(3))) const volatile BlInt2 *)sh_flag;
             // ------------------------------------- phase A: compute waves, site log-lik ----
 #ifdef BL_STAMPS
             const long long st_a0 = (long long)clock64();
@@ -606,25 +613,41 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #ifdef BL_STAMPS
             st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
 #endif
+            if (ctl.x != 0) break;
+            const bool local_c = ctl.y != 0;
             // ---- the LAST compute wave to finish publishes the workgroup's partial to the chain at once: the hand-off to the
             // other workgroups then runs beside the control wave's decisions about the previous leaf (which outlast phase A on
             // every doubling and transition-end tick) instead of after them.  Every evaluation is published, also one the
             // decisions are about to drop (all workgroups drop the same ones and skip that epoch's poll).
+            // Who is last is found with ONE LDS round trip (round 3; an arrival counter -- atomic with return, then the rows -- took two):
+            // behind its row of the partial table a wave writes the evaluation's number as the row's tag, then reads every row and every
+            // tag in one go.  A wave's LDS instructions execute in order and the LDS serves the waves' instructions one after another,
+            // so the wave whose reads see all tags current has read rows that are complete -- the last one always does; when two finish
+            // together both may, and both publish the same granule (fixed wave order of the sum), which is harmless.
+            // (The tags are read BEFORE the rows: tags all current at that point => every row was complete at that point.  Volatile
+            // accesses through LDS-address-space pointers: program order kept, ds_read / ds_write -- a volatile generic pointer makes
+            // them flat_load / flat_store with system coherence bits.)
             epoch_c++;
-            int arrived = 0;
-            if (lane == 0) arrived = __hip_atomic_fetch_add(&sh_flag[2], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            arrived = __builtin_amdgcn_readfirstlane(arrived);
-            if (arrived == CW - 1) {
-                if (lane == 0) sh_flag[2] = 0; // (the next arrivals come after the two barriers below)
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                // workgroup partial (fixed wave order): lanes < D their gradient component, lane D the log-lik
-                const float *part = bl_lds_f(BL_OFF_PART) + part_pos;
-                float comp = 0.0f;
+            typedef __attribute__((address_space(3))) volatile unsigned BlLdsU;
+            typedef __attribute__((address_space(3))) const volatile float BlLdsF;
+            BlLdsU *tags = (BlLdsU *)bl_lds_i(BL_OFF_TAG);
+            BlLdsF *part = (BlLdsF *)(bl_lds_f(BL_OFF_PART) + part_pos);
+            asm volatile("" ::: "memory"); // (compiler only: the row's stores stay in front of the tag's)
+            if (lane == 0) tags[wave - 1] = epoch_c;
+            unsigned stale = 0u;
 #pragma unroll
-                for (int w = 0; w < CW; w++) comp += part[w * part_rs];
+            for (int w = 0; w < CW; w++) stale |= tags[w] ^ epoch_c;
+            float row[CW];
+#pragma unroll
+            for (int w = 0; w < CW; w++) row[w] = part[w * part_rs];
+            if (__builtin_amdgcn_readfirstlane(stale) == 0u) {
+                // workgroup partial (fixed wave order): lanes < D their gradient component, lane D the log-lik
+                float comp = row[0];
+#pragma unroll
+                for (int w = 1; w < CW; w++) comp += row[w];
                 for (int sp = 1; sp < nsp; sp++) { // several species: the log-lik and the shared coordinate add the other species' slots
 #pragma unroll
-                    for (int w = 0; w < CW; w++) comp += part_all ? part[w * part_rs + sp * BL_SP_PART(KS, KO)] : 0.0f;
+                    for (int w = 0; w < CW; w++) comp += part_all ? (float)part[w * part_rs + sp * BL_SP_PART(KS, KO)] : 0.0f;
                 }
                 if (lane > D) comp = 0.0f;
                 if (lane == D + 1 && member == 0 && (epoch_c & 255u) == 0u)
@@ -653,10 +676,9 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             // reads guarding the one write that the barrier ordered: 2 % slower, the poll loop competes with the evaluation's tail.)
             __syncthreads(); // (the control wave's decisions are done)
             __syncthreads(); // the next position is in LDS
-            if (sh_flag[0] != 0) break;
-            local_c = sh_flag[1] != 0;
         }
-    } else
+    } else {
+    int run_status = 0;
     while (true) {
         bool redo = false; // the evaluation in flight is not the one the sampler needs next
         if (SPEC && have_pending) {
@@ -742,6 +764,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             // that epoch is skipped by every workgroup alike; hand the compute waves the right position
             if (act) sh_coef[my_pos] = cz;
             if (lane == 0) sh_flag[0] = flag;
+            run_status = flag;
         } else {
             // ------------------------------ all-gather of the k partials (G16 / R2) ----
             const unsigned char *rbase = xbase + (epoch & (BL_XCHG_SLOTS - 1u)) * rec_bytes;
@@ -837,6 +860,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 decide();
                 if (act) sh_coef[my_pos] = cz;
                 if (lane == 0) sh_flag[0] = flag;
+                run_status = flag;
                 BL_STAMP_CRIT
             } else {
             if (spec_kind != 0 && !timed_out) {
@@ -849,12 +873,14 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             }
             if (act && cz_spec == cz_spec) sh_coef[my_pos] = cz_spec;
             if (lane == 0) sh_flag[0] = 0;
+            run_status = 0;
             }
             BL_STAMP(4)
         }
         __syncthreads();
         BL_STAMP(5)
-        if (sh_flag[0] != 0) break;
+        if (run_status != 0) break; // (what this wave just wrote to sh_flag[0]: no need to read it back)
+    }
     }
 #ifdef BL_STAMPS
     if (cold->dbg && chain == 0 && member == 0 && tid == 0) {

@@ -28,13 +28,14 @@
 // ---- dynamic LDS carve (bytes; every offset a multiple of 16: guide G17) ----
 #define BL_OFF_COEF 0       // 64 floats : coefficients being evaluated, PADDED layout (beta[0..KS], alpha[0..KO])
 #define BL_OFF_FLAG 256     // 4 ints    : loop control
-#define BL_OFF_PART 272     // <= 16 compute waves x BL_PART_STRIDE floats : per-wave partial sums (padded layout + log-lik)
+#define BL_OFF_TAG 272      // 16 ints   : per compute wave, the evaluation (epoch) its row of the partial table belongs to
+#define BL_OFF_PART 336     // <= 16 compute waves x BL_PART_STRIDE floats : per-wave partial sums (padded layout + log-lik)
 #define BL_PART_STRIDE 48
-#define BL_OFF_CKR 3344     // 10 x 64 floats: r checkpoints      (numpyro r_ckpts)
-#define BL_OFF_CKRS 5904    // 10 x 64 floats: r_sum checkpoints  (numpyro r_sum_ckpts)
-#define BL_OFF_SV 8464      // 16 x 64 floats: control wave's rarely-touched per-dimension state (tree edges, proposal, ...)
-#define BL_OFF_SS 12560     // 256 bytes     : control wave's rarely-touched scalars (BlCtlScalars)
-#define BL_OFF_DATA 12816   // staged site records start here
+#define BL_OFF_CKR 3408     // 10 x 64 floats: r checkpoints      (numpyro r_ckpts)
+#define BL_OFF_CKRS 5968    // 10 x 64 floats: r_sum checkpoints  (numpyro r_sum_ckpts)
+#define BL_OFF_SV 8528      // 16 x 64 floats: control wave's rarely-touched per-dimension state (tree edges, proposal, ...)
+#define BL_OFF_SS 12624     // 256 bytes     : control wave's rarely-touched scalars (BlCtlScalars)
+#define BL_OFF_DATA 12880   // staged site records start here
 #define BL_LDS_TOTAL 163840
 
 extern __shared__ __attribute__((aligned(16))) unsigned char bl_smem_raw[];
@@ -212,6 +213,87 @@ __device__ __forceinline__ void bl_wave_sum_vec_l63(float (&v)[N])
         for (int i = 0; i < N; i++) v[i] += bl_dpp<0x143, 0xC>(v[i]);
     }
 }
+// ---- NV <= 16 wave sums as a REDUCE-SCATTER: each total ends up in one lane group instead of all of them in lane 63 ----
+// The butterfly above spends NV adds on each of its six levels (54 for the 9 values of the (3, 3) kernels).  Here every level halves
+// the values a lane still carries -- the lane groups a level separates keep different halves:
+//   1. row_half_mirror (banks 0<->1, 2<->3 of a row): banks 0, 2 keep v[0, H1), banks 1, 3 keep v[H1, NV)      NV  masked DPP adds
+//   2. row_ror:8       (banks 0<->2, 1<->3):          banks 0, 1 keep the first H2 of theirs, banks 2, 3 the rest  H1
+//   3. v_permlane16_swap (rows 0<->1, 2<->3): a swap + an add folds TWO values, even rows keep one, odd rows the other   ~H2
+//   4. v_permlane32_swap (the wave's halves): likewise                                                              2
+//   5. the two quad levels on the one value left                                                                     2
+// -- 23 instead of 54 for NV = 9, and one LDS store per lane group instead of nine from lane 63.  (bank_mask selects groups of four
+// lanes, which is why the quad levels come last.)  BlScatter<NV>::slot(bank, row): the index of the total the lanes of a (bank, row) hold,
+// -1 where nothing is to be stored; lanes a level does not write keep stale values, which stay inside their own (bank, value) slots.
+template <int NV>
+struct BlScatter {
+    static_assert(NV >= 3 && NV <= 16, "reduce-scatter form: 3..16 values");
+    static constexpr int H1 = (NV + 1) / 2, H2 = (H1 + 1) / 2, H3 = (H2 + 1) / 2;
+    static constexpr int slot(int b, int r)
+    {
+        const int c1 = b & 1, c2 = b >> 1, rp = r & 1, hh = r >> 1;
+        const int xi = hh;                       // level 4: the lower half keeps x0, the upper x1 (a single x: the lower half stores it)
+        if (xi >= H3) return -1;
+        int ui = 2 * xi + rp;                    // level 3: even rows keep u[2 xi], odd rows u[2 xi + 1] (a single u: the even row stores it)
+        if (2 * xi + 1 >= H2) { if (rp) return -1; ui = 2 * xi; }
+        if (ui >= (c2 ? H1 - H2 : H2)) return -1;
+        const int wj = (c2 ? H2 : 0) + ui;       // level 2
+        if (wj >= (c1 ? NV - H1 : H1)) return -1;
+        return (c1 ? H1 : 0) + wj;               // level 1
+    }
+    static constexpr unsigned long long slots() // 16 x 4 bits, indexed by (row << 2) | bank = lane >> 2
+    {
+        unsigned long long t = 0;
+        for (int g = 0; g < 16; g++) { const int k = slot(g & 3, g >> 2); t |= (unsigned long long)(k < 0 ? 0 : k) << (4 * g); }
+        return t;
+    }
+    static constexpr unsigned stores()          // bit g: the lane group g = lane >> 2 stores
+    {
+        unsigned m = 0;
+        for (int g = 0; g < 16; g++) m |= (slot(g & 3, g >> 2) >= 0 ? 1u : 0u) << g;
+        return m;
+    }
+};
+#define BL_DPP_ADD_TO(dst, src, MOD) asm volatile("v_add_f32_dpp %0, %1, %1 " MOD : "+v"(dst) : "v"(src))
+// On return: the lane holds the wave total of value BlScatter<NV>::slot(bank, row) (all four lanes of its bank alike).
+template <int NV>
+__device__ __forceinline__ float bl_wave_reduce_scatter(const float (&v)[NV])
+{
+    using S = BlScatter<NV>;
+    float t[NV], w[S::H1], u[S::H2];
+    // The assembler does not see through inline asm, so the DPP read-after-VALU-write distance (2 wait states) is this code's to keep:
+    // every input is pinned to a register HERE (the compiler otherwise sinks the instruction that produces it to just in front of the
+    // DPP add that reads it), then one gap; inside a level the adds read registers nothing writes any more.
+#pragma unroll
+    for (int i = 0; i < NV; i++) { t[i] = v[i]; asm volatile("" : "+v"(t[i])); }
+#pragma unroll
+    for (int i = 0; i < S::H1; i++) w[i] = t[i];
+    BL_DPP_GAP;
+#pragma unroll
+    for (int i = 0; i < S::H1; i++) BL_DPP_ADD_TO(w[i], t[i], "row_half_mirror row_mask:0xf bank_mask:0x5");
+#pragma unroll
+    for (int i = 0; i < NV - S::H1; i++) BL_DPP_ADD_TO(w[i], t[S::H1 + i], "row_half_mirror row_mask:0xf bank_mask:0xa");
+    BL_DPP_GAP;
+#pragma unroll
+    for (int i = 0; i < S::H2; i++) u[i] = w[i];
+#pragma unroll
+    for (int i = 0; i < S::H2; i++) BL_DPP_ADD_TO(u[i], w[i], "row_ror:8 row_mask:0xf bank_mask:0x3");
+#pragma unroll
+    for (int i = 0; i < S::H1 - S::H2; i++) BL_DPP_ADD_TO(u[i], w[S::H2 + i], "row_ror:8 row_mask:0xf bank_mask:0xc");
+    BL_DPP_GAP;
+    float x[S::H3];
+#pragma unroll
+    for (int i = 0; i < S::H3; i++) {
+        const unsigned a = __float_as_uint(u[2 * i]), b = __float_as_uint(u[2 * i + 1 < S::H2 ? 2 * i + 1 : 2 * i]);
+        const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+        x[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[0]), __float_as_uint(x[S::H3 > 1 ? 1 : 0]), false, false);
+    float y = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    y += bl_dpp<0xB1, 0xF>(y);
+    y += bl_dpp<0x4E, 0xF>(y);
+    return y;
+}
+
 __device__ __forceinline__ void bl_wave_sum2(float &a, float &b)
 {
     float v[2] = {a, b};
@@ -1007,11 +1089,19 @@ __device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, con
     for (int k = 0; k <= KO; k++) v[KS + 1 + k] = ga[k];
     v[KS + KO + 2] = ll;
     if constexpr (EXTRA) v[KS + KO + 3] = gextra;
-    bl_wave_sum_vec_l63<NV>(v);
-    if (lane == 63) {
-        float *part = bl_lds_f(BL_OFF_PART) + wave * row_stride + row_off;
+    if constexpr (NV <= 16) {
+        // reduce-scatter: one lane of every (bank, row) group that ends up with a total stores it
+        const float y = bl_wave_reduce_scatter<NV>(v);
+        const int g = lane >> 2;
+        const int k = (int)(BlScatter<NV>::slots() >> (4 * g)) & 15;
+        if ((lane & 3) == 0 && ((BlScatter<NV>::stores() >> g) & 1u)) bl_lds_f(BL_OFF_PART)[wave * row_stride + row_off + k] = y;
+    } else {
+        bl_wave_sum_vec_l63<NV>(v);
+        if (lane == 63) {
+            float *part = bl_lds_f(BL_OFF_PART) + wave * row_stride + row_off;
 #pragma unroll
-        for (int k = 0; k < NV; k++) part[k] = v[k];
+            for (int k = 0; k < NV; k++) part[k] = v[k];
+        }
     }
 }
 
@@ -1033,14 +1123,16 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
     for (int sp = 0; sp < n_species; sp++) {
     float beta[KS + 1], alpha[KO + 1];
     bl_load_coefs<KS, KO>(beta, alpha, sp * BL_SP_COEF(KS, KO));
-    float ll = 0.0f, gb[KS + 1], ga[KO + 1];
+    // (-0.0f: the identity of IEEE addition, so the evaluators' closing `acc += a.x + a.y` folds to a plain add; with +0.0f the
+    // compiler has to keep a `0 + x` per value -- 9 instructions per evaluation at (3, 3))
+    float ll = -0.0f, gb[KS + 1], ga[KO + 1];
 #pragma unroll
-    for (int k = 0; k <= KS; k++) gb[k] = 0.0f;
+    for (int k = 0; k <= KS; k++) gb[k] = -0.0f;
 #pragma unroll
-    for (int k = 0; k <= KO; k++) ga[k] = 0.0f;
+    for (int k = 0; k <= KO; k++) ga[k] = -0.0f;
     if constexpr (MODEL == 2) {
         static_assert(LDS, "false-positive model: LDS records only");
-        float gphi = 0.0f;
+        float gphi = -0.0f;
         const BlFpScalars fp = bl_fp_scalars(bl_lds_f(BL_OFF_COEF)[n_species * BL_SP_COEF(KS, KO) + 1], fp_mode == 1);
         bl_eval_sites_fp<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
         bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi, row_stride, sp * BL_SP_PART(KS, KO));
@@ -1068,7 +1160,7 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga);
     } else if constexpr (MODEL == 3) {
         static_assert(LDS, "count occupancy model: LDS records only");
-        float gphi = 0.0f;
+        float gphi = -0.0f;
         const BlCopScalars fp = bl_cop_scalars(bl_lds_f(BL_OFF_COEF)[KS + KO + 3], fp_mode);
         bl_eval_sites_cop<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi);
         bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi);
