@@ -184,6 +184,8 @@ template <int N>
 __device__ __forceinline__ void bl_wave_sum_vec_l63(float (&v)[N])
 {
     if constexpr (N >= 3) {
+#pragma unroll
+        for (int i = 0; i < N; i++) asm volatile("" : "+v"(v[i])); // (pinned: see bl_low_sum2)
         BL_DPP_GAP; // the values were just produced by ordinary VALU code
 #pragma unroll
         for (int i = 0; i < N; i++) BL_DPP_ADD(v[i], BL_DPP_XOR1);
@@ -305,7 +307,9 @@ __device__ __forceinline__ void bl_wave_sum2(float &a, float &b)
 // lane 0's group covers n lanes; totals are read from lane 0.  n is wave-uniform.
 __device__ __forceinline__ void bl_low_sum2(float &a, float &b, int n)
 {
-    // two chains only: a gap between levels provides the DPP read-after-write distance
+    // two chains only: a gap between levels provides the DPP read-after-write distance.  (The inputs are pinned first: without it
+    // the compiler may sink the instruction producing one to behind the gap, next to the DPP add that reads it.)
+    asm volatile("" : "+v"(a), "+v"(b));
     BL_DPP_GAP; BL_DPP_ADD(a, BL_DPP_XOR1); BL_DPP_ADD(b, BL_DPP_XOR1);
     BL_DPP_GAP; BL_DPP_ADD(a, BL_DPP_XOR2); BL_DPP_ADD(b, BL_DPP_XOR2);
     if (n > 4) { BL_DPP_GAP; BL_DPP_ADD(a, BL_DPP_HALF); BL_DPP_ADD(b, BL_DPP_HALF); }  // 8 lanes
