@@ -336,20 +336,26 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     }
     __syncthreads();
 
+    // The tree in progress -- its two edges (z, r, g), the momentum sum, the proposal and the weight / acceptance counters -- lives in
+    // the control wave's REGISTERS since round 3 (13 values; until then in its private LDS block, where every subtree's end and every
+    // transition's end fetched them one dependent round trip after the other: two to four per such tick).  LDS keeps what only the
+    // warmup adapter and the outputs touch.
+    float t_zl = 0.f, t_rl = 0.f, t_gl = 0.f, t_zr = 0.f, t_rr = 0.f, t_gr = 0.f, t_rsum = 0.f, t_zp = 0.f, t_gp = 0.f;
+    float t_wt = 0.f, t_sumacc = 0.f;
+    double t_Up = 0.0;
+    int t_nprop = 0, t_it = 0;
     auto mom_refresh = [&]() { // (after M^-1 changed: the same z under the new metric)
         mom_r0 = act ? sv[SV_MOMZ * 64] * __builtin_amdgcn_rsqf(minv) : 0.0f;
         mom_kin = (double)(0.5f * bl_wave_sum(minv * mom_r0 * mom_r0));
     };
     // The rest of a transition's end (everything the next position did not need), see end_kind above.  The tree's proposal
-    // (SV_ZP, SV_GP, ss->Up), its counters (ss->nprop, ss->sumacc), ss->it and the started transition's momentum (mom_r0) are
+    // (t_zp, t_gp, t_Up), its counters (t_nprop, t_sumacc), t_it and the started transition's momentum (mom_r0) are
     // untouched since the decisions.
     auto end_deferred = [&]() {
         if (end_kind == 0) return;
-        const float th = sv[SV_ZP * 64], gr = sv[SV_GP * 64], r0 = mom_r0;
-        const double U = ss->Up;
-        const int nprop = ss->nprop, it = ss->it;
-        sv[SV_TH * 64] = th; sv[SV_GR * 64] = gr;
-        ss->U = U;
+        const float th = t_zp, gr = t_gp, r0 = mom_r0;
+        const double U = t_Up;
+        const int nprop = t_nprop, it = t_it;
         if (end_kind & 2) {
             ss->nleap_w += nprop;
             if (end_kind & 4) { // Welford moments of the draw (a window's last draw was added by the decisions themselves)
@@ -369,19 +375,19 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 if (act) cold->draws[s * D + lane] = th;
                 if (lane == 0) {
                     cold->num_steps[s] = nprop;
-                    cold->accept_prob[s] = ss->sumacc * bl_rcp((float)nprop);
+                    cold->accept_prob[s] = t_sumacc * bl_rcp((float)nprop);
                     cold->diverging[s] = pend_sdiv ? 1 : 0;
                     cold->potential[s] = (float)U;
                 }
             }
         }
-        if (end_kind & (2 | 16)) ss->it = it + 1;
+        if (end_kind & (2 | 16)) t_it = it + 1;
         end_kind = 0;
         // the fresh tree of the transition that has already started
-        sv[SV_ZL * 64] = th; sv[SV_RL * 64] = r0; sv[SV_GL * 64] = gr;
-        sv[SV_ZR * 64] = th; sv[SV_RR * 64] = r0; sv[SV_GRR * 64] = gr;
-        sv[SV_RSUM * 64] = r0;
-        ss->wt = 0.f; ss->sumacc = 0.f; ss->nprop = 0;
+        t_zl = th; t_rl = r0; t_gl = gr;
+        t_zr = th; t_rr = r0; t_gr = gr;
+        t_rsum = r0;
+        t_wt = 0.f; t_sumacc = 0.f; t_nprop = 0;
         // and the momentum of the one after it
         const float z = bl_rng_normal(rng_d);
         sv[SV_MOMZ * 64] = z;
@@ -409,14 +415,14 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         }
         if (pend_end) {
             // biased=True: merge the finished subtree into the tree
-            const float wt = ss->wt;
+            const float wt = t_wt;
             float pr = fminf(1.0f, bl_exp(swt - wt));
             if (pend_sturn || pend_sdiv) pr = 0.0f;
             const float u = bl_rng_uniform(rng_u);
-            if (u < pr) { sv[SV_ZP * 64] = szp; sv[SV_GP * 64] = sgp; ss->Up = sUp; }
-            ss->wt = bl_logaddexp(wt, swt);
-            ss->sumacc += ssumacc;
-            ss->nprop += pend_snprop;
+            if (u < pr) { t_zp = szp; t_gp = sgp; t_Up = sUp; }
+            t_wt = bl_logaddexp(wt, swt);
+            t_sumacc += ssumacc;
+            t_nprop += pend_snprop;
         }
     };
 
@@ -456,7 +462,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 init_pending = false;
                 new_transition = true;
                 // (no transition behind it: the deferred part only installs the start state and the first tree)
-                sv[SV_ZP * 64] = cz; sv[SV_GP * 64] = cg; ss->Up = Un;
+                t_zp = cz; t_gp = cg; t_Up = Un;
                 end_kind = 1;
             } else {
                 // ------- CRITICAL: finish the leaf (_build_basetree), decide where the next one goes -------
@@ -494,12 +500,11 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                     // ---------- subtree complete: extend the tree edge, tree-level U-turn ----------
                     BL_STAMP_KIND(1)
                     pend_end = true; pend_sturn = sturn; pend_sdiv = sdiv; pend_snprop = snprop;
-                    const int e_ext = going_right ? SV_ZR : SV_ZL;  // edge this subtree extends (z, r, g slots follow)
-                    const int e_in = going_right ? SV_ZL : SV_ZR;   // opposite edge
-                    sv[e_ext * 64] = cz; sv[(e_ext + 1) * 64] = cr; sv[(e_ext + 2) * 64] = cg;
-                    const float r_other = sv[(e_in + 1) * 64];
-                    const float rsum = sv[SV_RSUM * 64] + srsum;
-                    sv[SV_RSUM * 64] = rsum;
+                    // the edge this subtree extends takes its last leaf; the opposite edge stays
+                    const float o_z = going_right ? t_zl : t_zr, r_other = going_right ? t_rl : t_rr, o_g = going_right ? t_gl : t_gr;
+                    if (going_right) { t_zr = cz; t_rr = cr; t_gr = cg; } else { t_zl = cz; t_rl = cr; t_gl = cg; }
+                    const float rsum = t_rsum + srsum;
+                    t_rsum = rsum;
                     // numpyro _combine_tree (biased): turning = new_tree.turning | _is_turning(edges, r_sum)
                     const bool turning = sturn || bl_is_turning(minv, going_right ? r_other : cr, going_right ? cr : r_other, rsum, D);
                     depth++;
@@ -511,7 +516,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                         snprop = 0; sturn = false; sdiv = false;
                         // the edge the next doubling starts from: the one just extended (this leaf, in registers) or the other one
                         float ez = cz, er = cr, eg = cg;
-                        if (going_right != was_right) { ez = sv[e_in * 64]; er = sv[(e_in + 1) * 64]; eg = sv[(e_in + 2) * 64]; }
+                        if (going_right != was_right) { ez = o_z; er = r_other; eg = o_g; }
                         bl_next_leaf(ez, er, eg, epsdir, minv, rh, cz);
                     } else {
                         // ---------------- transition complete ----------------
@@ -522,11 +527,11 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                         BL_SUB0
                         run_deferred();
                         BL_SUB(0)
-                        const int it = ss->it;
+                        const int it = t_it;
                         end_kind = it < W ? (1 | 2) : (1 | 16);
                         if (it < W) {
                             // warmup_adapter.update_fn: dual averaging (t0=10, kappa=.75, gamma=.05)
-                            const float accp = ss->sumacc * bl_rcp((float)ss->nprop);
+                            const float accp = t_sumacc * bl_rcp((float)t_nprop);
                             const float g = cold->target_accept - accp;
                             const int da_t = ss->da_t + 1;
                             const float tt = (float)da_t;
@@ -546,7 +551,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                             if (at_end && middle) {
                                 // a window closes: the new metric enters the very next leaf, so this draw's moments are
                                 // added here and now (a handful of times per run)
-                                const float th = sv[SV_ZP * 64];
+                                const float th = t_zp;
                                 const int wf_n = ss->wf_n + 1;
                                 const float wf_mean0 = sv[SV_WFMEAN * 64];
                                 const float dpre = th - wf_mean0;
@@ -569,10 +574,10 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 }
             }
             if (new_transition) {
-                // a fresh tree from the proposal (SV_ZP, SV_GP, ss->Up) with the momentum drawn ahead; its first doubling, first leaf
-                const float th = sv[SV_ZP * 64], gr = sv[SV_GP * 64];
+                // a fresh tree from the proposal (t_zp, t_gp, t_Up) with the momentum drawn ahead; its first doubling, first leaf
+                const float th = t_zp, gr = t_gp;
                 const float r0 = mom_r0;
-                E0 = ss->Up + mom_kin;
+                E0 = t_Up + mom_kin;
                 depth = 0;
                 going_right = (bl_rng_next(rng_dir) >> 31) != 0u;
                 epsdir = going_right ? eps : -eps;
@@ -746,9 +751,8 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                     spec_ed = gr2 ? eps : -eps;
                     spec_kind = 2;
                     if (gr2 != going_right) { // that edge is in LDS, untouched by the subtree in progress
-                        const int e = gr2 ? SV_ZR : SV_ZL;
                         float rh2;
-                        bl_next_leaf(sv[e * 64], sv[(e + 1) * 64], sv[(e + 2) * 64], spec_ed, minv, rh2, spec_other);
+                        bl_next_leaf(gr2 ? t_zr : t_zl, gr2 ? t_rr : t_rl, gr2 ? t_gr : t_gl, spec_ed, minv, rh2, spec_other);
                         spec_kind = 3;
                     }
                 }
