@@ -340,6 +340,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     // the control wave's REGISTERS since round 3 (13 values; until then in its private LDS block, where every subtree's end and every
     // transition's end fetched them one dependent round trip after the other: two to four per such tick).  LDS keeps what only the
     // warmup adapter and the outputs touch.
+    float ck_last = 0.f, cks_last = 0.f;
     float t_zl = 0.f, t_rl = 0.f, t_gl = 0.f, t_zr = 0.f, t_rr = 0.f, t_gr = 0.f, t_rsum = 0.f, t_zp = 0.f, t_gp = 0.f;
     float t_wt = 0.f, t_sumacc = 0.f;
     double t_Up = 0.0;
@@ -486,8 +487,12 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 if ((leaf_idx & 1) == 0) {
                     sh_ckr[idx_max * 64 + lane] = cr;
                     sh_ckrs[idx_max * 64 + lane] = srsum;
+                    ck_last = cr; cks_last = srsum; // (the checkpoint the NEXT leaf's first test compares with: kept in registers too)
                 } else {
-                    for (int i = idx_max; i >= idx_min && !sturn; i--) {
+                    // the first test is against the checkpoint the previous (even) leaf has just written -- popc((L - 1) >> 1) = popc(L >> 1)
+                    // for odd L -- so it needs no LDS round trip; half of the odd leaves have no other test
+                    sturn = bl_is_turning(minv, ck_last, cr, srsum - cks_last + ck_last, D);
+                    for (int i = idx_max - 1; i >= idx_min && !sturn; i--) {
                         const float ck = sh_ckr[i * 64 + lane];
                         const float srs = srsum - sh_ckrs[i * 64 + lane] + ck;
                         sturn = bl_is_turning(minv, ck, cr, srs, D);
