@@ -150,11 +150,12 @@ __device__ __forceinline__ void bl_merge_weights(float a, float b, float &lse, f
 }
 
 // numpyro hmc_util._is_turning (diagonal mass); lane d = dim d, lanes >= D hold zeros.
+// (D <= 0: "at most 8 dimensions", decided once per launch -- the fixed three-level sum)
 __device__ __forceinline__ bool bl_is_turning(float minv, float rl, float rr, float rsum, int D)
 {
     const float rho = rsum - 0.5f * (rl + rr);
     float dl = minv * rl * rho, dr = minv * rr * rho;
-    bl_low_sum2(dl, dr, D);
+    if (D <= 0) bl_low_sum2_w8(dl, dr); else bl_low_sum2(dl, dr, D);
     return (dl <= 0.0f) || (dr <= 0.0f);
 }
 
@@ -283,7 +284,8 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     bool local = false;                 // L2-local exchange proven safe for this chain
     float prior_loc = 0.f, prior_isc2 = 0.f, prior_l1 = 0.f;
     double prior_const = 0.0;
-    int S = 0, W = 0, total = 0;
+    int S = 0, W = 0, total = 0, nwin = 0, win_end_cur = 0;
+    float target_accept = 0.8f;
 
     // exchange addressing (per lane, fixed for the whole launch): byte offsets of the <= 8 granules this
     // lane polls per round; record indices beyond k are clamped to k-1 (duplicates carry valid
@@ -305,6 +307,9 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 
     if (wave == 0) {
         S = cold->num_samples; W = cold->num_warmup; total = W + S;
+        // what a warmup transition's end needs of the cold block, in registers: read there they are three device-memory loads one
+        // behind the other (the last one's index behind an LDS read) between a transition's last gradient and the next one's first position
+        target_accept = cold->target_accept; nwin = cold->nwin; win_end_cur = cold->win_end[0];
         prior_loc = beta_lane ? cold->loc_b : cold->loc_a;
         prior_isc2 = act ? (beta_lane ? cold->isc2_b : cold->isc2_a) : 0.0f;
         prior_l1 = act ? (beta_lane ? cold->l1_b : cold->l1_a) : 0.0f;
@@ -340,6 +345,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     // the control wave's REGISTERS since round 3 (13 values; until then in its private LDS block, where every subtree's end and every
     // transition's end fetched them one dependent round trip after the other: two to four per such tick).  LDS keeps what only the
     // warmup adapter and the outputs touch.
+    const int Dred = D <= 8 ? 0 : D; // (0: the sums over the dimensions take the fixed three-level form)
     float ck_last = 0.f, cks_last = 0.f;
     float t_zl = 0.f, t_rl = 0.f, t_gl = 0.f, t_zr = 0.f, t_rr = 0.f, t_gr = 0.f, t_rsum = 0.f, t_zp = 0.f, t_gp = 0.f;
     float t_wt = 0.f, t_sumacc = 0.f;
@@ -368,7 +374,11 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 sv[SV_WFM2 * 64] += dpre * (th - wf_mean);
                 ss->wf_n = wf_n;
             }
-            if (end_kind & 8) ss->win_idx = ss->win_idx + 1;
+            if (end_kind & 8) {
+                const int wi = ss->win_idx + 1;
+                ss->win_idx = wi;
+                win_end_cur = cold->win_end[wi < 31 ? wi : 31]; // (beside the next transition's first evaluation)
+            }
         } else if (end_kind & 16) {
             ss->nleap_s += nprop;
             if (member == 0) {
@@ -469,7 +479,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 // ------- CRITICAL: finish the leaf (_build_basetree), decide where the next one goes -------
                 const float cr = bl_leaf_momentum(rh, epsdir, cg);
                 float s_prior = pe2, s_kin = minv * cr * cr;
-                bl_low_sum2(s_prior, s_kin, D);
+                if (Dred <= 0) bl_low_sum2_w8(s_prior, s_kin); else bl_low_sum2(s_prior, s_kin, D);
                 const double Un = -ll_tot + (double)(0.5f * s_prior) + prior_const;
                 const double Kn = (double)(0.5f * s_kin);
                 double dE = (Un + Kn) - E0;
@@ -491,11 +501,11 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 } else {
                     // the first test is against the checkpoint the previous (even) leaf has just written -- popc((L - 1) >> 1) = popc(L >> 1)
                     // for odd L -- so it needs no LDS round trip; half of the odd leaves have no other test
-                    sturn = bl_is_turning(minv, ck_last, cr, srsum - cks_last + ck_last, D);
+                    sturn = bl_is_turning(minv, ck_last, cr, srsum - cks_last + ck_last, Dred);
                     for (int i = idx_max - 1; i >= idx_min && !sturn; i--) {
                         const float ck = sh_ckr[i * 64 + lane];
                         const float srs = srsum - sh_ckrs[i * 64 + lane] + ck;
-                        sturn = bl_is_turning(minv, ck, cr, srs, D);
+                        sturn = bl_is_turning(minv, ck, cr, srs, Dred);
                     }
                 }
                 if (snprop < (1 << depth) && !sturn && !sdiv) {
@@ -511,7 +521,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                     const float rsum = t_rsum + srsum;
                     t_rsum = rsum;
                     // numpyro _combine_tree (biased): turning = new_tree.turning | _is_turning(edges, r_sum)
-                    const bool turning = sturn || bl_is_turning(minv, going_right ? r_other : cr, going_right ? cr : r_other, rsum, D);
+                    const bool turning = sturn || bl_is_turning(minv, going_right ? r_other : cr, going_right ? cr : r_other, rsum, Dred);
                     depth++;
                     if (depth < p.max_depth && !turning && !sdiv) {
                         // next doubling
@@ -537,7 +547,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                         if (it < W) {
                             // warmup_adapter.update_fn: dual averaging (t0=10, kappa=.75, gamma=.05)
                             const float accp = t_sumacc * bl_rcp((float)t_nprop);
-                            const float g = cold->target_accept - accp;
+                            const float g = target_accept - accp;
                             const int da_t = ss->da_t + 1;
                             const float tt = (float)da_t;
                             const float rt10 = bl_rcp(tt + 10.0f);
@@ -549,8 +559,8 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                             eps = fminf(fmaxf(eps, 1.1754944e-38f), 3.4028235e+38f);
                             ss->da_t = da_t; ss->da_gavg = da_gavg; ss->da_xt = da_xt; ss->da_xavg = da_xavg;
                             const int win_idx = ss->win_idx;
-                            const bool middle = win_idx > 0 && win_idx < cold->nwin - 1;
-                            const bool at_end = it == cold->win_end[win_idx];
+                            const bool middle = win_idx > 0 && win_idx < nwin - 1;
+                            const bool at_end = it == win_end_cur;
                             if (middle) end_kind |= 4;
                             if (at_end) end_kind |= 8;
                             if (at_end && middle) {

@@ -326,6 +326,17 @@ __device__ __forceinline__ void bl_low_sum2(float &a, float &b, int n)
     a = bl_readlane(a, 0); b = bl_readlane(b, 0);
 }
 
+// The same for n <= 8 known beforehand (the (<= 3, <= 3)-covariate kernels of one species): three levels, no branches on n.
+__device__ __forceinline__ void bl_low_sum2_w8(float &a, float &b)
+{
+    asm volatile("" : "+v"(a), "+v"(b));
+    BL_DPP_GAP; BL_DPP_ADD(a, BL_DPP_XOR1); BL_DPP_ADD(b, BL_DPP_XOR1);
+    BL_DPP_GAP; BL_DPP_ADD(a, BL_DPP_XOR2); BL_DPP_ADD(b, BL_DPP_XOR2);
+    BL_DPP_GAP; BL_DPP_ADD(a, BL_DPP_HALF); BL_DPP_ADD(b, BL_DPP_HALF);
+    BL_DPP_GAP;
+    a = bl_readlane(a, 0); b = bl_readlane(b, 0);
+}
+
 // ------------------------------------------------------------------- RNG ----
 // xoshiro128++ 1.0; identical sequence to oracle/occu_oracle.c (tests compare them).
 struct BlRng {
