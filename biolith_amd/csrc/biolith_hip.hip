@@ -268,7 +268,7 @@ struct BlPredRng {
 __global__ void bl_predict_kernel(const float *__restrict__ rows, const float *__restrict__ wraw, int n_stride, int N, int T, int J,
                                   int Ks, int Ko, int D, const float *__restrict__ draws, int n0, int n1,
                                   unsigned long long seed, int model, int max_abundance, int fp_mode,
-                                  unsigned char *__restrict__ latent, unsigned char *__restrict__ y, int o_u, int o_v, int o_e)
+                                  unsigned char *__restrict__ latent, unsigned char *__restrict__ y, int o_u, int o_v, int o_e, int o_fp)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -281,7 +281,8 @@ __global__ void bl_predict_kernel(const float *__restrict__ rows, const float *_
         for (int k = 0; k < Ks; k++) eta = fmaf(x[k], th[k + 1], eta);
         if (o_u >= 0) eta += th[o_u + i]; // random effects (model 6; offsets into a draw, -1 = absent): occu.py:198-202, 221-228
         // false-positive rate (model 2): acts on every site ("constant") or on unoccupied ones only
-        const float fpr = model == 2 ? 1.0f / (1.0f + __expf(-th[D - 1])) : 0.0f;
+        // (o_fp: where phi = logit(rate) sits in a draw -- the last coordinate, or right behind the coefficients with random effects)
+        const float fpr = model == 2 ? 1.0f / (1.0f + __expf(-th[o_fp])) : 0.0f;
         const float f_c = fp_mode == BL_FP_CONSTANT ? fpr : 0.0f, f_u = fp_mode == BL_FP_UNOCCUPIED ? fpr : 0.0f;
         for (int t = 0; t < T; t++) {
             BlPredRng rng(seed, ((unsigned long long)n * T + t) * N + i);
@@ -332,7 +333,7 @@ extern "C" int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint6
     if (ds->model == 6 && ds->re.kind == 1)
         return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: not built for occu_cs (its observed site is a continuous score)");
     if (ds->model == 6 && ds->re.kind == 3)
-        return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: not built for the N-mixture model with random effects");
+        return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: the N-mixture model's sampled sites are counts (bl_predict_counts)");
     if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
     int rc = set_device(ds);
     if (rc) return rc;
@@ -357,9 +358,12 @@ extern "C" int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint6
         const int n1 = (n0 + chunk < n_draws) ? n0 + chunk : n_draws;
         const dim3 grid((N + 255) / 256, (n1 - n0) < 1024 ? (n1 - n0) : 1024);
         hipLaunchKernelGGL(bl_predict_kernel, grid, block, 0, nullptr, ds->d_rows, ds->d_wraw, ds->n_stride, N, T, J, ds->Ks, ds->Ko, D,
-                           d_draws, n0, n1, (unsigned long long)seed, ds->model == 6 && ds->re.kind == 4 ? 1 : ds->model /* Royle-Nichols with effects */,
-                           ds->max_abundance, ds->fp_mode, d_lat, d_y,
-                           ds->model == 6 ? ds->re.o_u : -1, ds->model == 6 ? ds->re.o_v : -1, ds->model == 6 ? ds->re.o_e : -1);
+                           d_draws, n0, n1, (unsigned long long)seed,
+                           // random-effects handles: Royle-Nichols (kind 4) / false positives (kind 2) run those branches with the effects
+                           ds->model == 6 && ds->re.kind == 4 ? 1 : (ds->model == 6 && ds->re.kind == 2 ? 2 : ds->model),
+                           ds->max_abundance, ds->model == 6 && ds->re.kind == 2 ? ds->re.fp_mode : ds->fp_mode, d_lat, d_y,
+                           ds->model == 6 ? ds->re.o_u : -1, ds->model == 6 ? ds->re.o_v : -1, ds->model == 6 ? ds->re.o_e : -1,
+                           ds->model == 6 && ds->re.kind == 2 ? ds->re.o_fp : D - 1);
         BL_HIP(hipGetLastError());
         if (latent) BL_HIP(hipMemcpy(latent + (size_t)n0 * T * N, d_lat, (size_t)(n1 - n0) * T * N, hipMemcpyDeviceToHost));
         if (y) BL_HIP(hipMemcpy(y + (size_t)n0 * J * T * N, d_y, (size_t)(n1 - n0) * J * T * N, hipMemcpyDeviceToHost));
@@ -472,7 +476,8 @@ __device__ inline int bl_poisson(BlPredRng &rng, double lam)
 __global__ void bl_predict_counts_kernel(const float *__restrict__ rows, const float *__restrict__ wraw, const float *__restrict__ dur,
                                          int n_stride, int N, int T, int J, int Ks, int Ko, int D,
                                          const float *__restrict__ draws, int n0, int n1, unsigned long long seed, int model,
-                                         int max_abundance, int fp_mode, int *__restrict__ latent, int *__restrict__ y)
+                                         int max_abundance, int fp_mode, int *__restrict__ latent, int *__restrict__ y,
+                                         int o_u, int o_v, int o_e)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -483,6 +488,7 @@ __global__ void bl_predict_counts_kernel(const float *__restrict__ rows, const f
         const float *al = th + Ks + 1;
         float eta = th[0];
         for (int k = 0; k < Ks; k++) eta = fmaf(x[k], th[k + 1], eta);
+        if (o_u >= 0) eta += th[o_u + i]; // random effects (offsets into a draw, -1 = absent): nmixture.py:166-172, 199-214
         const float f = (model == 3 && fp_mode) ? __expf(th[D - 1]) : 0.0f;
         const float f_c = fp_mode == BL_FP_CONSTANT ? f : 0.0f, f_u = fp_mode == BL_FP_UNOCCUPIED ? f : 0.0f;
         for (int t = 0; t < T; t++) {
@@ -510,6 +516,8 @@ __global__ void bl_predict_counts_kernel(const float *__restrict__ rows, const f
                 const int v = t * J + j;
                 float nu = al[0];
                 for (int k = 0; k < Ko; k++) nu = fmaf(wraw[((size_t)v * Ko + k) * n_stride + i], al[k + 1], nu);
+                if (o_v >= 0) nu += th[o_v + i];
+                if (o_e >= 0) nu += th[o_e + (size_t)i * T * J + v];
                 int cnt = 0;
                 if (model == 4) {
                     const float p = 1.0f / (1.0f + __expf(-nu));
@@ -527,7 +535,8 @@ __global__ void bl_predict_counts_kernel(const float *__restrict__ rows, const f
 extern "C" int bl_predict_counts(bl_dataset *ds, int n_draws, const float *draws, uint64_t seed, int32_t *latent, int32_t *y)
 {
     if (!ds || !draws || n_draws <= 0 || (!latent && !y)) return bl_fail(BL_ERR_INVALID, "bl_predict_counts: bad argument");
-    if (ds->model != 3 && ds->model != 4)
+    const bool nmix_re = ds->model == 6 && ds->re.kind == 3; // the N-mixture model with random effects
+    if (ds->model != 3 && ds->model != 4 && !nmix_re)
         return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict_counts: for the count models (occu_cop, nmixture); use bl_predict");
     if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
     int rc = set_device(ds);
@@ -557,8 +566,8 @@ extern "C" int bl_predict_counts(bl_dataset *ds, int n_draws, const float *draws
         const int n1 = (n0 + chunk < n_draws) ? n0 + chunk : n_draws;
         const dim3 grid((N + 255) / 256, (n1 - n0) < 1024 ? (n1 - n0) : 1024);
         hipLaunchKernelGGL(bl_predict_counts_kernel, grid, block, 0, nullptr, ds->d_rows, ds->d_wraw, ds->d_dur, ds->n_stride, N, T, J,
-                           ds->Ks, ds->Ko, D, d_draws, n0, n1, (unsigned long long)seed, ds->model, ds->max_abundance, ds->fp_mode,
-                           d_lat, d_y);
+                           ds->Ks, ds->Ko, D, d_draws, n0, n1, (unsigned long long)seed, nmix_re ? 4 : ds->model, ds->max_abundance, ds->fp_mode,
+                           d_lat, d_y, nmix_re ? ds->re.o_u : -1, nmix_re ? ds->re.o_v : -1, nmix_re ? ds->re.o_e : -1);
         BL_HIP(hipGetLastError());
         if (latent) BL_HIP(hipMemcpy(latent + (size_t)n0 * T * N, d_lat, (size_t)(n1 - n0) * T * N * 4, hipMemcpyDeviceToHost));
         if (y) BL_HIP(hipMemcpy(y + (size_t)n0 * J * T * N, d_y, (size_t)(n1 - n0) * J * T * N * 4, hipMemcpyDeviceToHost));

@@ -90,11 +90,9 @@ def predict(
     from ..engine import OccuDataset
     from .fit import engine_options
 
-    if spec.model == "occu_re" and spec.extras.get("re_fp_mode") is not None:
-        raise NotImplementedError("predict(): random effects together with false positives are fitted, not yet predicted, on the HIP engine")
-    if spec.model == "nmixture" and "site_random_effects" in spec.extras:
-        raise NotImplementedError("predict(): the N-mixture model with random effects is fitted, not yet predicted, on the HIP engine")
     fp_site = f"prob_fp_{spec.extras['fp_mode']}" if spec.model == "occu_fp" else None
+    if spec.model == "occu_re" and spec.extras.get("re_fp_mode") is not None:   # random effects + a false-positive rate: [beta, alpha, phi, log sds, effects]
+        fp_site = f"prob_fp_{spec.extras['re_fp_mode']}"
     if fp_site is not None:
         rate = np.clip(np.asarray(posterior[fp_site], dtype=np.float64).reshape(n), 1e-300, 1 - 1e-16)
         phi = np.log(rate / (1.0 - rate)).astype(np.float32)[:, None]   # the engine's coordinate: logit(rate)
@@ -105,7 +103,7 @@ def predict(
 
     def re_block(sp):
         """The random-effects coordinates of species ``sp`` in the engine's one-species layout (see fit._assemble)."""
-        if spec.model != "occu_re" and not (spec.model == "occu_rn" and "site_random_effects" in spec.extras):
+        if spec.model != "occu_re" and not (spec.model in ("occu_rn", "nmixture") and "site_random_effects" in spec.extras):
             return None
         cols = []
         if spec.extras["site_random_effects"]:
@@ -113,7 +111,7 @@ def predict(
         if spec.extras["obs_random_effects"]:
             cols.append(np.log(np.maximum(np.asarray(posterior["obs_re_sd"], dtype=np.float64).reshape(n, 1), 1e-300)))
         if spec.extras["site_random_effects"]:   # (n, N, species)
-            first = "site_re_abu" if spec.model == "occu_rn" else "site_re_occ"   # (occu_rn.py:172-176)
+            first = "site_re_abu" if spec.model in ("occu_rn", "nmixture") else "site_re_occ"   # (occu_rn.py:172-176, nmixture.py:166-169)
             cols += [np.asarray(posterior[first])[..., sp].reshape(n, -1), np.asarray(posterior["site_re_det"])[..., sp].reshape(n, -1)]
         if spec.extras["obs_random_effects"]:   # (n, J, T, N, species) -> [N][T][J]
             cols.append(np.asarray(posterior["obs_re"])[..., sp].transpose(0, 3, 2, 1).reshape(n, -1))

@@ -163,7 +163,7 @@ int bl_dataset_create_re_fp(const bl_dims *dims, const float *site_covs, const f
  * abundance predictor, site_re_det and obs_re the detection predictor): `counts` / max_abundance as for bl_dataset_create_nmix,
  * theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_abu[N], site_re_det[N]), (obs_re[N][T][J])].  One species
  * per dataset.  bl_logp_grad / bl_nuts_* as above; bl_deterministic returns abundance = exp(eta + site_re_abu) and the
- * detection probability with its effects; bl_predict / bl_predict_counts are not built for it. */
+ * detection probability with its effects; bl_predict_counts draws N and the counts from them. */
 int bl_dataset_create_nmix_re(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *counts,
                               int max_abundance, int site_random_effects, int obs_random_effects,
                               double prior_site_re_sd_scale, double prior_obs_re_sd_scale, const bl_normal_prior *prior_beta,

@@ -104,8 +104,16 @@ def test_reference_nmixture_site_random_effects():
     assert s["site_re_sd"].mean() > 0
     assert s["site_re_abu"].shape == (300, 100, 1) and s["abundance"].shape == (300, 1, 100, 1)
     assert np.allclose(s["abundance"].mean(), truth["abundance"].mean(), rtol=0.25)
-    with pytest.raises(NotImplementedError):
-        predict(nmixture, res.mcmc, **data, site_random_effects=True, max_abundance=int(np.nanmax(data["obs"])))
+    # predict(): N_i and the counts drawn with the effects in both predictors (nmixture.py:181-220)
+    K = int(np.nanmax(data["obs"]))
+    pred = predict(nmixture, res.mcmc, **data, site_random_effects=True, max_abundance=K, num_samples=300)
+    J = data["obs"].shape[3]
+    assert pred["N_i"].shape == (300, 1, 100, 1) and pred["y"].shape == (300, J, 1, 100, 1)
+    assert np.allclose(pred["abundance"], s["abundance"], rtol=1e-5)
+    assert pred["N_i"].max() <= K and pred["y"].max() <= K
+    # E[y | N, p] = N p: the predicted counts against the latent draws and the detection probabilities they were made from
+    expect = (pred["N_i"][:, None].astype(np.float64) * pred["prob_detection"]).mean()
+    assert abs(pred["y"].mean() - expect) < 0.05 * max(expect, 1.0)
 
 
 def test_reference_nmixture_obs_random_effects():

@@ -92,8 +92,16 @@ def test_fit_occu_with_random_effects_and_false_positives():
     assert 0.0 < float(s["prob_fp_constant"].mean()) < 0.35
     assert abs(float(s["psi"].mean()) - truth["z"].mean()) < 0.15
     assert s["prob_detection_fp"].shape[:3] == (1600, 2, 12)
-    with pytest.raises(NotImplementedError):
-        predict(occu, res.mcmc, **data, false_positives_constant=True, site_random_effects=True)
+    # predict(): z and y drawn with the effects in both predictors and the rate on top (occu.py:229-241)
+    pred = predict(occu, res.mcmc, **data, false_positives_constant=True, site_random_effects=True, num_samples=1600)
+    assert pred["z"].shape == (1600, 1, 300, 1) and pred["y"].shape == (1600, 12, 1, 300, 1)
+    assert np.allclose(pred["psi"], s["psi"], rtol=1e-5)
+    assert abs(pred["z"].mean() - s["psi"].mean()) < 0.02
+    # P(y = 1) = 1 - (1 - z p)(1 - f): its mean over draws, sites and visits against the data's detection frequency
+    assert abs(pred["y"].mean() - np.nanmean(data["obs"])) < 0.03
+    zp = pred["prob_detection"] * pred["z"][:, None].astype(np.float32)
+    f = s["prob_fp_constant"].reshape(-1, 1, 1, 1, 1)
+    assert abs(pred["y"].mean() - float((1.0 - (1.0 - zp) * (1.0 - f)).mean())) < 0.01
 
 
 def test_re_fp_rejects_several_species():
