@@ -282,7 +282,7 @@ __global__ void bl_predict_kernel(const float *__restrict__ rows, const float *_
         if (o_u >= 0) eta += th[o_u + i]; // random effects (model 6; offsets into a draw, -1 = absent): occu.py:198-202, 221-228
         // false-positive rate (model 2): acts on every site ("constant") or on unoccupied ones only
         // (o_fp: where phi = logit(rate) sits in a draw -- the last coordinate, or right behind the coefficients with random effects)
-        const float fpr = model == 2 ? 1.0f / (1.0f + __expf(-th[o_fp])) : 0.0f;
+        const float fpr = (model == 2 || (model == 1 && fp_mode == BL_FP_CONSTANT && o_fp >= 0)) ? 1.0f / (1.0f + __expf(-th[o_fp])) : 0.0f;
         const float f_c = fp_mode == BL_FP_CONSTANT ? fpr : 0.0f, f_u = fp_mode == BL_FP_UNOCCUPIED ? fpr : 0.0f;
         for (int t = 0; t < T; t++) {
             BlPredRng rng(seed, ((unsigned long long)n * T + t) * N + i);
@@ -316,6 +316,7 @@ __global__ void bl_predict_kernel(const float *__restrict__ rows, const float *_
                 const float r = 1.0f / (1.0f + __expf(-nu));
                 float pd = model == 1 ? 1.0f - __powf(1.0f - r, (float)zn) : (float)zn * r;
                 if (model == 2) pd = 1.0f - (1.0f - pd) * (1.0f - f_c) * (1.0f - (zn ? 0.0f : f_u));
+                if (model == 1) pd = 1.0f - (1.0f - pd) * (1.0f - fpr); // (Royle-Nichols with a false-positive rate: occu_rn.py:214-221; fpr = 0 without)
                 const float u = rng.uniform();
                 y[(((size_t)(n - n0) * J + j) * T + t) * N + i] = (u < pd) ? 1 : 0;
             }
@@ -360,10 +361,10 @@ extern "C" int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint6
         hipLaunchKernelGGL(bl_predict_kernel, grid, block, 0, nullptr, ds->d_rows, ds->d_wraw, ds->n_stride, N, T, J, ds->Ks, ds->Ko, D,
                            d_draws, n0, n1, (unsigned long long)seed,
                            // random-effects handles: Royle-Nichols (kind 4) / false positives (kind 2) run those branches with the effects
-                           ds->model == 6 && ds->re.kind == 4 ? 1 : (ds->model == 6 && ds->re.kind == 2 ? 2 : ds->model),
-                           ds->max_abundance, ds->model == 6 && ds->re.kind == 2 ? ds->re.fp_mode : ds->fp_mode, d_lat, d_y,
+                           ds->model == 6 && (ds->re.kind == 4 || ds->re.kind == 5) ? 1 : (ds->model == 6 && ds->re.kind == 2 ? 2 : ds->model),
+                           ds->max_abundance, ds->model == 6 && (ds->re.kind == 2 || ds->re.kind == 5) ? ds->re.fp_mode : ds->fp_mode, d_lat, d_y,
                            ds->model == 6 ? ds->re.o_u : -1, ds->model == 6 ? ds->re.o_v : -1, ds->model == 6 ? ds->re.o_e : -1,
-                           ds->model == 6 && ds->re.kind == 2 ? ds->re.o_fp : D - 1);
+                           ds->model == 6 ? ((ds->re.kind == 2 || ds->re.kind == 5) ? ds->re.o_fp : -1) : D - 1);
         BL_HIP(hipGetLastError());
         if (latent) BL_HIP(hipMemcpy(latent + (size_t)n0 * T * N, d_lat, (size_t)(n1 - n0) * T * N, hipMemcpyDeviceToHost));
         if (y) BL_HIP(hipMemcpy(y + (size_t)n0 * J * T * N, d_y, (size_t)(n1 - n0) * J * T * N, hipMemcpyDeviceToHost));
@@ -1046,6 +1047,7 @@ static hipError_t re_nuts_dispatch(int mk, const BlReRun &run, int grid, size_t 
     if (run.m.kind == 2) return mk == 4 ? re_nuts_dispatch_lds<4, 2>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 2>(run, grid, lds, st);
     if (run.m.kind == 3) return mk == 4 ? re_nuts_dispatch_lds<4, 3>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 3>(run, grid, lds, st);
     if (run.m.kind == 4) return mk == 4 ? re_nuts_dispatch_lds<4, 4>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 4>(run, grid, lds, st);
+    if (run.m.kind == 5) return mk == 4 ? re_nuts_dispatch_lds<4, 5>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 5>(run, grid, lds, st);
     if (mk == 4) return run.m.kind == 1 ? re_nuts_dispatch_lds<4, 1>(run, grid, lds, st) : re_nuts_dispatch_lds<4, 0>(run, grid, lds, st);
     return run.m.kind == 1 ? re_nuts_dispatch_lds<16, 1>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 0>(run, grid, lds, st);
 }
@@ -1096,6 +1098,25 @@ extern "C" int bl_dataset_create_re(const bl_dims *dims, const float *site_covs,
 {
     return create_re_impl(dims, site_covs, obs_covs, obs, site_random_effects, obs_random_effects, prior_site_re_sd_scale,
                           prior_obs_re_sd_scale, 0, 0.0, 0.0, 0, 0, prior_beta, prior_alpha, device, out);
+}
+
+// occu_rn(false_positives_constant = True [, site_random_effects / obs_random_effects = True]): occu_rn.py:133-138, 214-221 --
+// y ~ Bernoulli(1 - (1 - p)(1 - f)), f ~ Beta(a, b).  theta = [beta, alpha, phi = logit f, (log sds), (effects)]; one species.  The
+// model runs on the random-effects kernels also WITHOUT effects (kind 5; the work-proportional kernel of the plain model has no such term).
+extern "C" int bl_dataset_create_rn_fp(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
+                                       int max_abundance, int site_random_effects, int obs_random_effects,
+                                       double prior_site_re_sd_scale, double prior_obs_re_sd_scale, const bl_beta_prior *prior_fp,
+                                       const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha, int device, bl_dataset **out)
+{
+    if (max_abundance < 1 || max_abundance >= BL_RN_NB)
+        return bl_fail(BL_ERR_UNSUPPORTED, "max_abundance=%d outside 1..%d", max_abundance, BL_RN_NB - 1);
+    if (dims && dims->n_species != 1)
+        return bl_fail(BL_ERR_UNSUPPORTED, "Royle-Nichols with a false-positive rate: one species per dataset (n_species=%d)", dims->n_species);
+    const double a = prior_fp ? prior_fp->a : 2.0, b = prior_fp ? prior_fp->b : 5.0;
+    if (!(a > 0.0) || !(b > 0.0) || !std::isfinite(a) || !std::isfinite(b)) return bl_fail(BL_ERR_INVALID, "Beta prior needs finite a, b > 0");
+    return create_re_impl(dims, site_covs, obs_covs, obs, site_random_effects, obs_random_effects,
+                          site_random_effects ? prior_site_re_sd_scale : 1.0, obs_random_effects ? prior_obs_re_sd_scale : 1.0,
+                          BL_FP_CONSTANT, a, b, 1, max_abundance, prior_beta, prior_alpha, device, out);
 }
 
 // occu(site_random_effects / obs_random_effects = True, false_positives_constant / _unoccupied = True): occu.py:146-157 with
@@ -1150,7 +1171,7 @@ static int create_re_impl(const bl_dims *dims, const float *site_covs, const flo
                           double prior_obs_re_sd_scale, int fp_mode, double fp_a, double fp_b, int count_model, int count_K, const bl_normal_prior *prior_beta,
                           const bl_normal_prior *prior_alpha, int device, bl_dataset **out)
 {
-    if (!site_random_effects && !obs_random_effects)
+    if (!site_random_effects && !obs_random_effects && !(count_model == 1 && fp_mode))
         return bl_fail(BL_ERR_INVALID, "bl_dataset_create_re: neither random effect requested (use bl_dataset_create)");
     if (dims && (dims->n_site_covs > BL_RE_MAXK || dims->n_obs_covs > BL_RE_MAXK))
         return bl_fail(BL_ERR_UNSUPPORTED, "random-effects kernels are built for at most %d covariates per side (Ks=%d, Ko=%d)",
@@ -1177,7 +1198,7 @@ static int create_re_impl(const bl_dims *dims, const float *site_covs, const flo
     m.n_species = S; m.G0s = Ks + Ko + 2; m.sp = 0; m.cb = 0; m.rv0 = ds->KS; m.sp_rows = T * J * (ds->KO + 1 + (count_model ? 1 : 0)) + 2 * T;
     m.G0 = S * m.G0s; m.G = m.G0 + (fp_mode ? 1 : 0) + m.site_re + m.obs_re; m.D = (int)Dll;
     int at = m.G0;
-    m.kind = count_model == 4 ? 3 : (count_model == 1 ? 4 : (fp_mode ? 2 : 0)); m.fp_mode = fp_mode; m.fp_a = (float)fp_a; m.fp_b = (float)fp_b;
+    m.kind = count_model == 4 ? 3 : (count_model == 1 ? (fp_mode ? 5 : 4) : (fp_mode ? 2 : 0)); m.fp_mode = fp_mode; m.fp_a = (float)fp_a; m.fp_b = (float)fp_b;
     m.tab = ds->d_tab; m.tab_ld = ds->n_stride; m.max_abundance = count_K;
     m.o_fp = fp_mode ? at++ : -1;       // phi = logit(false-positive rate): right behind the regression coefficients
     m.o_phi_s = m.site_re ? at++ : -1;
@@ -1406,7 +1427,11 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     // RNG: one stream per coordinate (the model's order), then the scalar and the direction stream; chains are D + 2 streams
     // apart (>= 64).  Each workgroup gets the streams of ITS coordinates in its own order; the fixed effects' and the two
     // scalar streams are replicated (every workgroup advances its copy identically).
-    const int stride = (int)D + 2;
+    // (With at most 61 coordinates -- occu_cs, occu_rn with a false-positive rate and no effects -- the layout is the small models':
+    // chains 64 streams apart, the scalar stream 63 and the direction stream 62, as the oracle's orc_nuts_run lays them out.)
+    const bool small_layout = D + 2 <= (size_t)BL_RNG_STREAMS_PER_CHAIN - 1;
+    const int stride = small_layout ? BL_RNG_STREAMS_PER_CHAIN : (int)D + 2;
+    const int ext_scalar = small_layout ? BL_RNG_STREAMS_PER_CHAIN - 1 : (int)D, ext_dir = small_layout ? BL_RNG_STREAMS_PER_CHAIN - 2 : (int)D + 1;
     std::vector<uint32_t> all((size_t)C * stride * 4), rs((size_t)C * k * (dl_max + 2) * 4, 0u);
     rng_streams_strided(cfg->seed, cfg->chain_offset, stride, C, all.data());
     for (int c = 0; c < C; c++)
@@ -1425,8 +1450,8 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
             if (g.obs_re)
                 for (int v = 0; v < V; v++)
                     for (int i = 0; i < cnt; i++) put(at + v * cnt + i, g.o_e + (sp * N + s0 + i) * V + v);
-            put(dl_max, (int)D);         // scalar stream
-            put(dl_max + 1, (int)D + 1); // direction stream
+            put(dl_max, ext_scalar);   // scalar stream
+            put(dl_max + 1, ext_dir);  // direction stream
         }
     BL_HIP(hipMemcpyAsync(ds->d_rng, rs.data(), rs.size() * 4, hipMemcpyHostToDevice, st));
     std::vector<float> it32;

@@ -62,7 +62,7 @@ struct BlReModel {
     // kind 2 only (kept at the end: the other kinds' kernels never load them)
     int fp_mode, o_fp;                    // 1 = the rate acts on every site ("constant"), 2 = on unoccupied sites; phi = logit(rate) at o_fp = G0
     float fp_a, fp_b;                     // Beta(a, b) prior of the rate
-    // kinds 3 and 4 (max_abundance; the table is kind 3's): N-mixture / Royle-Nichols with random effects (nmixture.py:139-141, 166-172, 199-214) -- the count model's rows
+    // kinds 3, 4 and 5 (max_abundance; the table is kind 3's): N-mixture / Royle-Nichols with random effects / Royle-Nichols with a false-positive rate (nmixture.py:139-141, 166-172, 199-214) -- the count model's rows
     // (visit = (m y, m, w..)) and its data-only table tab[t][n][site] = sum_j m log C(n, y_j) (-inf below the largest count)
     const float *tab;
     int tab_ld, max_abundance;
@@ -646,9 +646,12 @@ __device__ __forceinline__ void bl_nmix_re_site_pass(const BlReModel &m, const f
 // one thread per site with the K + 1 terms of a (site, period) in a private column: the effects make every site's predictors its own,
 // and this form serves the reference's sizes (its tests: 100 sites) -- the work-proportional kernel of the plain model is not reused.
 // rows: the plain model's (visit = (c, c w_1..w_KO, spare), c = +1 detection, -1 none, 0 masked).
-template <int MK>
+// FP (kind 5; occu_rn.py:133-138, 214-221): y ~ Bernoulli(1 - (1 - p)(1 - f)), f = sigmoid(phi) at z[m.o_fp]:  P(y = 1 | n) = f + (1 - f) r b_n,
+// P(y = 0 | n) = q^n (1 - f); *gphi accumulates d ll / d phi (chain rule through f included).
+template <int MK, bool FP = false>
 __device__ __forceinline__ void bl_rn_re_site_pass(const BlReModel &m, const float *__restrict__ rows, int ns, int rv,
-                                                   const float *__restrict__ z, float *__restrict__ g, float (&part)[2 * MK + 3])
+                                                   const float *__restrict__ z, float *__restrict__ g, float (&part)[2 * MK + 3],
+                                                   float *gphi = nullptr)
 {
     const int N = m.n_sites, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 2, K = m.max_abundance;
     constexpr float LOG_EPS = -15.9423847f, LOG_TINY = -87.3365448f, ONE_M_EPS = 0.99999988f, TINY = 1.17549435e-38f;
@@ -661,6 +664,13 @@ __device__ __forceinline__ void bl_rn_re_site_pass(const BlReModel &m, const flo
     }
     const float isd2_s = m.site_re ? bl_exp(-2.0f * z[m.o_phi_s]) : 0.0f;
     const float isd2_o = m.obs_re ? bl_exp(-2.0f * z[m.o_phi_o]) : 0.0f;
+    float fpr = 0.0f, gq = 1.0f, lgq = 0.0f, dfp = 0.0f; // the rate f, 1 - f, log(1 - f); d ll / d f
+    if constexpr (FP) {
+        const float phi = z[m.o_fp], e = bl_exp(-fabsf(phi)), op = 1.0f + e, iop = bl_rcp(op);
+        fpr = (phi > 0.0f ? 1.0f : e) * iop;
+        gq = (phi > 0.0f ? e : 1.0f) * iop;
+        lgq = -(fmaxf(phi, 0.0f) + bl_log(op));
+    }
 #pragma unroll
     for (int k = 0; k < 2 * MK + 3; k++) part[k] = 0.0f;
     float term[BL_RN_NB];
@@ -703,12 +713,13 @@ __device__ __forceinline__ void bl_rn_re_site_pass(const BlReModel &m, const flo
                 const float r = (nu > 0.0f ? 1.0f : e) * iop, q = (nu > 0.0f ? e : 1.0f) * iop;
                 const float lq = -(fmaxf(nu, 0.0f) + bl_log(op)); // log(1 - r)
                 if (c < 0.0f) {
-                    for (int n = 1; n <= K; n++) term[n] += fmaxf((float)n * lq, LOG_EPS);
+                    if constexpr (FP) term[0] += lgq;
+                    for (int n = 1; n <= K; n++) term[n] += fmaxf(fmaf((float)n, lq, lgq), LOG_EPS);
                 } else {
-                    term[0] += LOG_TINY;
+                    term[0] += FP ? bl_log(fmaxf(fminf(fpr, ONE_M_EPS), TINY)) : LOG_TINY;
                     float b = 1.0f;
                     for (int n = 1; n <= K; n++) {
-                        term[n] += bl_log(fmaxf(fminf(r * b, ONE_M_EPS), TINY));
+                        term[n] += bl_log(fmaxf(fminf(fmaf(gq * r, b, fpr), ONE_M_EPS), TINY));
                         b = fmaf(b, q, 1.0f);
                     }
                 }
@@ -741,12 +752,17 @@ __device__ __forceinline__ void bl_rn_re_site_pass(const BlReModel &m, const flo
                     const float nu = fmaf(c, sc, vi + ev);
                     const float e = bl_exp(-fabsf(nu)), op = 1.0f + e, iop = bl_rcp(op);
                     const float r = (nu > 0.0f ? 1.0f : e) * iop, q = (nu > 0.0f ? e : 1.0f) * iop;
-                    if (c < 0.0f) { // d (n log q) / d nu = -n r, where the floor does not hold
+                    if (c < 0.0f) { // d (n log q) / d nu = -n r, where the floor does not hold  (FP: d log(q^n (1 - f)) / d f = -1 / (1 - f))
                         const float lq = -(fmaxf(nu, 0.0f) + bl_log(op));
-                        float acc = 0.0f;
-                        for (int n = 1; n <= K; n++) acc = fmaf((float)n * lq > LOG_EPS ? (float)n : 0.0f, term[n], acc);
+                        float acc = 0.0f, acc0 = 0.0f;
+                        for (int n = 1; n <= K; n++) {
+                            const bool open_ = fmaf((float)n, lq, lgq) > LOG_EPS;
+                            acc = fmaf(open_ ? (float)n : 0.0f, term[n], acc);
+                            if constexpr (FP) acc0 += open_ ? term[n] : 0.0f;
+                        }
                         dnu = -r * acc * inv;
-                    } else {        // d log(1 - q^n) / d nu = n q^n / b_n = n (1 / b_n - r), where neither clamp holds
+                        if constexpr (FP) dfp -= (acc0 + (lgq > LOG_EPS ? term[0] : 0.0f)) * inv * bl_rcp(gq);
+                    } else if constexpr (!FP) { // d log(1 - q^n) / d nu = n q^n / b_n = n (1 / b_n - r), where neither clamp holds
                         float b = 1.0f, acc = 0.0f;
                         for (int n = 1; n <= K; n++) {
                             const float p = r * b;
@@ -754,6 +770,17 @@ __device__ __forceinline__ void bl_rn_re_site_pass(const BlReModel &m, const flo
                             b = fmaf(b, q, 1.0f);
                         }
                         dnu = acc * inv;
+                    } else {        // P = f + (1 - f) r b_n:  d log P / d nu = n r q^n (1 - f) / P,  d log P / d f = q^n / P,  q^n = 1 - r b_n
+                        float b = 1.0f, acc = 0.0f, accf = (fpr <= ONE_M_EPS && fpr >= TINY) ? term[0] * bl_rcp(fpr) : 0.0f; // (n = 0: P = f, q^0 = 1)
+                        for (int n = 1; n <= K; n++) {
+                            const float p = fmaf(gq * r, b, fpr), qn = fmaf(-r, b, 1.0f);
+                            const float wp = (p <= ONE_M_EPS && p >= TINY) ? term[n] * bl_rcp(p) : 0.0f;
+                            acc = fmaf((float)n * qn, wp, acc);
+                            accf = fmaf(qn, wp, accf);
+                            b = fmaf(b, q, 1.0f);
+                        }
+                        dnu = acc * r * gq * inv;
+                        dfp += accf * inv;
                     }
                 }
                 part[MK + 2] += dnu;
@@ -771,6 +798,7 @@ __device__ __forceinline__ void bl_rn_re_site_pass(const BlReModel &m, const flo
             g[m.o_v + i] = fmaf(vi, isd2_s, -dl_dv);
         }
     }
+    if constexpr (FP) *gphi = dfp * fpr * gq; // (d f / d phi = f (1 - f))
 }
 
 // ---- occu_cs (biolith/models/occu_cs.py:120-232): s ~ Normal(mu_f, sigma_f), f ~ Bernoulli(z p), z ~ Bernoulli(psi); z and every
@@ -1026,6 +1054,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel gm
             if (m.kind == 2) bl_re_site_pass<MK, true>(m, rows, ns, rv, z, g, part, &gphi);
             else if (m.kind == 3) bl_nmix_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
             else if (m.kind == 4) bl_rn_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
+            else if (m.kind == 5) bl_rn_re_site_pass<MK, true>(m, rows, ns, rv, z, g, part, &gphi);
             else bl_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
             bl_re_effect_squares(m, z, ss);
 #pragma unroll
@@ -1041,9 +1070,9 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel gm
         if (sp == S - 1) { // fixed effects of every species and the log sds, from the species' and the total sums
             for (int d = tid; d < m.G; d += BL_RE_NT)
                 grad[(size_t)b * gm.D + d] = (double)((m.kind == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red_tot)
-                                                      : (m.kind == 2 ? bl_re_global_grad<MK, true>(m, d, z[d], red_tot, red_sp, NRED)
+                                                      : ((m.kind == 2 || m.kind == 5) ? bl_re_global_grad<MK, true>(m, d, z[d], red_tot, red_sp, NRED)
                                                                      : bl_re_global_grad<MK>(m, d, z[d], red_tot, red_sp, NRED)));
-            if (tid == 0) U[b] = (m.kind == 2 ? bl_re_potential<true>(m, z, red_tot, red_tot[OX + 2], OX) : bl_re_potential(m, z, red_tot, red_tot[OX + 2], OX))
+            if (tid == 0) U[b] = ((m.kind == 2 || m.kind == 5) ? bl_re_potential<true>(m, z, red_tot, red_tot[OX + 2], OX) : bl_re_potential(m, z, red_tot, red_tot[OX + 2], OX))
                                  + (m.kind == 1 ? bl_cs_extra_potential(m, z) : 0.0);
         }
     }
@@ -1143,6 +1172,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
             if constexpr (KIND == 2) bl_re_site_pass<MK, true>(m, rows, rows_ns, rows_rv, z, g, part, &gphi);
             else if constexpr (KIND == 3) bl_nmix_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
             else if constexpr (KIND == 4) bl_rn_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
+            else if constexpr (KIND == 5) bl_rn_re_site_pass<MK, true>(m, rows, rows_ns, rows_rv, z, g, part, &gphi);
             else bl_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
             BL_RE_T(8)
             bl_re_effect_squares(m, z, ss);
@@ -1157,7 +1187,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
         v[OX + 4] = tid == 0 ? xcc : 0.0f; v[OX + 5] = tid == 0 ? xcc * xcc : 0.0f;
         BL_RE_T(0)
         ev_first = xc.epoch == 0u;
-        ev_nv = KIND == 1 ? NV1 : (KIND == 2 ? OX + 7 : (ev_first ? OX + 6 : OX + 4));
+        ev_nv = KIND == 1 ? NV1 : ((KIND == 2 || KIND == 5) ? OX + 7 : (ev_first ? OX + 6 : OX + 4));
         bl_re_block_sum<NV1, NRED>(v, scr, red, ev_nv, xc.k == 1);
         BL_RE_T(9)
         bl_re_publish<NRED>(xc, red, ev_nv);
@@ -1172,8 +1202,8 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
         if (ev_first && R.allow_local) xc.local = ((double)R.k * red[OX + 5] == red[OX + 4] * red[OX + 4]); // exact: small integers
         if (red[OX + 3] > 0.0) flag = 5;
         for (int d = tid; d < G; d += BL_RE_NT)
-            g[d] = (KIND == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red) : bl_re_global_grad<MK, KIND == 2>(m, d, z[d], red, red_sp, NRED);
-        double U = bl_re_potential<KIND == 2>(m, z, red, red[OX + 2], OX);
+            g[d] = (KIND == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red) : bl_re_global_grad<MK, KIND == 2 || KIND == 5>(m, d, z[d], red, red_sp, NRED);
+        double U = bl_re_potential<KIND == 2 || KIND == 5>(m, z, red, red[OX + 2], OX);
         if constexpr (KIND == 1) U += bl_cs_extra_potential(m, z);
         BL_RE_T(1)
         return U;

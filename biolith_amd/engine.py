@@ -160,6 +160,18 @@ class OccuDataset:
                 raise NotImplementedError("occu_dyn: one species per dataset")
             _ffi.check(lib.bl_dataset_create_dyn(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), C.byref(pb), C.byref(pa), device, C.byref(h)))
             self.D = 3 * (Ks + 1) + Ko + 1
+        elif model == "occu_rn" and re_fp_mode is not None:
+            # Royle-Nichols with a false-positive rate (with or without random effects): theta = [beta, alpha, phi = logit(rate), (log sds), (effects)]
+            if re_fp_mode != "constant":
+                raise ValueError("occu_rn: the false-positive rate acts on every site (re_fp_mode='constant')")
+            pf = _ffi.bl_beta_prior(*self.prior_fp)
+            _ffi.check(lib.bl_dataset_create_rn_fp(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), int(max_abundance),
+                                                   int(bool(site_random_effects)), int(bool(obs_random_effects)),
+                                                   float(prior_site_re_sd), float(prior_obs_re_sd), C.byref(pf), C.byref(pb), C.byref(pa),
+                                                   device, C.byref(h)))
+            d = C.c_int()
+            _ffi.check(lib.bl_dataset_param_dim(h, C.byref(d)))
+            self.D = int(d.value)
         elif model == "occu_rn" and (site_random_effects or obs_random_effects):
             # theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_abu[N], site_re_det[N]), (obs_re[N][T][J])]
             _ffi.check(lib.bl_dataset_create_rn_re(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), int(max_abundance),
@@ -241,7 +253,7 @@ class OccuDataset:
         if "laplace" in fam:
             _ffi.check(lib.bl_dataset_set_prior_family(h, int(fam[0] == "laplace"), int(fam[1] == "laplace")))
         self.site_re, self.obs_re = bool(site_random_effects), bool(obs_random_effects)
-        self.re_fp_mode = re_fp_mode if model == "occu_re" else None
+        self.re_fp_mode = re_fp_mode if model in ("occu_re", "occu_rn") else None
 
     def close(self):
         if getattr(self, "_h", None):

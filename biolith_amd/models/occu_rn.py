@@ -12,7 +12,7 @@ from typing import Any
 
 import numpy as np
 
-from ..distributions import Beta, HalfNormal, Normal, as_half_normal, as_normal
+from ..distributions import Beta, HalfNormal, Normal, as_beta, as_half_normal, as_normal
 from ..regression import LinearRegression
 from ._generators import Generator, expit, observed_mean, within
 from .occu import OccuSpec
@@ -44,7 +44,8 @@ def occu_rn(
 ) -> OccuSpec:
     """Royle-Nichols abundance-occupancy model on the HIP engine (parameters: occu_rn.py:20-40).
 
-    Built: linear regressors, Normal priors, no false positives, no spatial effect; ``site_random_effects`` /
+    Built: linear regressors, Normal priors, no spatial effect; ``false_positives_constant`` (occu_rn.py:133-138, 214-221; Beta prior),
+    ``site_random_effects`` /
     ``obs_random_effects`` with HalfNormal priors on their sds (occu_rn.py:151-154, 172-184, 199-212) run on the random-effects
     kernels, one species per fit (the sds are sampled outside the species plate).  Everything else raises ``NotImplementedError``.
 
@@ -68,8 +69,8 @@ def occu_rn(
     unsupported = []
     if coords is not None:
         unsupported.append("coords (spatial effect, occu_rn.py:140-148)")
-    if false_positives_constant:
-        unsupported.append("false positives (occu_rn.py:133-138)")
+    if false_positives_constant and obs is not None and n_species > 1:
+        unsupported.append("false positives with several species (the rate is shared across the species plate, occu_rn.py:133-138)")
     if (site_random_effects or obs_random_effects) and obs is not None and n_species > 1:
         unsupported.append("random effects with several species (the sds are shared across the species plate, occu_rn.py:151-154)")
     if regressor_abu is not LinearRegression or regressor_det is not LinearRegression:
@@ -90,7 +91,9 @@ def occu_rn(
     spec = OccuSpec(site_covs, obs_covs, obs, n_species, as_normal(prior_beta, "prior_beta"),
                     as_normal(prior_alpha, "prior_alpha"), model="occu_rn",
                     extras=dict(max_abundance=int(max_abundance)))
-    if site_random_effects or obs_random_effects:
+    if false_positives_constant:   # occu_rn.py:133-138, 214-221: runs on the random-effects kernels, with or without effects
+        spec.extras.update(re_fp_mode="constant", prior_fp=as_beta(prior_prob_fp_constant, "prior_prob_fp_constant"))
+    if site_random_effects or obs_random_effects or false_positives_constant:
         spec.extras.update(site_random_effects=bool(site_random_effects), obs_random_effects=bool(obs_random_effects),
                            prior_site_re_sd=as_half_normal(prior_site_re_sd, "prior_site_re_sd"),
                            prior_obs_re_sd=as_half_normal(prior_obs_re_sd, "prior_obs_re_sd"))

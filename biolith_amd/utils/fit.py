@@ -283,6 +283,8 @@ def engine_options(spec) -> dict:
             opts.update(re_fp_mode=spec.extras["re_fp_mode"], prior_fp=spec.extras["prior_fp"])
     if spec.model in ("nmixture", "occu_rn") and "site_random_effects" in spec.extras:
         opts.update({k: spec.extras[k] for k in ("site_random_effects", "obs_random_effects", "prior_site_re_sd", "prior_obs_re_sd")})
+        if spec.extras.get("re_fp_mode") is not None:   # occu_rn with a false-positive rate
+            opts.update(re_fp_mode=spec.extras["re_fp_mode"], prior_fp=spec.extras["prior_fp"])
     if spec.model == "occu_cs":
         opts.update(prior_mu=spec.extras["prior_mu"], prior_sigma=spec.extras["prior_sigma"])
     return opts

@@ -91,7 +91,7 @@ def predict(
     from .fit import engine_options
 
     fp_site = f"prob_fp_{spec.extras['fp_mode']}" if spec.model == "occu_fp" else None
-    if spec.model == "occu_re" and spec.extras.get("re_fp_mode") is not None:   # random effects + a false-positive rate: [beta, alpha, phi, log sds, effects]
+    if spec.model in ("occu_re", "occu_rn") and spec.extras.get("re_fp_mode") is not None:   # (random effects +) a false-positive rate: [beta, alpha, phi, log sds, effects]
         fp_site = f"prob_fp_{spec.extras['re_fp_mode']}"
     if fp_site is not None:
         rate = np.clip(np.asarray(posterior[fp_site], dtype=np.float64).reshape(n), 1e-300, 1 - 1e-16)
@@ -115,7 +115,7 @@ def predict(
             cols += [np.asarray(posterior[first])[..., sp].reshape(n, -1), np.asarray(posterior["site_re_det"])[..., sp].reshape(n, -1)]
         if spec.extras["obs_random_effects"]:   # (n, J, T, N, species) -> [N][T][J]
             cols.append(np.asarray(posterior["obs_re"])[..., sp].transpose(0, 3, 2, 1).reshape(n, -1))
-        return np.concatenate(cols, axis=1).astype(np.float32)
+        return np.concatenate(cols, axis=1).astype(np.float32) if cols else None   # (occu_rn with a false-positive rate and no effects)
 
     if spec.model == "occu_cs":   # sites psi, z, f, s (occu_cs.py:196-232); mu / sigma travel in the engine's coordinates
         from ..engine import OccuDataset

@@ -146,7 +146,8 @@ int bl_dataset_create_nmix(const bl_dims *dims, const float *site_covs, const fl
  * slicing the sites of one species; bl_deterministic / bl_predict take one-species handles (cut the draws per species).
  * bl_logp_grad / bl_nuts_* work as for the other models (the sampler
  * runs k workgroups per chain -- site slices, partial sums exchanged through device memory; all num_chains x k must be
- * resident, so num_chains x k <= compute units -- with its vectors in device memory / LDS; RNG: one stream per coordinate, D + 2 per chain).
+ * resident, so num_chains x k <= compute units -- with its vectors in device memory / LDS; RNG: one stream per coordinate, D + 2 per chain;
+ * with D <= 61 the layout of the other models: 64 per chain, the two scalar streams last).
  * At most 16 covariates per side.  bl_deterministic adds the effects to both predictors; bl_predict draws z and y from them.
  */
 int bl_dataset_create_re(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
@@ -175,6 +176,13 @@ int bl_dataset_create_rn_re(const bl_dims *dims, const float *site_covs, const f
                             int max_abundance, int site_random_effects, int obs_random_effects,
                             double prior_site_re_sd_scale, double prior_obs_re_sd_scale, const bl_normal_prior *prior_beta,
                             const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
+/* ... and with a false-positive rate (occu_rn.py:133-138, 214-221: y ~ Bernoulli(1 - (1 - p)(1 - f)), f ~ Beta(a, b)), with or without the
+ * random effects: theta = [beta, alpha, phi = logit f, (log sds), (effects)].  One species.  Runs on the random-effects kernels in
+ * either case; bl_deterministic / bl_predict apply the effects and the rate. */
+int bl_dataset_create_rn_fp(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
+                            int max_abundance, int site_random_effects, int obs_random_effects,
+                            double prior_site_re_sd_scale, double prior_obs_re_sd_scale, const bl_beta_prior *prior_fp,
+                            const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
 /*
  * The continuous-score occupancy model biolith.models.occu_cs (models/occu_cs.py:17-232; Rhinehart et al. 2022): `scores`
  * [S=1][N][T][J] (NaN = missing) ~ Normal(mu_f, sigma_f) with f ~ Bernoulli(z p) and z ~ Bernoulli(psi) summed out.

@@ -61,6 +61,7 @@ def lib():
             L.orc_data_set_re_fp.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_nmix_re.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_rn_re.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
+            L.orc_data_set_rn_fp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
             L.orc_data_set_prior_family.argtypes = [C.c_void_p, C.c_int, C.c_int]
             L.orc_data_set_cs.argtypes = [C.c_void_p, dp, dp, dp]
             L.orc_data_set_dyn.argtypes = [C.c_void_p]
@@ -128,7 +129,12 @@ class OracleData:
         self.model, self.max_abundance = model, int(max_abundance)
         assert model in ("occu", "occu_rn", "occu_fp", "occu_cop", "nmixture", "occu_re", "occu_cs", "occu_dyn")
         lib().orc_data_set_model(self._h, 1 if model == "occu_rn" else 0, int(max_abundance))
-        if model == "occu_rn" and (site_random_effects or obs_random_effects):   # occu_rn.py:151-154, 172-184, 199-212
+        if model == "occu_rn" and re_fp_mode is not None:   # occu_rn.py:133-138, 214-221 (+ the random effects): [beta, alpha, phi, log sds, effects]
+            assert re_fp_mode == "constant"
+            lib().orc_data_set_rn_fp(self._h, int(bool(site_random_effects)), int(bool(obs_random_effects)),
+                                     float(prior_site_re_sd), float(prior_obs_re_sd), float(prior_fp[0]), float(prior_fp[1]))
+            self.D = int(lib().orc_data_dim(self._h))
+        elif model == "occu_rn" and (site_random_effects or obs_random_effects):   # occu_rn.py:151-154, 172-184, 199-212
             lib().orc_data_set_rn_re(self._h, int(bool(site_random_effects)), int(bool(obs_random_effects)),
                                      float(prior_site_re_sd), float(prior_obs_re_sd))
             self.D = int(lib().orc_data_dim(self._h))
@@ -612,7 +618,8 @@ def literal_log_joint_dyn(theta, site_covs, obs_covs, obs, prior_beta=(0.0, 1.0)
 
 
 def literal_log_joint_rn(theta, site_covs, obs_covs, obs, max_abundance=100, prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0),
-                         site_random_effects=False, obs_random_effects=False, prior_site_re_sd=1.0, prior_obs_re_sd=1.0):
+                         site_random_effects=False, obs_random_effects=False, prior_site_re_sd=1.0, prior_obs_re_sd=1.0,
+                         false_positives_constant=False, prior_fp=(2.0, 5.0)):
     """log p(theta, y) of the Royle-Nichols model, stated literally (biolith/models/occu_rn.py:123-222):
     N enumerated over 0..max_abundance under Categorical(logits=Poisson(lambda).log_prob(support))
     (utils/distributions.py:31-40; Categorical renormalises), Bernoulli(1-(1-r)^N) with clamp_probs."""
@@ -639,6 +646,13 @@ def literal_log_joint_rn(theta, site_covs, obs_covs, obs, max_abundance=100, pri
     def normal0(v, sd):
         return (-0.5 * (v / sd) ** 2 - np.log(sd) - 0.5 * np.log(2 * np.pi)).sum()
 
+    fpr = 0.0
+    if false_positives_constant:   # occu_rn.py:133-138: the rate lives on the logit scale (+ log-Jacobian), right behind the coefficients
+        from scipy.special import betaln
+        phi = theta[at]; at += 1
+        fpr = 1.0 / (1.0 + np.exp(-phi))
+        a_, b_ = prior_fp
+        lp_re += (a_ - 1.0) * np.log(fpr) + (b_ - 1.0) * np.log1p(-fpr) - betaln(a_, b_) + np.log(fpr) + np.log1p(-fpr)
     sd_s = sd_o = None
     if site_random_effects:
         lp_re += half_normal_on_log_scale(theta[at], prior_site_re_sd); sd_s = np.exp(theta[at]); at += 1
@@ -663,6 +677,7 @@ def literal_log_joint_rn(theta, site_covs, obs_covs, obs, max_abundance=100, pri
     finite = np.isfinite(Y)
     y0 = np.where(finite, Y, 0.0)
     p = 1.0 - (1.0 - r[..., None]) ** support                                   # (N,T,J,K+1)  occu_rn.py:219
+    p = 1.0 - (1.0 - p) * (1.0 - fpr)                                           # occu_rn.py:214-221
     ly = _bernoulli_logpmf_clamped(p, y0[..., None])
     ly = np.where(finite[..., None], ly, 0.0).sum(axis=2)                       # (N,T,K+1)
     ll = logsumexp(log_prior[:, None, :] + ly, axis=2).sum()

@@ -70,7 +70,7 @@ def test_vector_kernels_leave_the_lds_budget(tmp_path_factory):
         if not re.match(r"_Z\d+bl_re_(?:nuts|logp)_kernel", name):
             continue
         assert static + budget_kb * 1024 <= 160 * 1024, (name, static)
-        if "ILi4ELi4E" in name or ("ILi4E" in name and "logp" in name):   # (the parity hook dispatches on the kind at run time: it holds kind 4's column too) kind 4 (Royle-Nichols with random effects): a thread's K + 1 terms of a (site, period) are a private column BY DESIGN
+        if "ILi4ELi4E" in name or "ILi4ELi5E" in name or ("ILi4E" in name and "logp" in name):   # (kind 5 = kind 4 with a false-positive rate)   # (the parity hook dispatches on the kind at run time: it holds kind 4's column too) kind 4 (Royle-Nichols with random effects): a thread's K + 1 terms of a (site, period) are a private column BY DESIGN
             assert scratch <= 512 + 192, (name, scratch)
         elif "ILi4E" in name:   # (a few spilled dwords in the rarer forms -- rows in device memory -- are tolerated, an array in scratch is not)
             # kind 2 (random effects + false positives: ILi4ELi2E) and the parity hook carry more live state: a few dozen dwords
@@ -78,4 +78,4 @@ def test_vector_kernels_leave_the_lds_budget(tmp_path_factory):
             if "Lb1ELi2EE" in name and "ILi4ELi2E" not in name:   # the form the bench sizes run: rows and every per-leapfrog vector in LDS
                 assert scratch == 0, (name, scratch)
         seen += 1
-    assert seen >= 62   # 2 capacities x 5 kinds x 2 x 3 LDS forms of the sampler + 2 parity kernels
+    assert seen >= 74   # 2 capacities x 6 kinds x 2 x 3 LDS forms of the sampler + 2 parity kernels

@@ -81,6 +81,29 @@ def test_rn_re_closed_form_equals_literal_model(name, site, obs):
     assert np.max(np.abs(fd - grad[idx])) <= 1e-5 * max(1.0, np.max(np.abs(grad)))
 
 
+@pytest.mark.parametrize("name,site,obs", [("rn_small_2x2", False, False), ("rn_small_2x2", True, False), ("rn_missing", True, True)])
+def test_rn_fp_closed_form_equals_literal_model(name, site, obs):
+    """A false-positive rate on top (occu_rn.py:133-138, 214-221), with and without random effects: the oracle against the literal
+    model and central differences; theta = [beta, alpha, phi = logit f, (log sds), (effects)]."""
+    g = load_golden(name)
+    kw = dict(site_random_effects=site, obs_random_effects=obs, prior_site_re_sd=0.8, prior_obs_re_sd=1.2)
+    od = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], (0.2, 1.5), (-0.1, 0.7), model="occu_rn", max_abundance=15,
+                           re_fp_mode="constant", prior_fp=(2.0, 6.0), **kw)
+    N, T, J = g["obs"].shape[1:]
+    G = od.Ks + od.Ko + 2
+    assert od.D == G + 1 + site * (1 + 2 * N) + obs * (1 + N * T * J)
+    rng = np.random.default_rng(6)
+    th = rng.uniform(-0.8, 0.8, size=od.D)
+    U, grad = od.potential_grad(th)
+    lit = oracle.literal_log_joint_rn(th, g["site_covs"], g["obs_covs"], g["obs"][0], max_abundance=15, prior_beta=(0.2, 1.5),
+                                      prior_alpha=(-0.1, 0.7), false_positives_constant=True, prior_fp=(2.0, 6.0), **kw)
+    assert abs(U + lit) <= 1e-10 * abs(U)
+    h = 1e-6
+    idx = np.unique(np.concatenate([np.arange(min(G + 3, od.D)), rng.integers(0, od.D, size=10)]))
+    fd = np.array([(od.potential_grad(th + h * e)[0] - od.potential_grad(th - h * e)[0]) / (2 * h) for e in np.eye(od.D)[idx]])
+    assert np.max(np.abs(fd - grad[idx])) <= 1e-5 * max(1.0, np.max(np.abs(grad)))
+
+
 def test_rn_max_abundance_renormalises_the_prior():
     """Categorical(logits) renormalises the truncated Poisson (utils/distributions.py:31-40): with all
     data masked the marginal likelihood is exactly 1 whatever the cutoff."""
@@ -97,7 +120,9 @@ def test_occu_rn_validation():
     g = load_golden("rn_small_2x2")
     spec = occu_rn(g["site_covs"], g["obs_covs"], obs=g["obs"], coords=None, ell=0.0)
     assert spec.model == "occu_rn" and spec.extras["max_abundance"] == 100
-    for kw in (dict(false_positives_constant=True), dict(coords=np.zeros((60, 2))), dict(max_abundance=500)):
+    fp = occu_rn(g["site_covs"], g["obs_covs"], obs=g["obs"], false_positives_constant=True)   # occu_rn.py:133-138
+    assert fp.extras["re_fp_mode"] == "constant" and fp.extras["prior_fp"] == (2.0, 5.0) and not fp.extras["site_random_effects"]
+    for kw in (dict(coords=np.zeros((60, 2))), dict(max_abundance=500)):
         with pytest.raises(NotImplementedError):
             occu_rn(g["site_covs"], g["obs_covs"], obs=g["obs"], **kw)
     re = occu_rn(g["site_covs"], g["obs_covs"], obs=g["obs"], site_random_effects=True)   # occu_rn.py:151-154
