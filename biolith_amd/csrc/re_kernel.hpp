@@ -801,6 +801,102 @@ __device__ __forceinline__ void bl_rn_re_site_pass(const BlReModel &m, const flo
     if constexpr (FP) *gphi = dfp * fpr * gq; // (d f / d phi = f (1 - f))
 }
 
+// ---- occu_cop with random effects (kind 6; biolith/models/occu_cop.py:183-186, 204-210, 229-243) ----
+// site_re_occ_i joins the occupancy predictor, site_re_det_i and obs_re_itj the log detection rate; no false-positive rates.  Per
+// (site, period), with the parameter-free part of the Poisson log-pmf in the potential's constant (the count model's rows:
+// visit = (y, dur, w..), masked visits y = dur = 0; ka = sum y):
+//   a = sum_j (y_j nu_j - dur_j e^nu_j),   l = log psi + a  if any count is positive (Poisson(0) gives it probability 0 at z = 0),
+//   else logaddexp(log psi + a, log(1 - psi));   q = P(z = 1 | y);   d l / d eta = q - psi,   d l / d nu_j = q (y_j - dur_j e^nu_j).
+// One thread per site (bl_eval_sites_cop's arithmetic without the false-positive terms).
+template <int MK>
+__device__ __forceinline__ void bl_cop_re_site_pass(const BlReModel &m, const float *__restrict__ rows, int ns, int rv,
+                                                    const float *__restrict__ z, float *__restrict__ g, float (&part)[2 * MK + 3])
+{
+    const int N = m.n_sites, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 2, V = T * J;
+    float beta[MK + 1], alpha[MK + 1];
+#pragma unroll
+    for (int k = 0; k <= MK; k++) {
+        const float b = z[m.cb + min(k, Ks)], a = z[m.cb + Ks + 1 + min(k, Ko)];
+        beta[k] = k <= Ks ? b : 0.0f;
+        alpha[k] = k <= Ko ? a : 0.0f;
+    }
+    const float isd2_s = m.site_re ? bl_exp(-2.0f * z[m.o_phi_s]) : 0.0f;
+    const float isd2_o = m.obs_re ? bl_exp(-2.0f * z[m.o_phi_o]) : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2 * MK + 3; k++) part[k] = 0.0f;
+    for (int i = threadIdx.x; i < N; i += BL_RE_NT) {
+        float x[MK];
+        float eta = beta[0];
+#pragma unroll
+        for (int k = 0; k < MK; k++) {
+            const float xk = rows[min(k, Ks) * ns + i];
+            x[k] = k < Ks ? xk : 0.0f;
+            eta = fmaf(x[k], beta[k + 1], eta);
+        }
+        const float ui = m.site_re ? z[m.o_u + i] : 0.0f, vi = m.site_re ? z[m.o_v + i] : 0.0f;
+        eta += ui;
+        const float ee = bl_exp(-fabsf(eta)), ope = 1.0f + ee, le = bl_log(ope);
+        const float psi = (eta > 0.0f ? 1.0f : ee) * bl_rcp(ope);
+        const float log_psi = fminf(eta, 0.0f) - le, log_1mpsi = -fmaxf(eta, 0.0f) - le;
+        float dl_deta = 0.0f, dl_dv = 0.0f;
+        for (int t = 0; t < T; t++) {
+            float a = 0.0f, gy[MK + 1], gd[MK + 1];
+#pragma unroll
+            for (int k = 0; k <= MK; k++) { gy[k] = 0.0f; gd[k] = 0.0f; }
+            for (int j = 0; j < J; j++) {
+                const int v = t * J + j, r0 = (rv + v * vw) * ns + i;
+                const float y = rows[r0], dur = rows[r0 + ns];
+                float w[MK];
+                float nu = alpha[0] + vi + (m.obs_re ? z[m.o_e + v * N + i] : 0.0f);
+#pragma unroll
+                for (int k = 0; k < MK; k++) {
+                    const float wk = rows[r0 + (2 + min(k, max(Ko, 1) - 1)) * ns];
+                    w[k] = k < Ko ? wk : 0.0f;
+                    nu = fmaf(w[k], alpha[k + 1], nu);
+                }
+                const float rate = dur * bl_exp(fminf(nu, 80.0f));
+                a += fmaf(y, nu, -rate);
+                gy[0] += y; gd[0] += rate;
+#pragma unroll
+                for (int k = 0; k < MK; k++) { gy[k + 1] = fmaf(y, w[k], gy[k + 1]); gd[k + 1] = fmaf(rate, w[k], gd[k + 1]); }
+            }
+            const float ka = rows[(rv + V * vw + t) * ns + i];
+            const float A = log_psi + a;
+            float l = A, q = 1.0f;
+            if (!(ka > 0.0f)) { // no count at all: the unoccupied branch is possible
+                const float d = A - log_1mpsi, e = bl_exp(-fabsf(d)), op = 1.0f + e;
+                l = fmaxf(A, log_1mpsi) + bl_log(op);
+                q = (d > 0.0f ? 1.0f : e) * bl_rcp(op);
+            }
+            part[0] += l;
+            dl_deta += q - psi;
+#pragma unroll
+            for (int k = 0; k <= MK; k++) part[MK + 2 + k] = fmaf(q, gy[k] - gd[k], part[MK + 2 + k]);
+            dl_dv = fmaf(q, gy[0] - gd[0], dl_dv);
+            if (m.obs_re) { // each replicate's own effect (its rate recomputed: nothing was kept per visit)
+                for (int j = 0; j < J; j++) {
+                    const int v = t * J + j, r0 = (rv + v * vw) * ns + i;
+                    const float y = rows[r0], dur = rows[r0 + ns], ev = z[m.o_e + v * N + i];
+                    float nu = alpha[0] + vi + ev;
+#pragma unroll
+                    for (int k = 0; k < MK; k++) {
+                        const float wk = rows[r0 + (2 + min(k, max(Ko, 1) - 1)) * ns];
+                        nu = fmaf(k < Ko ? wk : 0.0f, alpha[k + 1], nu);
+                    }
+                    g[m.o_e + v * N + i] = fmaf(ev, isd2_o, -q * (y - dur * bl_exp(fminf(nu, 80.0f))));
+                }
+            }
+        }
+        part[1] += dl_deta;
+#pragma unroll
+        for (int k = 0; k < MK; k++) part[2 + k] = fmaf(dl_deta, x[k], part[2 + k]);
+        if (m.site_re) {
+            g[m.o_u + i] = fmaf(ui, isd2_s, -dl_deta);
+            g[m.o_v + i] = fmaf(vi, isd2_s, -dl_dv);
+        }
+    }
+}
+
 // ---- occu_cs (biolith/models/occu_cs.py:120-232): s ~ Normal(mu_f, sigma_f), f ~ Bernoulli(z p), z ~ Bernoulli(psi); z and every
 // f summed out (the f of different replicates are independent given z).  Coordinates: [beta, alpha, mu0, x1 = log(mu1 - mu0),
 // log sigma0, log sigma1].  Site pass: part[0] = ll, [1..5] d/d beta, [6..10] d/d alpha, [11..14] d/d (mu0, mu1, log sigma0, log sigma1).
@@ -1055,6 +1151,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel gm
             else if (m.kind == 3) bl_nmix_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
             else if (m.kind == 4) bl_rn_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
             else if (m.kind == 5) bl_rn_re_site_pass<MK, true>(m, rows, ns, rv, z, g, part, &gphi);
+            else if (m.kind == 6) bl_cop_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
             else bl_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
             bl_re_effect_squares(m, z, ss);
 #pragma unroll
@@ -1173,6 +1270,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
             else if constexpr (KIND == 3) bl_nmix_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
             else if constexpr (KIND == 4) bl_rn_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
             else if constexpr (KIND == 5) bl_rn_re_site_pass<MK, true>(m, rows, rows_ns, rows_rv, z, g, part, &gphi);
+            else if constexpr (KIND == 6) bl_cop_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
             else bl_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
             BL_RE_T(8)
             bl_re_effect_squares(m, z, ss);

@@ -207,8 +207,19 @@ class OccuDataset:
             if Dur.shape != (N, T, J):
                 raise ValueError("session_duration must have shape (n_sites, n_periods, n_replicates)")
             mode = {None: 0, "constant": _ffi.FP_CONSTANT, "unoccupied": _ffi.FP_UNOCCUPIED}[fp_mode]
-            _ffi.check(lib.bl_dataset_create_cop(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), _fp(Dur), mode,
-                                                 float(prior_fp_rate), C.byref(pb), C.byref(pa), device, C.byref(h)))
+            if site_random_effects or obs_random_effects:
+                # theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_occ[N], site_re_det[N]), (obs_re[N][T][J])]
+                if fp_mode is not None:
+                    raise NotImplementedError("occu_cop: random effects together with a false-positive rate are not built")
+                _ffi.check(lib.bl_dataset_create_cop_re(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), _fp(Dur), int(bool(site_random_effects)),
+                                                        int(bool(obs_random_effects)), float(prior_site_re_sd), float(prior_obs_re_sd),
+                                                        C.byref(pb), C.byref(pa), device, C.byref(h)))
+                d = C.c_int()
+                _ffi.check(lib.bl_dataset_param_dim(h, C.byref(d)))
+                self.D = int(d.value)
+            else:
+                _ffi.check(lib.bl_dataset_create_cop(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), _fp(Dur), mode,
+                                                     float(prior_fp_rate), C.byref(pb), C.byref(pa), device, C.byref(h)))
         elif model == "occu_cs":
             # obs holds the scores; theta = [beta, alpha, mu0, log(mu1 - mu0), log sigma0, log sigma1]
             pm = np.ascontiguousarray(np.asarray(prior_mu, dtype=np.float64).reshape(4))

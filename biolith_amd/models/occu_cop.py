@@ -12,7 +12,7 @@ from typing import Any
 
 import numpy as np
 
-from ..distributions import Exponential, HalfNormal, Normal, as_exponential, as_normal
+from ..distributions import Exponential, HalfNormal, Normal, as_exponential, as_half_normal, as_normal
 from ..regression import LinearRegression
 from ._generators import Generator, expit, observed_mean, within
 from .occu import OccuSpec
@@ -46,9 +46,9 @@ def occu_cop(
     """Count occupancy model with a Poisson detection process on the HIP engine (parameters: occu_cop.py:17-39).
 
     Built: linear regressors, Normal priors, ``false_positives_constant`` / ``false_positives_unoccupied`` with an
-    Exponential prior on the rate, no spatial / random effects; one species when a false-positive rate is
-    sampled (it is shared across species, occu_cop.py:158-170).  Everything else
-    raises ``NotImplementedError``.
+    Exponential prior on the rate, no spatial effect; one species when a false-positive rate is sampled (it is shared across species,
+    occu_cop.py:158-170); ``site_random_effects`` / ``obs_random_effects`` (occu_cop.py:183-186, 204-210, 229-243) on the random-effects
+    kernels, one species, not together with a false-positive rate.  Everything else raises ``NotImplementedError``.
 
     Examples
     --------
@@ -89,8 +89,10 @@ def occu_cop(
     unsupported = []
     if coords is not None:
         unsupported.append("coords (spatial HSGP effect, occu_cop.py:172-180)")
-    if site_random_effects or obs_random_effects:
-        unsupported.append("random effects (occu_cop.py:183-186)")
+    if (site_random_effects or obs_random_effects) and obs is not None and n_species > 1:
+        unsupported.append("random effects with several species (the sds are shared across the species plate, occu_cop.py:183-186)")
+    if (site_random_effects or obs_random_effects) and fp_mode is not None:
+        unsupported.append("random effects together with a false-positive rate")
     if regressor_occ is not LinearRegression or regressor_det is not LinearRegression:
         unsupported.append("non-linear regressors (occu_cop.py:199-200)")
     if obs is None:
@@ -104,6 +106,10 @@ def occu_cop(
     spec = OccuSpec(site_covs, obs_covs, obs, n_species, as_normal(prior_beta, "prior_beta"),
                     as_normal(prior_alpha, "prior_alpha"), model="occu_cop")
     spec.extras.update(session_duration=session_duration, fp_mode=fp_mode)
+    if site_random_effects or obs_random_effects:   # occu_cop.py:183-186, 204-210, 229-243: on the random-effects kernels
+        spec.extras.update(site_random_effects=bool(site_random_effects), obs_random_effects=bool(obs_random_effects),
+                           prior_site_re_sd=as_half_normal(prior_site_re_sd, "prior_site_re_sd"),
+                           prior_obs_re_sd=as_half_normal(prior_obs_re_sd, "prior_obs_re_sd"))
     if fp_mode is not None:
         prior = prior_rate_fp_constant if fp_mode == "constant" else prior_rate_fp_unoccupied
         spec.extras["prior_fp_rate"] = as_exponential(prior, f"prior_rate_fp_{fp_mode}")

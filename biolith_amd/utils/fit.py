@@ -281,7 +281,7 @@ def engine_options(spec) -> dict:
         opts.update({k: spec.extras[k] for k in ("site_random_effects", "obs_random_effects", "prior_site_re_sd", "prior_obs_re_sd")})
         if spec.extras.get("re_fp_mode") is not None:
             opts.update(re_fp_mode=spec.extras["re_fp_mode"], prior_fp=spec.extras["prior_fp"])
-    if spec.model in ("nmixture", "occu_rn") and "site_random_effects" in spec.extras:
+    if spec.model in ("nmixture", "occu_rn", "occu_cop") and "site_random_effects" in spec.extras:
         opts.update({k: spec.extras[k] for k in ("site_random_effects", "obs_random_effects", "prior_site_re_sd", "prior_obs_re_sd")})
         if spec.extras.get("re_fp_mode") is not None:   # occu_rn with a false-positive rate
             opts.update(re_fp_mode=spec.extras["re_fp_mode"], prior_fp=spec.extras["prior_fp"])
@@ -348,7 +348,7 @@ def _assemble(per_species, spec, num_warmup, joint_result=None) -> HipMCMC:
         latent["mu0"] = e[..., 0].astype(np.float32)
         latent["mu1"] = (e[..., 0] + np.exp(e[..., 1])).astype(np.float32)
         latent["sigma0"], latent["sigma1"] = np.exp(e[..., 2]).astype(np.float32), np.exp(e[..., 3]).astype(np.float32)
-    if spec.model == "occu_re" or (spec.model in ("nmixture", "occu_rn") and "site_random_effects" in spec.extras):
+    if spec.model == "occu_re" or (spec.model in ("nmixture", "occu_rn", "occu_cop") and "site_random_effects" in spec.extras):
         # theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_occ[N], site_re_det[N]), (obs_re[N][T][J])]; the
         # model's sites are the sds themselves, the effects with the species plate last (occu.py:170-173, 191-196, 215-218)
         N, T, J = ds0.N, ds0.T, ds0.J

@@ -103,7 +103,7 @@ def predict(
 
     def re_block(sp):
         """The random-effects coordinates of species ``sp`` in the engine's one-species layout (see fit._assemble)."""
-        if spec.model != "occu_re" and not (spec.model in ("occu_rn", "nmixture") and "site_random_effects" in spec.extras):
+        if spec.model != "occu_re" and not (spec.model in ("occu_rn", "nmixture", "occu_cop") and "site_random_effects" in spec.extras):
             return None
         cols = []
         if spec.extras["site_random_effects"]:

@@ -61,6 +61,7 @@ def lib():
             L.orc_data_set_re_fp.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_nmix_re.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_rn_re.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
+            L.orc_data_set_cop_re.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_rn_fp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
             L.orc_data_set_prior_family.argtypes = [C.c_void_p, C.c_int, C.c_int]
             L.orc_data_set_cs.argtypes = [C.c_void_p, dp, dp, dp]
@@ -156,6 +157,11 @@ class OracleData:
             lib().orc_data_set_cop(self._h, _dp(Y), _dp(Dur), {None: 0, "constant": 1, "unoccupied": 2}[fp_mode],
                                    float(prior_fp_rate))
             self.D += 1 if fp_mode else 0
+            if site_random_effects or obs_random_effects:   # occu_cop.py:183-186, 204-210, 229-243
+                assert fp_mode is None
+                lib().orc_data_set_cop_re(self._h, int(bool(site_random_effects)), int(bool(obs_random_effects)),
+                                          float(prior_site_re_sd), float(prior_obs_re_sd))
+                self.D = int(lib().orc_data_dim(self._h))
         self.fp_mode, self.prior_fp, self.prior_fp_rate = fp_mode, tuple(prior_fp), float(prior_fp_rate)
         if model == "occu_cs":
             # theta = [beta, alpha, mu0, log(mu1 - mu0), log sigma0, log sigma1]; obs holds the scores
@@ -465,7 +471,8 @@ def literal_log_joint_fp(theta, site_covs, obs_covs, obs, fp_mode="constant", pr
 
 
 def literal_log_joint_cop(theta, site_covs, obs_covs, obs, session_duration, fp_mode=None, prior_fp_rate=1.0,
-                          prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):
+                          prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0),
+                          site_random_effects=False, obs_random_effects=False, prior_site_re_sd=1.0, prior_obs_re_sd=1.0):
     """log density of the count occupancy model (biolith/models/occu_cop.py:150-255) in NumPyro's unconstrained
     space, z summed by brute force: theta = [beta, alpha (, phi = log rate_fp)]."""
     from scipy.special import gammaln, xlogy
@@ -478,11 +485,38 @@ def literal_log_joint_cop(theta, site_covs, obs_covs, obs, session_duration, fp_
     beta, alpha = theta[: Ks + 1], theta[Ks + 1: Ks + Ko + 2]
     f = np.exp(theta[-1]) if fp_mode else 0.0
     f_c, f_u = (f if fp_mode == "constant" else 0.0), (f if fp_mode == "unoccupied" else 0.0)
+    # random effects (occu_cop.py:183-186, 204-210, 229-243; not together with a false-positive rate here):
+    # theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_occ[N], site_re_det[N]), (obs_re[N][T][J])]
+    N_, T_, J_ = Y.shape
+    at, lp_re = Ks + Ko + 2, 0.0
+    re_occ = re_det = np.zeros(N_)
+    obs_re = np.zeros((N_, T_, J_))
+    if site_random_effects or obs_random_effects:
+        assert not fp_mode
+
+        def half_normal_on_log_scale(phi, scale):
+            return 0.5 * np.log(2.0 / np.pi) - np.log(scale) - 0.5 * (np.exp(phi) / scale) ** 2 + phi
+
+        def normal0(v, sd):
+            return (-0.5 * (v / sd) ** 2 - np.log(sd) - 0.5 * np.log(2 * np.pi)).sum()
+
+        sd_s = sd_o = None
+        if site_random_effects:
+            lp_re += half_normal_on_log_scale(theta[at], prior_site_re_sd); sd_s = np.exp(theta[at]); at += 1
+        if obs_random_effects:
+            lp_re += half_normal_on_log_scale(theta[at], prior_obs_re_sd); sd_o = np.exp(theta[at]); at += 1
+        if site_random_effects:
+            re_occ, re_det = theta[at: at + N_], theta[at + N_: at + 2 * N_]; at += 2 * N_
+            lp_re += normal0(re_occ, sd_s) + normal0(re_det, sd_s)
+        if obs_random_effects:
+            obs_re = theta[at: at + N_ * T_ * J_].reshape(N_, T_, J_); at += N_ * T_ * J_
+            lp_re += normal0(obs_re, sd_o)
+        assert at == theta.size
     obs_mask = np.isnan(W).any(-1) | np.isnan(X).any(-1)[:, None, None]     # occu_cop.py:150-156
     Y = np.where(obs_mask, np.nan, Y)
     W, X = np.nan_to_num(W), np.nan_to_num(X)
-    psi = 1.0 / (1.0 + np.exp(-(beta[0] + X @ beta[1:])))                   # occu_cop.py:222-227
-    rate_detection = np.exp(alpha[0] + np.tensordot(W, alpha[1:], axes=([3], [0])))   # occu_cop.py:236-243
+    psi = 1.0 / (1.0 + np.exp(-(beta[0] + X @ beta[1:] + re_occ)))          # occu_cop.py:222-227
+    rate_detection = np.exp(alpha[0] + np.tensordot(W, alpha[1:], axes=([3], [0])) + re_det[:, None, None] + obs_re)   # occu_cop.py:236-243
     finite = np.isfinite(Y)
     y0 = np.where(finite, Y, 0.0)
     per_z = []
@@ -498,7 +532,7 @@ def literal_log_joint_cop(theta, site_covs, obs_covs, obs, session_duration, fp_
     def normal_logpdf(v, loc, scale):
         return (-0.5 * ((v - loc) / scale) ** 2 - np.log(scale) - 0.5 * np.log(2 * np.pi)).sum()
 
-    out = ll + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
+    out = ll + lp_re + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
     if fp_mode:
         out += np.log(prior_fp_rate) - prior_fp_rate * f + theta[-1]       # Exponential log-pdf + log|d f / d phi|
     return out

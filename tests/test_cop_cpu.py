@@ -50,6 +50,28 @@ def test_cop_potential_equals_literal_model_and_fd(name, mode, rate):
         assert np.max(np.abs(fd - G)) <= 1e-7 * max(1.0, np.max(np.abs(G)))
 
 
+@pytest.mark.parametrize("name,site,obs", [("cop_small_2x2", True, False), ("cop_small_2x2", False, True), ("cop_missing", True, True)])
+def test_cop_re_potential_equals_literal_model_and_fd(name, site, obs):
+    """Random effects (occu_cop.py:183-186, 204-210, 229-243): the oracle against the literal model and central differences."""
+    g = load_golden(name)
+    kw = dict(site_random_effects=site, obs_random_effects=obs, prior_site_re_sd=0.8, prior_obs_re_sd=1.2)
+    od = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], (0.2, 1.5), (-0.1, 0.7), model="occu_cop",
+                           session_duration=g["session_duration"], fp_mode=None, **kw)
+    N, T, J = g["obs"].shape[1:]
+    G = od.Ks + od.Ko + 2
+    assert od.D == G + site * (1 + 2 * N) + obs * (1 + N * T * J)
+    rng = np.random.default_rng(5)
+    th = rng.uniform(-0.8, 0.8, size=od.D)
+    U, grad = od.potential_grad(th)
+    lit = oracle.literal_log_joint_cop(th, g["site_covs"], g["obs_covs"], g["obs"], g["session_duration"], prior_beta=(0.2, 1.5),
+                                       prior_alpha=(-0.1, 0.7), **kw)
+    assert abs(U + lit) <= 1e-10 * abs(U)
+    h = 1e-6
+    idx = np.unique(np.concatenate([np.arange(min(G + 2, od.D)), rng.integers(0, od.D, size=12)]))
+    fd = np.array([(od.potential_grad(th + h * e)[0] - od.potential_grad(th - h * e)[0]) / (2 * h) for e in np.eye(od.D)[idx]])
+    assert np.max(np.abs(fd - grad[idx])) <= 1e-6 * max(1.0, np.max(np.abs(grad)))
+
+
 def test_cop_detection_at_an_unoccupied_site_is_impossible_without_false_positives():
     # Poisson(0) puts no mass on y > 0 (numpyro: xlogy(y, 0) = -inf): a site-period with any count is occupied for sure
     g = load_golden("cop_default")
@@ -77,9 +99,12 @@ def test_occu_cop_validates_like_reference():
         occu_cop(g["site_covs"], g["obs_covs"], obs=g["obs"], session_duration=g["session_duration"][:10])
     with pytest.raises(NotImplementedError, match="Exponential"):
         occu_cop(**kw, false_positives_constant=True, prior_rate_fp_constant=Normal())
-    for bad in (dict(coords=np.zeros((80, 2))), dict(site_random_effects=True), dict(obs_random_effects=True)):
-        with pytest.raises(NotImplementedError):
-            occu_cop(**kw, **bad)
+    with pytest.raises(NotImplementedError):
+        occu_cop(**kw, coords=np.zeros((80, 2)))
+    re = occu_cop(**kw, site_random_effects=True)   # occu_cop.py:183-186
+    assert re.extras["site_random_effects"] and not re.extras["obs_random_effects"] and re.extras["prior_site_re_sd"] == 1.0
+    with pytest.raises(NotImplementedError, match="together with a false-positive rate"):
+        occu_cop(**kw, obs_random_effects=True, false_positives_unoccupied=True)
     with pytest.raises(NotImplementedError, match="shared across species"):
         occu_cop(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]), session_duration=g["session_duration"],
                  false_positives_constant=True)
