@@ -113,7 +113,7 @@ def load():
         L.bl_dataset_create_rn_re.argtypes = L.bl_dataset_create_nmix_re.argtypes
         L.bl_dataset_create_rn_fp.argtypes = [C.POINTER(bl_dims), fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                               C.POINTER(bl_beta_prior), C.POINTER(bl_normal_prior), C.POINTER(bl_normal_prior), C.c_int, C.POINTER(vp)]
-        L.bl_dataset_create_cop_re.argtypes = [C.POINTER(bl_dims), fp, fp, fp, fp, C.c_int, C.c_int, C.c_double, C.c_double,
+        L.bl_dataset_create_cop_re.argtypes = [C.POINTER(bl_dims), fp, fp, fp, fp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double,
                                                C.POINTER(bl_normal_prior), C.POINTER(bl_normal_prior), C.c_int, C.POINTER(vp)]
         L.bl_dataset_create_cs.argtypes = [C.POINTER(bl_dims), fp, fp, fp, dp, dp, C.POINTER(bl_normal_prior),
                                            C.POINTER(bl_normal_prior), C.c_int, C.POINTER(vp)]

@@ -333,7 +333,7 @@ extern "C" int bl_predict(bl_dataset *ds, int n_draws, const float *draws, uint6
         return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: the count models (occu_cop, nmixture) use bl_predict_counts");
     if (ds->model == 6 && ds->re.kind == 1)
         return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: not built for occu_cs (its observed site is a continuous score)");
-    if (ds->model == 6 && (ds->re.kind == 3 || ds->re.kind == 6))
+    if (ds->model == 6 && (ds->re.kind == 3 || ds->re.kind >= 6))
         return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict: the count models' sampled sites are counts (bl_predict_counts)");
     if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
     int rc = set_device(ds);
@@ -478,7 +478,7 @@ __global__ void bl_predict_counts_kernel(const float *__restrict__ rows, const f
                                          int n_stride, int N, int T, int J, int Ks, int Ko, int D,
                                          const float *__restrict__ draws, int n0, int n1, unsigned long long seed, int model,
                                          int max_abundance, int fp_mode, int *__restrict__ latent, int *__restrict__ y,
-                                         int o_u, int o_v, int o_e)
+                                         int o_u, int o_v, int o_e, int o_fp)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -490,7 +490,7 @@ __global__ void bl_predict_counts_kernel(const float *__restrict__ rows, const f
         float eta = th[0];
         for (int k = 0; k < Ks; k++) eta = fmaf(x[k], th[k + 1], eta);
         if (o_u >= 0) eta += th[o_u + i]; // random effects (offsets into a draw, -1 = absent): nmixture.py:166-172, 199-214
-        const float f = (model == 3 && fp_mode) ? __expf(th[D - 1]) : 0.0f;
+        const float f = (model == 3 && fp_mode) ? __expf(th[o_fp]) : 0.0f; // (the last coordinate, or right behind the coefficients with random effects)
         const float f_c = fp_mode == BL_FP_CONSTANT ? f : 0.0f, f_u = fp_mode == BL_FP_UNOCCUPIED ? f : 0.0f;
         for (int t = 0; t < T; t++) {
             BlPredRng rng(seed, ((unsigned long long)n * T + t) * N + i);
@@ -537,7 +537,7 @@ extern "C" int bl_predict_counts(bl_dataset *ds, int n_draws, const float *draws
 {
     if (!ds || !draws || n_draws <= 0 || (!latent && !y)) return bl_fail(BL_ERR_INVALID, "bl_predict_counts: bad argument");
     const bool nmix_re = ds->model == 6 && ds->re.kind == 3; // the N-mixture model with random effects
-    const bool cop_re = ds->model == 6 && ds->re.kind == 6;  // occu_cop with random effects
+    const bool cop_re = ds->model == 6 && ds->re.kind >= 6;  // occu_cop with random effects (and a false-positive rate: kind 7)
     if (ds->model != 3 && ds->model != 4 && !nmix_re && !cop_re)
         return bl_fail(BL_ERR_UNSUPPORTED, "bl_predict_counts: for the count models (occu_cop, nmixture); use bl_predict");
     if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
@@ -569,7 +569,8 @@ extern "C" int bl_predict_counts(bl_dataset *ds, int n_draws, const float *draws
         const dim3 grid((N + 255) / 256, (n1 - n0) < 1024 ? (n1 - n0) : 1024);
         hipLaunchKernelGGL(bl_predict_counts_kernel, grid, block, 0, nullptr, ds->d_rows, ds->d_wraw, ds->d_dur, ds->n_stride, N, T, J,
                            ds->Ks, ds->Ko, D, d_draws, n0, n1, (unsigned long long)seed, nmix_re ? 4 : (cop_re ? 3 : ds->model), ds->max_abundance, ds->fp_mode,
-                           d_lat, d_y, (nmix_re || cop_re) ? ds->re.o_u : -1, (nmix_re || cop_re) ? ds->re.o_v : -1, (nmix_re || cop_re) ? ds->re.o_e : -1);
+                           d_lat, d_y, (nmix_re || cop_re) ? ds->re.o_u : -1, (nmix_re || cop_re) ? ds->re.o_v : -1, (nmix_re || cop_re) ? ds->re.o_e : -1,
+                           cop_re && ds->fp_mode ? ds->re.o_fp : D - 1);
         BL_HIP(hipGetLastError());
         if (latent) BL_HIP(hipMemcpy(latent + (size_t)n0 * T * N, d_lat, (size_t)(n1 - n0) * T * N * 4, hipMemcpyDeviceToHost));
         if (y) BL_HIP(hipMemcpy(y + (size_t)n0 * J * T * N, d_y, (size_t)(n1 - n0) * J * T * N * 4, hipMemcpyDeviceToHost));
@@ -1050,6 +1051,7 @@ static hipError_t re_nuts_dispatch(int mk, const BlReRun &run, int grid, size_t 
     if (run.m.kind == 4) return mk == 4 ? re_nuts_dispatch_lds<4, 4>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 4>(run, grid, lds, st);
     if (run.m.kind == 5) return mk == 4 ? re_nuts_dispatch_lds<4, 5>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 5>(run, grid, lds, st);
     if (run.m.kind == 6) return mk == 4 ? re_nuts_dispatch_lds<4, 6>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 6>(run, grid, lds, st);
+    if (run.m.kind == 7) return mk == 4 ? re_nuts_dispatch_lds<4, 7>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 7>(run, grid, lds, st);
     if (mk == 4) return run.m.kind == 1 ? re_nuts_dispatch_lds<4, 1>(run, grid, lds, st) : re_nuts_dispatch_lds<4, 0>(run, grid, lds, st);
     return run.m.kind == 1 ? re_nuts_dispatch_lds<16, 1>(run, grid, lds, st) : re_nuts_dispatch_lds<16, 0>(run, grid, lds, st);
 }
@@ -1094,20 +1096,23 @@ static int create_re_impl(const bl_dims *dims, const float *site_covs, const flo
                           const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
 static thread_local const float *cop_session_duration = nullptr; // (occu_cop with random effects: handed to create_re_impl's packer call)
 
-// occu_cop(site_random_effects / obs_random_effects = True): occu_cop.py:183-186, 204-210, 229-243.  theta = [beta, alpha, (log sds),
-// site_re_occ [N], site_re_det [N], obs_re [N][T][J]]; `counts` / `session_duration` as bl_dataset_create_cop; no false-positive
-// rates together with the effects; one species.
+// occu_cop(site_random_effects / obs_random_effects = True [, false_positives_constant / _unoccupied = True]): occu_cop.py:158-170,
+// 183-186, 204-210, 229-248.  theta = [beta, alpha, (phi = log rate_fp), (log sds), site_re_occ [N], site_re_det [N], obs_re [N][T][J]];
+// `counts` / `session_duration` / fp_mode / prior_fp_rate as bl_dataset_create_cop; one species.
 extern "C" int bl_dataset_create_cop_re(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *counts,
-                                        const float *session_duration, int site_random_effects, int obs_random_effects,
-                                        double prior_site_re_sd_scale, double prior_obs_re_sd_scale, const bl_normal_prior *prior_beta,
-                                        const bl_normal_prior *prior_alpha, int device, bl_dataset **out)
+                                        const float *session_duration, int fp_mode, double prior_fp_rate, int site_random_effects,
+                                        int obs_random_effects, double prior_site_re_sd_scale, double prior_obs_re_sd_scale,
+                                        const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha, int device, bl_dataset **out)
 {
+    if (fp_mode != 0 && fp_mode != BL_FP_CONSTANT && fp_mode != BL_FP_UNOCCUPIED)
+        return bl_fail(BL_ERR_INVALID, "fp_mode must be 0, BL_FP_CONSTANT or BL_FP_UNOCCUPIED");
+    if (fp_mode && (!(prior_fp_rate > 0.0) || !std::isfinite(prior_fp_rate))) return bl_fail(BL_ERR_INVALID, "Exponential prior needs a finite rate > 0");
     if (!session_duration) return bl_fail(BL_ERR_INVALID, "session_duration is NULL");
     if (dims && dims->n_species != 1)
         return bl_fail(BL_ERR_UNSUPPORTED, "occu_cop with random effects: one species per dataset (n_species=%d)", dims->n_species);
     cop_session_duration = session_duration;
     const int rc = create_re_impl(dims, site_covs, obs_covs, counts, site_random_effects, obs_random_effects, prior_site_re_sd_scale,
-                                  prior_obs_re_sd_scale, 0, 0.0, 0.0, 3, 0, prior_beta, prior_alpha, device, out);
+                                  prior_obs_re_sd_scale, fp_mode, fp_mode ? prior_fp_rate : 1.0, 0.0, 3, 0, prior_beta, prior_alpha, device, out);
     cop_session_duration = nullptr;
     return rc;
 }
@@ -1206,7 +1211,7 @@ static int create_re_impl(const bl_dims *dims, const float *site_covs, const flo
     // (N-mixture: the count model's rows -- visit = (m y, m, w..) -- and its table of log-binomial sums)
     ModelOpts mo; mo.vector_kernels = true;
     if (count_model) { mo.model = count_model; mo.max_abundance = count_K; } // 4: N-mixture, 1: Royle-Nichols, 3: occu_cop (no false positives)
-    if (count_model == 3) { mo.fp_mode = 0; mo.fp_a = 1.0; mo.session_duration = cop_session_duration; }
+    if (count_model == 3) { mo.fp_mode = fp_mode; mo.fp_a = fp_mode ? fp_a : 1.0; mo.session_duration = cop_session_duration; } // (fp_a: the Exponential prior's rate)
     int rc = dataset_create_impl(mo, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
     if (rc) return rc;
     bl_dataset *ds = *out;
@@ -1220,7 +1225,7 @@ static int create_re_impl(const bl_dims *dims, const float *site_covs, const flo
     m.n_species = S; m.G0s = Ks + Ko + 2; m.sp = 0; m.cb = 0; m.rv0 = ds->KS; m.sp_rows = T * J * (ds->KO + 1 + (count_model ? 1 : 0)) + 2 * T;
     m.G0 = S * m.G0s; m.G = m.G0 + (fp_mode ? 1 : 0) + m.site_re + m.obs_re; m.D = (int)Dll;
     int at = m.G0;
-    m.kind = count_model == 4 ? 3 : (count_model == 1 ? (fp_mode ? 5 : 4) : (count_model == 3 ? 6 : (fp_mode ? 2 : 0))); m.fp_mode = fp_mode; m.fp_a = (float)fp_a; m.fp_b = (float)fp_b;
+    m.kind = count_model == 4 ? 3 : (count_model == 1 ? (fp_mode ? 5 : 4) : (count_model == 3 ? (fp_mode ? 7 : 6) : (fp_mode ? 2 : 0))); m.fp_mode = fp_mode; m.fp_a = (float)fp_a; m.fp_b = (float)fp_b;
     m.tab = ds->d_tab; m.tab_ld = ds->n_stride; m.max_abundance = count_K;
     m.o_fp = fp_mode ? at++ : -1;       // phi = logit(false-positive rate): right behind the regression coefficients
     m.o_phi_s = m.site_re ? at++ : -1;
@@ -1234,7 +1239,7 @@ static int create_re_impl(const bl_dims *dims, const float *site_covs, const flo
     m.hn_is2_o = obs_random_effects ? (float)(1.0 / (prior_obs_re_sd_scale * prior_obs_re_sd_scale)) : 0.0f;
     const double HL2PI = 0.91893853320467274178, HN0 = 0.5 * std::log(2.0 / 3.14159265358979323846);
     m.u_const = ds->dd.prior_const;
-    if (fp_mode) m.u_const += std::lgamma(fp_a) + std::lgamma(fp_b) - std::lgamma(fp_a + fp_b); // + log B(a, b)
+    if (fp_mode && count_model != 3) m.u_const += std::lgamma(fp_a) + std::lgamma(fp_b) - std::lgamma(fp_a + fp_b); // + log B(a, b)  (occu_cop: -log rate is in prior_const)
     if (m.site_re) m.u_const += -HN0 + std::log(prior_site_re_sd_scale) + 2.0 * S * N * HL2PI;
     if (m.obs_re) m.u_const += -HN0 + std::log(prior_obs_re_sd_scale) + (double)S * N * T * J * HL2PI;
     m.n_total = N; m.s0 = 0; m.x_u = m.o_u; m.x_v = m.o_v; m.x_e = m.o_e;
@@ -1857,7 +1862,7 @@ extern "C" int bl_deterministic(bl_dataset *ds, int n_draws, const float *draws,
         }
         if (prob_detection) {
             hipLaunchKernelGGL(bl_pdet_kernel, grid, block, 0, nullptr, ds->d_wraw, ds->n_stride, N, T, J, ds->Ks, ds->Ko, D, d_draws, n0, n1, d_out,
-                               ds->model == 6 && ds->re.kind == 6 ? 3 : ds->model /* occu_cop with effects: rate_detection = exp(nu) */,
+                               ds->model == 6 && ds->re.kind >= 6 ? 3 : ds->model /* occu_cop with effects: rate_detection = exp(nu) */,
                                ds->model == 6 ? ds->re.o_v : -1, ds->model == 6 ? ds->re.o_e : -1);
             BL_HIP(hipGetLastError());
             BL_HIP(hipMemcpy(prob_detection + (size_t)n0 * J * T * N, d_out, (size_t)(n1 - n0) * J * T * N * 4, hipMemcpyDeviceToHost));

@@ -808,9 +808,12 @@ __device__ __forceinline__ void bl_rn_re_site_pass(const BlReModel &m, const flo
 //   a = sum_j (y_j nu_j - dur_j e^nu_j),   l = log psi + a  if any count is positive (Poisson(0) gives it probability 0 at z = 0),
 //   else logaddexp(log psi + a, log(1 - psi));   q = P(z = 1 | y);   d l / d eta = q - psi,   d l / d nu_j = q (y_j - dur_j e^nu_j).
 // One thread per site (bl_eval_sites_cop's arithmetic without the false-positive terms).
-template <int MK>
+// FP (kind 7; occu_cop.py:158-170, 244-248): a false-positive rate f = e^phi (phi at z[m.o_fp]) on every site ("constant") or on the
+// unoccupied ones: rate_1 = dur (e^nu + f_c), rate_0 = dur (f_u + f_c); both branches are then live, y log dur - lgamma stays in the constant.
+template <int MK, bool FP = false>
 __device__ __forceinline__ void bl_cop_re_site_pass(const BlReModel &m, const float *__restrict__ rows, int ns, int rv,
-                                                    const float *__restrict__ z, float *__restrict__ g, float (&part)[2 * MK + 3])
+                                                    const float *__restrict__ z, float *__restrict__ g, float (&part)[2 * MK + 3],
+                                                    float *gphi = nullptr)
 {
     const int N = m.n_sites, T = m.T, J = m.J, Ks = m.Ks, Ko = m.Ko, vw = m.KO + 2, V = T * J;
     float beta[MK + 1], alpha[MK + 1];
@@ -822,6 +825,13 @@ __device__ __forceinline__ void bl_cop_re_site_pass(const BlReModel &m, const fl
     }
     const float isd2_s = m.site_re ? bl_exp(-2.0f * z[m.o_phi_s]) : 0.0f;
     const float isd2_o = m.obs_re ? bl_exp(-2.0f * z[m.o_phi_o]) : 0.0f;
+    float fr = 0.0f, f_c = 0.0f, f0 = 0.0f, lf0 = 0.0f, dfp = 0.0f; // the rate, its part on occupied sites, the unoccupied sites' rate and its log; d ll / d f
+    if constexpr (FP) {
+        fr = bl_exp(fminf(z[m.o_fp], 80.0f));
+        f_c = m.fp_mode == 1 ? fr : 0.0f;
+        f0 = fr; // (f_u + f_c: one of the two is the rate, the other 0)
+        lf0 = bl_log(f0);
+    }
 #pragma unroll
     for (int k = 0; k < 2 * MK + 3; k++) part[k] = 0.0f;
     for (int i = threadIdx.x; i < N; i += BL_RE_NT) {
@@ -840,7 +850,7 @@ __device__ __forceinline__ void bl_cop_re_site_pass(const BlReModel &m, const fl
         const float log_psi = fminf(eta, 0.0f) - le, log_1mpsi = -fmaxf(eta, 0.0f) - le;
         float dl_deta = 0.0f, dl_dv = 0.0f;
         for (int t = 0; t < T; t++) {
-            float a = 0.0f, gy[MK + 1], gd[MK + 1];
+            float a = 0.0f, df1 = 0.0f, gy[MK + 1], gd[MK + 1];
 #pragma unroll
             for (int k = 0; k <= MK; k++) { gy[k] = 0.0f; gd[k] = 0.0f; }
             for (int j = 0; j < J; j++) {
@@ -854,20 +864,32 @@ __device__ __forceinline__ void bl_cop_re_site_pass(const BlReModel &m, const fl
                     w[k] = k < Ko ? wk : 0.0f;
                     nu = fmaf(w[k], alpha[k + 1], nu);
                 }
-                const float rate = dur * bl_exp(fminf(nu, 80.0f));
-                a += fmaf(y, nu, -rate);
-                gy[0] += y; gd[0] += rate;
+                const float lam = bl_exp(fminf(nu, 80.0f)), rate = dur * lam;
+                if constexpr (!FP) {
+                    a += fmaf(y, nu, -rate);
+                    gy[0] += y; gd[0] += rate;
 #pragma unroll
-                for (int k = 0; k < MK; k++) { gy[k + 1] = fmaf(y, w[k], gy[k + 1]); gd[k + 1] = fmaf(rate, w[k], gd[k + 1]); }
+                    for (int k = 0; k < MK; k++) { gy[k + 1] = fmaf(y, w[k], gy[k + 1]); gd[k + 1] = fmaf(rate, w[k], gd[k + 1]); }
+                } else { // rate_1 = dur (lam + f_c):  d / d nu = (y / (lam + f_c) - dur) lam,  d / d f_c = y / (lam + f_c) - dur
+                    const float l1 = lam + f_c, il1 = bl_rcp(l1);
+                    a += fmaf(y, bl_log(l1), -dur * l1);
+                    const float yw = y * lam * il1; // (the weight y takes in the nu-gradient)
+                    gy[0] += yw; gd[0] += rate;
+#pragma unroll
+                    for (int k = 0; k < MK; k++) { gy[k + 1] = fmaf(yw, w[k], gy[k + 1]); gd[k + 1] = fmaf(rate, w[k], gd[k + 1]); }
+                    df1 += m.fp_mode == 1 ? fmaf(y, il1, -dur) : 0.0f;
+                }
             }
-            const float ka = rows[(rv + V * vw + t) * ns + i];
+            const float ka = rows[(rv + V * vw + t) * ns + i], kb = rows[(rv + V * vw + T + t) * ns + i]; // sum y, sum dur over the valid visits
             const float A = log_psi + a;
             float l = A, q = 1.0f;
-            if (!(ka > 0.0f)) { // no count at all: the unoccupied branch is possible
-                const float d = A - log_1mpsi, e = bl_exp(-fabsf(d)), op = 1.0f + e;
-                l = fmaxf(A, log_1mpsi) + bl_log(op);
+            if (FP || !(ka > 0.0f)) { // (no rate: the unoccupied branch is possible only with no count at all)
+                const float B = log_1mpsi + (FP ? fmaf(ka, lf0, -kb * f0) : 0.0f);
+                const float d = A - B, e = bl_exp(-fabsf(d)), op = 1.0f + e;
+                l = fmaxf(A, B) + bl_log(op);
                 q = (d > 0.0f ? 1.0f : e) * bl_rcp(op);
             }
+            if constexpr (FP) dfp += q * df1 + (1.0f - q) * (ka * bl_rcp(f0) - kb); // d a0 / d f = sum y / f0 - sum dur
             part[0] += l;
             dl_deta += q - psi;
 #pragma unroll
@@ -883,7 +905,8 @@ __device__ __forceinline__ void bl_cop_re_site_pass(const BlReModel &m, const fl
                         const float wk = rows[r0 + (2 + min(k, max(Ko, 1) - 1)) * ns];
                         nu = fmaf(k < Ko ? wk : 0.0f, alpha[k + 1], nu);
                     }
-                    g[m.o_e + v * N + i] = fmaf(ev, isd2_o, -q * (y - dur * bl_exp(fminf(nu, 80.0f))));
+                    const float lam = bl_exp(fminf(nu, 80.0f));
+                    g[m.o_e + v * N + i] = fmaf(ev, isd2_o, -q * (y * (FP ? lam * bl_rcp(lam + f_c) : 1.0f) - dur * lam));
                 }
             }
         }
@@ -895,6 +918,7 @@ __device__ __forceinline__ void bl_cop_re_site_pass(const BlReModel &m, const fl
             g[m.o_v + i] = fmaf(vi, isd2_s, -dl_dv);
         }
     }
+    if constexpr (FP) *gphi = dfp * fr; // (d f / d phi = f)
 }
 
 // ---- occu_cs (biolith/models/occu_cs.py:120-232): s ~ Normal(mu_f, sigma_f), f ~ Bernoulli(z p), z ~ Bernoulli(psi); z and every
@@ -1056,6 +1080,8 @@ __device__ __forceinline__ float bl_re_global_grad(const BlReModel &m, int d, fl
         return (float)(-gl) + fmaf(dth, isc2, dth > 0.0f ? l1 : (dth < 0.0f ? -l1 : 0.0f));
     }
     if (m.kind == 1) return 0.0f; // (occu_cs: its four extra coordinates are handled by bl_cs_extra_grad)
+    if (FP && d == m.o_fp && m.kind == 7) // phi = log f, f ~ Exponential(rate = fp_a), Jacobian included: energy rate e^phi - phi
+        return (float)(-red[OX + 6]) + m.fp_a * bl_exp(fminf(zd, 80.0f)) - 1.0f;
     if (FP && d == m.o_fp) {
         // phi = logit f, f ~ Beta(a, b), Jacobian included: energy a softplus(-phi) + b softplus(phi); red[OX + 6] = d ll / d phi
         const float e = bl_exp(-fabsf(zd)), sig = (zd > 0.0f ? 1.0f : e) * bl_rcp(1.0f + e);
@@ -1076,7 +1102,8 @@ __device__ __forceinline__ double bl_re_potential(const BlReModel &m, const floa
     double U = -red[0] + 0.5 * pe2 + m.u_const;
     if constexpr (FP) {
         const double phi = z[m.o_fp], l = log1p(exp(-fabs(phi)));
-        U += m.fp_a * (fmax(-phi, 0.0) + l) + m.fp_b * (fmax(phi, 0.0) + l);
+        if (m.kind == 7) U += (double)m.fp_a * exp(fmin(phi, 80.0)) - phi; // (Exponential prior of occu_cop's rate; - log rate is in u_const)
+        else U += m.fp_a * (fmax(-phi, 0.0) + l) + m.fp_b * (fmax(phi, 0.0) + l);
     }
     if (m.site_re) {
         const float phi = z[m.o_phi_s];
@@ -1152,6 +1179,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel gm
             else if (m.kind == 4) bl_rn_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
             else if (m.kind == 5) bl_rn_re_site_pass<MK, true>(m, rows, ns, rv, z, g, part, &gphi);
             else if (m.kind == 6) bl_cop_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
+            else if (m.kind == 7) bl_cop_re_site_pass<MK, true>(m, rows, ns, rv, z, g, part, &gphi);
             else bl_re_site_pass<MK>(m, rows, ns, rv, z, g, part);
             bl_re_effect_squares(m, z, ss);
 #pragma unroll
@@ -1167,9 +1195,9 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel gm
         if (sp == S - 1) { // fixed effects of every species and the log sds, from the species' and the total sums
             for (int d = tid; d < m.G; d += BL_RE_NT)
                 grad[(size_t)b * gm.D + d] = (double)((m.kind == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red_tot)
-                                                      : ((m.kind == 2 || m.kind == 5) ? bl_re_global_grad<MK, true>(m, d, z[d], red_tot, red_sp, NRED)
+                                                      : ((m.kind == 2 || m.kind == 5 || m.kind == 7) ? bl_re_global_grad<MK, true>(m, d, z[d], red_tot, red_sp, NRED)
                                                                      : bl_re_global_grad<MK>(m, d, z[d], red_tot, red_sp, NRED)));
-            if (tid == 0) U[b] = ((m.kind == 2 || m.kind == 5) ? bl_re_potential<true>(m, z, red_tot, red_tot[OX + 2], OX) : bl_re_potential(m, z, red_tot, red_tot[OX + 2], OX))
+            if (tid == 0) U[b] = ((m.kind == 2 || m.kind == 5 || m.kind == 7) ? bl_re_potential<true>(m, z, red_tot, red_tot[OX + 2], OX) : bl_re_potential(m, z, red_tot, red_tot[OX + 2], OX))
                                  + (m.kind == 1 ? bl_cs_extra_potential(m, z) : 0.0);
         }
     }
@@ -1271,6 +1299,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
             else if constexpr (KIND == 4) bl_rn_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
             else if constexpr (KIND == 5) bl_rn_re_site_pass<MK, true>(m, rows, rows_ns, rows_rv, z, g, part, &gphi);
             else if constexpr (KIND == 6) bl_cop_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
+            else if constexpr (KIND == 7) bl_cop_re_site_pass<MK, true>(m, rows, rows_ns, rows_rv, z, g, part, &gphi);
             else bl_re_site_pass<MK>(m, rows, rows_ns, rows_rv, z, g, part);
             BL_RE_T(8)
             bl_re_effect_squares(m, z, ss);
@@ -1285,7 +1314,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
         v[OX + 4] = tid == 0 ? xcc : 0.0f; v[OX + 5] = tid == 0 ? xcc * xcc : 0.0f;
         BL_RE_T(0)
         ev_first = xc.epoch == 0u;
-        ev_nv = KIND == 1 ? NV1 : ((KIND == 2 || KIND == 5) ? OX + 7 : (ev_first ? OX + 6 : OX + 4));
+        ev_nv = KIND == 1 ? NV1 : ((KIND == 2 || KIND == 5 || KIND == 7) ? OX + 7 : (ev_first ? OX + 6 : OX + 4));
         bl_re_block_sum<NV1, NRED>(v, scr, red, ev_nv, xc.k == 1);
         BL_RE_T(9)
         bl_re_publish<NRED>(xc, red, ev_nv);
@@ -1300,8 +1329,8 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
         if (ev_first && R.allow_local) xc.local = ((double)R.k * red[OX + 5] == red[OX + 4] * red[OX + 4]); // exact: small integers
         if (red[OX + 3] > 0.0) flag = 5;
         for (int d = tid; d < G; d += BL_RE_NT)
-            g[d] = (KIND == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red) : bl_re_global_grad<MK, KIND == 2 || KIND == 5>(m, d, z[d], red, red_sp, NRED);
-        double U = bl_re_potential<KIND == 2 || KIND == 5>(m, z, red, red[OX + 2], OX);
+            g[d] = (KIND == 1 && d >= m.G0) ? bl_cs_extra_grad<MK>(m, d - m.G0, z, red) : bl_re_global_grad<MK, KIND == 2 || KIND == 5 || KIND == 7>(m, d, z[d], red, red_sp, NRED);
+        double U = bl_re_potential<KIND == 2 || KIND == 5 || KIND == 7>(m, z, red, red[OX + 2], OX);
         if constexpr (KIND == 1) U += bl_cs_extra_potential(m, z);
         BL_RE_T(1)
         return U;

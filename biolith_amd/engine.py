@@ -209,11 +209,10 @@ class OccuDataset:
             mode = {None: 0, "constant": _ffi.FP_CONSTANT, "unoccupied": _ffi.FP_UNOCCUPIED}[fp_mode]
             if site_random_effects or obs_random_effects:
                 # theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_occ[N], site_re_det[N]), (obs_re[N][T][J])]
-                if fp_mode is not None:
-                    raise NotImplementedError("occu_cop: random effects together with a false-positive rate are not built")
-                _ffi.check(lib.bl_dataset_create_cop_re(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), _fp(Dur), int(bool(site_random_effects)),
-                                                        int(bool(obs_random_effects)), float(prior_site_re_sd), float(prior_obs_re_sd),
-                                                        C.byref(pb), C.byref(pa), device, C.byref(h)))
+                # (+ phi = log rate_fp right behind the coefficients with a false-positive rate)
+                _ffi.check(lib.bl_dataset_create_cop_re(C.byref(self.dims), _fp(X), _fp(W), _fp(Y), _fp(Dur), mode, float(prior_fp_rate),
+                                                        int(bool(site_random_effects)), int(bool(obs_random_effects)),
+                                                        float(prior_site_re_sd), float(prior_obs_re_sd), C.byref(pb), C.byref(pa), device, C.byref(h)))
                 d = C.c_int()
                 _ffi.check(lib.bl_dataset_param_dim(h, C.byref(d)))
                 self.D = int(d.value)

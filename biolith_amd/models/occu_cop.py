@@ -48,7 +48,7 @@ def occu_cop(
     Built: linear regressors, Normal priors, ``false_positives_constant`` / ``false_positives_unoccupied`` with an
     Exponential prior on the rate, no spatial effect; one species when a false-positive rate is sampled (it is shared across species,
     occu_cop.py:158-170); ``site_random_effects`` / ``obs_random_effects`` (occu_cop.py:183-186, 204-210, 229-243) on the random-effects
-    kernels, one species, not together with a false-positive rate.  Everything else raises ``NotImplementedError``.
+    kernels, one species, with or without a false-positive rate.  Everything else raises ``NotImplementedError``.
 
     Examples
     --------
@@ -91,8 +91,6 @@ def occu_cop(
         unsupported.append("coords (spatial HSGP effect, occu_cop.py:172-180)")
     if (site_random_effects or obs_random_effects) and obs is not None and n_species > 1:
         unsupported.append("random effects with several species (the sds are shared across the species plate, occu_cop.py:183-186)")
-    if (site_random_effects or obs_random_effects) and fp_mode is not None:
-        unsupported.append("random effects together with a false-positive rate")
     if regressor_occ is not LinearRegression or regressor_det is not LinearRegression:
         unsupported.append("non-linear regressors (occu_cop.py:199-200)")
     if obs is None:

@@ -353,6 +353,8 @@ def _assemble(per_species, spec, num_warmup, joint_result=None) -> HipMCMC:
         # model's sites are the sds themselves, the effects with the species plate last (occu.py:170-173, 191-196, 215-218)
         N, T, J = ds0.N, ds0.T, ds0.J
         at = Ks + Ko + 2
+        if spec.model == "occu_cop" and spec.extras["fp_mode"] is not None:   # [beta, alpha, phi = log(rate), log sds, effects]: the rate was read above
+            at += 1
         if spec.extras.get("re_fp_mode") is not None:   # [beta, alpha, phi = logit(rate), log sds, effects]
             phi = res0.draws[:, :, at].astype(np.float64)
             latent[f"prob_fp_{spec.extras['re_fp_mode']}"] = (1.0 / (1.0 + np.exp(-phi))).astype(np.float32)

@@ -184,13 +184,14 @@ int bl_dataset_create_rn_fp(const bl_dims *dims, const float *site_covs, const f
                             double prior_site_re_sd_scale, double prior_obs_re_sd_scale, const bl_beta_prior *prior_fp,
                             const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
 /* occu_cop with the same random effects (biolith/models/occu_cop.py:183-186, 204-210, 229-243: site_re_occ joins the occupancy
- * predictor, site_re_det and obs_re the log detection rate): `counts` / `session_duration` as for bl_dataset_create_cop, theta laid
- * out as for bl_dataset_create_re, no false-positive rates together with the effects.  One species.  bl_deterministic returns psi and
- * rate_detection with the effects; bl_predict_counts draws z and the counts from them. */
+ * predictor, site_re_det and obs_re the log detection rate), with or without a false-positive rate (occu_cop.py:158-170, 244-248):
+ * `counts` / `session_duration` / fp_mode / prior_fp_rate as for bl_dataset_create_cop, theta = [beta, alpha, (phi = log rate_fp),
+ * (log sds), (effects)].  One species.  bl_deterministic returns psi and rate_detection with the effects; bl_predict_counts draws z
+ * and the counts from them. */
 int bl_dataset_create_cop_re(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *counts,
-                             const float *session_duration, int site_random_effects, int obs_random_effects,
-                             double prior_site_re_sd_scale, double prior_obs_re_sd_scale, const bl_normal_prior *prior_beta,
-                             const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
+                             const float *session_duration, int fp_mode, double prior_fp_rate, int site_random_effects,
+                             int obs_random_effects, double prior_site_re_sd_scale, double prior_obs_re_sd_scale,
+                             const bl_normal_prior *prior_beta, const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
 /*
  * The continuous-score occupancy model biolith.models.occu_cs (models/occu_cs.py:17-232; Rhinehart et al. 2022): `scores`
  * [S=1][N][T][J] (NaN = missing) ~ Normal(mu_f, sigma_f) with f ~ Bernoulli(z p) and z ~ Bernoulli(psi) summed out.

@@ -157,8 +157,7 @@ class OracleData:
             lib().orc_data_set_cop(self._h, _dp(Y), _dp(Dur), {None: 0, "constant": 1, "unoccupied": 2}[fp_mode],
                                    float(prior_fp_rate))
             self.D += 1 if fp_mode else 0
-            if site_random_effects or obs_random_effects:   # occu_cop.py:183-186, 204-210, 229-243
-                assert fp_mode is None
+            if site_random_effects or obs_random_effects:   # occu_cop.py:183-186, 204-210, 229-243 (a rate stays: [beta, alpha, phi, log sds, effects])
                 lib().orc_data_set_cop_re(self._h, int(bool(site_random_effects)), int(bool(obs_random_effects)),
                                           float(prior_site_re_sd), float(prior_obs_re_sd))
                 self.D = int(lib().orc_data_dim(self._h))
@@ -483,16 +482,16 @@ def literal_log_joint_cop(theta, site_covs, obs_covs, obs, session_duration, fp_
     Ks, Ko = X.shape[1], W.shape[-1]
     theta = np.asarray(theta, dtype=np.float64)
     beta, alpha = theta[: Ks + 1], theta[Ks + 1: Ks + Ko + 2]
-    f = np.exp(theta[-1]) if fp_mode else 0.0
+    i_fp = Ks + Ko + 2 if (site_random_effects or obs_random_effects) else -1   # (with random effects the rate sits right behind the coefficients)
+    f = np.exp(theta[i_fp]) if fp_mode else 0.0
     f_c, f_u = (f if fp_mode == "constant" else 0.0), (f if fp_mode == "unoccupied" else 0.0)
-    # random effects (occu_cop.py:183-186, 204-210, 229-243; not together with a false-positive rate here):
+    # random effects (occu_cop.py:183-186, 204-210, 229-243):
     # theta = [beta, alpha, (log site_re_sd), (log obs_re_sd), (site_re_occ[N], site_re_det[N]), (obs_re[N][T][J])]
     N_, T_, J_ = Y.shape
-    at, lp_re = Ks + Ko + 2, 0.0
+    at, lp_re = Ks + Ko + 2 + (1 if fp_mode else 0), 0.0
     re_occ = re_det = np.zeros(N_)
     obs_re = np.zeros((N_, T_, J_))
     if site_random_effects or obs_random_effects:
-        assert not fp_mode
 
         def half_normal_on_log_scale(phi, scale):
             return 0.5 * np.log(2.0 / np.pi) - np.log(scale) - 0.5 * (np.exp(phi) / scale) ** 2 + phi
@@ -534,7 +533,7 @@ def literal_log_joint_cop(theta, site_covs, obs_covs, obs, session_duration, fp_
 
     out = ll + lp_re + normal_logpdf(beta, *prior_beta) + normal_logpdf(alpha, *prior_alpha)
     if fp_mode:
-        out += np.log(prior_fp_rate) - prior_fp_rate * f + theta[-1]       # Exponential log-pdf + log|d f / d phi|
+        out += np.log(prior_fp_rate) - prior_fp_rate * f + theta[i_fp]     # Exponential log-pdf + log|d f / d phi|
     return out
 
 

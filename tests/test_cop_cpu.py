@@ -50,16 +50,18 @@ def test_cop_potential_equals_literal_model_and_fd(name, mode, rate):
         assert np.max(np.abs(fd - G)) <= 1e-7 * max(1.0, np.max(np.abs(G)))
 
 
-@pytest.mark.parametrize("name,site,obs", [("cop_small_2x2", True, False), ("cop_small_2x2", False, True), ("cop_missing", True, True)])
-def test_cop_re_potential_equals_literal_model_and_fd(name, site, obs):
-    """Random effects (occu_cop.py:183-186, 204-210, 229-243): the oracle against the literal model and central differences."""
+@pytest.mark.parametrize("name,site,obs,mode", [("cop_small_2x2", True, False, None), ("cop_small_2x2", False, True, "unoccupied"),
+                                                ("cop_missing", True, True, None), ("cop_missing", True, True, "constant")])
+def test_cop_re_potential_equals_literal_model_and_fd(name, site, obs, mode):
+    """Random effects (occu_cop.py:183-186, 204-210, 229-243), with and without a false-positive rate: the oracle against the literal
+    model and central differences; theta = [beta, alpha, (phi = log rate_fp), (log sds), (effects)]."""
     g = load_golden(name)
-    kw = dict(site_random_effects=site, obs_random_effects=obs, prior_site_re_sd=0.8, prior_obs_re_sd=1.2)
+    kw = dict(site_random_effects=site, obs_random_effects=obs, prior_site_re_sd=0.8, prior_obs_re_sd=1.2, fp_mode=mode, prior_fp_rate=2.0)
     od = oracle.OracleData(g["site_covs"], g["obs_covs"], g["obs"], (0.2, 1.5), (-0.1, 0.7), model="occu_cop",
-                           session_duration=g["session_duration"], fp_mode=None, **kw)
+                           session_duration=g["session_duration"], **kw)
     N, T, J = g["obs"].shape[1:]
     G = od.Ks + od.Ko + 2
-    assert od.D == G + site * (1 + 2 * N) + obs * (1 + N * T * J)
+    assert od.D == G + (mode is not None) + site * (1 + 2 * N) + obs * (1 + N * T * J)
     rng = np.random.default_rng(5)
     th = rng.uniform(-0.8, 0.8, size=od.D)
     U, grad = od.potential_grad(th)
@@ -103,8 +105,8 @@ def test_occu_cop_validates_like_reference():
         occu_cop(**kw, coords=np.zeros((80, 2)))
     re = occu_cop(**kw, site_random_effects=True)   # occu_cop.py:183-186
     assert re.extras["site_random_effects"] and not re.extras["obs_random_effects"] and re.extras["prior_site_re_sd"] == 1.0
-    with pytest.raises(NotImplementedError, match="together with a false-positive rate"):
-        occu_cop(**kw, obs_random_effects=True, false_positives_unoccupied=True)
+    both = occu_cop(**kw, obs_random_effects=True, false_positives_unoccupied=True)   # (what the reference's own random-effects tests fit)
+    assert both.extras["fp_mode"] == "unoccupied" and both.extras["obs_random_effects"]
     with pytest.raises(NotImplementedError, match="shared across species"):
         occu_cop(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]), session_duration=g["session_duration"],
                  false_positives_constant=True)

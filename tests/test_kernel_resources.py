@@ -78,4 +78,4 @@ def test_vector_kernels_leave_the_lds_budget(tmp_path_factory):
             if "Lb1ELi2EE" in name and "ILi4ELi2E" not in name:   # the form the bench sizes run: rows and every per-leapfrog vector in LDS
                 assert scratch == 0, (name, scratch)
         seen += 1
-    assert seen >= 86   # 2 capacities x 7 kinds x 2 x 3 LDS forms of the sampler + 2 parity kernels
+    assert seen >= 98   # 2 capacities x 8 kinds x 2 x 3 LDS forms of the sampler + 2 parity kernels
