@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 CFG2 = dict(n_sites=10000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=35, session_duration=7, random_seed=0)
 CFG4 = dict(n_sites=5000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7, random_seed=0)
-CHAINS_PER_GPU = 4
+CHAINS_PER_GPU = 4   # default; --chains-per-gpu C overrides it for every workload (BASELINE.json configs[2]: --gpus 8 --chains-per-gpu 1)
 CFG5S = dict(n_sites=2000, n_periods=8, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=28, session_duration=7, random_seed=0)
 # --workload: "occu" is the headline (BASELINE.json configs[1], what the driver runs); the others are the secondary lines
 # (same JSON shape): "occu_rn" = configs[3] (metric on `abundance`), "occu_re" = SURVEY section 8 row f3, "occu_stacked" = the
@@ -46,6 +46,11 @@ WORKLOADS = {
     "occu": dict(model="occu", cfg=CFG2, num_warmup=1000, num_samples=1000, cpu_sample=(1000, 1000), site="psi",
                  metric="effective samples/sec (psi) for occu NUTS, 10k sites x 5 visits",
                  text="biolith simulate(n_sites=10000, n_site_covs=3, n_obs_covs=3, 5 visits, seed 0); fit(occu)"),
+    # BASELINE.json configs[0]: simulate()'s own defaults (100 sites x 52 visits, one covariate each; occu.py:251-252, 336), 2 chains --
+    # the many-visits regime, where a site pair is shared by a group of lanes (occu_device.hpp: bl_eval_sites_grp)
+    "occu_cfg1": dict(model="occu", cfg=dict(random_seed=0), chains=2, num_warmup=1000, num_samples=1000, cpu_sample=(1000, 1000), site="psi",
+                      metric="effective samples/sec (psi) for occu NUTS, simulate() defaults: 100 sites x 52 visits, 2 chains",
+                      text="biolith simulate() defaults (100 sites, 52 visits, 1 + 1 covariates, seed 0); fit(occu, num_chains=2)"),
     "occu_rn": dict(model="occu_rn", cfg=CFG4, num_warmup=1000, num_samples=1000, cpu_sample=(40, 40), site="abundance",
                     metric="effective samples/sec (abundance) for occu_rn NUTS, 5k sites x 10 visits",
                     text="biolith simulate_rn(n_sites=5000, n_site_covs=3, n_obs_covs=3, 10 visits, seed 0); "
@@ -76,7 +81,7 @@ WORKLOADS = {
                      text="biolith_amd simulate_dyn(n_sites=2000, n_periods=8, n_site_covs=3, n_obs_covs=3, 4 visits per season, seed 0); fit(occu_dyn)"),
 }
 # (workload, timed steps, untimed steps) appended to the default run's line; each with a bounded cpu_baseline
-SECONDARY = (("occu_rn", 3, 1), ("occu_re", 2, 1), ("occu_stacked", 3, 1), ("occu_dyn", 3, 1))
+SECONDARY = (("occu_rn", 3, 1), ("occu_re", 2, 1), ("occu_stacked", 3, 1), ("occu_dyn", 3, 1), ("occu_cfg1", 3, 1))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # Transcendental (v_exp / v_log / v_rcp ...) issue rate: quarter rate, 16 lanes per SIMD per cycle, 4 SIMDs per CU, 2.4 GHz
 # (MI355X_MICROARCH.md) = 153.6 G per second per CU; 256 CUs.
@@ -99,6 +104,9 @@ def parse_args(argv=None):
                     help="roofline.traffic from profiles/pmc_traffic.json instead of the two rocprofv3 --pmc passes this run makes over a child process")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the child those passes profile: launches only
     ap.add_argument("--wgs-per-chain", type=int, default=0)
+    ap.add_argument("--chains-per-gpu", type=int, default=0,
+                    help="chains every rank runs (default: the workload's own, 4 for the headline); BASELINE.json configs[2] "
+                         "(8 chains sharded 1 per GPU) is --gpus 8 --chains-per-gpu 1")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="occu")
     return ap.parse_args(argv)
 
@@ -181,6 +189,17 @@ def launch_ranks(args, argv):
 
 
 # --------------------------------------------------------------------------------------------- helpers ----
+def workload_chains(wl, chains_per_gpu=0):
+    """Chains per GPU of a workload: --chains-per-gpu if given, else the workload's own (BASELINE configs[0]: 2), else 4."""
+    return int(chains_per_gpu) if chains_per_gpu and chains_per_gpu > 0 else int(wl.get("chains", CHAINS_PER_GPU))
+
+
+def rank_shard(rank, chains):
+    """The chains rank `rank` runs (fit.py:109-113, chain_method="parallel"): `chains` consecutive global chain ids starting at
+    rank x chains; a chain's xoshiro streams depend on its global id only, so N ranks x C chains are the chains of one N C-chain launch."""
+    return dict(num_chains=int(chains), chain_offset=int(rank) * int(chains))
+
+
 def algorithmic_bytes_per_eval(N, T, J, Ks, Ko, S=1):
     """float32 bytes one potential+gradient evaluation of one chain must read."""
     return 4 * (N * Ks + N * T * J * Ko + S * N * T * J)
@@ -210,7 +229,7 @@ def ess_of_site_function(draws, X, site="psi", chunk=1000, o_u=None):
     return total / n
 
 
-def cpu_baseline(data, threads, wl):
+def cpu_baseline(data, threads, wl, chains=CHAINS_PER_GPU):
     """Oracle (port of the same algorithm, float64 C) on host cores: the same chains x (warmup + draws) as the GPU for the
     headline workload, a bounded sample for the heavier ones.  Built -O3 -march=native on THIS host (oracle/Makefile `native`)."""
     import numpy as np
@@ -222,7 +241,7 @@ def cpu_baseline(data, threads, wl):
     od = oracle.OracleData(data["site_covs"], data["obs_covs"], data["obs"], model=wl["model"], **wl.get("options", {}))
     w, s = wl["cpu_sample"]
     t0 = time.perf_counter()
-    r = oracle.nuts_run(od, w, s, num_chains=CHAINS_PER_GPU, seed=0, threads=threads)
+    r = oracle.nuts_run(od, w, s, num_chains=chains, seed=0, threads=threads)
     wall = time.perf_counter() - t0
     X = np.asarray(data["site_covs"], dtype=np.float32).astype(np.float64)
     ess = ess_of_site_function(r["draws"], X, wl["site"], o_u=od.Ks + od.Ko + 3 if wl["model"] == "occu_re" else None)
@@ -230,12 +249,12 @@ def cpu_baseline(data, threads, wl):
     same = (w, s) == (wl["num_warmup"], wl["num_samples"])
     return dict(value=ess / wall, unit="ESS/s", cores=int(r["threads"]), kind="port",
                 sample=f"oracle NUTS (float64 C restatement, gcc -O3 -march=native -fno-fast-math, one thread per chain), same data, "
-                       f"{CHAINS_PER_GPU} chains x ({w} warmup + {s} draws){' = the GPU workload' if same else ' (bounded sample)'} "
+                       f"{chains} chains x ({w} warmup + {s} draws){' = the GPU workload' if same else ' (bounded sample)'} "
                        f"on {int(r['threads'])} of {os.cpu_count()} host cores: {wall:.1f} s, {nleap} gradient evaluations, "
                        f"{1e3 * wall * int(r['threads']) / nleap:.2f} ms per evaluation per core, ESS({wl['site']}) {ess:.0f}")
 
 
-def cpu_baseline_scaled(aux, wl, threads, budget_s=12.0):
+def cpu_baseline_scaled(aux, wl, threads, budget_s=12.0, chains=CHAINS_PER_GPU):
     """Bounded CPU leg of a secondary workload: the oracle's potential + gradient (the whole cost of a leapfrog) is timed at
     posterior draws of the GPU run for about `budget_s` seconds on `threads` cores, and scaled to the metric's unit with the run's
     own size: CPU seconds per step = gradient evaluations per chain x seconds per evaluation (chains side by side, one per core);
@@ -265,16 +284,20 @@ def cpu_baseline_scaled(aux, wl, threads, budget_s=12.0):
         list(ex.map(work, range(threads)))
     wall = time.perf_counter() - t0
     s_eval = wall / per_thread                        # seconds per evaluation per core, all `threads` cores busy
-    chains_rounds = -(-CHAINS_PER_GPU // threads)
-    cpu_s_per_step = chains_rounds * (aux["leap_per_step"] / CHAINS_PER_GPU) * s_eval
-    return dict(value=aux["ess_per_step"] / cpu_s_per_step, unit="ESS/s", cores=threads, kind="port",
-                sample=f"oracle potential + gradient (float64 C restatement, gcc -O3 -march=native -fno-fast-math) at {per_thread} posterior "
+    chains_rounds = -(-chains // threads)
+    cpu_s_per_step = chains_rounds * (aux["leap_per_step"] / chains) * s_eval
+    # NOT like for like with the GPU figure: ESS per step is borrowed from the GPU run, not measured; the oracle is the plain
+    # float64 statement of the model (occu_rn: all max_abundance + 1 terms of every visit, where the kernel cuts each site's range to about
+    # an eighth of them) on `threads` of the host's cores.  Reported as context; no gpu_over_cpu is derived from a scaled baseline.
+    return dict(value=aux["ess_per_step"] / cpu_s_per_step, unit="ESS/s", cores=threads, kind="port", scaled=True, comparable=False,
+                sample=f"SCALED ESTIMATE, not a sampler run: oracle potential + gradient (float64 C restatement, gcc -O3 -march=native -fno-fast-math) at {per_thread} posterior "
                        f"draws per core on {threads} of {os.cpu_count()} host cores: {wall:.1f} s, {1e3 * s_eval:.2f} ms per evaluation per core; scaled: "
-                       f"{aux['leap_per_step'] / CHAINS_PER_GPU:.0f} gradient evaluations per chain per step x that = {cpu_s_per_step:.1f} s per step "
-                       f"({CHAINS_PER_GPU} chains side by side), ESS per step as the GPU run's ({aux['ess_per_step']:.0f})")
+                       f"{aux['leap_per_step'] / chains:.0f} gradient evaluations per chain per step x that = {cpu_s_per_step:.1f} s per step "
+                       f"({chains} chains side by side), ESS per step as the GPU run's ({aux['ess_per_step']:.0f}); validated once against the oracle's "
+                       f"own sampler run: profiles/r04/ (cpu_baseline_validation)")
 
 
-def fit_end_to_end(data, reps=3):
+def fit_end_to_end(data, reps=3, chains=CHAINS_PER_GPU):
     """What biolith's own benchmark times (benchmarks/occu_spoccupancy.py:104-113): the clock around the whole
     ``fit(occu, **data, num_chains=4)`` -- host arrays in, upload, sampling, draws back -- plus the ``psi`` fetch that the
     metric needs (the reference's samples are device arrays until looked at; here psi is computed on first access)."""
@@ -285,7 +308,7 @@ def fit_end_to_end(data, reps=3):
     runs = []
     for _ in range(reps):
         t0 = time.perf_counter()
-        res = fit(occu, **data, num_chains=CHAINS_PER_GPU)
+        res = fit(occu, **data, num_chains=chains)
         t1 = time.perf_counter()
         psi = res.samples["psi"]
         t2 = time.perf_counter()
@@ -309,11 +332,12 @@ def pmc_child(args):
         data, _ = {"occu_rn": simulate_rn, "occu_dyn": simulate_dyn}.get(wl["model"], simulate)(**wl["cfg"])
     ds = OccuDataset(data["site_covs"], data["obs_covs"], data["obs"], model=wl["model"], **wl.get("options", {}))
     for s in range(1 + PMC_CHILD_LAUNCHES):
-        ds.launch(num_warmup=wl["num_warmup"], num_samples=wl["num_samples"], num_chains=CHAINS_PER_GPU, seed=s, wgs_per_chain=args.wgs_per_chain)
+        ds.launch(num_warmup=wl["num_warmup"], num_samples=wl["num_samples"], num_chains=workload_chains(wl, args.chains_per_gpu), seed=s,
+                  wgs_per_chain=args.wgs_per_chain)
         ds.wait()
 
 
-def live_hbm_traffic(name, kernel_substr, wgs_per_chain=0, timeout_s=240):
+def live_hbm_traffic(name, kernel_substr, wgs_per_chain=0, timeout_s=240, chains_per_gpu=0):
     """HBM bytes per launch of the workload's sampler kernel measured in THIS run: one rocprofv3 --pmc pass per counter (FETCH_SIZE and
     WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md) over a child process that only launches (`--pmc-child`), the counters summed
     over each dispatch's rows, the mean over its dispatches taken, FETCH_SIZE doubled (that guide's gfx950 correction) -- what
@@ -334,7 +358,8 @@ def live_hbm_traffic(name, kernel_substr, wgs_per_chain=0, timeout_s=240):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(td, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
-                   os.path.abspath(__file__), "--pmc-child", "--workload", name, "--wgs-per-chain", str(wgs_per_chain)]
+                   os.path.abspath(__file__), "--pmc-child", "--workload", name, "--wgs-per-chain", str(wgs_per_chain),
+                   "--chains-per-gpu", str(chains_per_gpu)]
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
             except subprocess.TimeoutExpired:
@@ -426,7 +451,6 @@ def main(argv=None):
             comm = comm_from_env(local_rank, rank, world)
         except Exception as exc:  # noqa: BLE001 -- the scaling line must not be lost to the engine's own communicator
             gather_fallback = f"bl_comm_init_rank failed on rank {rank}: {type(exc).__name__}: {exc}"
-    chains_per_rank = [CHAINS_PER_GPU] * world
     GATHERED = ("draws", "diverging", "num_steps", "accept_prob", "potential_energy", "step_size", "inv_mass", "n_leapfrog")
 
     def agree_on_gather():
@@ -475,6 +499,9 @@ def main(argv=None):
         nonlocal comm
         wl = WORKLOADS[name]
         NUM_WARMUP, NUM_SAMPLES = wl["num_warmup"], wl["num_samples"]
+        NCH = workload_chains(wl, args.chains_per_gpu)   # chains per GPU of this workload
+        chains_per_rank = [NCH] * world
+        shard = rank_shard(rank, NCH)
         with contextlib.redirect_stdout(io.StringIO()):
             data, truth = {"occu_rn": simulate_rn, "occu_dyn": simulate_dyn}.get(wl["model"], simulate)(**wl["cfg"])
         X = np.asarray(data["site_covs"], dtype=np.float32).astype(np.float64)
@@ -482,8 +509,7 @@ def main(argv=None):
                          model=wl["model"], **wl.get("options", {}))  # resident in HBM from here on
 
         def one_step(step_seed):
-            ds.launch(num_warmup=NUM_WARMUP, num_samples=NUM_SAMPLES, num_chains=CHAINS_PER_GPU, seed=step_seed,
-                      chain_offset=rank * CHAINS_PER_GPU, wgs_per_chain=args.wgs_per_chain, stream=stream)
+            ds.launch(num_warmup=NUM_WARMUP, num_samples=NUM_SAMPLES, seed=step_seed, wgs_per_chain=args.wgs_per_chain, stream=stream, **shard)
             ds.wait()
             if comm is None:
                 res = ds.fetch()
@@ -503,17 +529,35 @@ def main(argv=None):
                 return res, None
             local = ds.fetch() if rank != 0 else None
             if rank == 0:
-                lo = rank * CHAINS_PER_GPU
+                lo = shard["chain_offset"]
                 import copy
 
                 local = copy.copy(full)
                 for nm in ("draws", "diverging", "num_steps", "accept_prob", "potential_energy", "step_size", "inv_mass", "n_leapfrog"):
-                    setattr(local, nm, getattr(full, nm)[lo: lo + CHAINS_PER_GPU])
+                    setattr(local, nm, getattr(full, nm)[lo: lo + NCH])
             return local, (full.draws if full is not None else None)
 
         for w in range(n_warmup):
             in_warmup[0] = True
+            watchdog = None
+            if comm is not None and world > 1 and w == 0:
+                # The run's first gather, untimed.  If it fails on ONE rank its peers stay inside the collective and never reach the
+                # agreement below: bound it -- a rank still in its first step after BENCH_FIRST_GATHER_TIMEOUT seconds exits non-zero
+                # (no re-exec), which makes the launcher (bench.py's own or torchrun) end the others instead of hanging for its 3000 s.
+                # (--warmup 0 has no untimed gather: neither this bound nor the fallback to torch.distributed applies then.)
+                import threading
+
+                def give_up():
+                    sys.stderr.write(f"bench.py: rank {rank}: the first bl_gather_draws did not return within its bound; exiting\n")
+                    sys.stderr.flush()
+                    os._exit(3)
+
+                watchdog = threading.Timer(float(os.environ.get("BENCH_FIRST_GATHER_TIMEOUT", "300")), give_up)
+                watchdog.daemon = True
+                watchdog.start()
             one_step(10_000 + w)
+            if watchdog is not None:
+                watchdog.cancel()
             in_warmup[0] = False
             if comm is not None and world > 1 and w == 0:   # the first gather of the run, untimed: did it work on every rank?
                 nonlocal gather_fallback
@@ -531,7 +575,7 @@ def main(argv=None):
 
         # ---- per-rank kernel statistics (HIP events on the launch stream, recorded inside the timed region)
         kernel_ms = np.array([r.kernel_ms for r, _ in steps])
-        leap = np.array([int(r.n_leapfrog.sum()) + CHAINS_PER_GPU for r, _ in steps])  # + the initial evaluation of each chain
+        leap = np.array([int(r.n_leapfrog.sum()) + NCH for r, _ in steps])  # + the initial evaluation of each chain
         kernel_ms_per_rank = [float(kernel_ms.mean())]
         if dist is not None:
             agg = torch.tensor([kernel_ms.mean(), leap.mean()], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -575,7 +619,8 @@ def main(argv=None):
             # measured NOW (two --pmc passes over a child process, after this workload's timed region; a few seconds each); the
             # committed figure stays as the fallback and is quoted beside it
             try:
-                live, how = live_hbm_traffic(name, "bl_re_nuts_kernel" if wl["model"] == "occu_re" else "bl_nuts_kernel", args.wgs_per_chain)
+                live, how = live_hbm_traffic(name, "bl_re_nuts_kernel" if wl["model"] == "occu_re" else "bl_nuts_kernel", args.wgs_per_chain,
+                                                 chains_per_gpu=args.chains_per_gpu)
             except Exception as e:  # noqa: BLE001 -- a profiler hiccup must not cost the line
                 live, how = None, f"live PMC passes failed: {e!r}"
             if live is not None:
@@ -590,7 +635,7 @@ def main(argv=None):
                        if wl["model"] == "occu_re" else
                        # <KS, KO, LDS-staged, model id, compute waves>: occu = 0; occu_rn = 1; dynamic occupancy = 8
                        f"bl_nuts_kernel<{ds.Ks}, {ds.Ko}, true, {dict(occu_rn=1, occu_dyn=8).get(wl['model'], 0)}, {res0.threads_per_wg // 64 - 1}>")
-        us_leap = 1e3 * kernel_ms_mean / (leap_mean / CHAINS_PER_GPU)
+        us_leap = 1e3 * kernel_ms_mean / (leap_mean / NCH)
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_source, **({"traffic_committed": traffic_static} if traffic_static is not None else {}),
@@ -605,7 +650,7 @@ def main(argv=None):
             # config 4 is VALU-transcendental-bound (about 5 M enumerated (site, visit, n) terms per evaluation,
             # one transcendental each), not HBM-bound.  Peak = quarter-rate transcendental issue of the CUs the launch occupies.
             terms = N * T * J * 101
-            cus = CHAINS_PER_GPU * res0.wgs_per_chain
+            cus = NCH * res0.wgs_per_chain
             ach = leap_mean * terms / (kernel_ms_mean * 1e-3) / 1e9
             roofline = {
                 "bound": "valu-transcendental", "achieved": ach, "peak": cus * TRANS_PER_CU_PER_S / 1e9, "unit": "Gtrans/s",
@@ -634,11 +679,12 @@ def main(argv=None):
             "rccl_world": comm.world if comm is not None else 1,
             "kernel_ms_per_rank": kernel_ms_per_rank,
             "config": {
-                "workload": f"{wl['text']}: NUTS {CHAINS_PER_GPU} chains per GPU x ({NUM_WARMUP} warmup + {NUM_SAMPLES} draws), "
+                "workload": f"{wl['text']}: NUTS {NCH} chain{'s' if NCH != 1 else ''} per GPU x ({NUM_WARMUP} warmup + {NUM_SAMPLES} draws), "
                             "one step = one full fit",
-                "chains_per_gpu": CHAINS_PER_GPU, "total_chains": CHAINS_PER_GPU * world,
+                "chains_per_gpu": NCH, "total_chains": NCH * world,
                 "num_warmup": NUM_WARMUP, "num_samples": NUM_SAMPLES, "parallelism": f"chains x{world} (1 process per GPU)",
                 "wgs_per_chain": res0.wgs_per_chain, "lds_bytes_per_wg": res0.lds_bytes, "lds_staged": res0.lds_staged,
+                "lanes_per_site_pair": {"period_lanes": res0.lane_group[0], "visit_lanes": res0.lane_group[1]},
                 "gather": (f"bl_gather_draws: one ncclAllGather of {world} result blocks (RCCL {rccl_version()}), communicator init "
                            f"{comm.init_ms:.0f} ms outside the timed region") if comm is not None else
                           ("none (one rank)" if gather_fallback is None else
@@ -650,13 +696,13 @@ def main(argv=None):
             "sampler": {  # rank 0's chains, last timed step (SURVEY.md section 8d "also report")
                 "mean_num_steps": float(steps[-1][0].num_steps.mean()), "divergences": int(steps[-1][0].diverging.sum()),
                 "step_size": [float(x) for x in steps[-1][0].step_size], "mean_accept_prob": float(steps[-1][0].accept_prob.mean()),
-                "leapfrogs_per_s_per_chain": 1e3 * (leap_mean / CHAINS_PER_GPU) / kernel_ms_mean,
+                "leapfrogs_per_s_per_chain": 1e3 * (leap_mean / NCH) / kernel_ms_mean,
             },
             "ess": {f"{wl['site']}_mean_over_sites_per_step": ess_psi, "min_coef_per_step": [float(x) for x in ess_coef],
-                    "max_split_rhat": max(rhat), "draws_per_step": CHAINS_PER_GPU * world * NUM_SAMPLES},
+                    "max_split_rhat": max(rhat), "draws_per_step": NCH * world * NUM_SAMPLES},
         }
         # what the scaled CPU baseline of a secondary workload needs: posterior draws to evaluate at, and the launch's size
-        aux = dict(data=data, X=X, draws=steps[-1][1], leap_per_step=leap_mean, ess_per_step=total_ess / n_steps, D=ds.D)
+        aux = dict(data=data, X=X, draws=steps[-1][1], leap_per_step=leap_mean, ess_per_step=total_ess / n_steps, D=ds.D, chains=NCH)
         del ds
         return out, aux, wl
 
@@ -666,7 +712,7 @@ def main(argv=None):
         if world == 1 and args.workload == "occu" and not args.no_e2e:
             try:
                 # SURVEY section 8d's second clock: end-to-end fit() from host arrays, PCIe and the psi fetch included (never `value`)
-                runs = fit_end_to_end(aux["data"])
+                runs = fit_end_to_end(aux["data"], chains=aux["chains"])
                 e2e = min(runs, key=lambda r: r["total_ms"])
                 ess_e2e = ess_of_site_function(e2e["draws"].astype(np.float64), aux["X"], "psi")
                 out["fit_e2e_ms"] = e2e["total_ms"]
@@ -675,19 +721,22 @@ def main(argv=None):
                                   "ess_psi": ess_e2e, "total_ms_each": [r["total_ms"] for r in runs],
                                   "total_ms_median": float(np.median([r["total_ms"] for r in runs])),
                                   "what": "best of 3 (all three and their median beside it; the first call pins its output buffers, later ones "
-                                          "reuse them): clock around fit(occu, **data, num_chains=4) from host NumPy arrays (upload, sampling, "
-                                          "draws back) + samples['psi'] (4000 x 10000 float32 computed on the device and copied over PCIe), "
+                                          f"reuse them): clock around fit(occu, **data, num_chains={aux['chains']}) from host NumPy arrays (upload, sampling, "
+                                          f"draws back) + samples['psi'] ({aux['chains'] * 1000} x 10000 float32 computed on the device and copied over PCIe), "
                                           "as biolith/benchmarks/occu_spoccupancy.py:104-113 times it; library already loaded"}
             except Exception as exc:  # noqa: BLE001
                 out["fit_e2e_error"] = f"{type(exc).__name__}: {exc}"
         if world == 1 and not args.no_cpu_baseline:
             try:
-                threads = min(CHAINS_PER_GPU, os.cpu_count() or 1)
-                if args.workload == "occu" or args.cpu_baseline:   # the oracle's own sampler run (the headline: the same chains x draws as the GPU)
-                    out["cpu_baseline"] = cpu_baseline(aux["data"], threads=threads, wl=wl)
-                else:                                              # the other workloads: a bounded sample of oracle evaluations, scaled
-                    out["cpu_baseline"] = cpu_baseline_scaled(aux, wl, threads=threads)
-                out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+                threads = min(aux["chains"], os.cpu_count() or 1)
+                if args.workload in ("occu", "occu_cfg1") or args.cpu_baseline:   # the oracle's own sampler run (the headline: the same chains x draws as the GPU)
+                    out["cpu_baseline"] = cpu_baseline(aux["data"], threads=threads, wl=wl, chains=aux["chains"])
+                    out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+                    if args.cpu_baseline and args.workload not in ("occu", "occu_cfg1"):   # ... and the scaled estimate beside it: validates the scaling once
+                        out["cpu_baseline_scaled"] = cpu_baseline_scaled(aux, wl, threads=threads, chains=aux["chains"])
+                        out["cpu_baseline_scaled"]["sampler_run_over_scaled"] = out["cpu_baseline"]["value"] / out["cpu_baseline_scaled"]["value"]
+                else:                                              # the other workloads: a bounded sample of oracle evaluations, scaled (no ratio derived)
+                    out["cpu_baseline"] = cpu_baseline_scaled(aux, wl, threads=threads, chains=aux["chains"])
             except Exception as exc:  # noqa: BLE001
                 out["cpu_baseline_error"] = f"{type(exc).__name__}: {exc}"
     aux = None
@@ -706,14 +755,26 @@ def main(argv=None):
                     entry["reference_counterpart"] = "none for BASELINE.json configs[4] as worded (dynamic colonisation / extinction); this is the stacked-period form of occu.py:198-210 at its size"
                 if not args.no_cpu_baseline:
                     try:
-                        entry["cpu_baseline"] = cpu_baseline_scaled(a2, w2, threads=min(CHAINS_PER_GPU, os.cpu_count() or 1))
-                        entry["gpu_over_cpu"] = entry["value"] / entry["cpu_baseline"]["value"]
+                        thr = min(a2["chains"], os.cpu_count() or 1)
+                        if name == "occu_cfg1":   # small enough for the oracle's own sampler: the same 2 chains x (1000 + 1000), a measured baseline
+                            entry["cpu_baseline"] = cpu_baseline(a2["data"], threads=thr, wl=w2, chains=a2["chains"])
+                            entry["gpu_over_cpu"] = entry["value"] / entry["cpu_baseline"]["value"]
+                        else:                     # a scaled estimate (flagged "comparable": false): no speed-up is derived from it
+                            entry["cpu_baseline"] = cpu_baseline_scaled(a2, w2, threads=thr, chains=a2["chains"])
                     except Exception as exc:  # noqa: BLE001
                         entry["cpu_baseline_error"] = f"{type(exc).__name__}: {exc}"
                 out["secondary"].append(entry)
             except Exception as exc:  # noqa: BLE001
                 out["secondary"].append({"workload": name, "error": f"{type(exc).__name__}: {exc}"})
     if rank == 0:
+        if "secondary" in out:
+            # LAST key of the line, short: a record that keeps only the tail of stdout still holds every workload's figures
+            # [value ESS/s, ms_per_step, us_per_leapfrog_per_chain, roofline.frac, cpu_baseline.value]
+            out["secondary_summary"] = {
+                e["workload"]: ([round(e["value"], 1), round(e["ms_per_step"], 2), round(e["us_per_leapfrog_per_chain"], 3),
+                                 round(e["roofline"]["frac"], 4),
+                                 (round(e["cpu_baseline"]["value"], 2) if "cpu_baseline" in e else None)]
+                                if "error" not in e else "error") for e in out["secondary"]}
         print(json.dumps(out))
     if comm is not None:
         comm.close()

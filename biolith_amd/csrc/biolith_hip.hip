@@ -202,7 +202,7 @@ struct bl_dataset {
     float *d_dur = nullptr;
     // ---- last NUTS launch ----
     bool in_flight = false, have_run = false;
-    int C = 0, S = 0, W = 0, k = 0, nloc = 0, lds_ld = 0, lds_bytes = 0, staged = 0, nvp = 0, ncw = 0;
+    int C = 0, S = 0, W = 0, k = 0, nloc = 0, lds_ld = 0, lds_bytes = 0, staged = 0, nvp = 0, ncw = 0, lane_grp = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *d_run = nullptr;  // one slab for all run buffers
@@ -930,8 +930,37 @@ static int dyn_lanes_per_pair(const bl_dataset *ds, int chains)
     return G;
 }
 
+// Plain occupancy model and its false-positive form: lanes that share one site pair (occu_device.hpp: bl_eval_sites_grp), as the code
+// log2(period lanes) | log2(visit lanes) << 4; 0 = one pair per lane.  More lanes per pair while a lane would still walk more than
+// BL_GRP_VISITS visits of its pair and the lanes one XCD offers the chain (4 compute waves on each of its <= kmax workgroups) allow it;
+// the periods are split first (nothing to exchange between those lanes), then the visits of a period (one DPP fold per period).
+#define BL_GRP_VISITS 6
+static int occu_lane_group(const bl_dataset *ds, int chains, int want_k)
+{
+    if (ds->model != 0 && ds->model != 2) return 0;
+    const int T = ds->dims.n_periods, J = ds->dims.n_replicates;
+    const long long V = (long long)T * J, npairs = (ds->dims.n_sites + 1) / 2;
+    const int per_xcd = ((chains > 0 ? chains : 1) + 7) / 8;
+    int kmax = std::max(1, 32 / per_xcd);
+    if (want_k > 0) kmax = std::min(kmax, want_k);
+    int target = BL_GRP_VISITS;
+    if (const char *e = getenv("BIOLITH_HIP_GRP_VISITS")) { const int v = atoi(e); if (v >= 1) target = v; } // A/B knob
+    int lg = 0;
+    while (lg < 4 && ((V + (1 << lg) - 1) >> lg) > target && (npairs << (lg + 1)) <= (long long)kmax * 4 * 64) lg++;
+    if (const char *e = getenv("BIOLITH_HIP_OCCU_G")) { // tests / A/B: force the lanes per pair (1, 2, 4, 8, 16)
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) { lg = 0; while ((1 << lg) < v) lg++; }
+    }
+    int lgt = 0;
+    while (lgt < lg && (2 << lgt) <= T) lgt++;
+    if (const char *e = getenv("BIOLITH_HIP_OCCU_GT")) { const int v = atoi(e); if (v >= 0 && v <= lg) lgt = v; } // tests: log2 of the period lanes
+    int lgj = lg - lgt;
+    while (lgj > 0 && (1 << (lgj - 1)) >= J) lgj--; // (visit lanes beyond a period's visits would only idle)
+    return lgt | (lgj << 4);
+}
+
 static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k_out, int *nloc_out, int *ld_out,
-                            int *lds_bytes_out, int *staged_out, int *ncw_out, int *wide_out)
+                            int *lds_bytes_out, int *staged_out, int *ncw_out, int *wide_out, int *grp_out = nullptr)
 {
     const int N = ds->dims.n_sites;
     // chains are dealt to the 8 XCDs (32 CUs each); a chain's k workgroups share one XCD, one per CU
@@ -943,11 +972,22 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     // used whenever one pair per lane still fits the chain's workgroup budget, else 4 compute waves.
     // occu_rn (rn_device.hpp): 7 compute waves; its cost is per item of the sums over N, not per lane, so a chain takes
     // all the workgroups its XCD offers once it has more than a wave of sites for each.
-    int ncw = BL_CWAVES_RN, per_wg = 64;
+    int ncw = BL_CWAVES_RN, per_wg = 64, grp = 0;
     if (ds->model != 1) {
-        ncw = ((N + 2 * 3 * 64 - 1) / (2 * 3 * 64) <= kmax) ? 3 : 4;
-        if (const char *e = getenv("BIOLITH_HIP_CWAVES")) { const int v = atoi(e); if (v >= 3 && v <= 15) ncw = v; } // A/B knob (variant builds hold other counts)
-        per_wg = 2 * ncw * 64;
+        grp = occu_lane_group(ds, chains, want_k);
+        const int G = 1 << ((grp & 15) + (grp >> 4)); // lanes per site pair
+        ncw = (((long long)N * G + 2 * 3 * 64 - 1) / (2 * 3 * 64) <= kmax) ? 3 : 4;
+        // A/B knob: only the counts this library was built with (3, 4, and BL_OCCU_CWX in a variant build of the plain model); anything
+        // else is ignored rather than turned into a launch that no instantiation serves
+        if (const char *e = getenv("BIOLITH_HIP_CWAVES")) {
+            const int v = atoi(e);
+            bool built = v == 3 || v == 4;
+#ifdef BL_OCCU_CWX
+            built = built || (ds->model == 0 && v == BL_OCCU_CWX);
+#endif
+            if (built) ncw = v;
+        }
+        per_wg = std::max(2, 2 * ncw * 64 / G);
         if (ds->model == 8) { ncw = 3; per_wg = 2 * 3 * 64 / dyn_lanes_per_pair(ds, chains); } // one site pair per lane group
     }
     int k = want_k > 0 ? want_k : (N + per_wg - 1) / per_wg;
@@ -964,7 +1004,9 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     };
     int nloc;
     bool ok = fits(k, &nloc);
-    if (!ok && want_k <= 0)
+    // (an explicit count that does not fit is raised too for the models that have no HBM-row form -- fit()'s retry at k/2 after an engine
+    // timeout must not turn into a refusal -- but kept for the plain model, whose HBM-row form serves any count)
+    if (!ok && (want_k <= 0 || ds->model != 0))
         for (int kk = k + 1; kk <= kmax && !ok; kk++) { ok = fits(kk, &nloc); if (ok) k = kk; }
     // Wide geometry: the slice does not fit the LDS of one XCD's workgroups, but it does when the chain takes more
     // CUs than one XCD has.  The exchange then crosses XCDs (the kernel's placement census makes it take the fabric
@@ -986,6 +1028,8 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     if (!ok) fits(k, &nloc);
     if (!ok && ds->model == 0) ncw = 4; // HBM-row form is built for 4 compute waves only
     if (wide) ncw = ds->model == 1 ? BL_CWAVES_RN : 4; // full slices: all four SIMDs evaluate
+    if (!ok) grp = 0; // (the HBM-row form keeps one pair per lane)
+    if (grp_out) *grp_out = grp;
     *k_out = k; *nloc_out = nloc; *ld_out = stride; *staged_out = ok ? 1 : 0; *ncw_out = ncw; *wide_out = wide;
     *lds_bytes_out = ok ? BL_OFF_DATA + ((nloc + 1) / 2) * stride * 4 * ds->nsp + rn_scratch : BL_OFF_DATA;
 }
@@ -1093,8 +1137,7 @@ static size_t re_geometry(BlReModel &m, int nloc, int with_hot, int dl_max)
 static int create_re_impl(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
                           int site_random_effects, int obs_random_effects, double prior_site_re_sd_scale,
                           double prior_obs_re_sd_scale, int fp_mode, double fp_a, double fp_b, int count_model, int count_K, const bl_normal_prior *prior_beta,
-                          const bl_normal_prior *prior_alpha, int device, bl_dataset **out);
-static thread_local const float *cop_session_duration = nullptr; // (occu_cop with random effects: handed to create_re_impl's packer call)
+                          const bl_normal_prior *prior_alpha, int device, bl_dataset **out, const float *session_duration = nullptr);
 
 // occu_cop(site_random_effects / obs_random_effects = True [, false_positives_constant / _unoccupied = True]): occu_cop.py:158-170,
 // 183-186, 204-210, 229-248.  theta = [beta, alpha, (phi = log rate_fp), (log sds), site_re_occ [N], site_re_det [N], obs_re [N][T][J]];
@@ -1110,11 +1153,8 @@ extern "C" int bl_dataset_create_cop_re(const bl_dims *dims, const float *site_c
     if (!session_duration) return bl_fail(BL_ERR_INVALID, "session_duration is NULL");
     if (dims && dims->n_species != 1)
         return bl_fail(BL_ERR_UNSUPPORTED, "occu_cop with random effects: one species per dataset (n_species=%d)", dims->n_species);
-    cop_session_duration = session_duration;
-    const int rc = create_re_impl(dims, site_covs, obs_covs, counts, site_random_effects, obs_random_effects, prior_site_re_sd_scale,
-                                  prior_obs_re_sd_scale, fp_mode, fp_mode ? prior_fp_rate : 1.0, 0.0, 3, 0, prior_beta, prior_alpha, device, out);
-    cop_session_duration = nullptr;
-    return rc;
+    return create_re_impl(dims, site_covs, obs_covs, counts, site_random_effects, obs_random_effects, prior_site_re_sd_scale,
+                          prior_obs_re_sd_scale, fp_mode, fp_mode ? prior_fp_rate : 1.0, 0.0, 3, 0, prior_beta, prior_alpha, device, out, session_duration);
 }
 
 extern "C" int bl_dataset_create_re(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
@@ -1195,7 +1235,7 @@ extern "C" int bl_dataset_create_rn_re(const bl_dims *dims, const float *site_co
 static int create_re_impl(const bl_dims *dims, const float *site_covs, const float *obs_covs, const float *obs,
                           int site_random_effects, int obs_random_effects, double prior_site_re_sd_scale,
                           double prior_obs_re_sd_scale, int fp_mode, double fp_a, double fp_b, int count_model, int count_K, const bl_normal_prior *prior_beta,
-                          const bl_normal_prior *prior_alpha, int device, bl_dataset **out)
+                          const bl_normal_prior *prior_alpha, int device, bl_dataset **out, const float *session_duration /* occu_cop only */)
 {
     if (!site_random_effects && !obs_random_effects && !(count_model == 1 && fp_mode))
         return bl_fail(BL_ERR_INVALID, "bl_dataset_create_re: neither random effect requested (use bl_dataset_create)");
@@ -1211,7 +1251,7 @@ static int create_re_impl(const bl_dims *dims, const float *site_covs, const flo
     // (N-mixture: the count model's rows -- visit = (m y, m, w..) -- and its table of log-binomial sums)
     ModelOpts mo; mo.vector_kernels = true;
     if (count_model) { mo.model = count_model; mo.max_abundance = count_K; } // 4: N-mixture, 1: Royle-Nichols, 3: occu_cop (no false positives)
-    if (count_model == 3) { mo.fp_mode = fp_mode; mo.fp_a = fp_mode ? fp_a : 1.0; mo.session_duration = cop_session_duration; } // (fp_a: the Exponential prior's rate)
+    if (count_model == 3) { mo.fp_mode = fp_mode; mo.fp_a = fp_mode ? fp_a : 1.0; mo.session_duration = session_duration; } // (fp_a: the Exponential prior's rate)
     int rc = dataset_create_impl(mo, dims, site_covs, obs_covs, obs, prior_beta, prior_alpha, device, out);
     if (rc) return rc;
     bl_dataset *ds = *out;
@@ -1339,10 +1379,10 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
     if (rc) return rc;
     if (ds->model == 6) return re_logp_grad(ds, B, theta, U, grad);
     const int D = ds->D;
-    int k, nloc, ld, lds_bytes, can_stage, ncw, wide;
-    choose_geometry(ds, 1, 0, &k, &nloc, &ld, &lds_bytes, &can_stage, &ncw, &wide);
+    int k, nloc, ld, lds_bytes, can_stage, ncw, wide, grp;
+    choose_geometry(ds, 1, 0, &k, &nloc, &ld, &lds_bytes, &can_stage, &ncw, &wide, &grp);
     const int use_staged = staged && can_stage;
-    if (!use_staged) { lds_bytes = BL_OFF_DATA; ncw = 4; }
+    if (!use_staged) { lds_bytes = BL_OFF_DATA; ncw = 4; grp = 0; }
     std::vector<float> th32((size_t)B * D);
     for (size_t i = 0; i < th32.size(); i++) th32[i] = (float)theta[i];
     float *d_th32 = nullptr;
@@ -1360,7 +1400,7 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
     p.dd = ds->dd; p.k = k; p.nloc = nloc; p.rec_stride = ld; p.B = B; p.theta = d_th32; p.partial = d_partial;
     p.max_abundance = ds->max_abundance;
     p.rn_off = BL_OFF_DATA + ((nloc + 1) / 2) * ld * 4; // (occu_rn: one species)
-    p.dyn_g = ds->model == 8 ? dyn_lanes_per_pair(ds, 1) : 1;
+    p.lane_grp = ds->model == 8 ? dyn_lanes_per_pair(ds, 1) : grp;
     p.fp_mode = ds->fp_mode;
     p.nmix_tab = ds->d_tab;
     p.ncw = ncw;
@@ -1520,7 +1560,7 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     BL_HIP(re_nuts_dispatch(cap4 ? 4 : 16, run, 8 * k * ((C + 7) / 8), lds, st));
     BL_HIP(hipEventRecord(ds->ev1, st));
     ds->stream = st; ds->in_flight = true; ds->have_run = true;
-    ds->C = C; ds->S = S; ds->W = W; ds->k = k; ds->nloc = nloc; ds->lds_ld = 0; ds->lds_bytes = (int)lds; ds->staged = run.m.lds_rows | (run.m.lds_hot << 1); ds->nvp = 0; ds->ncw = BL_RE_NW;
+    ds->C = C; ds->S = S; ds->W = W; ds->k = k; ds->nloc = nloc; ds->lds_ld = 0; ds->lds_bytes = (int)lds; ds->staged = run.m.lds_rows | (run.m.lds_hot << 1); ds->nvp = 0; ds->ncw = BL_RE_NW; ds->lane_grp = 0;
     return BL_OK;
 }
 
@@ -1540,8 +1580,8 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     if (ds->model == 6) return re_nuts_launch(ds, cfg, (hipStream_t)stream, max_depth);
 
     int k, nloc, ld, lds_bytes, staged;
-    int ncw, wide;
-    choose_geometry(ds, C, cfg->wgs_per_chain, &k, &nloc, &ld, &lds_bytes, &staged, &ncw, &wide);
+    int ncw, wide, grp;
+    choose_geometry(ds, C, cfg->wgs_per_chain, &k, &nloc, &ld, &lds_bytes, &staged, &ncw, &wide, &grp);
     const int nvp = (D + 4 <= 16) ? 16 : (D + 4 <= 32 ? 32 : 64);
 
     // ---- (re)allocate run slab ----
@@ -1616,7 +1656,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.max_depth = max_depth;
     p.max_abundance = ds->max_abundance;
     p.rn_off = BL_OFF_DATA + ((nloc + 1) / 2) * ld * 4; // (occu_rn: one species)
-    p.dyn_g = ds->model == 8 ? dyn_lanes_per_pair(ds, C) : 1;
+    p.lane_grp = ds->model == 8 ? dyn_lanes_per_pair(ds, C) : grp;
     p.fp_mode = ds->fp_mode;
     p.nmix_tab = ds->d_tab;
     p.ncw = ncw;
@@ -1653,7 +1693,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     if (lrc != 0) return bl_fail(BL_ERR_NO_DEVICE, "NUTS kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
     BL_HIP(hipEventRecord(ds->ev1, st));
     ds->stream = st; ds->in_flight = true; ds->have_run = true;
-    ds->C = C; ds->S = S; ds->W = W; ds->k = k; ds->nloc = nloc; ds->lds_ld = ld; ds->lds_bytes = lds_bytes; ds->staged = staged; ds->nvp = nvp; ds->ncw = ncw;
+    ds->C = C; ds->S = S; ds->W = W; ds->k = k; ds->nloc = nloc; ds->lds_ld = ld; ds->lds_bytes = lds_bytes; ds->staged = staged; ds->nvp = nvp; ds->ncw = ncw; ds->lane_grp = p.lane_grp;
     return BL_OK;
 }
 
@@ -1761,6 +1801,18 @@ extern "C" int bl_host_alloc(size_t bytes, void **out)
 extern "C" int bl_host_free(void *ptr)
 {
     if (ptr) BL_HIP(hipHostFree(ptr));
+    return BL_OK;
+}
+
+extern "C" int bl_nuts_lane_group(bl_dataset *ds, int *period_lanes, int *visit_lanes)
+{
+    if (!ds) return bl_fail(BL_ERR_INVALID, "NULL argument");
+    if (!ds->have_run) return bl_fail(BL_ERR_INVALID, "no NUTS launch on this handle");
+    int gt = 1, gj = 1;
+    if (ds->model == 8) gt = ds->lane_grp > 0 ? ds->lane_grp : 1;                                    // dynamic occupancy: the seasons
+    else if (ds->model == 0 || ds->model == 2) { gt = 1 << (ds->lane_grp & 15); gj = 1 << (ds->lane_grp >> 4); }
+    if (period_lanes) *period_lanes = gt;
+    if (visit_lanes) *visit_lanes = gj;
     return BL_OK;
 }
 

@@ -9,7 +9,7 @@ struct BlLogpParams {
     int k, nloc, rec_stride;
     int max_abundance;   // occu_rn only
     int rn_off;          // occu_rn / dynamic occupancy: byte offset in LDS of its scratch (see BlNutsParams)
-    int dyn_g;           // dynamic occupancy: lanes per site pair (see BlNutsParams)
+    int lane_grp;        // lanes per site pair (see BlNutsParams)
     int fp_mode;         // false-positive coordinate (see BlNutsParams)
     const float *nmix_tab; // MODEL 4 (see BlNutsParams)
     int ncw;             // compute waves per workgroup: selects the CW instantiation (host side)
@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_logp_kernel(const BlLogpPara
         if (wave == 0 && lane < D) sh_coef[my_pos] = p.theta[(size_t)b * D + lane];
         __syncthreads();
         if (wave > 0) { // compute waves, exactly as in the NUTS kernel
-            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, p.dd.T, p.dd.J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, p.dd.n_stride, nsp, p.sp_lds, p.rn_off, p.dyn_g);
+            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, p.dd.T, p.dd.J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, p.dd.n_stride, nsp, p.sp_lds, p.rn_off, p.lane_grp);
         }
         __syncthreads();
         if (wave == 0) {

@@ -105,7 +105,8 @@ struct BlNutsParams {
     int max_abundance;             // occu_rn only (occu_rn.py:26)
     int rn_off;                    // occu_rn: byte offset in LDS of its scratch (lgamma table + wave-private tables), behind the records;
                                    // dynamic occupancy (MODEL 8): of its lane-private columns (dyn_device.hpp)
-    int dyn_g;                     // dynamic occupancy: lanes that share one site pair (1, 2, 4, 8; dyn_device.hpp)
+    int lane_grp;                  // lanes that share one site pair -- dynamic occupancy: 1, 2, 4, 8 (dyn_device.hpp); occu / false positives:
+                                   // log2(period lanes) | log2(visit lanes) << 4, 0 = one pair per lane (occu_device.hpp: bl_eval_sites_grp)
     int allow_local;               // 0: always use the placement-independent exchange
     int poll_sleep;                // s_sleep(1) repeats between re-polls (fabric form)
     int first_delay;               // s_sleep(1) repeats between publishing and the first poll
@@ -629,7 +630,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #ifdef BL_STAMPS
             const long long st_a0 = (long long)clock64();
 #endif
-            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, p.n_stride, nsp, p.sp_lds, p.rn_off, p.dyn_g);
+            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, p.n_stride, nsp, p.sp_lds, p.rn_off, p.lane_grp);
 #ifdef BL_STAMPS
             st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
 #endif

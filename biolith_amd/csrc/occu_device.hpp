@@ -727,6 +727,147 @@ __device__ __forceinline__ void bl_eval_sites_fp(int ct, int pstride, int cnt, i
 }
 
 
+// ------------------------------------------- lane groups over the visits of a site pair (MODEL 0 and 2) ----
+// One site pair per lane (above) is the latency optimum only while a (site, period) has few visits: the lane walks them one after the
+// other, and at biolith's own defaults (simulate(): 100 sites x 52 visits, occu.py:251-252, 336), on its benchmark grid
+// (benchmarks/occu_spoccupancy.py:16-70: up to 90 visits) and with stacked periods (T > 1, occu.py:198-210) most of a chain's lanes
+// idle meanwhile.  Here a pair is worked on by a GROUP of G = Gt x Gj neighbouring lanes (host: occu_lane_group):
+//   * Gt lanes split the PERIODS (lane's periods t = sub_t, sub_t + Gt, ...): nothing to exchange at all -- a period's share of
+//     d/d eta (q - psi), of the log-likelihood and of d/d alpha are plain addends of sums that the wave reduction forms anyway;
+//   * Gj lanes split the VISITS of a period (contiguous chunks): the one per-period quantity every lane needs whole is
+//     a = sum_j log sigma(u_j), folded across the Gj lanes with log2(Gj) DPP adds per site of the pair; each lane then forms the
+//     posterior occupancy weight q itself (one exp / log / rcp: less than one visit) and scales ITS visits' gradient partials by it.
+//     Per-(site, period) addends (log-lik, q - psi) are counted by the chunk's first lane, per-site ones by the group's first lane.
+// grp = log2(Gt) | log2(Gj) << 4 (wave-uniform; 0 selects the one-pair-per-lane forms above).  Runtime J; the records are the same.
+template <int CTRL>
+__device__ __forceinline__ bl_f2 bl_dpp2(bl_f2 v) { return bl_f2{bl_dpp<CTRL, 0xF>(v.x), bl_dpp<CTRL, 0xF>(v.y)}; }
+// sum over 2^lg neighbouring lanes (aligned groups), result in every lane of the group
+__device__ __forceinline__ bl_f2 bl_group_sum2(bl_f2 v, int lg)
+{
+    if (lg >= 1) v += bl_dpp2<0xB1>(v);  // quad_perm [1,0,3,2]
+    if (lg >= 2) v += bl_dpp2<0x4E>(v);  // quad_perm [2,3,0,1]
+    if (lg >= 3) v += bl_dpp2<0x141>(v); // row_half_mirror
+    if (lg >= 4) v += bl_dpp2<0x140>(v); // row_mirror
+    return v;
+}
+
+template <int KS, int KO, int CT, bool FP>
+__device__ __forceinline__ void bl_eval_sites_grp(int ct, int pstride, int cnt, int T, int J, int grp, const BlFpScalars fp,
+                                                  const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
+                                                  float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], float &gphi, int data_off = 0)
+{
+    constexpr int XQ = (KS + 3) & ~3;
+    const int lgt = grp & 15, lgj = grp >> 4, lg = lgt + lgj;
+    const int sub = ct & ((1 << lg) - 1), slot = ct >> lg, nslots = CT >> lg;
+    const int sub_j = sub & ((1 << lgj) - 1), sub_t = sub >> lgj, Gt = 1 << lgt;
+    const int jc = (J + (1 << lgj) - 1) >> lgj;              // visits per chunk
+    const int j0 = min(sub_j * jc, J), j1 = min(j0 + jc, J); // this lane's chunk of every period
+    const bl_f2 firstj = bl2(sub_j == 0 ? 1.0f : 0.0f);
+    const int pb = bl_period_block(J, KO);
+    const float *data = bl_lds_f(BL_OFF_DATA) + data_off;
+    const int npairs = (cnt + 1) >> 1;
+    const float Jf = (float)J;
+    bl_f2 ll2 = bl2(0.0f), gb2[KS + 1], ga2[KO + 1], gp2 = bl2(0.0f);
+#pragma unroll
+    for (int k = 0; k <= KS; k++) gb2[k] = bl2(0.0f);
+#pragma unroll
+    for (int k = 0; k <= KO; k++) ga2[k] = bl2(0.0f);
+    for (int m = slot; m < npairs; m += nslots) { // (all lanes of a group share m: they enter and leave the loop together)
+        const float4 *rec = reinterpret_cast<const float4 *>(data + (size_t)m * pstride);
+        const bl_f2 vmask = bl_f2{1.0f, (2 * m + 1 < cnt) ? 1.0f : 0.0f}; // odd slice: the last pair's second site is a dummy
+        bl_f2 x[XQ];
+#pragma unroll
+        for (int q = 0; q < XQ / 2; q++) {
+            const float4 v = rec[q];
+            x[2 * q] = bl_f2{v.x, v.y};
+            x[2 * q + 1] = bl_f2{v.z, v.w};
+        }
+        bl_f2 eta = bl2(beta[0]);
+#pragma unroll
+        for (int k = 0; k < KS; k++) eta = bl_fma2(x[k], bl2(beta[k + 1]), eta);
+        const bl_f2 e_eta = bl_exp2_2(__builtin_elementwise_abs(eta) * bl2(-BL_LOG2E));
+        const bl_f2 op_eta = e_eta + bl2(1.0f);
+        const bl_f2 sp = bl_fma2(bl_log2_2(op_eta), bl2(BL_LN2), __builtin_elementwise_max(eta, bl2(0.0f)));
+        const bl_f2 psi = bl_sel_pos_one(eta, e_eta) * bl_rcp_2(op_eta);
+        bl_f2 dsum = bl2(0.0f), lsite = bl2(0.0f), gpsite = bl2(0.0f);
+        const float2 *pp0 = reinterpret_cast<const float2 *>(data + (size_t)m * pstride) + XQ;
+        for (int t = sub_t; t < T; t += Gt) { // (the lanes that fold a period's sums share sub_t, hence this loop's trip count)
+            const float2 *pp = pp0 + t * pb;
+            bl_f2 g[KO + 1];
+#pragma unroll
+            for (int k = 0; k <= KO; k++) g[k] = bl2(0.0f);
+            const float2 a_ = pp[J * (KO + 1)], kb_ = pp[J * (KO + 1) + 1];
+            bl_f2 a = bl_f2{a_.x, a_.y} * firstj; // ka once per (site, period)
+            bl_f2 gf = bl2(0.0f);                 // FP: d a / d f1 (this lane's visits)
+#pragma unroll 2
+            for (int j = j0; j < j1; j++) {
+                bl_f2 w[KO + 1];
+#pragma unroll
+                for (int k = 0; k <= KO; k++) {
+                    const float2 v = pp[j * (KO + 1) + k];
+                    w[k] = bl_f2{v.x, v.y};
+                }
+                if constexpr (!FP) {
+                    bl_visit2<KO>(w, alpha, a, g);
+                } else { // (bl_eval_sites_fp's visit)
+                    bl_f2 u = w[0] * bl2(alpha[0]);
+#pragma unroll
+                    for (int k = 1; k <= KO; k++) u = bl_fma2(w[k], bl2(alpha[k]), u);
+                    const bl_f2 tt = bl_expneg_2(u);
+                    const bl_f2 op = tt + bl2(1.0f);
+                    a = bl_fma2(bl_log2_2(op), bl2(-BL_LN2), a);
+                    const bl_f2 det = __builtin_elementwise_max(w[0], bl2(0.0f)) * bl2(fp.z1);
+                    const bl_f2 td = tt * det;
+                    const bl_f2 opf = bl_fma2(td, bl2(fp.f1), bl2(1.0f));
+                    a = bl_fma2(bl_log2_2(opf), bl2(BL_LN2), a);
+                    const bl_f2 tr = td * bl_rcp_2(opf);
+                    gf += tr;
+                    const bl_f2 s = bl_fma2(tr, bl2(-fp.f1), tt * bl_rcp_2(op));
+#pragma unroll
+                    for (int k = 0; k <= KO; k++) g[k] = bl_fma2(s, w[k], g[k]);
+                }
+            }
+            a = bl_group_sum2(a, lgj);
+            bl_f2 kb = bl_f2{kb_.x, kb_.y}, ndet = bl2(0.0f), nnon = bl2(0.0f);
+            if constexpr (FP) { // counts of this (site, period) from the record's ka = n_masked ln2, kb = n_det log(tiny)
+                ndet = bl_f2{__builtin_rintf(kb_.x * (1.0f / -87.33654475f)), __builtin_rintf(kb_.y * (1.0f / -87.33654475f))};
+                const bl_f2 nmask = bl_f2{__builtin_rintf(a_.x * (1.0f / BL_LN2)), __builtin_rintf(a_.y * (1.0f / BL_LN2))};
+                nnon = bl2(Jf) - ndet - nmask;
+                a = bl_fma2(nnon, bl2(fp.l1f1), a);
+                kb = bl_fma2(ndet, bl2(fp.lf), nnon * bl2(fp.l1f));
+            }
+            const bl_f2 A = eta - sp + a, B = kb - sp;
+            const bl_f2 d = eta + a - kb; // = A - B
+            const bl_f2 e_d = bl_exp2_2(__builtin_elementwise_abs(d) * bl2(-BL_LOG2E));
+            const bl_f2 op_d = e_d + bl2(1.0f);
+            lsite = bl_fma2(bl_fma2(bl_log2_2(op_d), bl2(BL_LN2), __builtin_elementwise_max(A, B)), firstj, lsite);
+            const bl_f2 q = bl_sel_pos_one(d, e_d) * bl_rcp_2(op_d); // P(z=1 | y, theta)
+            dsum = bl_fma2(q - psi, firstj, dsum);
+#pragma unroll
+            for (int k = 0; k <= KO; k++) ga2[k] = bl_fma2(q, g[k], ga2[k]); // this lane's visits (dummy site: g == 0)
+            if constexpr (FP) {
+                // d/dphi is linear in gf: q gf ff1 from every lane, the counts' part once per (site, period)
+                const bl_f2 d1c = nnon * bl2(-fp.f * fp.z1);
+                const bl_f2 d0 = bl_fma2(ndet, bl2(1.0f - fp.f), nnon * bl2(-fp.f));
+                gpsite += q * gf * bl2(fp.ff1) + bl_fma2(q, d1c - d0, d0) * firstj;
+            }
+        }
+        ll2 = bl_fma2(lsite, vmask, ll2);
+        if constexpr (FP) gp2 = bl_fma2(gpsite, vmask, gp2);
+        dsum *= vmask;
+        gb2[0] += dsum;
+#pragma unroll
+        for (int k = 0; k < KS; k++) gb2[k + 1] = bl_fma2(dsum, x[k], gb2[k + 1]);
+    }
+    ll += ll2.x + ll2.y;
+    if constexpr (FP) gphi += gp2.x + gp2.y;
+#pragma unroll
+    for (int k = 0; k <= KS; k++) gb[k] += gb2[k].x + gb2[k].y;
+#pragma unroll
+    for (int k = 0; k <= KO; k++) ga[k] += ga2[k].x + ga2[k].y;
+}
+
+
 // ------------------------------------------------------- count occupancy (occu_cop, MODEL 3) ----
 // biolith/models/occu_cop.py:17-255: y_itj ~ Poisson(dur_itj * (z lambda_itj + (1 - z) f_u + f_c)),
 // lambda = exp(alpha0 + w alpha), z ~ Bernoulli(psi) summed out; at most one of the false-positive rates
@@ -1132,7 +1273,7 @@ __device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, con
 template <int KS, int KO, bool LDS, int MODEL, int CW>
 __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__restrict__ grows, int ld_or_stride, int cnt,
                                            int T, int J, int max_abundance, int fp_mode, const float *__restrict__ tab = nullptr,
-                                           int tab_ld = 0, int n_species = 1, int sp_lds = 0, int rn_off = 0, int dyn_g = 1)
+                                           int tab_ld = 0, int n_species = 1, int sp_lds = 0, int rn_off = 0, int lane_grp = 0)
 {
     const int row_stride = n_species > 1 ? n_species * BL_SP_PART(KS, KO) : BL_PART_STRIDE;
     for (int sp = 0; sp < n_species; sp++) {
@@ -1149,7 +1290,8 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         static_assert(LDS, "false-positive model: LDS records only");
         float gphi = -0.0f;
         const BlFpScalars fp = bl_fp_scalars(bl_lds_f(BL_OFF_COEF)[n_species * BL_SP_COEF(KS, KO) + 1], fp_mode == 1);
-        bl_eval_sites_fp<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
+        if (lane_grp > 0) bl_eval_sites_grp<KS, KO, CW * 64, true>(ct, ld_or_stride, cnt, T, J, lane_grp, fp, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
+        else bl_eval_sites_fp<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
         bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi, row_stride, sp * BL_SP_PART(KS, KO));
     } else if constexpr (MODEL == 4) {
         static_assert(LDS, "N-mixture model: LDS records only");
@@ -1166,7 +1308,7 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
                 for (int k = 0; k <= KS; k++) { bq[b][k] = c[b * (KS + 1) + k]; gq[b][k] = 0.0f; }
 #pragma unroll
             for (int k = 0; k <= KO; k++) alpha[k] = c[BL_DYN_OA(KS) + k];
-            bl_eval_sites_dyn<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, dyn_g, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
+            bl_eval_sites_dyn<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, lane_grp, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
             bl_wave_partials_dyn<KS, KO>(cwave, ll, gq, ga);
         }
     } else if constexpr (MODEL == 1) {
@@ -1180,7 +1322,15 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         bl_eval_sites_cop<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi);
         bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi);
     } else {
-        bl_eval_sites<KS, KO, LDS, MODEL, CW * 64>(ct, grows, ld_or_stride, cnt, T, J, max_abundance, beta, alpha, ll, gb, ga, sp * sp_lds);
+        bool grouped = false;
+        if constexpr (LDS) {
+            if (lane_grp > 0) { // lane groups over the visits (wave-uniform)
+                float gphi = 0.0f;
+                bl_eval_sites_grp<KS, KO, CW * 64, false>(ct, ld_or_stride, cnt, T, J, lane_grp, BlFpScalars{}, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
+                grouped = true;
+            }
+        }
+        if (!grouped) bl_eval_sites<KS, KO, LDS, MODEL, CW * 64>(ct, grows, ld_or_stride, cnt, T, J, max_abundance, beta, alpha, ll, gb, ga, sp * sp_lds);
         bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga, 0.0f, row_stride, sp * BL_SP_PART(KS, KO));
     }
     }

@@ -103,6 +103,7 @@ class NutsResult:
     threads_per_wg: int = 0       # 64 x (compute waves + 1 control wave)
     lds_vector_tier: int = 0      # random-effects / occu_cs kernels: sampler vectors kept in LDS (0 none, 1 the leaf in flight, 2 all a leapfrog touches)
     comm_init_ms: float = 0.0     # fit(devices=[...]): wall time of ncclCommInitAll (outside the sampling clock)
+    lane_group: tuple = (1, 1)    # lanes that shared one site pair: (period lanes, visit lanes); (1, 1) = one pair per lane
 
 
 class OccuDataset:
@@ -365,9 +366,12 @@ class OccuDataset:
     def _result(self, a) -> NutsResult:
         k, thr, lds, staged, loc = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
         _ffi.check(self._lib.bl_nuts_geometry(self._h, C.byref(k), C.byref(thr), C.byref(lds), C.byref(staged), C.byref(loc)))
+        gt, gj = C.c_int(1), C.c_int(1)
+        _ffi.check(self._lib.bl_nuts_lane_group(self._h, C.byref(gt), C.byref(gj)))
         return NutsResult(a["draws"], a["diverging"].astype(bool), a["num_steps"], a["accept_prob"], a["potential_energy"],
                           a["step_size"], a["inv_mass"], a["n_leapfrog"], self.elapsed_ms(),
-                          k.value, lds.value, bool(staged.value & 1), loc.value, thr.value, staged.value >> 1)
+                          k.value, lds.value, bool(staged.value & 1), loc.value, thr.value, staged.value >> 1,
+                          lane_group=(int(gt.value), int(gj.value)))
 
     def fetch(self) -> NutsResult:
         Cn, S = self._shape

@@ -7,6 +7,7 @@ calls ``mcmc.run`` (fit.py:92-130), this lowers the model onto the C-ABI in
 """
 from __future__ import annotations
 
+import os
 import time
 from collections import namedtuple
 from typing import Callable, Optional
@@ -38,8 +39,8 @@ def fit(
 ) -> FitResult:
     """Fit an occupancy model with NUTS on an MI355X.
 
-    Parameters are those of the reference ``fit`` (fit.py:33-66).  ``model_fn`` must be
-    :func:`biolith_amd.models.occu` or :func:`biolith_amd.models.occu_rn`.  ``kernel`` must be ``None`` or ``"nuts"``; ``init_strategy``
+    Parameters are those of the reference ``fit`` (fit.py:33-66).  ``model_fn`` must be one of ``biolith_amd.models``' model functions
+    (``occu``, ``occu_rn``, ``occu_cop``, ``nmixture``, ``occu_cs``, and the builder-defined ``occu_dyn``).  ``kernel`` must be ``None`` or ``"nuts"``; ``init_strategy``
     must be ``None`` (= ``init_to_uniform``, fit.py:93).  Extra keyword arguments go to the model,
     plus engine knobs that the reference does not have: ``device`` (GPU index, default 0), ``devices``
     (list of GPU indices: the chains are dealt over them in contiguous blocks and sampled concurrently,
@@ -126,12 +127,13 @@ def fit(
         jobs = make_jobs(False)
     n_units = 1 if joint else n_species
 
-    def run_all(wgs_per_chain=0):
+    def run_all(wgs_per_chain=None):
+        # (wgs_per_chain: one entry per job -- the engine-timeout retry below -- or None = the engine's own choice)
         t_end = None if timeout is None else time.monotonic() + float(timeout) + 1.0
         launched = []
         try:
-            for _, ds, kw in jobs:   # launches on one device queue behind each other, devices overlap
-                ds.launch(**kw, wgs_per_chain=wgs_per_chain)
+            for j, (_, ds, kw) in enumerate(jobs):   # launches on one device queue behind each other, devices overlap
+                ds.launch(**kw, wgs_per_chain=0 if wgs_per_chain is None else wgs_per_chain[j])
                 launched.append(ds)
             for ds in launched:
                 while t_end is not None and not ds.done():
@@ -162,7 +164,9 @@ def fit(
     # timeout starts; their cost is reported in mcmc.result.comm_init_ms).  A device named twice (tests on a one-GPU box)
     # cannot hold two RCCL ranks: the shards are then fetched one by one and concatenated on the host.
     used = [dev for r, dev in enumerate(devices) if shard_chains(num_chains, world, r)[0] > 0]
-    use_rccl = explicit_devices and len(set(used)) == len(used)
+    # (BIOLITH_RCCL_LIB names another collective library: tests only -- tests/fake_rccl, a double of the collective that lets the
+    # several-ranks branch of bl_gather_draws run on a one-GPU box; whether it takes a device twice is then its to answer)
+    use_rccl = explicit_devices and (len(set(used)) == len(used) or bool(os.environ.get("BIOLITH_RCCL_LIB")))
     comms = []
     if use_rccl:
         from .._ffi import BL_ERR_COMM, EngineError
@@ -180,33 +184,45 @@ def fit(
             warnings.warn(f"fit(devices={devices}): no RCCL communicator ({exc}); gathering the chains on the host instead", RuntimeWarning)
             use_rccl = False
 
+    def run_retrying():
+        try:
+            return run_all()
+        except TimeoutError as exc:
+            # BL_ERR_TIMEOUT from the ENGINE (not the caller's time limit, which says "Timed out"): a chain's workgroups spin on each
+            # other's partial sums and must all be resident; on a shared or profiled device they may not be.  One fresh launch on half
+            # the workgroups per chain -- every job's own count halved; nothing of the failed launch is reused -- before giving up.
+            # (A halved count whose slices no longer fit LDS is raised again by the engine for the LDS-only models; should the second
+            # launch be refused all the same, the caller sees the ORIGINAL timeout, with the refusal as its cause.)
+            if not str(exc).startswith("biolith_hip:"):
+                raise
+            ks = [ds.wgs_per_chain() for _, ds, _ in jobs]
+            if max(ks) <= 1:
+                raise
+            import warnings
+
+            half = [max(1, k // 2) for k in ks]
+            warnings.warn(f"fit(): the engine's exchange timed out with {max(ks)} workgroups per chain ({exc}); retrying once with {max(half)}", RuntimeWarning)
+            try:
+                return run_all(wgs_per_chain=half)
+            except TimeoutError:
+                raise
+            except Exception as second:  # noqa: BLE001 -- the retry's own refusal must not mask the timeout
+                raise exc from second
+
     def run_with_fallback():
         # Joint sampling of several species needs all species' records in LDS for the chain count asked for; that is decided by the
         # launch (geometry depends on num_chains), which refuses with BL_ERR_UNSUPPORTED before anything runs.  Plain occu then
         # falls back to one dataset and one sampler per species, as documented above (same marginals).
         nonlocal jobs, joint, n_units
         try:
-            return run_all()
+            return run_retrying()
         except NotImplementedError:
             if not joint or spec.model != "occu":
                 raise
             joint = False
             jobs = make_jobs(False)
             n_units = n_species
-            return run_all()
-        except TimeoutError as exc:
-            # BL_ERR_TIMEOUT from the ENGINE (not the caller's time limit, which says "Timed out"): a chain's workgroups spin on each
-            # other's partial sums and must all be resident; on a shared or profiled device they may not be.  One fresh launch on half
-            # the workgroups per chain (nothing of the failed launch is reused) before giving up.
-            if not str(exc).startswith("biolith_hip:"):
-                raise
-            k = jobs[0][1].wgs_per_chain()
-            if k <= 1:
-                raise
-            import warnings
-
-            warnings.warn(f"fit(): the engine's exchange timed out with {k} workgroups per chain ({exc}); retrying once with {k // 2}", RuntimeWarning)
-            return run_all(wgs_per_chain=max(1, k // 2))
+            return run_retrying()
 
     try:
         if timeout is not None:

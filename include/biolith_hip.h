@@ -276,6 +276,12 @@ int bl_nuts_device_draws(bl_dataset *ds, void **dev_ptr, size_t *bytes);
 int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads_per_wg, int *lds_bytes, int *lds_staged,
                      int *chains_on_l2_local_exchange);
 
+/* Lanes that shared one site pair in the last launch (1, 1 = one pair per lane): period_lanes split the pair's periods, visit_lanes
+ * the visits of a period -- the layout SURVEY.md 7.1 asks for when a site has many visits (simulate() defaults: 52 per site,
+ * biolith/models/occu.py:251-252, 336; benchmarks/occu_spoccupancy.py:16-70: up to 90).  Environment knobs for tests and A/B
+ * runs: BIOLITH_HIP_OCCU_G = 1 | 2 | 4 | 8 | 16 forces the lanes per pair, BIOLITH_HIP_OCCU_GT the log2 of the period lanes. */
+int bl_nuts_lane_group(bl_dataset *ds, int *period_lanes, int *visit_lanes);
+
 /* Page-locked host memory for large outputs (bl_deterministic / bl_predict write into caller memory; into page-locked memory the
  * device copies at PCIe rate instead of staging through the runtime's bounce buffers).  The caller owns and frees it.  The
  * reference's counterpart is jax.device_get() of a deterministic site (utils/fit.py:132). */
