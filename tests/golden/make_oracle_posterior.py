@@ -6,7 +6,7 @@ once here: MAP + Laplace sd (BFGS on the analytic gradient) and 4 chains x (1000
 NUTS.  GPU tests compare the HIP engine's full-size posterior with these numbers.
 Run:  python tests/golden/make_oracle_posterior.py [cfg2|cfg4|cfg5]     (about a minute on 4 cores; cfg4: a quarter of an hour)
 cfg4 = BASELINE.json configs[3]: occu_rn, simulate_rn(5000 sites x 10 visits, 3 + 3 covariates), max_abundance 100, 4 chains x (500 + 500).
-cfg5 = the stacked-period stand-in of BASELINE.json configs[4] (2000 sites x 8 periods x 4 visits), 4 chains x (500 + 500).
+cfg5 = the stacked-period stand-in of BASELINE.json configs[4] (2000 sites x 8 periods x 4 visits), 4 chains x (1000 + 1000).
 """
 import json
 import os
@@ -32,7 +32,7 @@ CFG4 = dict(n_sites=5000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=
 
 
 def main(which="cfg2"):
-    cfg, W, S = {"cfg2": (CFG2, 1000, 1000), "cfg4": (CFG4, 500, 500), "cfg5": (CFG5, 500, 500)}[which]
+    cfg, W, S = {"cfg2": (CFG2, 1000, 1000), "cfg4": (CFG4, 500, 500), "cfg5": (CFG5, 1000, 1000)}[which]
     if which == "cfg4":
         import contextlib
         import io

@@ -19,8 +19,10 @@ CFG5 = dict(n_sites=2000, n_periods=8, n_site_covs=3, n_obs_covs=3, deployment_d
 def test_config5_standin_at_size_no_reference_counterpart():
     """BASELINE.json configs[4] names a dynamic (colonisation / extinction) model that the reference does NOT have (SURVEY.md
     section 0.7): NO REFERENCE COUNTERPART.  The nearest reference behaviour is stacked periods sharing psi (occu.py:198-210),
-    run here at the stated size 2000 sites x 8 periods x 4 visits: K1 parity, first trees, and 4 x (500 + 500) against the
-    oracle's captured posterior (tests/golden/oracle_posterior_cfg5.json, make_oracle_posterior.py cfg5)."""
+    run here at the stated size 2000 sites x 8 periods x 4 visits: K1 parity, first trees, and 4 x (500 + 2000) against the
+    oracle's captured posterior (tests/golden/oracle_posterior_cfg5.json, make_oracle_posterior.py cfg5: 4 x (1000 + 1000)) at
+    SURVEY.md section 8c's tolerances -- mean within 4 MCSE, sd within 10 %, split R-hat < 1.01 -- as everywhere else.
+    (Round 4: the kernel shares a site pair among 8 lanes here -- one period each -- occu_device.hpp: bl_eval_sites_grp.)"""
     data, truth, _ = quiet_simulate(**CFG5)
     assert data["obs"].shape == (1, 2000, 8, 4)
     od = oracle.OracleData(data["site_covs"], data["obs_covs"], data["obs"])
@@ -35,15 +37,16 @@ def test_config5_standin_at_size_no_reference_counterpart():
     assert np.array_equal(o["num_steps"][:, :3], r.num_steps[:, :3]), (o["num_steps"], r.num_steps)
     assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=2e-3)
     fx = json.load(open(os.path.join(GOLDEN, "oracle_posterior_cfg5.json")))
-    r = ds.nuts(num_warmup=500, num_samples=500, num_chains=4, seed=0)
+    r = ds.nuts(num_warmup=500, num_samples=2000, num_chains=4, seed=0)
     assert r.lds_staged and r.diverging.sum() == 0
+    assert r.lane_group[0] * r.lane_group[1] > 1, r.lane_group   # 32 visits per site: lanes share a pair
     flat = r.draws.reshape(-1, od.D).astype(np.float64)
     mcse = np.sqrt(flat.var(0) / effective_sample_size(r.draws) + np.array(fx["sd"]) ** 2 / np.array(fx["ess"]))
     assert np.all(np.abs(flat.mean(0) - fx["mean"]) <= 4 * mcse), (flat.mean(0) - fx["mean"], mcse)
-    assert np.all(np.abs(flat.std(0) / fx["sd"] - 1) < 0.15)
+    assert np.all(np.abs(flat.std(0) / fx["sd"] - 1) < 0.1)
     assert np.all(np.abs(flat.mean(0) - fx["map"]) < 3 * np.array(fx["laplace_sd"]))
-    assert split_gelman_rubin(r.draws).max() < 1.02
-    assert abs(r.num_steps.mean() / fx["mean_num_steps"] - 1) < 0.2
+    assert split_gelman_rubin(r.draws).max() < 1.01
+    assert abs(r.num_steps.mean() / fx["mean_num_steps"] - 1) < 0.15
     psi, _ = ds.deterministic(flat[::10])
     assert abs(psi.mean() - truth["z"].mean()) < 0.1
 

@@ -99,3 +99,26 @@ def test_config3_analogue_eight_chains_one_launch_vs_shards_vs_gather(cfg2_data)
     assert np.all(np.abs(flat.std(0) / fx["sd"] - 1) < 0.1)
     assert split_gelman_rubin(one.draws).max() < 1.01
     assert abs(float(via_fit.samples["psi"].mean()) - truth["z"].mean()) < 0.1     # occu.py:440
+
+
+def test_config3_as_worded_one_chain_per_rank_through_the_bench_shard(cfg2_data):
+    """BASELINE.json configs[2] verbatim is `bench.py --gpus 8 --chains-per-gpu 1`: rank r runs ONE chain, global id r.  On one GPU:
+    the shard bench.py's `rank_shard` hands rank r of 8 (what its `one_step` launches with), for r = 0..7, against the 8-chain
+    launch -- bit-equal -- and the flag's plumbing (`workload_chains`)."""
+    import bench
+
+    wl = bench.WORKLOADS["occu"]
+    assert bench.workload_chains(wl) == 4 and bench.workload_chains(wl, 1) == 1 and bench.workload_chains(bench.WORKLOADS["occu_cfg1"]) == 2
+    assert bench.parse_args(["--gpus", "8", "--chains-per-gpu", "1"]).chains_per_gpu == 1
+    data, _ = cfg2_data
+    ds = OccuDataset(data["site_covs"], data["obs_covs"], data["obs"])
+    W = S = 300
+    one = ds.nuts(num_warmup=W, num_samples=S, num_chains=8, seed=0)
+    for r in range(8):
+        shard = bench.rank_shard(r, bench.workload_chains(wl, 1))
+        assert shard == dict(num_chains=1, chain_offset=r)
+        got = ds.nuts(num_warmup=W, num_samples=S, seed=0, **shard)
+        assert np.array_equal(got.draws[0], one.draws[r]) and np.array_equal(got.num_steps[0], one.num_steps[r]), r
+    # (4 chains per GPU, the default: rank 1 of 2 runs chains 4..7)
+    got = ds.nuts(num_warmup=W, num_samples=S, seed=0, **bench.rank_shard(1, 4))
+    assert np.array_equal(got.draws, one.draws[4:8])
