@@ -646,6 +646,17 @@ def main(argv=None):
             "note": "data is LDS-resident after one HBM read, so this is an effective (algorithmic) bandwidth; "
                     "the sequential-leapfrog latency (us_per_leapfrog_per_chain) is the real bound",
         }
+        if name == "occu":
+            # the tick's floor as numbers (in-kernel stamps, profiles/r04/c_stamps.txt).  A leaf tick =
+            # one site evaluation (2 250-2 400 cycles, ~1 430 of them issue cycles of one wave on its own SIMD) + the hand-off to the chain's other
+            # workgroups (publish, ONE L2 round trip of 663-674 cycles at 1.4 poll rounds, f64 sums and folds: 1 530-1 610) + the speculative
+            # position (180) + two barriers: ~4 600 cycles at 2.39 GHz.  What is measured above it is NumPyro's sequential bookkeeping at subtree
+            # and transition ends (an evaluation dropped and redone per transition: ~570 cycles per leapfrog at 6.2 leapfrogs per transition).
+            roofline["latency_floor_us"] = 1.9
+            roofline["latency_floor_note"] = ("leaf tick from in-kernel stamps (profiles/r04/c_stamps.txt): site evaluation 2 250-2 400 cycles + "
+                                              "hand-off through L2 1 530-1 610 (one 663-674-cycle round trip at 1.4 poll rounds + sums) + speculative "
+                                              "position 180 + barriers, at 2.39 GHz; the rest of us_per_leapfrog_per_chain is NumPyro's bookkeeping at "
+                                              "subtree / transition ends; three A/Bs on the tick in round 4 moved nothing (profiles/NOTES.md)")
         if wl["model"] == "occu_rn":
             # config 4 is VALU-transcendental-bound (about 5 M enumerated (site, visit, n) terms per evaluation,
             # one transcendental each), not HBM-bound.  Peak = quarter-rate transcendental issue of the CUs the launch occupies.

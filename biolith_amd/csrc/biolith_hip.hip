@@ -925,7 +925,7 @@ static int dyn_lanes_per_pair(const bl_dataset *ds, int chains)
     const long long npairs = (ds->dims.n_sites + 1) / 2;
     int G = 1;
     while (2 * G <= 8 && 2 * G <= ds->dims.n_periods) G *= 2;
-    while (G > 1 && npairs * G > (long long)kmax * 3 * 64) G >>= 1;
+    while (G > 1 && npairs * G > (long long)kmax * 4 * 64) G >>= 1; // (round 4: up to four compute waves per workgroup)
     if (const char *e = getenv("BIOLITH_HIP_DYN_G")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) G = v; } // A/B knob
     return G;
 }
@@ -959,6 +959,32 @@ static int occu_lane_group(const bl_dataset *ds, int chains, int want_k)
     return lgt | (lgj << 4);
 }
 
+// Small problems (plain model and false positives): the whole chain on ONE workgroup of BL_CWAVES_SINGLE compute waves -- no exchange
+// through L2 at all (nuts_kernel.hpp: the k == 1 path), the site pairs shared among as many lanes as the 448 offer.  Taken when a lane
+// is then left with at most BL_SINGLE_VISITS visits of its pair and the records fit one CU's LDS.  Returns the lane-group code or -1.
+#define BL_SINGLE_VISITS 8
+static int occu_single_workgroup(const bl_dataset *ds, int want_k)
+{
+    if ((ds->model != 0 && ds->model != 2) || want_k > 0 || ds->nsp > 1) return -1; // (several species: the partial table is sized for 4 waves)
+    if (const char *e = getenv("BIOLITH_HIP_SINGLE")) { if (e[0] == '0') return -1; } // A/B knob
+    const int T = ds->dims.n_periods, J = ds->dims.n_replicates;
+    const long long V = (long long)T * J, npairs = (ds->dims.n_sites + 1) / 2, lanes = BL_CWAVES_SINGLE * 64;
+    if (npairs > lanes) return -1;
+    int lg = 0;
+    while (lg < 4 && (npairs << (lg + 1)) <= lanes && ((V + (1 << lg) - 1) >> lg) > 1) lg++;
+    if (((V + (1 << lg) - 1) >> lg) > BL_SINGLE_VISITS) return -1;
+    if (const char *e = getenv("BIOLITH_HIP_OCCU_G")) { // tests / A/B: force the lanes per pair
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) { lg = 0; while ((1 << lg) < v) lg++; }
+    }
+    int lgt = 0;
+    while (lgt < lg && (2 << lgt) <= T) lgt++;
+    if (const char *e = getenv("BIOLITH_HIP_OCCU_GT")) { const int v = atoi(e); if (v >= 0 && v <= lg) lgt = v; }
+    int lgj = lg - lgt;
+    while (lgj > 0 && (1 << (lgj - 1)) >= J) lgj--;
+    return lgt | (lgj << 4);
+}
+
 static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k_out, int *nloc_out, int *ld_out,
                             int *lds_bytes_out, int *staged_out, int *ncw_out, int *wide_out, int *grp_out = nullptr)
 {
@@ -988,11 +1014,21 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
             if (built) ncw = v;
         }
         per_wg = std::max(2, 2 * ncw * 64 / G);
-        if (ds->model == 8) { ncw = 3; per_wg = 2 * 3 * 64 / dyn_lanes_per_pair(ds, chains); } // one site pair per lane group
+        if (ds->model == 8) { // one site pair per lane group; three compute waves while the chain's workgroups offer the lanes, else four
+            const int Gd = dyn_lanes_per_pair(ds, chains);
+            ncw = (((long long)N * Gd + 2 * 3 * 64 - 1) / (2 * 3 * 64) <= kmax) ? 3 : 4;
+            if (const char *e = getenv("BIOLITH_HIP_CWAVES")) { const int v = atoi(e); if (v == 3 || v == 4) ncw = v; }
+            per_wg = std::max(2, 2 * ncw * 64 / Gd);
+        }
     }
     int k = want_k > 0 ? want_k : (N + per_wg - 1) / per_wg;
     if (k > kmax) k = kmax;
     if (k < 1) k = 1;
+    const int single_grp = occu_single_workgroup(ds, want_k);
+    if (single_grp >= 0 && (long long)((N + 1) / 2) * bl_record_stride(ds->dims.n_periods, ds->dims.n_replicates, ds->KS, ds->ko_layout) * 4 * ds->nsp
+                               <= BL_LDS_TOTAL - BL_OFF_DATA) {
+        k = 1; ncw = BL_CWAVES_SINGLE; grp = single_grp; // one workgroup per chain: no exchange
+    }
     // behind the records: occu_rn's tables; the dynamic model's lane-private columns (sized for 4 compute waves: ncw is settled below)
     const int rn_scratch = ds->model == 1 ? bl_rn_scratch_bytes(BL_CWAVES_RN) : (ds->model == 8 ? bl_dyn_scratch_bytes(ds->dims.n_periods, 4) : 0);
     const int lds_cap = BL_LDS_TOTAL - BL_OFF_DATA - rn_scratch;

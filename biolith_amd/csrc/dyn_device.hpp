@@ -29,7 +29,8 @@
 
 // bytes of LDS behind the staged records: two float2 per period and compute lane (the lane's forward / smoothed columns), and one
 // more per period and lane GROUP for the periods' visit sums that the lanes of a group hand each other (host: choose_geometry)
-__host__ __device__ inline int bl_dyn_scratch_bytes(int T, int cw) { return T * 3 * 8 * cw * 64; }
+// (round 4: two more float2 per period and lane group -- the scaled likelihoods of bl_eval_sites_dyn_scaled; sized for one lane per group)
+__host__ __device__ inline int bl_dyn_scratch_bytes(int T, int cw) { return T * 4 * 8 * cw * 64; }
 // coefficient / partial-sum layout of MODEL 8 (LDS coefficient block and a wave's row of the partial table alike):
 // block b in {psi 0, gamma 1, eps 2}: coefficient k at b (KS + 1) + k;  alpha_k at 3 (KS + 1) + k;  the log-lik at 3 (KS + 1) + KO + 1
 #define BL_DYN_OA(KS) (3 * ((KS) + 1))
@@ -184,6 +185,166 @@ __device__ __forceinline__ void bl_eval_sites_dyn(int ct, int pstride, int cnt, 
     for (int k = 0; k <= KO; k++) ga[k] += ga2[k].x + ga2[k].y;
 }
 
+// Round 4: the same sums for at most TWO periods per lane of a group (T <= 2 G: the host picks G accordingly), restructured around
+// what the first form spent its time on -- (a) the visits were evaluated twice (log-likelihood, then the gradient once the smoothed
+// marginals were known): a lane now keeps its periods' gradient sums g_t[k] = sum_j sigma(-u_j) (c, c w)_j in registers and scales
+// them by rho_t at the end, d/d alpha = sum_t rho_t g_t; (b) every step of the forward recursion was a chain of six dependent
+// transcendentals (log pi, log(1 - pi), exp, log, rcp, ...): the recursion now runs on SCALED likelihoods, the standard normalised
+// forward algorithm -- E1_t = exp(a_t - m_t), E0_t = exp(kb_t - m_t), m_t = max(a_t, kb_t), computed by the period's lane beside its
+// visit pass -- so that a step is  c = pi E1 + (1 - pi) E0,  phi = pi E1 / c,  pi' = gamma + phi (1 - eps - gamma): ONE reciprocal on
+// the chain; the log-likelihood sum_t (m_t + log c_t) is added by the lane that owns period t (its own one or two logs, off the chain).
+// The backward recursion is the first form's.  Same records, same scratch region (two more float2 per period and group).
+template <int KS, int KO, int CT>
+__device__ __forceinline__ void bl_eval_sites_dyn_scaled(int ct, int pstride, int cnt, int T, int J, int G, int scratch_off,
+                                                         const float (&bpsi)[KS + 1], const float (&bgam)[KS + 1], const float (&beps)[KS + 1],
+                                                         const float (&alpha)[KO + 1],
+                                                         float &ll, float (&gb)[3][KS + 1], float (&ga)[KO + 1])
+{
+    constexpr int XQ = (KS + 3) & ~3;
+    const int pb = bl_period_block(J, KO);
+    const float *data = bl_lds_f(BL_OFF_DATA);
+    float2 *col = reinterpret_cast<float2 *>(bl_smem_raw + scratch_off) + ct; // lane-private: element (t, which): col[(2 t + which) * CT]
+    const int sub = ct & (G - 1), slot = ct / G, nslots = CT / G;
+    float2 *ecol = reinterpret_cast<float2 *>(bl_smem_raw + scratch_off) + 2 * T * CT + slot; // the group's (E1_t, E0_t): ecol[(2 t + which) * nslots]
+    const float first = sub == 0 ? 1.0f : 0.0f; // (per-site sums, formed by every lane of the group alike, are counted by its first lane)
+    const int npairs = (cnt + 1) >> 1;
+    const int rounds = (npairs + nslots - 1) / nslots;
+    bl_f2 ll2 = bl2(0.0f), gb2[3][KS + 1], ga2[KO + 1];
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+        for (int k = 0; k <= KS; k++) gb2[b][k] = bl2(0.0f);
+#pragma unroll
+    for (int k = 0; k <= KO; k++) ga2[k] = bl2(0.0f);
+    for (int rd = 0; rd < rounds; rd++) {
+        const int m_raw = rd * nslots + slot;
+        const int m = min(m_raw, npairs - 1);
+        const float live = m_raw < npairs ? 1.0f : 0.0f;
+        const float2 *rec = reinterpret_cast<const float2 *>(data + (size_t)m * pstride);
+        const float second = (2 * m + 1 < cnt) ? live : 0.0f; // odd slice: the last pair's second site is a dummy
+        const bl_f2 vm_own = bl_f2{live, second}, vm_site = bl_f2{live * first, second * first};
+        bl_f2 x[KS > 0 ? KS : 1];
+        bl_f2 e_psi = bl2(bpsi[0]), e_gam = bl2(bgam[0]), e_eps = bl2(beps[0]);
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            const float2 v = rec[k];
+            x[k] = bl_f2{v.x, v.y};
+            e_psi = bl_fma2(x[k], bl2(bpsi[k + 1]), e_psi);
+            e_gam = bl_fma2(x[k], bl2(bgam[k + 1]), e_gam);
+            e_eps = bl_fma2(x[k], bl2(beps[k + 1]), e_eps);
+        }
+        const bl_f2 gam = bl_sigmoid2(e_gam), eps = bl_sigmoid2(e_eps), psi = bl_sigmoid2(e_psi);
+        const bl_f2 stay = bl2(1.0f) - eps - gam;                                // pi_t+1 = gamma + phi_t (1 - eps - gamma)
+        // ---- this lane's periods t = sub, sub + G: visits (log-likelihood and gradient sums at once), scaled likelihoods -> LDS ----
+        bl_f2 gt[2][KO + 1], own_m[2], own_c[2], own_rho[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int t = sub + i * G;
+#pragma unroll
+            for (int k = 0; k <= KO; k++) gt[i][k] = bl2(0.0f);
+            own_m[i] = bl2(0.0f); own_c[i] = bl2(1.0f); own_rho[i] = bl2(0.0f);
+            if (t < T) {
+                const float2 *pp = rec + XQ + t * pb;
+                const float2 a_ = pp[J * (KO + 1)], kb_ = pp[J * (KO + 1) + 1];
+                bl_f2 a = bl_f2{a_.x, a_.y};                   // ka: cancels the log sigma(0) of the masked visits
+                const bl_f2 kb = bl_f2{kb_.x, kb_.y};
+#pragma unroll 2
+                for (int j = 0; j < J; j++) {
+                    bl_f2 w[KO + 1];
+#pragma unroll
+                    for (int k = 0; k <= KO; k++) {
+                        const float2 v = pp[j * (KO + 1) + k];
+                        w[k] = bl_f2{v.x, v.y};
+                    }
+                    bl_visit2<KO>(w, alpha, a, gt[i]);
+                }
+                const bl_f2 mm = __builtin_elementwise_max(a, kb);
+                const bl_f2 E1 = bl_exp2_2((a - mm) * bl2(BL_LOG2E)), E0 = bl_exp2_2((kb - mm) * bl2(BL_LOG2E));
+                ecol[(2 * t) * nslots] = make_float2(E1.x, E1.y);
+                ecol[(2 * t + 1) * nslots] = make_float2(E0.x, E0.y);
+                own_m[i] = mm;
+            }
+        }
+        if (G > 1) bl_wave_lds_fence();
+        // ---- the scaled forward recursion (every lane of the group, all periods) ----
+        // One step's dependent chain is  c = E0 + pi (E1 - E0)  ->  1 / c  ->  phi = (pi E1) / c  ->  pi' = gamma + phi stay ; the next
+        // step's scaled likelihoods are loaded a step ahead (the compiler will not move an LDS load across the stores of the loop, so the
+        // order is written out here: without it every step paid an LDS round trip on top of its chain).
+        bl_f2 pi = psi, phi = bl2(0.0f);
+        float2 e1n = ecol[0], e0n = ecol[nslots];
+        for (int t = 0; t < T; t++) {
+            const bl_f2 E1 = bl_f2{e1n.x, e1n.y}, E0 = bl_f2{e0n.x, e0n.y};
+            const int tn = min(t + 1, T - 1);
+            e1n = ecol[(2 * tn) * nslots]; e0n = ecol[(2 * tn + 1) * nslots];
+            const bl_f2 a1 = pi * E1;
+            const bl_f2 c = __builtin_elementwise_max(bl_fma2(pi, E1 - E0, E0), bl2(1e-37f)); // P(y_t | y_1..t-1) / e^m_t  (> 0 unless pi left (0, 1) in f32)
+            phi = a1 * bl_rcp_2(c);                            // P(z_t = 1 | y_1..t)
+            const bl_f2 pin = bl_fma2(phi, stay, gam);         // P(z_t+1 = 1 | y_1..t)
+            col[(2 * t) * CT] = make_float2(phi.x, phi.y);
+            col[(2 * t + 1) * CT] = make_float2(pin.x, pin.y);
+            if (t == sub) own_c[0] = c;
+            if (t == sub + G) own_c[1] = c;
+            pi = pin;
+        }
+        // ---- backward: the smoothed marginals rho_t and the transitions' gradient sums ----
+        // With r1 = 1 / pi_t+1, r0 = 1 / (1 - pi_t+1) (0 where that state cannot be reached) the pairwise marginals are
+        //   xi(1,1) = rho r1 f (1 - eps),  xi(0,1) = rho r1 (1 - f) gamma,  xi(1,0) = (1 - rho) r0 f eps,  xi(0,0) = (1 - rho) r0 (1 - f)(1 - gamma),
+        // so  rho_t = xi(1,1) + xi(1,0) = A0 + rho (A1 - A0)  with A1 = r1 f (1 - eps), A0 = r0 f eps -- ONE fma on the dependent chain --
+        // and with  Dl = rho r1 - (1 - rho) r0 :  d/d eta_gamma += (1 - f) gamma (1 - gamma) Dl,  d/d eta_eps -= f eps (1 - eps) Dl
+        // (the first form's xi(0,1)(1 - gamma) - xi(0,0) gamma and xi(1,0)(1 - eps) - xi(1,1) eps, factored).  Everything but the fma hangs
+        // off (f, pi_t+1), which are loaded a step ahead.
+        bl_f2 rho = phi, d_gam = bl2(0.0f), d_eps = bl2(0.0f);
+        if (T - 1 == sub) own_rho[0] = rho;
+        if (T - 1 == sub + G) own_rho[1] = rho;
+        const bl_f2 g1g = gam * (bl2(1.0f) - gam), e1e = eps * (bl2(1.0f) - eps);
+        {
+            const int t0 = max(T - 2, 0);
+            float2 fn = col[(2 * t0) * CT], pn = col[(2 * t0 + 1) * CT];
+            for (int t = T - 2; t >= 0; t--) {
+                const bl_f2 f = bl_f2{fn.x, fn.y}, p1 = bl_f2{pn.x, pn.y};
+                const int tp = max(t - 1, 0);
+                fn = col[(2 * tp) * CT]; pn = col[(2 * tp + 1) * CT];
+                const bl_f2 q1 = bl_rcp_2(p1), q0 = bl_rcp_2(bl2(1.0f) - p1);
+                const bl_f2 r1 = bl_f2{p1.x > 0.0f ? q1.x : 0.0f, p1.y > 0.0f ? q1.y : 0.0f};
+                const bl_f2 r0 = bl_f2{p1.x < 1.0f ? q0.x : 0.0f, p1.y < 1.0f ? q0.y : 0.0f};
+                const bl_f2 A1 = r1 * f * (bl2(1.0f) - eps), A0 = r0 * f * eps;
+                const bl_f2 Dl = bl_fma2(rho, r1 + r0, -r0);
+                d_gam = bl_fma2((bl2(1.0f) - f) * g1g, Dl, d_gam);
+                d_eps = bl_fma2(f * e1e, -Dl, d_eps);
+                rho = bl_fma2(rho, A1 - A0, A0);
+                if (t == sub) own_rho[0] = rho;
+                if (t == sub + G) own_rho[1] = rho;
+            }
+        }
+        if (G > 1) bl_wave_lds_fence(); // (the next round's scaled likelihoods overwrite this round's)
+        // ---- this lane's periods: log-likelihood terms m_t + log c_t, d/d alpha = rho_t g_t ----
+        bl_f2 lown = bl2(0.0f);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float valid = sub + i * G < T ? 1.0f : 0.0f;
+            lown += bl_fma2(bl_log2_2(own_c[i]), bl2(BL_LN2), own_m[i]) * bl2(valid);
+            const bl_f2 rt = own_rho[i] * vm_own; // (a masked visit or the dummy site: its w = 0 anyway)
+#pragma unroll
+            for (int k = 0; k <= KO; k++) ga2[k] = bl_fma2(rt, gt[i][k], ga2[k]);
+        }
+        ll2 = bl_fma2(lown, vm_own, ll2);
+        const bl_f2 dv[3] = {(rho - psi) * vm_site, d_gam * vm_site, d_eps * vm_site};
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            gb2[b][0] += dv[b];
+#pragma unroll
+            for (int k = 0; k < KS; k++) gb2[b][k + 1] = bl_fma2(dv[b], x[k], gb2[b][k + 1]);
+        }
+    }
+    ll += ll2.x + ll2.y;
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+        for (int k = 0; k <= KS; k++) gb[b][k] += gb2[b][k].x + gb2[b][k].y;
+#pragma unroll
+    for (int k = 0; k <= KO; k++) ga[k] += ga2[k].x + ga2[k].y;
+}
+
 // Wave reduction of (gb[3], ga, ll) -> this wave's row of the LDS partial table in the MODEL 8 layout (one interleaved DPP butterfly)
 template <int KS, int KO>
 __device__ __forceinline__ void bl_wave_partials_dyn(int cwave, float ll, const float (&gb)[3][KS + 1], const float (&ga)[KO + 1])
@@ -199,10 +360,27 @@ __device__ __forceinline__ void bl_wave_partials_dyn(int cwave, float ll, const 
 #pragma unroll
     for (int k = 0; k <= KO; k++) v[BL_DYN_OA(KS) + k] = ga[k];
     v[BL_DYN_LL(KS, KO)] = ll;
+    if constexpr (NV > 16 && NV <= 20) {
+        // (round 4) the first sixteen as a reduce-scatter (occu_device.hpp: 35 instructions instead of the butterfly's 96), the rest one by one
+        float head[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) head[k] = v[k];
+        const float y = bl_wave_reduce_scatter<16>(head);
+        const int g = lane >> 2;
+        const int k = (int)(BlScatter<16>::slots() >> (4 * g)) & 15;
+        float *part = bl_lds_f(BL_OFF_PART) + cwave * BL_PART_STRIDE;
+        if ((lane & 3) == 0 && ((BlScatter<16>::stores() >> g) & 1u)) part[k] = y;
+#pragma unroll
+        for (int i = 16; i < NV; i++) {
+            const float t = bl_wave_sum(v[i]);
+            if (lane == 0) part[i] = t;
+        }
+    } else {
     bl_wave_sum_vec_l63<NV>(v);
     if (lane == 63) {
         float *part = bl_lds_f(BL_OFF_PART) + cwave * BL_PART_STRIDE;
 #pragma unroll
         for (int k = 0; k < NV; k++) part[k] = v[k];
+    }
     }
 }

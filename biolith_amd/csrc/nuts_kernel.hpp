@@ -649,6 +649,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             // accesses through LDS-address-space pointers: program order kept, ds_read / ds_write -- a volatile generic pointer makes
             // them flat_load / flat_store with system coherence bits.)
             epoch_c++;
+            if (p.k > 1) { // (one workgroup per chain: nothing to publish -- the control wave reads the rows from LDS behind the barrier)
             typedef __attribute__((address_space(3))) volatile unsigned BlLdsU;
             typedef __attribute__((address_space(3))) const volatile float BlLdsF;
             BlLdsU *tags = (BlLdsU *)bl_lds_i(BL_OFF_TAG);
@@ -692,6 +693,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                     else         // write-through: visible to any XCD
                         __hip_atomic_store(dst, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+            }
             }
             // (Measured and dropped: no barrier here -- the control wave polling straight after its decisions, a counter of coefficient
             // reads guarding the one write that the barrier ordered: 2 % slower, the poll loop competes with the evaluation's tail.)
@@ -794,7 +796,24 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             for (int z = 0; z < p.first_delay; z++) __builtin_amdgcn_s_sleep(1);
             double acc = 0.0;
             bool timed_out = false;
-            if (one_batch) {
+            if (p.k == 1) {
+                // ONE workgroup per chain (round 4; small problems -- simulate()'s defaults, the size of the reference's own tests): there is
+                // nobody to exchange with, so the hand-off through L2 (a store, a round trip, the sums: ~1 500 cycles of a 5 000-cycle tick)
+                // is skipped and the waves' rows are added straight from LDS -- complete and visible behind the barrier above.  Same fixed
+                // wave order as the publishing wave's sum.
+                const float *part = bl_lds_f(BL_OFF_PART) + part_pos;
+                float comp = part[0];
+#pragma unroll
+                for (int w = 1; w < CW; w++) comp += part[w * part_rs];
+                for (int sp = 1; sp < nsp; sp++) {
+#pragma unroll
+                    for (int w = 0; w < CW; w++) comp += part_all ? part[w * part_rs + sp * BL_SP_PART(KS, KO)] : 0.0f;
+                }
+                if (lane > D) comp = 0.0f;
+                if (lane == D + 1 && (epoch & 255u) == 0u) // the host's abort request (fit(timeout=...))
+                    comp = (__hip_atomic_load(cold->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) ? 1.0f : 0.0f;
+                acc = (double)comp;
+            } else if (one_batch) {
                 // common shape: one round of <= 8 loads per lane covers all k records.  (Measured and dropped: two rounds in flight
                 // half a round trip apart, the first complete one taken -- 4-11 % slower: the waits on the second round's loads
                 // serialise behind the first's.)
@@ -856,8 +875,10 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             }
             // fold the 64/nvp lane groups (each summed a different subset of the workgroups): element-wise
             // across rows, by gfx950's v_permlane16_swap / v_permlane32_swap (one VALU op per 32-bit half)
-            if (nvp <= 16) acc = bl_fold_rows16_d(acc);
-            if (nvp <= 32) acc = bl_fold_halves32_d(acc);
+            if (p.k > 1) {
+                if (nvp <= 16) acc = bl_fold_rows16_d(acc);
+                if (nvp <= 32) acc = bl_fold_halves32_d(acc);
+            }
             BL_STAMP(3)
             if (epoch == 1u && p.allow_local) {
                 const double sx = bl_readlane_d(acc, D + 2), sxx = bl_readlane_d(acc, D + 3);

@@ -19,6 +19,9 @@
 //      N <= 384 sites per workgroup);
 // 4 -> all four SIMDs evaluate sites (larger slices, where the evaluation dominates the tick);
 // BL_CWAVES_RN -> occu_rn (rn_device.hpp): several waves per SIMD hide each other's LDS / exp / log / rcp latencies.
+// 7 (BL_CWAVES_SINGLE) -> a chain of ONE workgroup (small problems -- simulate()'s defaults, the reference's own test sizes): all of a CU's
+//      eight wave slots at two per SIMD, so that 448 lanes share the site pairs (lane groups) and nothing leaves the CU: no exchange.
+#define BL_CWAVES_SINGLE 7
 #define BL_CWAVES_MAX 4   // (of the kernels that sample several species jointly: sizes their partial table)
 #define BL_DIR_STREAM 62
 #define BL_MAX_DEPTH 10
@@ -1308,6 +1311,11 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
                 for (int k = 0; k <= KS; k++) { bq[b][k] = c[b * (KS + 1) + k]; gq[b][k] = 0.0f; }
 #pragma unroll
             for (int k = 0; k <= KO; k++) alpha[k] = c[BL_DYN_OA(KS) + k];
+            // (at most two periods per lane of a group: the one-visit-pass form on scaled likelihoods; BL_DYN_FORM1: the first form, for A/B)
+#ifndef BL_DYN_FORM1
+            if (T <= 2 * lane_grp) bl_eval_sites_dyn_scaled<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, lane_grp, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
+            else
+#endif
             bl_eval_sites_dyn<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, lane_grp, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
             bl_wave_partials_dyn<KS, KO>(cwave, ll, gq, ga);
         }

@@ -66,8 +66,6 @@ def predict(
         raise TypeError("predict(): model_fn must be a biolith_amd model (biolith_amd.models.occu / occu_rn)")
     infer_discrete = bool(infer_discrete)   # (same sites, same distribution: see the docstring)
     if infer_discrete:
-        import warnings
-
         # (the warnings module shows it once per call site) -- an UNVERIFIED upstream assumption: DESIGN.md section 3
         warnings.warn("predict(infer_discrete=True) runs the default ancestral path on the HIP engine: with `obs` withheld from the model "
                       "call (biolith/utils/predict.py:78-80) NumPyro's posterior draw of the discrete sites is taken to be their joint "

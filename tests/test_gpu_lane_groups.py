@@ -17,8 +17,12 @@ pytestmark = pytest.mark.gpu
 U_RTOL, G_RTOL = 1e-6, 1e-5
 
 
-@pytest.fixture
-def force_group(monkeypatch):
+@pytest.fixture(params=["single", "multi"])
+def force_group(monkeypatch, request):
+    """Forces the lanes per pair; once with the small problems' one-workgroup form allowed (k = 1, 7 compute waves, no exchange --
+    taken when the shape qualifies), once with it switched off (the multi-workgroup form at the same group size)."""
+    monkeypatch.setenv("BIOLITH_HIP_SINGLE", "1" if request.param == "single" else "0")
+
     def force(g, gt=None):
         monkeypatch.setenv("BIOLITH_HIP_OCCU_G", str(g))
         if gt is None:
@@ -99,14 +103,20 @@ def test_first_trees_are_the_oracles_for_every_group_size(name, seed, g, gt, for
     d = load_golden(name)
     od = oracle.OracleData(d["site_covs"], d["obs_covs"], d["obs"])
     ds = OccuDataset(d["site_covs"], d["obs_covs"], d["obs"])
+    force_group(g, gt)
+    want = (1 << (gt if gt is not None else 0))
+    # the very first transitions (no adaptation in front of them): the same trees, the same positions
+    o = oracle.nuts_run(od, 0, 4, num_chains=3, seed=seed)
+    r = ds.nuts(num_warmup=0, num_samples=4, num_chains=3, seed=seed)
+    assert r.lane_group[0] * r.lane_group[1] == g and (gt is None or r.lane_group[0] == want), r.lane_group
+    assert np.array_equal(o["num_steps"][:, :2], r.num_steps[:, :2]), (o["num_steps"], r.num_steps)
+    assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=2e-3)
+    # ... and through the first adaptation steps: float32-vs-float64 rounding is amplified by the dynamics by then (a U-turn test that
+    # is decided in the last bits may flip), so: most trees equal, positions and step sizes close
     W, S = 12, 8
     o = oracle.nuts_run(od, W, S, num_chains=3, seed=seed)
-    force_group(g, gt)
     r = ds.nuts(num_warmup=W, num_samples=S, num_chains=3, seed=seed)
-    want = (1 << (gt if gt is not None else 0))
-    assert r.lane_group[0] * r.lane_group[1] == g and (gt is None or r.lane_group[0] == want), r.lane_group
-    assert np.array_equal(o["num_steps"][:, :4], r.num_steps[:, :4]), (o["num_steps"], r.num_steps)
-    assert (o["num_steps"] == r.num_steps).mean() >= 0.8
+    assert (o["num_steps"] == r.num_steps).mean() >= 0.8, (o["num_steps"], r.num_steps)
     assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=2e-2)
     assert np.allclose(o["step_size"], r.step_size, rtol=0.05)
     ds.close()
@@ -139,7 +149,14 @@ def test_the_hosts_choice():
     d = load_golden("default")                      # 100 sites x 52 visits
     ds = OccuDataset(d["site_covs"], d["obs_covs"], d["obs"])
     r = ds.nuts(num_warmup=5, num_samples=5, num_chains=2, seed=0)
-    assert r.lane_group[0] == 1 and r.lane_group[1] >= 8 and r.wgs_per_chain > 1, (r.lane_group, r.wgs_per_chain)
+    # a small problem: the whole chain on ONE workgroup of 7 compute waves (no exchange), 8 lanes per pair
+    assert r.lane_group == (1, 8) and r.wgs_per_chain == 1 and r.threads_per_wg == 512, (r.lane_group, r.wgs_per_chain, r.threads_per_wg)
+    os.environ["BIOLITH_HIP_SINGLE"] = "0"          # ... and with that form switched off: several workgroups, 16 lanes per pair
+    try:
+        r = ds.nuts(num_warmup=5, num_samples=5, num_chains=2, seed=0)
+    finally:
+        del os.environ["BIOLITH_HIP_SINGLE"]
+    assert r.lane_group == (1, 16) and r.wgs_per_chain > 1 and r.threads_per_wg == 256, (r.lane_group, r.wgs_per_chain)
     ds.close()
     d = _stacked(2000)                              # 4 periods x 6 visits
     ds = OccuDataset(d["site_covs"], d["obs_covs"], d["obs"])

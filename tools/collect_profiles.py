@@ -12,7 +12,7 @@ def main():
     src, dst, pre = sys.argv[1], sys.argv[2], sys.argv[3]
     only = set(sys.argv[4:])
     os.makedirs(dst, exist_ok=True)
-    short = {"occu": "", "occu_rn": "_rn", "occu_re": "_re", "occu_stacked": "_stacked", "occu_dyn": "_dyn"}
+    short = {"occu": "", "occu_rn": "_rn", "occu_re": "_re", "occu_stacked": "_stacked", "occu_dyn": "_dyn", "occu_cfg1": "_cfg1"}
 
     def cp(a, b):
         if os.path.exists(a):
@@ -29,11 +29,12 @@ def main():
         cp(os.path.join(src, f"bench_{wl}_under_rocprof.json"), f"bench{sfx}_under_rocprof.json")
         for f in glob.glob(os.path.join(src, f"stats_{wl}", "**", "*kernel_stats.csv"), recursive=True)[:1]:
             cp(f, f"kernel_stats{sfx}.csv")
-        key = {"occu": "occu", "occu_rn": "rn", "occu_re": "re", "occu_dyn": "dyn"}.get(wl)
+        key = {"occu": "occu", "occu_rn": "rn", "occu_re": "re", "occu_dyn": "dyn", "occu_stacked": "stacked"}.get(wl)
         if key:
             cp(os.path.join(src, f"pmc_summary_{key}.json"), f"pmc_summary{sfx}.json")
     if not only:
-        for name in ("time_models.txt", "time_re.txt", "time_fit_e2e.txt", "time_rn.txt", "stamps_rn.txt", "time_dyn.txt"):
+        for name in ("time_models.txt", "time_re.txt", "time_fit_e2e.txt", "time_rn.txt", "stamps_rn.txt", "time_dyn.txt", "time_occu_g.txt",
+                     "fit_time_grid.json", "stamps.txt", "stamps_re.txt", "stamps_models.txt", "cpu_baseline_validation_rn.json"):
             cp(os.path.join(src, name), name)
 
 

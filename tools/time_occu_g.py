@@ -25,6 +25,8 @@ def sim(**kw):
 
 def shapes(quick):
     s = [("cfg1 100x52 (2 chains)", sim(), 2, {}),
+         ("small 200x10 3+3", sim(n_sites=200, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7), 4, {}),
+         ("test 100x52x3periods", sim(n_periods=3, simulate_missing=True), 2, {}),
          ("stacked 2000x8x4", sim(n_sites=2000, n_periods=8, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=28, session_duration=7), 4, {}),
          ("occu 5000x10", sim(n_sites=5000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7), 4, {}),
          ("headline 10000x5", sim(n_sites=10000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=35, session_duration=7), 4, {})]
@@ -48,8 +50,11 @@ def main():
             th[:, -1] = -2.0
         ref = od.potential_grad(th) if od is not None else None
         base_steps = None
-        for g in ("1", "2", "4", "8", "16", ""):
-            if g:
+        for g in ("1", "2", "4", "8", "16", "", "multi"):
+            # "": the host's own choice (small problems: ONE workgroup of 7 compute waves, no exchange); "multi": its choice with
+            # that form switched off (BIOLITH_HIP_SINGLE=0); the forced sizes run on the multi-workgroup form too
+            os.environ["BIOLITH_HIP_SINGLE"] = "1" if g == "" else "0"
+            if g and g != "multi":
                 os.environ["BIOLITH_HIP_OCCU_G"] = g
             else:
                 os.environ.pop("BIOLITH_HIP_OCCU_G", None)
