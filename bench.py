@@ -466,8 +466,11 @@ def main(argv=None):
             dist.all_gather_object(reasons, gather_fallback)
             gather_fallback = "; ".join(r for r in reasons if r) or "a peer failed"
             if comm is not None:
-                with contextlib.suppress(Exception):
-                    comm.close()
+                if gather_hung[0]:
+                    comm._h = None   # a collective is still pending on it: neither waited for nor destroyed (bl_comm_destroy would wait)
+                else:
+                    with contextlib.suppress(Exception):
+                        comm.close()
                 comm = None
 
     def torch_gather(res):
@@ -493,6 +496,7 @@ def main(argv=None):
         torch.cuda.synchronize()
 
     in_warmup, nonlocal_fail = [False], [None]
+    first_gather, gather_hung = [True], [False]
 
     def bench_workload(name, n_steps, n_warmup):
         """W untimed + exactly K timed steps of one workload; rank 0 gets the line (a dict), the others None."""
@@ -520,7 +524,35 @@ def main(argv=None):
             # bl_gather_draws: ONE all-gather of every rank's result block over RCCL / xGMI, the path's only collective;
             # only rank 0 copies the gathered blocks to the host
             try:
-                full = gather_draws([comm], [ds], chains_per_rank, want_result=(rank == 0))
+                if in_warmup[0] and first_gather[0] and (world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"):
+                    # The run's FIRST gather over several ranks (untimed): bounded.  It runs in a worker thread; if it has not returned
+                    # after BENCH_FIRST_GATHER_TIMEOUT seconds (a peer failed inside the collective, a rendezvous that never completes)
+                    # this rank gives the engine's communicator up -- the thread and the communicator are left behind, not waited for --
+                    # and the ranks agree (agree_on_gather) to gather through torch.distributed for the rest of the run.
+                    import threading
+
+                    first_gather[0] = False
+                    box = {}
+
+                    def work():
+                        try:
+                            if os.environ.get("BENCH_TEST_FIRST_GATHER_HANG") == "1":   # (exercises the bound on a one-GPU box)
+                                time.sleep(3600)
+                            box["full"] = gather_draws([comm], [ds], chains_per_rank, want_result=(rank == 0))
+                        except Exception as exc_:  # noqa: BLE001
+                            box["exc"] = exc_
+
+                    th = threading.Thread(target=work, daemon=True)
+                    th.start()
+                    th.join(float(os.environ.get("BENCH_FIRST_GATHER_TIMEOUT", "180")))
+                    if th.is_alive():
+                        gather_hung[0] = True
+                        raise TimeoutError("the first bl_gather_draws did not return within its bound")
+                    if "exc" in box:
+                        raise box["exc"]
+                    full = box["full"]
+                else:
+                    full = gather_draws([comm], [ds], chains_per_rank, want_result=(rank == 0))
             except Exception as exc:  # noqa: BLE001 -- only recoverable during the untimed steps (see below); else it ends the run
                 if not in_warmup[0]:
                     raise
@@ -538,28 +570,11 @@ def main(argv=None):
             return local, (full.draws if full is not None else None)
 
         for w in range(n_warmup):
+            # (--warmup 0 has no untimed gather: neither the bound on the first gather nor the fallback to torch.distributed applies then)
             in_warmup[0] = True
-            watchdog = None
-            if comm is not None and world > 1 and w == 0:
-                # The run's first gather, untimed.  If it fails on ONE rank its peers stay inside the collective and never reach the
-                # agreement below: bound it -- a rank still in its first step after BENCH_FIRST_GATHER_TIMEOUT seconds exits non-zero
-                # (no re-exec), which makes the launcher (bench.py's own or torchrun) end the others instead of hanging for its 3000 s.
-                # (--warmup 0 has no untimed gather: neither this bound nor the fallback to torch.distributed applies then.)
-                import threading
-
-                def give_up():
-                    sys.stderr.write(f"bench.py: rank {rank}: the first bl_gather_draws did not return within its bound; exiting\n")
-                    sys.stderr.flush()
-                    os._exit(3)
-
-                watchdog = threading.Timer(float(os.environ.get("BENCH_FIRST_GATHER_TIMEOUT", "300")), give_up)
-                watchdog.daemon = True
-                watchdog.start()
             one_step(10_000 + w)
-            if watchdog is not None:
-                watchdog.cancel()
             in_warmup[0] = False
-            if comm is not None and world > 1 and w == 0:   # the first gather of the run, untimed: did it work on every rank?
+            if comm is not None and (world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1") and w == 0:   # the first gather of the run, untimed: did it work on every rank?
                 nonlocal gather_fallback
                 gather_fallback = nonlocal_fail[0]
                 agree_on_gather()
@@ -791,6 +806,9 @@ def main(argv=None):
         comm.close()
     if dist is not None:
         dist.barrier()
+        if gather_hung[0]:   # a pending collective of the abandoned communicator would block the runtime's teardown
+            sys.stdout.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 
