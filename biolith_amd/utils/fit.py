@@ -41,7 +41,8 @@ def fit(
 
     Parameters are those of the reference ``fit`` (fit.py:33-66).  ``model_fn`` must be one of ``biolith_amd.models``' model functions
     (``occu``, ``occu_rn``, ``occu_cop``, ``nmixture``, ``occu_cs``, and the builder-defined ``occu_dyn``).  ``kernel`` must be ``None`` or ``"nuts"``; ``init_strategy``
-    must be ``None`` (= ``init_to_uniform``, fit.py:93).  Extra keyword arguments go to the model,
+    is ``None`` (= ``init_to_uniform``, fit.py:93) or one of :mod:`biolith_amd.utils.init`'s strategies (NumPyro's callables of the same
+    names are recognised).  Extra keyword arguments go to the model,
     plus engine knobs that the reference does not have: ``device`` (GPU index, default 0), ``devices``
     (list of GPU indices: the chains are dealt over them in contiguous blocks and sampled concurrently,
     the in-process counterpart of ``chain_method="parallel"``, fit.py:109-113) and ``chain_offset``
@@ -66,8 +67,9 @@ def fit(
         raise NotImplementedError(f"kernel={kernel!r}: the HIP engine implements NUTS only (fit.py:92-104)")
     if kernel != "nuts":
         raise KeyError(kernel)
-    if init_strategy is not None:
-        raise NotImplementedError("init_strategy: only the default init_to_uniform (fit.py:93) is built")
+    from .init import as_strategy, initial_positions
+
+    strategy = as_strategy(init_strategy)   # None = init_to_uniform (fit.py:93); NotImplementedError for anything unknown
     device = int(kwargs.pop("device", 0))
     devices = kwargs.pop("devices", None)
     explicit_devices = devices is not None
@@ -114,8 +116,15 @@ def fit(
                     continue
                 ds = OccuDataset(spec.site_covs, spec.obs_covs, spec.obs if joint else spec.obs[sp:sp + 1], spec.prior_beta, spec.prior_alpha,
                                  device=dev, model=spec.model, **engine_options(spec))
-                jobs.append((sp, ds, dict(num_warmup=num_warmup, num_samples=num_samples, num_chains=count,
-                                          seed=random_seed, chain_offset=chain_offset + sp * num_chains + first)))
+                kw = dict(num_warmup=num_warmup, num_samples=num_samples, num_chains=count,
+                          seed=random_seed, chain_offset=chain_offset + sp * num_chains + first)
+                nsp_here = n_species if joint else 1
+                init = initial_positions(strategy, D=ds.D, Ks=ds.Ks, Ko=ds.Ko, n_species=nsp_here, plain=ds.D == nsp_here * (ds.Ks + ds.Ko + 2) and spec.model != "occu_dyn", blocks_first=spec.model != "occu_dyn",
+                                         prior_beta=spec.prior_beta, prior_alpha=spec.prior_alpha, num_chains=count,
+                                         first_chain=kw["chain_offset"], seed=random_seed, species=sp)
+                if init is not None:
+                    kw["init_theta"] = init
+                jobs.append((sp, ds, kw))
         return jobs
 
     try:

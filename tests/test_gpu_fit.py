@@ -109,3 +109,28 @@ def test_chains_dealt_over_devices_reproduce_the_single_launch():  # fit.py:109-
     assert two.mcmc.num_chains == 4
     with pytest.raises(ValueError):
         fit(occu, **data, **kw, devices=[])
+
+
+def test_init_strategies():  # fit.py:29, 93: NUTS(model_fn, init_strategy=init_strategy or init_to_uniform)
+    from biolith_amd.utils import init_to_feasible, init_to_median, init_to_uniform, init_to_value
+
+    data, truth = simulate(n_sites=300, n_site_covs=2, n_obs_covs=2, deployment_days_per_site=70, random_seed=3)
+    kw = dict(num_chains=3, num_warmup=0, num_samples=4, random_seed=1)
+    base = fit(occu, **data, **kw)
+    same = fit(occu, **data, **kw, init_strategy=init_to_uniform())                 # the default by its name: the kernel's own draw
+    assert np.array_equal(base.mcmc.result.draws, same.mcmc.result.draws)
+    other = fit(occu, **data, **kw, init_strategy=init_to_uniform(radius=0.1))
+    assert not np.array_equal(base.mcmc.result.draws, other.mcmc.result.draws)
+    # no warmup, step size 1: from the generating values the first draws stay in their neighbourhood; from Uniform(-2, 2) they do not
+    start = init_to_value(values={"beta": truth["beta"], "alpha": truth["alpha"]})
+    near = fit(occu, **data, **{**kw, "num_samples": 1}, init_strategy=start)
+    th = np.concatenate([truth["beta"][0], truth["alpha"][0]])
+    assert np.max(np.abs(near.mcmc.result.draws[:, 0] - th)) < 1.0
+    # the dealing of chains to launches does not change where a chain starts
+    split = fit(occu, **data, **kw, init_strategy=init_to_uniform(radius=0.1), devices=[0, 0])
+    assert np.array_equal(split.mcmc.result.draws, other.mcmc.result.draws)
+    for strat in (init_to_feasible(), init_to_median(num_samples=5)):
+        res = fit(occu, **data, num_chains=2, num_warmup=200, num_samples=200, init_strategy=strat)
+        assert abs(float(res.samples["psi"].mean()) - truth["z"].mean()) < 0.1      # occu.py:440
+    with pytest.raises(NotImplementedError, match="all regression coefficients"):
+        fit(occu, **data, **kw, false_positives_constant=True, init_strategy=init_to_median())

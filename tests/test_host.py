@@ -288,3 +288,45 @@ def test_pinned_pool_hands_out_page_locked_buffers_from_the_second_request_on():
     gc.collect()
     assert len(lib.allocs) == 2 and len(lib.frees) == 1 and pool.held == 1 << 25   # 16 + 32 MB > cap: one of them was released
     assert threading.active_count() >= 1 and d.shape == (6000, 1000)
+
+
+def test_init_strategies_resolve_to_start_positions():
+    """fit(init_strategy=...) (fit.py:29, 93): the descriptors of biolith_amd.utils.init and how they become the kernel's init_theta."""
+    import functools
+
+    from biolith_amd.distributions import LocScale
+    from biolith_amd.utils import init_to_feasible, init_to_mean, init_to_median, init_to_sample, init_to_uniform, init_to_value
+    from biolith_amd.utils.init import as_strategy, initial_positions
+
+    kw = dict(D=7, Ks=2, Ko=3, n_species=1, plain=True, prior_beta=LocScale(0.5, 2.0), prior_alpha=LocScale(-1.0, 0.1, "laplace"),
+              num_chains=3, first_chain=4, seed=9)
+    assert initial_positions(None, **kw) is None and initial_positions(init_to_uniform(), **kw) is None   # the kernel's own draw
+    u = initial_positions(init_to_uniform(radius=0.5), **kw)
+    assert u.shape == (3, 7) and np.all(np.abs(u) <= 0.5) and len(np.unique(u)) == 21
+    # a chain's start depends on its global id only: chains 5, 6 of this launch = chains 0, 1 of a launch that starts at 5
+    v = initial_positions(init_to_uniform(radius=0.5), **{**kw, "first_chain": 5, "num_chains": 2})
+    assert np.array_equal(v, u[1:])
+    assert np.all(initial_positions(init_to_feasible(), **kw) == 0.0)
+    m = initial_positions(init_to_mean(), **kw)
+    assert np.all(m[:, :3] == 0.5) and np.all(m[:, 3:] == -1.0)
+    s = initial_positions(init_to_sample(), **kw)
+    assert s.shape == (3, 7) and np.std(s[:, :3]) > 0.3 and np.std(s[:, 3:]) < 0.5
+    med = initial_positions(init_to_median(num_samples=401), **kw)
+    assert np.all(np.abs(med[:, :3] - 0.5) < 0.5) and np.all(np.abs(med[:, 3:] + 1.0) < 0.05)
+    val = initial_positions(init_to_value(values={"alpha": [1.0, 2.0, 3.0, 4.0]}), **kw)
+    assert np.all(val[:, 3:] == [1.0, 2.0, 3.0, 4.0]) and np.all(np.abs(val[:, :3]) <= 2.0)   # the rest as init_to_uniform (NumPyro's rule)
+    two = initial_positions(init_to_value(values={"beta": np.arange(6.0).reshape(2, 3)}), **{**kw, "D": 15, "n_species": 2, "plain": False})
+    assert np.all(two[:, 0:3] == [0, 1, 2]) and np.all(two[:, 7:10] == [3, 4, 5])
+    with pytest.raises(NotImplementedError, match="coefficient sites"):
+        initial_positions(init_to_value(values={"site_re_sd": 1.0}), **kw)
+    with pytest.raises(NotImplementedError, match="all regression coefficients"):
+        initial_positions(init_to_median(), **{**kw, "D": 8, "plain": False})
+    # NumPyro's own callables are recognised by name (functools.partial forms, as numpyro.infer.init_to_value(values=...) returns)
+    def init_to_median(site=None, num_samples=15):  # noqa: F811 -- stands for numpyro.infer.init_to_median
+        raise AssertionError("never called")
+
+    st = as_strategy(functools.partial(init_to_median, num_samples=7))
+    assert st.kind == "median" and st.num_samples == 7
+    assert as_strategy(init_to_feasible).kind == "feasible"
+    with pytest.raises(NotImplementedError, match="init_strategy"):
+        as_strategy(lambda: None)
