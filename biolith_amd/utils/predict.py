@@ -52,6 +52,7 @@ def predict(
         (n, J, T, N, S), ``y`` (n, J, T, N, S) int32 -- the sites of occu.py:207-241.
         occu_rn / nmixture: ``abundance``, ``N_i``, ``prob_detection``, ``y`` (occu_rn.py:192-221, nmixture.py:181-220).
         occu_cop: ``psi``, ``z``, ``rate_detection``, ``y`` (counts; occu_cop.py:222-255).
+        occu_dyn (builder-defined): ``psi``, ``gamma``, ``epsilon`` (n, N, S), ``z`` (n, T, N, S), ``prob_detection``, ``y``.
         The three replicate-level arrays are materialised on first access.
 
     Examples
@@ -77,6 +78,8 @@ def predict(
         site_covs, obs_covs, obs, session_duration
     )
     posterior = mcmc.get_samples()
+    if getattr(model_fn, "__biolith_amd_model__", None) == "occu_dyn":
+        return _predict_dyn(model_fn, posterior, site_covs, obs_covs, site_names, obs_names, num_samples, random_seed, kwargs)
     beta = np.asarray(posterior["beta"], dtype=np.float32)    # (n, S, Ks+1)
     alpha = np.asarray(posterior["alpha"], dtype=np.float32)  # (n, S, Ko+1)
     n, n_species = beta.shape[0], beta.shape[1]
@@ -196,4 +199,51 @@ def predict(
 
         out.set_lazy("prob_detection_fp", prob_detection_fp)
     out.set_lazy("y", lambda: np.stack(y8, axis=-1).astype(np.int32))                 # (n, J, T, N, S)
+    return rename_samples(out, site_names, obs_names)
+
+
+def _predict_dyn(model_fn, posterior, site_covs, obs_covs, site_names, obs_names, num_samples, random_seed, kwargs):
+    """Posterior predictive sites of the BUILDER-DEFINED dynamic occupancy model (models/occu_dyn.py; no reference counterpart): per
+    posterior draw the latent path z_i1 ~ Bernoulli(psi_i), z_i,t+1 | z_it ~ Bernoulli(gamma_i) / Bernoulli(1 - epsilon_i) and
+    y_itj ~ Bernoulli(z_it p_itj), drawn ancestrally on the host (predict is not on the hot path; the path has T dependent steps).
+    Sites, species plate last as everywhere: ``psi``, ``gamma``, ``epsilon`` (n, N, 1); ``z`` (n, T, N, 1) int32; ``prob_detection`` and
+    ``y`` (n, J, T, N, 1), materialised on first access.  The generator is keyed by ``random_seed``."""
+    b = {k: np.asarray(posterior[k], dtype=np.float32)[:, 0, :] for k in ("beta", "beta_col", "beta_ext", "alpha")}
+    n = b["beta"].shape[0]
+    if num_samples is not None and num_samples != n:
+        warnings.warn(f"Sample's batch dimension size {n} is different from the provided {num_samples} "
+                      f"num_samples argument. Defaulting to {n}.", UserWarning, stacklevel=3)
+    blank = np.full((1,) + np.shape(obs_covs)[:3], np.nan, dtype=np.float32)
+    spec = model_fn(site_covs=site_covs, obs_covs=obs_covs, obs=blank, **kwargs)
+    X = np.nan_to_num(np.asarray(spec.site_covs, dtype=np.float32))
+    W = np.nan_to_num(np.asarray(spec.obs_covs, dtype=np.float32))
+    if b["beta"].shape[1] != X.shape[1] + 1 or b["alpha"].shape[1] != W.shape[3] + 1:
+        raise ValueError("predict(): covariate counts differ from the fitted model's coefficients")
+    N, T, J = W.shape[:3]
+
+    def prob(block):
+        eta = block[:, :1] + block[:, 1:] @ X.T
+        return (1.0 / (1.0 + np.exp(-eta))).astype(np.float32)   # (n, N)
+
+    psi, gam, eps = prob(b["beta"]), prob(b["beta_col"]), prob(b["beta_ext"])
+    rng = np.random.default_rng([int(random_seed) & 0x7FFFFFFF, 0xD1A])
+    z = np.empty((n, T, N), dtype=np.int8)
+    z[:, 0] = rng.random((n, N), dtype=np.float32) < psi
+    for t in range(1, T):
+        z[:, t] = rng.random((n, N), dtype=np.float32) < np.where(z[:, t - 1] == 1, 1.0 - eps, gam)
+
+    def prob_detection():   # (n, J, T, N, 1)
+        nu = b["alpha"][:, :1, None, None] + np.einsum("itjk,nk->nitj", W, b["alpha"][:, 1:])
+        return (1.0 / (1.0 + np.exp(-nu))).astype(np.float32).transpose(0, 3, 2, 1)[..., None]
+
+    def y():
+        p = prob_detection()[..., 0]
+        u = np.random.default_rng([int(random_seed) & 0x7FFFFFFF, 0xD1B]).random(p.shape, dtype=np.float32)
+        return ((u < p) & (z[:, None] == 1)).astype(np.int32)[..., None]
+
+    out = LazySamples()
+    out["psi"], out["gamma"], out["epsilon"] = psi[..., None], gam[..., None], eps[..., None]
+    out["z"] = z.astype(np.int32)[..., None]
+    out.set_lazy("prob_detection", prob_detection)
+    out.set_lazy("y", y)
     return rename_samples(out, site_names, obs_names)

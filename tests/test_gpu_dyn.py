@@ -102,3 +102,33 @@ def test_dyn_rejects_what_is_not_built():
     data, _ = _sim(n_sites=40, n_periods=3, n_site_covs=9, random_seed=2)
     with pytest.raises(NotImplementedError):
         fit(occu_dyn, **data)
+
+
+def test_predict_for_the_dynamic_model():
+    """Posterior predictive sites of the builder-defined model (no reference counterpart): exact identities and 5-sigma frequencies."""
+    from biolith_amd.utils import predict
+
+    data, truth = _sim(n_sites=150, n_periods=5, n_site_covs=2, n_obs_covs=1, random_seed=6)
+    res = fit(occu_dyn, **data, num_chains=2, num_warmup=200, num_samples=400)
+    pp = predict(occu_dyn, res.mcmc, **data, random_seed=3)
+    n, N, T, J = 800, 150, 5, data["obs"].shape[3]
+    assert pp["psi"].shape == pp["gamma"].shape == pp["epsilon"].shape == (n, N, 1)
+    assert pp["z"].shape == (n, T, N, 1) and pp["prob_detection"].shape == pp["y"].shape == (n, J, T, N, 1)
+    assert np.array_equal(pp["psi"], res.samples["psi"]) and np.array_equal(pp["gamma"], res.samples["gamma"])   # the fit's own deterministic sites
+    z, y, p = pp["z"][..., 0], pp["y"][..., 0], pp["prob_detection"][..., 0]
+    assert set(np.unique(z)) <= {0, 1} and np.all(y[(z[:, None] == 0) & np.ones_like(y, bool)] == 0)   # no detection at an unoccupied site
+    # z_1 ~ Bernoulli(psi); z_t+1 | z_t ~ Bernoulli(gamma) / Bernoulli(1 - epsilon); y | z = 1 ~ Bernoulli(p): frequencies within 5 sigma
+    def close(freq, prob, count):
+        return abs(freq - prob) < 5 * np.sqrt(prob * (1 - prob) / count) + 1e-3
+    psi, gam, eps = pp["psi"][..., 0], pp["gamma"][..., 0], pp["epsilon"][..., 0]
+    assert close(z[:, 0].mean(), psi.mean(), n * N)
+    was0, was1 = z[:, :-1] == 0, z[:, :-1] == 1
+    g_b = np.broadcast_to(gam[:, None], z[:, 1:].shape)
+    e_b = np.broadcast_to(eps[:, None], z[:, 1:].shape)
+    assert close(z[:, 1:][was0].mean(), g_b[was0].mean(), was0.sum())
+    assert close(z[:, 1:][was1].mean(), 1.0 - e_b[was1].mean(), was1.sum())
+    occ = np.broadcast_to(z[:, None] == 1, y.shape)
+    assert close(y[occ].mean(), p[occ].mean(), occ.sum())
+    again = predict(occu_dyn, res.mcmc, **data, random_seed=3)
+    assert np.array_equal(again["z"], pp["z"]) and np.array_equal(again["y"], pp["y"])   # keyed by the seed
+    assert not np.array_equal(predict(occu_dyn, res.mcmc, **data, random_seed=4)["z"], pp["z"])
