@@ -721,6 +721,7 @@ def main(argv=None):
             "roofline": roofline,
             "sampler": {  # rank 0's chains, last timed step (SURVEY.md section 8d "also report")
                 "mean_num_steps": float(steps[-1][0].num_steps.mean()), "divergences": int(steps[-1][0].diverging.sum()),
+                "mean_tree_depth": float(np.log2(steps[-1][0].num_steps.astype(np.float64) + 1.0).mean()),
                 "step_size": [float(x) for x in steps[-1][0].step_size], "mean_accept_prob": float(steps[-1][0].accept_prob.mean()),
                 "leapfrogs_per_s_per_chain": 1e3 * (leap_mean / NCH) / kernel_ms_mean,
             },

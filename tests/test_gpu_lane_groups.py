@@ -186,3 +186,25 @@ def test_posterior_with_groups_matches_the_one_pair_per_lane_kernel(force_group)
     assert np.all(np.abs(fa.std(0) / fb.std(0) - 1) < 0.1)
     assert split_gelman_rubin(b.draws).max() < 1.01
     ds.close()
+
+
+@pytest.mark.parametrize("i", [4, 6])
+def test_benchmark_grid_rows_at_full_size(i):
+    """Rows of the reference's own benchmark grid (benchmarks/occu_spoccupancy.py:16-70: 100 * 2^i sites x int(8 * 2^(i/2)) visits, 2 + 1
+    covariates, one chain) at full size with the host's own choice of lanes per pair: K1 against the oracle and its first trees."""
+    n, j = 100 * 2 ** i, int(8 * 2 ** (i / 2))
+    d, _, _ = quiet_simulate(n_site_covs=2, n_obs_covs=1, n_sites=n, deployment_days_per_site=7 * j, session_duration=7, random_seed=42 + i)
+    assert d["obs"].shape == (1, n, 1, j)
+    od = oracle.OracleData(d["site_covs"], d["obs_covs"], d["obs"])
+    ds = OccuDataset(d["site_covs"], d["obs_covs"], d["obs"])
+    th = np.random.default_rng(i).uniform(-2, 2, size=(3, od.D)).astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= U_RTOL
+    assert np.max(np.abs(Gg - Go)) <= G_RTOL * np.max(np.abs(Go))
+    o = oracle.nuts_run(od, 0, 3, num_chains=1, seed=i)
+    r = ds.nuts(num_warmup=0, num_samples=3, num_chains=1, seed=i)
+    assert r.lds_staged and r.lane_group[0] * r.lane_group[1] >= 2, r.lane_group      # 32 / 64 visits per site: lanes share a pair
+    assert np.array_equal(o["num_steps"][:, :2], r.num_steps[:, :2]), (o["num_steps"], r.num_steps)
+    assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=2e-3)
+    ds.close()
