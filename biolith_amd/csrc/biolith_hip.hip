@@ -937,7 +937,7 @@ static int dyn_lanes_per_pair(const bl_dataset *ds, int chains)
 #define BL_GRP_VISITS 6
 static int occu_lane_group(const bl_dataset *ds, int chains, int want_k)
 {
-    if (ds->model != 0 && ds->model != 2) return 0;
+    if (ds->model != 0 && ds->model != 2 && ds->model != 3 && ds->model != 4) return 0; // (occu, false positives, occu_cop, nmixture)
     const int T = ds->dims.n_periods, J = ds->dims.n_replicates;
     const long long V = (long long)T * J, npairs = (ds->dims.n_sites + 1) / 2;
     const int per_xcd = ((chains > 0 ? chains : 1) + 7) / 8;
@@ -1846,7 +1846,7 @@ extern "C" int bl_nuts_lane_group(bl_dataset *ds, int *period_lanes, int *visit_
     if (!ds->have_run) return bl_fail(BL_ERR_INVALID, "no NUTS launch on this handle");
     int gt = 1, gj = 1;
     if (ds->model == 8) gt = ds->lane_grp > 0 ? ds->lane_grp : 1;                                    // dynamic occupancy: the seasons
-    else if (ds->model == 0 || ds->model == 2) { gt = 1 << (ds->lane_grp & 15); gj = 1 << (ds->lane_grp >> 4); }
+    else if (ds->model == 0 || ds->model == 2 || ds->model == 3 || ds->model == 4) { gt = 1 << (ds->lane_grp & 15); gj = 1 << (ds->lane_grp >> 4); }
     if (period_lanes) *period_lanes = gt;
     if (visit_lanes) *visit_lanes = gj;
     return BL_OK;

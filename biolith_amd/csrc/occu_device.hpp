@@ -899,10 +899,13 @@ __device__ __forceinline__ BlCopScalars bl_cop_scalars(float phi, int fp_mode)
     return s;
 }
 
+// grp (round 4): lanes that share a site pair, as for the plain model (bl_eval_sites_grp: log2(period lanes) | log2(visit lanes) << 4; 0 = one pair
+// per lane) -- the reference's own sizes for this model are simulate_cop()'s defaults, 100 sites x 52 visits (occu_cop.py:258-396).  The one
+// per-period value every lane needs whole is the z = 1 branch's sum a; the z = 0 branch is data (Ysum, Dsum) and the rate.
 template <int KS, int KO, int CT>
 __device__ __forceinline__ void bl_eval_sites_cop(int ct, int pstride, int cnt, int T, int J, const BlCopScalars fp,
                                                   const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
-                                                  float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], float &gphi)
+                                                  float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], float &gphi, int grp = 0)
 {
     constexpr int XQ = (KS + 3) & ~3;
     constexpr int VW = KO + 2; // floats per visit
@@ -910,12 +913,18 @@ __device__ __forceinline__ void bl_eval_sites_cop(int ct, int pstride, int cnt, 
     const float *data = bl_lds_f(BL_OFF_DATA);
     const int npairs = (cnt + 1) >> 1;
     const bool with_f1 = fp.z1 != 0.0f; // wave-uniform
+    const int lgt = grp & 15, lgj = grp >> 4, lg = lgt + lgj;
+    const int sub = ct & ((1 << lg) - 1), slot = ct >> lg, nslots = CT >> lg;
+    const int sub_j = sub & ((1 << lgj) - 1), sub_t = sub >> lgj, Gt = 1 << lgt;
+    const int jc = (J + (1 << lgj) - 1) >> lgj;
+    const int j0 = min(sub_j * jc, J), j1 = min(j0 + jc, J); // this lane's chunk of every period's visits
+    const bl_f2 firstj = bl2(sub_j == 0 ? 1.0f : 0.0f);      // per-(site, period) addends are counted by the chunk's first lane
     bl_f2 ll2 = bl2(0.0f), gb2[KS + 1], ga2[KO + 1], gp2 = bl2(0.0f);
 #pragma unroll
     for (int k = 0; k <= KS; k++) gb2[k] = bl2(0.0f);
 #pragma unroll
     for (int k = 0; k <= KO; k++) ga2[k] = bl2(0.0f);
-    for (int m = ct; m < npairs; m += CT) {
+    for (int m = slot; m < npairs; m += nslots) {
         const float4 *rec = reinterpret_cast<const float4 *>(data + (size_t)m * pstride);
         const bl_f2 vmask = bl_f2{1.0f, (2 * m + 1 < cnt) ? 1.0f : 0.0f};
         bl_f2 x[XQ];
@@ -934,7 +943,7 @@ __device__ __forceinline__ void bl_eval_sites_cop(int ct, int pstride, int cnt, 
         const bl_f2 psi = bl_sel_pos_one(eta, e_eta) * bl_rcp_2(op_eta);
         bl_f2 dsum = bl2(0.0f), lsite = bl2(0.0f), gpsite = bl2(0.0f);
         const float2 *pp0 = reinterpret_cast<const float2 *>(data + (size_t)m * pstride) + XQ;
-        for (int t = 0; t < T; t++) {
+        for (int t = sub_t; t < T; t += Gt) {
             const float2 *pp = pp0 + t * pb;
             bl_f2 g[KO + 1];
 #pragma unroll
@@ -943,7 +952,7 @@ __device__ __forceinline__ void bl_eval_sites_cop(int ct, int pstride, int cnt, 
             const bl_f2 ysum = bl_f2{ys_.x, ys_.y}, dsm = bl_f2{ds_.x, ds_.y};
             bl_f2 a = bl2(0.0f), gf = bl2(0.0f);
 #pragma unroll 2
-            for (int j = 0; j < J; j++) {
+            for (int j = j0; j < j1; j++) {
                 const float2 y_ = pp[j * VW], d_ = pp[j * VW + 1];
                 const bl_f2 ym = bl_f2{y_.x, y_.y}, dm = bl_f2{d_.x, d_.y};
                 bl_f2 w[KO > 0 ? KO : 1];
@@ -971,6 +980,7 @@ __device__ __forceinline__ void bl_eval_sites_cop(int ct, int pstride, int cnt, 
 #pragma unroll
                 for (int k = 0; k < KO; k++) g[k + 1] = bl_fma2(s, w[k], g[k + 1]);
             }
+            a = bl_group_sum2(a, lgj);
             // z = 0 branch: Ysum log f - Dsum f, or Poisson(0): 0 / -inf
             const bl_f2 b_f = bl_fma2(ysum, bl2(fp.phi), dsm * bl2(-fp.f));
             const bl_f2 b_0 = bl_f2{ysum.x > 0.0f ? -INFINITY : 0.0f, ysum.y > 0.0f ? -INFINITY : 0.0f};
@@ -979,15 +989,15 @@ __device__ __forceinline__ void bl_eval_sites_cop(int ct, int pstride, int cnt, 
             const bl_f2 d = eta + a - kb;
             const bl_f2 e_d = bl_exp2_2(__builtin_elementwise_abs(d) * bl2(-BL_LOG2E));
             const bl_f2 op_d = e_d + bl2(1.0f);
-            lsite += bl_fma2(bl_log2_2(op_d), bl2(BL_LN2), __builtin_elementwise_max(A, B));
+            lsite = bl_fma2(bl_fma2(bl_log2_2(op_d), bl2(BL_LN2), __builtin_elementwise_max(A, B)), firstj, lsite);
             const bl_f2 q = bl_sel_pos_one(d, e_d) * bl_rcp_2(op_d); // P(z=1 | y, theta)
-            dsum += q - psi;
+            dsum = bl_fma2(q - psi, firstj, dsum);
 #pragma unroll
-            for (int k = 0; k <= KO; k++) ga2[k] = bl_fma2(q, g[k], ga2[k]);
-            // d/dphi = f d/df:  z=1: f sum_j (y/(lambda+f) - d)  ("constant" only);  z=0: Ysum - Dsum f
+            for (int k = 0; k <= KO; k++) ga2[k] = bl_fma2(q, g[k], ga2[k]); // (this lane's visits)
+            // d/dphi = f d/df:  z=1: f sum_j (y/(lambda+f) - d)  ("constant" only; linear in this lane's share gf);  z=0: Ysum - Dsum f
             const bl_f2 d1 = gf * bl2(fp.f * fp.z1);
             const bl_f2 d0 = bl_fma2(dsm, bl2(-fp.f), ysum) * bl2(fp.has0);
-            gpsite += bl_fma2(q, d1 - d0, d0);
+            gpsite += bl_fma2(q, d1, (bl2(1.0f) - q) * d0 * firstj);
         }
         ll2 = bl_fma2(lsite, vmask, ll2);
         gp2 = bl_fma2(gpsite, vmask, gp2);
@@ -1019,23 +1029,32 @@ __device__ constexpr float BL_LGAMMA1P[128] = {0.000000000e+00f, 0.000000000e+00
 // Records as for occu_cop: visit = (m y, m, w_1..w_KO) (layout KO + 1); B lives in HBM/L2 as
 // tab[t][n][site] (site fastest: lanes read consecutive floats).  Two passes over n (max, then sums); the second
 // stops at the last term that can matter.
+// grp (round 4): lanes that share a site pair as for the plain model (simulate_nmixture()'s defaults are 100 sites x 52 visits,
+// nmixture.py:223-369): the visit lanes fold c = sum_j m log(1 - p_j) (the slope of the terms in n); the sums over n are then formed by
+// every lane of the group alike (same table entries), y's and p's gradient sums stay per lane and enter linearly.
 template <int KS, int KO, int CT>
 __device__ __forceinline__ void bl_eval_sites_nmix(int ct, int pstride, int cnt, int T, int J, int K,
                                                    const float *__restrict__ tab, int tab_ld,
                                                    const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
-                                                   float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
+                                                   float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], int grp = 0)
 {
     constexpr int XQ = (KS + 3) & ~3;
     constexpr int VW = KO + 2;
     const int pb = bl_period_block(J, KO + 1);
     const float *data = bl_lds_f(BL_OFF_DATA);
     const int npairs = (cnt + 1) >> 1;
+    const int lgt = grp & 15, lgj = grp >> 4, lg = lgt + lgj;
+    const int sub = ct & ((1 << lg) - 1), slot = ct >> lg, nslots = CT >> lg;
+    const int sub_j = sub & ((1 << lgj) - 1), sub_t = sub >> lgj, Gt = 1 << lgt;
+    const int jc = (J + (1 << lgj) - 1) >> lgj;
+    const int j0 = min(sub_j * jc, J), j1 = min(j0 + jc, J);
+    const bl_f2 firstj = bl2(sub_j == 0 ? 1.0f : 0.0f);
     bl_f2 ll2 = bl2(0.0f), gb2[KS + 1], ga2[KO + 1];
 #pragma unroll
     for (int k = 0; k <= KS; k++) gb2[k] = bl2(0.0f);
 #pragma unroll
     for (int k = 0; k <= KO; k++) ga2[k] = bl2(0.0f);
-    for (int m = ct; m < npairs; m += CT) {
+    for (int m = slot; m < npairs; m += nslots) {
         const float4 *rec = reinterpret_cast<const float4 *>(data + (size_t)m * pstride);
         const bool second = 2 * m + 1 < cnt;
         const bl_f2 vmask = bl_f2{1.0f, second ? 1.0f : 0.0f};
@@ -1053,14 +1072,14 @@ __device__ __forceinline__ void bl_eval_sites_nmix(int ct, int pstride, int cnt,
         const bl_f2 lam = bl_exp2_2(__builtin_elementwise_min(eta, bl2(80.0f)) * bl2(BL_LOG2E));
         bl_f2 dsum = bl2(0.0f), lsite = bl2(0.0f);
         const float2 *pp0 = reinterpret_cast<const float2 *>(data + (size_t)m * pstride) + XQ;
-        for (int t = 0; t < T; t++) {
+        for (int t = sub_t; t < T; t += Gt) {
             const float2 *pp = pp0 + t * pb;
             bl_f2 gy[KO + 1], gp[KO + 1];
 #pragma unroll
             for (int k = 0; k <= KO; k++) { gy[k] = bl2(0.0f); gp[k] = bl2(0.0f); }
             bl_f2 a = bl2(0.0f), c = bl2(0.0f);
 #pragma unroll 2
-            for (int j = 0; j < J; j++) {
+            for (int j = j0; j < j1; j++) {
                 const float2 y_ = pp[j * VW], m_ = pp[j * VW + 1];
                 const bl_f2 ym = bl_f2{y_.x, y_.y}, mk = bl_f2{m_.x, m_.y};
                 bl_f2 w[KO > 0 ? KO : 1];
@@ -1082,6 +1101,7 @@ __device__ __forceinline__ void bl_eval_sites_nmix(int ct, int pstride, int cnt,
                 for (int k = 0; k < KO; k++) { gy[k + 1] = bl_fma2(ym, w[k], gy[k + 1]); gp[k + 1] = bl_fma2(p, w[k], gp[k + 1]); }
             }
             // logsumexp over n of  n (eta + c) - lgamma(n+1) + B_n
+            c = bl_group_sum2(c, lgj);
             const bl_f2 slope = eta + c;
             const float *b0 = t0 + (size_t)t * (K + 1) * tab_ld, *b1 = t1 + (size_t)t * (K + 1) * tab_ld;
             // pass 1: the maximum, and the last n whose term is within 25 nats of the running maximum -- a superset of
@@ -1120,8 +1140,8 @@ __device__ __forceinline__ void bl_eval_sites_nmix(int ct, int pstride, int cnt,
                 S1 = bl_fma2(bl2((float)n), en, S1);
             }
             const bl_f2 En = S1 * bl_rcp_2(S);
-            lsite += a - lam + mx + bl_log2_2(S) * bl2(BL_LN2);
-            dsum += En - lam;
+            lsite += a + (mx - lam + bl_log2_2(S) * bl2(BL_LN2)) * firstj; // (a: this lane's visits)
+            dsum = bl_fma2(En - lam, firstj, dsum);
 #pragma unroll
             for (int k = 0; k <= KO; k++) ga2[k] += (gy[k] - En * gp[k]) * vmask;
         }
@@ -1298,7 +1318,7 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi, row_stride, sp * BL_SP_PART(KS, KO));
     } else if constexpr (MODEL == 4) {
         static_assert(LDS, "N-mixture model: LDS records only");
-        bl_eval_sites_nmix<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, max_abundance, tab, tab_ld, beta, alpha, ll, gb, ga);
+        bl_eval_sites_nmix<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, max_abundance, tab, tab_ld, beta, alpha, ll, gb, ga, lane_grp);
         bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga);
     } else if constexpr (MODEL == 8) {
         static_assert(LDS, "dynamic occupancy model: LDS records only");
@@ -1327,7 +1347,7 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         static_assert(LDS, "count occupancy model: LDS records only");
         float gphi = -0.0f;
         const BlCopScalars fp = bl_cop_scalars(bl_lds_f(BL_OFF_COEF)[KS + KO + 3], fp_mode);
-        bl_eval_sites_cop<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi);
+        bl_eval_sites_cop<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi, lane_grp);
         bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi);
     } else {
         bool grouped = false;

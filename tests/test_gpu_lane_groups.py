@@ -208,3 +208,51 @@ def test_benchmark_grid_rows_at_full_size(i):
     assert np.array_equal(o["num_steps"][:, :2], r.num_steps[:, :2]), (o["num_steps"], r.num_steps)
     assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=2e-3)
     ds.close()
+
+
+# ---- the count models at their generators' default sizes: 100 sites x 52 visits ----
+COUNT_GROUPS = [(1, None), (2, None), (8, None), (16, None), (4, 1)]
+
+
+@pytest.mark.parametrize("g,gt", COUNT_GROUPS)
+@pytest.mark.parametrize("name,mode", [("cop_default", None), ("cop_default", "constant"), ("cop_missing", "unoccupied")])
+def test_occu_cop_with_groups(name, mode, g, gt, force_group):
+    """occu_cop (occu_cop.py:197-255) on lane groups: K1 at its tolerance (2e-6 / 2e-5) and the oracle's first trees."""
+    d = load_golden(name)
+    kw = dict(model="occu_cop", fp_mode=mode, session_duration=d["session_duration"])
+    od = oracle.OracleData(d["site_covs"], d["obs_covs"], d["obs"], **kw)
+    ds = OccuDataset(d["site_covs"], d["obs_covs"], d["obs"], **kw)
+    th = np.random.default_rng(3).uniform(-1.2, 1.2, size=(4, od.D)).astype(np.float32).astype(np.float64)
+    if mode:
+        th[0, -1], th[1, -1] = -5.0, 0.7
+    Uo, Go = od.potential_grad(th)
+    force_group(g, gt)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= 2e-6, (Ug, Uo)
+    assert np.max(np.abs(Gg - Go) / np.max(np.abs(Go), axis=1, keepdims=True)) <= 2e-5
+    o = oracle.nuts_run(od, 0, 4, num_chains=2, seed=3)
+    r = ds.nuts(num_warmup=0, num_samples=4, num_chains=2, seed=3)
+    assert r.lane_group[0] * r.lane_group[1] == g, r.lane_group
+    assert np.array_equal(o["num_steps"][:, :2], r.num_steps[:, :2]), (o["num_steps"], r.num_steps)
+    ds.close()
+
+
+@pytest.mark.parametrize("g,gt", COUNT_GROUPS)
+@pytest.mark.parametrize("name,K", [("nmix_default", 100), ("nmix_ref_test_3periods", 19)])
+def test_nmixture_with_groups(name, K, g, gt, force_group):
+    """nmixture (nmixture.py:150-220) on lane groups: the visit lanes fold the slope's sum, the sums over n are formed by every lane alike."""
+    d = load_golden(name)
+    kw = dict(model="nmixture", max_abundance=K)
+    od = oracle.OracleData(d["site_covs"], d["obs_covs"], d["obs"], **kw)
+    ds = OccuDataset(d["site_covs"], d["obs_covs"], d["obs"], **kw)
+    th = np.random.default_rng(3).uniform(-1.0, 1.0, size=(4, od.D)).astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    force_group(g, gt)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= 2e-6, (Ug, Uo)
+    assert np.max(np.abs(Gg - Go) / np.max(np.abs(Go), axis=1, keepdims=True)) <= 2e-5
+    o = oracle.nuts_run(od, 0, 4, num_chains=2, seed=3)
+    r = ds.nuts(num_warmup=0, num_samples=4, num_chains=2, seed=3)
+    assert r.lane_group[0] * r.lane_group[1] == g, r.lane_group
+    assert np.array_equal(o["num_steps"][:, :2], r.num_steps[:, :2]), (o["num_steps"], r.num_steps)
+    ds.close()

@@ -32,3 +32,17 @@ K = int(np.nanmax(dnm["obs"])) + 10
 run(f"nmixture K={K} 5000x10", OccuDataset(dnm["site_covs"], dnm["obs_covs"], dnm["obs"], model="nmixture", max_abundance=K))
 run("nmixture K=100 5000x10", OccuDataset(dnm["site_covs"], dnm["obs_covs"], dnm["obs"], model="nmixture", max_abundance=100))
 run("occu_rn K=100 5000x10", OccuDataset(drn["site_covs"], drn["obs_covs"], drn["obs"], model="occu_rn"))
+# the generators' own default sizes (100 sites x 52 visits: what the reference's tests fit), lanes sharing a site pair / one pair per lane
+import os
+with contextlib.redirect_stdout(io.StringIO()):
+    c1, _ = simulate_cop()
+    n1, _ = simulate_nmixture()
+for g in ("", "1"):
+    if g:
+        os.environ["BIOLITH_HIP_OCCU_G"] = g
+    else:
+        os.environ.pop("BIOLITH_HIP_OCCU_G", None)
+    tag = "host's choice" if not g else "one pair per lane"
+    run(f"occu_cop defaults 100x52 ({tag})", OccuDataset(c1["site_covs"], c1["obs_covs"], c1["obs"], model="occu_cop", fp_mode=None, session_duration=c1["session_duration"]))
+    run(f"nmixture defaults 100x52 ({tag})", OccuDataset(n1["site_covs"], n1["obs_covs"], n1["obs"], model="nmixture", max_abundance=int(np.nanmax(n1["obs"])) + 10))
+
