@@ -1070,6 +1070,18 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     *lds_bytes_out = ok ? BL_OFF_DATA + ((nloc + 1) / 2) * stride * 4 * ds->nsp + rn_scratch : BL_OFF_DATA;
 }
 
+// nmixture: the columns of the table B[t][n][site] that belong to a workgroup's sites go to LDS behind the records when they fit
+// (T (K + 1) rows of 2 ceil(nloc / 2) floats); returns 1 and grows *lds_bytes if so.  BIOLITH_HIP_NMIX_LDS=0 keeps them in HBM / L2 (A/B).
+static int nmix_table_in_lds(const bl_dataset *ds, int staged, int nloc, int *lds_bytes)
+{
+    if (ds->model != 4 || !staged) return 0;
+    if (const char *e = getenv("BIOLITH_HIP_NMIX_LDS")) { if (e[0] == '0') return 0; }
+    const long long tb = (long long)ds->dims.n_periods * (ds->max_abundance + 1) * (2 * ((nloc + 1) / 2)) * 4;
+    if (*lds_bytes + tb > BL_LDS_TOTAL) return 0;
+    *lds_bytes += (int)tb;
+    return 1;
+}
+
 // ------------------------------------------------------------- K1 logp ----
 __global__ void bl_logp_final_kernel(BlDevData dd, int k, const double *theta, const double *partial, double *U, double *grad)
 {
@@ -1437,6 +1449,7 @@ extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *
     p.max_abundance = ds->max_abundance;
     p.rn_off = BL_OFF_DATA + ((nloc + 1) / 2) * ld * 4; // (occu_rn: one species)
     p.lane_grp = ds->model == 8 ? dyn_lanes_per_pair(ds, 1) : grp;
+    p.nmix_lds = nmix_table_in_lds(ds, use_staged, nloc, &lds_bytes);
     p.fp_mode = ds->fp_mode;
     p.nmix_tab = ds->d_tab;
     p.ncw = ncw;
@@ -1693,6 +1706,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.max_abundance = ds->max_abundance;
     p.rn_off = BL_OFF_DATA + ((nloc + 1) / 2) * ld * 4; // (occu_rn: one species)
     p.lane_grp = ds->model == 8 ? dyn_lanes_per_pair(ds, C) : grp;
+    p.nmix_lds = nmix_table_in_lds(ds, staged, nloc, &lds_bytes);
     p.fp_mode = ds->fp_mode;
     p.nmix_tab = ds->d_tab;
     p.ncw = ncw;

@@ -9,6 +9,7 @@ struct BlLogpParams {
     int k, nloc, rec_stride;
     int max_abundance;   // occu_rn only
     int rn_off;          // occu_rn / dynamic occupancy: byte offset in LDS of its scratch (see BlNutsParams)
+    int nmix_lds;        // MODEL 4: the table staged in LDS (see BlNutsParams)
     int lane_grp;        // lanes per site pair (see BlNutsParams)
     int fp_mode;         // false-positive coordinate (see BlNutsParams)
     const float *nmix_tab; // MODEL 4 (see BlNutsParams)
@@ -39,6 +40,9 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_logp_kernel(const BlLogpPara
         ld = p.dd.n_stride;
     }
     if constexpr (MODEL == 1) bl_rn_fill_lgamma(p.rn_off, p.max_abundance, 64 * (CW + 1)); // (the barrier below publishes it)
+    if constexpr (MODEL == 4) {
+        if (p.nmix_lds) bl_stage_nmix_tab(p.nmix_tab + s0, p.dd.n_stride, cnt, 2 * ((p.nloc + 1) / 2), p.dd.T * (p.max_abundance + 1), p.rn_off, 64 * (CW + 1));
+    }
     float *sh_coef = bl_lds_f(BL_OFF_COEF);
     if (tid < 64) sh_coef[tid] = 0.0f;
     __syncthreads();
@@ -55,7 +59,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_logp_kernel(const BlLogpPara
         if (wave == 0 && lane < D) sh_coef[my_pos] = p.theta[(size_t)b * D + lane];
         __syncthreads();
         if (wave > 0) { // compute waves, exactly as in the NUTS kernel
-            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, p.dd.T, p.dd.J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, p.dd.n_stride, nsp, p.sp_lds, p.rn_off, p.lane_grp);
+            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, p.dd.T, p.dd.J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, (MODEL == 4 && p.nmix_lds) ? 2 * ((p.nloc + 1) / 2) : p.dd.n_stride, nsp, p.sp_lds, p.rn_off, p.lane_grp, p.nmix_lds);
         }
         __syncthreads();
         if (wave == 0) {

@@ -105,6 +105,7 @@ struct BlNutsParams {
     int max_abundance;             // occu_rn only (occu_rn.py:26)
     int rn_off;                    // occu_rn: byte offset in LDS of its scratch (lgamma table + wave-private tables), behind the records;
                                    // dynamic occupancy (MODEL 8): of its lane-private columns (dyn_device.hpp)
+    int nmix_lds;                  // MODEL 4: 1 = the table's columns of a workgroup's sites are staged in LDS at rn_off (row length 2 ceil(nloc / 2))
     int lane_grp;                  // lanes that share one site pair -- dynamic occupancy: 1, 2, 4, 8 (dyn_device.hpp); occu / false positives:
                                    // log2(period lanes) | log2(visit lanes) << 4, 0 = one pair per lane (occu_device.hpp: bl_eval_sites_grp)
     int allow_local;               // 0: always use the placement-independent exchange
@@ -228,6 +229,9 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         ld = p.n_stride;
     }
     if constexpr (MODEL == 1) bl_rn_fill_lgamma(p.rn_off, p.max_abundance, 64 * (CW + 1)); // (the barrier below publishes it)
+    if constexpr (MODEL == 4) {
+        if (p.nmix_lds) bl_stage_nmix_tab(p.nmix_tab + s0, p.n_stride, cnt, 2 * ((p.nloc + 1) / 2), T * (p.max_abundance + 1), p.rn_off, 64 * (CW + 1));
+    }
     float *sh_coef = bl_lds_f(BL_OFF_COEF);
     int *sh_flag = bl_lds_i(BL_OFF_FLAG);
     float *sh_ckr = bl_lds_f(BL_OFF_CKR), *sh_ckrs = bl_lds_f(BL_OFF_CKRS);
@@ -630,7 +634,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #ifdef BL_STAMPS
             const long long st_a0 = (long long)clock64();
 #endif
-            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, p.n_stride, nsp, p.sp_lds, p.rn_off, p.lane_grp);
+            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, (MODEL == 4 && p.nmix_lds) ? 2 * ((p.nloc + 1) / 2) : p.n_stride, nsp, p.sp_lds, p.rn_off, p.lane_grp, p.nmix_lds);
 #ifdef BL_STAMPS
             st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
 #endif

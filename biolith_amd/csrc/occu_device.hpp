@@ -1215,6 +1215,15 @@ __device__ __forceinline__ void bl_stage_records(const float *__restrict__ rows,
     }
 }
 
+// nmixture: this workgroup's columns of the table B[rows = T (K + 1)][site] (HBM / L2, row length n_stride; `tab` already points at
+// the slice's first site) copied to LDS at byte offset `off`, row length `ld` floats (an even number >= cnt)
+__device__ __forceinline__ void bl_stage_nmix_tab(const float *__restrict__ tab, int n_stride, int cnt, int ld, int rows, int off, int nthreads)
+{
+    float *dst = reinterpret_cast<float *>(bl_smem_raw + off);
+    for (int r = 0; r < rows; r++)
+        for (int i = threadIdx.x; i < cnt; i += nthreads) dst[(size_t)r * ld + i] = tab[(size_t)r * n_stride + i];
+}
+
 // Padded coefficient layout in LDS: beta_k at k (k <= KS), alpha_k at KS+1+k.  dim d of theta
 // (d <= Ks: beta_d, else alpha_{d-Ks-1}) lives at:
 // MODEL 2's extra coordinate phi (d = Ks+Ko+2) lives at KS+KO+3, after the log-lik slot of the partial rows.
@@ -1296,7 +1305,7 @@ __device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, con
 template <int KS, int KO, bool LDS, int MODEL, int CW>
 __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__restrict__ grows, int ld_or_stride, int cnt,
                                            int T, int J, int max_abundance, int fp_mode, const float *__restrict__ tab = nullptr,
-                                           int tab_ld = 0, int n_species = 1, int sp_lds = 0, int rn_off = 0, int lane_grp = 0)
+                                           int tab_ld = 0, int n_species = 1, int sp_lds = 0, int rn_off = 0, int lane_grp = 0, int nmix_lds = 0)
 {
     const int row_stride = n_species > 1 ? n_species * BL_SP_PART(KS, KO) : BL_PART_STRIDE;
     for (int sp = 0; sp < n_species; sp++) {
@@ -1318,7 +1327,12 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi, row_stride, sp * BL_SP_PART(KS, KO));
     } else if constexpr (MODEL == 4) {
         static_assert(LDS, "N-mixture model: LDS records only");
-        bl_eval_sites_nmix<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, max_abundance, tab, tab_ld, beta, alpha, ll, gb, ga, lane_grp);
+        // (round 4) the data-only table B[t][n][site] of this workgroup's sites staged in LDS behind the records when it fits (host:
+        // nmix_lds; bl_stage_nmix_tab): the two passes over n then wait for LDS instead of L2 -- two instances, so that the staged one's
+        // loads are DS instructions (one generic pointer for both would make them FLAT)
+        if (nmix_lds) bl_eval_sites_nmix<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, max_abundance, reinterpret_cast<const float *>(bl_smem_raw + rn_off),
+                                                           tab_ld, beta, alpha, ll, gb, ga, lane_grp);
+        else bl_eval_sites_nmix<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, max_abundance, tab, tab_ld, beta, alpha, ll, gb, ga, lane_grp);
         bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga);
     } else if constexpr (MODEL == 8) {
         static_assert(LDS, "dynamic occupancy model: LDS records only");
