@@ -298,12 +298,15 @@ __device__ __forceinline__ void bl_eval_sites_dyn_scaled(int ct, int pstride, in
         if (T - 1 == sub + G) own_rho[1] = rho;
         const bl_f2 g1g = gam * (bl2(1.0f) - gam), e1e = eps * (bl2(1.0f) - eps);
         {
+            // (volatile LDS-address-space loads: the loop has no store, so the compiler is otherwise free to sink the "a step ahead" loads
+            // to right in front of their use -- it did: `ds_read2st64_b64 ... s_waitcnt lgkmcnt(0)` at the head of every step)
+            typedef __attribute__((address_space(3))) const volatile bl_f2 BlLdsV2;
             const int t0 = max(T - 2, 0);
-            float2 fn = col[(2 * t0) * CT], pn = col[(2 * t0 + 1) * CT];
+            bl_f2 fn = *(BlLdsV2 *)&col[(2 * t0) * CT], pn = *(BlLdsV2 *)&col[(2 * t0 + 1) * CT];
             for (int t = T - 2; t >= 0; t--) {
-                const bl_f2 f = bl_f2{fn.x, fn.y}, p1 = bl_f2{pn.x, pn.y};
+                const bl_f2 f = fn, p1 = pn;
                 const int tp = max(t - 1, 0);
-                fn = col[(2 * tp) * CT]; pn = col[(2 * tp + 1) * CT];
+                fn = *(BlLdsV2 *)&col[(2 * tp) * CT]; pn = *(BlLdsV2 *)&col[(2 * tp + 1) * CT];
                 const bl_f2 q1 = bl_rcp_2(p1), q0 = bl_rcp_2(bl2(1.0f) - p1);
                 const bl_f2 r1 = bl_f2{p1.x > 0.0f ? q1.x : 0.0f, p1.y > 0.0f ? q1.y : 0.0f};
                 const bl_f2 r0 = bl_f2{p1.x < 1.0f ? q0.x : 0.0f, p1.y < 1.0f ? q0.y : 0.0f};
