@@ -648,8 +648,10 @@ def main(argv=None):
         # random effects: <covariate capacity, model kind, rows in LDS, sampler-vector tier in LDS>
         kernel_name = (f"bl_re_nuts_kernel<{4 if max(ds.Ks, ds.Ko) <= 4 else 16}, 0, {'true' if res0.lds_staged else 'false'}, {res0.lds_vector_tier}>"
                        if wl["model"] == "occu_re" else
-                       # <KS, KO, LDS-staged, model id, compute waves>: occu = 0; occu_rn = 1; dynamic occupancy = 8
-                       f"bl_nuts_kernel<{ds.Ks}, {ds.Ko}, true, {dict(occu_rn=1, occu_dyn=8).get(wl['model'], 0)}, {res0.threads_per_wg // 64 - 1}>")
+                       # <KS, KO, LDS-staged, model id, compute waves, GRP>: occu = 0; occu_rn = 1; dynamic occupancy = 8; GRP = the instantiation
+                       # that carries the lane groups / the one-workgroup path (the plain model only when the host chose them)
+                       f"bl_nuts_kernel<{ds.Ks}, {ds.Ko}, true, {dict(occu_rn=1, occu_dyn=8).get(wl['model'], 0)}, {res0.threads_per_wg // 64 - 1}, "
+                       f"{'true' if wl['model'] == 'occu' and (res0.lane_group != (1, 1) or res0.wgs_per_chain == 1) else 'false'}>")
         us_leap = 1e3 * kernel_ms_mean / (leap_mean / NCH)
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

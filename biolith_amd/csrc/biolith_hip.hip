@@ -1707,6 +1707,10 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.rn_off = BL_OFF_DATA + ((nloc + 1) / 2) * ld * 4; // (occu_rn: one species)
     p.lane_grp = ds->model == 8 ? dyn_lanes_per_pair(ds, C) : grp;
     p.nmix_lds = nmix_table_in_lds(ds, staged, nloc, &lds_bytes);
+    // the GRP instantiation (lane groups; the exchange-free path of a one-workgroup chain) only where it is needed: the headline's kernel
+    // stays the one-pair-per-lane form alone
+    p.grp_kernel = ((ds->model == 0 || ds->model == 2) && staged && (grp > 0 || k == 1)) ? 1 : 0;
+    if (const char *e = getenv("BIOLITH_HIP_GRP_KERNEL")) { if (e[0] == '1' && (ds->model == 0 || ds->model == 2) && staged) p.grp_kernel = 1; } // A/B knob: the GRP form although it is not needed
     p.fp_mode = ds->fp_mode;
     p.nmix_tab = ds->d_tab;
     p.ncw = ncw;

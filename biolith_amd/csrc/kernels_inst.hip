@@ -28,6 +28,8 @@ static int bl_launch(K kernel, const P *p, int grid, int threads, int lds_bytes,
 // Instantiations (CW = compute waves per workgroup, chosen by the host's choose_geometry):
 //   occu and false positives, LDS-staged: CW 3 and 4, and BL_CWAVES_SINGLE (7) for chains of ONE workgroup (small problems: no exchange);  occu, HBM rows: CW 4;  occu_rn: CW 7 (BL_CWAVES_RN);  false positives, occu_cop, nmixture: CW 3 and 4.
 #define BL_PICK(KERNEL, P, LDS, MODEL, CW) bl_launch(KERNEL<BL_KS, BL_KO, LDS, MODEL, CW>, P, grid, 64 * (CW + 1), lds_bytes, stream)
+// the sampler's GRP instantiation (lane groups / one workgroup per chain: nuts_kernel.hpp) of the plain and false-positive models
+#define BL_PICK_GRP(P, MODEL, CW) bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true>, P, grid, 64 * (CW + 1), lds_bytes, stream)
 
 extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int grid, int lds_bytes, int staged, int model, hipStream_t stream)
 {
@@ -39,9 +41,11 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
     }
     if (model == 2) {
 #if BL_HAVE_RN
+        if (staged && p->grp_kernel && p->ncw == 3) return BL_PICK_GRP(p, 2, 3);
+        if (staged && p->grp_kernel && p->ncw == 4) return BL_PICK_GRP(p, 2, 4);
+        if (staged && p->ncw == BL_CWAVES_SINGLE) return BL_PICK_GRP(p, 2, BL_CWAVES_SINGLE);
         if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 2, 3);
         if (staged && p->ncw == 4) return BL_PICK(bl_nuts_kernel, p, true, 2, 4);
-        if (staged && p->ncw == BL_CWAVES_SINGLE) return BL_PICK(bl_nuts_kernel, p, true, 2, BL_CWAVES_SINGLE);
 #endif
         return (int)hipErrorNotSupported;
     }
@@ -66,9 +70,11 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
 #endif
         return (int)hipErrorNotSupported;
     }
+    if (staged && p->grp_kernel && p->ncw == 3) return BL_PICK_GRP(p, 0, 3);
+    if (staged && p->grp_kernel && p->ncw == 4) return BL_PICK_GRP(p, 0, 4);
+    if (staged && p->ncw == BL_CWAVES_SINGLE) return BL_PICK_GRP(p, 0, BL_CWAVES_SINGLE);
     if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 0, 3);
     if (staged && p->ncw == 4) return BL_PICK(bl_nuts_kernel, p, true, 0, 4);
-    if (staged && p->ncw == BL_CWAVES_SINGLE) return BL_PICK(bl_nuts_kernel, p, true, 0, BL_CWAVES_SINGLE);
 #ifdef BL_OCCU_CWX
     if (staged && p->ncw == BL_OCCU_CWX) return BL_PICK(bl_nuts_kernel, p, true, 0, BL_OCCU_CWX);
 #endif

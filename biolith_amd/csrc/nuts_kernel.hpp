@@ -98,6 +98,7 @@ struct BlNutsParams {
     int rec_stride;                // floats per LDS pair record
     int nvp;                       // granules per workgroup record: 16, 32 or 64 (>= D+4)
     int ncw;                       // compute waves per workgroup: selects the CW instantiation (host side)
+    int grp_kernel;                // 1: launch the GRP instantiation (lane groups chosen, or a chain of one workgroup); host side
     int wide;                      // 1: the chain's workgroups span XCDs (blocks chain*k .. chain*k + k - 1), fabric exchange
     const float *nmix_tab;         // MODEL 4: B[t][n][site] = sum_j m log C(n, y_j) (-inf below the largest count), row length n_stride
     int fp_mode;                   // MODEL 2 / 3: 0 none, 1 = rate acts on every site ("constant"), 2 = on unoccupied sites only
@@ -202,9 +203,12 @@ struct BlSpinBound {
 // to publish the corrected one without reading anybody's record in between, so it can be two epochs ahead of a peer that is still
 // reading -- four slots keep those apart (two sufficed while dropped evaluations were not published).
 #define BL_XCHG_SLOTS 4u
-template <int KS, int KO, bool LDS, int MODEL, int CW>
+// GRP: the instantiation for lane groups and for chains of ONE workgroup (occu_device.hpp: bl_phase_a); without it a chain of one
+// workgroup goes through the exchange like any other (as until round 3)
+template <int KS, int KO, bool LDS, int MODEL, int CW, bool GRP = false>
 __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsParams p)
 {
+    const bool multi_wg = !GRP || p.k > 1; // (compile-time true without GRP)
     // XCD-aware mapping (speed only; see header): label = b % 8 names a set of blocks that share an XCD.
     // Wide geometry (slices that only fit LDS when a chain takes more than one XCD's CUs): consecutive blocks, any XCD.
     const int label = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -634,7 +638,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #ifdef BL_STAMPS
             const long long st_a0 = (long long)clock64();
 #endif
-            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, (MODEL == 4 && p.nmix_lds) ? 2 * ((p.nloc + 1) / 2) : p.n_stride, nsp, p.sp_lds, p.rn_off, p.lane_grp, p.nmix_lds);
+            bl_phase_a<KS, KO, LDS, MODEL, CW, GRP || (MODEL != 0 && MODEL != 2)>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, (MODEL == 4 && p.nmix_lds) ? 2 * ((p.nloc + 1) / 2) : p.n_stride, nsp, p.sp_lds, p.rn_off, p.lane_grp, p.nmix_lds);
 #ifdef BL_STAMPS
             st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
 #endif
@@ -653,7 +657,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             // accesses through LDS-address-space pointers: program order kept, ds_read / ds_write -- a volatile generic pointer makes
             // them flat_load / flat_store with system coherence bits.)
             epoch_c++;
-            if (p.k > 1) { // (one workgroup per chain: nothing to publish -- the control wave reads the rows from LDS behind the barrier)
+            if (multi_wg) { // (one workgroup per chain: nothing to publish -- the control wave reads the rows from LDS behind the barrier)
             typedef __attribute__((address_space(3))) volatile unsigned BlLdsU;
             typedef __attribute__((address_space(3))) const volatile float BlLdsF;
             BlLdsU *tags = (BlLdsU *)bl_lds_i(BL_OFF_TAG);
@@ -800,7 +804,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             for (int z = 0; z < p.first_delay; z++) __builtin_amdgcn_s_sleep(1);
             double acc = 0.0;
             bool timed_out = false;
-            if (p.k == 1) {
+            if (!multi_wg) {
                 // ONE workgroup per chain (round 4; small problems -- simulate()'s defaults, the size of the reference's own tests): there is
                 // nobody to exchange with, so the hand-off through L2 (a store, a round trip, the sums: ~1 500 cycles of a 5 000-cycle tick)
                 // is skipped and the waves' rows are added straight from LDS -- complete and visible behind the barrier above.  Same fixed
@@ -879,7 +883,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             }
             // fold the 64/nvp lane groups (each summed a different subset of the workgroups): element-wise
             // across rows, by gfx950's v_permlane16_swap / v_permlane32_swap (one VALU op per 32-bit half)
-            if (p.k > 1) {
+            if (multi_wg) {
                 if (nvp <= 16) acc = bl_fold_rows16_d(acc);
                 if (nvp <= 32) acc = bl_fold_halves32_d(acc);
             }

@@ -1302,7 +1302,11 @@ __device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, con
 #define BL_SP_COEF(KS, KO) ((KS) + (KO) + 2)
 #define BL_SP_PART(KS, KO) ((KS) + (KO) + 4)
 #define BL_PART_FLOATS 768 // floats between BL_OFF_PART and BL_OFF_CKR
-template <int KS, int KO, bool LDS, int MODEL, int CW>
+// GRP (round 4): the kernel instantiation carries the lane-group evaluators of the plain / false-positive models (and, in the NUTS kernel,
+// the one-workgroup path without an exchange).  The headline's instantiation does NOT: with both forms in one kernel the one-pair-per-lane
+// evaluation ran 4.4 % slower and the k == 1 branches cost another 2.5 % (same-box A/B of variant libraries, profiles/NOTES.md) -- the
+// host launches the GRP form only when it has chosen lane groups or a single workgroup.
+template <int KS, int KO, bool LDS, int MODEL, int CW, bool GRP = true>
 __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__restrict__ grows, int ld_or_stride, int cnt,
                                            int T, int J, int max_abundance, int fp_mode, const float *__restrict__ tab = nullptr,
                                            int tab_ld = 0, int n_species = 1, int sp_lds = 0, int rn_off = 0, int lane_grp = 0, int nmix_lds = 0)
@@ -1322,8 +1326,14 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         static_assert(LDS, "false-positive model: LDS records only");
         float gphi = -0.0f;
         const BlFpScalars fp = bl_fp_scalars(bl_lds_f(BL_OFF_COEF)[n_species * BL_SP_COEF(KS, KO) + 1], fp_mode == 1);
-        if (lane_grp > 0) bl_eval_sites_grp<KS, KO, CW * 64, true>(ct, ld_or_stride, cnt, T, J, lane_grp, fp, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
-        else bl_eval_sites_fp<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
+        bool grouped = false;
+        if constexpr (GRP) {
+            if (lane_grp > 0) {
+                bl_eval_sites_grp<KS, KO, CW * 64, true>(ct, ld_or_stride, cnt, T, J, lane_grp, fp, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
+                grouped = true;
+            }
+        }
+        if (!grouped) bl_eval_sites_fp<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
         bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi, row_stride, sp * BL_SP_PART(KS, KO));
     } else if constexpr (MODEL == 4) {
         static_assert(LDS, "N-mixture model: LDS records only");
@@ -1365,7 +1375,7 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi);
     } else {
         bool grouped = false;
-        if constexpr (LDS) {
+        if constexpr (LDS && GRP) {
             if (lane_grp > 0) { // lane groups over the visits (wave-uniform)
                 float gphi = 0.0f;
                 bl_eval_sites_grp<KS, KO, CW * 64, false>(ct, ld_or_stride, cnt, T, J, lane_grp, BlFpScalars{}, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
