@@ -203,6 +203,9 @@ struct BlSpinBound {
 // to publish the corrected one without reading anybody's record in between, so it can be two epochs ahead of a peer that is still
 // reading -- four slots keep those apart (two sufficed while dropped evaluations were not published).
 #define BL_XCHG_SLOTS 4u
+#ifndef BL_GRP_FORM
+#define BL_GRP_FORM 2 // what the sampler's GRP instantiation carries: 2 = the lane-group evaluator alone, 1 = both evaluators (A/B)
+#endif
 // GRP: the instantiation for lane groups and for chains of ONE workgroup (occu_device.hpp: bl_phase_a); without it a chain of one
 // workgroup goes through the exchange like any other (as until round 3)
 template <int KS, int KO, bool LDS, int MODEL, int CW, bool GRP = false>
@@ -638,7 +641,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #ifdef BL_STAMPS
             const long long st_a0 = (long long)clock64();
 #endif
-            bl_phase_a<KS, KO, LDS, MODEL, CW, GRP || (MODEL != 0 && MODEL != 2)>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, (MODEL == 4 && p.nmix_lds) ? 2 * ((p.nloc + 1) / 2) : p.n_stride, nsp, p.sp_lds, p.rn_off, p.lane_grp, p.nmix_lds);
+            bl_phase_a<KS, KO, LDS, MODEL, CW, GRP ? BL_GRP_FORM : 0>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, (MODEL == 4 && p.nmix_lds) ? 2 * ((p.nloc + 1) / 2) : p.n_stride, nsp, p.sp_lds, p.rn_off, p.lane_grp, p.nmix_lds);
 #ifdef BL_STAMPS
             st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
 #endif

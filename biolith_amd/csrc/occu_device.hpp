@@ -1306,7 +1306,10 @@ __device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, con
 // the one-workgroup path without an exchange).  The headline's instantiation does NOT: with both forms in one kernel the one-pair-per-lane
 // evaluation ran 4.4 % slower and the k == 1 branches cost another 2.5 % (same-box A/B of variant libraries, profiles/NOTES.md) -- the
 // host launches the GRP form only when it has chosen lane groups or a single workgroup.
-template <int KS, int KO, bool LDS, int MODEL, int CW, bool GRP = true>
+// GRP = 0: the one-pair-per-lane evaluators only; 1: both, chosen at run time by lane_grp (the parity hook: one launch serves either);
+// 2: the lane-group evaluator only (lane_grp = 0 is its one-lane group) -- the sampler's GRP instantiation, which then does not carry the
+// eight unrolled one-pair forms either.
+template <int KS, int KO, bool LDS, int MODEL, int CW, int GRP = 1>
 __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__restrict__ grows, int ld_or_stride, int cnt,
                                            int T, int J, int max_abundance, int fp_mode, const float *__restrict__ tab = nullptr,
                                            int tab_ld = 0, int n_species = 1, int sp_lds = 0, int rn_off = 0, int lane_grp = 0, int nmix_lds = 0)
@@ -1326,14 +1329,18 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         static_assert(LDS, "false-positive model: LDS records only");
         float gphi = -0.0f;
         const BlFpScalars fp = bl_fp_scalars(bl_lds_f(BL_OFF_COEF)[n_species * BL_SP_COEF(KS, KO) + 1], fp_mode == 1);
-        bool grouped = false;
-        if constexpr (GRP) {
-            if (lane_grp > 0) {
-                bl_eval_sites_grp<KS, KO, CW * 64, true>(ct, ld_or_stride, cnt, T, J, lane_grp, fp, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
-                grouped = true;
+        if constexpr (GRP == 2) {
+            bl_eval_sites_grp<KS, KO, CW * 64, true>(ct, ld_or_stride, cnt, T, J, lane_grp, fp, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
+        } else {
+            bool grouped = false;
+            if constexpr (GRP == 1) {
+                if (lane_grp > 0) {
+                    bl_eval_sites_grp<KS, KO, CW * 64, true>(ct, ld_or_stride, cnt, T, J, lane_grp, fp, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
+                    grouped = true;
+                }
             }
+            if (!grouped) bl_eval_sites_fp<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
         }
-        if (!grouped) bl_eval_sites_fp<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
         bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi, row_stride, sp * BL_SP_PART(KS, KO));
     } else if constexpr (MODEL == 4) {
         static_assert(LDS, "N-mixture model: LDS records only");
@@ -1374,15 +1381,20 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         bl_eval_sites_cop<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, fp, beta, alpha, ll, gb, ga, gphi, lane_grp);
         bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi);
     } else {
-        bool grouped = false;
-        if constexpr (LDS && GRP) {
-            if (lane_grp > 0) { // lane groups over the visits (wave-uniform)
-                float gphi = 0.0f;
-                bl_eval_sites_grp<KS, KO, CW * 64, false>(ct, ld_or_stride, cnt, T, J, lane_grp, BlFpScalars{}, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
-                grouped = true;
+        if constexpr (LDS && GRP == 2) {
+            float gphi = 0.0f;
+            bl_eval_sites_grp<KS, KO, CW * 64, false>(ct, ld_or_stride, cnt, T, J, lane_grp, BlFpScalars{}, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
+        } else {
+            bool grouped = false;
+            if constexpr (LDS && GRP == 1) {
+                if (lane_grp > 0) { // lane groups over the visits (wave-uniform)
+                    float gphi = 0.0f;
+                    bl_eval_sites_grp<KS, KO, CW * 64, false>(ct, ld_or_stride, cnt, T, J, lane_grp, BlFpScalars{}, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
+                    grouped = true;
+                }
             }
+            if (!grouped) bl_eval_sites<KS, KO, LDS, MODEL, CW * 64>(ct, grows, ld_or_stride, cnt, T, J, max_abundance, beta, alpha, ll, gb, ga, sp * sp_lds);
         }
-        if (!grouped) bl_eval_sites<KS, KO, LDS, MODEL, CW * 64>(ct, grows, ld_or_stride, cnt, T, J, max_abundance, beta, alpha, ll, gb, ga, sp * sp_lds);
         bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga, 0.0f, row_stride, sp * BL_SP_PART(KS, KO));
     }
     }

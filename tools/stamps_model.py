@@ -22,6 +22,12 @@ with contextlib.redirect_stdout(io.StringIO()):
     elif which == "occu_dyn":
         d, _ = simulate_dyn(n_sites=2000, n_periods=8, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=28, session_duration=7)
         ds = OccuDataset(d["site_covs"], d["obs_covs"], d["obs"], model="occu_dyn")
+    elif which == "occu_small":   # one workgroup per chain (k = 1: no exchange), 7 compute waves
+        d, _ = simulate(n_sites=200, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7)
+        ds = OccuDataset(d["site_covs"], d["obs_covs"], d["obs"])
+    elif which == "occu_cfg1like":   # simulate()'s defaults' shape (100 x 52) at the stamps build's 3 + 3 covariates
+        d, _ = simulate(n_sites=100, n_site_covs=3, n_obs_covs=3)
+        ds = OccuDataset(d["site_covs"], d["obs_covs"], d["obs"])
     elif which == "occu_stacked":
         d, _ = simulate(n_sites=2000, n_periods=8, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=28, session_duration=7)
         ds = OccuDataset(d["site_covs"], d["obs_covs"], d["obs"])
