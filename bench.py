@@ -651,7 +651,9 @@ def main(argv=None):
                        # <KS, KO, LDS-staged, model id, compute waves, GRP>: occu = 0; occu_rn = 1; dynamic occupancy = 8; GRP = the instantiation
                        # that carries the lane groups / the one-workgroup path (the plain model only when the host chose them)
                        f"bl_nuts_kernel<{ds.Ks}, {ds.Ko}, true, {dict(occu_rn=1, occu_dyn=8).get(wl['model'], 0)}, {res0.threads_per_wg // 64 - 1}, "
-                       f"{'true' if wl['model'] == 'occu' and (res0.lane_group != (1, 1) or res0.wgs_per_chain == 1) else 'false'}>")
+                       f"{'true' if (wl['model'] == 'occu' and (res0.lane_group != (1, 1) or res0.wgs_per_chain == 1)) or wl['model'] == 'occu_dyn' else 'false'}"
+                       # the plain model, one pair per lane: one instantiation per visits-per-period form (1 .. 6, 8 unrolled, 0 = run-time J)
+                       + (f", {ds.J if ds.J in (1, 2, 3, 4, 5, 6, 8) else 0}>" if wl['model'] == 'occu' and res0.lane_group == (1, 1) and res0.wgs_per_chain > 1 else ", -1>"))
         us_leap = 1e3 * kernel_ms_mean / (leap_mean / NCH)
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

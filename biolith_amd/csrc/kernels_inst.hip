@@ -30,6 +30,22 @@ static int bl_launch(K kernel, const P *p, int grid, int threads, int lds_bytes,
 #define BL_PICK(KERNEL, P, LDS, MODEL, CW) bl_launch(KERNEL<BL_KS, BL_KO, LDS, MODEL, CW>, P, grid, 64 * (CW + 1), lds_bytes, stream)
 // the sampler's GRP instantiation (lane groups / one workgroup per chain: nuts_kernel.hpp) of the plain and false-positive models
 #define BL_PICK_GRP(P, MODEL, CW) bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true>, P, grid, 64 * (CW + 1), lds_bytes, stream)
+// the plain model, one pair per lane: one instantiation per visits-per-period form (1 .. 6, 8 unrolled; 0 = any J at run time)
+#ifndef BL_J_LEAN
+#define BL_J_LEAN true // (A/B: -DBL_J_LEAN=false)
+#endif
+#define BL_PICK_J(P, CW, JSEL) bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, 0, CW, false, JSEL, BL_J_LEAN>, P, grid, 64 * (CW + 1), lds_bytes, stream)
+#define BL_PICK_J_ANY(P, CW)                                   \
+    switch ((P)->J) {                                          \
+    case 1: return BL_PICK_J(P, CW, 1);                        \
+    case 2: return BL_PICK_J(P, CW, 2);                        \
+    case 3: return BL_PICK_J(P, CW, 3);                        \
+    case 4: return BL_PICK_J(P, CW, 4);                        \
+    case 5: return BL_PICK_J(P, CW, 5);                        \
+    case 6: return BL_PICK_J(P, CW, 6);                        \
+    case 8: return BL_PICK_J(P, CW, 8);                        \
+    default: return BL_PICK_J(P, CW, 0);                       \
+    }
 
 extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int grid, int lds_bytes, int staged, int model, hipStream_t stream)
 {
@@ -58,6 +74,9 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
     }
     if (model == 8) { // dynamic occupancy (dyn_device.hpp): site-covariate capacities up to BL_DYN_MAX_KS
 #if BL_KS <= BL_DYN_MAX_KS
+        // (T <= 2 G: the instantiation that carries the scaled-likelihood form alone; else the one with the first form alone)
+        if (staged && p->ncw == 3 && p->T <= 2 * p->lane_grp) return BL_PICK_GRP(p, 8, 3);
+        if (staged && p->ncw == 4 && p->T <= 2 * p->lane_grp) return BL_PICK_GRP(p, 8, 4);
         if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 8, 3);
         if (staged && p->ncw == 4) return BL_PICK(bl_nuts_kernel, p, true, 8, 4);
 #endif
@@ -73,6 +92,10 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
     if (staged && p->grp_kernel && p->ncw == 3) return BL_PICK_GRP(p, 0, 3);
     if (staged && p->grp_kernel && p->ncw == 4) return BL_PICK_GRP(p, 0, 4);
     if (staged && p->ncw == BL_CWAVES_SINGLE) return BL_PICK_GRP(p, 0, BL_CWAVES_SINGLE);
+    // one species and a one-batch poll (k <= 8 x 64 / nvp): the lean per-form instantiations; else the kernel that carries everything
+    const bool lean = !BL_J_LEAN || (p->n_species <= 1 && p->k <= 8 * (64 / p->nvp));
+    if (staged && p->ncw == 3 && lean) { BL_PICK_J_ANY(p, 3) }
+    if (staged && p->ncw == 4 && lean) { BL_PICK_J_ANY(p, 4) }
     if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 0, 3);
     if (staged && p->ncw == 4) return BL_PICK(bl_nuts_kernel, p, true, 0, 4);
 #ifdef BL_OCCU_CWX

@@ -208,7 +208,10 @@ struct BlSpinBound {
 #endif
 // GRP: the instantiation for lane groups and for chains of ONE workgroup (occu_device.hpp: bl_phase_a); without it a chain of one
 // workgroup goes through the exchange like any other (as until round 3)
-template <int KS, int KO, bool LDS, int MODEL, int CW, bool GRP = false>
+// JSEL: the plain model's one-pair-per-lane form this instantiation carries (occu_device.hpp: bl_eval_sites; -1 = all of them)
+// LEAN: ONE species, and every workgroup's record polled in one batch (k <= 8 x 64 / nvp) -- by far the commonest launch; the kernel then
+// carries neither the species loops nor the several-batches poll (same reason as JSEL: what a kernel merely carries costs the rest).
+template <int KS, int KO, bool LDS, int MODEL, int CW, bool GRP = false, int JSEL = -1, bool LEAN = false>
 __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsParams p)
 {
     const bool multi_wg = !GRP || p.k > 1; // (compile-time true without GRP)
@@ -219,7 +222,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     const int member = p.wide ? (int)blockIdx.x % p.k : slot % p.k;
     if (chain >= p.num_chains) return; // whole block leaves before any barrier or exchange
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int Ks = p.Ks, Ko = p.Ko, nsp = p.n_species;
+    const int Ks = p.Ks, Ko = p.Ko, nsp = LEAN ? 1 : p.n_species;
     const int Dsp = Ks + Ko + 2;    // coordinates of one species
     const int D = bl_model_dim<MODEL>(Ks, Ko, p.fp_mode) + (nsp - 1) * Dsp;
     const int T = p.T, J = p.J;
@@ -315,7 +318,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         pval[q] = (w < p.k) ? 1.0f : 0.0f;
     }
     const int nq = (p.k + G - 1) / G; // loads per round actually needed (<= 8 when k <= 8 G)
-    const bool one_batch = p.k <= 8 * G;
+    const bool one_batch = LEAN || p.k <= 8 * G;
 
     if (wave == 0) {
         S = cold->num_samples; W = cold->num_warmup; total = W + S;
@@ -641,7 +644,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #ifdef BL_STAMPS
             const long long st_a0 = (long long)clock64();
 #endif
-            bl_phase_a<KS, KO, LDS, MODEL, CW, GRP ? BL_GRP_FORM : 0>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, (MODEL == 4 && p.nmix_lds) ? 2 * ((p.nloc + 1) / 2) : p.n_stride, nsp, p.sp_lds, p.rn_off, p.lane_grp, p.nmix_lds);
+            bl_phase_a<KS, KO, LDS, MODEL, CW, GRP ? BL_GRP_FORM : 0, JSEL>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, (MODEL == 4 && p.nmix_lds) ? 2 * ((p.nloc + 1) / 2) : p.n_stride, nsp, p.sp_lds, p.rn_off, p.lane_grp, p.nmix_lds);
 #ifdef BL_STAMPS
             st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
 #endif

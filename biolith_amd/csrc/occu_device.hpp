@@ -1165,13 +1165,18 @@ __device__ __forceinline__ void bl_eval_sites_nmix(int ct, int pstride, int cnt,
 
 // MODEL 0 = occu (occu.py); MODEL 1 = occu_rn (occu_rn.py) has its own entry, bl_eval_sites_rn (rn_device.hpp), called by bl_phase_a;
 // MODEL 2 (occu with false positives), 3 (occu_cop), 4 (nmixture) are dispatched by bl_phase_a below
-template <int KS, int KO, bool LDS, int MODEL, int CT>
+// JSEL: -1 = every form in one kernel, chosen by a switch on J (the parity hook); >= 0 = THE form of this kernel -- JSEL visits per period
+// unrolled (1 .. 6, 8), or 0: any J at run time.  The sampler is instantiated per form (round 4): a kernel that carries all eight runs the
+// one it needs 3 % slower (headline: 2.353 -> 2.278 us per leapfrog with J = 5 alone; profiles/r04/e_ab_grp_instantiation.txt).
+template <int KS, int KO, bool LDS, int MODEL, int CT, int JSEL = -1>
 __device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ grows, int ld_or_stride, int cnt, int T, int J, int K,
                                               const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                               float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], int data_off = 0)
 {
     static_assert(MODEL == 0, "bl_eval_sites: the plain occupancy model only");
-    if constexpr (LDS) {
+    if constexpr (LDS && JSEL >= 0) {
+        bl_eval_sites_lds<KS, KO, JSEL, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off);
+    } else if constexpr (LDS) {
         switch (J) { // wave-uniform
         case 1: bl_eval_sites_lds<KS, KO, 1, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off); break;
         case 2: bl_eval_sites_lds<KS, KO, 2, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off); break;
@@ -1309,7 +1314,7 @@ __device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, con
 // GRP = 0: the one-pair-per-lane evaluators only; 1: both, chosen at run time by lane_grp (the parity hook: one launch serves either);
 // 2: the lane-group evaluator only (lane_grp = 0 is its one-lane group) -- the sampler's GRP instantiation, which then does not carry the
 // eight unrolled one-pair forms either.
-template <int KS, int KO, bool LDS, int MODEL, int CW, int GRP = 1>
+template <int KS, int KO, bool LDS, int MODEL, int CW, int GRP = 1, int JSEL = -1>
 __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__restrict__ grows, int ld_or_stride, int cnt,
                                            int T, int J, int max_abundance, int fp_mode, const float *__restrict__ tab = nullptr,
                                            int tab_ld = 0, int n_species = 1, int sp_lds = 0, int rn_off = 0, int lane_grp = 0, int nmix_lds = 0)
@@ -1363,11 +1368,11 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
 #pragma unroll
             for (int k = 0; k <= KO; k++) alpha[k] = c[BL_DYN_OA(KS) + k];
             // (at most two periods per lane of a group: the one-visit-pass form on scaled likelihoods; BL_DYN_FORM1: the first form, for A/B)
-#ifndef BL_DYN_FORM1
-            if (T <= 2 * lane_grp) bl_eval_sites_dyn_scaled<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, lane_grp, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
-            else
-#endif
-            bl_eval_sites_dyn<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, lane_grp, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
+            // GRP = 2 (the sampler's instantiation for T <= 2 G): the scaled form alone; 0: the first form alone (any T); 1: both (parity hook)
+            if constexpr (GRP == 2) bl_eval_sites_dyn_scaled<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, lane_grp, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
+            else if constexpr (GRP == 0) bl_eval_sites_dyn<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, lane_grp, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
+            else if (T <= 2 * lane_grp) bl_eval_sites_dyn_scaled<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, lane_grp, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
+            else bl_eval_sites_dyn<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, lane_grp, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
             bl_wave_partials_dyn<KS, KO>(cwave, ll, gq, ga);
         }
     } else if constexpr (MODEL == 1) {
@@ -1393,7 +1398,7 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
                     grouped = true;
                 }
             }
-            if (!grouped) bl_eval_sites<KS, KO, LDS, MODEL, CW * 64>(ct, grows, ld_or_stride, cnt, T, J, max_abundance, beta, alpha, ll, gb, ga, sp * sp_lds);
+            if (!grouped) bl_eval_sites<KS, KO, LDS, MODEL, CW * 64, JSEL>(ct, grows, ld_or_stride, cnt, T, J, max_abundance, beta, alpha, ll, gb, ga, sp * sp_lds);
         }
         bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga, 0.0f, row_stride, sp * BL_SP_PART(KS, KO));
     }
