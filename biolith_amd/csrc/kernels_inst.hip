@@ -30,6 +30,9 @@ static int bl_launch(K kernel, const P *p, int grid, int threads, int lds_bytes,
 #define BL_PICK(KERNEL, P, LDS, MODEL, CW) bl_launch(KERNEL<BL_KS, BL_KO, LDS, MODEL, CW>, P, grid, 64 * (CW + 1), lds_bytes, stream)
 // the sampler's GRP instantiation (lane groups / one workgroup per chain: nuts_kernel.hpp) of the plain and false-positive models
 #define BL_PICK_GRP(P, MODEL, CW) bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true>, P, grid, 64 * (CW + 1), lds_bytes, stream)
+// ... and its lean form (one species, one-batch poll; nuts_kernel.hpp LEAN)
+#define BL_PICK_GRP_LEAN(P, MODEL, CW) bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true, -1, true>, P, grid, 64 * (CW + 1), lds_bytes, stream)
+#define BL_IS_LEAN(P) ((P)->n_species <= 1 && (P)->k <= 8 * (64 / (P)->nvp))
 // the plain model, one pair per lane: one instantiation per visits-per-period form (1 .. 6, 8 unrolled; 0 = any J at run time)
 #ifndef BL_J_LEAN
 #define BL_J_LEAN true // (A/B: -DBL_J_LEAN=false)
@@ -51,6 +54,8 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
 {
     if (model == 1) { // occu_rn
 #if BL_HAVE_RN
+        if (staged && p->ncw == BL_CWAVES_RN && BL_IS_LEAN(p))
+            return bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, 1, BL_CWAVES_RN, false, -1, true>, p, grid, 64 * (BL_CWAVES_RN + 1), lds_bytes, stream);
         if (staged && p->ncw == BL_CWAVES_RN) return BL_PICK(bl_nuts_kernel, p, true, 1, BL_CWAVES_RN);
 #endif
         return (int)hipErrorNotSupported;
@@ -89,11 +94,12 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
 #endif
         return (int)hipErrorNotSupported;
     }
-    if (staged && p->grp_kernel && p->ncw == 3) return BL_PICK_GRP(p, 0, 3);
-    if (staged && p->grp_kernel && p->ncw == 4) return BL_PICK_GRP(p, 0, 4);
-    if (staged && p->ncw == BL_CWAVES_SINGLE) return BL_PICK_GRP(p, 0, BL_CWAVES_SINGLE);
+    if (staged && p->grp_kernel && p->ncw == 3) return BL_IS_LEAN(p) ? BL_PICK_GRP_LEAN(p, 0, 3) : BL_PICK_GRP(p, 0, 3);
+    if (staged && p->grp_kernel && p->ncw == 4) return BL_IS_LEAN(p) ? BL_PICK_GRP_LEAN(p, 0, 4) : BL_PICK_GRP(p, 0, 4);
+    if (staged && p->ncw == BL_CWAVES_SINGLE) return BL_IS_LEAN(p) ? BL_PICK_GRP_LEAN(p, 0, BL_CWAVES_SINGLE) : BL_PICK_GRP(p, 0, BL_CWAVES_SINGLE);
     // one species and a one-batch poll (k <= 8 x 64 / nvp): the lean per-form instantiations; else the kernel that carries everything
-    const bool lean = !BL_J_LEAN || (p->n_species <= 1 && p->k <= 8 * (64 / p->nvp));
+    // (and one period, at most one site pair per compute lane: nuts_kernel.hpp LEAN)
+    const bool lean = !BL_J_LEAN || (BL_IS_LEAN(p) && p->T == 1 && p->nloc <= 2 * 64 * p->ncw);
     if (staged && p->ncw == 3 && lean) { BL_PICK_J_ANY(p, 3) }
     if (staged && p->ncw == 4 && lean) { BL_PICK_J_ANY(p, 4) }
     if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 0, 3);

@@ -203,14 +203,18 @@ struct BlSpinBound {
 // to publish the corrected one without reading anybody's record in between, so it can be two epochs ahead of a peer that is still
 // reading -- four slots keep those apart (two sufficed while dropped evaluations were not published).
 #define BL_XCHG_SLOTS 4u
+#define SMALL_D_NVP(LEAN, MODEL, KS, KO) ((LEAN) && ((MODEL) == 0 || (MODEL) == 1) && (KS) + (KO) + 2 <= 8)
 #ifndef BL_GRP_FORM
 #define BL_GRP_FORM 2 // what the sampler's GRP instantiation carries: 2 = the lane-group evaluator alone, 1 = both evaluators (A/B)
 #endif
 // GRP: the instantiation for lane groups and for chains of ONE workgroup (occu_device.hpp: bl_phase_a); without it a chain of one
 // workgroup goes through the exchange like any other (as until round 3)
 // JSEL: the plain model's one-pair-per-lane form this instantiation carries (occu_device.hpp: bl_eval_sites; -1 = all of them)
-// LEAN: ONE species, and every workgroup's record polled in one batch (k <= 8 x 64 / nvp) -- by far the commonest launch; the kernel then
-// carries neither the species loops nor the several-batches poll (same reason as JSEL: what a kernel merely carries costs the rest).
+// LEAN: ONE species, ONE period, at most one site pair per compute lane, and every workgroup's record polled in one batch
+// (k <= 8 x 64 / nvp) -- by far the commonest launch of the plain model, the headline among them.  The kernel then carries neither the
+// species loops nor the several-batches poll, its evaluation is straight-line code (no loop over periods or pairs), and with <= 8
+// coefficients the sums over the dimensions and the granule count are compile-time facts too.  Same reason as JSEL: what a kernel merely
+// carries costs the rest (same-box A/Bs: 2.27 -> 2.15 -> 2.12 -> 2.03 us per leapfrog, profiles/r04/e_ab_grp_instantiation.txt).
 template <int KS, int KO, bool LDS, int MODEL, int CW, bool GRP = false, int JSEL = -1, bool LEAN = false>
 __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsParams p)
 {
@@ -222,10 +226,14 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     const int member = p.wide ? (int)blockIdx.x % p.k : slot % p.k;
     if (chain >= p.num_chains) return; // whole block leaves before any barrier or exchange
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int Ks = p.Ks, Ko = p.Ko, nsp = LEAN ? 1 : p.n_species;
+    // (one species: a compile-time fact in the lean kernels and for the models that are never sampled jointly)
+    const int Ks = p.Ks, Ko = p.Ko, nsp = (LEAN || (MODEL != 0 && MODEL != 2)) ? 1 : p.n_species;
     const int Dsp = Ks + Ko + 2;    // coordinates of one species
     const int D = bl_model_dim<MODEL>(Ks, Ko, p.fp_mode) + (nsp - 1) * Dsp;
-    const int T = p.T, J = p.J;
+    // (lean, one pair per lane: one period, a compile-time fact -- the evaluation is then straight-line code; the lane-group and the
+    // Royle-Nichols kernels keep their loops)
+    constexpr bool ONE1 = LEAN && !GRP && MODEL == 0;
+    const int T = ONE1 ? 1 : p.T, J = p.J;
     const int s0 = member * p.nloc;
     int cnt = p.n_sites - s0;
     cnt = cnt < 0 ? 0 : (cnt > p.nloc ? p.nloc : cnt);
@@ -305,7 +313,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     // exchange addressing (per lane, fixed for the whole launch): byte offsets of the <= 8 granules this
     // lane polls per round; record indices beyond k are clamped to k-1 (duplicates carry valid
     // tags and are ignored in the sum, so a round needs no predication)
-    const int nvp = p.nvp, G = 64 / nvp;
+    const int nvp = SMALL_D_NVP(LEAN, MODEL, KS, KO) ? 16 : p.nvp, G = 64 / nvp; // (<= 8 coefficients: D + 4 <= 16 granules, a compile-time fact when lean)
     const int c_idx = lane & (nvp - 1), sub = lane / nvp;
     const unsigned rec_bytes = (unsigned)(p.k * p.pitch * 8);
     const unsigned char *xbase = reinterpret_cast<const unsigned char *>(p.xchg) + (size_t)chain * BL_XCHG_SLOTS * rec_bytes;
@@ -360,7 +368,9 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     // the control wave's REGISTERS since round 3 (13 values; until then in its private LDS block, where every subtree's end and every
     // transition's end fetched them one dependent round trip after the other: two to four per such tick).  LDS keeps what only the
     // warmup adapter and the outputs touch.
-    const int Dred = D <= 8 ? 0 : D; // (0: the sums over the dimensions take the fixed three-level form)
+    // (0: the sums over the dimensions take the fixed three-level form; a compile-time fact in the lean kernels of <= 8 coefficients)
+    constexpr bool SMALL_D = SMALL_D_NVP(LEAN, MODEL, KS, KO);
+    const int Dred = (SMALL_D || D <= 8) ? 0 : D;
     float ck_last = 0.f, cks_last = 0.f;
     float t_zl = 0.f, t_rl = 0.f, t_gl = 0.f, t_zr = 0.f, t_rr = 0.f, t_gr = 0.f, t_rsum = 0.f, t_zp = 0.f, t_gp = 0.f;
     float t_wt = 0.f, t_sumacc = 0.f;
@@ -494,7 +504,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 // ------- CRITICAL: finish the leaf (_build_basetree), decide where the next one goes -------
                 const float cr = bl_leaf_momentum(rh, epsdir, cg);
                 float s_prior = pe2, s_kin = minv * cr * cr;
-                if (Dred <= 0) bl_low_sum2_w8(s_prior, s_kin); else bl_low_sum2(s_prior, s_kin, D);
+                if (SMALL_D || Dred <= 0) bl_low_sum2_w8(s_prior, s_kin); else bl_low_sum2(s_prior, s_kin, D);
                 const double Un = -ll_tot + (double)(0.5f * s_prior) + prior_const;
                 const double Kn = (double)(0.5f * s_kin);
                 double dE = (Un + Kn) - E0;
@@ -516,11 +526,11 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 } else {
                     // the first test is against the checkpoint the previous (even) leaf has just written -- popc((L - 1) >> 1) = popc(L >> 1)
                     // for odd L -- so it needs no LDS round trip; half of the odd leaves have no other test
-                    sturn = bl_is_turning(minv, ck_last, cr, srsum - cks_last + ck_last, Dred);
+                    sturn = bl_is_turning(minv, ck_last, cr, srsum - cks_last + ck_last, SMALL_D ? 0 : Dred);
                     for (int i = idx_max - 1; i >= idx_min && !sturn; i--) {
                         const float ck = sh_ckr[i * 64 + lane];
                         const float srs = srsum - sh_ckrs[i * 64 + lane] + ck;
-                        sturn = bl_is_turning(minv, ck, cr, srs, Dred);
+                        sturn = bl_is_turning(minv, ck, cr, srs, SMALL_D ? 0 : Dred);
                     }
                 }
                 if (snprop < (1 << depth) && !sturn && !sdiv) {
@@ -644,7 +654,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #ifdef BL_STAMPS
             const long long st_a0 = (long long)clock64();
 #endif
-            bl_phase_a<KS, KO, LDS, MODEL, CW, GRP ? BL_GRP_FORM : 0, JSEL>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, (MODEL == 4 && p.nmix_lds) ? 2 * ((p.nloc + 1) / 2) : p.n_stride, nsp, p.sp_lds, p.rn_off, p.lane_grp, p.nmix_lds);
+            bl_phase_a<KS, KO, LDS, MODEL, CW, GRP ? BL_GRP_FORM : 0, JSEL, ONE1>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, (MODEL == 4 && p.nmix_lds) ? 2 * ((p.nloc + 1) / 2) : p.n_stride, nsp, p.sp_lds, p.rn_off, p.lane_grp, p.nmix_lds);
 #ifdef BL_STAMPS
             st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
 #endif

@@ -456,7 +456,8 @@ __device__ __forceinline__ void bl_visit2(const bl_f2 (&w)[KO + 1], const float 
 // LDS pair records (element e of the two sites adjacent); JC > 0: J == JC at compile time -> the
 // whole period block is read with ds_read_b128 at immediate offsets and the visits are unrolled
 // (their exp/log/rcp chains interleave).  JC == 0: runtime J.
-template <int KS, int KO, int JC, int CT>
+// ONE1 (the sampler's lean instantiations): one period and at most one pair per lane -- no loops, straight-line code
+template <int KS, int KO, int JC, int CT, bool ONE1 = false>
 __device__ __forceinline__ void bl_eval_sites_lds(int ct, int pstride, int cnt, int T, int J,
                                                   const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                                   float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], int data_off = 0)
@@ -471,7 +472,7 @@ __device__ __forceinline__ void bl_eval_sites_lds(int ct, int pstride, int cnt, 
     for (int k = 0; k <= KS; k++) gb2[k] = bl2(0.0f);
 #pragma unroll
     for (int k = 0; k <= KO; k++) ga2[k] = bl2(0.0f);
-    for (int m = ct; m < npairs; m += CT) {
+    auto one_pair = [&](int m) {
         const float4 *rec = reinterpret_cast<const float4 *>(data + (size_t)m * pstride);
         const bl_f2 vmask = bl_f2{1.0f, (2 * m + 1 < cnt) ? 1.0f : 0.0f}; // odd slice: the last pair's second site is a dummy
         bl_f2 x[XQ];
@@ -490,7 +491,7 @@ __device__ __forceinline__ void bl_eval_sites_lds(int ct, int pstride, int cnt, 
         const bl_f2 sp = bl_fma2(bl_log2_2(op_eta), bl2(BL_LN2), __builtin_elementwise_max(eta, bl2(0.0f)));
         const bl_f2 psi = bl_sel_pos_one(eta, e_eta) * bl_rcp_2(op_eta);
         bl_f2 dsum = bl2(0.0f), lsite = bl2(0.0f);
-        for (int t = 0; t < T; t++) {
+        auto one_period = [&](int t) {
             bl_f2 g[KO + 1];
 #pragma unroll
             for (int k = 0; k <= KO; k++) g[k] = bl2(0.0f);
@@ -540,13 +541,17 @@ __device__ __forceinline__ void bl_eval_sites_lds(int ct, int pstride, int cnt, 
             dsum += q - psi;
 #pragma unroll
             for (int k = 0; k <= KO; k++) ga2[k] = bl_fma2(q, g[k], ga2[k]); // dummy site: g == 0
-        }
+        };
+        if constexpr (ONE1) one_period(0); // (one period: no loop)
+        else for (int t = 0; t < T; t++) one_period(t);
         ll2 = bl_fma2(lsite, vmask, ll2);
         dsum *= vmask;
         gb2[0] += dsum;
 #pragma unroll
         for (int k = 0; k < KS; k++) gb2[k + 1] = bl_fma2(dsum, x[k], gb2[k + 1]);
-    }
+    };
+    if constexpr (ONE1) { if (ct < npairs) one_pair(ct); } // (at most one pair per lane: no loop)
+    else for (int m = ct; m < npairs; m += CT) one_pair(m);
     ll += ll2.x + ll2.y;
 #pragma unroll
     for (int k = 0; k <= KS; k++) gb[k] += gb2[k].x + gb2[k].y;
@@ -1168,14 +1173,14 @@ __device__ __forceinline__ void bl_eval_sites_nmix(int ct, int pstride, int cnt,
 // JSEL: -1 = every form in one kernel, chosen by a switch on J (the parity hook); >= 0 = THE form of this kernel -- JSEL visits per period
 // unrolled (1 .. 6, 8), or 0: any J at run time.  The sampler is instantiated per form (round 4): a kernel that carries all eight runs the
 // one it needs 3 % slower (headline: 2.353 -> 2.278 us per leapfrog with J = 5 alone; profiles/r04/e_ab_grp_instantiation.txt).
-template <int KS, int KO, bool LDS, int MODEL, int CT, int JSEL = -1>
+template <int KS, int KO, bool LDS, int MODEL, int CT, int JSEL = -1, bool ONE1 = false>
 __device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ grows, int ld_or_stride, int cnt, int T, int J, int K,
                                               const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                               float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], int data_off = 0)
 {
     static_assert(MODEL == 0, "bl_eval_sites: the plain occupancy model only");
     if constexpr (LDS && JSEL >= 0) {
-        bl_eval_sites_lds<KS, KO, JSEL, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off);
+        bl_eval_sites_lds<KS, KO, JSEL, CT, ONE1>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off);
     } else if constexpr (LDS) {
         switch (J) { // wave-uniform
         case 1: bl_eval_sites_lds<KS, KO, 1, CT>(ct, ld_or_stride, cnt, T, J, beta, alpha, ll, gb, ga, data_off); break;
@@ -1314,7 +1319,7 @@ __device__ __forceinline__ void bl_wave_partials_to_lds(int cwave, float ll, con
 // GRP = 0: the one-pair-per-lane evaluators only; 1: both, chosen at run time by lane_grp (the parity hook: one launch serves either);
 // 2: the lane-group evaluator only (lane_grp = 0 is its one-lane group) -- the sampler's GRP instantiation, which then does not carry the
 // eight unrolled one-pair forms either.
-template <int KS, int KO, bool LDS, int MODEL, int CW, int GRP = 1, int JSEL = -1>
+template <int KS, int KO, bool LDS, int MODEL, int CW, int GRP = 1, int JSEL = -1, bool ONE1 = false>
 __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__restrict__ grows, int ld_or_stride, int cnt,
                                            int T, int J, int max_abundance, int fp_mode, const float *__restrict__ tab = nullptr,
                                            int tab_ld = 0, int n_species = 1, int sp_lds = 0, int rn_off = 0, int lane_grp = 0, int nmix_lds = 0)
@@ -1398,7 +1403,7 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
                     grouped = true;
                 }
             }
-            if (!grouped) bl_eval_sites<KS, KO, LDS, MODEL, CW * 64, JSEL>(ct, grows, ld_or_stride, cnt, T, J, max_abundance, beta, alpha, ll, gb, ga, sp * sp_lds);
+            if (!grouped) bl_eval_sites<KS, KO, LDS, MODEL, CW * 64, JSEL, ONE1>(ct, grows, ld_or_stride, cnt, T, J, max_abundance, beta, alpha, ll, gb, ga, sp * sp_lds);
         }
         bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga, 0.0f, row_stride, sp * BL_SP_PART(KS, KO));
     }
