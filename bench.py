@@ -648,12 +648,9 @@ def main(argv=None):
         # random effects: <covariate capacity, model kind, rows in LDS, sampler-vector tier in LDS>
         kernel_name = (f"bl_re_nuts_kernel<{4 if max(ds.Ks, ds.Ko) <= 4 else 16}, 0, {'true' if res0.lds_staged else 'false'}, {res0.lds_vector_tier}>"
                        if wl["model"] == "occu_re" else
-                       # <KS, KO, LDS-staged, model id, compute waves, GRP>: occu = 0; occu_rn = 1; dynamic occupancy = 8; GRP = the instantiation
-                       # that carries the lane groups / the one-workgroup path (the plain model only when the host chose them)
-                       f"bl_nuts_kernel<{ds.Ks}, {ds.Ko}, true, {dict(occu_rn=1, occu_dyn=8).get(wl['model'], 0)}, {res0.threads_per_wg // 64 - 1}, "
-                       f"{'true' if (wl['model'] == 'occu' and (res0.lane_group != (1, 1) or res0.wgs_per_chain == 1)) or wl['model'] == 'occu_dyn' else 'false'}"
-                       # the plain model, one pair per lane: one instantiation per visits-per-period form (1 .. 6, 8 unrolled, 0 = run-time J)
-                       + (f", {ds.J if ds.J in (1, 2, 3, 4, 5, 6, 8) else 0}>" if wl['model'] == 'occu' and res0.lane_group == (1, 1) and res0.wgs_per_chain > 1 else ", -1>"))
+                       # the instantiation that ran, as the engine reports it (bl_nuts_kernel_name) and rocprofv3 prints it:
+                       # <KS, KO, LDS-staged, model, compute waves, lane-group form, visits-per-period form, lean form>
+                       res0.kernel_name)
         us_leap = 1e3 * kernel_ms_mean / (leap_mean / NCH)
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -666,16 +663,17 @@ def main(argv=None):
                     "the sequential-leapfrog latency (us_per_leapfrog_per_chain) is the real bound",
         }
         if name == "occu":
-            # the tick's floor as numbers (in-kernel stamps, profiles/r04/c_stamps.txt).  A leaf tick =
-            # one site evaluation (2 250-2 400 cycles, ~1 430 of them issue cycles of one wave on its own SIMD) + the hand-off to the chain's other
-            # workgroups (publish, ONE L2 round trip of 663-674 cycles at 1.4 poll rounds, f64 sums and folds: 1 530-1 610) + the speculative
-            # position (180) + two barriers: ~4 600 cycles at 2.39 GHz.  What is measured above it is NumPyro's sequential bookkeeping at subtree
-            # and transition ends (an evaluation dropped and redone per transition: ~570 cycles per leapfrog at 6.2 leapfrogs per transition).
-            roofline["latency_floor_us"] = 1.9
-            roofline["latency_floor_note"] = ("leaf tick from in-kernel stamps (profiles/r04/c_stamps.txt): site evaluation 2 250-2 400 cycles + "
-                                              "hand-off through L2 1 530-1 610 (one 663-674-cycle round trip at 1.4 poll rounds + sums) + speculative "
-                                              "position 180 + barriers, at 2.39 GHz; the rest of us_per_leapfrog_per_chain is NumPyro's bookkeeping at "
-                                              "subtree / transition ends; three A/Bs on the tick in round 4 moved nothing (profiles/NOTES.md)")
+            # the tick's floor as numbers (in-kernel stamps of the lean kernel, profiles/r04/g_stamps.txt).
+            # The site evaluation (1 527 cycles) is shorter than a leaf tick's decisions (1 688) since round 4, so a leaf tick = decisions + the
+            # hand-off to the chain's other workgroups (ONE L2 round trip of 655 cycles at 1.35 poll rounds + f64 sums and folds: 1 279) + the
+            # speculative position (210) + a barrier: ~3 400 cycles at 2.39 GHz.  What is measured above it is NumPyro's sequential bookkeeping
+            # at subtree and transition ends (an evaluation dropped and redone per transition).
+            roofline["latency_floor_us"] = 1.4
+            roofline["latency_floor_note"] = ("leaf tick from in-kernel stamps of the lean kernel (profiles/r04/g_stamps.txt): decisions 1 688 cycles (the site "
+                                              "evaluation beside them: 1 527) + hand-off through L2 1 279 (one 655-cycle round trip at 1.35 poll rounds + sums) + "
+                                              "speculative position 210 + barrier, at 2.39 GHz; the rest of us_per_leapfrog_per_chain is NumPyro's bookkeeping at "
+                                              "subtree / transition ends; five A/Bs on the tick's protocol in round 4 moved nothing or cost 5 % (profiles/NOTES.md); "
+                                              "the round's gain (2.35 -> 1.99 us) came from per-form / lean instantiations of the kernel")
         if wl["model"] == "occu_rn":
             # config 4 is VALU-transcendental-bound (about 5 M enumerated (site, visit, n) terms per evaluation,
             # one transcendental each), not HBM-bound.  Peak = quarter-rate transcendental issue of the CUs the launch occupies.

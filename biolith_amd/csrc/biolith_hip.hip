@@ -22,6 +22,7 @@
 
 // ------------------------------------------------------------------ errors ----
 static thread_local std::string g_err;
+static thread_local char g_kernel_name[160]; // the sampler instantiation the last launch of this thread picked (kernels_inst.hip: bl_launch)
 static int bl_fail(int code, const char *fmt, ...)
 {
     char buf[512];
@@ -203,6 +204,7 @@ struct bl_dataset {
     // ---- last NUTS launch ----
     bool in_flight = false, have_run = false;
     int C = 0, S = 0, W = 0, k = 0, nloc = 0, lds_ld = 0, lds_bytes = 0, staged = 0, nvp = 0, ncw = 0, lane_grp = 0;
+    char kernel_name[160] = {0}; // the sampler instantiation of the last launch, as rocprofv3 names it
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *d_run = nullptr;  // one slab for all run buffers
@@ -1745,6 +1747,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
         return bl_fail(BL_ERR_UNSUPPORTED, "occu_rn / false-positive model: the dataset slice does not fit the LDS-staged path");
     const int lrc = ds->kern->nuts(&p, grid, lds_bytes, staged, ds->model, st);
     if (lrc != 0) return bl_fail(BL_ERR_NO_DEVICE, "NUTS kernel launch failed: %s", hipGetErrorString((hipError_t)lrc));
+    snprintf(ds->kernel_name, sizeof ds->kernel_name, "%s", g_kernel_name);
     BL_HIP(hipEventRecord(ds->ev1, st));
     ds->stream = st; ds->in_flight = true; ds->have_run = true;
     ds->C = C; ds->S = S; ds->W = W; ds->k = k; ds->nloc = nloc; ds->lds_ld = ld; ds->lds_bytes = lds_bytes; ds->staged = staged; ds->nvp = nvp; ds->ncw = ncw; ds->lane_grp = p.lane_grp;
@@ -1855,6 +1858,30 @@ extern "C" int bl_host_alloc(size_t bytes, void **out)
 extern "C" int bl_host_free(void *ptr)
 {
     if (ptr) BL_HIP(hipHostFree(ptr));
+    return BL_OK;
+}
+
+// (kernels_inst.hip: bl_launch hands over its __PRETTY_FUNCTION__, "... [Kernel = &bl_nuts_kernel<3, 3, true, 0, 3, false, 5, true>, P = ...]")
+extern "C" void bl_note_kernel_name(const char *pretty)
+{
+    g_kernel_name[0] = 0;
+    if (!pretty) return;
+    const char *a = strstr(pretty, "Kernel = ");
+    if (!a) return;
+    a += 9;
+    if (*a == '&') a++;
+    const char *b = strstr(a, ", P = ");
+    size_t n = b ? (size_t)(b - a) : strlen(a);
+    if (n >= sizeof g_kernel_name) n = sizeof g_kernel_name - 1;
+    memcpy(g_kernel_name, a, n);
+    g_kernel_name[n] = 0;
+}
+
+extern "C" int bl_nuts_kernel_name(bl_dataset *ds, char *buf, int n)
+{
+    if (!ds || !buf || n <= 0) return bl_fail(BL_ERR_INVALID, "bl_nuts_kernel_name: bad argument");
+    if (!ds->have_run) return bl_fail(BL_ERR_INVALID, "no NUTS launch on this handle");
+    snprintf(buf, (size_t)n, "%s", ds->kernel_name);
     return BL_OK;
 }
 

@@ -16,28 +16,34 @@
 #define BL_HAVE_RN 0
 #endif
 
-template <typename K, typename P>
-static int bl_launch(K kernel, const P *p, int grid, int threads, int lds_bytes, hipStream_t stream)
+// Kernel: the instantiation itself (a template argument, so that its exact name -- what rocprofv3 prints -- can be handed to the host)
+extern "C" void bl_note_kernel_name(const char *pretty_function);
+template <auto Kernel, typename P>
+static int bl_launch(const P *p, int grid, int threads, int lds_bytes, hipStream_t stream)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    bl_note_kernel_name(__PRETTY_FUNCTION__); // "... [Kernel = &bl_nuts_kernel<3, 3, true, 0, 3, false, 5, true>, P = BlNutsParams]"
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds_bytes, stream, *p);
+    hipLaunchKernelGGL(Kernel, dim3(grid), dim3(threads), lds_bytes, stream, *p);
     return (int)hipGetLastError();
 }
 
 // Instantiations (CW = compute waves per workgroup, chosen by the host's choose_geometry):
 //   occu and false positives, LDS-staged: CW 3 and 4, and BL_CWAVES_SINGLE (7) for chains of ONE workgroup (small problems: no exchange);  occu, HBM rows: CW 4;  occu_rn: CW 7 (BL_CWAVES_RN);  false positives, occu_cop, nmixture: CW 3 and 4.
-#define BL_PICK(KERNEL, P, LDS, MODEL, CW) bl_launch(KERNEL<BL_KS, BL_KO, LDS, MODEL, CW>, P, grid, 64 * (CW + 1), lds_bytes, stream)
+#define BL_PICK(KERNEL, P, LDS, MODEL, CW) bl_launch<KERNEL<BL_KS, BL_KO, LDS, MODEL, CW>>(P, grid, 64 * (CW + 1), lds_bytes, stream)
 // the sampler's GRP instantiation (lane groups / one workgroup per chain: nuts_kernel.hpp) of the plain and false-positive models
-#define BL_PICK_GRP(P, MODEL, CW) bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true>, P, grid, 64 * (CW + 1), lds_bytes, stream)
+#define BL_PICK_GRP(P, MODEL, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true>>(P, grid, 64 * (CW + 1), lds_bytes, stream)
 // ... and its lean form (one species, one-batch poll; nuts_kernel.hpp LEAN)
-#define BL_PICK_GRP_LEAN(P, MODEL, CW) bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true, -1, true>, P, grid, 64 * (CW + 1), lds_bytes, stream)
+#define BL_PICK_GRP_LEAN(P, MODEL, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true, -1, true>>(P, grid, 64 * (CW + 1), lds_bytes, stream)
+// ... and of one period (JSEL = 1 in a lane-group kernel: occu_device.hpp bl_eval_sites_grp<.., T1>)
+#define BL_PICK_GRP_LEAN_T1(P, MODEL, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true, 1, true>>(P, grid, 64 * (CW + 1), lds_bytes, stream)
 #define BL_IS_LEAN(P) ((P)->n_species <= 1 && (P)->k <= 8 * (64 / (P)->nvp))
+#define BL_PICK_GRP_ANY(P, CW) (!BL_IS_LEAN(P) ? BL_PICK_GRP(P, 0, CW) : ((P)->T == 1 && ((P)->lane_grp & 15) == 0) ? BL_PICK_GRP_LEAN_T1(P, 0, CW) : BL_PICK_GRP_LEAN(P, 0, CW))
 // the plain model, one pair per lane: one instantiation per visits-per-period form (1 .. 6, 8 unrolled; 0 = any J at run time)
 #ifndef BL_J_LEAN
 #define BL_J_LEAN true // (A/B: -DBL_J_LEAN=false)
 #endif
-#define BL_PICK_J(P, CW, JSEL) bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, 0, CW, false, JSEL, BL_J_LEAN>, P, grid, 64 * (CW + 1), lds_bytes, stream)
+#define BL_PICK_J(P, CW, JSEL) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, 0, CW, false, JSEL, BL_J_LEAN>>(P, grid, 64 * (CW + 1), lds_bytes, stream)
 #define BL_PICK_J_ANY(P, CW)                                   \
     switch ((P)->J) {                                          \
     case 1: return BL_PICK_J(P, CW, 1);                        \
@@ -55,7 +61,7 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
     if (model == 1) { // occu_rn
 #if BL_HAVE_RN
         if (staged && p->ncw == BL_CWAVES_RN && BL_IS_LEAN(p))
-            return bl_launch(bl_nuts_kernel<BL_KS, BL_KO, true, 1, BL_CWAVES_RN, false, -1, true>, p, grid, 64 * (BL_CWAVES_RN + 1), lds_bytes, stream);
+            return bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, 1, BL_CWAVES_RN, false, -1, true>>(p, grid, 64 * (BL_CWAVES_RN + 1), lds_bytes, stream);
         if (staged && p->ncw == BL_CWAVES_RN) return BL_PICK(bl_nuts_kernel, p, true, 1, BL_CWAVES_RN);
 #endif
         return (int)hipErrorNotSupported;
@@ -94,9 +100,9 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
 #endif
         return (int)hipErrorNotSupported;
     }
-    if (staged && p->grp_kernel && p->ncw == 3) return BL_IS_LEAN(p) ? BL_PICK_GRP_LEAN(p, 0, 3) : BL_PICK_GRP(p, 0, 3);
-    if (staged && p->grp_kernel && p->ncw == 4) return BL_IS_LEAN(p) ? BL_PICK_GRP_LEAN(p, 0, 4) : BL_PICK_GRP(p, 0, 4);
-    if (staged && p->ncw == BL_CWAVES_SINGLE) return BL_IS_LEAN(p) ? BL_PICK_GRP_LEAN(p, 0, BL_CWAVES_SINGLE) : BL_PICK_GRP(p, 0, BL_CWAVES_SINGLE);
+    if (staged && p->grp_kernel && p->ncw == 3) return BL_PICK_GRP_ANY(p, 3);
+    if (staged && p->grp_kernel && p->ncw == 4) return BL_PICK_GRP_ANY(p, 4);
+    if (staged && p->ncw == BL_CWAVES_SINGLE) return BL_PICK_GRP_ANY(p, BL_CWAVES_SINGLE);
     // one species and a one-batch poll (k <= 8 x 64 / nvp): the lean per-form instantiations; else the kernel that carries everything
     // (and one period, at most one site pair per compute lane: nuts_kernel.hpp LEAN)
     const bool lean = !BL_J_LEAN || (BL_IS_LEAN(p) && p->T == 1 && p->nloc <= 2 * 64 * p->ncw);

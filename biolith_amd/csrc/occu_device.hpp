@@ -759,7 +759,8 @@ __device__ __forceinline__ bl_f2 bl_group_sum2(bl_f2 v, int lg)
     return v;
 }
 
-template <int KS, int KO, int CT, bool FP>
+// T1: one period (and hence no period lanes) as a compile-time fact -- simulate()'s defaults and the whole benchmark grid
+template <int KS, int KO, int CT, bool FP, bool T1 = false>
 __device__ __forceinline__ void bl_eval_sites_grp(int ct, int pstride, int cnt, int T, int J, int grp, const BlFpScalars fp,
                                                   const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                                   float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], float &gphi, int data_off = 0)
@@ -799,7 +800,7 @@ __device__ __forceinline__ void bl_eval_sites_grp(int ct, int pstride, int cnt, 
         const bl_f2 psi = bl_sel_pos_one(eta, e_eta) * bl_rcp_2(op_eta);
         bl_f2 dsum = bl2(0.0f), lsite = bl2(0.0f), gpsite = bl2(0.0f);
         const float2 *pp0 = reinterpret_cast<const float2 *>(data + (size_t)m * pstride) + XQ;
-        for (int t = sub_t; t < T; t += Gt) { // (the lanes that fold a period's sums share sub_t, hence this loop's trip count)
+        auto one_period = [&](int t) {
             const float2 *pp = pp0 + t * pb;
             bl_f2 g[KO + 1];
 #pragma unroll
@@ -859,7 +860,9 @@ __device__ __forceinline__ void bl_eval_sites_grp(int ct, int pstride, int cnt, 
                 const bl_f2 d0 = bl_fma2(ndet, bl2(1.0f - fp.f), nnon * bl2(-fp.f));
                 gpsite += q * gf * bl2(fp.ff1) + bl_fma2(q, d1c - d0, d0) * firstj;
             }
-        }
+        };
+        if constexpr (T1) one_period(0); // (one period, no period lanes: no loop)
+        else for (int t = sub_t; t < T; t += Gt) one_period(t); // (the lanes that fold a period's sums share sub_t, hence this loop's trip count)
         ll2 = bl_fma2(lsite, vmask, ll2);
         if constexpr (FP) gp2 = bl_fma2(gpsite, vmask, gp2);
         dsum *= vmask;
@@ -1392,8 +1395,8 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         bl_wave_partials_to_lds<KS, KO, true>(cwave, ll, gb, ga, gphi);
     } else {
         if constexpr (LDS && GRP == 2) {
-            float gphi = 0.0f;
-            bl_eval_sites_grp<KS, KO, CW * 64, false>(ct, ld_or_stride, cnt, T, J, lane_grp, BlFpScalars{}, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
+            float gphi = 0.0f; // (JSEL == 1 in a lane-group kernel: the one-period form)
+            bl_eval_sites_grp<KS, KO, CW * 64, false, JSEL == 1>(ct, ld_or_stride, cnt, T, J, lane_grp, BlFpScalars{}, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
         } else {
             bool grouped = false;
             if constexpr (LDS && GRP == 1) {

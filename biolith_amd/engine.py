@@ -104,6 +104,7 @@ class NutsResult:
     lds_vector_tier: int = 0      # random-effects / occu_cs kernels: sampler vectors kept in LDS (0 none, 1 the leaf in flight, 2 all a leapfrog touches)
     comm_init_ms: float = 0.0     # fit(devices=[...]): wall time of ncclCommInitAll (outside the sampling clock)
     lane_group: tuple = (1, 1)    # lanes that shared one site pair: (period lanes, visit lanes); (1, 1) = one pair per lane
+    kernel_name: str = ""         # the sampler instantiation that ran, as rocprofv3 names it (empty: random-effects kernels)
 
 
 class OccuDataset:
@@ -332,6 +333,11 @@ class OccuDataset:
         _ffi.check(self._lib.bl_nuts_geometry(self._h, C.byref(k), C.byref(thr), C.byref(lds), C.byref(staged), C.byref(loc)))
         return int(k.value)
 
+    def _kernel_name(self) -> str:
+        buf = C.create_string_buffer(192)
+        _ffi.check(self._lib.bl_nuts_kernel_name(self._h, buf, 192))
+        return buf.value.decode()
+
     def elapsed_ms(self) -> float:
         ms = C.c_float(0)
         _ffi.check(self._lib.bl_nuts_elapsed_ms(self._h, C.byref(ms)))
@@ -371,7 +377,7 @@ class OccuDataset:
         return NutsResult(a["draws"], a["diverging"].astype(bool), a["num_steps"], a["accept_prob"], a["potential_energy"],
                           a["step_size"], a["inv_mass"], a["n_leapfrog"], self.elapsed_ms(),
                           k.value, lds.value, bool(staged.value & 1), loc.value, thr.value, staged.value >> 1,
-                          lane_group=(int(gt.value), int(gj.value)))
+                          lane_group=(int(gt.value), int(gj.value)), kernel_name=self._kernel_name())
 
     def fetch(self) -> NutsResult:
         Cn, S = self._shape

@@ -282,6 +282,11 @@ int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads_per_wg, in
  * runs: BIOLITH_HIP_OCCU_G = 1 | 2 | 4 | 8 | 16 forces the lanes per pair, BIOLITH_HIP_OCCU_GT the log2 of the period lanes. */
 int bl_nuts_lane_group(bl_dataset *ds, int *period_lanes, int *visit_lanes);
 
+/* Name of the sampler instantiation the last launch ran, as a profiler prints it (e.g. "bl_nuts_kernel<3, 3, true, 0, 3, false, 5, true>":
+ * capacities, LDS-staged, model, compute waves, lane-group form, visits-per-period form, lean form); empty for the random-effects kernels.
+ * Measurement only: bench.py's roofline.kernel. */
+int bl_nuts_kernel_name(bl_dataset *ds, char *buf, int n);
+
 /* Page-locked host memory for large outputs (bl_deterministic / bl_predict write into caller memory; into page-locked memory the
  * device copies at PCIe rate instead of staging through the runtime's bounce buffers).  The caller owns and frees it.  The
  * reference's counterpart is jax.device_get() of a deterministic site (utils/fit.py:132). */
