@@ -1861,20 +1861,10 @@ extern "C" int bl_host_free(void *ptr)
     return BL_OK;
 }
 
-// (kernels_inst.hip: bl_launch hands over its __PRETTY_FUNCTION__, "... [Kernel = &bl_nuts_kernel<3, 3, true, 0, 3, false, 5, true>, P = ...]")
-extern "C" void bl_note_kernel_name(const char *pretty)
+// (kernels_inst.hip: bl_launch hands over the name of the instantiation it launches)
+extern "C" void bl_note_kernel_name(const char *name)
 {
-    g_kernel_name[0] = 0;
-    if (!pretty) return;
-    const char *a = strstr(pretty, "Kernel = ");
-    if (!a) return;
-    a += 9;
-    if (*a == '&') a++;
-    const char *b = strstr(a, ", P = ");
-    size_t n = b ? (size_t)(b - a) : strlen(a);
-    if (n >= sizeof g_kernel_name) n = sizeof g_kernel_name - 1;
-    memcpy(g_kernel_name, a, n);
-    g_kernel_name[n] = 0;
+    snprintf(g_kernel_name, sizeof g_kernel_name, "%s", name ? name : "");
 }
 
 extern "C" int bl_nuts_kernel_name(bl_dataset *ds, char *buf, int n)

@@ -16,34 +16,39 @@
 #define BL_HAVE_RN 0
 #endif
 
-// Kernel: the instantiation itself (a template argument, so that its exact name -- what rocprofv3 prints -- can be handed to the host)
-extern "C" void bl_note_kernel_name(const char *pretty_function);
+// `name`: the instantiation as a profiler prints it (handed to the host: bl_nuts_kernel_name, bench.py's roofline.kernel)
+extern "C" void bl_note_kernel_name(const char *name);
 template <auto Kernel, typename P>
-static int bl_launch(const P *p, int grid, int threads, int lds_bytes, hipStream_t stream)
+static int bl_launch(const char *name, const P *p, int grid, int threads, int lds_bytes, hipStream_t stream)
 {
-    bl_note_kernel_name(__PRETTY_FUNCTION__); // "... [Kernel = &bl_nuts_kernel<3, 3, true, 0, 3, false, 5, true>, P = BlNutsParams]"
+    bl_note_kernel_name(name);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(Kernel, dim3(grid), dim3(threads), lds_bytes, stream, *p);
     return (int)hipGetLastError();
 }
+#define BL_STR2(x) #x
+#define BL_STR(x) BL_STR2(x)
+#define BL_KHEAD(KERNEL, LDS, MODEL, CW) #KERNEL "<" BL_STR(BL_KS) ", " BL_STR(BL_KO) ", " #LDS ", " BL_STR(MODEL) ", " BL_STR(CW)
+#define BL_TAIL_bl_nuts_kernel ", false, -1, false>"
+#define BL_TAIL_bl_logp_kernel ">"
 
 // Instantiations (CW = compute waves per workgroup, chosen by the host's choose_geometry):
 //   occu and false positives, LDS-staged: CW 3 and 4, and BL_CWAVES_SINGLE (7) for chains of ONE workgroup (small problems: no exchange);  occu, HBM rows: CW 4;  occu_rn: CW 7 (BL_CWAVES_RN);  false positives, occu_cop, nmixture: CW 3 and 4.
-#define BL_PICK(KERNEL, P, LDS, MODEL, CW) bl_launch<KERNEL<BL_KS, BL_KO, LDS, MODEL, CW>>(P, grid, 64 * (CW + 1), lds_bytes, stream)
+#define BL_PICK(KERNEL, P, LDS, MODEL, CW) bl_launch<KERNEL<BL_KS, BL_KO, LDS, MODEL, CW>>(BL_KHEAD(KERNEL, LDS, MODEL, CW) BL_TAIL_##KERNEL, P, grid, 64 * (CW + 1), lds_bytes, stream)
 // the sampler's GRP instantiation (lane groups / one workgroup per chain: nuts_kernel.hpp) of the plain and false-positive models
-#define BL_PICK_GRP(P, MODEL, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true>>(P, grid, 64 * (CW + 1), lds_bytes, stream)
+#define BL_PICK_GRP(P, MODEL, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true>>(BL_KHEAD(bl_nuts_kernel, true, MODEL, CW) ", true, -1, false>", P, grid, 64 * (CW + 1), lds_bytes, stream)
 // ... and its lean form (one species, one-batch poll; nuts_kernel.hpp LEAN)
-#define BL_PICK_GRP_LEAN(P, MODEL, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true, -1, true>>(P, grid, 64 * (CW + 1), lds_bytes, stream)
+#define BL_PICK_GRP_LEAN(P, MODEL, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true, -1, true>>(BL_KHEAD(bl_nuts_kernel, true, MODEL, CW) ", true, -1, true>", P, grid, 64 * (CW + 1), lds_bytes, stream)
 // ... and of one period (JSEL = 1 in a lane-group kernel: occu_device.hpp bl_eval_sites_grp<.., T1>)
-#define BL_PICK_GRP_LEAN_T1(P, MODEL, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true, 1, true>>(P, grid, 64 * (CW + 1), lds_bytes, stream)
+#define BL_PICK_GRP_LEAN_T1(P, MODEL, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true, 1, true>>(BL_KHEAD(bl_nuts_kernel, true, MODEL, CW) ", true, 1, true>", P, grid, 64 * (CW + 1), lds_bytes, stream)
 #define BL_IS_LEAN(P) ((P)->n_species <= 1 && (P)->k <= 8 * (64 / (P)->nvp))
 #define BL_PICK_GRP_ANY(P, CW) (!BL_IS_LEAN(P) ? BL_PICK_GRP(P, 0, CW) : ((P)->T == 1 && ((P)->lane_grp & 15) == 0) ? BL_PICK_GRP_LEAN_T1(P, 0, CW) : BL_PICK_GRP_LEAN(P, 0, CW))
 // the plain model, one pair per lane: one instantiation per visits-per-period form (1 .. 6, 8 unrolled; 0 = any J at run time)
 #ifndef BL_J_LEAN
 #define BL_J_LEAN true // (A/B: -DBL_J_LEAN=false)
 #endif
-#define BL_PICK_J(P, CW, JSEL) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, 0, CW, false, JSEL, BL_J_LEAN>>(P, grid, 64 * (CW + 1), lds_bytes, stream)
+#define BL_PICK_J(P, CW, JSEL) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, 0, CW, false, JSEL, BL_J_LEAN>>(BL_KHEAD(bl_nuts_kernel, true, 0, CW) ", false, " BL_STR(JSEL) ", " BL_STR(BL_J_LEAN) ">", P, grid, 64 * (CW + 1), lds_bytes, stream)
 #define BL_PICK_J_ANY(P, CW)                                   \
     switch ((P)->J) {                                          \
     case 1: return BL_PICK_J(P, CW, 1);                        \
@@ -61,7 +66,7 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
     if (model == 1) { // occu_rn
 #if BL_HAVE_RN
         if (staged && p->ncw == BL_CWAVES_RN && BL_IS_LEAN(p))
-            return bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, 1, BL_CWAVES_RN, false, -1, true>>(p, grid, 64 * (BL_CWAVES_RN + 1), lds_bytes, stream);
+            return bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, 1, BL_CWAVES_RN, false, -1, true>>(BL_KHEAD(bl_nuts_kernel, true, 1, BL_CWAVES_RN) ", false, -1, true>", p, grid, 64 * (BL_CWAVES_RN + 1), lds_bytes, stream);
         if (staged && p->ncw == BL_CWAVES_RN) return BL_PICK(bl_nuts_kernel, p, true, 1, BL_CWAVES_RN);
 #endif
         return (int)hipErrorNotSupported;
