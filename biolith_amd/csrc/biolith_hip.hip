@@ -963,8 +963,8 @@ static int occu_lane_group(const bl_dataset *ds, int chains, int want_k)
 
 // Small problems (plain model and false positives): the whole chain on ONE workgroup of BL_CWAVES_SINGLE compute waves -- no exchange
 // through L2 at all (nuts_kernel.hpp: the k == 1 path), the site pairs shared among as many lanes as the 448 offer.  Taken when a lane
-// is then left with at most BL_SINGLE_VISITS visits of its pair and the records fit one CU's LDS.  Returns the lane-group code or -1.
-#define BL_SINGLE_VISITS 8
+// is then left with at most BL_SINGLE_VISITS visits of its pair (400 x 16, 8 visits per lane: 2.00 us on one workgroup against 1.86 on five) and the records fit one CU's LDS.  Returns the lane-group code or -1.
+#define BL_SINGLE_VISITS 7
 static int occu_single_workgroup(const bl_dataset *ds, int want_k)
 {
     if ((ds->model != 0 && ds->model != 2) || want_k > 0 || ds->nsp > 1) return -1; // (several species: the partial table is sized for 4 waves)

@@ -1385,7 +1385,7 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         }
     } else if constexpr (MODEL == 1) {
         static_assert(LDS, "Royle-Nichols model: LDS records only");
-        bl_eval_sites_rn<KS, KO, CW>(cwave, ld_or_stride, cnt, T, J, max_abundance, rn_off, beta, alpha, ll, gb, ga);
+        bl_eval_sites_rn<KS, KO, CW, JSEL == 10>(cwave, ld_or_stride, cnt, T, J, max_abundance, rn_off, beta, alpha, ll, gb, ga); // (JSEL == 10: J <= 10)
         bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga);
     } else if constexpr (MODEL == 3) {
         static_assert(LDS, "count occupancy model: LDS records only");

@@ -95,7 +95,8 @@ __device__ __forceinline__ float bl_rn_mode_lb(float a, float K)
 // LDS records: the plain model's, one float wider per visit (bl_layout_ko<1>: [c, c w_1 .. c w_KO, v]).  The last slot is DYNAMIC:
 // at every evaluation the site's lane leaves there what the item lanes need of the visit -- q_j > 0 (a detection), log2 q_j < 0
 // (a non-detection) or 0 (masked) -- so that the items read one float per visit instead of repeating the dot product and its exp / rcp.
-template <int KS, int KO, int CW>
+// J10: at most ten visits per period as a compile-time fact (the sampler's instantiation for J <= 10 carries the one-group paths alone)
+template <int KS, int KO, int CW, bool J10 = false>
 __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt, int T, int J, int K, int rn_off,
                                                  const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                                  float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
@@ -295,7 +296,7 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                 // J <= 10 (one group): the reciprocals 1 / b_jn, which pass C needs, are formed here and kept (80 registers), the
                 // product runs over them, and C is left with ten dot products -- no second recursion.
                 static_assert(BL_RN_GA == 10, "the product tree below is written for five pairs");
-                const bool one_group = J <= BL_RN_GA; // wave-uniform
+                const bool one_group = J10 || J <= BL_RN_GA; // wave-uniform (a compile-time fact with J10)
                 bl_f2 rb[BL_RN_CH][5], q2k[5];
                 if (one_group) {
 #pragma unroll
