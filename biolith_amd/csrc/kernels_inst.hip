@@ -66,7 +66,7 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
     if (model == 1) { // occu_rn
 #if BL_HAVE_RN
         // (lean and at most ten visits per period -- config 4 -- : the instantiation that carries the one-group paths alone)
-        if (staged && p->ncw == BL_CWAVES_RN && BL_IS_LEAN(p) && p->J <= 10)
+        if (staged && p->ncw == BL_CWAVES_RN && BL_IS_LEAN(p) && p->J <= 10 && p->T == 1)
             return bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, 1, BL_CWAVES_RN, false, 10, true>>(BL_KHEAD(bl_nuts_kernel, true, 1, BL_CWAVES_RN) ", false, 10, true>", p, grid, 64 * (BL_CWAVES_RN + 1), lds_bytes, stream);
         if (staged && p->ncw == BL_CWAVES_RN && BL_IS_LEAN(p))
             return bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, 1, BL_CWAVES_RN, false, -1, true>>(BL_KHEAD(bl_nuts_kernel, true, 1, BL_CWAVES_RN) ", false, -1, true>", p, grid, 64 * (BL_CWAVES_RN + 1), lds_bytes, stream);

@@ -1375,7 +1375,7 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
                 for (int k = 0; k <= KS; k++) { bq[b][k] = c[b * (KS + 1) + k]; gq[b][k] = 0.0f; }
 #pragma unroll
             for (int k = 0; k <= KO; k++) alpha[k] = c[BL_DYN_OA(KS) + k];
-            // (at most two periods per lane of a group: the one-visit-pass form on scaled likelihoods; BL_DYN_FORM1: the first form, for A/B)
+            // (at most two periods per lane of a group: the one-visit-pass form on scaled likelihoods; else the first form)
             // GRP = 2 (the sampler's instantiation for T <= 2 G): the scaled form alone; 0: the first form alone (any T); 1: both (parity hook)
             if constexpr (GRP == 2) bl_eval_sites_dyn_scaled<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, lane_grp, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
             else if constexpr (GRP == 0) bl_eval_sites_dyn<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, lane_grp, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);

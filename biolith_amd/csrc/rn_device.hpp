@@ -95,7 +95,8 @@ __device__ __forceinline__ float bl_rn_mode_lb(float a, float K)
 // LDS records: the plain model's, one float wider per visit (bl_layout_ko<1>: [c, c w_1 .. c w_KO, v]).  The last slot is DYNAMIC:
 // at every evaluation the site's lane leaves there what the item lanes need of the visit -- q_j > 0 (a detection), log2 q_j < 0
 // (a non-detection) or 0 (masked) -- so that the items read one float per visit instead of repeating the dot product and its exp / rcp.
-// J10: at most ten visits per period as a compile-time fact (the sampler's instantiation for J <= 10 carries the one-group paths alone)
+// J10: at most ten visits per period AND one period as compile-time facts (the sampler's instantiation for that case -- config 4 --
+// carries the one-group paths alone and no loop over periods)
 template <int KS, int KO, int CW, bool J10 = false>
 __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt, int T, int J, int K, int rn_off,
                                                  const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
@@ -166,7 +167,8 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
         }
         float ll_s = 0.0f, deta = 0.0f;
         BL_RN_T(0)
-        for (int t = 0; t < T; t++) {
+        const int Tn = J10 ? 1 : T; // (J10: also ONE period, a compile-time fact -- the loop folds away)
+        for (int t = 0; t < Tn; t++) {
             float *pv = rec + 2 * (XQ + t * pb);
             float cnon = 0.0f, clr = 0.0f, ndet = 0.0f;
             float lqmin = 0.0f; // smallest log q over the non-detections
