@@ -1128,10 +1128,30 @@ static hipError_t re_nuts_launch_inst(const BlReRun &run, int grid, size_t lds, 
     hipLaunchKernelGGL((bl_re_nuts_kernel<MK, KIND, LROWS, LT>), dim3(grid), dim3(BL_RE_NT), lds, st, run);
     return hipGetLastError();
 }
+// the bench form's instantiations with the model's effects as compile-time facts (re_kernel.hpp: EFF)
+template <int EFF>
+static hipError_t re_nuts_launch_eff(const BlReRun &run, int grid, size_t lds, hipStream_t st)
+{
+    if (lds) {
+        const hipError_t e = hipFuncSetAttribute((const void *)bl_re_nuts_kernel<4, 0, true, 2, EFF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((bl_re_nuts_kernel<4, 0, true, 2, EFF>), dim3(grid), dim3(BL_RE_NT), lds, st, run);
+    return hipGetLastError();
+}
 template <int MK, int KIND>
 static hipError_t re_nuts_dispatch_lds(const BlReRun &run, int grid, size_t lds, hipStream_t st)
 {
     const int lt = run.m.lds_hot;
+    if constexpr (MK == 4 && KIND == 0) {
+        const char *e = getenv("BIOLITH_HIP_RE_EFF"); // A/B knob: 0 = the general kernel
+        if (run.m.lds_rows && lt == 2 && run.m.n_species == 1 && !(e && e[0] == '0')) {
+            const int eff = (run.m.site_re ? 1 : 0) | (run.m.obs_re ? 2 : 0);
+            if (eff == 1) return re_nuts_launch_eff<1>(run, grid, lds, st);
+            if (eff == 2) return re_nuts_launch_eff<2>(run, grid, lds, st);
+            if (eff == 3) return re_nuts_launch_eff<3>(run, grid, lds, st);
+        }
+    }
     if (run.m.lds_rows)
         return lt == 2 ? re_nuts_launch_inst<MK, KIND, true, 2>(run, grid, lds, st)
                        : (lt == 1 ? re_nuts_launch_inst<MK, KIND, true, 1>(run, grid, lds, st) : re_nuts_launch_inst<MK, KIND, true, 0>(run, grid, lds, st));

@@ -1207,7 +1207,11 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel gm
 // KIND: BlReModel::kind; LROWS / LT: BlReModel::lds_rows / lds_hot as compile-time facts, so that every access to the rows and to
 // the sampler's vectors is a DS or a GLOBAL instruction (one generic pointer for both made all of them FLAT: 272 flat loads, 230 spilled
 // SGPRs of 64-bit bases)
-template <int MK, int KIND, bool LROWS, int LT>
+// EFF (round 4, the bench form only): which effects the model has, as a compile-time fact -- 0: read from the model at run time (the
+// general kernel); 1: site effects only, one species; 2: observation effects only, one species; 3: both, one species.  The workgroup's
+// local copy of the model gets those fields as CONSTANTS, and every `if (m.obs_re)` / species loop behind them folds away (what a kernel
+// merely carries costs the rest: profiles/NOTES.md).
+template <int MK, int KIND, bool LROWS, int LT, int EFF = 0>
 __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
 {
     constexpr int NRED = BL_RE_NRED_OF(MK), OX = BL_RE_OX(MK), NV1 = BL_RE_NV1(MK);
@@ -1222,7 +1226,9 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
     if (chain >= R.num_chains) return;
     // several species: the chain's k workgroups are n_species groups of kps, each group slicing the sites of its species
     const int kps = R.k / R.m.n_species, sp = wg / kps, s0 = (wg - sp * kps) * R.nloc;
-    const BlReModel m = bl_re_slice(R.m, sp, s0, min(R.nloc, R.m.n_sites - s0)); // this workgroup's slice as a model of its own
+    BlReModel m_ = bl_re_slice(R.m, sp, s0, min(R.nloc, R.m.n_sites - s0)); // this workgroup's slice as a model of its own
+    if constexpr (EFF != 0) { m_.site_re = (EFF & 1) ? 1 : 0; m_.obs_re = (EFF & 2) ? 1 : 0; m_.n_species = 1; m_.sp = 0; }
+    const BlReModel &m = m_;
     const int D = m.D, G = m.G;
     const bool lead = wg == 0; // the fixed effects / log sds are replicated; workgroup 0 accounts for them in every sum and output
     float *sv = R.state + ((size_t)chain * R.k + wg) * RE_SLOTS * R.dl_max;
