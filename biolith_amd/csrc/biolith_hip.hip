@@ -1146,8 +1146,10 @@ static hipError_t re_nuts_dispatch_lds(const BlReRun &run, int grid, size_t lds,
     if constexpr (MK == 4 && KIND == 0) {
         const char *e = getenv("BIOLITH_HIP_RE_EFF"); // A/B knob: 0 = the general kernel
         if (run.m.lds_rows && lt == 2 && run.m.n_species == 1 && !(e && e[0] == '0')) {
+            // one period as a fact too, for site effects alone (measured: 9.26 -> 8.77 us on the bench shape; with observation effects
+            // the same fact made the kernel slower -- 8.35 -> 9.41, 7.74 -> 7.89 -- so those keep the period loop); knob 1: without it
             const int eff = (run.m.site_re ? 1 : 0) | (run.m.obs_re ? 2 : 0);
-            if (eff == 1) return re_nuts_launch_eff<1>(run, grid, lds, st);
+            if (eff == 1) return run.m.T == 1 && !(e && e[0] == '1') ? re_nuts_launch_eff<5>(run, grid, lds, st) : re_nuts_launch_eff<1>(run, grid, lds, st);
             if (eff == 2) return re_nuts_launch_eff<2>(run, grid, lds, st);
             if (eff == 3) return re_nuts_launch_eff<3>(run, grid, lds, st);
         }
@@ -1731,7 +1733,9 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.nmix_lds = nmix_table_in_lds(ds, staged, nloc, &lds_bytes);
     // the GRP instantiation (lane groups; the exchange-free path of a one-workgroup chain) only where it is needed: the headline's kernel
     // stays the one-pair-per-lane form alone
-    p.grp_kernel = ((ds->model == 0 || ds->model == 2) && staged && (grp > 0 || k == 1)) ? 1 : 0;
+    // (a chain of ONE workgroup always runs on BL_CWAVES_SINGLE compute waves: that kernel alone has the exchange-free path)
+    p.grp_kernel = ((ds->model == 0 || ds->model == 2) && staged && (grp > 0 || ncw == BL_CWAVES_SINGLE)) ? 1 : 0;
+    if (ncw == BL_CWAVES_SINGLE && k != 1) return bl_fail(BL_ERR_INVALID, "internal: %d compute waves are the one-workgroup form, k = %d", ncw, k);
     if (const char *e = getenv("BIOLITH_HIP_GRP_KERNEL")) { if (e[0] == '1' && (ds->model == 0 || ds->model == 2) && staged) p.grp_kernel = 1; } // A/B knob: the GRP form although it is not needed
     p.fp_mode = ds->fp_mode;
     p.nmix_tab = ds->d_tab;

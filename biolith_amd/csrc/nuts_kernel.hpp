@@ -218,7 +218,10 @@ struct BlSpinBound {
 template <int KS, int KO, bool LDS, int MODEL, int CW, bool GRP = false, int JSEL = -1, bool LEAN = false>
 __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsParams p)
 {
-    const bool multi_wg = !GRP || p.k > 1; // (compile-time true without GRP)
+    // a chain of ONE workgroup runs on BL_CWAVES_SINGLE compute waves and nothing else does (biolith_hip.hip: choose_geometry), so
+    // which of the two paths a kernel has is a compile-time fact: the one-workgroup kernels carry no publish / poll, the others no
+    // k == 1 branches (stacked 2.525 -> 2.513 us, dynamic 4.99 -> 4.95: profiles/r04/i_ab_split_single.txt)
+    constexpr bool multi_wg = !(GRP && CW == BL_CWAVES_SINGLE);
     // XCD-aware mapping (speed only; see header): label = b % 8 names a set of blocks that share an XCD.
     // Wide geometry (slices that only fit LDS when a chain takes more than one XCD's CUs): consecutive blocks, any XCD.
     const int label = blockIdx.x & 7, slot = blockIdx.x >> 3;

@@ -398,7 +398,10 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
         eta += ui;
         const float ee = bl_exp(-fabsf(eta)), lop = bl_log(1.0f + ee);
         const float log_psi = fminf(eta, 0.0f) - lop, log_1mpsi = fminf(-eta, 0.0f) - lop;
-        const float psi = (eta > 0.0f ? 1.0f : ee) * bl_rcp(1.0f + ee);
+        // psi = sel / (1 + e^-|eta|) enters only d l / d eta = q - psi, written as ONE fused multiply-add in every instantiation (left to
+        // the compiler, `q - sel * rc` is contracted when one period is a compile-time fact -- product and difference in one basic
+        // block -- and not behind a period loop: the forms' draws would differ in the last bit)
+        const float psi_sel = eta > 0.0f ? 1.0f : ee, psi_rc = bl_rcp(1.0f + ee);
         float dl_deta = 0.0f, dl_dv = 0.0f;
         for (int t = 0; t < T; t++) {
             float a = 0.0f, ga[MK + 1], gf = 0.0f;
@@ -479,7 +482,7 @@ __device__ __forceinline__ void bl_re_site_pass(const BlReModel &m, const float 
 #pragma unroll
                 for (int k = 0; k <= MK; k++) part[MK + 2 + k] = fmaf(q, ga[k], part[MK + 2 + k]);
             }
-            dl_deta += q - psi;
+            dl_deta += fmaf(-psi_sel, psi_rc, q);
             dl_dv = fmaf(q, ga[0], dl_dv);
             if (m.obs_re && live) {
                 // each replicate's own effect: d U / d e = -q d a / d nu + e / sd^2 (d a / d nu recomputed: nothing was kept per visit)
@@ -1208,7 +1211,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_logp_kernel(const BlReModel gm
 // the sampler's vectors is a DS or a GLOBAL instruction (one generic pointer for both made all of them FLAT: 272 flat loads, 230 spilled
 // SGPRs of 64-bit bases)
 // EFF (round 4, the bench form only): which effects the model has, as a compile-time fact -- 0: read from the model at run time (the
-// general kernel); 1: site effects only, one species; 2: observation effects only, one species; 3: both, one species.  The workgroup's
+// general kernel); 1: site effects only, one species; 2: observation effects only, one species; 3: both, one species; + 4: one period.  The workgroup's
 // local copy of the model gets those fields as CONSTANTS, and every `if (m.obs_re)` / species loop behind them folds away (what a kernel
 // merely carries costs the rest: profiles/NOTES.md).
 template <int MK, int KIND, bool LROWS, int LT, int EFF = 0>
@@ -1228,6 +1231,7 @@ __global__ void __launch_bounds__(BL_RE_NT) bl_re_nuts_kernel(const BlReRun R)
     const int kps = R.k / R.m.n_species, sp = wg / kps, s0 = (wg - sp * kps) * R.nloc;
     BlReModel m_ = bl_re_slice(R.m, sp, s0, min(R.nloc, R.m.n_sites - s0)); // this workgroup's slice as a model of its own
     if constexpr (EFF != 0) { m_.site_re = (EFF & 1) ? 1 : 0; m_.obs_re = (EFF & 2) ? 1 : 0; m_.n_species = 1; m_.sp = 0; }
+    if constexpr ((EFF & 4) != 0) m_.T = 1; // one period (the shape of simulate()'s defaults and of the bench)
     const BlReModel &m = m_;
     const int D = m.D, G = m.G;
     const bool lead = wg == 0; // the fixed effects / log sds are replicated; workgroup 0 accounts for them in every sum and output

@@ -1,7 +1,9 @@
 #!/bin/bash
 # Round-end artefacts on the GPU box (run from the repo root through gpurun): bench lines, rocprofv3 kernel stats and PMC passes of the
-# bench workloads on the library as built.   usage: bash tools/refresh_profiles.sh <outdir under gpurun_out/>
+# bench workloads on the library as built.   usage: [LIGHT=1] bash tools/refresh_profiles.sh <outdir under gpurun_out/>
+# LIGHT=1: bench lines, kernel stats and PMC passes only (no timing tools, stamps, grid or CPU-baseline validation run)
 set -u
+LIGHT=${LIGHT:-0}
 OUT=${1:-gpurun_out/refresh}
 mkdir -p "$OUT"
 ROOT=$(pwd)
@@ -9,6 +11,7 @@ python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench (default: h
 for wl in occu_rn occu_re occu_stacked occu_dyn occu_cfg1; do
   python bench.py --workload $wl --steps 3 --no-e2e > "$OUT/bench_$wl.json" 2> "$OUT/bench_$wl.err"; echo "bench $wl rc=$?"
 done
+if [ "$LIGHT" != 1 ]; then
 python tools/time_models.py > "$OUT/time_models.txt" 2>&1
 python tools/time_re.py > "$OUT/time_re.txt" 2>&1
 python tools/time_fit_e2e.py > "$OUT/time_fit_e2e.txt" 2>&1
@@ -24,6 +27,7 @@ if [ -f biolith_amd/lib/libbiolith_hip_stamps.so ]; then
 fi
 # the scaled CPU baselines validated once: the oracle's own (short) sampler run beside the scaled estimate (minutes)
 python bench.py --workload occu_rn --steps 2 --no-e2e --cpu-baseline > "$OUT/cpu_baseline_validation_rn.json" 2> "$OUT/cpu_baseline_validation_rn.err"; echo "cpu baseline validation rc=$?"
+fi
 cd /tmp && export TMPDIR=/tmp
 for wl in occu occu_rn occu_re occu_stacked occu_dyn occu_cfg1; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_$wl" -- python3 "$ROOT/bench.py" --workload $wl --steps 3 --no-cpu-baseline --no-e2e --no-secondary --no-live-pmc > "$ROOT/$OUT/bench_${wl}_under_rocprof.json" 2> "$ROOT/$OUT/stats_$wl.err"
