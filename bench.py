@@ -645,12 +645,13 @@ def main(argv=None):
                 traffic_source = f"{traffic_source}; live passes: {how}"
         else:
             traffic_static = None
-        # random effects: <covariate capacity, model kind, rows in LDS, sampler-vector tier in LDS>
-        kernel_name = (f"bl_re_nuts_kernel<{4 if max(ds.Ks, ds.Ko) <= 4 else 16}, 0, {'true' if res0.lds_staged else 'false'}, {res0.lds_vector_tier}>"
-                       if wl["model"] == "occu_re" else
-                       # the instantiation that ran, as the engine reports it (bl_nuts_kernel_name) and rocprofv3 prints it:
-                       # <KS, KO, LDS-staged, model, compute waves, lane-group form, visits-per-period form, lean form>
-                       res0.kernel_name)
+        # the instantiation that ran, as the engine reports it (bl_nuts_kernel_name) and rocprofv3 prints it:
+        # bl_nuts_kernel<KS, KO, LDS-staged, model, compute waves, lane-group form, visits-per-period form, lean form>,
+        # bl_re_nuts_kernel<covariate capacity, model kind, rows in LDS, sampler-vector tier in LDS, effects as compile-time facts>
+        kernel_name = res0.kernel_name
+        # (the launch ends with its slowest chain: this rank's kernel time over THAT chain's gradient evaluations is the kernel's own
+        # per-leapfrog time; the figure over the mean below also moves with how evenly the chains adapted)
+        us_leap_slowest = float(np.mean([r.kernel_ms * 1e3 / (int(r.n_leapfrog.reshape(NCH, -1).sum(axis=1).max()) + 1) for r, _ in steps]))
         us_leap = 1e3 * kernel_ms_mean / (leap_mean / NCH)
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -658,7 +659,7 @@ def main(argv=None):
             "kernel": kernel_name, "kernel_ms": kernel_ms_mean,
             "algorithmic_bytes_per_launch": leap_mean * bytes_eval, "bytes_per_gradient_evaluation": bytes_eval,
             "gradient_evaluations_per_launch": leap_mean,
-            "us_per_leapfrog_per_chain": us_leap,
+            "us_per_leapfrog_per_chain": us_leap, "us_per_leapfrog_slowest_chain": us_leap_slowest,
             "note": "data is LDS-resident after one HBM read, so this is an effective (algorithmic) bandwidth; "
                     "the sequential-leapfrog latency (us_per_leapfrog_per_chain) is the real bound",
         }
@@ -685,7 +686,7 @@ def main(argv=None):
                 "frac": ach / (cus * TRANS_PER_CU_PER_S / 1e9), "frac_of_chip": ach / (N_CUS * TRANS_PER_CU_PER_S / 1e9),
                 "cus_used": cus, "transcendentals_per_gradient_evaluation": terms,
                 "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_name, "kernel_ms": kernel_ms_mean,
-                "gradient_evaluations_per_launch": leap_mean, "us_per_leapfrog_per_chain": us_leap,
+                "gradient_evaluations_per_launch": leap_mean, "us_per_leapfrog_per_chain": us_leap, "us_per_leapfrog_slowest_chain": us_leap_slowest,
                 "hbm_effective_GBps": achieved, "bytes_per_gradient_evaluation": bytes_eval,
                 "note": "algorithmic transcendentals = N x T x J x (max_abundance + 1) enumerated terms (SURVEY.md section 8d); the kernel "
                         "cuts every site's n-range where its terms die out (items of 8 terms, rn_device.hpp), so it executes about an "

@@ -1126,6 +1126,7 @@ static hipError_t re_nuts_launch_inst(const BlReRun &run, int grid, size_t lds, 
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((bl_re_nuts_kernel<MK, KIND, LROWS, LT>), dim3(grid), dim3(BL_RE_NT), lds, st, run);
+    snprintf(g_kernel_name, sizeof g_kernel_name, "bl_re_nuts_kernel<%d, %d, %s, %d, 0>", MK, KIND, LROWS ? "true" : "false", LT); // (as rocprofv3 prints it)
     return hipGetLastError();
 }
 // the bench form's instantiations with the model's effects as compile-time facts (re_kernel.hpp: EFF)
@@ -1137,6 +1138,7 @@ static hipError_t re_nuts_launch_eff(const BlReRun &run, int grid, size_t lds, h
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((bl_re_nuts_kernel<4, 0, true, 2, EFF>), dim3(grid), dim3(BL_RE_NT), lds, st, run);
+    snprintf(g_kernel_name, sizeof g_kernel_name, "bl_re_nuts_kernel<4, 0, true, 2, %d>", EFF);
     return hipGetLastError();
 }
 template <int MK, int KIND>
@@ -1146,8 +1148,8 @@ static hipError_t re_nuts_dispatch_lds(const BlReRun &run, int grid, size_t lds,
     if constexpr (MK == 4 && KIND == 0) {
         const char *e = getenv("BIOLITH_HIP_RE_EFF"); // A/B knob: 0 = the general kernel
         if (run.m.lds_rows && lt == 2 && run.m.n_species == 1 && !(e && e[0] == '0')) {
-            // one period as a fact too, for site effects alone (measured: 9.26 -> 8.77 us on the bench shape; with observation effects
-            // the same fact made the kernel slower -- 8.35 -> 9.41, 7.74 -> 7.89 -- so those keep the period loop); knob 1: without it
+            // one period as a fact too, for site effects alone (same trajectories, one box: 8.91 -> 8.85 us on the bench shape; not
+            // instantiated for the forms with observation effects); knob 1: without it
             const int eff = (run.m.site_re ? 1 : 0) | (run.m.obs_re ? 2 : 0);
             if (eff == 1) return run.m.T == 1 && !(e && e[0] == '1') ? re_nuts_launch_eff<5>(run, grid, lds, st) : re_nuts_launch_eff<1>(run, grid, lds, st);
             if (eff == 2) return re_nuts_launch_eff<2>(run, grid, lds, st);
@@ -1631,6 +1633,7 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     BL_HIP(hipMemsetAsync(ds->d_loc, 0, (size_t)C * 4, st));
     // XCD-aware mapping in the kernel (surplus blocks exit at once)
     BL_HIP(re_nuts_dispatch(cap4 ? 4 : 16, run, 8 * k * ((C + 7) / 8), lds, st));
+    snprintf(ds->kernel_name, sizeof ds->kernel_name, "%s", g_kernel_name);
     BL_HIP(hipEventRecord(ds->ev1, st));
     ds->stream = st; ds->in_flight = true; ds->have_run = true;
     ds->C = C; ds->S = S; ds->W = W; ds->k = k; ds->nloc = nloc; ds->lds_ld = 0; ds->lds_bytes = (int)lds; ds->staged = run.m.lds_rows | (run.m.lds_hot << 1); ds->nvp = 0; ds->ncw = BL_RE_NW; ds->lane_grp = 0;

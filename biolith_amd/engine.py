@@ -104,7 +104,7 @@ class NutsResult:
     lds_vector_tier: int = 0      # random-effects / occu_cs kernels: sampler vectors kept in LDS (0 none, 1 the leaf in flight, 2 all a leapfrog touches)
     comm_init_ms: float = 0.0     # fit(devices=[...]): wall time of ncclCommInitAll (outside the sampling clock)
     lane_group: tuple = (1, 1)    # lanes that shared one site pair: (period lanes, visit lanes); (1, 1) = one pair per lane
-    kernel_name: str = ""         # the sampler instantiation that ran, as rocprofv3 names it (empty: random-effects kernels)
+    kernel_name: str = ""         # the sampler instantiation that ran, as rocprofv3 names it
 
 
 class OccuDataset:

@@ -27,7 +27,8 @@ def main():
         if wl != "occu":
             cp(os.path.join(src, f"bench_{wl}.json"), f"bench{sfx}.json")
         cp(os.path.join(src, f"bench_{wl}_under_rocprof.json"), f"bench{sfx}_under_rocprof.json")
-        for f in glob.glob(os.path.join(src, f"stats_{wl}", "**", "*kernel_stats.csv"), recursive=True)[:1]:
+        # (gpurun MERGES into an existing directory: the newest file is this run's)
+        for f in sorted(glob.glob(os.path.join(src, f"stats_{wl}", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1:]:
             cp(f, f"kernel_stats{sfx}.csv")
         key = {"occu": "occu", "occu_rn": "rn", "occu_re": "re", "occu_dyn": "dyn", "occu_stacked": "stacked"}.get(wl)
         if key:
