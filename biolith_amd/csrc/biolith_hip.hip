@@ -1148,8 +1148,9 @@ static hipError_t re_nuts_dispatch_lds(const BlReRun &run, int grid, size_t lds,
     if constexpr (MK == 4 && KIND == 0) {
         const char *e = getenv("BIOLITH_HIP_RE_EFF"); // A/B knob: 0 = the general kernel
         if (run.m.lds_rows && lt == 2 && run.m.n_species == 1 && !(e && e[0] == '0')) {
-            // one period as a fact too, for site effects alone (same trajectories, one box: 8.91 -> 8.85 us on the bench shape; not
-            // instantiated for the forms with observation effects); knob 1: without it
+            // one period as a fact too, for site effects alone (same trajectories, one box: 8.91 -> 8.85 us on the bench shape; with
+            // observation effects the same fact measured 0.1-2 % slower on four shapes -- profiles/r04/i_ab_re_t1_all.txt -- and is not
+            // instantiated); knob 1: without it
             const int eff = (run.m.site_re ? 1 : 0) | (run.m.obs_re ? 2 : 0);
             if (eff == 1) return run.m.T == 1 && !(e && e[0] == '1') ? re_nuts_launch_eff<5>(run, grid, lds, st) : re_nuts_launch_eff<1>(run, grid, lds, st);
             if (eff == 2) return re_nuts_launch_eff<2>(run, grid, lds, st);

@@ -283,8 +283,9 @@ int bl_nuts_geometry(bl_dataset *ds, int *wgs_per_chain, int *threads_per_wg, in
 int bl_nuts_lane_group(bl_dataset *ds, int *period_lanes, int *visit_lanes);
 
 /* Name of the sampler instantiation the last launch ran, as a profiler prints it (e.g. "bl_nuts_kernel<3, 3, true, 0, 3, false, 5, true>":
- * capacities, LDS-staged, model, compute waves, lane-group form, visits-per-period form, lean form); empty for the random-effects kernels.
- * Measurement only: bench.py's roofline.kernel. */
+ * capacities, LDS-staged, model, compute waves, lane-group form, visits-per-period form, lean form; or, for the random-effects models,
+ * "bl_re_nuts_kernel<4, 0, true, 2, 5>": covariate capacity, model kind, rows in LDS, sampler-vector tier in LDS, effects / one period as
+ * compile-time facts).  Measurement only: bench.py's roofline.kernel. */
 int bl_nuts_kernel_name(bl_dataset *ds, char *buf, int n);
 
 /* Page-locked host memory for large outputs (bl_deterministic / bl_predict write into caller memory; into page-locked memory the
