@@ -454,7 +454,7 @@ def literal_log_joint_cs(theta, site_covs, obs_covs, scores, prior_mu=((0.0, 10.
 
 
 def literal_log_joint_fp(theta, site_covs, obs_covs, obs, fp_mode="constant", prior_fp=(2.0, 5.0),
-                         prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0)):
+                         prior_beta=(0.0, 1.0), prior_alpha=(0.0, 1.0), clamp_z1=False):
     """log density of the false-positive model in NumPyro's unconstrained space: theta = [beta, alpha, phi],
     rate = sigmoid(phi) ~ Beta(a, b) (occu.py:32-33,146-157), plus the log-Jacobian of the sigmoid."""
     from scipy.special import betaln
@@ -465,7 +465,7 @@ def literal_log_joint_fp(theta, site_covs, obs_covs, obs, fp_mode="constant", pr
     kw = {"prob_fp_constant": f} if fp_mode == "constant" else {"prob_fp_unoccupied": f}
     a, b = prior_fp
     beta_logpdf = (a - 1.0) * np.log(f) + (b - 1.0) * np.log1p(-f) - betaln(a, b)
-    return (literal_log_joint(theta[:-1], site_covs, obs_covs, obs, prior_beta, prior_alpha, **kw)
+    return (literal_log_joint(theta[:-1], site_covs, obs_covs, obs, prior_beta, prior_alpha, clamp_z1=clamp_z1, **kw)
             + beta_logpdf + np.log(f) + np.log1p(-f))
 
 

@@ -1,0 +1,89 @@
+"""Helpers for the fixtures ``tests/golden/reference_logjoint_<case>.json`` (TEST INFRASTRUCTURE).
+
+The fixtures hold potentials U that the REFERENCE'S OWN model functions produced (biolith/models/occu.py:136-242,
+occu_rn.py:123-222, occu_cop.py:150-255, nmixture.py:150-220, executed by ``tests/golden/make_reference_logjoint.py`` under a
+functional NumPy shim of the numpyro / jax names they use).  A fixture names its data by the simulator's kwargs (the repo's
+simulators are bit-identical to the reference's: tests/test_simulate_golden.py) and pins them by SHA-256; it names a point by the
+unconstrained value of every latent site.  This module rebuilds the data and lays the named values out as the flat theta of the
+oracle / the engine:
+
+    [species 0: beta, alpha | species 1: ... | (phi) | (log site_re_sd) | (log obs_re_sd)
+     | site_re_occ [S][N] | site_re_det [S][N] | obs_re [S][N][T][J]]
+"""
+import contextlib
+import hashlib
+import io
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def case_names():
+    with open(os.path.join(GOLDEN, "reference_logjoint_index.json")) as f:
+        return list(json.load(f))
+
+
+def load(case):
+    with open(os.path.join(GOLDEN, f"reference_logjoint_{case}.json")) as f:
+        return json.load(f)
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(np.asarray(a, dtype=np.float32).astype(np.float64)).tobytes()).hexdigest()
+
+
+def build(entry):
+    """-> (site_covs, obs_covs, obs, kwargs) for ``oracle.OracleData`` / ``biolith_amd.engine.OccuDataset``."""
+    from biolith_amd import models
+    from biolith_amd.utils.data import prepare_data
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        data, _ = getattr(models, entry["simulator"])(**entry["simulator_kwargs"])
+    X, W, Y, dur, _, _ = prepare_data(data["site_covs"], data["obs_covs"], data["obs"], data.get("session_duration"))
+    X, W, Y = np.asarray(X), np.asarray(W), np.asarray(Y)
+    for k, a in (("site_covs", X), ("obs_covs", W), ("obs", Y)):
+        assert _sha(a) == entry["sha256"][k], f"{entry['case']}: {k} differs from the data the reference's model saw"
+    mk, model = entry["model_kwargs"], entry["model"]
+    site, obs_re = bool(mk.get("site_random_effects")), bool(mk.get("obs_random_effects"))
+    fp = "constant" if mk.get("false_positives_constant") else ("unoccupied" if mk.get("false_positives_unoccupied") else None)
+    kw = dict(site_random_effects=site, obs_random_effects=obs_re)
+    if "max_abundance" in mk:
+        kw["max_abundance"] = mk["max_abundance"]
+    if model == "occu":
+        if site or obs_re:
+            kw.update(model="occu_re", re_fp_mode=fp)
+        elif fp:
+            kw.update(model="occu_fp", fp_mode=fp)
+        else:
+            kw.update(model="occu")
+    elif model == "occu_rn":
+        kw.update(model="occu_rn", re_fp_mode=fp)
+    elif model == "occu_cop":
+        assert _sha(dur) == entry["sha256"]["session_duration"]
+        kw.update(model="occu_cop", fp_mode=fp, session_duration=np.asarray(dur))
+    elif model == "nmixture":
+        kw.update(model="nmixture")
+    return X, W, Y, kw
+
+
+def flat_theta(entry, named):
+    """The fixture's named unconstrained values (plate layout of the model: beta (S, Ks+1), site effects (N, S), obs_re
+    (J, T, N, S)) as the flat theta of the oracle / engine; also used for the fixture's central-difference gradients."""
+    v = {k: np.asarray(a, dtype=np.float64) for k, a in named.items()}
+    S = v["beta"].shape[0]
+    parts = [np.concatenate([v["beta"][s], v["alpha"][s]]) for s in range(S)]
+    for k in ("prob_fp_constant", "prob_fp_unoccupied", "rate_fp_constant", "rate_fp_unoccupied"):
+        if k in v:
+            parts.append(v[k].reshape(1))
+    for k in ("site_re_sd", "obs_re_sd"):
+        if k in v:
+            parts.append(v[k].reshape(1))
+    for k in ("site_re_occ", "site_re_abu", "site_re_det"):          # (N, S) -> [S][N]
+        if k in v:
+            parts.append(v[k].T.reshape(-1))
+    if "obs_re" in v:                                                # (J, T, N, S) -> [S][N][T][J]
+        parts.append(v["obs_re"].transpose(3, 2, 1, 0).reshape(-1))
+    return np.concatenate(parts)
