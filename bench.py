@@ -496,7 +496,7 @@ def main(argv=None):
         torch.cuda.synchronize()
 
     in_warmup, nonlocal_fail = [False], [None]
-    first_gather, gather_hung = [True], [False]
+    first_gather, gather_hung, kept_alive = [True], [False], []
 
     def bench_workload(name, n_steps, n_warmup):
         """W untimed + exactly K timed steps of one workload; rank 0 gets the line (a dict), the others None."""
@@ -706,6 +706,9 @@ def main(argv=None):
             "dtype": "f32",
             "data": "synthetic",
             "rccl_world": comm.world if comm is not None else 1,
+            # true: the engine's first (untimed) bl_gather_draws did not return within its bound on this rank; the run went on with
+            # torch.distributed's all-gather (config.gather says so).  That path has only been exercised with a simulated hang on one GPU.
+            "gather_hung": bool(gather_hung[0]),
             "kernel_ms_per_rank": kernel_ms_per_rank,
             "config": {
                 "workload": f"{wl['text']}: NUTS {NCH} chain{'s' if NCH != 1 else ''} per GPU x ({NUM_WARMUP} warmup + {NUM_SAMPLES} draws), "
@@ -733,6 +736,8 @@ def main(argv=None):
         }
         # what the scaled CPU baseline of a secondary workload needs: posterior draws to evaluate at, and the launch's size
         aux = dict(data=data, X=X, draws=steps[-1][1], leap_per_step=leap_mean, ess_per_step=total_ess / n_steps, D=ds.D, chains=NCH)
+        if gather_hung[0]:
+            kept_alive.append(ds)   # the abandoned worker thread still refers to it (its events must outlive the thread): kept until exit
         del ds
         return out, aux, wl
 

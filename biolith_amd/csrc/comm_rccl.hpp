@@ -160,10 +160,11 @@ extern "C" int bl_comm_init_all(int ndev, const int *devices, bl_comm **out)
 {
     if (ndev <= 0 || ndev > 64 || !devices || !out) return bl_fail(BL_ERR_INVALID, "bl_comm_init_all: bad argument");
     for (int i = 0; i < ndev; i++) out[i] = nullptr;
-    // (RCCL refuses two ranks on one device; said here in plain words.  With BIOLITH_RCCL_LIB naming another collective library -- tests
-    // only: tests/fake_rccl, a double that copies between the ranks' buffers -- the question is that library's to answer.)
-    const char *other_lib = getenv("BIOLITH_RCCL_LIB");
-    for (int i = 0; i < ndev && !(other_lib && *other_lib); i++)
+    // (RCCL refuses two ranks on one device; said here in plain words.  BIOLITH_TEST_ALLOW_DUP_DEVICES=1 -- tests only: tests/fake_rccl,
+    // a double of the collective that copies between the ranks' buffers and so can take a device twice -- lifts the refusal.  It is
+    // NOT keyed on BIOLITH_RCCL_LIB: that variable is also how a real librccl in another place is named, and a real one keeps the refusal.)
+    const char *allow_dup = getenv("BIOLITH_TEST_ALLOW_DUP_DEVICES");
+    for (int i = 0; i < ndev && !(allow_dup && allow_dup[0] == '1'); i++)
         for (int j = 0; j < i; j++)
             if (devices[i] == devices[j]) return bl_fail(BL_ERR_INVALID, "bl_comm_init_all: device %d named twice (one rank per GPU)", devices[i]);
     RcclApi *api;

@@ -173,9 +173,9 @@ def fit(
     # timeout starts; their cost is reported in mcmc.result.comm_init_ms).  A device named twice (tests on a one-GPU box)
     # cannot hold two RCCL ranks: the shards are then fetched one by one and concatenated on the host.
     used = [dev for r, dev in enumerate(devices) if shard_chains(num_chains, world, r)[0] > 0]
-    # (BIOLITH_RCCL_LIB names another collective library: tests only -- tests/fake_rccl, a double of the collective that lets the
-    # several-ranks branch of bl_gather_draws run on a one-GPU box; whether it takes a device twice is then its to answer)
-    use_rccl = explicit_devices and (len(set(used)) == len(used) or bool(os.environ.get("BIOLITH_RCCL_LIB")))
+    # (BIOLITH_TEST_ALLOW_DUP_DEVICES=1: tests only -- with tests/fake_rccl, a double of the collective that lets the several-ranks
+    # branch of bl_gather_draws run on a one-GPU box.  Not keyed on BIOLITH_RCCL_LIB, which may simply name a real librccl elsewhere.)
+    use_rccl = explicit_devices and (len(set(used)) == len(used) or os.environ.get("BIOLITH_TEST_ALLOW_DUP_DEVICES") == "1")
     comms = []
     if use_rccl:
         from .._ffi import BL_ERR_COMM, EngineError

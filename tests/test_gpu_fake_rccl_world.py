@@ -22,7 +22,7 @@ FAKE = os.path.join(HERE, "fake_rccl", "libfakerccl.so")
 def world_run():
     if not os.path.exists(FAKE):
         subprocess.run(["make", "-C", os.path.join(HERE, "fake_rccl")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    env = dict(os.environ, BIOLITH_RCCL_LIB=FAKE)
+    env = dict(os.environ, BIOLITH_RCCL_LIB=FAKE, BIOLITH_TEST_ALLOW_DUP_DEVICES="1")
     env.pop("FAKE_RCCL_FAIL_CALL", None)
     r = subprocess.run([sys.executable, os.path.join(HERE, "fake_rccl", "run_world.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]

@@ -78,7 +78,10 @@ def test_predict_on_new_sites():  # grid_search.py:85-92 style: predict for held
         predict(occu, res.mcmc, site_covs=rng.normal(size=(33, 3)), obs_covs=new_obs, num_samples=50)
     # infer_discrete=True (predict.py:18, 71): obs is withheld from the model call (predict.py:78-80), so (z, y) are drawn from their
     # joint distribution given the posterior draw -- the sites and the distribution of the default path (same seed: the same sample)
-    with pytest.warns(UserWarning, match=r"infer_discrete=True\) runs the default ancestral path"):   # (an unverified upstream assumption: said aloud)
+    import warnings
+
+    with warnings.catch_warnings():      # silent, as the reference hands the flag to Predictive (predict.py:67-72): pipelines with -W error
+        warnings.simplefilter("error")
         disc = predict(occu, res.mcmc, site_covs=new_site, obs_covs=new_obs, num_samples=50, infer_discrete=True)
     assert set(disc.keys()) == set(preds.keys())
     assert np.array_equal(disc["z"], preds["z"]) and np.array_equal(disc["y"], preds["y"])

@@ -198,6 +198,36 @@ def test_ess_and_rhat_against_oracle_restatement():
     assert t["x"]["n_eff"].shape == (3, 2) and "5.0%" in t["x"] and "95.0%" in t["x"]
 
 
+@pytest.mark.parametrize("rho", [0.0, 0.5, 0.9, -0.3])
+def test_ess_against_the_analytic_value_of_an_ar1_process(rho):
+    """ESS is the numerator of the metric (reference: evaluation/diagnostics.py:23 -> numpyro.diagnostics.summary); pin the estimator
+    to something OUTSIDE the repo: a stationary AR(1) process has integrated autocorrelation time (1 + rho) / (1 - rho), so
+    ESS = C n (1 - rho) / (1 + rho) (iid: C n; antithetic rho < 0: more than C n).  Mean over 256 independent series, 4 x 2000."""
+    rng = np.random.default_rng(11)
+    C, n, m = 4, 2000, 256
+    x = np.empty((C, n, m))
+    x[:, 0] = rng.normal(size=(C, m)) / np.sqrt(1.0 - rho * rho)          # stationary start
+    e = rng.normal(size=(C, n, m))
+    for t in range(1, n):
+        x[:, t] = rho * x[:, t - 1] + e[:, t]
+    ess = effective_sample_size(x)
+    want = C * n * (1.0 - rho) / (1.0 + rho)
+    assert ess.shape == (m,)
+    assert abs(ess.mean() / want - 1.0) < 0.05, (rho, ess.mean(), want)
+    assert abs(split_gelman_rubin(x).mean() - 1.0) < (0.02 if rho >= 0.9 else 0.005)
+
+
+def test_rhat_against_the_analytic_value_of_shifted_chains():
+    """Two chains of iid N(0, 1) draws whose means differ by d: var+ / W -> 1 + d^2 / 2 (between-chain variance of the two means
+    (ddof 1) is d^2 / 2), split-R-hat -> sqrt(1 + d^2 / 2) for long chains."""
+    rng = np.random.default_rng(12)
+    n, d = 20000, 1.0
+    x = rng.normal(size=(2, n, 8))
+    x[1] += d
+    # split chains: 4 half-chains, two at 0 and two at d: variance of the four means (ddof 1) = d^2 / 3
+    assert np.allclose(split_gelman_rubin(x), np.sqrt(1.0 + d * d / 3.0), rtol=0.02)
+
+
 def test_grid_search_hands_kernel_and_init_strategy_to_fit_only(monkeypatch):
     """grid_search_priors(kernel='nuts') must not leak `kernel` into predict() / lppd(), whose unknown keywords
     go to the model (reference: grid_search.py:64-96 passes kernel / init_strategy to fit() alone)."""
