@@ -81,6 +81,14 @@ def test_occu_rn_multi_season():  # occu_rn.py:391-407
     assert np.allclose(results.samples["abundance"].mean(), true_params["abundance"].mean(), rtol=0.2)
 
 
+def test_occu_rn_multi_species():  # occu_rn.py:412-420 (the reference's own test: a shape assert)
+    data, _ = simulate_rn(simulate_missing=True, n_species=2, n_sites=30)
+    results = fit(occu_rn, **data, num_chains=1, num_samples=200, timeout=600)
+    assert results.samples["abundance"].shape[-1] == 2
+    assert results.samples["abundance"].shape == (200, 1, 30, 2) and results.samples["cov_state_0"].shape == (200, 2)
+    assert np.all(np.isfinite(results.samples["abundance"])) and not results.mcmc.get_extra_fields()["diverging"].all()
+
+
 def test_rn_config4_runs_and_recovers_truth():
     """BASELINE config 4: 5 000 sites x 10 visits, 3+3 covariates, 4 chains."""
     data, truth = simulate_rn(n_sites=5000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7)

@@ -27,6 +27,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         ms.append(r.kernel_ms)
         leaps.append(int(r.n_leapfrog.sum()) + 4)
     nl = leaps[-1]
+    import hashlib
+    r0 = ds.nuts(num_warmup=1000, num_samples=1000, num_chains=4, seed=0)
+    print("  cfg2 seed 0: sha256(draws | num_steps | step_size | inv_mass) =", hashlib.sha256(r0.draws.tobytes() + r0.num_steps.tobytes() + r0.step_size.tobytes() + r0.inv_mass.tobytes()).hexdigest()[:24],
+          "threads per workgroup", r0.threads_per_wg)
     print(f"  cfg2: kernel ms {np.round(ms, 2).tolist()}  ALL (after the first): {1e3 * sum(ms[1:]) / (sum(leaps[1:]) / 4):.4f} us/leapfrog/chain;  last: {1e3 * r.kernel_ms / (nl / 4):.3f} us/leapfrog/chain, div {int(r.diverging.sum())}, "
           f"l2local {r.chains_l2_local}, coef means {r.draws.reshape(-1, 8).mean(0).round(4).tolist()}")
 else:
