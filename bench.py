@@ -51,7 +51,9 @@ WORKLOADS = {
     "occu_cfg1": dict(model="occu", cfg=dict(random_seed=0), chains=2, num_warmup=1000, num_samples=1000, cpu_sample=(1000, 1000), site="psi",
                       metric="effective samples/sec (psi) for occu NUTS, simulate() defaults: 100 sites x 52 visits, 2 chains",
                       text="biolith simulate() defaults (100 sites, 52 visits, 1 + 1 covariates, seed 0); fit(occu, num_chains=2)"),
-    "occu_rn": dict(model="occu_rn", cfg=CFG4, num_warmup=1000, num_samples=1000, cpu_sample=(40, 40), site="abundance",
+    # (cpu_sample: --cpu-baseline runs the oracle's OWN sampler, 4 x (200 + 200), a few minutes on 4 cores -- the measured figure of
+    # profiles/r05/e_cpu_baseline_rn.json; the default run's secondary line carries the scaled estimate)
+    "occu_rn": dict(model="occu_rn", cfg=CFG4, num_warmup=1000, num_samples=1000, cpu_sample=(200, 200), site="abundance",
                     metric="effective samples/sec (abundance) for occu_rn NUTS, 5k sites x 10 visits",
                     text="biolith simulate_rn(n_sites=5000, n_site_covs=3, n_obs_covs=3, 10 visits, seed 0); "
                          "fit(occu_rn, max_abundance=100)"),
@@ -287,14 +289,14 @@ def cpu_baseline_scaled(aux, wl, threads, budget_s=12.0, chains=CHAINS_PER_GPU):
     chains_rounds = -(-chains // threads)
     cpu_s_per_step = chains_rounds * (aux["leap_per_step"] / chains) * s_eval
     # NOT like for like with the GPU figure: ESS per step is borrowed from the GPU run, not measured; the oracle is the plain
-    # float64 statement of the model (occu_rn: all max_abundance + 1 terms of every visit, where the kernel cuts each site's range to about
-    # an eighth of them) on `threads` of the host's cores.  Reported as context; no gpu_over_cpu is derived from a scaled baseline.
+    # float64 statement of the model (occu_rn: every term of every visit up to where the terms have died out under a double's rounding --
+    # about a third of the max_abundance + 1, where the kernel keeps the eighth within 20 nats of the largest) on `threads` of the host's cores.  Reported as context; no gpu_over_cpu is derived from a scaled baseline.
     return dict(value=aux["ess_per_step"] / cpu_s_per_step, unit="ESS/s", cores=threads, kind="port", scaled=True, comparable=False,
                 sample=f"SCALED ESTIMATE, not a sampler run: oracle potential + gradient (float64 C restatement, gcc -O3 -march=native -fno-fast-math) at {per_thread} posterior "
                        f"draws per core on {threads} of {os.cpu_count()} host cores: {wall:.1f} s, {1e3 * s_eval:.2f} ms per evaluation per core; scaled: "
                        f"{aux['leap_per_step'] / chains:.0f} gradient evaluations per chain per step x that = {cpu_s_per_step:.1f} s per step "
-                       f"({chains} chains side by side), ESS per step as the GPU run's ({aux['ess_per_step']:.0f}); validated once against the oracle's "
-                       f"own sampler run: profiles/r04/ (cpu_baseline_validation)")
+                       f"({chains} chains side by side), ESS per step as the GPU run's ({aux['ess_per_step']:.0f}); validated against the oracle's "
+                       f"own sampler run: profiles/r04/c_cpu_baseline_validation_rn.json, profiles/r05/e_cpu_baseline_rn.json")
 
 
 def fit_end_to_end(data, reps=3, chains=CHAINS_PER_GPU):

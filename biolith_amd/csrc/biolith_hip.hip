@@ -937,13 +937,17 @@ static int dyn_lanes_per_pair(const bl_dataset *ds, int chains)
 // BL_GRP_VISITS visits of its pair and the lanes one XCD offers the chain (4 compute waves on each of its <= kmax workgroups) allow it;
 // the periods are split first (nothing to exchange between those lanes), then the visits of a period (one DPP fold per period).
 #define BL_GRP_VISITS 6
-static int occu_lane_group(const bl_dataset *ds, int chains, int want_k)
+#ifndef BL_WIDE_KMAX
+#define BL_WIDE_KMAX 128   // workgroups of a chain in the wide geometry when lane groups ask for more than the slice needs (measured: tools/time_wide.py)
+#endif
+static int occu_lane_group(const bl_dataset *ds, int chains, int want_k, int kcap = 0)
 {
     if (ds->model != 0 && ds->model != 2 && ds->model != 3 && ds->model != 4) return 0; // (occu, false positives, occu_cop, nmixture)
     const int T = ds->dims.n_periods, J = ds->dims.n_replicates;
     const long long V = (long long)T * J, npairs = (ds->dims.n_sites + 1) / 2;
     const int per_xcd = ((chains > 0 ? chains : 1) + 7) / 8;
     int kmax = std::max(1, 32 / per_xcd);
+    if (kcap > 0) kmax = kcap; // (wide geometry: the chain's workgroups span XCDs -- the lanes of up to 256 / chains workgroups)
     if (want_k > 0) kmax = std::min(kmax, want_k);
     int target = BL_GRP_VISITS;
     if (const char *e = getenv("BIOLITH_HIP_GRP_VISITS")) { const int v = atoi(e); if (v >= 1) target = v; } // A/B knob
@@ -1062,6 +1066,30 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
             int nl;
             if (kk > kmax && kk <= kwide && fits(kk, &nl)) { k = kk; nloc = nl; wide = 1; }
         }
+    }
+    if (ds->model == 0 && want_k <= 0) { // A/B knob: the plain model over kk workgroups across XCDs although one XCD's would do
+        if (const char *e = getenv("BIOLITH_HIP_WIDE_K")) {
+            const int kk = atoi(e), kwide = 256 / (chains > 0 ? chains : 1);
+            int nl;
+            if (kk > 0 && kk <= kwide && fits(kk, &nl)) { k = kk; nloc = nl; wide = 1; ok = true; }
+        }
+    }
+    // Wide geometry and many visits per site (the top rows of the reference's benchmark grid: 6 400 x 64, 12 800 x 90): the lanes of
+    // one XCD no longer cap the lane groups -- a site pair is shared by as many lanes as BL_GRP_VISITS asks for and the chain takes
+    // the workgroups that offer them (four compute waves each), up to 256 / chains.  More workgroups make the exchange longer (every
+    // workgroup gathers every record over the fabric); BL_WIDE_KMAX bounds them where that costs more than the shorter visit loops save.
+    if (wide && ok && (ds->model == 0 || ds->model == 2) && want_k <= 0 && !getenv("BIOLITH_HIP_WIDE_K")) {
+        const int kwide = std::min(256 / (chains > 0 ? chains : 1), BL_WIDE_KMAX);
+        if (kwide > k) {
+            const int g2 = occu_lane_group(ds, chains, 0, kwide);
+            const int G2 = 1 << ((g2 & 15) + (g2 >> 4));
+            int kk = (int)((((long long)N + 1) / 2 * G2 + 4 * 64 - 1) / (4 * 64));
+            kk = std::min(std::max(kk, k), kwide);
+            int nl;
+            if (fits(kk, &nl)) { k = kk; nloc = nl; grp = g2; }
+        }
+    } else if (wide && ok && (ds->model == 0 || ds->model == 2) && want_k <= 0) {
+        grp = occu_lane_group(ds, chains, 0, k); // (forced k: the groups its lanes allow)
     }
     if (!ok) fits(k, &nloc);
     if (!ok && ds->model == 0) ncw = 4; // HBM-row form is built for 4 compute waves only

@@ -203,6 +203,9 @@ struct BlSpinBound {
 // to publish the corrected one without reading anybody's record in between, so it can be two epochs ahead of a peer that is still
 // reading -- four slots keep those apart (two sufficed while dropped evaluations were not published).
 #define BL_XCHG_SLOTS 4u
+#ifndef BL_POLL_NB
+#define BL_POLL_NB 4 // batches of 8 polls per lane in flight at once when a chain has more workgroups than one batch covers (A/B: 1 = one after the other)
+#endif
 #define SMALL_D_NVP(LEAN, MODEL, KS, KO) ((LEAN) && ((MODEL) == 0 || (MODEL) == 1) && (KS) + (KO) + 2 <= 8)
 #ifndef BL_GRP_FORM
 #define BL_GRP_FORM 2 // what the sampler's GRP instantiation carries: 2 = the lane-group evaluator alone, 1 = both evaluators (A/B)
@@ -876,28 +879,45 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #pragma unroll
                 for (int q = 0; q < 8; q++) acc += (double)(pval[q] * __uint_as_float((unsigned)v[q]));
             } else {
-                for (int p0 = 0; p0 < p.k && !timed_out; p0 += 8 * G) {
-                    unsigned long long v[8];
+                // Many workgroups (the wide geometry: a chain across XCDs, up to 128 records): the loads of up to BL_POLL_NB batches
+                // of 8 per lane are ALL in flight before the first tag is looked at -- one round trip over the fabric for the lot.
+                // (Until round 5 the batches were polled one after the other, a round trip each: the exchange of the benchmark grid's
+                // top rows grew with k faster than the visit loops shrank -- profiles/r05/d_time_wide_before.txt.)  Same lanes, same
+                // records, same order of the f64 sums as the batch-by-batch form.
+                for (int p0 = 0; p0 < p.k && !timed_out; p0 += BL_POLL_NB * 8 * G) {
+                    unsigned long long v[BL_POLL_NB][8];
                     BlSpinBound bound;
                     while (true) {
                         unsigned bad = 0u;
 #pragma unroll
-                        for (int q = 0; q < 8; q++) {
-                            const int w = p0 + q * G + sub;
-                            v[q] = bl_poll_load(rbase, (unsigned)(((w < p.k ? w : p.k - 1) * p.pitch + c_idx) * 8));
+                        for (int b = 0; b < BL_POLL_NB; b++) {
+                            if (b == 0 || p0 + b * 8 * G < p.k) { // wave-uniform: batches past the last record are not loaded
+#pragma unroll
+                                for (int q = 0; q < 8; q++) {
+                                    const int w = p0 + (b * 8 + q) * G + sub;
+                                    v[b][q] = bl_poll_load(rbase, (unsigned)(((w < p.k ? w : p.k - 1) * p.pitch + c_idx) * 8));
+                                }
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 8; q++) v[b][q] = v[0][0];
+                            }
                         }
 #pragma unroll
-                        for (int q = 0; q < 8; q++) bad |= ((unsigned)(v[q] >> 32)) ^ epoch;
+                        for (int b = 0; b < BL_POLL_NB; b++)
+#pragma unroll
+                            for (int q = 0; q < 8; q++) bad |= ((unsigned)(v[b][q] >> 32)) ^ epoch;
                         if (__all(bad == 0u)) break;
                         if (bound.expired(p.spin_limit)) { timed_out = true; break; }
                         if (!local)
                             for (int z = 0; z < p.poll_sleep; z++) __builtin_amdgcn_s_sleep(1);
                     }
 #pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const int w = p0 + q * G + sub;
-                        acc += (w < p.k) ? (double)__uint_as_float((unsigned)v[q]) : 0.0;
-                    }
+                    for (int b = 0; b < BL_POLL_NB; b++)
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const int w = p0 + (b * 8 + q) * G + sub;
+                            acc += (w < p.k) ? (double)__uint_as_float((unsigned)v[b][q]) : 0.0;
+                        }
                 }
             }
             // fold the 64/nvp lane groups (each summed a different subset of the workgroups): element-wise

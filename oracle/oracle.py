@@ -54,6 +54,7 @@ def lib():
             L.orc_data_destroy.argtypes = [C.c_void_p]
             L.orc_data_dim.argtypes = [C.c_void_p]
             L.orc_data_set_model.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            L.orc_data_set_rn_cut.argtypes = [C.c_void_p, C.c_int]
             L.orc_data_set_fp.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
             L.orc_data_set_cop.argtypes = [C.c_void_p, dp, dp, C.c_int, C.c_double]
             L.orc_data_set_nmix.argtypes = [C.c_void_p, dp, C.c_int]
@@ -207,6 +208,10 @@ class OracleData:
                 self._h = None
         except Exception:
             pass
+
+    def set_rn_cut(self, on: bool):
+        """occu_rn: stop the sums over n where the terms have died out (default) or sum every n <= max_abundance (tests of the stop)."""
+        lib().orc_data_set_rn_cut(self._h, int(bool(on)))
 
     def potential_grad(self, theta):
         th = np.ascontiguousarray(theta, dtype=np.float64)

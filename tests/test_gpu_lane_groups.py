@@ -188,7 +188,7 @@ def test_posterior_with_groups_matches_the_one_pair_per_lane_kernel(force_group)
     ds.close()
 
 
-@pytest.mark.parametrize("i", [4, 6])
+@pytest.mark.parametrize("i", [4, 6, 7])
 def test_benchmark_grid_rows_at_full_size(i):
     """Rows of the reference's own benchmark grid (benchmarks/occu_spoccupancy.py:16-70: 100 * 2^i sites x int(8 * 2^(i/2)) visits, 2 + 1
     covariates, one chain) at full size with the host's own choice of lanes per pair: K1 against the oracle and its first trees."""
@@ -204,7 +204,9 @@ def test_benchmark_grid_rows_at_full_size(i):
     assert np.max(np.abs(Gg - Go)) <= G_RTOL * np.max(np.abs(Go))
     o = oracle.nuts_run(od, 0, 3, num_chains=1, seed=i)
     r = ds.nuts(num_warmup=0, num_samples=3, num_chains=1, seed=i)
-    assert r.lds_staged and r.lane_group[0] * r.lane_group[1] >= 2, r.lane_group      # 32 / 64 visits per site: lanes share a pair
+    assert r.lds_staged and r.lane_group[0] * r.lane_group[1] >= 2, r.lane_group      # 32 / 64 / 90 visits per site: lanes share a pair
+    if i == 7:   # 12 800 x 90 = 9.2 MB of records: more than one XCD's LDS -- the wide geometry (a chain across XCDs) WITH lane groups (round 5)
+        assert r.wgs_per_chain > 32 and r.lane_group[0] * r.lane_group[1] >= 4, (r.wgs_per_chain, r.lane_group)
     assert np.array_equal(o["num_steps"][:, :2], r.num_steps[:, :2]), (o["num_steps"], r.num_steps)
     assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=2e-3)
     ds.close()

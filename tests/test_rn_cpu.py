@@ -131,3 +131,22 @@ def test_occu_rn_validation():
         occu_rn(g["site_covs"], g["obs_covs"], obs=np.concatenate([g["obs"], g["obs"]]), obs_random_effects=True)
     with pytest.raises(AssertionError):
         occu_rn(g["site_covs"], g["obs_covs"], obs=g["obs"][0])
+
+
+def test_the_stop_of_the_sums_over_n_changes_no_bit():
+    """oracle/occu_oracle.c: potential_grad_rn stops a (site, period)'s sums over n where every later term is more than 45 nats below
+    the largest one (each term is at most its prior part, which falls monotonically beyond the Poisson mode): what is dropped is under
+    a double's rounding, so the value and the gradient are bit-equal to the sums over every n <= max_abundance."""
+    import reference_logjoint as R
+
+    for case in ("rn_default", "rn_missing", "rn_small_2x2"):
+        e = R.load(case)
+        X, W, Y, kw = R.build(e)
+        od = oracle.OracleData(X, W, Y, **kw)
+        for p in e["points"]:
+            th = R.flat_theta(e, p["unconstrained"])
+            U1, g1 = od.potential_grad(th)
+            od.set_rn_cut(False)
+            U0, g0 = od.potential_grad(th)
+            od.set_rn_cut(True)
+            assert U1 == U0 and np.array_equal(g1, g0), (case, p["label"])
