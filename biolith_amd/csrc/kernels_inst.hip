@@ -16,6 +16,16 @@
 #define BL_HAVE_RN 0
 #endif
 
+// Per-FORM instantiations of the sampler (JSEL / LEAN / lean lane-group and Royle-Nichols forms: nuts_kernel.hpp) exist for the capacity
+// pairs up to 4 + 4 -- what the reference's own datasets, its benchmark grid and BASELINE.json's configs use; with 8 or 16 covariates on
+// a side the general kernels serve (they carry every form at run time: 3-7 % slower on the shapes a form serves).  20 of the 36
+// translation units are then a third of their former size: the library builds in 3.5 minutes on 8 cores instead of 5.5 and is 36 MB, not 55.
+#if BL_KS <= 4 && BL_KO <= 4
+#define BL_FORMS_FULL 1
+#else
+#define BL_FORMS_FULL 0
+#endif
+
 // `name`: the instantiation as a profiler prints it (handed to the host: bl_nuts_kernel_name, bench.py's roofline.kernel)
 extern "C" void bl_note_kernel_name(const char *name);
 template <auto Kernel, typename P>
@@ -43,7 +53,11 @@ static int bl_launch(const char *name, const P *p, int grid, int threads, int ld
 // ... and of one period (JSEL = 1 in a lane-group kernel: occu_device.hpp bl_eval_sites_grp<.., T1>)
 #define BL_PICK_GRP_LEAN_T1(P, MODEL, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true, 1, true>>(BL_KHEAD(bl_nuts_kernel, true, MODEL, CW) ", true, 1, true>", P, grid, 64 * (CW + 1), lds_bytes, stream)
 #define BL_IS_LEAN(P) ((P)->n_species <= 1 && (P)->k <= 8 * (64 / (P)->nvp))
+#if BL_FORMS_FULL
 #define BL_PICK_GRP_ANY(P, CW) (!BL_IS_LEAN(P) ? BL_PICK_GRP(P, 0, CW) : ((P)->T == 1 && ((P)->lane_grp & 15) == 0) ? BL_PICK_GRP_LEAN_T1(P, 0, CW) : BL_PICK_GRP_LEAN(P, 0, CW))
+#else
+#define BL_PICK_GRP_ANY(P, CW) BL_PICK_GRP(P, 0, CW)
+#endif
 // the plain model, one pair per lane: one instantiation per visits-per-period form (1 .. 6, 8 unrolled; 0 = any J at run time)
 #ifndef BL_J_LEAN
 #define BL_J_LEAN true // (A/B: -DBL_J_LEAN=false)
@@ -65,11 +79,13 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
 {
     if (model == 1) { // occu_rn
 #if BL_HAVE_RN
+#if BL_FORMS_FULL
         // (lean and at most ten visits per period -- config 4 -- : the instantiation that carries the one-group paths alone)
         if (staged && p->ncw == BL_CWAVES_RN && BL_IS_LEAN(p) && p->J <= 10 && p->T == 1)
             return bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, 1, BL_CWAVES_RN, false, 10, true>>(BL_KHEAD(bl_nuts_kernel, true, 1, BL_CWAVES_RN) ", false, 10, true>", p, grid, 64 * (BL_CWAVES_RN + 1), lds_bytes, stream);
         if (staged && p->ncw == BL_CWAVES_RN && BL_IS_LEAN(p))
             return bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, 1, BL_CWAVES_RN, false, -1, true>>(BL_KHEAD(bl_nuts_kernel, true, 1, BL_CWAVES_RN) ", false, -1, true>", p, grid, 64 * (BL_CWAVES_RN + 1), lds_bytes, stream);
+#endif
         if (staged && p->ncw == BL_CWAVES_RN) return BL_PICK(bl_nuts_kernel, p, true, 1, BL_CWAVES_RN);
 #endif
         return (int)hipErrorNotSupported;
@@ -113,9 +129,11 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
     if (staged && p->ncw == BL_CWAVES_SINGLE) return BL_PICK_GRP_ANY(p, BL_CWAVES_SINGLE);
     // one species and a one-batch poll (k <= 8 x 64 / nvp): the lean per-form instantiations; else the kernel that carries everything
     // (and one period, at most one site pair per compute lane: nuts_kernel.hpp LEAN)
+#if BL_FORMS_FULL
     const bool lean = !BL_J_LEAN || (BL_IS_LEAN(p) && p->T == 1 && p->nloc <= 2 * 64 * p->ncw);
     if (staged && p->ncw == 3 && lean) { BL_PICK_J_ANY(p, 3) }
     if (staged && p->ncw == 4 && lean) { BL_PICK_J_ANY(p, 4) }
+#endif
     if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 0, 3);
     if (staged && p->ncw == 4) return BL_PICK(bl_nuts_kernel, p, true, 0, 4);
 #ifdef BL_OCCU_CWX

@@ -204,7 +204,7 @@ struct BlSpinBound {
 // reading -- four slots keep those apart (two sufficed while dropped evaluations were not published).
 #define BL_XCHG_SLOTS 4u
 #ifndef BL_POLL_NB
-#define BL_POLL_NB 4 // batches of 8 polls per lane in flight at once when a chain has more workgroups than one batch covers (A/B: 1 = one after the other)
+#define BL_POLL_NB 2 // batches of 8 polls per lane in flight at once when a chain has more workgroups than one batch covers (A/B: 1 = one after the other)
 #endif
 #define SMALL_D_NVP(LEAN, MODEL, KS, KO) ((LEAN) && ((MODEL) == 0 || (MODEL) == 1) && (KS) + (KO) + 2 <= 8)
 #ifndef BL_GRP_FORM
@@ -884,13 +884,16 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                 // (Until round 5 the batches were polled one after the other, a round trip each: the exchange of the benchmark grid's
                 // top rows grew with k faster than the visit loops shrank -- profiles/r05/d_time_wide_before.txt.)  Same lanes, same
                 // records, same order of the f64 sums as the batch-by-batch form.
-                for (int p0 = 0; p0 < p.k && !timed_out; p0 += BL_POLL_NB * 8 * G) {
-                    unsigned long long v[BL_POLL_NB][8];
+                // (occu_rn keeps one batch at a time: its kernel sits at the 256-register budget -- tests/test_kernel_resources.py -- and its
+                // chains do not leave their XCD)
+                constexpr int NB = MODEL == 1 ? 1 : BL_POLL_NB;
+                for (int p0 = 0; p0 < p.k && !timed_out; p0 += NB * 8 * G) {
+                    unsigned long long v[NB][8];
                     BlSpinBound bound;
                     while (true) {
                         unsigned bad = 0u;
 #pragma unroll
-                        for (int b = 0; b < BL_POLL_NB; b++) {
+                        for (int b = 0; b < NB; b++) {
                             if (b == 0 || p0 + b * 8 * G < p.k) { // wave-uniform: batches past the last record are not loaded
 #pragma unroll
                                 for (int q = 0; q < 8; q++) {
@@ -903,7 +906,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                             }
                         }
 #pragma unroll
-                        for (int b = 0; b < BL_POLL_NB; b++)
+                        for (int b = 0; b < NB; b++)
 #pragma unroll
                             for (int q = 0; q < 8; q++) bad |= ((unsigned)(v[b][q] >> 32)) ^ epoch;
                         if (__all(bad == 0u)) break;
@@ -912,7 +915,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
                             for (int z = 0; z < p.poll_sleep; z++) __builtin_amdgcn_s_sleep(1);
                     }
 #pragma unroll
-                    for (int b = 0; b < BL_POLL_NB; b++)
+                    for (int b = 0; b < NB; b++)
 #pragma unroll
                         for (int q = 0; q < 8; q++) {
                             const int w = p0 + (b * 8 + q) * G + sub;
