@@ -2,6 +2,7 @@
 // Built N times by the Makefile (-DBL_KS=.. -DBL_KO=..) so the instantiations compile in parallel.
 // model 0 = occu (LDS-staged and HBM-row forms); model 1 = occu_rn and model 2 = occu with false
 // positives, model 3 = occu_cop, model 4 = nmixture (LDS-staged form, capacities <= 4).
+#include <cstdlib>
 #include "logp_kernel.hpp"
 #include "nuts_kernel.hpp"
 
@@ -52,7 +53,10 @@ static int bl_launch(const char *name, const P *p, int grid, int threads, int ld
 #define BL_PICK_GRP_LEAN(P, MODEL, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true, -1, true>>(BL_KHEAD(bl_nuts_kernel, true, MODEL, CW) ", true, -1, true>", P, grid, 64 * (CW + 1), lds_bytes, stream)
 // ... and of one period (JSEL = 1 in a lane-group kernel: occu_device.hpp bl_eval_sites_grp<.., T1>)
 #define BL_PICK_GRP_LEAN_T1(P, MODEL, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true, 1, true>>(BL_KHEAD(bl_nuts_kernel, true, MODEL, CW) ", true, 1, true>", P, grid, 64 * (CW + 1), lds_bytes, stream)
-#define BL_IS_LEAN(P) ((P)->n_species <= 1 && (P)->k <= 8 * (64 / (P)->nvp))
+// (BIOLITH_HIP_GENERAL=1: tests / A/B -- the general kernel although a per-form instantiation would serve; draws must not change by a bit:
+// tests/test_gpu_kernel_forms.py)
+static inline bool bl_force_general() { const char *e = getenv("BIOLITH_HIP_GENERAL"); return e && e[0] == '1'; }
+#define BL_IS_LEAN(P) (!bl_force_general() && (P)->n_species <= 1 && (P)->k <= 8 * (64 / (P)->nvp))
 #if BL_FORMS_FULL
 #define BL_PICK_GRP_ANY(P, CW) (!BL_IS_LEAN(P) ? BL_PICK_GRP(P, 0, CW) : ((P)->T == 1 && ((P)->lane_grp & 15) == 0) ? BL_PICK_GRP_LEAN_T1(P, 0, CW) : BL_PICK_GRP_LEAN(P, 0, CW))
 #else
@@ -130,7 +134,7 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
     // one species and a one-batch poll (k <= 8 x 64 / nvp): the lean per-form instantiations; else the kernel that carries everything
     // (and one period, at most one site pair per compute lane: nuts_kernel.hpp LEAN)
 #if BL_FORMS_FULL
-    const bool lean = !BL_J_LEAN || (BL_IS_LEAN(p) && p->T == 1 && p->nloc <= 2 * 64 * p->ncw);
+    const bool lean = (!BL_J_LEAN && !bl_force_general()) || (BL_IS_LEAN(p) && p->T == 1 && p->nloc <= 2 * 64 * p->ncw);
     if (staged && p->ncw == 3 && lean) { BL_PICK_J_ANY(p, 3) }
     if (staged && p->ncw == 4 && lean) { BL_PICK_J_ANY(p, 4) }
 #endif
