@@ -520,7 +520,31 @@ CASES = OrderedDict([
                         dict(max_abundance=60))),
     ("nmix_re_site", ("nmixture", dict(n_sites=50, n_site_covs=1, n_obs_covs=1, deployment_days_per_site=35, random_seed=12),
                       dict(site_random_effects=True))),
+    # non-default priors (a prior is written as [family, parameters...] and handed to the model as the shim's distribution object):
+    # regression coefficients Normal(loc, scale) / Laplace(loc, scale) (occu.py:28-29, linear.py:28; utils/grid_search.py:366-371),
+    # the false-positive Beta (occu.py:32-33), the effects' HalfNormal scales (occu.py:38-39), occu_cop's Exponential rate (occu_cop.py:33-34)
+    ("priors_normal", ("occu", dict(n_sites=120, n_site_covs=2, n_obs_covs=2, deployment_days_per_site=42, random_seed=21),
+                       dict(prior_beta=["Normal", 0.3, 2.0], prior_alpha=["Normal", -0.2, 0.8]))),
+    ("priors_laplace", ("occu", dict(n_sites=120, n_site_covs=2, n_obs_covs=2, deployment_days_per_site=42, random_seed=21, simulate_missing=True),
+                        dict(prior_beta=["Laplace", 0.0, 1.5], prior_alpha=["Laplace", 0.1, 0.7]))),
+    ("priors_fp", ("occu", dict(n_sites=100, n_site_covs=1, n_obs_covs=2, deployment_days_per_site=49, prob_fp_unoccupied=0.05, random_seed=22),
+                   dict(false_positives_unoccupied=True, prior_prob_fp_unoccupied=["Beta", 3.0, 8.0], prior_beta=["Normal", 0.0, 1.5]))),
+    ("priors_re", ("occu", dict(n_sites=40, n_site_covs=1, n_obs_covs=1, random_seed=23, deployment_days_per_site=35),
+                   dict(site_random_effects=True, obs_random_effects=True, prior_site_re_sd=["HalfNormal", 0.7], prior_obs_re_sd=["HalfNormal", 1.3],
+                        prior_alpha=["Normal", 0.2, 1.2]))),
+    ("priors_rn", ("occu_rn", dict(n_sites=60, n_site_covs=2, n_obs_covs=1, deployment_days_per_site=42, random_seed=24),
+                   dict(prior_beta=["Normal", -0.3, 0.9], prior_alpha=["Normal", 0.0, 2.0], max_abundance=45))),
+    ("priors_cop", ("occu_cop", dict(n_sites=70, n_site_covs=1, n_obs_covs=2, deployment_days_per_site=42, random_seed=25),
+                    dict(false_positives_constant=True, prior_rate_fp_constant=["Exponential", 2.0], prior_beta=["Normal", 0.1, 1.5]))),
+    ("priors_nmix", ("nmixture", dict(n_sites=60, n_site_covs=1, n_obs_covs=1, deployment_days_per_site=35, random_seed=26),
+                     dict(prior_beta=["Normal", 0.5, 0.7], prior_alpha=["Normal", -0.5, 1.4], max_abundance=80))),
 ])
+PRIOR_CLASSES = dict(Normal=Normal, Laplace=Laplace, Beta=Beta, HalfNormal=HalfNormal, Exponential=Exponential)
+
+
+def materialise(mkw):
+    """Model kwargs with every [family, parameters...] prior as the shim's distribution object."""
+    return {k: (PRIOR_CLASSES[v[0]](*v[1:]) if isinstance(v, list) and v and v[0] in PRIOR_CLASSES else v) for k, v in mkw.items()}
 
 SIMULATORS = dict(occu="simulate", occu_rn="simulate_rn", occu_cop="simulate_cop", nmixture="simulate_nmixture")
 SITE_RE_NAMES = dict(occu=("site_re_occ", "site_re_det"), occu_cop=("site_re_occ", "site_re_det"),
@@ -591,7 +615,7 @@ def main():
             data, truth = simulate(**skw)
         site_covs, obs_covs, obs, dur, _, _ = prepare_data(data["site_covs"], data["obs_covs"], data["obs"], data.get("session_duration"))
         # float32 values (utils/data.py:135-140 hands the model float32 arrays), float64 arithmetic
-        args = dict(site_covs=f32(site_covs), obs_covs=f32(obs_covs), obs=f32(obs), **mkw)
+        args = dict(site_covs=f32(site_covs), obs_covs=f32(obs_covs), obs=f32(obs), **materialise(mkw))
         if model == "occu_cop":
             args["session_duration"] = f32(dur)
         S, N, T, J = args["obs"].shape

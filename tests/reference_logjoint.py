@@ -52,6 +52,26 @@ def build(entry):
     kw = dict(site_random_effects=site, obs_random_effects=obs_re)
     if "max_abundance" in mk:
         kw["max_abundance"] = mk["max_abundance"]
+    # non-default priors, written in the fixture as [family, parameters...]
+    fam = []
+    for key, arg in (("prior_beta", "prior_beta"), ("prior_alpha", "prior_alpha")):
+        pr = mk.get(key, ["Normal", 0.0, 1.0])
+        assert pr[0] in ("Normal", "Laplace")
+        kw[arg] = (float(pr[1]), float(pr[2]))
+        fam.append(pr[0].lower())
+    kw["prior_family"] = tuple(fam)
+    for key in ("prior_prob_fp_constant", "prior_prob_fp_unoccupied"):
+        if key in mk:
+            assert mk[key][0] == "Beta"
+            kw["prior_fp"] = (float(mk[key][1]), float(mk[key][2]))
+    for key in ("prior_rate_fp_constant", "prior_rate_fp_unoccupied"):
+        if key in mk:
+            assert mk[key][0] == "Exponential"
+            kw["prior_fp_rate"] = float(mk[key][1])
+    for key, arg in (("prior_site_re_sd", "prior_site_re_sd"), ("prior_obs_re_sd", "prior_obs_re_sd")):
+        if key in mk:
+            assert mk[key][0] == "HalfNormal"
+            kw[arg] = float(mk[key][1])
     if model == "occu":
         if site or obs_re:
             kw.update(model="occu_re", re_fp_mode=fp)
@@ -67,6 +87,17 @@ def build(entry):
     elif model == "nmixture":
         kw.update(model="nmixture")
     return X, W, Y, kw
+
+
+def engine_kwargs(kw):
+    """The same kwargs for ``biolith_amd.engine.OccuDataset``: it takes a coefficient prior's family on the (loc, scale) pair itself."""
+    from biolith_amd.distributions import LocScale
+
+    out = dict(kw)
+    fam = out.pop("prior_family")
+    out["prior_beta"] = LocScale(*kw["prior_beta"], family=fam[0])
+    out["prior_alpha"] = LocScale(*kw["prior_alpha"], family=fam[1])
+    return out
 
 
 def flat_theta(entry, named):

@@ -27,7 +27,7 @@ def _tol(e, kw):
 def test_engine_potential_equals_the_reference_models(case):
     e = R.load(case)
     X, W, Y, kw = R.build(e)
-    ds = OccuDataset(X, W, Y, **kw)
+    ds = OccuDataset(X, W, Y, **R.engine_kwargs(kw))
     assert ds.D == e["dims"]["D"]
     u_tol, g_tol = _tol(e, kw)
     pts = e["points"][:4]
@@ -49,7 +49,7 @@ def test_engine_in_the_clamp_regime(case):
     ORACLE there, which tests/test_reference_logjoint.py relates to the reference)."""
     e = R.load(case)
     X, W, Y, kw = R.build(e)
-    ds, p = OccuDataset(X, W, Y, **kw), e["points"][4]
+    ds, p = OccuDataset(X, W, Y, **R.engine_kwargs(kw)), e["points"][4]
     th = R.flat_theta(e, p["unconstrained"])[None]
     U = ds.logp_grad(th)[0][0]
     want = p["U"] if e["model"] in ("occu_rn", "nmixture") else oracle.OracleData(X, W, Y, **kw).potential_grad(th[0])[0]

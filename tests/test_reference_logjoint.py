@@ -26,7 +26,8 @@ def test_the_fixture_set_covers_the_models_and_options_of_the_path():
     models = {R.load(c)["model"] for c in CASES}
     assert models == {"occu", "occu_rn", "occu_cop", "nmixture"}
     want = {"default", "missing", "missing_3periods", "small_3x3", "two_species", "fp_constant", "fp_unoccupied", "re_site", "re_obs",
-            "re_both", "rn_default", "rn_missing", "cop_default", "nmix_ref_test"}
+            "re_both", "rn_default", "rn_missing", "cop_default", "nmix_ref_test", "priors_normal", "priors_laplace", "priors_fp", "priors_re",
+            "priors_rn", "priors_cop", "priors_nmix"}
     assert want <= set(CASES)
     for c in CASES:
         e = R.load(c)
@@ -68,9 +69,10 @@ def test_clamp_regime_is_the_one_documented_deviation(case):
     if e["model"] == "occu" and e["dims"]["S"] == 1 and not kw["site_random_effects"] and not kw["obs_random_effects"]:
         # the literal statement with numpyro's clamp in both branches IS the reference there
         if kw["model"] == "occu_fp":
-            lj = oracle.literal_log_joint_fp(th, X, W, Y, fp_mode=kw["fp_mode"], clamp_z1=True)
+            lj = oracle.literal_log_joint_fp(th, X, W, Y, fp_mode=kw["fp_mode"], prior_fp=kw.get("prior_fp", (2.0, 5.0)),
+                                             prior_beta=kw["prior_beta"], prior_alpha=kw["prior_alpha"], clamp_z1=True)
         else:
-            lj = oracle.literal_log_joint(th, X, W, Y, clamp_z1=True)
+            lj = oracle.literal_log_joint(th, X, W, Y, kw["prior_beta"], kw["prior_alpha"], clamp_z1=True, prior_family=kw["prior_family"])
         assert abs(-lj - p["U"]) <= 1e-10 * abs(p["U"]), (-lj, p["U"])
 
 
