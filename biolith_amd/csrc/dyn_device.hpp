@@ -26,6 +26,9 @@
 // of the group takes the periods t = g, g + G, ... in both visit passes -- they are nine tenths of the transcendentals -- and the
 // recursions between them, which need every period in order, are run by all G lanes alike on the visit sums exchanged through LDS.
 #pragma once
+#ifndef BL_DYN_SCAN
+#define BL_DYN_SCAN 1 // the two-scans form (bl_eval_sites_dyn_scan) where a lane owns ONE period; 0: the scaled recursions everywhere (A/B)
+#endif
 
 // bytes of LDS behind the staged records: two float2 per period and compute lane (the lane's forward / smoothed columns), and one
 // more per period and lane GROUP for the periods' visit sums that the lanes of a group hand each other (host: choose_geometry)
@@ -332,6 +335,175 @@ __device__ __forceinline__ void bl_eval_sites_dyn_scaled(int ct, int pstride, in
         }
         ll2 = bl_fma2(lown, vm_own, ll2);
         const bl_f2 dv[3] = {(rho - psi) * vm_site, d_gam * vm_site, d_eps * vm_site};
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            gb2[b][0] += dv[b];
+#pragma unroll
+            for (int k = 0; k < KS; k++) gb2[b][k + 1] = bl_fma2(dv[b], x[k], gb2[b][k + 1]);
+        }
+    }
+    ll += ll2.x + ll2.y;
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+        for (int k = 0; k <= KS; k++) gb[b][k] += gb2[b][k].x + gb2[b][k].y;
+#pragma unroll
+    for (int k = 0; k <= KO; k++) ga[k] += ga2[k].x + ga2[k].y;
+}
+
+// Round 5: ONE period per lane (T == G in {2, 4, 8}: BASELINE.json configs[4], 8 seasons on 8 lanes) and no recursion at all -- the
+// forward-backward algorithm as two SCANS over the lanes of a group.  With the scaled likelihoods L_t = (E0_t, E1_t) and the transition
+// matrix A = [[1 - gamma, gamma], [eps, 1 - eps]] every period is a 2 x 2 matrix, X_0 = diag(L_0), X_t = A diag(L_t):
+//     alpha_t = pi X_0 X_1 ... X_t            (unnormalised forward vector;  pi = (1 - psi, psi))
+//     beta_t  = X_t+1 ... X_T-1 (1, 1)'       (backward vector)
+// so the INCLUSIVE PREFIX products P_t = X_0 ... X_t and SUFFIX products S_t = X_t ... X_T-1 are all a lane needs, and both are
+// log2(G) Hillis-Steele steps of a 2 x 2 product with the lane 1, 2, 4 places to the left / right (DPP row_shr / row_shl; lanes
+// without a partner multiply by the identity).  The two recursions of the other forms are 2 T - 1 dependent steps (a reciprocal or
+// two on each) that every lane of a group executes alike; here a lane does 6 dependent matrix products, no reciprocal but its own
+// normaliser's, and nothing goes through LDS.
+//   rho_t(1) = alpha_t(1) beta_t(1) / Z_t,   xi_t(a, b) = alpha_t(a) Q_t+1(a, b) / Z_t,   Q_u(a, b) = X_u(a, b) beta_u(b),
+//   Z_t = sum_a alpha_t(a) sum_b Q_t+1(a, b)    -- every lane normalises by ITS Z_t, whatever power of two its products carry:
+// the products are rescaled once, after the second step (entries of a product of 4 periods' matrices: an exact power of two, by
+// the exponent of the largest entry), and only the prefix keeps count of it -- the log-likelihood is the last lane's
+// log(alpha_T-1 . 1) + ln 2 x that count + sum_t m_t.  Every lane adds ITS period's share of the gradients (the transition t -> t + 1,
+// its rho_t g_t, lane 0 the initial state's): the wave sums them anyway.  Same records; the scratch region behind them is not touched.
+struct BlM22 { bl_f2 a, b, c, d; }; // [[a, b], [c, d]], both sites of the pair
+__device__ __forceinline__ BlM22 bl_m22_mul(const BlM22 &L, const BlM22 &R)
+{
+    BlM22 r;
+    r.a = bl_fma2(L.b, R.c, L.a * R.a); r.b = bl_fma2(L.b, R.d, L.a * R.b);
+    r.c = bl_fma2(L.d, R.c, L.c * R.a); r.d = bl_fma2(L.d, R.d, L.c * R.b);
+    return r;
+}
+template <int CTRL> __device__ __forceinline__ float bl_dpp_row(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// the neighbour's value (row_shr / row_shl by CTRL & 15 lanes) where this lane has a partner inside its group, else `id`
+template <int CTRL> __device__ __forceinline__ bl_f2 bl_dpp_or(bl_f2 v, bool has, float id)
+{
+    const float x = bl_dpp_row<CTRL>(v.x), y = bl_dpp_row<CTRL>(v.y);
+    return bl_f2{has ? x : id, has ? y : id};
+}
+template <int CTRL> __device__ __forceinline__ BlM22 bl_m22_dpp_or_identity(const BlM22 &m, bool has)
+{
+    BlM22 r;
+    r.a = bl_dpp_or<CTRL>(m.a, has, 1.0f); r.b = bl_dpp_or<CTRL>(m.b, has, 0.0f);
+    r.c = bl_dpp_or<CTRL>(m.c, has, 0.0f); r.d = bl_dpp_or<CTRL>(m.d, has, 1.0f);
+    return r;
+}
+// m / 2^e with e = the exponent of m's largest entry (per site; exact); returns e as a float (0 for an all-zero matrix)
+__device__ __forceinline__ bl_f2 bl_m22_rescale(BlM22 &m)
+{
+    const bl_f2 mx = __builtin_elementwise_max(__builtin_elementwise_max(m.a, m.b), __builtin_elementwise_max(m.c, m.d));
+    const int ex = mx.x > 0.0f ? __builtin_amdgcn_frexp_expf(mx.x) : 0, ey = mx.y > 0.0f ? __builtin_amdgcn_frexp_expf(mx.y) : 0;
+    auto sc = [&](bl_f2 v) { return bl_f2{__builtin_amdgcn_ldexpf(v.x, -ex), __builtin_amdgcn_ldexpf(v.y, -ey)}; };
+    m.a = sc(m.a); m.b = sc(m.b); m.c = sc(m.c); m.d = sc(m.d);
+    return bl_f2{(float)ex, (float)ey};
+}
+
+template <int KS, int KO, int CT>
+__device__ __forceinline__ void bl_eval_sites_dyn_scan(int ct, int pstride, int cnt, int T, int J, int G,
+                                                       const float (&bpsi)[KS + 1], const float (&bgam)[KS + 1], const float (&beps)[KS + 1],
+                                                       const float (&alpha)[KO + 1],
+                                                       float &ll, float (&gb)[3][KS + 1], float (&ga)[KO + 1])
+{
+    constexpr int XQ = (KS + 3) & ~3;
+    const int pb = bl_period_block(J, KO);
+    const float *data = bl_lds_f(BL_OFF_DATA);
+    const int sub = ct & (G - 1), slot = ct / G, nslots = CT / G; // lane `sub` of group `slot` owns period t = sub
+    const int npairs = (cnt + 1) >> 1;
+    const int rounds = (npairs + nslots - 1) / nslots;
+    const bool is_first = sub == 0, is_last = sub == G - 1;
+    bl_f2 ll2 = bl2(0.0f), gb2[3][KS + 1], ga2[KO + 1];
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+        for (int k = 0; k <= KS; k++) gb2[b][k] = bl2(0.0f);
+#pragma unroll
+    for (int k = 0; k <= KO; k++) ga2[k] = bl2(0.0f);
+    for (int rd = 0; rd < rounds; rd++) {
+        const int m_raw = rd * nslots + slot;
+        const int m = min(m_raw, npairs - 1);
+        const float live = m_raw < npairs ? 1.0f : 0.0f;
+        const float2 *rec = reinterpret_cast<const float2 *>(data + (size_t)m * pstride);
+        const float second = (2 * m + 1 < cnt) ? live : 0.0f; // odd slice: the last pair's second site is a dummy
+        const bl_f2 vm = bl_f2{live, second};
+        bl_f2 x[KS > 0 ? KS : 1];
+        bl_f2 e_psi = bl2(bpsi[0]), e_gam = bl2(bgam[0]), e_eps = bl2(beps[0]);
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            const float2 v = rec[k];
+            x[k] = bl_f2{v.x, v.y};
+            e_psi = bl_fma2(x[k], bl2(bpsi[k + 1]), e_psi);
+            e_gam = bl_fma2(x[k], bl2(bgam[k + 1]), e_gam);
+            e_eps = bl_fma2(x[k], bl2(beps[k + 1]), e_eps);
+        }
+        const bl_f2 gam = bl_sigmoid2(e_gam), eps = bl_sigmoid2(e_eps), psi = bl_sigmoid2(e_psi);
+        // ---- this lane's period: visits (log-likelihood and gradient sums at once), scaled likelihoods ----
+        bl_f2 gt[KO + 1];
+#pragma unroll
+        for (int k = 0; k <= KO; k++) gt[k] = bl2(0.0f);
+        const float2 *pp = rec + XQ + sub * pb;
+        const float2 a_ = pp[J * (KO + 1)], kb_ = pp[J * (KO + 1) + 1];
+        bl_f2 a = bl_f2{a_.x, a_.y};                   // ka: cancels the log sigma(0) of the masked visits
+        const bl_f2 kb = bl_f2{kb_.x, kb_.y};
+#pragma unroll 2
+        for (int j = 0; j < J; j++) {
+            bl_f2 w[KO + 1];
+#pragma unroll
+            for (int k = 0; k <= KO; k++) {
+                const float2 v = pp[j * (KO + 1) + k];
+                w[k] = bl_f2{v.x, v.y};
+            }
+            bl_visit2<KO>(w, alpha, a, gt);
+        }
+        const bl_f2 mm = __builtin_elementwise_max(a, kb);
+        const bl_f2 E1 = bl_exp2_2((a - mm) * bl2(BL_LOG2E)), E0 = bl_exp2_2((kb - mm) * bl2(BL_LOG2E));
+        // ---- this period's matrix: X_0 = diag(L_0), X_t = A diag(L_t) ----
+        BlM22 X;
+        X.a = is_first ? E0 : (bl2(1.0f) - gam) * E0; X.b = is_first ? bl2(0.0f) : gam * E1;
+        X.c = is_first ? bl2(0.0f) : eps * E0;        X.d = is_first ? E1 : (bl2(1.0f) - eps) * E1;
+        // ---- inclusive prefix products P_t = X_0 ... X_t and suffix products S_t = X_t ... X_T-1 over the group's lanes ----
+        BlM22 P = X, S = X;
+        bl_f2 eP = bl2(0.0f);                          // P's true value is P x 2^eP
+#define BL_DYN_SCAN_STEP(s)                                                                          \
+        if (G > (s)) {                                                                               \
+            const bool hl = sub >= (s), hr = sub + (s) < G;                                          \
+            const BlM22 Lp = bl_m22_dpp_or_identity<0x110 + (s)>(P, hl);                             \
+            eP += bl_dpp_or<0x110 + (s)>(eP, hl, 0.0f);                                              \
+            P = bl_m22_mul(Lp, P);                                                                   \
+            const BlM22 Rs = bl_m22_dpp_or_identity<0x100 + (s)>(S, hr);                             \
+            S = bl_m22_mul(S, Rs);                                                                   \
+        }
+        BL_DYN_SCAN_STEP(1)
+        BL_DYN_SCAN_STEP(2)
+        if (G > 4) { eP += bl_m22_rescale(P); (void)bl_m22_rescale(S); }
+        BL_DYN_SCAN_STEP(4)
+#undef BL_DYN_SCAN_STEP
+        // ---- beta_t = (row sums of S_t+1), Q_t+1 = X_t+1 (.) beta_t+1 from the lane to the right; alpha_t = pi P_t ----
+        const bl_f2 rs0 = S.a + S.b, rs1 = S.c + S.d;
+        const bl_f2 be0 = bl_dpp_or<0x101>(rs0, !is_last, 1.0f), be1 = bl_dpp_or<0x101>(rs1, !is_last, 1.0f); // this lane's beta_t
+        BlM22 Qo; // what this lane hands to the left: X_t (.) beta_t, column-wise
+        Qo.a = X.a * be0; Qo.b = X.b * be1; Qo.c = X.c * be0; Qo.d = X.d * be1;
+        const BlM22 Q = bl_m22_dpp_or_identity<0x101>(Qo, !is_last); // Q_t+1 (the last lane: the identity -- beta = 1, no transition)
+        const bl_f2 al0 = bl_fma2(psi, P.c, (bl2(1.0f) - psi) * P.a), al1 = bl_fma2(psi, P.d, (bl2(1.0f) - psi) * P.b);
+        const bl_f2 Z = __builtin_elementwise_max(bl_fma2(al1, Q.c + Q.d, al0 * (Q.a + Q.b)), bl2(1e-37f));
+        const bl_f2 rz = bl_rcp_2(Z);
+        const bl_f2 rho = al1 * (Q.c + Q.d) * rz;      // P(z_t = 1 | y)
+        const bl_f2 t0 = al0 * rz, t1 = al1 * rz;
+        const bl_f2 nx = is_last ? bl2(0.0f) : vm;     // (the last period starts no transition)
+        const bl_f2 d_gam = (t0 * Q.b * (bl2(1.0f) - gam) - t0 * Q.a * gam) * nx;   // xi(0,1)(1 - gamma) - xi(0,0) gamma
+        const bl_f2 d_eps = (t1 * Q.c * (bl2(1.0f) - eps) - t1 * Q.d * eps) * nx;   // xi(1,0)(1 - eps) - xi(1,1) eps
+        const bl_f2 d_psi = is_first ? (rho - psi) * vm : bl2(0.0f);
+        // ---- log-likelihood: every lane its period's scale m_t, the last lane log(alpha_T-1 . 1) and the prefix's power of two ----
+        bl_f2 lown = mm;
+        if (is_last) lown += (bl_log2_2(__builtin_elementwise_max(al0 + al1, bl2(1e-37f))) + eP) * bl2(BL_LN2);
+        ll2 = bl_fma2(lown, vm, ll2);
+        const bl_f2 rt = rho * vm;
+#pragma unroll
+        for (int k = 0; k <= KO; k++) ga2[k] = bl_fma2(rt, gt[k], ga2[k]);
+        const bl_f2 dv[3] = {d_psi, d_gam, d_eps};
 #pragma unroll
         for (int b = 0; b < 3; b++) {
             gb2[b][0] += dv[b];

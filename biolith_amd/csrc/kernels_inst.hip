@@ -56,6 +56,8 @@ static int bl_launch(const char *name, const P *p, int grid, int threads, int ld
 // (BIOLITH_HIP_GENERAL=1: tests / A/B -- the general kernel although a per-form instantiation would serve; draws must not change by a bit:
 // tests/test_gpu_kernel_forms.py)
 static inline bool bl_force_general() { const char *e = getenv("BIOLITH_HIP_GENERAL"); return e && e[0] == '1'; }
+// the dynamic model on one period per lane (JSEL = 1 in a MODEL 8 lane-group kernel: the two-scans form, dyn_device.hpp)
+#define BL_PICK_DYN_SCAN(P, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, 8, CW, true, 1, false>>(BL_KHEAD(bl_nuts_kernel, true, 8, CW) ", true, 1, false>", P, grid, 64 * (CW + 1), lds_bytes, stream)
 #define BL_IS_LEAN(P) (!bl_force_general() && (P)->n_species <= 1 && (P)->k <= 8 * (64 / (P)->nvp))
 #if BL_FORMS_FULL
 #define BL_PICK_GRP_ANY(P, CW) (!BL_IS_LEAN(P) ? BL_PICK_GRP(P, 0, CW) : ((P)->T == 1 && ((P)->lane_grp & 15) == 0) ? BL_PICK_GRP_LEAN_T1(P, 0, CW) : BL_PICK_GRP_LEAN(P, 0, CW))
@@ -114,6 +116,9 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
     if (model == 8) { // dynamic occupancy (dyn_device.hpp): site-covariate capacities up to BL_DYN_MAX_KS
 #if BL_KS <= BL_DYN_MAX_KS
         // (T <= 2 G: the instantiation that carries the scaled-likelihood form alone; else the one with the first form alone)
+        // (one period per lane, T == G: the instantiation that carries the two-scans form alone -- dyn_device.hpp, round 5)
+        if (BL_DYN_SCAN && staged && p->ncw == 3 && p->T == p->lane_grp && p->T > 1) return BL_PICK_DYN_SCAN(p, 3);
+        if (BL_DYN_SCAN && staged && p->ncw == 4 && p->T == p->lane_grp && p->T > 1) return BL_PICK_DYN_SCAN(p, 4);
         if (staged && p->ncw == 3 && p->T <= 2 * p->lane_grp) return BL_PICK_GRP(p, 8, 3);
         if (staged && p->ncw == 4 && p->T <= 2 * p->lane_grp) return BL_PICK_GRP(p, 8, 4);
         if (staged && p->ncw == 3) return BL_PICK(bl_nuts_kernel, p, true, 8, 3);

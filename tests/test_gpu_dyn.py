@@ -41,6 +41,33 @@ def test_dyn_logp_grad_parity(cfg):
     assert np.max(np.abs(Gg - Go)) <= 1e-5 * np.max(np.abs(Go)), np.max(np.abs(Gg - Go)) / np.max(np.abs(Go))
 
 
+@pytest.mark.parametrize("T", [2, 4, 8])
+def test_dyn_two_scans_form(T, monkeypatch):
+    """One period per lane (lanes per pair == periods: dyn_device.hpp bl_eval_sites_dyn_scan, round 5 -- the forward-backward algorithm
+    as a prefix and a suffix scan of 2 x 2 matrices over the group's lanes): K1 at the occu kernel's tolerances, also with missing
+    visits, an odd site count, at coefficients far out (|logit| up to ~12: the products' power-of-two rescaling), and the oracle's
+    first trees."""
+    data, _ = _sim(random_seed=5 + T, n_sites=203, n_periods=T, n_site_covs=2, n_obs_covs=2, simulate_missing=True)
+    monkeypatch.setenv("BIOLITH_HIP_DYN_G", str(T))
+    od, ds = _pair(data)
+    rng = np.random.default_rng(T)
+    th = rng.uniform(-1.5, 1.5, size=(6, od.D))
+    th[4] *= 3.0                      # far out: transition probabilities down to ~1e-5
+    th[5, [0, 3, 6]] = [6.0, -7.0, -7.0]   # psi ~ 1, gamma ~ eps ~ 1e-3
+    th = th.astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.all(np.isfinite(Ug)) and np.all(np.isfinite(Gg))
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= 1e-6, (Ug, Uo)
+    assert np.max(np.abs(Gg - Go) / np.max(np.abs(Go), axis=1, keepdims=True)) <= 1e-5, np.abs(Gg - Go).max(1)
+    o = oracle.nuts_run(od, 0, 4, num_chains=2, seed=T)
+    r = ds.nuts(num_warmup=0, num_samples=4, num_chains=2, seed=T)
+    assert r.kernel_name.rstrip().endswith(", true, 1, false>"), r.kernel_name     # the two-scans instantiation ran
+    assert np.array_equal(o["num_steps"][:, :3], r.num_steps[:, :3]), (o["num_steps"], r.num_steps)
+    assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=2e-3)
+    ds.close()
+
+
 def test_dyn_first_transitions_match_oracle():
     data, _ = _sim(n_sites=200, n_periods=6, random_seed=1)
     od, ds = _pair(data)
