@@ -666,17 +666,19 @@ def main(argv=None):
                     "the sequential-leapfrog latency (us_per_leapfrog_per_chain) is the real bound",
         }
         if name == "occu":
-            # the tick's floor as numbers (in-kernel stamps of the lean kernel, profiles/r04/g_stamps.txt).
-            # The site evaluation (1 527 cycles) is shorter than a leaf tick's decisions (1 688) since round 4, so a leaf tick = decisions + the
-            # hand-off to the chain's other workgroups (ONE L2 round trip of 655 cycles at 1.35 poll rounds + f64 sums and folds: 1 279) + the
-            # speculative position (210) + a barrier: ~3 400 cycles at 2.39 GHz.  What is measured above it is NumPyro's sequential bookkeeping
-            # at subtree and transition ends (an evaluation dropped and redone per transition).
-            roofline["latency_floor_us"] = 1.4
-            roofline["latency_floor_note"] = ("leaf tick from in-kernel stamps of the lean kernel (profiles/r04/g_stamps.txt): decisions 1 688 cycles (the site "
-                                              "evaluation beside them: 1 527) + hand-off through L2 1 279 (one 655-cycle round trip at 1.35 poll rounds + sums) + "
-                                              "speculative position 210 + barrier, at 2.39 GHz; the rest of us_per_leapfrog_per_chain is NumPyro's bookkeeping at "
-                                              "subtree / transition ends; five A/Bs on the tick's protocol in round 4 moved nothing or cost 5 % (profiles/NOTES.md); "
-                                              "the round's gain (2.35 -> 1.99 us) came from per-form / lean instantiations of the kernel")
+            # The tick's floor as numbers, re-derived in round 5 from a variant that took NumPyro's decisions off the
+            # critical path altogether (a gather wave + a decision wave: profiles/r05/b_split_control_waves.patch, b_stamps_split_v*.txt --
+            # bit-identical, 2.48 us): a tick cannot be shorter than the site evaluation (1 605 cycles) + evaluation-complete-to-gathered
+            # (~1 800: store to L2, round alignment, one L2 round trip, skew of the chain's 81 compute waves, f64 sums and folds) +
+            # the next position (210) + the release barrier (~170) = ~3 780 cycles at 2.39 GHz, times 1.137 ticks per leapfrog (one
+            # evaluation is dropped per transition).  The kernel of record is 10 % above it: the part of the decisions at doubling and
+            # transition-end ticks that outlasts the evaluation.
+            roofline["latency_floor_us"] = 1.8
+            roofline["latency_floor_note"] = ("per leapfrog, every decision hidden: site evaluation 1 605 cycles + evaluation-complete-to-gathered ~1 800 (store to L2 "
+                                              "~300, round alignment ~330, one L2 round trip 650-730, skew of 81 compute waves, f64 sums and folds ~200) + next "
+                                              "position 210 + release barrier ~170 = ~3 780 cycles per tick at 2.39 GHz x 1.137 ticks per leapfrog; measured on a "
+                                              "variant with the decisions on a wave of their own (profiles/r05/b_stamps_split_v1.txt, b_ab_split.txt: bit-identical "
+                                              "draws, 2.48 us -- dropped); stamps of the kernel of record: profiles/r05/h_stamps.txt (tick 4 201 cycles)")
         if wl["model"] == "occu_rn":
             # config 4 is VALU-transcendental-bound (about 5 M enumerated (site, visit, n) terms per evaluation,
             # one transcendental each), not HBM-bound.  Peak = quarter-rate transcendental issue of the CUs the launch occupies.
