@@ -268,8 +268,13 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                 const int nitems = __builtin_amdgcn_readlane(P, last - 1) - base;
                 const bool mine = lane >= first && lane < last;
                 const int start = P - nch - base;
-                for (int c = 0; __any(mine && c < nch); c++)
+                // (a site's first three items without a loop -- their stores go out together; more than three: the rare tail)
+#pragma unroll
+                for (int c = 0; c < 3; c++)
                     if (mine && c < nch) imap[start + c] = (unsigned)lane | ((unsigned)c << 8) | ((unsigned)start << 16) | ((unsigned)nch << 24);
+                if (__any(mine && nch > 3))
+                    for (int c = 3; __any(mine && c < nch); c++)
+                        if (mine && c < nch) imap[start + c] = (unsigned)lane | ((unsigned)c << 8) | ((unsigned)start << 16) | ((unsigned)nch << 24);
                 bl_wave_lds_fence(); // (also: the sites' dynamic visit slots are written)
                 const bool item = lane < nitems;
                 const unsigned im = imap[item ? lane : 0];
@@ -435,15 +440,32 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                 }
                 if (multi) {
                     bl_wave_lds_fence();
-                    for (int s = 0; __any(s < nc); s++) m_s = fmaxf(m_s, comb[(st + min(s, nc - 1)) * 4]);
+                    // The first four items of the site (n <= 32: all but one site in two hundred at config 4) are read in ONE go -- four
+                    // float4 loads in flight, then the maximum and the sums from registers; until round 5 every item was a round trip of its
+                    // own in each of two loops (floors + B + combine: 3 809 -> of the 14.7 k-cycle evaluation).  Same order of the sums.
+                    float4 cv[4];
+#pragma unroll
+                    for (int s = 0; s < 4; s++) cv[s] = *reinterpret_cast<const float4 *>(comb + (st + min(s, nc - 1)) * 4);
+                    const bool more = __any(nc > 4);
+#pragma unroll
+                    for (int s = 0; s < 4; s++) m_s = fmaxf(m_s, cv[s].x); // (an item read twice changes no maximum)
+                    if (more)
+                        for (int s = 4; __any(s < nc); s++) m_s = fmaxf(m_s, comb[(st + min(s, nc - 1)) * 4]);
                     f_it = __builtin_amdgcn_exp2f(m_it - m_s);
                     S = 0.0f; a1 = 0.0f;
-                    for (int s = 0; __any(s < nc); s++) { // (fixed order: every item of a site forms the same sums)
-                        const float4 v = *reinterpret_cast<const float4 *>(comb + (st + min(s, nc - 1)) * 4);
-                        const float f = s < nc ? __builtin_amdgcn_exp2f(v.x - m_s) : 0.0f;
-                        S = fmaf(f, v.y, S);
-                        a1 = fmaf(f, v.z, a1);
+#pragma unroll
+                    for (int s = 0; s < 4; s++) { // (fixed order: every item of a site forms the same sums)
+                        const float f = s < nc ? __builtin_amdgcn_exp2f(cv[s].x - m_s) : 0.0f;
+                        S = fmaf(f, cv[s].y, S);
+                        a1 = fmaf(f, cv[s].z, a1);
                     }
+                    if (more)
+                        for (int s = 4; __any(s < nc); s++) {
+                            const float4 v = *reinterpret_cast<const float4 *>(comb + (st + min(s, nc - 1)) * 4);
+                            const float f = s < nc ? __builtin_amdgcn_exp2f(v.x - m_s) : 0.0f;
+                            S = fmaf(f, v.y, S);
+                            a1 = fmaf(f, v.z, a1);
+                        }
                 }
                 if (item && ch == 0) *reinterpret_cast<float4 *>(sres + sl * 4) = make_float4(m_s, S, a1, 0.0f);
                 const float rs = item ? f_it * __builtin_amdgcn_rcpf(S) : 0.0f;
