@@ -59,8 +59,12 @@ static inline bool bl_force_general() { const char *e = getenv("BIOLITH_HIP_GENE
 // the dynamic model on one period per lane (JSEL = 1 in a MODEL 8 lane-group kernel: the two-scans form, dyn_device.hpp)
 #define BL_PICK_DYN_SCAN(P, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, 8, CW, true, 1, false>>(BL_KHEAD(bl_nuts_kernel, true, 8, CW) ", true, 1, false>", P, grid, 64 * (CW + 1), lds_bytes, stream)
 #define BL_IS_LEAN(P) (!bl_force_general() && (P)->n_species <= 1 && (P)->k <= 8 * (64 / (P)->nvp))
+// ... and of one period per lane at four visits each (JSEL = 104: stacked periods, BASELINE.json configs[4]'s stand-in 2 000 x 8 x 4 --
+// the lane's period is straight-line code: 2.56 -> 2.32 us per leapfrog there, profiles/r05/l_ab_stacked_own_period.txt)
+#define BL_PICK_GRP_LEAN_OWN4(P, MODEL, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true, 104, true>>(BL_KHEAD(bl_nuts_kernel, true, MODEL, CW) ", true, 104, true>", P, grid, 64 * (CW + 1), lds_bytes, stream)
+#define BL_GRP_OWN4(P) ((P)->J == 4 && ((P)->lane_grp >> 4) == 0 && (1 << ((P)->lane_grp & 15)) == (P)->T && (P)->T > 1)
 #if BL_FORMS_FULL
-#define BL_PICK_GRP_ANY(P, CW) (!BL_IS_LEAN(P) ? BL_PICK_GRP(P, 0, CW) : ((P)->T == 1 && ((P)->lane_grp & 15) == 0) ? BL_PICK_GRP_LEAN_T1(P, 0, CW) : BL_PICK_GRP_LEAN(P, 0, CW))
+#define BL_PICK_GRP_ANY(P, CW) (!BL_IS_LEAN(P) ? BL_PICK_GRP(P, 0, CW) : ((P)->T == 1 && ((P)->lane_grp & 15) == 0) ? BL_PICK_GRP_LEAN_T1(P, 0, CW) : BL_GRP_OWN4(P) ? BL_PICK_GRP_LEAN_OWN4(P, 0, CW) : BL_PICK_GRP_LEAN(P, 0, CW))
 #else
 #define BL_PICK_GRP_ANY(P, CW) BL_PICK_GRP(P, 0, CW)
 #endif

@@ -760,17 +760,20 @@ __device__ __forceinline__ bl_f2 bl_group_sum2(bl_f2 v, int lg)
 }
 
 // T1: one period (and hence no period lanes) as a compile-time fact -- simulate()'s defaults and the whole benchmark grid
-template <int KS, int KO, int CT, bool FP, bool T1 = false>
-__device__ __forceinline__ void bl_eval_sites_grp(int ct, int pstride, int cnt, int T, int J, int grp, const BlFpScalars fp,
+// JC > 0 with OWNT: J == JC visits per period, no visit lanes, and ONE period per lane (period lanes == periods) as compile-time facts
+// -- stacked periods at a few visits each (2 000 x 8 x 4): the lane's period is straight-line code, its visits unrolled
+template <int KS, int KO, int CT, bool FP, bool T1 = false, int JC = 0, bool OWNT = false>
+__device__ __forceinline__ void bl_eval_sites_grp(int ct, int pstride, int cnt, int T, int J_rt, int grp, const BlFpScalars fp,
                                                   const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                                   float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], float &gphi, int data_off = 0)
 {
     constexpr int XQ = (KS + 3) & ~3;
-    const int lgt = grp & 15, lgj = grp >> 4, lg = lgt + lgj;
+    const int J = JC > 0 ? JC : J_rt;
+    const int lgt = grp & 15, lgj = (JC > 0 && OWNT) ? 0 : grp >> 4, lg = lgt + lgj;
     const int sub = ct & ((1 << lg) - 1), slot = ct >> lg, nslots = CT >> lg;
     const int sub_j = sub & ((1 << lgj) - 1), sub_t = sub >> lgj, Gt = 1 << lgt;
     const int jc = (J + (1 << lgj) - 1) >> lgj;              // visits per chunk
-    const int j0 = min(sub_j * jc, J), j1 = min(j0 + jc, J); // this lane's chunk of every period
+    const int j0 = (JC > 0 && OWNT) ? 0 : min(sub_j * jc, J), j1 = (JC > 0 && OWNT) ? JC : min(j0 + jc, J); // this lane's chunk of every period
     const bl_f2 firstj = bl2(sub_j == 0 ? 1.0f : 0.0f);
     const int pb = bl_period_block(J, KO);
     const float *data = bl_lds_f(BL_OFF_DATA) + data_off;
@@ -808,7 +811,7 @@ __device__ __forceinline__ void bl_eval_sites_grp(int ct, int pstride, int cnt, 
             const float2 a_ = pp[J * (KO + 1)], kb_ = pp[J * (KO + 1) + 1];
             bl_f2 a = bl_f2{a_.x, a_.y} * firstj; // ka once per (site, period)
             bl_f2 gf = bl2(0.0f);                 // FP: d a / d f1 (this lane's visits)
-#pragma unroll 2
+#pragma unroll(JC > 0 && OWNT ? JC : 2)
             for (int j = j0; j < j1; j++) {
                 bl_f2 w[KO + 1];
 #pragma unroll
@@ -862,6 +865,7 @@ __device__ __forceinline__ void bl_eval_sites_grp(int ct, int pstride, int cnt, 
             }
         };
         if constexpr (T1) one_period(0); // (one period, no period lanes: no loop)
+        else if constexpr (OWNT) one_period(sub_t); // (period lanes == periods: this lane's one)
         else for (int t = sub_t; t < T; t += Gt) one_period(t); // (the lanes that fold a period's sums share sub_t, hence this loop's trip count)
         ll2 = bl_fma2(lsite, vmask, ll2);
         if constexpr (FP) gp2 = bl_fma2(gpsite, vmask, gp2);
@@ -1399,7 +1403,9 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
     } else {
         if constexpr (LDS && GRP == 2) {
             float gphi = 0.0f; // (JSEL == 1 in a lane-group kernel: the one-period form)
-            bl_eval_sites_grp<KS, KO, CW * 64, false, JSEL == 1>(ct, ld_or_stride, cnt, T, J, lane_grp, BlFpScalars{}, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
+            // (JSEL > 100 in a lane-group kernel: one period per lane and JSEL - 100 visits per period as compile-time facts)
+            if constexpr (JSEL > 100) bl_eval_sites_grp<KS, KO, CW * 64, false, false, JSEL - 100, true>(ct, ld_or_stride, cnt, T, J, lane_grp, BlFpScalars{}, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
+            else bl_eval_sites_grp<KS, KO, CW * 64, false, JSEL == 1>(ct, ld_or_stride, cnt, T, J, lane_grp, BlFpScalars{}, beta, alpha, ll, gb, ga, gphi, sp * sp_lds);
         } else {
             bool grouped = false;
             if constexpr (LDS && GRP == 1) {

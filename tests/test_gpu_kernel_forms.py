@@ -36,6 +36,8 @@ CASES = {
     "grid_row_4": lambda: (quiet_simulate(n_site_covs=2, n_obs_covs=1, n_sites=1600, deployment_days_per_site=7 * 32, session_duration=7, random_seed=46)[0], {}),
     # lane groups over periods (the lean group form)
     "stacked": lambda: (quiet_simulate(n_sites=600, n_periods=4, n_site_covs=2, n_obs_covs=3, deployment_days_per_site=42, session_duration=7, random_seed=3)[0], {}),
+    # one period per lane at four visits each (the lean own-period group form: BASELINE configs[4]'s stand-in shape)
+    "stacked_8x4": lambda: (quiet_simulate(n_sites=500, n_periods=8, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=28, session_duration=7, random_seed=2)[0], {}),
     # Royle-Nichols: the lean J <= 10 form
     "rn": lambda: (load_golden("rn_small_2x2"), dict(model="occu_rn")),
 }
