@@ -402,13 +402,15 @@ __device__ __forceinline__ bl_f2 bl_m22_rescale(BlM22 &m)
     return bl_f2{(float)ex, (float)ey};
 }
 
-template <int KS, int KO, int CT>
-__device__ __forceinline__ void bl_eval_sites_dyn_scan(int ct, int pstride, int cnt, int T, int J, int G,
+// GC, JC > 0: the lanes per pair (= periods) and the visits per period as compile-time facts (8 and 4: BASELINE.json configs[4])
+template <int KS, int KO, int CT, int GC = 0, int JC = 0>
+__device__ __forceinline__ void bl_eval_sites_dyn_scan(int ct, int pstride, int cnt, int T, int J_rt, int G_rt,
                                                        const float (&bpsi)[KS + 1], const float (&bgam)[KS + 1], const float (&beps)[KS + 1],
                                                        const float (&alpha)[KO + 1],
                                                        float &ll, float (&gb)[3][KS + 1], float (&ga)[KO + 1])
 {
     constexpr int XQ = (KS + 3) & ~3;
+    const int J = JC > 0 ? JC : J_rt, G = GC > 0 ? GC : G_rt;
     const int pb = bl_period_block(J, KO);
     const float *data = bl_lds_f(BL_OFF_DATA);
     const int sub = ct & (G - 1), slot = ct / G, nslots = CT / G; // lane `sub` of group `slot` owns period t = sub
@@ -448,7 +450,7 @@ __device__ __forceinline__ void bl_eval_sites_dyn_scan(int ct, int pstride, int 
         const float2 a_ = pp[J * (KO + 1)], kb_ = pp[J * (KO + 1) + 1];
         bl_f2 a = bl_f2{a_.x, a_.y};                   // ka: cancels the log sigma(0) of the masked visits
         const bl_f2 kb = bl_f2{kb_.x, kb_.y};
-#pragma unroll 2
+#pragma unroll(JC > 0 ? JC : 2)
         for (int j = 0; j < J; j++) {
             bl_f2 w[KO + 1];
 #pragma unroll

@@ -58,6 +58,8 @@ static int bl_launch(const char *name, const P *p, int grid, int threads, int ld
 static inline bool bl_force_general() { const char *e = getenv("BIOLITH_HIP_GENERAL"); return e && e[0] == '1'; }
 // the dynamic model on one period per lane (JSEL = 1 in a MODEL 8 lane-group kernel: the two-scans form, dyn_device.hpp)
 #define BL_PICK_DYN_SCAN(P, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, 8, CW, true, 1, false>>(BL_KHEAD(bl_nuts_kernel, true, 8, CW) ", true, 1, false>", P, grid, 64 * (CW + 1), lds_bytes, stream)
+// ... and with eight periods on eight lanes at four visits each as compile-time facts (JSEL = 2)
+#define BL_PICK_DYN_SCAN84(P, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, 8, CW, true, 2, false>>(BL_KHEAD(bl_nuts_kernel, true, 8, CW) ", true, 2, false>", P, grid, 64 * (CW + 1), lds_bytes, stream)
 #define BL_IS_LEAN(P) (!bl_force_general() && (P)->n_species <= 1 && (P)->k <= 8 * (64 / (P)->nvp))
 // ... and of one period per lane at four visits each (JSEL = 104: stacked periods, BASELINE.json configs[4]'s stand-in 2 000 x 8 x 4 --
 // the lane's period is straight-line code: 2.56 -> 2.32 us per leapfrog there, profiles/r05/l_ab_stacked_own_period.txt)
@@ -121,6 +123,10 @@ extern "C" int BL_NAME(bl_launch_nuts, BL_KS, BL_KO)(const BlNutsParams *p, int 
 #if BL_KS <= BL_DYN_MAX_KS
         // (T <= 2 G: the instantiation that carries the scaled-likelihood form alone; else the one with the first form alone)
         // (one period per lane, T == G: the instantiation that carries the two-scans form alone -- dyn_device.hpp, round 5)
+#if BL_FORMS_FULL
+        if (BL_DYN_SCAN && !bl_force_general() && staged && p->ncw == 3 && p->T == 8 && p->lane_grp == 8 && p->J == 4) return BL_PICK_DYN_SCAN84(p, 3);
+        if (BL_DYN_SCAN && !bl_force_general() && staged && p->ncw == 4 && p->T == 8 && p->lane_grp == 8 && p->J == 4) return BL_PICK_DYN_SCAN84(p, 4);
+#endif
         if (BL_DYN_SCAN && staged && p->ncw == 3 && p->T == p->lane_grp && p->T > 1) return BL_PICK_DYN_SCAN(p, 3);
         if (BL_DYN_SCAN && staged && p->ncw == 4 && p->T == p->lane_grp && p->T > 1) return BL_PICK_DYN_SCAN(p, 4);
         if (staged && p->ncw == 3 && p->T <= 2 * p->lane_grp) return BL_PICK_GRP(p, 8, 3);

@@ -1382,7 +1382,9 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
             // (at most two periods per lane of a group: the one-visit-pass form on scaled likelihoods; else the first form)
             // GRP = 2 (the sampler's instantiation for T <= 2 G): the scaled form alone; 0: the first form alone (any T); 1: both (parity hook)
             // JSEL == 1 (the sampler's instantiation for T == G: one period per lane): the two-scans form alone
-            if constexpr (GRP == 2 && JSEL == 1) bl_eval_sites_dyn_scan<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, lane_grp, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
+            // JSEL == 2: eight periods on eight lanes at four visits each as compile-time facts (BASELINE.json configs[4]: 3.86 -> 3.67 us)
+            if constexpr (GRP == 2 && JSEL == 2) bl_eval_sites_dyn_scan<KS, KO, CW * 64, 8, 4>(ct, ld_or_stride, cnt, T, J, lane_grp, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
+            else if constexpr (GRP == 2 && JSEL == 1) bl_eval_sites_dyn_scan<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, lane_grp, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
             else if constexpr (GRP == 2) bl_eval_sites_dyn_scaled<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, lane_grp, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
             else if constexpr (GRP == 0) bl_eval_sites_dyn<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, lane_grp, rn_off, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
             else if (T == lane_grp && T > 1 && BL_DYN_SCAN) bl_eval_sites_dyn_scan<KS, KO, CW * 64>(ct, ld_or_stride, cnt, T, J, lane_grp, bq[0], bq[1], bq[2], alpha, ll, gq, ga);
