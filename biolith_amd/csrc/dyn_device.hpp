@@ -410,6 +410,7 @@ __device__ __forceinline__ void bl_eval_sites_dyn_scan(int ct, int pstride, int 
                                                        float &ll, float (&gb)[3][KS + 1], float (&ga)[KO + 1])
 {
     constexpr int XQ = (KS + 3) & ~3;
+    constexpr int UNR = JC > 0 ? JC : 2; // the visit loop's unrolling
     const int J = JC > 0 ? JC : J_rt, G = GC > 0 ? GC : G_rt;
     const int pb = bl_period_block(J, KO);
     const float *data = bl_lds_f(BL_OFF_DATA);
@@ -450,7 +451,7 @@ __device__ __forceinline__ void bl_eval_sites_dyn_scan(int ct, int pstride, int 
         const float2 a_ = pp[J * (KO + 1)], kb_ = pp[J * (KO + 1) + 1];
         bl_f2 a = bl_f2{a_.x, a_.y};                   // ka: cancels the log sigma(0) of the masked visits
         const bl_f2 kb = bl_f2{kb_.x, kb_.y};
-#pragma unroll(JC > 0 ? JC : 2)
+#pragma unroll UNR
         for (int j = 0; j < J; j++) {
             bl_f2 w[KO + 1];
 #pragma unroll

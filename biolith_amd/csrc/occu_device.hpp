@@ -760,6 +760,9 @@ __device__ __forceinline__ bl_f2 bl_group_sum2(bl_f2 v, int lg)
 }
 
 // T1: one period (and hence no period lanes) as a compile-time fact -- simulate()'s defaults and the whole benchmark grid
+#ifndef BL_GRP_UNROLL
+#define BL_GRP_UNROLL 2 // visits per iteration of a lane's run-time visit loop (A/B: 4)
+#endif
 // JC > 0 with OWNT: J == JC visits per period, no visit lanes, and ONE period per lane (period lanes == periods) as compile-time facts
 // -- stacked periods at a few visits each (2 000 x 8 x 4): the lane's period is straight-line code, its visits unrolled
 template <int KS, int KO, int CT, bool FP, bool T1 = false, int JC = 0, bool OWNT = false>
@@ -768,6 +771,7 @@ __device__ __forceinline__ void bl_eval_sites_grp(int ct, int pstride, int cnt, 
                                                   float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1], float &gphi, int data_off = 0)
 {
     constexpr int XQ = (KS + 3) & ~3;
+    constexpr int UNR = (JC > 0 && OWNT) ? JC : BL_GRP_UNROLL; // the visit loop's unrolling
     const int J = JC > 0 ? JC : J_rt;
     const int lgt = grp & 15, lgj = (JC > 0 && OWNT) ? 0 : grp >> 4, lg = lgt + lgj;
     const int sub = ct & ((1 << lg) - 1), slot = ct >> lg, nslots = CT >> lg;
@@ -811,7 +815,7 @@ __device__ __forceinline__ void bl_eval_sites_grp(int ct, int pstride, int cnt, 
             const float2 a_ = pp[J * (KO + 1)], kb_ = pp[J * (KO + 1) + 1];
             bl_f2 a = bl_f2{a_.x, a_.y} * firstj; // ka once per (site, period)
             bl_f2 gf = bl2(0.0f);                 // FP: d a / d f1 (this lane's visits)
-#pragma unroll(JC > 0 && OWNT ? JC : 2)
+#pragma unroll UNR
             for (int j = j0; j < j1; j++) {
                 bl_f2 w[KO + 1];
 #pragma unroll
