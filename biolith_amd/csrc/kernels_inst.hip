@@ -20,7 +20,7 @@
 // Per-FORM instantiations of the sampler (JSEL / LEAN / lean lane-group and Royle-Nichols forms: nuts_kernel.hpp) exist for the capacity
 // pairs up to 4 + 4 -- what the reference's own datasets, its benchmark grid and BASELINE.json's configs use; with 8 or 16 covariates on
 // a side the general kernels serve (they carry every form at run time: 3-7 % slower on the shapes a form serves).  20 of the 36
-// translation units are then a third of their former size: the library builds in 3.5 minutes on 8 cores instead of 5.5 and is 36 MB, not 55.
+// translation units are then 40 % smaller: the library builds from scratch in 5 minutes on 8 cores instead of 5.5 (bounded by biolith_hip.o) and is 46 MB, not 55.
 #if BL_KS <= 4 && BL_KO <= 4
 #define BL_FORMS_FULL 1
 #else
