@@ -44,6 +44,15 @@ def main():
                   % (c[16] / n_end, c[17] / n_end, c[18] / n_end))
             for name, n_, cyc in zip(("next leaf of the subtree", "next doubling", "transition end / init"), kn, kc):
                 print(f"    decisions, {name:26s}: {int(n_):7d} ticks ({100 * n_ / max(ticks, 1):4.1f} %), {cyc / max(n_, 1):7.0f} cyc each")
+            # the same counters of a launch that is warm-up only (1000 + 2), subtracted -> the sampling phase alone:
+            # the adaptation's share of a transition's end (dual averaging, Welford moments, window ends) must be gone there
+            rw = ds.nuts(num_warmup=1000, num_samples=2, num_chains=chains, seed=0, wgs_per_chain=k)
+            cw = ds.debug_counters()
+            n_end_w, n_end_s = max(float(cw[13]), 1.0), max(float(c[13] - cw[13]), 1.0)
+            for label, cc, ne in (("warm-up (1000 transitions)", cw, n_end_w), ("sampling (the other 998)", c - cw, n_end_s)):
+                tk = max(float(cc[8]), 1.0)
+                print(f"    {label:28s}: {int(cc[8]):6d} ticks, {cc[:7].sum() / tk:6.0f} cyc per tick; transition end {float(cc[7]) / ne:6.0f} cyc = flush bookkeeping {cc[16] / ne:.0f} | "
+                      f"select/adapt/output {cc[17] / ne:.0f} | new momentum+tree {cc[18] / ne:.0f} | the leaf's own decisions {(float(cc[7]) - cc[16] - cc[17] - cc[18]) / ne:.0f}")
 
 
 if __name__ == "__main__":
