@@ -484,6 +484,14 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     // forms (<= ~3 site pairs per lane) and nmixture (measured: 8.0 -> 7.6 us).  occu_rn's evaluation (sums over N) dominates its tick and the HBM-row form serves huge
     // slices: there the decisions are taken right after the exchange and only the bookkeeping overlaps.
     constexpr bool SPEC = LDS && MODEL != 1;
+    // occu_rn (round 5): speculate where the guess cannot be wrong short of a divergence -- behind an EVEN leaf of a subtree (no U-turn
+    // test is made there and the subtree cannot be full: hmc_util._leaf_idx_to_ckpt_idxs, _iterative_build_subtree) the next leaf is the
+    // next leaf, so its evaluation starts at once and the decisions about the even leaf run beside it; everywhere else the decisions
+    // come first, as before (a dropped occu_rn evaluation costs more than they do).  BL_RN_HYBRID=0: A/B.
+#ifndef BL_RN_HYBRID
+#define BL_RN_HYBRID 1
+#endif
+    constexpr bool HYBRID = BL_RN_HYBRID && LDS && MODEL == 1;
     auto decide = [&]() {
         have_pending = false;
         const double acc = p_acc;
@@ -734,7 +742,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     int run_status = 0;
     while (true) {
         bool redo = false; // the evaluation in flight is not the one the sampler needs next
-        if (SPEC && have_pending) {
+        if ((SPEC || HYBRID) && have_pending) {
             end_deferred(); // (only if the guess at a transition's end happened to be right: otherwise done in the branch below)
             decide();
             // was the position being evaluated right now the one just chosen?  (bit-equal or redo: correctness
@@ -748,7 +756,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             BL_STAMP(0)
         } else if (!SPEC) {
             end_deferred();
-            run_deferred(); // non-speculative form: only the bookkeeping overlaps the evaluation
+            run_deferred(); // non-speculative form (HYBRID: a tick whose decisions came first): only the bookkeeping overlaps the evaluation
             BL_STAMP(0)
         } else {
             end_deferred(); // beside the evaluation of the new transition's first leaf
@@ -790,6 +798,10 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         // shadow of the store -> poll latency: which kind of leaf comes next, the peeked direction bit, and -- when
         // the next doubling starts from the tree's OTHER edge -- the whole position (it does not depend on this leaf).
         spec_ed = epsdir;
+        if constexpr (HYBRID) {
+            // the leaf in flight has index snprop: even and not the subtree's last (which is odd whenever there is more than one leaf)
+            if (!init_pending && (snprop & 1) == 0 && snprop + 1 < (1 << depth)) spec_kind = 1;
+        }
         if constexpr (SPEC) {
             if (!init_pending) {
                 if (snprop + 1 < (1 << depth)) spec_kind = 1;
@@ -945,7 +957,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
             // at once and the tests run beside them (loop head).  A wrong guess costs nothing extra: it happens
             // when a transition ends, and the decisions of that tick outlast a phase A anyway.
             cz_spec = __builtin_nanf("");
-            if constexpr (!SPEC) {
+            if (!SPEC && !(HYBRID && spec_kind != 0 && !timed_out)) {
                 // Long site evaluations (occu_rn; many site pairs per lane): a dropped evaluation would cost more than
                 // the overlap saves, so the decisions are taken here and the compute waves get the decided position.
                 decide();
