@@ -203,6 +203,9 @@ struct BlSpinBound {
 // to publish the corrected one without reading anybody's record in between, so it can be two epochs ahead of a peer that is still
 // reading -- four slots keep those apart (two sufficed while dropped evaluations were not published).
 #define BL_XCHG_SLOTS 4u
+#ifndef BL_COMPUTE_PRIO
+#define BL_COMPUTE_PRIO 3 // s_setprio of the compute waves (not occu_rn's); 0: left at the launch value (A/B)
+#endif
 #ifndef BL_POLL_NB
 #define BL_POLL_NB 2 // batches of 8 polls per lane in flight at once when a chain has more workgroups than one batch covers (A/B: 1 = one after the other)
 #endif
@@ -657,6 +660,12 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     // compute waves' evaluation and the control wave's sampler state as DISJOINT live ranges (one shared loop keeps every
     // loop-carried register of either role alive through the other role's code: spills on both sides).
     if (wave > 0) {
+        // A compute wave that shares its SIMD with the control wave (four or more compute waves: five waves on four SIMDs) is issued ahead
+        // of it: the decisions have slack beside the evaluation, the evaluation has none (s_setprio: 0 ... 3, 0 at launch).  Same box,
+        // priority 0 -> 3: stacked 2.343 -> 2.252 us per leapfrog, dynamic 3.705 -> 3.617, headline 1.976 -> 1.955; occu_rn -- whose
+        // decisions are on the critical path -- 8.34 -> 8.45, and the one-workgroup form (simulate()'s defaults) 1.92 -> 1.96, so not there
+        // (profiles/r05/p_ab_compute_priority.txt).
+        if constexpr (BL_COMPUTE_PRIO > 0 && MODEL != 1 && multi_wg) __builtin_amdgcn_s_setprio(BL_COMPUTE_PRIO);
         unsigned epoch_c = 0;  // evaluations so far = the exchange epoch of the one in flight (the control wave counts the same)
         while (true) {
             // The loop control of this tick (run status, "the exchange is L2-local") is read in ONE ds_read_b64 that is issued here
