@@ -18,6 +18,12 @@ with contextlib.redirect_stdout(io.StringIO()):
     sets.append(("occu_re", OccuDataset(d["site_covs"], d["obs_covs"], d["obs"], model="occu_re", site_random_effects=True)))
     d, _ = simulate(n_species=2, n_sites=1000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7, site_random_effects=True)
     sets.append(("occu_re 2 species", OccuDataset(d["site_covs"], d["obs_covs"], d["obs"], model="occu_re", site_random_effects=True)))
+    from biolith_amd.models import simulate_rn
+    d, _ = simulate_rn(n_sites=5000, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=70, session_duration=7)
+    sets.append(("occu_rn", OccuDataset(d["site_covs"], d["obs_covs"], d["obs"], model="occu_rn")))      # config 4: speculation behind even leaves
+    d, _ = simulate(n_sites=2000, n_periods=8, n_site_covs=3, n_obs_covs=3, deployment_days_per_site=28, session_duration=7)
+    sets.append(("occu", OccuDataset(d["site_covs"], d["obs_covs"], d["obs"])))                           # 2 000 x 8 x 4: one period per lane
+    sets.append(("occu_dyn", OccuDataset(d["site_covs"], d["obs_covs"], d["obs"], model="occu_dyn")))    # the two-scans form
 while time.time() - t0 < budget:
     name, ds = sets[n % len(sets)]
     C = int(rng.choice([1, 2, 4, 8, 16] if name == "occu" else [1, 2, 4]))
@@ -25,4 +31,4 @@ while time.time() - t0 < budget:
     assert np.all(np.isfinite(r.draws)), (name, C)
     n += 1
     leap += int(r.n_leapfrog.sum())
-print(f"soak: {n} launches, {leap} leapfrogs, {time.time() - t0:.0f} s, no exchange timed out")
+print(f"soak: {len(sets)} datasets, {n} launches, {leap} leapfrogs, {time.time() - t0:.0f} s, no exchange timed out")
