@@ -22,8 +22,7 @@ def prior_predictive(rng, model, n_sites, n_visits, ks, ko, n_periods=1, missing
     [beta_0 .. beta_ks, alpha_0 .. alpha_ko | logit(prob_fp) or log(rate_fp)] (a rank is invariant under the monotone maps); kwargs =
     what oracle.OracleData / engine.OccuDataset need beyond the arrays.  Priors are the reference's defaults: Normal(0, 1) coefficients,
     Beta(2, 5) false-positive probability (occu.py:32-33), Exponential(1) false-positive rate (occu_cop.py:32-33).
-    (The random-effects models are left out on purpose: their centred effects ~ Normal(0, sd), sd ~ HalfNormal(1) are a funnel that NUTS --
-    numpyro's as much as this one -- samples with a bias where sd is small, and calibration under the PRIOR visits that region.)"""
+    (Random effects: prior_predictive_re below.)"""
     beta, alpha = rng.normal(size=ks + 1), rng.normal(size=ko + 1)
     X = rng.normal(size=(n_sites, ks))
     W = rng.normal(size=(n_sites, n_periods, n_visits, ko))
@@ -76,6 +75,37 @@ def prior_predictive(rng, model, n_sites, n_visits, ks, ko, n_periods=1, missing
             raise ValueError(model)
     Y[rng.uniform(size=Y.shape) < missing] = np.nan
     return X.astype(np.float32), W.astype(np.float32), Y[None].astype(np.float32), np.concatenate(parts), kw
+
+
+def prior_predictive_re(rng, n_sites, n_visits, ks, ko, site_re=True, obs_re=False, missing=0.1):
+    """occu with random effects (occu.py:167-171, 190-215): sd ~ HalfNormal(1), site effects on both linear predictors, observation
+    effects on the detection's.  theta = [beta, alpha | log site_re_sd | log obs_re_sd |
+    site_re_occ [N] | site_re_det [N] | obs_re [N][1][J]]."""
+    beta, alpha = rng.normal(size=ks + 1), rng.normal(size=ko + 1)
+    X = rng.normal(size=(n_sites, ks))
+    W = rng.normal(size=(n_sites, 1, n_visits, ko))
+    parts, tail = [beta, alpha], []
+    re_occ = re_det = np.zeros(n_sites)
+    re_obs = np.zeros((n_sites, 1, n_visits))
+
+    def half_normal():
+        return abs(rng.normal())
+
+    if site_re:
+        sd = half_normal()
+        parts.append(np.array([np.log(sd)]))
+        re_occ, re_det = rng.normal(size=n_sites) * sd, rng.normal(size=n_sites) * sd
+        tail += [re_occ, re_det]
+    if obs_re:
+        sdo = half_normal()
+        parts.append(np.array([np.log(sdo)]))
+        re_obs = rng.normal(size=re_obs.shape) * sdo
+        tail.append(re_obs.reshape(-1))
+    z = (rng.uniform(size=(n_sites, 1)) < _sigmoid(beta[0] + X @ beta[1:] + re_occ)[:, None])[:, :, None]
+    Y = ((rng.uniform(size=re_obs.shape) < _sigmoid(alpha[0] + W @ alpha[1:] + re_det[:, None, None] + re_obs)) & z) * 1.0
+    Y[rng.uniform(size=Y.shape) < missing] = np.nan
+    kw = dict(model="occu_re", site_random_effects=site_re, obs_random_effects=obs_re)
+    return X.astype(np.float32), W.astype(np.float32), Y[None].astype(np.float32), np.concatenate(parts + tail), kw
 
 
 def rank_of_truth(draws, theta, thin, keep=None):
