@@ -66,3 +66,14 @@ def test_header_is_plain_c():
     hdr = os.path.join(ROOT, "include", "biolith_hip.h")
     r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_library_in_tree_was_linked_from_the_sources_in_tree():
+    """``__graft_entry__.build()`` skips ``make`` for a library whose stamp holds the hash of the current sources (the object files do not
+    travel to a GPU box): a stamp that is present must therefore BE that hash -- an edited kernel with a stale library fails here."""
+    import __graft_entry__ as entry
+
+    stamp = os.path.join(ROOT, "biolith_amd", "lib", "build_stamp.txt")
+    if not os.path.exists(stamp):
+        pytest.skip("no stamp: the library was built by `make` directly; build() will run make")
+    assert open(stamp).read().strip() == entry._sources_digest()
