@@ -4,9 +4,10 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 import this package.  The product (``biolith_amd``) never does; it fails loudly when its HIP
 library is missing instead of falling back to anything in here.
 
-Parity status (see ``occu_oracle.c`` header and DESIGN.md): the log-density and the sampler are
-"parity unpinned" (the reference pins no numbers for them and numpyro/jax cannot be installed);
-the simulator is pinned bit-exactly by ``tests/golden``.
+Parity status (see ``occu_oracle.c`` header and DESIGN.md section 3): the log-densities are PINNED to values the reference's own
+model functions produced (``tests/golden/reference_logjoint_*.json``, made by ``tests/golden/make_reference_logjoint.py``) and the
+simulators bit for bit (``tests/golden/make_golden.py``); the sampler is "parity unpinned" against numpyro's trees (numpyro / jax cannot
+be installed) and is held to the distribution it must sample instead (``tests/quadrature.py``, ``tests/sbc.py``).
 """
 from .oracle import (  # noqa: F401
     OracleData,
