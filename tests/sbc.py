@@ -6,8 +6,9 @@ exactly, for every coordinate and every data size -- a property of the MODEL, so
 numpyro: a sampler that targets anything but the posterior of the generative model below (wrong mask rule, a transposed plate, a
 biased transition, a step size adapted past the end of warm-up ...) bends the ranks' histogram.  The generative models are the
 reference's (biolith/models/occu.py:136-242: psi per site, z per (site, period), y ~ Bernoulli(z p); occu_rn.py:123-222:
-N ~ Poisson(lambda) truncated at max_abundance, y ~ Bernoulli(1 - (1 - r)^N); nmixture.py:150-220: y ~ Binomial(N, p)), priors
-Normal(0, 1) on every coefficient (their defaults).
+N ~ Poisson(lambda) truncated at max_abundance and renormalised, y ~ Bernoulli(1 - (1 - r)^N); nmixture.py:150-220: N ~ Poisson(lambda)
+-- its `numpyro.factor` undoes the renormalisation, max_abundance is only the bound of the sum --, y ~ Binomial(N, p)), priors Normal(0, 1)
+on every coefficient (their defaults) unless a test narrows one and says so.
 """
 import numpy as np
 from scipy.stats import chi2
@@ -17,17 +18,18 @@ def _sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
 
 
-def prior_predictive(rng, model, n_sites, n_visits, ks, ko, n_periods=1, missing=0.1, max_abundance=100, fp=None):
+def prior_predictive(rng, model, n_sites, n_visits, ks, ko, n_periods=1, missing=0.1, max_abundance=100, fp=None, beta_scale=1.0):
     """-> (site_covs, obs_covs, obs, theta, kwargs): theta drawn from the prior, in the flat UNCONSTRAINED layout of the oracle / engine
     [beta_0 .. beta_ks, alpha_0 .. alpha_ko | logit(prob_fp) or log(rate_fp)] (a rank is invariant under the monotone maps); kwargs =
     what oracle.OracleData / engine.OccuDataset need beyond the arrays.  Priors are the reference's defaults: Normal(0, 1) coefficients,
     Beta(2, 5) false-positive probability (occu.py:32-33), Exponential(1) false-positive rate (occu_cop.py:32-33).
     (Random effects: prior_predictive_re below.)"""
-    beta, alpha = rng.normal(size=ks + 1), rng.normal(size=ko + 1)
+    beta, alpha = rng.normal(size=ks + 1) * beta_scale, rng.normal(size=ko + 1)
     X = rng.normal(size=(n_sites, ks))
     W = rng.normal(size=(n_sites, n_periods, n_visits, ko))
     if model == "occu_dyn":   # the builder's dynamic model (oracle.literal_log_joint_dyn): theta = [beta_psi | beta_gamma | beta_eps | alpha]
         assert fp is None
+        assert beta_scale == 1.0
         bg, be = rng.normal(size=ks + 1), rng.normal(size=ks + 1)
         psi, gam, eps = (_sigmoid(b[0] + X @ b[1:]) for b in (beta, bg, be))
         z = np.empty((n_sites, n_periods), dtype=bool)
@@ -37,7 +39,7 @@ def prior_predictive(rng, model, n_sites, n_visits, ks, ko, n_periods=1, missing
         Y = ((rng.uniform(size=W.shape[:3]) < _sigmoid(alpha[0] + W @ alpha[1:])) & z[:, :, None]) * 1.0
         Y[rng.uniform(size=Y.shape) < missing] = np.nan
         return X.astype(np.float32), W.astype(np.float32), Y[None].astype(np.float32), np.concatenate([beta, bg, be, alpha]), dict(model="occu_dyn")
-    parts, kw = [beta, alpha], {}
+    parts, kw = [beta, alpha], dict(prior_beta=(0.0, float(beta_scale)))
     fp_c = fp_u = 0.0
     if fp is not None:
         v = rng.exponential() if model == "occu_cop" else rng.beta(2.0, 5.0)
@@ -60,13 +62,21 @@ def prior_predictive(rng, model, n_sites, n_visits, ks, ko, n_periods=1, missing
         assert n_periods == 1 and fp is None
         kw["max_abundance"] = max_abundance
         p = _sigmoid(nu)
-        # truncated Poisson, as the reference states it: Categorical(logits = Poisson(lambda).log_prob(0 .. K))
-        from scipy.special import gammaln
-        n = np.arange(max_abundance + 1)
-        logits = n[None, :] * eta[:, None] - gammaln(n + 1.0)[None, :]
-        pmf = np.exp(logits - logits.max(1, keepdims=True))
-        cdf = np.cumsum(pmf / pmf.sum(1, keepdims=True), axis=1)
-        N = np.minimum((rng.uniform(size=n_sites)[:, None] > cdf).sum(1), max_abundance)
+        if model == "occu_rn":
+            # truncated Poisson, as the reference states it (utils/distributions.py:6-40): Categorical(logits = Poisson(lambda).log_prob(0 .. K))
+            from scipy.special import gammaln
+            n = np.arange(max_abundance + 1)
+            logits = n[None, :] * eta[:, None] - gammaln(n + 1.0)[None, :]
+            pmf = np.exp(logits - logits.max(1, keepdims=True))
+            cdf = np.cumsum(pmf / pmf.sum(1, keepdims=True), axis=1)
+            N = np.minimum((rng.uniform(size=n_sites)[:, None] > cdf).sum(1), max_abundance)
+        else:
+            # nmixture.py:183-194 adds the Categorical's normaliser back (numpyro.factor): the density is p(theta) sum_{N <= K} Poisson(N;
+            # lambda) Binomial(y | N, p) = the joint of theta, y AND the event "every N <= K" under N ~ Poisson(lambda) untruncated.  Its
+            # posterior is therefore the one given y and that event: a replication with some N > K is rejected and drawn again, whole.
+            N = rng.poisson(np.minimum(np.exp(eta), 1e6))
+            if N.max() > max_abundance:
+                return prior_predictive(rng, model, n_sites, n_visits, ks, ko, n_periods, missing, max_abundance, fp, beta_scale)
         if model == "occu_rn":
             Y = (rng.uniform(size=p.shape) < 1.0 - (1.0 - p) ** N[:, None, None]) * 1.0
         elif model == "nmixture":
