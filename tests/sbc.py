@@ -48,7 +48,10 @@ def prior_predictive(rng, model, n_sites, n_visits, ks, ko, n_periods=1, missing
     eta = beta[0] + X @ beta[1:]
     nu = alpha[0] + W @ alpha[1:]                                       # (N, T, J)
     kw["model"] = {"occu": "occu_fp" if fp else "occu"}.get(model, model)
-    if fp or model == "occu_cop":
+    if model == "occu_rn":
+        if fp:
+            kw["re_fp_mode"] = fp
+    elif fp or model == "occu_cop":
         kw["fp_mode"] = fp
     if model in ("occu", "occu_cop"):
         z = (rng.uniform(size=(n_sites, n_periods)) < _sigmoid(eta)[:, None])[:, :, None] * 1.0
@@ -59,7 +62,7 @@ def prior_predictive(rng, model, n_sites, n_visits, ks, ko, n_periods=1, missing
             Y = rng.poisson(dur * (z * np.exp(nu) + (1.0 - z) * fp_u + fp_c)) * 1.0
             kw["session_duration"] = dur.astype(np.float32)
     else:
-        assert n_periods == 1 and fp is None
+        assert n_periods == 1 and (fp is None or (model == "occu_rn" and fp == "constant"))   # occu_rn.py:135-137, 216-219
         kw["max_abundance"] = max_abundance
         p = _sigmoid(nu)
         if model == "occu_rn":
@@ -78,7 +81,7 @@ def prior_predictive(rng, model, n_sites, n_visits, ks, ko, n_periods=1, missing
             if N.max() > max_abundance:
                 return prior_predictive(rng, model, n_sites, n_visits, ks, ko, n_periods, missing, max_abundance, fp, beta_scale)
         if model == "occu_rn":
-            Y = (rng.uniform(size=p.shape) < 1.0 - (1.0 - p) ** N[:, None, None]) * 1.0
+            Y = (rng.uniform(size=p.shape) < 1.0 - (1.0 - p) ** N[:, None, None] * (1.0 - fp_c)) * 1.0
         elif model == "nmixture":
             Y = rng.binomial(N[:, None, None], p) * 1.0
         else:

@@ -41,6 +41,8 @@ def _engine_posterior(model, k, divergences, kernels, warmup=300, samples=250):
     ("occu", 100, 0, dict(SHAPE, n_sites=2000, n_periods=8, n_visits=4, ks=3, ko=3)),   # config 5's stand-in shape: one period per lane
     ("occu_rn", 200, 0, dict(SHAPE, n_sites=60)),
     ("occu_rn", 60, 0, dict(SHAPE, n_sites=1500, n_visits=10, ks=3, ko=3)),              # several workgroups per chain
+    # (occu_rn with a false-positive probability -- the random-effects kernel's Royle-Nichols kind -- is calibrated too, at 200 replications and
+    #  two seeds; at 6 minutes a run it is kept out of the suite: profiles/r05/s_gpu_sbc_rn_false_positives.txt, sbc.prior_predictive(fp="constant"))
     ("nmixture", 200, 0, dict(SHAPE, beta_scale=0.7)),   # (prior_beta = Normal(0, 0.7) on both sides: few replications reach the sum's bound K = 100 and are redrawn, tests/sbc.py)
     ("occu_dyn", 300, 0, dict(SHAPE, n_sites=80, n_periods=4, n_visits=3)),      # (no reference counterpart: the builder's model)
     ("occu_dyn", 200, 0, dict(SHAPE, n_sites=200, n_periods=8, n_visits=4, ks=0)),  # the two-scans form: one period per lane
