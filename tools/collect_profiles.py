@@ -20,12 +20,14 @@ def main():
             print(f"{pre}_{b}")
 
     if not only or "occu" in only:
-        cp(os.path.join(src, "bench.json"), "bench.json")
+        cp(os.path.join(src, "bench.json"), "bench.json")            # the compact line the driver reads
+        cp(os.path.join(src, "bench_full.json"), "bench_full.json")  # the verbose record beside it
     for wl, sfx in short.items():
         if only and wl not in only:
             continue
         if wl != "occu":
             cp(os.path.join(src, f"bench_{wl}.json"), f"bench{sfx}.json")
+            cp(os.path.join(src, f"bench_full_{wl}.json"), f"bench_full{sfx}.json")
         cp(os.path.join(src, f"bench_{wl}_under_rocprof.json"), f"bench{sfx}_under_rocprof.json")
         # (gpurun MERGES into an existing directory: the newest file is this run's)
         for f in sorted(glob.glob(os.path.join(src, f"stats_{wl}", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1:]:

@@ -7,9 +7,9 @@ LIGHT=${LIGHT:-0}
 OUT=${1:-gpurun_out/refresh}
 mkdir -p "$OUT"
 ROOT=$(pwd)
-python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench (default: headline + secondary) rc=$?"
+python bench.py --full-out "$OUT/bench_full.json" > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench (default: headline + secondary) rc=$?"
 for wl in occu_rn occu_re occu_stacked occu_dyn occu_cfg1; do
-  python bench.py --workload $wl --steps 3 --no-e2e > "$OUT/bench_$wl.json" 2> "$OUT/bench_$wl.err"; echo "bench $wl rc=$?"
+  python bench.py --workload $wl --steps 3 --no-e2e --full-out "$OUT/bench_full_$wl.json" > "$OUT/bench_$wl.json" 2> "$OUT/bench_$wl.err"; echo "bench $wl rc=$?"
 done
 if [ "$LIGHT" != 1 ]; then
 python tools/time_models.py > "$OUT/time_models.txt" 2>&1
@@ -26,11 +26,11 @@ if [ -f biolith_amd/lib/libbiolith_hip_stamps.so ]; then
   for m in occu_stacked occu_dyn; do python tools/stamps_model.py $m; done > "$OUT/stamps_models.txt" 2>&1
 fi
 # the scaled CPU baselines validated once: the oracle's own (short) sampler run beside the scaled estimate (minutes)
-python bench.py --workload occu_rn --steps 2 --no-e2e --cpu-baseline > "$OUT/cpu_baseline_validation_rn.json" 2> "$OUT/cpu_baseline_validation_rn.err"; echo "cpu baseline validation rc=$?"
+python bench.py --workload occu_rn --steps 2 --no-e2e --cpu-baseline --full-line > "$OUT/cpu_baseline_validation_rn.json" 2> "$OUT/cpu_baseline_validation_rn.err"; echo "cpu baseline validation rc=$?"
 fi
 cd /tmp && export TMPDIR=/tmp
 for wl in occu occu_rn occu_re occu_stacked occu_dyn occu_cfg1; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_$wl" -- python3 "$ROOT/bench.py" --workload $wl --steps 3 --no-cpu-baseline --no-e2e --no-secondary --no-live-pmc > "$ROOT/$OUT/bench_${wl}_under_rocprof.json" 2> "$ROOT/$OUT/stats_$wl.err"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/stats_$wl" -- python3 "$ROOT/bench.py" --workload $wl --steps 3 --no-cpu-baseline --no-e2e --no-secondary --no-live-pmc --full-line > "$ROOT/$OUT/bench_${wl}_under_rocprof.json" 2> "$ROOT/$OUT/stats_$wl.err"
   echo "stats $wl rc=$?"
 done
 cd "$ROOT"
