@@ -124,7 +124,7 @@ def compact_line(out, full_path=None):
                                       "vs_baseline", "dtype", "data", "rccl_world", "gather_hung") if k in out}
     line["metric"] = _short(line.get("metric", ""), 160)
     line["config"] = {k: (_short(cfg[k], 200 if k == "workload" else 120) if isinstance(cfg[k], str) else cfg[k])
-                      for k in ("workload", "chains_per_gpu", "total_chains", "num_warmup", "num_samples", "parallelism", "wgs_per_chain", "gather")
+                      for k in ("workload", "chains_per_gpu", "total_chains", "num_warmup", "num_samples", "parallelism", "wgs_per_chain", "gather", "env_overrides")
                       if k in cfg}
     line["roofline"] = {k: (_short(rf[k]) if isinstance(rf[k], str) else _num(rf[k]))
                         for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_gradient_evaluation",
@@ -848,6 +848,7 @@ def main(argv=None):
                 "chains_per_gpu": NCH, "total_chains": NCH * world,
                 "num_warmup": NUM_WARMUP, "num_samples": NUM_SAMPLES, "parallelism": f"chains x{world} (1 process per GPU)",
                 "wgs_per_chain": res0.wgs_per_chain, "lds_bytes_per_wg": res0.lds_bytes, "lds_staged": res0.lds_staged,
+                "env_overrides": res0.env_overrides,   # BIOLITH_HIP_* knobs set at the launch ("" = none)
                 "lanes_per_site_pair": {"period_lanes": res0.lane_group[0], "visit_lanes": res0.lane_group[1]},
                 "gather": (f"bl_gather_draws: one ncclAllGather of {world} result blocks (RCCL {rccl_version()}), communicator init "
                            f"{comm.init_ms:.0f} ms outside the timed region") if comm is not None else

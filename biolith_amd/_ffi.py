@@ -68,6 +68,7 @@ EXPORTS = (
     "bl_nuts_geometry", "bl_nuts_lane_group", "bl_nuts_kernel_name", "bl_nuts_debug_counters", "bl_deterministic", "bl_predict", "bl_predict_counts", "bl_predict_scores", "bl_dataset_create_fp", "bl_dataset_create_cop", "bl_dataset_create_nmix", "bl_dataset_create_re", "bl_dataset_create_re_fp", "bl_dataset_create_nmix_re", "bl_dataset_create_rn_re", "bl_dataset_create_rn_fp", "bl_dataset_create_cop_re", "bl_dataset_create_cs", "bl_dataset_set_prior_family", "bl_rng_streams", "bl_adaptation_schedule",
     "bl_comm_rccl_version", "bl_comm_unique_id", "bl_comm_init_rank", "bl_comm_init_all", "bl_comm_info", "bl_comm_destroy",
     "bl_gather_draws", "bl_result_block_layout", "bl_gather_unpack", "bl_host_alloc", "bl_host_free",
+    "bl_nuts_env_overrides", "bl_env_overrides",
 )
 
 _lib = None
@@ -132,6 +133,8 @@ def load():
         L.bl_nuts_geometry.argtypes = [vp, ip, ip, ip, ip, ip]
         L.bl_nuts_lane_group.argtypes = [vp, ip, ip]
         L.bl_nuts_kernel_name.argtypes = [vp, C.c_char_p, C.c_int]
+        L.bl_nuts_env_overrides.argtypes = [vp, C.c_char_p, C.c_int]
+        L.bl_env_overrides.argtypes = [C.c_char_p, C.c_int]
         L.bl_nuts_debug_counters.argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
         L.bl_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
         L.bl_host_free.argtypes = [C.c_void_p]

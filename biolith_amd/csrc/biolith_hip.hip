@@ -205,6 +205,7 @@ struct bl_dataset {
     bool in_flight = false, have_run = false;
     int C = 0, S = 0, W = 0, k = 0, nloc = 0, lds_ld = 0, lds_bytes = 0, staged = 0, nvp = 0, ncw = 0, lane_grp = 0;
     char kernel_name[160] = {0}; // the sampler instantiation of the last launch, as rocprofv3 names it
+    char env_overrides[512] = {0}; // BIOLITH_HIP_* knobs that were set when the last launch read the environment (bl_env_snapshot)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *d_run = nullptr;  // one slab for all run buffers
@@ -220,6 +221,58 @@ struct bl_dataset {
     size_t xchg_bytes = 0;
     int *h_abort = nullptr, *d_abort = nullptr;
 };
+
+
+// ------------------------------------------------------------------------------------------ environment knobs ----
+// Every environment variable the launch path looks at, in ONE table (INTEGRATION.md lists them with their meaning).  None is needed in
+// production: they force a geometry or a kernel form for tests, A/B runs and measurement.  They are read in ONE place --
+// bl_env_snapshot(), at the top of the public entries that can reach one (dataset creation, bl_logp_grad, bl_nuts_launch) -- so a launch
+// sees one consistent set, and bl_env_overrides() / bl_nuts_env_overrides() report the ones that were set (bench.py prints them: a
+// stray variable must not change a geometry silently).  A snapshot per entry rather than per process: the parity tests switch forms
+// between two launches of one process (tests/test_gpu_kernel_forms.py, test_gpu_re.py).
+#define BL_ENV_TABLE(X) X(DYN_G) X(GRP_VISITS) X(OCCU_G) X(OCCU_GT) X(SINGLE) X(CWAVES) X(NO_WIDE) X(RN_K) X(WIDE_K) X(NMIX_LDS) X(RE_EFF) \
+    X(RE_NO_SPLIT) X(RE_LDS_ROWS) X(RE_LDS_TIER) X(RE_WGS) X(NO_LOCAL) X(PITCH) X(GRP_KERNEL) X(SPIN_US) X(POLL_SLEEP) X(FIRST_DELAY) X(GENERAL)
+enum bl_env_knob {
+#define X(n) BL_ENV_##n,
+    BL_ENV_TABLE(X)
+#undef X
+    BL_ENV_COUNT
+};
+static const char *const BL_ENV_NAMES[BL_ENV_COUNT] = {
+#define X(n) "BIOLITH_HIP_" #n,
+    BL_ENV_TABLE(X)
+#undef X
+};
+struct bl_env_config {
+    bool set[BL_ENV_COUNT] = {};
+    char val[BL_ENV_COUNT][32] = {};
+};
+static bl_env_config g_env;
+static void bl_env_snapshot()
+{
+    for (int i = 0; i < BL_ENV_COUNT; i++) {
+        const char *e = getenv(BL_ENV_NAMES[i]);
+        g_env.set[i] = e != nullptr;
+        snprintf(g_env.val[i], sizeof g_env.val[i], "%s", e ? e : "");
+    }
+}
+// the knob's value at the last snapshot, or NULL when it was not set
+static const char *bl_env(bl_env_knob k) { return g_env.set[k] ? g_env.val[k] : nullptr; }
+static std::string bl_env_active()
+{
+    std::string out;
+    for (int i = 0; i < BL_ENV_COUNT; i++)
+        if (g_env.set[i]) out += (out.empty() ? "" : ",") + std::string(BL_ENV_NAMES[i]) + "=" + g_env.val[i];
+    return out;
+}
+extern "C" int bl_env_force_general(void) { const char *e = bl_env(BL_ENV_GENERAL); return e && e[0] == '1'; } // (kernels_inst.hip)
+extern "C" int bl_env_overrides(char *buf, int n)
+{
+    if (!buf || n <= 0) return bl_fail(BL_ERR_INVALID, "NULL argument");
+    bl_env_snapshot();
+    snprintf(buf, (size_t)n, "%s", bl_env_active().c_str());
+    return BL_OK;
+}
 
 static int set_device(const bl_dataset *ds)
 {
@@ -672,6 +725,7 @@ static int dataset_create_impl(const ModelOpts &mo, const bl_dims *dims, const f
 {
     const int model = mo.model, max_abundance = mo.max_abundance;
     if (!dims || !out) return bl_fail(BL_ERR_INVALID, "dims/out is NULL");
+    bl_env_snapshot();
     *out = nullptr;
     const int S = dims->n_species, N = dims->n_sites, T = dims->n_periods, J = dims->n_replicates;
     const int Ks = dims->n_site_covs, Ko = dims->n_obs_covs;
@@ -928,7 +982,7 @@ static int dyn_lanes_per_pair(const bl_dataset *ds, int chains)
     int G = 1;
     while (2 * G <= 8 && 2 * G <= ds->dims.n_periods) G *= 2;
     while (G > 1 && npairs * G > (long long)kmax * 4 * 64) G >>= 1; // (round 4: up to four compute waves per workgroup)
-    if (const char *e = getenv("BIOLITH_HIP_DYN_G")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) G = v; } // A/B knob
+    if (const char *e = bl_env(BL_ENV_DYN_G)) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) G = v; } // A/B knob
     return G;
 }
 
@@ -950,16 +1004,16 @@ static int occu_lane_group(const bl_dataset *ds, int chains, int want_k, int kca
     if (kcap > 0) kmax = kcap; // (wide geometry: the chain's workgroups span XCDs -- the lanes of up to 256 / chains workgroups)
     if (want_k > 0) kmax = std::min(kmax, want_k);
     int target = BL_GRP_VISITS;
-    if (const char *e = getenv("BIOLITH_HIP_GRP_VISITS")) { const int v = atoi(e); if (v >= 1) target = v; } // A/B knob
+    if (const char *e = bl_env(BL_ENV_GRP_VISITS)) { const int v = atoi(e); if (v >= 1) target = v; } // A/B knob
     int lg = 0;
     while (lg < 4 && ((V + (1 << lg) - 1) >> lg) > target && (npairs << (lg + 1)) <= (long long)kmax * 4 * 64) lg++;
-    if (const char *e = getenv("BIOLITH_HIP_OCCU_G")) { // tests / A/B: force the lanes per pair (1, 2, 4, 8, 16)
+    if (const char *e = bl_env(BL_ENV_OCCU_G)) { // tests / A/B: force the lanes per pair (1, 2, 4, 8, 16)
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) { lg = 0; while ((1 << lg) < v) lg++; }
     }
     int lgt = 0;
     while (lgt < lg && (2 << lgt) <= T) lgt++;
-    if (const char *e = getenv("BIOLITH_HIP_OCCU_GT")) { const int v = atoi(e); if (v >= 0 && v <= lg) lgt = v; } // tests: log2 of the period lanes
+    if (const char *e = bl_env(BL_ENV_OCCU_GT)) { const int v = atoi(e); if (v >= 0 && v <= lg) lgt = v; } // tests: log2 of the period lanes
     int lgj = lg - lgt;
     while (lgj > 0 && (1 << (lgj - 1)) >= J) lgj--; // (visit lanes beyond a period's visits would only idle)
     return lgt | (lgj << 4);
@@ -972,20 +1026,20 @@ static int occu_lane_group(const bl_dataset *ds, int chains, int want_k, int kca
 static int occu_single_workgroup(const bl_dataset *ds, int want_k)
 {
     if ((ds->model != 0 && ds->model != 2) || want_k > 0 || ds->nsp > 1) return -1; // (several species: the partial table is sized for 4 waves)
-    if (const char *e = getenv("BIOLITH_HIP_SINGLE")) { if (e[0] == '0') return -1; } // A/B knob
+    if (const char *e = bl_env(BL_ENV_SINGLE)) { if (e[0] == '0') return -1; } // A/B knob
     const int T = ds->dims.n_periods, J = ds->dims.n_replicates;
     const long long V = (long long)T * J, npairs = (ds->dims.n_sites + 1) / 2, lanes = BL_CWAVES_SINGLE * 64;
     if (npairs > lanes) return -1;
     int lg = 0;
     while (lg < 4 && (npairs << (lg + 1)) <= lanes && ((V + (1 << lg) - 1) >> lg) > 1) lg++;
     if (((V + (1 << lg) - 1) >> lg) > BL_SINGLE_VISITS) return -1;
-    if (const char *e = getenv("BIOLITH_HIP_OCCU_G")) { // tests / A/B: force the lanes per pair
+    if (const char *e = bl_env(BL_ENV_OCCU_G)) { // tests / A/B: force the lanes per pair
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) { lg = 0; while ((1 << lg) < v) lg++; }
     }
     int lgt = 0;
     while (lgt < lg && (2 << lgt) <= T) lgt++;
-    if (const char *e = getenv("BIOLITH_HIP_OCCU_GT")) { const int v = atoi(e); if (v >= 0 && v <= lg) lgt = v; }
+    if (const char *e = bl_env(BL_ENV_OCCU_GT)) { const int v = atoi(e); if (v >= 0 && v <= lg) lgt = v; }
     int lgj = lg - lgt;
     while (lgj > 0 && (1 << (lgj - 1)) >= J) lgj--;
     return lgt | (lgj << 4);
@@ -1011,7 +1065,7 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
         ncw = (((long long)N * G + 2 * 3 * 64 - 1) / (2 * 3 * 64) <= kmax) ? 3 : 4;
         // A/B knob: only the counts this library was built with (3, 4, and BL_OCCU_CWX in a variant build of the plain model); anything
         // else is ignored rather than turned into a launch that no instantiation serves
-        if (const char *e = getenv("BIOLITH_HIP_CWAVES")) {
+        if (const char *e = bl_env(BL_ENV_CWAVES)) {
             const int v = atoi(e);
             bool built = v == 3 || v == 4;
 #ifdef BL_OCCU_CWX
@@ -1023,7 +1077,7 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
         if (ds->model == 8) { // one site pair per lane group; three compute waves while the chain's workgroups offer the lanes, else four
             const int Gd = dyn_lanes_per_pair(ds, chains);
             ncw = (((long long)N * Gd + 2 * 3 * 64 - 1) / (2 * 3 * 64) <= kmax) ? 3 : 4;
-            if (const char *e = getenv("BIOLITH_HIP_CWAVES")) { const int v = atoi(e); if (v == 3 || v == 4) ncw = v; }
+            if (const char *e = bl_env(BL_ENV_CWAVES)) { const int v = atoi(e); if (v == 3 || v == 4) ncw = v; }
             per_wg = std::max(2, 2 * ncw * 64 / Gd);
         }
     }
@@ -1055,20 +1109,20 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     // form), which costs a few thousand cycles per tick -- little next to re-reading the rows from HBM every tick.
     int wide = 0;
     if (!ok && want_k <= 0) {
-        const char *e = getenv("BIOLITH_HIP_NO_WIDE");
+        const char *e = bl_env(BL_ENV_NO_WIDE);
         const int kwide = 256 / (chains > 0 ? chains : 1);
         if (!(e && e[0] == '1'))
             for (int kk = kmax + 1; kk <= kwide && !ok; kk++) { ok = fits(kk, &nloc); if (ok) { k = kk; wide = 1; } }
     }
     if (ok && !wide && ds->model == 1 && want_k <= 0) { // A/B knob: occu_rn over more workgroups than one XCD offers a chain
-        if (const char *e = getenv("BIOLITH_HIP_RN_K")) {
+        if (const char *e = bl_env(BL_ENV_RN_K)) {
             const int kk = atoi(e), kwide = 256 / (chains > 0 ? chains : 1);
             int nl;
             if (kk > kmax && kk <= kwide && fits(kk, &nl)) { k = kk; nloc = nl; wide = 1; }
         }
     }
     if (ds->model == 0 && want_k <= 0) { // A/B knob: the plain model over kk workgroups across XCDs although one XCD's would do
-        if (const char *e = getenv("BIOLITH_HIP_WIDE_K")) {
+        if (const char *e = bl_env(BL_ENV_WIDE_K)) {
             const int kk = atoi(e), kwide = 256 / (chains > 0 ? chains : 1);
             int nl;
             if (kk > 0 && kk <= kwide && fits(kk, &nl)) { k = kk; nloc = nl; wide = 1; ok = true; }
@@ -1078,7 +1132,7 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
     // one XCD no longer cap the lane groups -- a site pair is shared by as many lanes as BL_GRP_VISITS asks for and the chain takes
     // the workgroups that offer them (four compute waves each), up to 256 / chains.  More workgroups make the exchange longer (every
     // workgroup gathers every record over the fabric); BL_WIDE_KMAX bounds them where that costs more than the shorter visit loops save.
-    if (wide && ok && (ds->model == 0 || ds->model == 2) && want_k <= 0 && !getenv("BIOLITH_HIP_WIDE_K")) {
+    if (wide && ok && (ds->model == 0 || ds->model == 2) && want_k <= 0 && !bl_env(BL_ENV_WIDE_K)) {
         const int kwide = std::min(256 / (chains > 0 ? chains : 1), BL_WIDE_KMAX);
         if (kwide > k) {
             const int g2 = occu_lane_group(ds, chains, 0, kwide);
@@ -1105,7 +1159,7 @@ static void choose_geometry(const bl_dataset *ds, int chains, int want_k, int *k
 static int nmix_table_in_lds(const bl_dataset *ds, int staged, int nloc, int *lds_bytes)
 {
     if (ds->model != 4 || !staged) return 0;
-    if (const char *e = getenv("BIOLITH_HIP_NMIX_LDS")) { if (e[0] == '0') return 0; }
+    if (const char *e = bl_env(BL_ENV_NMIX_LDS)) { if (e[0] == '0') return 0; }
     const long long tb = (long long)ds->dims.n_periods * (ds->max_abundance + 1) * (2 * ((nloc + 1) / 2)) * 4;
     if (*lds_bytes + tb > BL_LDS_TOTAL) return 0;
     *lds_bytes += (int)tb;
@@ -1174,7 +1228,7 @@ static hipError_t re_nuts_dispatch_lds(const BlReRun &run, int grid, size_t lds,
 {
     const int lt = run.m.lds_hot;
     if constexpr (MK == 4 && KIND == 0) {
-        const char *e = getenv("BIOLITH_HIP_RE_EFF"); // A/B knob: 0 = the general kernel
+        const char *e = bl_env(BL_ENV_RE_EFF); // A/B knob: 0 = the general kernel
         if (run.m.lds_rows && lt == 2 && run.m.n_species == 1 && !(e && e[0] == '0')) {
             // one period as a fact too, for site effects alone (same trajectories, one box: 8.91 -> 8.85 us on the bench shape; with
             // observation effects the same fact measured 0.1-2 % slower on four shapes -- profiles/r04/i_ab_re_t1_all.txt -- and is not
@@ -1219,7 +1273,7 @@ static size_t re_geometry(BlReModel &m, int nloc, int with_hot, int dl_max)
             const int n_a = half / tps, rest = nloc - n_a;
             int tb = tps;
             while (tb < 64 && 2 * tb * rest <= half && 2 * tb <= m.J) tb *= 2;
-            const char *e = getenv("BIOLITH_HIP_RE_NO_SPLIT"); // (measurement)
+            const char *e = bl_env(BL_ENV_RE_NO_SPLIT); // (measurement)
             if (tb > tps && !(e && e[0] == '1')) { m.w_a = BL_RE_NW / 2; m.n_a = n_a; m.tps_b = tb; }
         }
     }
@@ -1230,10 +1284,10 @@ static size_t re_geometry(BlReModel &m, int nloc, int with_hot, int dl_max)
     const size_t row_bytes = (size_t)m.n_rows * nloc * 4, budget = (size_t)148 * 1024;
     const size_t hot_bytes = (size_t)RE_HOT * dl_max * 4, warm_bytes = (size_t)RE_WARM * dl_max * 4;
     m.lds_rows = row_bytes <= budget ? 1 : 0;
-    if (const char *e = getenv("BIOLITH_HIP_RE_LDS_ROWS")) m.lds_rows = std::min(m.lds_rows, atoi(e)); // (tests: every instantiation)
+    if (const char *e = bl_env(BL_ENV_RE_LDS_ROWS)) m.lds_rows = std::min(m.lds_rows, atoi(e)); // (tests: every instantiation)
     const size_t used = m.lds_rows ? row_bytes : 0;
     m.lds_hot = !with_hot ? 0 : (used + warm_bytes <= budget ? 2 : (used + hot_bytes <= budget ? 1 : 0));
-    if (const char *e = getenv("BIOLITH_HIP_RE_LDS_TIER")) m.lds_hot = std::min(m.lds_hot, atoi(e)); // (measurement)
+    if (const char *e = bl_env(BL_ENV_RE_LDS_TIER)) m.lds_hot = std::min(m.lds_hot, atoi(e)); // (measurement)
     return used + (m.lds_hot == 2 ? warm_bytes : (m.lds_hot == 1 ? hot_bytes : 0));
 }
 
@@ -1340,6 +1394,7 @@ static int create_re_impl(const bl_dims *dims, const float *site_covs, const flo
                           double prior_obs_re_sd_scale, int fp_mode, double fp_a, double fp_b, int count_model, int count_K, const bl_normal_prior *prior_beta,
                           const bl_normal_prior *prior_alpha, int device, bl_dataset **out, const float *session_duration /* occu_cop only */)
 {
+    bl_env_snapshot();
     if (!site_random_effects && !obs_random_effects && !(count_model == 1 && fp_mode))
         return bl_fail(BL_ERR_INVALID, "bl_dataset_create_re: neither random effect requested (use bl_dataset_create)");
     if (dims && (dims->n_site_covs > BL_RE_MAXK || dims->n_obs_covs > BL_RE_MAXK))
@@ -1477,6 +1532,7 @@ static int re_logp_grad(bl_dataset *ds, int B, const double *theta, double *U, d
 extern "C" int bl_logp_grad(bl_dataset *ds, int B, const double *theta, double *U, double *grad, int staged)
 {
     if (!ds || !theta || !U || !grad || B <= 0) return bl_fail(BL_ERR_INVALID, "bl_logp_grad: bad argument");
+    bl_env_snapshot();
     if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is in flight on this handle");
     int rc = set_device(ds);
     if (rc) return rc;
@@ -1553,7 +1609,7 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     if (k <= 0) {
         const long long work = std::max<long long>((long long)D, (long long)N * V / 8);
         k = (int)((2 * work + BL_RE_NT - 1) / BL_RE_NT);
-        if (const char *e = getenv("BIOLITH_HIP_RE_WGS")) k = atoi(e);
+        if (const char *e = bl_env(BL_ENV_RE_WGS)) k = atoi(e);
     }
     int ncu = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ds->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
@@ -1573,7 +1629,7 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     auto carve = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
     const size_t o_draws = RL.draws, o_div = RL.div, o_steps = RL.steps, o_acc = RL.acc, o_pot = RL.pot, o_eps = RL.eps,
                  o_minv = RL.minv, o_nleap = RL.nleap, o_status = carve(16),
-                 o_rng = carve((size_t)C * k * (dl_max + 2) * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(32 * 8),
+                 o_rng = carve((size_t)C * k * (dl_max + 2) * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(BL_DBG_SLOTS * 8),
                  o_xchg = carve((size_t)C * 2 * k * BL_RE_NRED_MAX * 8), o_loc = carve((size_t)C * 4), o_run = carve(sizeof(BlReRun));
     if (off > ds->run_bytes) {
         if (ds->d_run) hipFree(ds->d_run);
@@ -1638,7 +1694,7 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     run.num_chains = C; run.num_warmup = W; run.num_samples = S; run.max_depth = max_depth;
     run.k = k; run.nloc = nloc; run.dl_max = dl_max;
     run.xchg = (unsigned long long *)(base + o_xchg);
-    { const char *e1 = getenv("BIOLITH_HIP_NO_LOCAL"); run.allow_local = (e1 && e1[0] == '1') ? 0 : 1; }
+    { const char *e1 = bl_env(BL_ENV_NO_LOCAL); run.allow_local = (e1 && e1[0] == '1') ? 0 : 1; }
     run.xcd_local = ds->d_loc;
     run.target_accept = (float)(cfg->target_accept > 0.0 ? cfg->target_accept : 0.8);
     int32_t ws[32], we[32];
@@ -1657,7 +1713,7 @@ static int re_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, hipStream_t
     *ds->h_abort = 0;
     BL_HIP(hipEventRecord(ds->ev0, st));
     BL_HIP(hipMemsetAsync(ds->d_status, 0, 16, st));
-    BL_HIP(hipMemsetAsync(ds->d_dbg, 0, 256, st));
+    BL_HIP(hipMemsetAsync(ds->d_dbg, 0, BL_DBG_SLOTS * 8, st));
     BL_HIP(hipMemsetAsync(run.xchg, 0, (size_t)C * 2 * k * BL_RE_NRED_MAX * 8, st));
     BL_HIP(hipMemsetAsync(ds->d_loc, 0, (size_t)C * 4, st));
     // XCD-aware mapping in the kernel (surplus blocks exit at once)
@@ -1673,6 +1729,8 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
 {
     if (!ds || !cfg) return bl_fail(BL_ERR_INVALID, "NULL argument");
     if (ds->in_flight) return bl_fail(BL_ERR_BUSY, "a NUTS launch is already in flight on this handle");
+    bl_env_snapshot(); // the one read of the environment for this launch
+    snprintf(ds->env_overrides, sizeof ds->env_overrides, "%s", bl_env_active().c_str());
     const int C = cfg->num_chains, S = cfg->num_samples, W = cfg->num_warmup, D = ds->D;
     if (C <= 0 || S < 0 || W < 0 || S + W <= 0) return bl_fail(BL_ERR_INVALID, "num_chains/num_samples/num_warmup out of range");
     if (C > 256) return bl_fail(BL_ERR_UNSUPPORTED, "num_chains=%d > 256 per device launch", C);
@@ -1696,7 +1754,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     auto carve = [&](size_t bytes) { size_t o = off; off = align256(off + bytes); return o; };
     const size_t o_draws = RL.draws, o_div = RL.div, o_steps = RL.steps, o_acc = RL.acc, o_pot = RL.pot, o_eps = RL.eps,
                  o_minv = RL.minv, o_nleap = RL.nleap, o_status = carve(16),
-                 o_rng = carve((size_t)C * BL_RNG_STREAMS_PER_CHAIN * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(32 * 8), o_loc = carve((size_t)C * 4),
+                 o_rng = carve((size_t)C * BL_RNG_STREAMS_PER_CHAIN * 16), o_init = carve((size_t)C * D * 4), o_dbg = carve(BL_DBG_SLOTS * 8), o_loc = carve((size_t)C * 4),
                  o_cold = carve(sizeof(BlNutsCold));
     if (off > ds->run_bytes) {
         if (ds->d_run) hipFree(ds->d_run);
@@ -1710,7 +1768,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     ds->d_minv = (float *)(base + o_minv); ds->d_nleap = (long long *)(base + o_nleap); ds->d_status = (int *)(base + o_status);
     ds->d_rng = (uint32_t *)(base + o_rng); ds->d_init = (float *)(base + o_init); ds->d_dbg = (long long *)(base + o_dbg); ds->d_loc = (int *)(base + o_loc);
     int pitch = nvp; // granules between workgroup records
-    { const char *e = getenv("BIOLITH_HIP_PITCH"); if (e && atoi(e) >= nvp && atoi(e) <= 4096) pitch = atoi(e); }
+    { const char *e = bl_env(BL_ENV_PITCH); if (e && atoi(e) >= nvp && atoi(e) <= 4096) pitch = atoi(e); }
     const size_t xb = align256((size_t)C * BL_XCHG_SLOTS * k * pitch * 8);
     if (xb > ds->xchg_bytes) {
         if (ds->d_xchg) hipFree(ds->d_xchg);
@@ -1768,7 +1826,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     // (a chain of ONE workgroup always runs on BL_CWAVES_SINGLE compute waves: that kernel alone has the exchange-free path)
     p.grp_kernel = ((ds->model == 0 || ds->model == 2) && staged && (grp > 0 || ncw == BL_CWAVES_SINGLE)) ? 1 : 0;
     if (ncw == BL_CWAVES_SINGLE && k != 1) return bl_fail(BL_ERR_INVALID, "internal: %d compute waves are the one-workgroup form, k = %d", ncw, k);
-    if (const char *e = getenv("BIOLITH_HIP_GRP_KERNEL")) { if (e[0] == '1' && (ds->model == 0 || ds->model == 2) && staged) p.grp_kernel = 1; } // A/B knob: the GRP form although it is not needed
+    if (const char *e = bl_env(BL_ENV_GRP_KERNEL)) { if (e[0] == '1' && (ds->model == 0 || ds->model == 2) && staged) p.grp_kernel = 1; } // A/B knob: the GRP form although it is not needed
     p.fp_mode = ds->fp_mode;
     p.nmix_tab = ds->d_tab;
     p.ncw = ncw;
@@ -1779,13 +1837,13 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     p.xchg = ds->d_xchg;
     p.cold = d_cold;
     p.spin_limit = 5000000u; // microseconds (BIOLITH_HIP_SPIN_US overrides: tests of the bound)
-    { const char *e = getenv("BIOLITH_HIP_SPIN_US"); if (e && atoi(e) > 0) p.spin_limit = (unsigned)atoi(e); }
+    { const char *e = bl_env(BL_ENV_SPIN_US); if (e && atoi(e) > 0) p.spin_limit = (unsigned)atoi(e); }
     {   // developer knobs (A/B measurements): exchange form and poll spacing
-        const char *e1 = getenv("BIOLITH_HIP_NO_LOCAL"), *e2 = getenv("BIOLITH_HIP_POLL_SLEEP");
+        const char *e1 = bl_env(BL_ENV_NO_LOCAL), *e2 = bl_env(BL_ENV_POLL_SLEEP);
         p.allow_local = (e1 && e1[0] == '1') ? 0 : 1;
         p.poll_sleep = e2 ? atoi(e2) : 3;
         if (p.poll_sleep < 0 || p.poll_sleep > 127) p.poll_sleep = 3;
-        const char *e3 = getenv("BIOLITH_HIP_FIRST_DELAY");
+        const char *e3 = bl_env(BL_ENV_FIRST_DELAY);
         p.pitch = pitch;
         p.first_delay = e3 ? atoi(e3) : 0;
         if (p.first_delay < 0 || p.first_delay > 127) p.first_delay = 0;
@@ -1795,7 +1853,7 @@ extern "C" int bl_nuts_launch(bl_dataset *ds, const bl_nuts_config *cfg, void *s
     BL_HIP(hipEventRecord(ds->ev0, st));
     BL_HIP(hipMemsetAsync(ds->d_xchg, 0, xb, st));
     BL_HIP(hipMemsetAsync(ds->d_status, 0, 16, st));
-    BL_HIP(hipMemsetAsync(ds->d_dbg, 0, 256, st));
+    BL_HIP(hipMemsetAsync(ds->d_dbg, 0, BL_DBG_SLOTS * 8, st));
     BL_HIP(hipMemsetAsync(ds->d_loc, 0, (size_t)C * 4, st));
     // XCD-aware mapping in the kernel (surplus blocks exit at once), or consecutive blocks per chain in the wide geometry
     const int grid = wide ? C * k : 8 * k * ((C + 7) / 8);
@@ -1896,7 +1954,7 @@ extern "C" int bl_nuts_device_draws(bl_dataset *ds, void **dev_ptr, size_t *byte
 
 extern "C" int bl_nuts_debug_counters(bl_dataset *ds, int64_t *out, int n)
 {
-    if (!ds || !out || n <= 0 || n > 32) return bl_fail(BL_ERR_INVALID, "bad argument");
+    if (!ds || !out || n <= 0 || n > BL_DBG_SLOTS) return bl_fail(BL_ERR_INVALID, "bad argument");
     if (!ds->have_run || ds->in_flight) return bl_fail(BL_ERR_BUSY, "no finished NUTS launch");
     BL_HIP(hipMemcpy(out, ds->d_dbg, (size_t)n * 8, hipMemcpyDeviceToHost));
     return BL_OK;
@@ -1940,6 +1998,14 @@ extern "C" int bl_nuts_lane_group(bl_dataset *ds, int *period_lanes, int *visit_
     else if (ds->model == 0 || ds->model == 2 || ds->model == 3 || ds->model == 4) { gt = 1 << (ds->lane_grp & 15); gj = 1 << (ds->lane_grp >> 4); }
     if (period_lanes) *period_lanes = gt;
     if (visit_lanes) *visit_lanes = gj;
+    return BL_OK;
+}
+
+extern "C" int bl_nuts_env_overrides(bl_dataset *ds, char *buf, int n)
+{
+    if (!ds || !buf || n <= 0) return bl_fail(BL_ERR_INVALID, "NULL argument");
+    if (!ds->have_run) return bl_fail(BL_ERR_INVALID, "no NUTS launch on this handle");
+    snprintf(buf, (size_t)n, "%s", ds->env_overrides);
     return BL_OK;
 }
 

@@ -55,7 +55,8 @@ static int bl_launch(const char *name, const P *p, int grid, int threads, int ld
 #define BL_PICK_GRP_LEAN_T1(P, MODEL, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, MODEL, CW, true, 1, true>>(BL_KHEAD(bl_nuts_kernel, true, MODEL, CW) ", true, 1, true>", P, grid, 64 * (CW + 1), lds_bytes, stream)
 // (BIOLITH_HIP_GENERAL=1: tests / A/B -- the general kernel although a per-form instantiation would serve; draws must not change by a bit:
 // tests/test_gpu_kernel_forms.py)
-static inline bool bl_force_general() { const char *e = getenv("BIOLITH_HIP_GENERAL"); return e && e[0] == '1'; }
+extern "C" int bl_env_force_general(void); // biolith_hip.hip: BIOLITH_HIP_GENERAL=1 at the launch's one read of the environment (A/B, tests)
+static inline bool bl_force_general() { return bl_env_force_general() != 0; }
 // the dynamic model on one period per lane (JSEL = 1 in a MODEL 8 lane-group kernel: the two-scans form, dyn_device.hpp)
 #define BL_PICK_DYN_SCAN(P, CW) bl_launch<bl_nuts_kernel<BL_KS, BL_KO, true, 8, CW, true, 1, false>>(BL_KHEAD(bl_nuts_kernel, true, 8, CW) ", true, 1, false>", P, grid, 64 * (CW + 1), lds_bytes, stream)
 // ... and with eight periods on eight lanes at four visits each as compile-time facts (JSEL = 2)

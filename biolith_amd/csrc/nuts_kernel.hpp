@@ -86,8 +86,10 @@ struct BlNutsCold {
     long long *nleap;              // [C][2]
     int *status;                   // [1]
     int *xcd_local;                // [C] 1 if the chain ran on the L2-local exchange
-    long long *dbg;                // [16] phase cycle counters (diagnostic BL_STAMPS builds only)
+    long long *dbg;                // [BL_DBG_SLOTS] phase cycle counters (diagnostic BL_STAMPS builds only); from 32: chain 0's site-evaluation
+                                   // cycles per compute wave, [workgroup][wave] at 8 per workgroup
 };
+#define BL_DBG_SLOTS 544           // 32 + 64 workgroups x 8 compute waves
 
 struct BlNutsParams {
     const float *rows;             // HBM data matrix [n_rows][n_stride]
@@ -1004,6 +1006,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         cold->dbg[14] = st_kc[0]; cold->dbg[15] = st_kc[1]; cold->dbg[7] = st_kc[2];
         for (int i = 0; i < 4; i++) cold->dbg[16 + i] = st_sub[i];
     }
+    if (cold->dbg && chain == 0 && member < 64 && wave >= 1 && wave <= 8 && (tid & 63) == 0) cold->dbg[32 + member * 8 + (wave - 1)] = st_sub[5];
     if (cold->dbg && chain == 0 && member == 0 && tid == 64) { // first compute wave: site-evaluation passes and their cycles
         cold->dbg[20] = st_sub[4]; cold->dbg[21] = st_sub[5];
         if constexpr (MODEL == 1) for (int i = 0; i < 8; i++) cold->dbg[22 + i] = bl_rn_dbg[i];

@@ -105,6 +105,7 @@ class NutsResult:
     comm_init_ms: float = 0.0     # fit(devices=[...]): wall time of ncclCommInitAll (outside the sampling clock)
     lane_group: tuple = (1, 1)    # lanes that shared one site pair: (period lanes, visit lanes); (1, 1) = one pair per lane
     kernel_name: str = ""         # the sampler instantiation that ran, as rocprofv3 names it
+    env_overrides: str = ""       # BIOLITH_HIP_* knobs set at the launch ("" = none: the engine's own geometry and kernel form)
 
 
 class OccuDataset:
@@ -338,6 +339,12 @@ class OccuDataset:
         _ffi.check(self._lib.bl_nuts_kernel_name(self._h, buf, 192))
         return buf.value.decode()
 
+    def env_overrides(self) -> str:
+        """BIOLITH_HIP_* knobs that were set when the last launch read the environment ("" = none; bl_nuts_env_overrides)."""
+        buf = C.create_string_buffer(512)
+        _ffi.check(self._lib.bl_nuts_env_overrides(self._h, buf, 512))
+        return buf.value.decode()
+
     def elapsed_ms(self) -> float:
         ms = C.c_float(0)
         _ffi.check(self._lib.bl_nuts_elapsed_ms(self._h, C.byref(ms)))
@@ -377,7 +384,7 @@ class OccuDataset:
         return NutsResult(a["draws"], a["diverging"].astype(bool), a["num_steps"], a["accept_prob"], a["potential_energy"],
                           a["step_size"], a["inv_mass"], a["n_leapfrog"], self.elapsed_ms(),
                           k.value, lds.value, bool(staged.value & 1), loc.value, thr.value, staged.value >> 1,
-                          lane_group=(int(gt.value), int(gj.value)), kernel_name=self._kernel_name())
+                          lane_group=(int(gt.value), int(gj.value)), kernel_name=self._kernel_name(), env_overrides=self.env_overrides())
 
     def fetch(self) -> NutsResult:
         Cn, S = self._shape

@@ -288,6 +288,14 @@ int bl_nuts_lane_group(bl_dataset *ds, int *period_lanes, int *visit_lanes);
  * compile-time facts).  Measurement only: bench.py's roofline.kernel. */
 int bl_nuts_kernel_name(bl_dataset *ds, char *buf, int n);
 
+/* The BIOLITH_HIP_* environment knobs (tests, A/B runs, measurement; INTEGRATION.md lists every one) that were SET when the last
+ * launch on this handle read the environment, as "NAME=value,NAME=value" ("" = none: the geometry and the kernel form are the
+ * engine's own choice).  The launch path reads the environment in one place, once per launch.  bl_env_overrides: the same for the
+ * environment as it is now (no handle).  Not part of the reference's interface (numpyro has no such knobs); bench.py prints it so
+ * that a stray variable cannot change a measured geometry silently. */
+int bl_nuts_env_overrides(bl_dataset *ds, char *buf, int n);
+int bl_env_overrides(char *buf, int n);
+
 /* Page-locked host memory for large outputs (bl_deterministic / bl_predict write into caller memory; into page-locked memory the
  * device copies at PCIe rate instead of staging through the runtime's bounce buffers).  The caller owns and frees it.  The
  * reference's counterpart is jax.device_get() of a deterministic site (utils/fit.py:132). */
@@ -296,7 +304,7 @@ int bl_host_free(void *ptr);
 
 /* In-kernel phase cycle counters of the last launch; all zero unless the library is a diagnostic
  * BL_STAMPS build (make -C biolith_amd/csrc stamps).  Not part of the reference's interface. */
-int bl_nuts_debug_counters(bl_dataset *ds, int64_t *out /*[n<=32]*/, int n);
+int bl_nuts_debug_counters(bl_dataset *ds, int64_t *out /*[n<=544]*/, int n);
 
 /*
  * Deterministic sites (occu.py:207, 221-228), recomputed from draws on the device:

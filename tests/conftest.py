@@ -61,6 +61,14 @@ def cfg2_data():
 PARITY_W, PARITY_S = 500, 2000          # warmup / draws per chain of the posterior-parity tests (4 chains each side)
 
 
+def load_oracle_draws(name, D, warmup, samples):
+    """(4, samples, kept) float64 draws of the oracle's NUTS from tests/golden/oracle_draws_<name>.npz (made by
+    tests/golden/make_oracle_posterior_draws.py with the same data set, model arguments, warm-up and draw counts -- checked here)."""
+    z = np.load(os.path.join(GOLDEN, f"oracle_draws_{name}.npz"))
+    assert int(z["D"]) == D and int(z["warmup"]) == warmup and int(z["samples"]) == samples and int(z["divergences"]) == 0, name
+    return z["draws"].astype(np.float64)
+
+
 def posterior_parity(draws_gpu, draws_orc, ess_gpu=None):
     """|mean_gpu - mean_oracle| <= 4 MCSE, 0.9 <= sd ratio <= 1.1, split R-hat < 1.01 (both sides) -- the tolerances SURVEY.md
     section 8c states; the runs are long enough (4 x 2000 draws) for them to hold with room."""

@@ -77,3 +77,36 @@ def test_library_in_tree_was_linked_from_the_sources_in_tree():
     if not os.path.exists(stamp):
         pytest.skip("no stamp: the library was built by `make` directly; build() will run make")
     assert open(stamp).read().strip() == entry._sources_digest()
+
+
+def test_environment_knobs_are_read_in_one_place_and_reported():
+    """every BIOLITH_HIP_* variable of the launch path sits in ONE table (csrc/biolith_hip.hip BL_ENV_TABLE), is read by
+    ONE function, and the set that is active is reported (bl_env_overrides here, without a GPU; bl_nuts_env_overrides per launch:
+    tests/test_gpu_lane_groups.py).  INTEGRATION.md lists every name of the table."""
+    import ctypes as C
+
+    src = open(os.path.join(ROOT, "biolith_amd", "csrc", "biolith_hip.hip")).read()
+    table = re.search(r"#define BL_ENV_TABLE\(X\)(.*?)\nenum bl_env_knob", src, flags=re.S).group(1)
+    names = re.findall(r"X\(([A-Z_]+)\)", table)
+    assert len(names) == len(set(names)) >= 20
+    for f in os.listdir(os.path.join(ROOT, "biolith_amd", "csrc")):         # no getenv on the launch path outside the snapshot
+        if f.endswith((".hip", ".hpp")):
+            text = open(os.path.join(ROOT, "biolith_amd", "csrc", f)).read()
+            calls = re.findall(r"getenv\(([^)]*)\)", text)
+            assert all(c in ("BL_ENV_NAMES[i]", '"BIOLITH_RCCL_LIB"', '"BIOLITH_TEST_ALLOW_DUP_DEVICES"') for c in calls), (f, calls)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for n in names:
+        assert re.search(r"`%s`|`[A-Z_, `/=0-9a-zµ…]*\b%s\b" % (n, n), doc), n
+    lib = _ffi.load()
+    buf = C.create_string_buffer(512)
+    saved = {k: os.environ.pop(k) for k in list(os.environ) if k.startswith("BIOLITH_HIP_") and k != "BIOLITH_HIP_LIB"}
+    try:
+        assert lib.bl_env_overrides(buf, 512) == 0 and buf.value == b""
+        os.environ["BIOLITH_HIP_OCCU_G"] = "4"
+        os.environ["BIOLITH_HIP_NO_WIDE"] = "1"
+        os.environ["BIOLITH_HIP_NOT_A_KNOB"] = "1"
+        assert lib.bl_env_overrides(buf, 512) == 0 and buf.value == b"BIOLITH_HIP_OCCU_G=4,BIOLITH_HIP_NO_WIDE=1"
+    finally:
+        for k in ("BIOLITH_HIP_OCCU_G", "BIOLITH_HIP_NO_WIDE", "BIOLITH_HIP_NOT_A_KNOB"):
+            os.environ.pop(k, None)
+        os.environ.update(saved)

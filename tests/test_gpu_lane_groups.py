@@ -258,3 +258,23 @@ def test_nmixture_with_groups(name, K, g, gt, force_group):
     assert r.lane_group[0] * r.lane_group[1] == g, r.lane_group
     assert np.array_equal(o["num_steps"][:, :2], r.num_steps[:, :2]), (o["num_steps"], r.num_steps)
     ds.close()
+
+
+def test_a_launch_reports_the_environment_knobs_it_saw(monkeypatch):
+    """bl_nuts_env_overrides: "" when no BIOLITH_HIP_* knob is set (the engine's own geometry), the knobs and their values otherwise --
+    what bench.py prints as config.env_overrides (INTEGRATION.md "Environment variables")."""
+    d = load_golden("default")
+    ds = OccuDataset(d["site_covs"], d["obs_covs"], d["obs"])
+    for k in [k for k in os.environ if k.startswith("BIOLITH_HIP_") and k != "BIOLITH_HIP_LIB"]:
+        monkeypatch.delenv(k)
+    r0 = ds.nuts(num_warmup=10, num_samples=10, num_chains=1, seed=0)
+    assert r0.env_overrides == ""
+    monkeypatch.setenv("BIOLITH_HIP_OCCU_G", "4")
+    monkeypatch.setenv("BIOLITH_HIP_SINGLE", "0")
+    r1 = ds.nuts(num_warmup=10, num_samples=10, num_chains=1, seed=0)
+    assert r1.env_overrides == "BIOLITH_HIP_OCCU_G=4,BIOLITH_HIP_SINGLE=0" and r1.lane_group[0] * r1.lane_group[1] == 4
+    monkeypatch.delenv("BIOLITH_HIP_OCCU_G")
+    monkeypatch.delenv("BIOLITH_HIP_SINGLE")
+    r2 = ds.nuts(num_warmup=10, num_samples=10, num_chains=1, seed=0)
+    assert r2.env_overrides == "" and np.array_equal(r2.draws, r0.draws)
+    ds.close()

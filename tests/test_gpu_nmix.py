@@ -7,7 +7,7 @@ import oracle
 from biolith_amd.engine import OccuDataset
 from biolith_amd.models import nmixture, simulate_nmixture
 from biolith_amd.utils import fit, predict
-from conftest import PARITY_S, PARITY_W, load_golden, posterior_parity
+from conftest import PARITY_S, PARITY_W, load_golden, load_oracle_draws, posterior_parity
 
 pytestmark = pytest.mark.gpu
 U_RTOL, G_RTOL = 2e-6, 2e-5   # float32 per-term math, sums over N in float32
@@ -68,10 +68,12 @@ def test_nmix_first_transitions_match_oracle():
 
 
 def test_nmix_posterior_matches_oracle():
+    """The oracle's leg is a committed fixture (tests/golden/make_oracle_posterior_draws.py: the same call, 59 s of CPU -- two thirds of this
+    test's 42 s on the GPU box until round 6); tests/test_nmix_cpu.py keeps the oracle itself honest."""
     _, od, ds = _pair("nmix_small_2x2", 40)
-    o = oracle.nuts_run(od, PARITY_W, PARITY_S, num_chains=4, seed=0)
+    o = load_oracle_draws("nmix_small_2x2", D=od.D, warmup=PARITY_W, samples=PARITY_S)
     r = ds.nuts(num_warmup=PARITY_W, num_samples=PARITY_S, num_chains=4, seed=50)
-    posterior_parity(r.draws, o["draws"])
+    posterior_parity(r.draws, o)
 
 
 def _assert_recovery(results, true_params):  # nmixture.py:400-420

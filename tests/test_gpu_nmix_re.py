@@ -13,7 +13,7 @@ import oracle
 from biolith_amd.engine import OccuDataset
 from biolith_amd.models import nmixture, simulate_nmixture
 from biolith_amd.utils import fit, predict
-from conftest import load_golden, posterior_parity
+from conftest import load_golden, load_oracle_draws, posterior_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -81,11 +81,12 @@ def test_nmix_re_adaptation_and_next_tree_match_oracle():
 def test_nmix_re_posterior_matches_oracle():
     _, od, ds = _pair("nmix_site_re", 0, True, False)
     G = od.Ks + od.Ko + 2
-    o = oracle.nuts_run(od, 500, 1000, num_chains=4, seed=0)
+    # (the oracle's 4 x (500 + 1000), 76 s of CPU, is a committed fixture: tests/golden/make_oracle_posterior_draws.py)
+    od_draws = load_oracle_draws("nmix_site_re", D=od.D, warmup=500, samples=1000)
     r = ds.nuts(num_warmup=500, num_samples=1000, num_chains=4, seed=50)
     # the fixed effects at SURVEY 8c's tolerances; log site_re_sd (the centred parameterisation's funnel: test_gpu_re.py) in mean
-    posterior_parity(r.draws[:, :, :G], o["draws"][:, :, :G])
-    sg, so = r.draws[:, :, G:G + 1].astype(np.float64), o["draws"][:, :, G:G + 1]
+    posterior_parity(r.draws[:, :, :G], od_draws[:, :, :G])
+    sg, so = r.draws[:, :, G:G + 1].astype(np.float64), od_draws[:, :, G:G + 1]
     mcse = np.sqrt(sg.var() / oracle.effective_sample_size(sg)[0] + so.var() / oracle.effective_sample_size(so)[0])
     assert abs(sg.mean() - so.mean()) <= 4 * mcse, (sg.mean(), so.mean(), mcse)
 

@@ -1,0 +1,29 @@
+"""The engine's random-effects sampler (csrc/re_kernel.hpp) against the EXACT marginal posterior of log sd (tests/quadrature_re.py):
+the assertions of tests/test_sampler_vs_quadrature_re.py -- an effective sample size of about a hundredth of the draws, the exact
+conditional law above the funnel's neck within Monte-Carlo errors at that effective size, a deficit below it of at most a fifth, and
+nothing worse at target_accept 0.99 than at numpyro's default 0.8 -- through the C-ABI, on runs long enough (4 x 60 000 draws) for
+those errors to be about a hundredth.  Reference: biolith/models/occu.py:170-173, 191-196, 215-218."""
+import pytest
+
+from biolith_amd.engine import OccuDataset
+from biolith_amd.evaluation import effective_sample_size
+from test_sampler_vs_quadrature_re import check_log_sd_against_exact
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("site_re,seed", [(True, 1), (False, 1), (True, 3)])
+def test_engine_nuts_has_the_exact_law_of_log_sd_above_the_neck(site_re, seed):
+    kernels = set()
+
+    def sample(X, W, Y, acc):
+        ds = OccuDataset(X, W, Y, model="occu_re", site_random_effects=site_re, obs_random_effects=not site_re)
+        r = ds.nuts(num_warmup=1000, num_samples=60000 if acc == 0.8 else 30000, num_chains=4, seed=0, target_accept=acc)
+        ds.close()
+        assert int(r.diverging.sum()) <= 4
+        kernels.add(r.kernel_name.strip())
+        return r.draws[:, :, 4]
+
+    out, x = check_log_sd_against_exact(sample, effective_sample_size, site_re, seed)
+    print("engine", "site" if site_re else "obs", sorted(kernels),
+          {k: dict(deficit=round(v["deficit"], 3), min_u=round(v["min_u"], 2), ess=round(v["ess"])) for k, v in out.items()}, {k: round(v, 2) for k, v in x.items()})

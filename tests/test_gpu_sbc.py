@@ -60,25 +60,56 @@ def test_engine_ranks_are_uniform(model, reps, k, shape):
     assert np.all(np.abs(ranks.std(0) / sd_u - 1.0) < 4.0 / np.sqrt(2.0 * L) * 1.35), ranks.std(0) / sd_u
 
 
+def re_rank_statistics(ranks, ranks_std, M, n_coef=4):
+    """What a random-effects posterior through NUTS owes the calibration, given what tests/test_gpu_sampler_vs_quadrature_re.py shows of
+    log sd against its EXACT marginal: the law is exact above the funnel's neck, mass is missing below it, and the chain of log sd has
+    an effective sample size of about a hundredth of its draws -- so the 199 thinned draws a replication ranks the truth among are a
+    handful of independent values, and ranks pile up at the two ENDS whatever else holds (the calibration's premise, independent
+    draws, fails for this one coordinate).  Asserted therefore:
+      * the coefficients' ranks are uniform;
+      * the STANDARDISED effects e / sd (what a non-centred parameterisation would sample) are uniform -- the raw effects inherit log sd's defect;
+      * log sd: the eight INTERIOR rank bins are uniform among themselves, and the two end bins' surpluses are bounded -- the low one by
+        the neck's mass (a fifth), the high one by what autocorrelation alone piles there.
+    -> (chi2 coefficients, chi2 standardised effects, chi2 of log sd's bins 2..9, surplus low, surplus high, critical values, the bins)"""
+    from scipy.stats import chi2
+
+    stat, crit, counts = sbc.uniformity(ranks, M, bins=10)
+    stat_std, _, _ = sbc.uniformity(ranks_std, M, bins=10)
+    c = counts[n_coef].astype(np.float64)
+    L = c.sum()
+    mid = c[1:-1]
+    chi_mid = float(((mid - mid.mean()) ** 2 / mid.mean()).sum())
+    return stat[:n_coef], stat_std[n_coef + 1:], chi_mid, float(c[0] / L - 0.1), float(c[-1] / L - 0.1), crit, float(chi2.ppf(0.999, 7)), counts[n_coef]
+
+
 @pytest.mark.parametrize("site_re,obs_re", [(True, False), (False, True)])
 def test_engine_ranks_are_uniform_with_random_effects(site_re, obs_re):
-    """occu with random effects (the other kernel, re_kernel.hpp: D = 85 / 245 here).  The COEFFICIENTS' ranks are asserted.  The centred
-    effects ~ Normal(0, sd) under sd ~ HalfNormal(1) are a funnel, and NUTS -- the oracle's on the CPU exactly like this one
-    (profiles/NOTES.md, round 5) -- over-states log sd where the true sd is small: strongly with observation effects (ONE binary observation
-    per effect: the lowest tenth of the ranks holds 50 - 55 of 200 at every seed), mildly with site effects (six visits per effect: within the
-    limit at seeds 5 - 7, 42 of 200 at seed 8).  log sd and the effects are therefore reported, not asserted."""
+    """occu with random effects (the other kernel, re_kernel.hpp: D = 85 / 245 here; occu.py:170-173, 191-196, 215-218).  The centred
+    effects ~ Normal(0, sd) under sd ~ HalfNormal(1) are a funnel, and NUTS at one step size -- the oracle's exactly like this one, at
+    target_accept 0.8, 0.95 and 0.99 alike (profiles/r06/b_sbc_re_sweep.txt) -- does not reach the bottom of its neck within 4 x 250
+    draws: the lowest tenth of log sd's ranks holds a surplus (strong with observation effects, ONE binary observation per effect; mild
+    with site effects).  That this is the neck and nothing else is shown against the EXACT marginal of log sd in
+    tests/test_gpu_sampler_vs_quadrature_re.py; here what that leaves to a calibration is ASSERTED (re_rank_statistics)."""
     rng = np.random.default_rng(SEED + 2)
-    ranks, div = [], 0
+    ranks, ranks_std, div = [], [], 0
     for l in range(200):
         X, W, Y, theta, kw = sbc.prior_predictive_re(rng, 40, 6, 1, 1, site_re, obs_re)
         ds = OccuDataset(X, W, Y, **kw)
         r = ds.nuts(num_warmup=500, num_samples=250, num_chains=4, seed=l)
         ds.close()
         div += int(r.diverging.sum())
-        rk, M = sbc.rank_of_truth(r.draws.astype(np.float64), theta, 5, 199)
-        ranks.append(rk)
-    ranks = np.stack(ranks)[:, :9]                          # beta (2), alpha (2), log sd, the first four effects
-    stat, crit, counts = sbc.uniformity(ranks, M, bins=10)
-    print("random effects", site_re, obs_re, "divergences", div, "chi2", stat.round(1).tolist(), "log sd bins", counts[4].tolist())
-    assert np.all(stat[:4] < crit), (stat, crit, counts)
+        d = r.draws.astype(np.float64)
+        rk, M = sbc.rank_of_truth(d, theta, 5, 199)
+        ranks.append(rk[:9])
+        d[:, :, 5:] /= np.exp(d[:, :, 4:5])                 # effects / sd, draw by draw; the truth likewise
+        t = theta.copy()
+        t[5:] /= np.exp(theta[4])
+        ranks_std.append(sbc.rank_of_truth(d, t, 5, 199)[0][:9])
+    coef, eff_std, chi_mid, low, high, crit, crit7, bins = re_rank_statistics(np.stack(ranks), np.stack(ranks_std), M)
+    print("random effects", site_re, obs_re, "divergences", div, "chi2 coefficients", coef.round(1).tolist(), "standardised effects",
+          eff_std.round(1).tolist(), "log sd bins", bins.tolist(), "bins 2..9 chi2", round(chi_mid, 1), "surplus low / high", round(low, 3), round(high, 3))
+    assert np.all(coef < crit), (coef, crit)
+    assert np.all(eff_std < crit), (eff_std, crit)
+    assert chi_mid < crit7, (chi_mid, crit7, bins)
+    assert -0.07 <= low <= 0.22 and -0.07 <= high <= 0.12, (low, high, bins)
     assert div <= 0.002 * 200 * 1000

@@ -1,0 +1,76 @@
+"""Funnel or implementation?  (biolith/models/occu.py:170-173, 191-196, 215-218)
+
+The random-effects scale fails simulation-based calibration in ONE way: the lowest tenth of log sd's ranks holds too many replications
+(tests/test_gpu_sbc.py).  Here the exact marginal posterior of u = log sd (tests/quadrature_re.py: effects integrated out by
+Gauss-Hermite, no sampler anywhere) is set against NUTS draws -- the ORACLE's in this file, the engine's in
+tests/test_gpu_sampler_vs_quadrature_re.py -- and what the comparison shows is asserted:
+
+  0. u mixes two orders of magnitude slower than anything else in the model: its effective sample size is about ONE PER CENT of the
+     draws (the funnel: NUTS at one step size creeps along the neck).  Calibration with 4 x 250 draws per replication therefore ranks
+     the truth among a handful of independent values of u -- its premise fails for this coordinate before any bias is looked at --
+     and every tolerance below is a Monte-Carlo error computed from the MEASURED effective sample size, not from the draw count;
+  1. ABOVE the neck the sampler has the exact law: conditional on u >= the exact 25 % point, the empirical CDF of u at the exact
+     50 / 75 / 90 / 95 % points is the exact conditional CDF within 4 such standard errors (an implementation error -- a wrong Jacobian
+     of the log scale, a wrong half step, a wrong prior on the effects -- would move these);
+  2. what is missing is mass BELOW that point: between nothing and a fifth of the whole (`deficit`), never a surplus beyond the error;
+  3. smaller steps do not make it worse and reach further down: at target_accept 0.99 the deficit is not larger (within errors) than at
+     numpyro's default 0.8, and the lowest u visited is lower -- a fixed bias of the density would not care about the step size.
+"""
+import numpy as np
+import pytest
+
+import oracle
+import quadrature_re as Q
+
+LEVELS = (0.25, 0.5, 0.75, 0.9, 0.95)
+
+
+def check_log_sd_against_exact(sample, ess_fn, site_re, seed):
+    """`sample(X, W, Y, target_accept) -> draws of u (chains, n)`; `ess_fn((chains, n, 1)) -> [ESS]`.  The assertions above.
+    Returns what was measured (for the record)."""
+    X, W, Y = Q.zero_covariate_data(40, 6, 0.15, site_re, seed)
+    U, _, cdf = Q.log_sd_marginal(Y, site_re)
+    x = {l: float(np.interp(l, cdf, U)) for l in (0.1,) + LEVELS}
+    out = {}
+    for acc in (0.8, 0.99):
+        u = np.asarray(sample(X, W, Y, acc), dtype=np.float64)
+        ess = float(np.asarray(ess_fn(u[:, :, None])).reshape(-1)[0])
+        assert ess <= 0.05 * u.size, (ess, u.size)                         # (0): far fewer independent values than draws
+        F = {l: float((u <= x[l]).mean()) for l in x}
+        se = lambda p, n=ess: np.sqrt(max(p * (1.0 - p), 0.01) / n)         # noqa: E731 -- binomial error at the measured ESS
+        deficit = 0.25 - F[0.25]
+        assert -4.0 * se(0.25) <= deficit <= 0.20 + 4.0 * se(0.25), (acc, deficit, ess, F)
+        for l in LEVELS[1:]:
+            cond, exact = (F[l] - F[0.25]) / (1.0 - F[0.25]), (l - 0.25) / 0.75
+            assert abs(cond - exact) <= 4.0 * se(exact, ess * (1.0 - F[0.25])) + 0.005, (acc, l, cond, exact, ess, F)
+        out[acc] = dict(F=F, deficit=deficit, min_u=float(u.min()), ess=ess, se25=float(se(0.25)))
+    assert out[0.99]["deficit"] <= out[0.8]["deficit"] + 4.0 * np.hypot(out[0.8]["se25"], out[0.99]["se25"]), out
+    assert out[0.99]["min_u"] < out[0.8]["min_u"], out
+    return out, x
+
+
+@pytest.mark.parametrize("site_re,seed", [(True, 1), (False, 1)])
+def test_oracle_nuts_has_the_exact_law_of_log_sd_above_the_neck(site_re, seed):
+    def sample(X, W, Y, acc):
+        od = oracle.OracleData(X, W, Y, model="occu_re", site_random_effects=site_re, obs_random_effects=not site_re)
+        return oracle.nuts_run(od, 1000, 12000 if acc == 0.8 else 6000, num_chains=4, seed=0, target_accept=acc)["draws"][:, :, 4]
+
+    out, x = check_log_sd_against_exact(sample, oracle.effective_sample_size, site_re, seed)
+    print("oracle", "site" if site_re else "obs", {k: dict(deficit=round(v["deficit"], 3), min_u=round(v["min_u"], 2), ess=round(v["ess"])) for k, v in out.items()},
+          {k: round(v, 2) for k, v in x.items()})
+
+
+def test_the_quadrature_itself():
+    """With no data (every visit missing) the marginal of u is its prior on the log scale, HalfNormal(1): cdf(u) = erf(e^u / sqrt 2)."""
+    from scipy.special import erf
+
+    X, W, Y = Q.zero_covariate_data(12, 3, 0.5, True, 0)
+    Y[:] = np.nan
+    for site_re in (True, False):
+        U, dens, cdf = Q.log_sd_marginal(Y, site_re)
+        assert np.max(np.abs(cdf - erf(np.exp(U) / np.sqrt(2.0)))) < 5e-4      # (trapezoid on 161 points)
+    # ... and refining the grid / the Gauss-Hermite rule moves nothing on real data
+    X, W, Y = Q.zero_covariate_data(40, 6, 0.15, True, 1)
+    a = Q.log_sd_marginal(Y, True)
+    b = Q.log_sd_marginal(Y, True, n_beta=121, n_alpha=121, n_u=241, gh=80)
+    assert np.max(np.abs(np.interp(a[0], b[0], b[2]) - a[2])) < 1e-3
