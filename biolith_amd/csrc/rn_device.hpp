@@ -258,12 +258,7 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
             // record for the item lanes
             *reinterpret_cast<float4 *>(srec + lane * 8) = make_float4(a, clr, term0, thr);
             *reinterpret_cast<float4 *>(srec + lane * 8 + 4) = make_float4(cnon, nstar, log_z, en_prior); // (the last two: parked for this lane itself)
-#ifdef BL_RN_EXP_NOMAP
-            nch = has ? 1 : 0;
-            const int P = min(lane + 1, ns);
-#else
             const int P = bl_wave_iscan(nch);
-#endif
             BL_RN_T(2)
             // ---- P2: items.  Sites are packed whole into rounds of <= 64 lanes (a site has <= 16 items) ----
             int first = 0, base = 0;
@@ -274,21 +269,15 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                 const bool mine = lane >= first && lane < last;
                 const int start = P - nch - base;
                 // (a site's first three items without a loop -- their stores go out together; more than three: the rare tail)
-#ifndef BL_RN_EXP_NOMAP
 #pragma unroll
                 for (int c = 0; c < 3; c++)
                     if (mine && c < nch) imap[start + c] = (unsigned)lane | ((unsigned)c << 8) | ((unsigned)start << 16) | ((unsigned)nch << 24);
                 if (__any(mine && nch > 3))
                     for (int c = 3; __any(mine && c < nch); c++)
                         if (mine && c < nch) imap[start + c] = (unsigned)lane | ((unsigned)c << 8) | ((unsigned)start << 16) | ((unsigned)nch << 24);
-#endif
                 bl_wave_lds_fence(); // (also: the sites' dynamic visit slots are written)
                 const bool item = lane < nitems;
-#ifdef BL_RN_EXP_NOMAP
-                const unsigned im = (unsigned)min(lane, ns - 1) | ((unsigned)min(lane, ns - 1) << 16) | (1u << 24);
-#else
                 const unsigned im = imap[item ? lane : 0];
-#endif
                 const int sl = (int)(im & 0xFFu), ch = (int)((im >> 8) & 0xFFu), st = (int)((im >> 16) & 0xFFu), nc = (int)(im >> 24);
                 const int is = r0 + sl;
                 const float *ipv = data + (size_t)(is >> 1) * pstride + (is & 1) + 2 * (XQ + t * pb);
@@ -314,9 +303,6 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                 // J <= 10 (one group): the reciprocals 1 / b_jn, which pass C needs, are formed here and kept (80 registers), the
                 // product runs over them, and C is left with ten dot products -- no second recursion.
                 static_assert(BL_RN_GA == 10, "the product tree below is written for five pairs");
-#ifndef BL_RN_EXP_PAIRS
-#define BL_RN_EXP_PAIRS 5
-#endif
                 const bool one_group = J10 || J <= BL_RN_GA; // wave-uniform (a compile-time fact with J10)
                 bl_f2 rb[BL_RN_CH][5], q2k[5];
                 if (one_group) {
@@ -351,9 +337,7 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                     for (int n = 0; n < BL_RN_CH; n++) {
                         float rp[5]; // 1 / (b_x b_y) of every pair: ONE reciprocal serves both visits (1 / b_x = b_y rp), and prod_j 1 / b_j = prod rp
 #pragma unroll
-                        for (int g = 0; g < 5; g++) rp[g] = 1.0f, rb[n][g] = bl2(0.0f);
-#pragma unroll
-                        for (int g = 0; g < BL_RN_EXP_PAIRS; g++) {
+                        for (int g = 0; g < 5; g++) {
                             b2[g] = bl_fma2(b2[g], q2k[g], bl2(1.0f));
                             rp[g] = __builtin_amdgcn_rcpf(b2[g].x * b2[g].y);
                             rb[n][g] = bl_f2{b2[g].y, b2[g].x} * bl2(rp[g]);
@@ -416,9 +400,6 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                         rel = rel || (nf > i_nstar && fmaf(LP[n], BL_LN2, i_cnon * (i_nstar - nf)) >= i_thr);
                     }
                     rel = rel && item && i_nstar > 0.0f;
-#ifdef BL_RN_EXP_NOFLOOR
-                    rel = false;
-#endif
                     if (__any(rel)) {
                         const float nmax = n0f + (float)BL_RN_CH;
                         for (int j = 0; j < J; j++) {
@@ -454,7 +435,7 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
 #pragma unroll
                     for (int n = 0; n < BL_RN_CH; n++) {
 #pragma unroll
-                        for (int g = 0; g < BL_RN_EXP_PAIRS; g++) h[g] = bl_fma2(bl2(LP[n]), rb[n][g], h[g]);
+                        for (int g = 0; g < 5; g++) h[g] = bl_fma2(bl2(LP[n]), rb[n][g], h[g]);
                     }
                 }
                 if (multi) {
@@ -508,7 +489,7 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                 // q^n / b_n = 1 / b_n - r  (1 - q^n = r b_n):  sum_n (n w_n) / b_jn - r_j sum_n n w_n  -- no q^n recursion ----
                 if (one_group) {
 #pragma unroll
-                    for (int g = 0; g < 2 * BL_RN_EXP_PAIRS; g++) {
+                    for (int g = 0; g < BL_RN_GA; g++) {
                         if (g < J) { // wave-uniform
                             const float *wv = ipv + 2 * (g * VW);
                             // (q_j is read again rather than kept: ten registers less across the combine -- the kernel sits at its 256-register budget)
