@@ -12,7 +12,7 @@ from biolith_amd.evaluation import effective_sample_size, split_gelman_rubin
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("ks,ppa,seed,n_sites,k", [(0, 301, 0, 80, 0), (1, 91, 1, 80, 0), (1, 91, 2, 700, 3)])
+@pytest.mark.parametrize("ks,ppa,seed,n_sites,k", [(0, 301, 0, 80, 0), (1, 91, 1, 80, 0), (1, 61, 2, 700, 3)])   # (61 points per axis: the same moments to 8 digits as 91, a third of the oracle evaluations)
 def test_engine_nuts_samples_the_integrated_posterior(ks, ppa, seed, n_sites, k):
     X, W, Y = Q.tiny_occupancy_data(n_sites=n_sites, ks=ks, seed=seed)
     q = Q.grid_posterior(oracle.OracleData(X, W, Y), ppa)

@@ -1,7 +1,7 @@
 """The engine's random-effects sampler (csrc/re_kernel.hpp) against the EXACT marginal posterior of log sd (tests/quadrature_re.py):
 the assertions of tests/test_sampler_vs_quadrature_re.py -- an effective sample size of about a hundredth of the draws, the exact
 conditional law above the funnel's neck within Monte-Carlo errors at that effective size, a deficit below it of at most a fifth, and
-nothing worse at target_accept 0.99 than at numpyro's default 0.8 -- through the C-ABI, on runs long enough (4 x 60 000 draws) for
+nothing worse at target_accept 0.99 than at numpyro's default 0.8 -- through the C-ABI, on runs long enough (4 x 40 000 draws) for
 those errors to be about a hundredth.  Reference: biolith/models/occu.py:170-173, 191-196, 215-218."""
 import pytest
 
@@ -12,13 +12,13 @@ from test_sampler_vs_quadrature_re import check_log_sd_against_exact
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("site_re,seed", [(True, 1), (False, 1), (True, 3)])
+@pytest.mark.parametrize("site_re,seed", [(True, 1), (False, 1)])
 def test_engine_nuts_has_the_exact_law_of_log_sd_above_the_neck(site_re, seed):
     kernels = set()
 
     def sample(X, W, Y, acc):
         ds = OccuDataset(X, W, Y, model="occu_re", site_random_effects=site_re, obs_random_effects=not site_re)
-        r = ds.nuts(num_warmup=1000, num_samples=60000 if acc == 0.8 else 30000, num_chains=4, seed=0, target_accept=acc)
+        r = ds.nuts(num_warmup=1000, num_samples=40000 if acc == 0.8 else 16000, num_chains=4, seed=0, target_accept=acc)
         ds.close()
         assert int(r.diverging.sum()) <= 4
         kernels.add(r.kernel_name.strip())
