@@ -13,8 +13,9 @@ tests/test_gpu_sampler_vs_quadrature_re.py -- and what the comparison shows is a
      50 / 75 / 90 / 95 % points is the exact conditional CDF within 4 such standard errors (an implementation error -- a wrong Jacobian
      of the log scale, a wrong half step, a wrong prior on the effects -- would move these);
   2. what is missing is mass BELOW that point: between nothing and a fifth of the whole (`deficit`), never a surplus beyond the error;
-  3. smaller steps do not make it worse and reach further down: at target_accept 0.99 the deficit is not larger (within errors) than at
-     numpyro's default 0.8, and the lowest u visited is lower -- a fixed bias of the density would not care about the step size.
+  3. smaller steps do not make it worse: at target_accept 0.99 the deficit is not larger (within errors) than at numpyro's default 0.8
+     (on the long GPU runs it falls from 0.05 - 0.08 to 0.00 - 0.03 and the lowest u visited from about -3 to about -4:
+     profiles/r06/e_gpu_quadrature_re.txt) -- a fixed bias of the density would not care about the step size.
 """
 import numpy as np
 import pytest
@@ -45,7 +46,7 @@ def check_log_sd_against_exact(sample, ess_fn, site_re, seed):
             assert abs(cond - exact) <= 4.0 * se(exact, ess * (1.0 - F[0.25])) + 0.005, (acc, l, cond, exact, ess, F)
         out[acc] = dict(F=F, deficit=deficit, min_u=float(u.min()), ess=ess, se25=float(se(0.25)))
     assert out[0.99]["deficit"] <= out[0.8]["deficit"] + 4.0 * np.hypot(out[0.8]["se25"], out[0.99]["se25"]), out
-    assert out[0.99]["min_u"] < out[0.8]["min_u"], out
+    # (the lowest log sd visited is reported, not asserted: an extreme of chains this slow moves with the run's length and seed)
     return out, x
 
 
