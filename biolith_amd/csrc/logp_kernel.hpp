@@ -32,9 +32,13 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_logp_kernel(const BlLogpPara
     cnt = cnt < 0 ? 0 : (cnt > p.nloc ? p.nloc : cnt);
     const float *grows = nullptr;
     int ld = p.rec_stride;
+    if constexpr (MODEL == 1) { // occu_rn: the order its records are staged in, and the waves' shares of the sites (rn_device.hpp)
+        bl_rn_split_init<KS, KO, CW>(p.dd.rows, p.dd.n_stride, s0, cnt, p.dd.T, p.dd.J, p.rn_off);
+        __syncthreads();
+    }
     if constexpr (LDS) {
         for (int sp = 0; sp < nsp; sp++)
-            bl_stage_records(p.dd.rows, p.dd.n_stride, s0, cnt, p.dd.T, p.dd.J, KS, bl_layout_ko<MODEL>(KO), p.rec_stride, 64 * (CW + 1), sp, sp * p.sp_lds);
+            bl_stage_records(p.dd.rows, p.dd.n_stride, s0, cnt, p.dd.T, p.dd.J, KS, bl_layout_ko<MODEL>(KO), p.rec_stride, 64 * (CW + 1), sp, sp * p.sp_lds, MODEL == 1 ? bl_rn_order<CW>(p.rn_off, cnt) : nullptr);
     } else {
         grows = p.dd.rows + s0;
         ld = p.dd.n_stride;
@@ -55,11 +59,12 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_logp_kernel(const BlLogpPara
     if constexpr (MODEL == 8) my_pos = part_pos = bl_dyn_pos(lane < D ? lane : D, Ks, Ko, KS, KO); // dynamic occupancy (dyn_device.hpp)
     const bool part_all = MODEL != 8 && lane >= nsp * Dsp;
     const int part_rs = nsp > 1 ? nsp * BL_SP_PART(KS, KO) : BL_PART_STRIDE;
+    const int lane_grp = MODEL == 1 ? bl_rn_npos(p.rn_off) : p.lane_grp; // (occu_rn: its waves' shares of the sites, rn_device.hpp)
     for (int b = 0; b < p.B; b++) {
         if (wave == 0 && lane < D) sh_coef[my_pos] = p.theta[(size_t)b * D + lane];
         __syncthreads();
         if (wave > 0) { // compute waves, exactly as in the NUTS kernel
-            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, p.dd.T, p.dd.J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, (MODEL == 4 && p.nmix_lds) ? 2 * ((p.nloc + 1) / 2) : p.dd.n_stride, nsp, p.sp_lds, p.rn_off, p.lane_grp, p.nmix_lds);
+            bl_phase_a<KS, KO, LDS, MODEL, CW>(tid - 64, wave - 1, grows, ld, cnt, p.dd.T, p.dd.J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, (MODEL == 4 && p.nmix_lds) ? 2 * ((p.nloc + 1) / 2) : p.dd.n_stride, nsp, p.sp_lds, p.rn_off, lane_grp, p.nmix_lds);
         }
         __syncthreads();
         if (wave == 0) {

@@ -250,9 +250,13 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     cnt = cnt < 0 ? 0 : (cnt > p.nloc ? p.nloc : cnt);
     const float *grows = nullptr;
     int ld = p.rec_stride;
+    if constexpr (MODEL == 1) { // occu_rn: the order its records are staged in, and the waves' shares of the sites (rn_device.hpp)
+        bl_rn_split_init<KS, KO, CW>(p.rows, p.n_stride, s0, cnt, T, J, p.rn_off);
+        __syncthreads();
+    }
     if constexpr (LDS) {
         for (int sp = 0; sp < nsp; sp++)
-            bl_stage_records(p.rows, p.n_stride, s0, cnt, T, J, KS, bl_layout_ko<MODEL>(KO), p.rec_stride, 64 * (CW + 1), sp, sp * p.sp_lds);
+            bl_stage_records(p.rows, p.n_stride, s0, cnt, T, J, KS, bl_layout_ko<MODEL>(KO), p.rec_stride, 64 * (CW + 1), sp, sp * p.sp_lds, MODEL == 1 ? bl_rn_order<CW>(p.rn_off, cnt) : nullptr);
     } else {
         grows = p.rows + s0;
         ld = p.n_stride;
@@ -669,6 +673,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         // (profiles/r05/p_ab_compute_priority.txt).
         if constexpr (BL_COMPUTE_PRIO > 0 && MODEL != 1 && multi_wg) __builtin_amdgcn_s_setprio(BL_COMPUTE_PRIO);
         unsigned epoch_c = 0;  // evaluations so far = the exchange epoch of the one in flight (the control wave counts the same)
+        const int lane_grp = MODEL == 1 ? bl_rn_npos(p.rn_off) : p.lane_grp; // (occu_rn: its waves' shares of the sites, rn_device.hpp)
         while (true) {
             // The loop control of this tick (run status, "the exchange is L2-local") is read in ONE ds_read_b64 that is issued here
             // and looked at after the evaluation: read and tested first -- two dependent LDS round trips, as it was until round 3 --
@@ -679,7 +684,7 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
 #ifdef BL_STAMPS
             const long long st_a0 = (long long)clock64();
 #endif
-            bl_phase_a<KS, KO, LDS, MODEL, CW, GRP ? BL_GRP_FORM : 0, JSEL, ONE1>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, (MODEL == 4 && p.nmix_lds) ? 2 * ((p.nloc + 1) / 2) : p.n_stride, nsp, p.sp_lds, p.rn_off, p.lane_grp, p.nmix_lds);
+            bl_phase_a<KS, KO, LDS, MODEL, CW, GRP ? BL_GRP_FORM : 0, JSEL, ONE1>(tid - 64, wave - 1, grows, ld, cnt, T, J, p.max_abundance, p.fp_mode, p.nmix_tab + s0, (MODEL == 4 && p.nmix_lds) ? 2 * ((p.nloc + 1) / 2) : p.n_stride, nsp, p.sp_lds, p.rn_off, lane_grp, p.nmix_lds);
 #ifdef BL_STAMPS
             st_sub[5] += (long long)clock64() - st_a0; st_sub[4]++;
 #endif
@@ -1006,7 +1011,17 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         cold->dbg[14] = st_kc[0]; cold->dbg[15] = st_kc[1]; cold->dbg[7] = st_kc[2];
         for (int i = 0; i < 4; i++) cold->dbg[16 + i] = st_sub[i];
     }
-    if (cold->dbg && chain == 0 && member < 64 && wave >= 1 && wave <= 8 && (tid & 63) == 0) cold->dbg[32 + member * 8 + (wave - 1)] = st_sub[5];
+    if (cold->dbg && chain == 0 && member < 32 && wave >= 1 && wave <= 8 && (tid & 63) == 0) {
+        cold->dbg[32 + member * 8 + (wave - 1)] = st_sub[5];
+        unsigned hw; // where the hardware put this wave: HW_ID bits 5:4 = SIMD, 11:8 = CU, 3:0 = wave slot
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        cold->dbg[32 + 256 + member * 8 + (wave - 1)] = (long long)hw;
+    }
+    if (cold->dbg && chain == 0 && member < 32 && wave == 0 && tid == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        cold->dbg[32 + 256 + member * 8 + 7] = (long long)hw; // (the control wave's, in the eighth slot)
+    }
     if (cold->dbg && chain == 0 && member == 0 && tid == 64) { // first compute wave: site-evaluation passes and their cycles
         cold->dbg[20] = st_sub[4]; cold->dbg[21] = st_sub[5];
         if constexpr (MODEL == 1) for (int i = 0; i < 8; i++) cold->dbg[22 + i] = bl_rn_dbg[i];

@@ -1212,8 +1212,10 @@ __device__ __forceinline__ void bl_eval_sites(int ct, const float *__restrict__ 
 // site axis) into LDS pair records: element `pos` of site i lands at pair (i/2), float 2*pos + (i&1).
 // Joint-species datasets (species > 0): the HBM rows hold the site covariates once and then one block of visit / ka / kb rows
 // per species; every species gets a full record region of its own in LDS (lds_off floats from the first).
+// ord (occu_rn, rn_device.hpp): position i takes site ord[i] of the slice instead of site i.
 __device__ __forceinline__ void bl_stage_records(const float *__restrict__ rows, int n_stride, int s0, int cnt,
-                                                 int T, int J, int KS, int KO, int pstride, int nthreads, int species = 0, int lds_off = 0)
+                                                 int T, int J, int KS, int KO, int pstride, int nthreads, int species = 0, int lds_off = 0,
+                                                 const int *ord = nullptr)
 {
     float *dst = bl_lds_f(BL_OFF_DATA) + lds_off;
     const int xq = bl_round4(KS), pb = bl_period_block(J, KO), V = T * J, vw = KO + 1;
@@ -1232,7 +1234,7 @@ __device__ __forceinline__ void bl_stage_records(const float *__restrict__ rows,
         } else if (r < KS + V * vw + T) pos = xq + (r - KS - V * vw) * pb + J * vw;
         else pos = xq + (r - KS - V * vw - T) * pb + J * vw + 1;
         const float *src = rows + (size_t)(r < KS ? r : r + species_rows) * n_stride + s0;
-        for (int i = threadIdx.x; i < cnt; i += nthreads) dst[(size_t)(i >> 1) * pstride + 2 * pos + (i & 1)] = src[i];
+        for (int i = threadIdx.x; i < cnt; i += nthreads) dst[(size_t)(i >> 1) * pstride + 2 * pos + (i & 1)] = src[ord ? ord[i] : i];
     }
 }
 
@@ -1398,7 +1400,8 @@ __device__ __forceinline__ void bl_phase_a(int ct, int cwave, const float *__res
         }
     } else if constexpr (MODEL == 1) {
         static_assert(LDS, "Royle-Nichols model: LDS records only");
-        bl_eval_sites_rn<KS, KO, CW, JSEL == 10>(cwave, ld_or_stride, cnt, T, J, max_abundance, rn_off, beta, alpha, ll, gb, ga); // (JSEL == 10: J <= 10)
+        // (lane_grp carries bl_rn_npos for this model -- it has no lane groups: the caller reads it once per launch)
+        bl_eval_sites_rn<KS, KO, CW, JSEL == 10>(cwave, ld_or_stride, cnt, T, J, max_abundance, rn_off, lane_grp, beta, alpha, ll, gb, ga); // (JSEL == 10: J <= 10)
         bl_wave_partials_to_lds<KS, KO>(cwave, ll, gb, ga);
     } else if constexpr (MODEL == 3) {
         static_assert(LDS, "count occupancy model: LDS records only");

@@ -35,11 +35,19 @@
 #endif
 #define BL_RN_CH 8                     // n-terms per item
 #define BL_RN_LGT 144                  // floats of the shifted lgamma table: lgt[i] = lgamma(i + 2) = the entry of n = i + 1
-#define BL_RN_WAVE_FLOATS 1088         // wave-private scratch: site records 64 x 8, site results 64 x 4, item map 64, combine 64 x 4
+#define BL_RN_WAVE_FLOATS 1344         // wave-private scratch: site records 64 x 12, site results 64 x 4, item map 64, combine 64 x 4
 #define BL_RN_GA 10                    // visits whose b_n recursions run side by side in pass A1 (one log per group and n)
 #define BL_RN_G0 5                     // visits evaluated side by side in pass A0
+// The workgroup's ORDER of its sites (round 6): [sites with a detection, in their own order | sites without one], built once per launch
+// (bl_rn_split_init), and how many of the first kind there are.  Why: five compute waves and the control wave are six waves on four SIMDs,
+// so two compute waves share one -- the first and the last -- and the last one's evaluation used to end 2 400 cycles after everybody
+// else's (profiles/r06/c_stamps_rn_waves.txt: 14.7 k against 11.7 k cycles, in every workgroup): the tick waited for it.  A site WITHOUT a
+// detection needs no sum over n at all (closed form below), so those sites -- a third of BASELINE.json's config 4 -- are what the last
+// wave takes: a short stream beside the first wave's full one, while the sites with detections are shared by the other CW - 1 waves.
+#define BL_RN_ORD_MAX 508              // sites per workgroup up to which the order is kept (beyond: the plain equal shares)
+#define BL_RN_HDR (4 + BL_RN_ORD_MAX)  // ints behind the lgamma table: [0] sites with a detection when the split is on, else -1; [4 ...] the order
 // bytes of LDS behind the staged records that the occu_rn kernels need (host: choose_geometry)
-__host__ __device__ inline int bl_rn_scratch_bytes(int cw) { return 4 * (BL_RN_LGT + cw * BL_RN_WAVE_FLOATS); }
+__host__ __device__ inline int bl_rn_scratch_bytes(int cw) { return 4 * (BL_RN_LGT + BL_RN_HDR + cw * BL_RN_WAVE_FLOATS); }
 
 #ifdef BL_STAMPS
 static __device__ long long bl_rn_dbg[16];
@@ -82,6 +90,58 @@ __device__ __forceinline__ void bl_wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Once per launch, by the workgroup's first wave, IN FRONT of the staging of the records (a barrier between the two): the order of the
+// sites (see BL_RN_HDR; bl_stage_records places site ord[i] of the slice at position i, so the evaluator never looks at the order again)
+// and whether the split is on -- it is when there are sites of both kinds, the sites with a detection fit CW - 1 waves at two lanes
+// per site (<= 32 each: the two-lane visit pass), and the order fits its table.  Read from the HBM rows: row KS + v (KO + 2) holds
+// visit v's sign c (> 0: a detection) of every site.
+template <int KS, int KO, int CW>
+__device__ __forceinline__ void bl_rn_split_init(const float *__restrict__ rows, int n_stride, int s0, int cnt, int T, int J, int rn_off)
+{
+    if (threadIdx.x >= 64) return;
+    constexpr int VW = KO + 2;
+    const int lane = threadIdx.x, V = T * J;
+    int *hdr = reinterpret_cast<int *>(bl_lds_f(rn_off) + BL_RN_LGT);
+    int *ord = hdr + 4;
+    if (cnt > BL_RN_ORD_MAX || CW < 3) {
+        if (lane == 0) hdr[0] = -1;
+        return;
+    }
+    auto detected = [&](int i) -> bool {
+        bool det = false;
+        for (int v = 0; v < V; v++) det = det || rows[(size_t)(KS + v * VW) * n_stride + s0 + i] > 0.0f;
+        return det;
+    };
+    int npos = 0;
+    for (int base = 0; base < cnt; base += 64) {
+        const int i = base + lane;
+        npos += (int)__popcll(__ballot(i < cnt && detected(i)));
+    }
+    int p1 = 0, p0 = npos;
+    for (int base = 0; base < cnt; base += 64) {
+        const int i = base + lane;
+        const bool in = i < cnt, det = in && detected(i);
+        const unsigned long long m1 = __ballot(det), m0 = __ballot(in && !det);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (det) ord[p1 + (int)__popcll(m1 & below)] = i;
+        else if (in) ord[p0 + (int)__popcll(m0 & below)] = i;
+        p1 += (int)__popcll(m1);
+        p0 += (int)__popcll(m0);
+    }
+    const bool split = npos > 0 && npos < cnt && (npos + CW - 2) / (CW - 1) <= 32;
+    if (lane == 0) hdr[0] = split ? npos : -1;
+}
+// what bl_rn_split_init decided (behind the barrier that follows it): the sites with a detection when the split is on, else -1
+__device__ __forceinline__ int bl_rn_npos(int rn_off)
+{
+    return __builtin_amdgcn_readfirstlane(reinterpret_cast<const int *>(bl_lds_f(rn_off) + BL_RN_LGT)[0]);
+}
+// the order to stage the records in, or NULL when none was built (bl_stage_records)
+template <int CW> __device__ __forceinline__ const int *bl_rn_order(int rn_off, int cnt)
+{
+    return (cnt > BL_RN_ORD_MAX || CW < 3) ? nullptr : reinterpret_cast<const int *>(bl_lds_f(rn_off) + BL_RN_LGT) + 4;
+}
+
 // lower bound of max_n (n a - lgamma(n+1)) over 1 <= n <= K: evaluate at the Poisson mode with
 // lgamma(n+1) <= (n + 1/2) ln n - n + 1  (n >= 1)
 __device__ __forceinline__ float bl_rn_mode_lb(float a, float K)
@@ -97,8 +157,10 @@ __device__ __forceinline__ float bl_rn_mode_lb(float a, float K)
 // (a non-detection) or 0 (masked) -- so that the items read one float per visit instead of repeating the dot product and its exp / rcp.
 // J10: at most ten visits per period AND one period as compile-time facts (the sampler's instantiation for that case -- config 4 --
 // carries the one-group paths alone and no loop over periods)
+// n_pos: the workgroup's sites with a detection when the waves' shares are split (bl_rn_npos, read ONCE per launch by the caller: read
+// here, at every evaluation, it was an LDS round trip in front of everything else), -1 when they are not.
 template <int KS, int KO, int CW, bool J10 = false>
-__device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt, int T, int J, int K, int rn_off,
+__device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt, int T, int J, int K, int rn_off, int n_pos,
                                                  const float (&beta)[KS + 1], const float (&alpha)[KO + 1],
                                                  float &ll, float (&gb)[KS + 1], float (&ga)[KO + 1])
 {
@@ -108,11 +170,12 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
     const int pb = bl_period_block(J, KO + 1);
     float *data = bl_lds_f(BL_OFF_DATA);
     const float *lgt = bl_lds_f(rn_off);
-    float *wsc = bl_lds_f(rn_off) + BL_RN_LGT + cwave * BL_RN_WAVE_FLOATS;
-    float *srec = wsc;                                              // [64][8]  site lane -> item lanes
-    float *sres = wsc + 512;                                        // [64][4]  chunk-0 item lane -> site lane
-    unsigned *imap = reinterpret_cast<unsigned *>(wsc + 768);       // [64]     item -> site lane | chunk << 8 | first lane << 16 | chunks << 24
-    float *comb = wsc + 832;                                        // [64][4]  items of one site: max, sum, sum n w
+    float *wsc = bl_lds_f(rn_off) + BL_RN_LGT + BL_RN_HDR + cwave * BL_RN_WAVE_FLOATS;
+    constexpr int SR = 12;                                          // floats of a site's record
+    float *srec = wsc;                                              // [64][12] site lane -> item lanes (8), parked for the site lane itself (2)
+    float *sres = wsc + 768;                                        // [64][4]  chunk-0 item lane -> site lane
+    unsigned *imap = reinterpret_cast<unsigned *>(wsc + 1024);      // [64]     item -> site lane | chunk << 8 | first lane << 16 | chunks << 24
+    float *comb = wsc + 1088;                                       // [64][4]  items of one site: max, sum, sum n w
     const float LOG_TINY = -87.33654475f;
     const float FL = -15.942385f; // log(finfo(float32).eps)
     const float Kf = (float)K;
@@ -121,8 +184,19 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
     const bool st_on = blockIdx.x == 0 && threadIdx.x == 64;
     long long st_prev = (long long)clock64();
 #endif
-    const int spw = (cnt + CW - 1) / CW;
-    const int w0 = cwave * spw, w1 = min(cnt, w0 + spw);
+    // this wave's share of the workgroup's sites (staged in the order of bl_rn_split_init): the sites with a detection in equal shares
+    // over the first CW - 1 waves and the others to the last wave, or -- no split -- equal shares of all for everybody
+
+    int w0, w1;
+    if (n_pos >= 0) {
+        const int spw = (n_pos + CW - 2) / (CW - 1);
+        w0 = cwave < CW - 1 ? cwave * spw : n_pos;
+        w1 = cwave < CW - 1 ? min(n_pos, w0 + spw) : cnt;
+    } else {
+        const int spw = (cnt + CW - 1) / CW;
+        w0 = cwave * spw;
+        w1 = min(cnt, w0 + spw);
+    }
     for (int r0 = w0; r0 < w1; r0 += 64) {
         const int ns = min(64, w1 - r0);           // sites of this round (wave-uniform), one per lane
         // A round of <= 32 sites gives every site TWO lanes for its visits (l and l + 32 take half of them each and fold their
@@ -171,7 +245,9 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
         for (int t = 0; t < Tn; t++) {
             float *pv = rec + 2 * (XQ + t * pb);
             float cnon = 0.0f, clr = 0.0f, ndet = 0.0f;
-            float lqmin = 0.0f; // smallest log q over the non-detections
+            float lqmin = 0.0f; // smallest log q over the non-detections, the visit it belongs to, and the second smallest (numpyro's floor: below)
+            float lq2nd = 0.0f;
+            int jmin = 0;
             float Rv[KO + 1];
 #pragma unroll
             for (int k = 0; k <= KO; k++) Rv[k] = 0.0f;
@@ -198,7 +274,12 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                     clr += ld;
                     ndet += c > 0.0f ? 1.0f : 0.0f;
                     cnon += ln;
-                    lqmin = fminf(lqmin, ln);
+                    {   // (a visit that ties with the smallest counts as the second smallest)
+                        const bool lower = ln < lqmin;
+                        lq2nd = lower ? lqmin : fminf(lq2nd, ln);
+                        jmin = lower ? j : jmin;
+                        lqmin = fminf(lqmin, ln);
+                    }
                     // d/dnu of n log q is -n r: rank-1; dnu * (1, w) = r E[n] * (c, c w)
 #pragma unroll
                     for (int k = 0; k <= KO; k++) Rv[k] = fmaf(sm, w[k], Rv[k]);
@@ -213,7 +294,19 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                     const float lo = __uint_as_float(r[0]), hi = __uint_as_float(r[1]);
                     return take_min ? fminf(lo, hi) : lo + hi;
                 };
-                cnon = both(cnon, false); clr = both(clr, false); ndet = both(ndet, false); lqmin = both(lqmin, true);
+                cnon = both(cnon, false); clr = both(clr, false); ndet = both(ndet, false);
+                {   // the smallest two of the halves' four, and the smallest one's visit
+                    const auto rm = __builtin_amdgcn_permlane32_swap(__float_as_uint(lqmin), __float_as_uint(lqmin), false, false);
+                    const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(lq2nd), __float_as_uint(lq2nd), false, false);
+                    const auto rj = __builtin_amdgcn_permlane32_swap((unsigned)jmin, (unsigned)jmin, false, false);
+                    const bool up = lane >= 32;                       // r[0]: lane l's value, r[1]: lane l + 32's, in both lanes
+                    const float om = __uint_as_float(up ? rm[0] : rm[1]), o2 = __uint_as_float(up ? r2[0] : r2[1]);
+                    const int oj = (int)(up ? rj[0] : rj[1]);
+                    const bool lower = om < lqmin;
+                    lq2nd = lower ? fminf(lqmin, o2) : fminf(lq2nd, om);
+                    jmin = lower ? oj : jmin;
+                    lqmin = fminf(lqmin, om);
+                }
 #pragma unroll
                 for (int k = 0; k <= KO; k++) Rv[k] = both(Rv[k], false);
             }
@@ -229,16 +322,24 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
             // and the best term is at least m_lb = max(term_0, term_1, term at the mode of n a - lgamma(n+1), with log b >= 0).
             // The site keeps n up to the last g(n) >= thr = m_lb - 20 (what is dropped is below 2e-9 of the sum, per term).
             const float ea = bl_exp_f(fminf(a, 80.0f));
-            const float n1 = fminf(fmaxf(floorf(ea), 1.0f), Kf);
-            const float mode_lb = fmaf(n1, a, -(fmaf(n1 + 0.5f, BL_LN2 * __builtin_amdgcn_logf(n1), 1.0f - n1))); // (bl_rn_mode_lb)
-            const float thr = fmaxf(fmaxf(term0, a + clr), mode_lb + clr) - 20.0f;
             const float nstar = lqmin < 0.0f ? FL * __builtin_amdgcn_rcpf(lqmin) : 0.0f; // cnon = 0 when there is none
             const float shiftB = cnon * nstar;
+            // ---- NO detection in this (site, period): every term is p_n + sum_j max(n log q_j, FL) and, the floor aside, the sum over n is
+            // closed: sum_n e^(n a) / n! = e^(e^a), l = e^a - log Z, E[n | y] = e^a -- no items.  The truncation at K is covered by
+            // `closed` (e^a <= lambda: its tail beyond K is the smaller one); the floor RAISES terms beyond n* only, by at most
+            // sum_(n > n*) e^(p_n + n* cnon) <= e^(lambda + n* cnon) against a sum of at least 1 (the n = 0 term): dropped when that is
+            // below e^-20.  (A site that fails either test takes its item like any other.) ----
+            const bool zero_closed = has && ndet == 0.0f && closed && (lqmin == 0.0f || lam + shiftB <= -20.0f);
+            float thr = 0.0f;
+            int nch = (has && !zero_closed) ? 1 : 0;
+            if (__any(nch > 0)) {
+            const float n1 = fminf(fmaxf(floorf(ea), 1.0f), Kf);
+            const float mode_lb = fmaf(n1, a, -(fmaf(n1 + 0.5f, BL_LN2 * __builtin_amdgcn_logf(n1), 1.0f - n1))); // (bl_rn_mode_lb)
+            thr = fmaxf(fmaxf(term0, a + clr), mode_lb + clr) - 20.0f;
             // ---- the site's item count: chunk c (n = 8c+1 ..) is needed while some n >= 8c+1 has g(n) >= thr.  Per branch: its mode
             // is at or beyond 8c+1 (floor(e^a), whose value is >= thr; floor(lambda), with p_n <= lambda - 0.9 as the test) or, past the
             // mode where the branch falls, its value AT 8c+1 still reaches thr.  Monotone in c, so the chunks are counted until no
             // site of the wave needs another (two or three steps at the posterior). ----
-            int nch = has ? 1 : 0;
             {
                 const bool okB = lam - 0.9f + shiftB >= thr;
                 auto need_chunk = [&](int c) -> bool {
@@ -246,7 +347,7 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                     return (ea >= tn) || (fmaf(tn, a, -lg) >= thr) || (okB && lam >= tn) || (fmaf(tn, eta, -lg) + shiftB >= thr);
                 };
                 // (chunks 1 and 2 are tested unconditionally -- their table reads and compares go out together -- the rest by the loop)
-                bool need = has && cK >= 1 && need_chunk(1);
+                bool need = nch > 0 && cK >= 1 && need_chunk(1);
                 nch += need ? 1 : 0;
                 need = need && cK >= 2 && need_chunk(2);
                 nch += need ? 1 : 0;
@@ -255,13 +356,25 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                     nch += need ? 1 : 0;
                 }
             }
-            // record for the item lanes
-            *reinterpret_cast<float4 *>(srec + lane * 8) = make_float4(a, clr, term0, thr);
-            *reinterpret_cast<float4 *>(srec + lane * 8 + 4) = make_float4(cnon, nstar, log_z, en_prior); // (the last two: parked for this lane itself)
-            const int P = bl_wave_iscan(nch);
+            }
+            // record for the item lanes.  (A site in closed form has none: this lane leaves its result where the site's first item would --
+            // log2 of e^(e^a), the sum relative to it, sum n w_n relative to it -- and nothing is kept across the item round for it.)
+            // The FIRST visit to floor -- the non-detection with the smallest log q, visit jmin -- is stated exactly by every item without a
+            // branch (its log2 q rides in the record: max(n log q, FL) = n log q + max(0, FL - n log q)); what the items still test for,
+            // and treat by the loop over the visits when it matters, is the SECOND visit to floor, at n2* = FL / (second smallest log q):
+            // beyond it the other non-detections' sum is at most n2* (cnon - lqmin).  (Round 6: with the first floor behind the test, a
+            // wave held such a site in every other workgroup and its evaluation took 14.8 k cycles where the others took 12.4 k --
+            // profiles/r06/h_*; no site of config 4 needs the second floor at the posterior.)
+            const float nstar2 = lq2nd < 0.0f ? FL * __builtin_amdgcn_rcpf(lq2nd) : 0.0f;
+            *reinterpret_cast<float4 *>(srec + lane * SR) = make_float4(a, clr, term0, thr);
+            if (zero_closed) *reinterpret_cast<float4 *>(sres + lane * 4) = make_float4(ea * BL_LOG2E, 1.0f, ea, 0.0f);
+            *reinterpret_cast<float4 *>(srec + lane * SR + 4) = make_float4(cnon - lqmin, nstar2, lqmin * BL_LOG2E, __int_as_float(jmin));
+            *reinterpret_cast<float2 *>(srec + lane * SR + 8) = make_float2(log_z, en_prior); // (parked for this lane itself)
+            const bool any_item = __any(nch > 0);    // (a wave of sites without detections has none: no item round at all)
+            const int P = any_item ? bl_wave_iscan(nch) : 0;
             BL_RN_T(2)
             // ---- P2: items.  Sites are packed whole into rounds of <= 64 lanes (a site has <= 16 items) ----
-            int first = 0, base = 0;
+            int first = any_item ? 0 : ns, base = 0;
             while (first < ns) {
                 const unsigned long long fit = __ballot(P - base <= 64);    // a prefix of the lanes (P is non-decreasing)
                 const int last = min(ns, (int)__popcll(fit));               // sites [first, last) go into this round
@@ -281,8 +394,10 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                 const int sl = (int)(im & 0xFFu), ch = (int)((im >> 8) & 0xFFu), st = (int)((im >> 16) & 0xFFu), nc = (int)(im >> 24);
                 const int is = r0 + sl;
                 const float *ipv = data + (size_t)(is >> 1) * pstride + (is & 1) + 2 * (XQ + t * pb);
-                const float4 s0v = *reinterpret_cast<const float4 *>(srec + sl * 8);
+                const float4 s0v = *reinterpret_cast<const float4 *>(srec + sl * SR);
+                const float4 s1v = *reinterpret_cast<const float4 *>(srec + sl * SR + 4);
                 const float i_a = s0v.x, i_clr = s0v.y, i_term0 = s0v.z, i_thr = s0v.w;
+                const float i_lq1 = s1v.z;                       // log2 q of the site's first visit to floor (0: no non-detection)
                 const bool deep = __any(ch > 0);                // some item is not a chunk 0: the recursions' starting values are needed
                 const bool multi = __any(nc > 1);               // some site has several items: combine through LDS
                 const float n0f = (float)(ch * BL_RN_CH);
@@ -294,7 +409,10 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                     const float4 l1 = *reinterpret_cast<const float4 *>(lgt + ch * BL_RN_CH + 4);
                     const float lg[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
 #pragma unroll
-                    for (int q = 0; q < BL_RN_CH; q++) LP[q] = (fmaf(n0f + (float)(q + 1), i_a, -lg[q]) + i_clr) * BL_LOG2E;
+                    for (int q = 0; q < BL_RN_CH; q++) {
+                        const float nf = n0f + (float)(q + 1);
+                        LP[q] = fmaf(fmaf(nf, i_a, -lg[q]) + i_clr, BL_LOG2E, fmaxf(fmaf(-nf, i_lq1, -23.0f), 0.0f)); // (+ the first floor; log2(eps_f32) = -23)
+                    }
                 }
                 // ---- A1: LP[n] += sum over detection visits of log2 b_n ----
                 // Visits are taken BL_RN_GA at a time, their b_n recursions side by side as five packed pairs, and ONE log per n for
@@ -385,25 +503,25 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                     }
                 }
                 BL_RN_T(4)
-                // ---- A1b: numpyro's floor.  Beyond n* the TRUE term is at most p_n + n* cnon + clr + sum log b = LP[n] + cnon (n* - n):
-                // only an item with such an n within 20 nats of m_lb needs the correction LP[n] += sum_j max(0, FL - n log q_j), and then
-                // only for the visits whose floor one of its n reaches (taking the floor where it does not matter is still the
-                // model, so a visit picked by any lane is corrected in all).  About one site in a hundred at the posterior. ----
+                // ---- A1b: numpyro's floor, second visit onwards (the first is in LP already).  Beyond n2* the TRUE term is at most
+                // LP[n] + (cnon - lqmin) (n2* - n): only an item with such an n within 20 nats of m_lb needs LP[n] += sum_j max(0, FL - n log q_j)
+                // over the OTHER visits, and then only for those whose floor one of its n reaches (taking the floor where it does not
+                // matter is still the model, so a visit picked by any lane is corrected in all). ----
                 unsigned long long floored = 0ull; // wave-uniform: visits (bit j & 63) that took the correction
                 {
-                    const float2 s1v = *reinterpret_cast<const float2 *>(srec + sl * 8 + 4);
-                    const float i_cnon = s1v.x, i_nstar = s1v.y;
+                    const float i_cnon1 = s1v.x, i_nstar2 = s1v.y;
                     bool rel = false;
 #pragma unroll
                     for (int n = 0; n < BL_RN_CH; n++) {
                         const float nf = n0f + (float)(n + 1);
-                        rel = rel || (nf > i_nstar && fmaf(LP[n], BL_LN2, i_cnon * (i_nstar - nf)) >= i_thr);
+                        rel = rel || (nf > i_nstar2 && fmaf(LP[n], BL_LN2, i_cnon1 * (i_nstar2 - nf)) >= i_thr);
                     }
-                    rel = rel && item && i_nstar > 0.0f;
+                    rel = rel && item && i_nstar2 > 0.0f;
                     if (__any(rel)) {
                         const float nmax = n0f + (float)BL_RN_CH;
+                        const int i_j1 = __float_as_int(s1v.w);
                         for (int j = 0; j < J; j++) {
-                            const float lq2 = fminf(ipv[2 * (j * VW + KO + 1)], 0.0f); // log2 q of a non-detection, else 0
+                            const float lq2 = j == i_j1 ? 0.0f : fminf(ipv[2 * (j * VW + KO + 1)], 0.0f); // log2 q of a non-detection other than the first to floor, else 0
                             if (!__any(rel && nmax * lq2 < -23.0f)) continue;          // log2(eps_f32) = -23
                             floored |= 1ull << (j & 63);
 #pragma unroll
@@ -470,12 +588,28 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                 if (item && ch == 0) *reinterpret_cast<float4 *>(sres + sl * 4) = make_float4(m_s, S, a1, 0.0f);
                 const float rs = item ? f_it * __builtin_amdgcn_rcpf(S) : 0.0f;
                 BL_RN_T(5)
-                // floored visits: d/du max(n log sigma(u), FL) vanishes for the floored n -- take their n w_n back out of the rank-1 part
+                // floored visits: d/du max(n log sigma(u), FL) vanishes for the floored n -- take their n w_n back out of the rank-1 part.
+                // The first visit to floor: its share is formed by every item (LP holds n w_n here) and is zero wherever no n of the item
+                // lies beyond n*; the visit's covariates are fetched only by a wave in which some item has one.
+                {
+                    float hf1 = 0.0f;
+#pragma unroll
+                    for (int n = 0; n < BL_RN_CH; n++) hf1 += ((n0f + (float)(n + 1)) * i_lq1 < -23.0f) ? LP[n] : 0.0f;
+                    // (hf1 rs = the posterior mass, times n, that the item holds beyond n*: below 2e-9 it is dropped like every term the
+                    // sites' thresholds drop)
+                    if (__any(hf1 * rs > 2.0e-9f)) {
+                        const float *wv = ipv + 2 * (__float_as_int(*(srec + sl * SR + 7)) * VW);
+                        const float dnu = -(1.0f - __builtin_amdgcn_exp2f(i_lq1)) * hf1 * rs; // r = 1 - q of that non-detection
+#pragma unroll
+                        for (int k = 0; k <= KO; k++) ga[k] = fmaf(dnu, wv[2 * k], ga[k]);
+                    }
+                }
                 if (floored != 0ull) {
+                    const int i_j1 = __float_as_int(*(srec + sl * SR + 7));
                     for (int j = 0; j < J; j++) {
                         if (!((floored >> (j & 63)) & 1ull)) continue;
                         const float *wv = ipv + 2 * (j * VW);
-                        const float lq2 = fminf(wv[2 * (KO + 1)], 0.0f);
+                        const float lq2 = j == i_j1 ? 0.0f : fminf(wv[2 * (KO + 1)], 0.0f);
                         const float sm = 1.0f - __builtin_amdgcn_exp2f(lq2); // r = sigma(-u) of a non-detection (a floor is reached where q <= 0.88)
                         float hf = 0.0f;
 #pragma unroll
@@ -536,7 +670,7 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
             float4 res = *reinterpret_cast<const float4 *>(sres + lane * 4);
             if (!has) res = make_float4(0.0f, 1.0f, 0.0f, 0.0f); // (no item wrote this lane's slot)
             const float en_post = res.z * __builtin_amdgcn_rcpf(res.y);
-            const float2 parked = *reinterpret_cast<const float2 *>(srec + lane * 8 + 6);   // log Z, E[n] of the prior
+            const float2 parked = *reinterpret_cast<const float2 *>(srec + lane * SR + 8);  // log Z, E[n] of the prior
             ll_s += BL_LN2 * (res.x + __builtin_amdgcn_logf(res.y)) - parked.x;
             deta += en_post - parked.y;
             const float enl = live * en_post;

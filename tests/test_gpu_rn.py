@@ -212,3 +212,53 @@ def test_rn_covariate_capacities(ks, ko):
     assert r.num_steps.mean() < 40 and np.all(r.step_size > 0.05) and r.diverging.sum() == 0
     want = np.concatenate([t["beta"][0], t["alpha"][0]])
     assert np.abs(r.draws.reshape(-1, od.D).mean(0) - want).max() < 0.5   # the reference's coefficient tolerance
+
+
+def _rn_data(rng, n_sites, n_visits, share_without_detection, n_periods=1, r_hi=False):
+    """Royle-Nichols data by construction: a share of the sites has no detection at all (closed form in the kernel; the last compute
+    wave's share of a workgroup when the split is on), the others at least one.  r_hi: detection probabilities near one at a few
+    non-detections, so that numpyro's floor of n log q matters (occu_rn.py:216-219 through clamp_probs)."""
+    X = rng.normal(size=(n_sites, 2)).astype(np.float32)
+    W = rng.normal(size=(n_sites, n_periods, n_visits, 2)).astype(np.float32)
+    Y = (rng.uniform(size=(1, n_sites, n_periods, n_visits)) < 0.35) * 1.0
+    none = rng.uniform(size=n_sites) < share_without_detection
+    Y[0, none] = 0.0
+    some = ~none & (Y[0].reshape(n_sites, -1).sum(1) == 0)
+    Y[0, some, 0, 0] = 1.0
+    Y[rng.uniform(size=Y.shape) < 0.05] = np.nan
+    if r_hi:
+        W[:: 7, :, 1, :] = 6.0      # |nu| large at one visit of every seventh site
+    return X, W, Y.astype(np.float32)
+
+
+@pytest.mark.parametrize("n_sites,share,n_periods,r_hi,k", [
+    (5000, 0.34, 1, False, 0),    # config 4's proportions: the split is on (32 workgroups x (4 x 26 + 53))
+    (5000, 0.34, 1, True, 0),     # ... with floored non-detections within reach
+    (5000, 0.0, 1, False, 0),     # every site with a detection: no split (equal shares for five waves)
+    (5000, 1.0, 1, False, 0),     # no detection anywhere: no split, every site in closed form, no item round at all
+    (5000, 0.05, 1, False, 0),    # few sites without one: their wave is nearly idle -- the detected ones do not fit four waves at two lanes: no split
+    (5000, 0.9, 1, False, 0),     # mostly without
+    (700, 0.4, 3, False, 0),      # several periods: a site counts as detected if any period has one; closed form per (site, period)
+    (40000, 0.34, 1, False, 0),   # more than 508 sites per workgroup: no order table, plain shares
+    (313, 0.3, 1, True, 2),       # two workgroups, odd counts
+])
+def test_rn_wave_shares_and_closed_form(n_sites, share, n_periods, r_hi, k):
+    """Round 6 (rn_device.hpp): a workgroup stages its sites with a detection first and gives the others -- closed form, no sum over n --
+    to its last compute wave; the first visit to floor is stated without a branch.  K1 against the float64 oracle on every branch of
+    that logic, and a short sampler run that must build the oracle's first trees."""
+    rng = np.random.default_rng(n_sites + int(100 * share) + n_periods)
+    X, W, Y = _rn_data(rng, n_sites, 10, share, n_periods, r_hi)
+    od = oracle.OracleData(X, W, Y, model="occu_rn")
+    ds = OccuDataset(X, W, Y, model="occu_rn")
+    th = np.concatenate([rng.uniform(-1.0, 1.0, size=(3, od.D)), [[0.3, 0.2, -0.1, 2.5, 0.5, -0.5]], [[1.5, 0.1, 0.1, -1.0, 0.2, 0.2]]]).astype(np.float32).astype(np.float64)
+    Uo, Go = od.potential_grad(th)
+    Ug, Gg = ds.logp_grad(th)
+    assert np.all(np.isfinite(Ug)) and np.all(np.isfinite(Gg))
+    assert np.max(np.abs(Ug - Uo) / np.abs(Uo)) <= 1e-5, (Ug, Uo)
+    assert np.max(np.abs(Gg - Go) / np.abs(Go).max(1, keepdims=True)) <= 1e-4, np.abs(Gg - Go).max(1) / np.abs(Go).max(1)
+    if n_sites <= 5000:
+        o = oracle.nuts_run(od, 0, 3, num_chains=2, seed=5)
+        r = ds.nuts(num_warmup=0, num_samples=3, num_chains=2, seed=5, wgs_per_chain=k)
+        assert np.array_equal(o["num_steps"][:, :2], r.num_steps[:, :2]), (o["num_steps"], r.num_steps)
+        assert np.allclose(o["draws"][:, 0], r.draws[:, 0], atol=3e-3)
+    ds.close()

@@ -129,7 +129,8 @@ def test_reference_rn_site_random_effects():
 def test_reference_rn_obs_random_effects():
     """occu_rn.py:466-487."""
     data, truth = _data()
-    res = fit(occu_rn, **data, obs_random_effects=True, num_chains=1, num_samples=500, timeout=600)
+    # (num_warmup 500 as above: 165 s of the GPU suite at fit()'s default 1000 -- 5 300 effects, 1.5 ms per leapfrog)
+    res = fit(occu_rn, **data, obs_random_effects=True, num_chains=1, num_warmup=500, num_samples=500, timeout=600)
     s = res.samples
     assert "obs_re_sd" in s and "obs_re" in s
     assert s["obs_re_sd"].mean() > 0

@@ -22,3 +22,9 @@ print(f"k={k} passes {passes}; per-wave site-evaluation cycles (mean over passes
 print("per workgroup (rows) x wave:")
 for b in range(k):
     print("  ", b, " ".join(f"{x:6.0f}" for x in w[b]))
+hw = c[32 + 256:32 + 256 + 8 * k].reshape(k, 8)
+print("SIMD of [compute waves 0..4 | control wave] per workgroup (HW_ID bits 5:4), and which compute waves share one:")
+for b in range(k):
+    simd = [(int(x) >> 4) & 3 for x in list(hw[b, :cw]) + [hw[b, 7]]]
+    pairs = [(i, j) for i in range(cw + 1) for j in range(i + 1, cw + 1) if simd[i] == simd[j]]
+    print("  ", b, simd, " shared:", [("c%d" % i if i < cw else "ctl", "c%d" % j if j < cw else "ctl") for i, j in pairs], " cycles", " ".join(f"{x:.0f}" for x in w[b]))
