@@ -286,7 +286,8 @@ def algorithmic_bytes_per_eval(N, T, J, Ks, Ko, S=1):
 def rn_executed_terms(data, theta, Ks, K=100, chunk=8, nats=20.0):
     """(n, visit) terms the Royle-Nichols evaluator EXECUTES per gradient evaluation at coefficients `theta` (the posterior mean of the
     run): every site keeps the n whose term is within `nats` of its largest (rn_device.hpp's rule, restated in NumPy as
-    tools/rn_workload_stats.py does), in items of `chunk` consecutive n over all J visits.  Returns (executed, items)."""
+    tools/rn_workload_stats.py does), in items of `chunk` consecutive n over all J visits; a site without a detection has a closed
+    form and no items (rn_device.hpp).  Returns (executed, items)."""
     import numpy as np
     from scipy.special import gammaln
 
@@ -305,7 +306,8 @@ def rn_executed_terms(data, theta, Ks, K=100, chunk=8, nats=20.0):
         L = L + np.where((Y == 1)[:, :, None], np.log1p(-np.exp(lq[:, :, None] * n[None, None, :])), 0.0).sum(1)
     keep = L >= L.max(1)[:, None] - nats
     cut = np.array([np.max(np.nonzero(k)[0]) for k in keep])
-    items = int(np.ceil(cut / chunk).clip(1).sum())
+    detected = np.nansum(Y == 1, axis=1) > 0      # (a site without a detection is in closed form since round 6: no items)
+    items = int((np.ceil(cut / chunk).clip(1) * detected).sum())
     return items * chunk * Y.shape[1], items
 
 
