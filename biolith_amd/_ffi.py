@@ -133,8 +133,9 @@ def load():
         L.bl_nuts_geometry.argtypes = [vp, ip, ip, ip, ip, ip]
         L.bl_nuts_lane_group.argtypes = [vp, ip, ip]
         L.bl_nuts_kernel_name.argtypes = [vp, C.c_char_p, C.c_int]
-        L.bl_nuts_env_overrides.argtypes = [vp, C.c_char_p, C.c_int]
-        L.bl_env_overrides.argtypes = [C.c_char_p, C.c_int]
+        if hasattr(L, "bl_nuts_env_overrides"):   # (absent from libraries built before round 6: tools/ A/B them by name, BIOLITH_HIP_LIB)
+            L.bl_nuts_env_overrides.argtypes = [vp, C.c_char_p, C.c_int]
+            L.bl_env_overrides.argtypes = [C.c_char_p, C.c_int]
         L.bl_nuts_debug_counters.argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
         L.bl_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
         L.bl_host_free.argtypes = [C.c_void_p]
@@ -155,7 +156,7 @@ def load():
         L.bl_result_block_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
         L.bl_gather_unpack.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(bl_nuts_output)]
         for name in EXPORTS:
-            if name != "bl_last_error":
+            if name != "bl_last_error" and (hasattr(L, name) or name not in ("bl_nuts_env_overrides", "bl_env_overrides")):
                 getattr(L, name).restype = C.c_int
         if L.bl_abi_version() != 1:
             raise RuntimeError("libbiolith_hip.so ABI version mismatch")

@@ -341,6 +341,8 @@ class OccuDataset:
 
     def env_overrides(self) -> str:
         """BIOLITH_HIP_* knobs that were set when the last launch read the environment ("" = none; bl_nuts_env_overrides)."""
+        if not hasattr(self._lib, "bl_nuts_env_overrides"):   # (a library built before round 6, loaded by name for an A/B)
+            return ""
         buf = C.create_string_buffer(512)
         _ffi.check(self._lib.bl_nuts_env_overrides(self._h, buf, 512))
         return buf.value.decode()
