@@ -23,6 +23,12 @@
 //       the items that hold a term it can matter for (a bound per term, no per-site flags).
 //       The item for chunk 0 also carries the n = 0 term and hands (max, sum, sum n w) back to the site's lane.
 //
+// Round 6 (from per-wave and per-SIMD stamps, profiles/r06): a (site, period) without a detection takes NO item -- its sum over n is closed
+// (e^(e^a)) whenever the truncation at K and numpyro's floor provably cannot matter; a workgroup stages its sites with a detection first
+// and, when they fit CW - 1 waves, gives the others to its LAST compute wave -- the one that shares a SIMD with the first -- whose stream
+// is then the visit pass alone; and the first non-detection to reach numpyro's floor is stated by every item without a branch (the loop
+// over the visits remains for a second one).
+//
 // Work is then sum_sites ceil(cutoff / 8) items of 8 terms instead of 64 x (wave's largest cutoff) per wave, the per-lane
 // table is 8 registers, and a workgroup runs 5 compute waves + the control wave (six waves on four SIMDs): a wave's instruction
 // stream is the same however few of its lanes are busy, so the count is the one that fills the lanes (31 sites, 46 items per wave at
@@ -34,6 +40,9 @@
                                        // 5 -> 9.5, 6 -> 10.0, 7 -> 9.9, 11 -> 13.5, 15 -> 16.0 us per leapfrog)
 #endif
 #define BL_RN_CH 8                     // n-terms per item
+#ifndef BL_RN_CHUNK3
+#define BL_RN_CHUNK3 1                 // the third chunk's test without a loop round (0: A/B; 7.55 -> 7.42 us per leapfrog, profiles/r06/m_rn_trims.txt)
+#endif
 #define BL_RN_LGT 144                  // floats of the shifted lgamma table: lgt[i] = lgamma(i + 2) = the entry of n = i + 1
 #define BL_RN_WAVE_FLOATS 1344         // wave-private scratch: site records 64 x 12, site results 64 x 4, item map 64, combine 64 x 4
 #define BL_RN_GA 10                    // visits whose b_n recursions run side by side in pass A1 (one log per group and n)
@@ -186,7 +195,6 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
 #endif
     // this wave's share of the workgroup's sites (staged in the order of bl_rn_split_init): the sites with a detection in equal shares
     // over the first CW - 1 waves and the others to the last wave, or -- no split -- equal shares of all for everybody
-
     int w0, w1;
     if (n_pos >= 0) {
         const int spw = (n_pos + CW - 2) / (CW - 1);
@@ -346,12 +354,16 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                     const float tn = (float)(c * BL_RN_CH + 1), lg = lgt[c * BL_RN_CH];
                     return (ea >= tn) || (fmaf(tn, a, -lg) >= thr) || (okB && lam >= tn) || (fmaf(tn, eta, -lg) + shiftB >= thr);
                 };
-                // (chunks 1 and 2 are tested unconditionally -- their table reads and compares go out together -- the rest by the loop)
+                // (chunks 1, 2 and 3 are tested unconditionally -- their table reads and compares go out together -- the rest by the loop)
                 bool need = nch > 0 && cK >= 1 && need_chunk(1);
                 nch += need ? 1 : 0;
                 need = need && cK >= 2 && need_chunk(2);
                 nch += need ? 1 : 0;
-                for (int c = 3; c <= cK && __any(need); c++) {
+#if BL_RN_CHUNK3
+                need = need && cK >= 3 && need_chunk(3);
+                nch += need ? 1 : 0;
+#endif
+                for (int c = 3 + BL_RN_CHUNK3; c <= cK && __any(need); c++) {
                     need = need && need_chunk(c);
                     nch += need ? 1 : 0;
                 }
