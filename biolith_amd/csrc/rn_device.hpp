@@ -40,8 +40,15 @@
                                        // 5 -> 9.5, 6 -> 10.0, 7 -> 9.9, 11 -> 13.5, 15 -> 16.0 us per leapfrog)
 #endif
 #define BL_RN_CH 8                     // n-terms per item
-#ifndef BL_RN_CHUNK3
-#define BL_RN_CHUNK3 1                 // the third chunk's test without a loop round (0: A/B; 7.55 -> 7.42 us per leapfrog, profiles/r06/m_rn_trims.txt)
+// Items of a site whose chunk tests / item-map stores are made without a loop.  Same-box A/B of both at once (profiles/r06/o_time_rn_unroll.txt,
+// us per leapfrog of the slowest chain): 3: 7.55 | 4: 7.46 | 5: 7.61 | 6: 7.58 -- a wave that holds a site of four or five items pays ~400
+// cycles per loop round (o_stamps_rn_slow_and_typical_wave.txt) and is the slowest of its chain, but every further unconditional test
+// costs all 128 main waves; tests 4 with stores 3 measured 7.42 and is what ships.
+#ifndef BL_RN_UNR_TESTS
+#define BL_RN_UNR_TESTS 4
+#endif
+#ifndef BL_RN_UNR_STORES
+#define BL_RN_UNR_STORES 3
 #endif
 #define BL_RN_LGT 144                  // floats of the shifted lgamma table: lgt[i] = lgamma(i + 2) = the entry of n = i + 1
 #define BL_RN_WAVE_FLOATS 1344         // wave-private scratch: site records 64 x 12, site results 64 x 4, item map 64, combine 64 x 4
@@ -190,7 +197,11 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
     const float Kf = (float)K;
     const int cK = (K - 1) / BL_RN_CH;         // last chunk that holds an n <= K
 #ifdef BL_STAMPS
-    const bool st_on = blockIdx.x == 0 && threadIdx.x == 64;
+#ifndef BL_RN_STAMP_WG
+#define BL_RN_STAMP_WG 0     // the workgroup (of chain 0) and the compute wave whose stages are stamped (tools/stamps_rn.py)
+#define BL_RN_STAMP_WAVE 0
+#endif
+    const bool st_on = blockIdx.x == 8 * BL_RN_STAMP_WG && threadIdx.x == 64 * (BL_RN_STAMP_WAVE + 1); // (chain 0, member BL_RN_STAMP_WG: the XCD-aware block mapping of nuts_kernel.hpp)
     long long st_prev = (long long)clock64();
 #endif
     // this wave's share of the workgroup's sites (staged in the order of bl_rn_split_init): the sites with a detection in equal shares
@@ -354,16 +365,15 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                     const float tn = (float)(c * BL_RN_CH + 1), lg = lgt[c * BL_RN_CH];
                     return (ea >= tn) || (fmaf(tn, a, -lg) >= thr) || (okB && lam >= tn) || (fmaf(tn, eta, -lg) + shiftB >= thr);
                 };
-                // (chunks 1, 2 and 3 are tested unconditionally -- their table reads and compares go out together -- the rest by the loop)
-                bool need = nch > 0 && cK >= 1 && need_chunk(1);
-                nch += need ? 1 : 0;
-                need = need && cK >= 2 && need_chunk(2);
-                nch += need ? 1 : 0;
-#if BL_RN_CHUNK3
-                need = need && cK >= 3 && need_chunk(3);
-                nch += need ? 1 : 0;
-#endif
-                for (int c = 3 + BL_RN_CHUNK3; c <= cK && __any(need); c++) {
+                // (the first BL_RN_UNR_TESTS - 1 further chunks are tested unconditionally -- their table reads and compares go out together --
+                // the rest by the loop: a round of it is an LDS read, a wave-wide `any` and a branch, ~400 cycles beside the other wave)
+                bool need = nch > 0;
+#pragma unroll
+                for (int c = 1; c < BL_RN_UNR_TESTS; c++) {
+                    need = need && cK >= c && need_chunk(c);
+                    nch += need ? 1 : 0;
+                }
+                for (int c = BL_RN_UNR_TESTS; c <= cK && __any(need); c++) {
                     need = need && need_chunk(c);
                     nch += need ? 1 : 0;
                 }
@@ -393,12 +403,12 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                 const int nitems = __builtin_amdgcn_readlane(P, last - 1) - base;
                 const bool mine = lane >= first && lane < last;
                 const int start = P - nch - base;
-                // (a site's first three items without a loop -- their stores go out together; more than three: the rare tail)
+                // (a site's first BL_RN_UNR_STORES items without a loop -- their stores go out together; more: the rare tail)
 #pragma unroll
-                for (int c = 0; c < 3; c++)
+                for (int c = 0; c < BL_RN_UNR_STORES; c++)
                     if (mine && c < nch) imap[start + c] = (unsigned)lane | ((unsigned)c << 8) | ((unsigned)start << 16) | ((unsigned)nch << 24);
-                if (__any(mine && nch > 3))
-                    for (int c = 3; __any(mine && c < nch); c++)
+                if (__any(mine && nch > BL_RN_UNR_STORES))
+                    for (int c = BL_RN_UNR_STORES; __any(mine && c < nch); c++)
                         if (mine && c < nch) imap[start + c] = (unsigned)lane | ((unsigned)c << 8) | ((unsigned)start << 16) | ((unsigned)nch << 24);
                 bl_wave_lds_fence(); // (also: the sites' dynamic visit slots are written)
                 const bool item = lane < nitems;

@@ -87,3 +87,11 @@ for i in np.nonzero(d>0)[0]:
         k2=kept[kept>nstar2[i]]
         if len(k2): rel2[i]=np.any(Lc[k2]+(cnon[i]-lq1[i])*(nstar2[i]-k2) >= Lc.max()-20)
 print("d>0 sites:", (d>0).sum(), " rel (first floor)", (rel&(d>0)).sum(), " rel2 (second floor after the first is exact)", rel2.sum())
+for m in sorted(set(feat["max"].ravel())):
+    s = feat["max"] == m
+    print(f"main waves whose largest site has {int(m)} items: {int(s.sum()):3d}, mean cycles {c[s].mean():.0f}, max {c[s].max():.0f}")
+order = np.argsort(-c.ravel())[:14]
+print("slowest main waves: cycles, items at the posterior mean, largest site:", [(int(c.ravel()[i]), int(feat["items"].ravel()[i]), int(feat["max"].ravel()[i])) for i in order])
+for lo, hi in ((0, 40), (40, 46), (46, 52), (52, 70)):
+    m = (feat["items"] >= lo) & (feat["items"] < hi)
+    print(f"items {lo}-{hi}: waves {int(m.sum()):3d} mean cycles {c[m].mean():.0f}")
