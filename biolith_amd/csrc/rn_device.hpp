@@ -44,6 +44,10 @@
 // us per leapfrog of the slowest chain): 3: 7.55 | 4: 7.46 | 5: 7.61 | 6: 7.58 -- a wave that holds a site of four or five items pays ~400
 // cycles per loop round (o_stamps_rn_slow_and_typical_wave.txt) and is the slowest of its chain, but every further unconditional test
 // costs all 128 main waves; tests 4 with stores 3 measured 7.42 and is what ships.
+#ifndef BL_RN_TWO_PER_ROUND
+#define BL_RN_TWO_PER_ROUND 1          // the rare loops (chunk count beyond the unrolled tests, item map's tail, the recursions' start values) take two steps a
+                                       // round (0: A/B; 7.44 -> 7.38 us per leapfrog, profiles/r06/q_time_rn_rare_loops.txt)
+#endif
 #ifndef BL_RN_UNR_TESTS
 #define BL_RN_UNR_TESTS 4
 #endif
@@ -373,10 +377,19 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                     need = need && cK >= c && need_chunk(c);
                     nch += need ? 1 : 0;
                 }
+#if BL_RN_TWO_PER_ROUND
+                for (int c = BL_RN_UNR_TESTS; c <= cK && __any(need); c += 2) { // (two chunks a round: their table reads go out together)
+                    const bool n1 = need && need_chunk(c);
+                    const bool n2 = n1 && c + 1 <= cK && need_chunk(c + 1);    // (the table reaches beyond the last chunk: huge values there)
+                    nch += (n1 ? 1 : 0) + (n2 ? 1 : 0);
+                    need = n2;
+                }
+#else
                 for (int c = BL_RN_UNR_TESTS; c <= cK && __any(need); c++) {
                     need = need && need_chunk(c);
                     nch += need ? 1 : 0;
                 }
+#endif
             }
             }
             // record for the item lanes.  (A site in closed form has none: this lane leaves its result where the site's first item would --
@@ -408,8 +421,10 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                 for (int c = 0; c < BL_RN_UNR_STORES; c++)
                     if (mine && c < nch) imap[start + c] = (unsigned)lane | ((unsigned)c << 8) | ((unsigned)start << 16) | ((unsigned)nch << 24);
                 if (__any(mine && nch > BL_RN_UNR_STORES))
-                    for (int c = BL_RN_UNR_STORES; __any(mine && c < nch); c++)
+                    for (int c = BL_RN_UNR_STORES; __any(mine && c < nch); c += 1 + BL_RN_TWO_PER_ROUND) {
                         if (mine && c < nch) imap[start + c] = (unsigned)lane | ((unsigned)c << 8) | ((unsigned)start << 16) | ((unsigned)nch << 24);
+                        if (BL_RN_TWO_PER_ROUND && mine && c + 1 < nch) imap[start + c + 1] = (unsigned)lane | ((unsigned)(c + 1) << 8) | ((unsigned)start << 16) | ((unsigned)nch << 24);
+                    }
                 bl_wave_lds_fence(); // (also: the sites' dynamic visit slots are written)
                 const bool item = lane < nitems;
                 const unsigned im = imap[item ? lane : 0];
@@ -464,12 +479,25 @@ __device__ __forceinline__ void bl_eval_sites_rn(int cwave, int pstride, int cnt
                             b2[g] = ((q2k[g] + bl2(1.0f)) * (qq + bl2(1.0f))) * (q4 + bl2(1.0f));
                             B[g] = bl2(0.0f);
                         }
+#if BL_RN_TWO_PER_ROUND
+                        for (int s = 0; __any(s < ch); s += 2) { // (two steps a round: a round costs a wave-wide `any` and a branch)
+                            if (s < ch) { // (exec-masked: the lanes with fewer steps sit this one out)
+#pragma unroll
+                                for (int g = 0; g < 5; g++) B[g] = bl_fma2(B[g], q8[g], bl2(1.0f));
+                            }
+                            if (s + 1 < ch) {
+#pragma unroll
+                                for (int g = 0; g < 5; g++) B[g] = bl_fma2(B[g], q8[g], bl2(1.0f));
+                            }
+                        }
+#else
                         for (int s = 0; __any(s < ch); s++) {
                             if (s < ch) { // (exec-masked: the lanes with fewer steps sit this one out)
 #pragma unroll
                                 for (int g = 0; g < 5; g++) B[g] = bl_fma2(B[g], q8[g], bl2(1.0f));
                             }
                         }
+#endif
 #pragma unroll
                         for (int g = 0; g < 5; g++) b2[g] = b2[g] * B[g];
                     }
