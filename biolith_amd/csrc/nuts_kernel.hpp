@@ -496,9 +496,12 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
     // occu_rn (round 5): speculate where the guess cannot be wrong short of a divergence -- behind an EVEN leaf of a subtree (no U-turn
     // test is made there and the subtree cannot be full: hmc_util._leaf_idx_to_ckpt_idxs, _iterative_build_subtree) the next leaf is the
     // next leaf, so its evaluation starts at once and the decisions about the even leaf run beside it; everywhere else the decisions
-    // come first, as before (a dropped occu_rn evaluation costs more than they do).  BL_RN_HYBRID=0: A/B.
+    // come first, as before (a dropped occu_rn evaluation costs more than they do).  Round 6 (BL_RN_HYBRID 2): behind EVERY leaf that is
+    // not its subtree's last -- an odd one can end the subtree by a checkpointed U-turn test, which drops the evaluation, but that is one
+    // leaf in forty where the decisions in front of the release were 2 800 cycles on one in five: 7.37 -> 7.30 us per leapfrog, draws,
+    // trees and adaptation bit-identical (profiles/r06/s_time_rn_hybrid.txt, tools/ab_rn_hybrid.py).  1: even leaves only; 0: none (A/B).
 #ifndef BL_RN_HYBRID
-#define BL_RN_HYBRID 1
+#define BL_RN_HYBRID 2
 #endif
     constexpr bool HYBRID = BL_RN_HYBRID && LDS && MODEL == 1;
     auto decide = [&]() {
@@ -815,8 +818,9 @@ __global__ void __launch_bounds__(64 * (CW + 1)) bl_nuts_kernel(const BlNutsPara
         // the next doubling starts from the tree's OTHER edge -- the whole position (it does not depend on this leaf).
         spec_ed = epsdir;
         if constexpr (HYBRID) {
-            // the leaf in flight has index snprop: even and not the subtree's last (which is odd whenever there is more than one leaf)
-            if (!init_pending && (snprop & 1) == 0 && snprop + 1 < (1 << depth)) spec_kind = 1;
+            // the leaf in flight has index snprop: not the subtree's last (which is odd whenever there is more than one leaf), and with
+            // BL_RN_HYBRID 1 even as well
+            if (!init_pending && ((snprop & 1) == 0 || BL_RN_HYBRID == 2) && snprop + 1 < (1 << depth)) spec_kind = 1;
         }
         if constexpr (SPEC) {
             if (!init_pending) {
