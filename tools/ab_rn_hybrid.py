@@ -10,7 +10,7 @@ if len(sys.argv) > 1:
     r = ds.nuts(num_warmup=300, num_samples=300, num_chains=4, seed=11)
     np.savez(sys.argv[1], draws=r.draws, steps=r.num_steps, eps=r.step_size, minv=r.inv_mass, acc=r.accept_prob)
 else:
-    for n in ("h1", "h2"):
+    for n in (os.environ.get("AB_A", "h1"), os.environ.get("AB_B", "h2")):
         subprocess.run([sys.executable, __file__, f"/tmp/{n}.npz"], env=dict(os.environ, BIOLITH_HIP_LIB=f"{ROOT}/biolith_amd/lib/libbiolith_hip_{n}.so"), check=True)
-    a, b = np.load("/tmp/h1.npz"), np.load("/tmp/h2.npz")
+    a, b = np.load(f"/tmp/{os.environ.get('AB_A', 'h1')}.npz"), np.load(f"/tmp/{os.environ.get('AB_B', 'h2')}.npz")
     print({k: bool(np.array_equal(a[k], b[k])) for k in a.files})
